@@ -1,0 +1,201 @@
+"""Pins the CPU oracle against the reference's own golden vectors:
+
+* test/BDGGG/valid/annotated.out  — per read RG, XB/XC (C `%g` of a float), QC-fail flag, raw barcodes
+* test/BDGGG/valid/annotated.err  — every counter, mean and estimated prior at 15 truncated decimals
+* SURVEY.md Appendix A            — known-answer values recorded from the reference's own code
+"""
+import numpy as np
+import pytest
+
+import bdggg
+from pheniqs_amd import jobspec
+
+
+@pytest.fixture(scope="module")
+def run(oracle):
+    job = jobspec.compile_job(bdggg.user_job())
+    reads = bdggg.load_reads(oracle.ascii_to_bam)
+    incoming = {"count": len(reads), "pf count": sum(1 for r in reads if not r["qcfail"])}
+    # TranscodingThread::filter_input transcode.h:193-205: min input length is checked from segment 1 on
+    minimum = job["min input length"]
+    kept = [r for r in reads
+            if not (job["filter incoming qc fail"] and r["qcfail"])
+            and not any(len(r["segments"][i]["code"]) < minimum[i] for i in range(1, 3))]
+    engine = oracle.OracleJob(job)
+    base, qual = engine.stage([[(s["code"], s["quality"]) for s in r["segments"]] for r in kept])
+    flags = np.array([1 if r["qcfail"] else 0 for r in kept], dtype=np.uint8)
+    result, word, distance, confidence = engine.classify(base, qual, flags, summary=True)
+    return {"job": job, "reads": kept, "engine": engine, "base": base, "qual": qual, "flags": flags,
+            "result": result, "word": word, "distance": distance, "confidence": confidence, "incoming": incoming}
+
+
+def test_compiled_job_matches_reference_compile(run):
+    """Our compile subset reproduces the decoder members of valid/compile_annotated.out."""
+    reference = bdggg.compiled_reference_job()
+    ours = run["job"]
+    for kind in ("sample", "molecular", "cellular"):
+        theirs = reference[kind] if isinstance(reference[kind], list) else [reference[kind]]
+        mine = ours[kind] if isinstance(ours[kind], list) else [ours[kind]]
+        assert len(theirs) == len(mine)
+        for t, m in zip(theirs, mine):
+            for key in ("algorithm", "barcode length", "segment cardinality", "nucleotide cardinality", "index",
+                        "high quality threshold", "high quality distance threshold", "quality masking threshold",
+                        "confidence threshold", "noise", "corrected quality"):
+                assert t[key] == m[key], (kind, key)
+            assert t["transform"] == m["transform"]
+            # printed at 15 truncated decimals: 1/4^8 = 0.0000152587890625 -> 0.000015258789062
+            assert 0 <= m["random barcode probability"] - t["random barcode probability"] < 1e-15
+            if "codec" in t:
+                assert t["distance tolerance"] == m["distance tolerance"]
+                assert t["shannon bound"] == m["shannon bound"]
+                assert list(t["codec"].keys()) == list(m["codec"].keys())
+                for key in t["codec"]:
+                    assert t["codec"][key]["index"] == m["codec"][key]["index"]
+                    assert t["codec"][key]["barcode"] == m["codec"][key]["barcode"]
+                    delta = m["codec"][key]["concentration"] - t["codec"][key]["concentration"]
+                    assert 0 <= delta < 1e-15 + 1e-18
+            assert t["undetermined"]["concentration"] == m["undetermined"]["concentration"]
+            assert t["undetermined"]["barcode"] == m["undetermined"]["barcode"]
+    assert ours["sample"]["multiplexing classifier"] is True
+
+
+def test_incoming_counters(run):
+    golden = bdggg.golden_report()["incoming"]
+    assert run["incoming"]["count"] == golden["count"] == 250
+    assert run["incoming"]["pf count"] == golden["pf count"] == 243
+
+
+def test_per_read_golden_sam(run):
+    records, order = bdggg.golden_records()
+    reads = run["reads"]
+    assert [r["name"] for r in reads] == order            # 248 reads, input order (threads: 1)
+    sample = run["job"]["sample"]
+    id_to_index = {"undetermined": 0}
+    for record in sample["codec"].values():
+        id_to_index[record["barcode"][0]] = record["index"]
+    for i, read in enumerate(reads):
+        golden = records[read["name"]]
+        tags = golden["tags"]
+        s = run["result"][i, 0]     # sample decoder
+        c = run["result"][i, 1]     # cellular decoder (the naive molecular decoder has no result record)
+        assert id_to_index[tags["RG"].split(":")[-1]] == s["index"], read["name"]
+        assert bool(golden["flag"] & 512) == bool(run["word"][i] >> 31), read["name"]
+        assert (run["word"][i] & 0x7fffffff) == s["index"]         # channel_index of the multiplexing decoder
+        # raw barcodes: BC/QT sample, CR/CY cellular, OX/BZ molecular (read.h:200-222)
+        index_read = read["segments"][1]
+        assert tags.get("BC", "") == index_read["sequence"][:8]
+        assert tags.get("QT", "") == index_read["quality_text"][:8]
+        assert tags.get("CR", "") == index_read["sequence"][:8]
+        assert tags.get("OX", "") == read["segments"][0]["sequence"][8:16]
+        assert tags.get("BZ", "") == read["segments"][0]["quality_text"][8:16]
+        # XB / XC: read.h:187-199 float(1 - confidence) iff 0 < confidence < 1, printed by htslib as %g
+        for tag, kind in (("XB", 0), ("XC", 2)):
+            confidence = run["confidence"][i, kind]
+            if 0 < confidence < 1:
+                assert tags[tag] == "%g" % float(np.float32(1.0 - confidence)), (read["name"], tag)
+            else:
+                assert tag not in tags
+        assert "XM" not in tags
+        # corrected cellular barcode CB = decoded barcode, or the '=' undetermined barcode
+        if c["index"] > 0:
+            barcode = [r["barcode"][0] for r in run["job"]["cellular"][0]["codec"].values() if r["index"] == c["index"]][0]
+            # append_corrected copies observation[i].length bases (read.h:296-300, sequence.h:382-398)
+            assert tags["CB"] == barcode[:len(tags["CR"])]
+        else:
+            assert tags["CB"] == "=" * len(tags["CR"])
+
+
+def _close(mine, golden):
+    if isinstance(golden, float):
+        # rapidjson SetMaxDecimalPlaces(15) truncates (json.cpp:39-46)
+        return -2e-16 <= mine - golden < 1e-15 + 2e-16
+    return mine == golden
+
+
+def _compare(mine, golden, path):
+    """Every key our restatement emits must be in the golden report with the same value; golden keys
+    we do not model (SAM @RG atoms merged in by transcode.cpp:1843-1860) are ignored."""
+    if isinstance(mine, dict):
+        for key, value in mine.items():
+            assert key in golden, path + "/" + key
+            _compare(value, golden[key], path + "/" + key)
+    elif isinstance(mine, list):
+        assert len(mine) == len(golden), path
+        for i, (m, g) in enumerate(zip(mine, golden)):
+            _compare(m, g, "%s[%d]" % (path, i))
+    else:
+        assert _close(mine, golden), (path, mine, golden)
+
+
+OPTION_KEYS = {"count", "average distance", "average confidence", "low conditional confidence count",
+               "low confidence count", "pooled fraction", "pooled classified fraction", "pf count",
+               "average pf distance", "average pf confidence", "pf fraction", "pf pooled fraction",
+               "pf pooled classified fraction", "estimated concentration", "index", "concentration", "barcode"}
+
+
+def test_report_golden(run):
+    golden = bdggg.golden_report()
+    engine = run["engine"]
+    count, pf_count = engine.outgoing()
+    assert {"count": count, "pf count": pf_count} == {k: golden["outgoing"][k] for k in ("count", "pf count")}
+    assert _close(pf_count / count, golden["outgoing"]["pf fraction"])
+    reports = [engine.report(i) for i in range(3)]
+    _compare(reports[0], golden["sample"], "sample")
+    _compare(reports[1], golden["molecular"][0], "molecular[0]")
+    _compare(reports[2], golden["cellular"][0], "cellular[0]")
+    # and nothing the reference reports from AccumulatingOption/Selector is missing on our side
+    for mine, theirs in ((reports[0], golden["sample"]), (reports[1], golden["molecular"][0]), (reports[2], golden["cellular"][0])):
+        selector_keys = {k for k in theirs if k not in ("classified", "unclassified")}
+        assert selector_keys <= set(mine.keys()) | {"CN", "DT", "PI", "PL", "PM", "SM", "LB", "PU", "ID", "BC"}
+        for m, t in zip(mine.get("classified", []), theirs.get("classified", [])):
+            assert {k for k in t if k in OPTION_KEYS} == set(m.keys())
+        assert {k for k in theirs["unclassified"] if k in OPTION_KEYS} == set(mine["unclassified"].keys())
+
+
+def test_known_answers(oracle, run):
+    """SURVEY.md Appendix A, values produced by the reference's own code."""
+    L = oracle.lib()
+    assert L.orc_substitution_quality(1, 1, 30) == 0.0043451177401769171
+    assert L.orc_substitution_quality(1, 2, 30) == 30
+    assert L.orc_substitution_quality(1, 15, 30) == 6.0205999132796242
+    assert L.orc_substitution_quality(1, 1, 0) == 0
+    import ctypes
+    expected = oracle.ascii_to_bam(b"GGACTCCT")
+    quality = np.array([33, 31, 34, 34, 34, 37, 34, 27], dtype=np.uint8)
+    p, d, hqd = ctypes.c_double(), ctypes.c_int32(), ctypes.c_int32()
+    L.orc_compensated_decoding_probability(expected.ctypes.data, expected.ctypes.data, quality.ctypes.data, 8, 30,
+                                           ctypes.byref(p), ctypes.byref(d), ctypes.byref(hqd), None)
+    assert (p.value, d.value, hqd.value) == (0.99492740514594347, 0, 0)
+
+    by_name = {r["name"].split(":", 5)[-1]: i for i, r in enumerate(run["reads"])}
+    codec = {r["index"]: r["barcode"][0] for r in run["job"]["sample"]["codec"].values()}
+    def sample(suffix):
+        s = run["result"][by_name[suffix], 0]
+        return codec.get(int(s["index"]), "undetermined"), int(s["distance"]), float(s["confidence"]), bool(s["qcfail"]), int(s["status"])
+    assert sample("10000:13973")[:3] == ("AGGCAGAA", 0, 0.99999870588404638)
+    assert sample("10000:2619")[:3] == ("TAAGGCGA", 1, 0.99999898737382487)      # 7 nt index read
+    assert sample("10000:4721")[:3] == ("CGTACTAG", 2, 0.99999883566464787)      # 6 nt index read
+    assert sample("10001:12543") == ("GGACTCCT", 1, 0.99734846374116537, True, 0)  # high quality distance filter
+    assert sample("10013:13268") == ("TCCTGAGC", 4, 0.92724976007737681, True, 1)  # low confidence, stays assigned
+    assert sample("10005:7907") == ("undetermined", 0, 0.0, True, 2)              # noise filter
+    selector, _ = run["engine"].finalize(0)
+    assert (selector["count"], selector["pf_count"], selector["classified_count"]) == (248, 236, 244)
+    assert abs(selector["estimated_noise_prior"] - 0.016196236559139) < 1e-15
+    assert abs(selector["average_classified_confidence"] - 0.99588592283837) < 1e-14
+
+
+def test_mdd_known_answers(oracle, run):
+    """MDD (tolerance 2, no masking) on BDGGG differs from PAMLD on 2 of 248 reads,
+    and read 10013:13268 is undetermined under MDD.  The reference's tests never run MDD."""
+    spec = bdggg.user_job()
+    spec["sample"]["algorithm"] = "mdd"
+    spec.pop("molecular"); spec.pop("cellular")
+    job = jobspec.compile_job(spec)
+    assert job["sample"]["distance tolerance"] == [2]
+    engine = oracle.OracleJob(job)
+    base = run["base"][:, :8]
+    result, word = engine.classify(base, run["qual"][:, :8], run["flags"])
+    pamld = run["result"][:, 0]["index"]
+    assert int((result[:, 0]["index"] != pamld).sum()) == 2
+    i = [k for k, r in enumerate(run["reads"]) if r["name"].endswith("10013:13268")][0]
+    assert result[i, 0]["index"] == 0 and result[i, 0]["qcfail"] == 1
