@@ -1,0 +1,192 @@
+/* pheniqs_amd.h — C ABI of the MI355X barcode classification path (libpheniqs_amd.so).
+ *
+ * The reference (Pheniqs 2.1.0) has no FFI: its classification surface is the C++ class family
+ * Classifier<T> / Decoder<T> / PamlDecoder<T> / MdDecoder<T> owned by a TranscodingDecoder and driven
+ * one read at a time by TranscodingThread::run.  Every entry point below names the reference
+ * interface it stands in for (file:line in the reference tree).  Reads cross the boundary in batches
+ * of structure-of-arrays planes instead of one `Read` object at a time; everything else — the compiled
+ * JSON decoder configuration, the order decoders run in, the sticky QC-fail flag, the counters that
+ * make the report — keeps the reference's meaning.
+ *
+ * All functions return an int in the reference's ErrorCode space (error.h:32-44) and never throw.
+ * Pointers are plain; no C++ or torch type appears in a signature.
+ */
+#ifndef PHENIQS_AMD_H
+#define PHENIQS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference error.h:32-44 */
+#define PHQ_OK                      0
+#define PHQ_UNKNOWN_ERROR           1
+#define PHQ_INTERNAL_ERROR          2
+#define PHQ_CONFIGURATION_ERROR     3
+#define PHQ_OUT_OF_MEMORY_ERROR     4
+#define PHQ_COMMAND_LINE_ERROR      5
+#define PHQ_IO_ERROR                6
+#define PHQ_SEQUENCE_ERROR          7
+#define PHQ_OVERFLOW_ERROR          8
+
+#define PHQ_ALGORITHM_PASSTHROUGH   0
+#define PHQ_ALGORITHM_PAMLD         1
+#define PHQ_ALGORITHM_MDD           2
+#define PHQ_ALGORITHM_NAIVE         3
+#define PHQ_KIND_SAMPLE             0
+#define PHQ_KIND_MOLECULAR          1
+#define PHQ_KIND_CELLULAR           2
+
+#define PHQ_STATUS_PASS             0   /* classified, confidence above threshold (may still fail the high quality filter) */
+#define PHQ_STATUS_LOW_CONFIDENCE   1   /* pamld.cpp:110-113: stays assigned, QC fail */
+#define PHQ_STATUS_NOISE            2   /* pamld.cpp:114-121: failed the noise filter, unclassified, QC fail */
+#define PHQ_STATUS_UNCLASSIFIED     3   /* mdd.cpp:82-84: no barcode within tolerance, QC fail */
+
+#define PHQ_MODE_LITERAL            0   /* every barcode scored with the reference's own Kahan recurrence */
+#define PHQ_MODE_FAST               1   /* product form scoring, near ties re-scored literally */
+
+#define PHQ_DEVICE_NONE            (-1) /* host only set: configuration, staging, statistics, report */
+
+/* What one PAMLD / MDD decoder leaves on a read: the members Decoder<T>/PamlDecoder<T> hold after
+ * classify() and the wrappers copy into the output Read (pamld.cpp:133-180, mdd.cpp:96-138). */
+typedef struct phq_result {
+    int32_t index;          /* decoded->index, 0 = undetermined            barcode.h:37-45      */
+    uint8_t distance;       /* edit_distance                                decoder.h:35         */
+    uint8_t hq_distance;    /* high_quality_edit_distance                   decoder.h:36         */
+    uint8_t status;         /* PHQ_STATUS_*                                                     */
+    uint8_t qcfail;         /* output.qcfail() right after this decoder     read.h:96-98         */
+    double  confidence;     /* decoding_confidence (0 for MDD)              pamld.h:34           */
+} phq_result_t;
+
+/* Shape of the buffers one decoder set exchanges. */
+typedef struct phq_layout {
+    int32_t n_decoder;          /* sample + molecular[] + cellular[], in classify order (transcode.h:51-60) */
+    int32_t n_result;           /* PAMLD / MDD decoders: each owns one result plane                         */
+    int32_t plane_width;        /* bytes per read over all observation planes                               */
+    int32_t nucleotide_width;   /* sum of nucleotide cardinality: the algorithmic base (= quality) bytes    */
+    int64_t stats_words;        /* uint64 words in the counter buffer                                       */
+    int32_t input_segment_cardinality;
+    int32_t reserved;
+} phq_layout_t;
+
+typedef struct phq_decoder_info {
+    int32_t kind;               /* PHQ_KIND_*                                                    */
+    int32_t algorithm;          /* PHQ_ALGORITHM_*                                               */
+    int32_t index;              /* position inside its topic ("index" member)                    */
+    int32_t n_barcode;          /* codec size, undetermined excluded                             */
+    int32_t nucleotide_cardinality;
+    int32_t segment_cardinality;
+    int32_t plane_stride;       /* bytes per read in this decoder's plane (cardinality rounded up to 4) */
+    int32_t plane_prefix;       /* plane starts at byte offset batch_capacity * plane_prefix     */
+    int32_t result_slot;        /* -1: no result plane (naive, passthrough)                      */
+    int32_t multiplexing;       /* drives channel_index (classifier.h:83-85)                     */
+    int64_t stats_offset;       /* first counter word of this decoder                            */
+} phq_decoder_info_t;
+
+/* AccumulatingOption raw counters, selector.h:34-41; record 0 = unclassified, then tag_array order */
+typedef struct phq_option {
+    uint64_t count;
+    uint64_t pf_count;
+    uint64_t accumulated_distance;
+    uint64_t accumulated_pf_distance;
+    uint64_t low_conditional_confidence_count;
+    uint64_t low_confidence_count;
+    double   accumulated_confidence;
+    double   accumulated_pf_confidence;
+} phq_option_t;
+
+typedef struct phq_decoder_set phq_decoder_set;
+
+/* ---- construction ---------------------------------------------------------------------------------
+ * Replaces TranscodingDecoder::TranscodingDecoder(const Value& ontology) and the per algorithm
+ * constructors it switches to (transcode.cpp:31-161; PamlDecoder pamld.cpp:24-36, MdDecoder
+ * mdd.cpp:24-36, Decoder decoder.h:44-60, Classifier classifier.h:53-66, Barcode barcode.cpp:24-46).
+ * `compiled_job_json` is the compiled ontology (`pheniqs mux --compile`, e.g. reference
+ * test/BDGGG/valid/compile_annotated.out); members outside sample / molecular / cellular and the
+ * few job level keys listed in INTEGRATION.md are ignored.  `device` is a HIP device ordinal or
+ * PHQ_DEVICE_NONE.  On failure *out is NULL and phq_last_error(NULL) holds the message. */
+int phq_create(const char* compiled_job_json, int32_t device, phq_decoder_set** out);
+void phq_destroy(phq_decoder_set* set);                                   /* ~TranscodingDecoder transcode.cpp:48-61 */
+const char* phq_last_error(const phq_decoder_set* set);                    /* Error::what error.h:71-73               */
+
+int phq_get_layout(const phq_decoder_set* set, phq_layout_t* layout);
+int phq_get_decoder_info(const phq_decoder_set* set, int32_t decoder, phq_decoder_info_t* info);
+int phq_set_mode(phq_decoder_set* set, int32_t mode);                      /* PHQ_MODE_* */
+
+/* ---- extraction -----------------------------------------------------------------------------------
+ * Rule::apply(const Read&, Observation&) for every decoder (transform.h:142-169 with
+ * Token::absolute_start/end transform.h:65-80 and BamToReverseComplementBam iupac.h:107-124), fused
+ * with the pre-filters of TranscodingThread::run (transcode.h:193-205) and the incoming counters of
+ * Transcode::pull (transcode.cpp:304-309).
+ *
+ * Input: n_read reads of n_segment input segments; segment s of read i is the length[s][i] bytes at
+ * code[s] + offset[s][i] (BAM 4-bit codes, one per byte) and quality[s] + offset[s][i] (Phred, offset
+ * removed).  in_flag[i] bit 0 is the leading segment's QC fail (fastq.h:264-272).
+ * Output: planes for up to batch_capacity reads.  Decoder d's plane starts at byte
+ * batch_capacity * plane_prefix[d] of `base` (and of `quality`); read k of the plane is plane_stride[d]
+ * bytes, positions past the observed length are (0, 0).  kept[k] receives the input
+ * ordinal of staged read k, out_flag[k] its incoming QC fail.  *n_kept is the number of staged reads;
+ * incoming_count / incoming_pf_count are incremented for every input read before filtering. */
+int phq_stage_reads(const phq_decoder_set* set, int64_t n_read, int32_t n_segment,
+                    const uint8_t* const* code, const uint8_t* const* quality,
+                    const int64_t* const* offset, const int32_t* const* length, const uint8_t* in_flag,
+                    int64_t batch_capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                    uint8_t* out_flag, int64_t* kept, int64_t* n_kept,
+                    uint64_t* incoming_count, uint64_t* incoming_pf_count);
+
+/* ---- classification -------------------------------------------------------------------------------
+ * TranscodingDecoder::classify(const Read&, Read&) (transcode.h:51-65) over reads
+ * [first_read, first_read + n_read) of a batch whose planes were laid out for batch_capacity reads.
+ * Every pointer is DEVICE memory of the set's device.  result holds n_result planes of
+ * batch_capacity records (plane r at result + r * batch_capacity); word[i] = channel_index
+ * (classifier.h:83-85) | final QC fail << 31 and is also the scratch that carries the sticky QC-fail
+ * flag from decoder to decoder, so it must not be NULL.  flag may be NULL (no incoming QC fail).
+ * The call only enqueues work on `hip_stream` (a hipStream_t, NULL = default stream); counters
+ * accumulate in the set's device counter buffer. */
+int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                        const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                        phq_result_t* result, uint32_t* word, void* hip_stream);
+
+/* Same call for HOST buffers: chunks the batch, stages through the set's pinned double buffers and
+ * overlaps hipMemcpyAsync in both directions with compute.  Blocks until results are in host memory. */
+int phq_classify_host(phq_decoder_set* set, int64_t n_read,
+                      const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                      phq_result_t* result, uint32_t* word);
+
+/* Pinned host memory for batches handed to phq_classify_host (hipHostMalloc / hipHostFree). */
+int phq_host_alloc(uint64_t bytes, void** pointer);
+void phq_host_free(void* pointer);
+
+/* ---- statistics -----------------------------------------------------------------------------------
+ * The counter buffer is the merged state of every AccumulatingOption of every decoder plus the
+ * outgoing count / pf count of the TranscodingDecoder, as integers (layout: INTEGRATION.md). */
+int phq_stats_reset(phq_decoder_set* set, void* hip_stream);
+int phq_stats_device_pointer(phq_decoder_set* set, uint64_t** device_words); /* for an in-place all-reduce       */
+int phq_stats_export(phq_decoder_set* set, uint64_t* host_words);            /* device -> host, synchronises     */
+int phq_stats_import(phq_decoder_set* set, const uint64_t* host_words);      /* host -> device, replaces          */
+/* TranscodingDecoder::collect (transcode.cpp:162-179) -> Classifier::collect (classifier.h:87-93)
+ * -> AccumulatingOption::collect (selector.cpp:68-77): dst += src, both on the host side of the sets */
+int phq_stats_merge(phq_decoder_set* dst, phq_decoder_set* src);
+/* The end of run merge over GPUs (reference Transcode::finalize transcode.cpp:1816-1818 over threads):
+ * one ncclAllReduce(sum, uint64) in place on the device counter buffer.  rccl_comm is an ncclComm_t. */
+int phq_stats_allreduce(phq_decoder_set* set, void* rccl_comm, void* hip_stream);
+/* per barcode counters of one decoder, n_barcode + 1 records */
+int phq_stats_options(phq_decoder_set* set, const uint64_t* host_words, int32_t decoder, phq_option_t* option);
+/* Transcode::finalize + TranscodingDecoder::finalize/encode + print_json (transcode.cpp:180-231,
+ * 1812-1863; classifier.h:94-124,161-177; selector.cpp:78-135,197-247; json.cpp:39-46): the report
+ * as sorted, pretty printed JSON with doubles truncated to `float precision` decimals.
+ * The string belongs to the set and is valid until the next call on it. */
+int phq_report_json(phq_decoder_set* set, const uint64_t* host_words, uint64_t incoming_count,
+                    uint64_t incoming_pf_count, const char** json);
+
+/* How print_json lays a double out under PrettyWriter::SetMaxDecimalPlaces(precision) (json.cpp:39-46):
+ * shortest round trip digits, plain decimal, truncated.  Writes a NUL terminated string; returns
+ * PHQ_OVERFLOW_ERROR when `capacity` is too small. */
+int phq_format_double(double value, int32_t precision, char* buffer, int32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHENIQS_AMD_H */

@@ -1,0 +1,256 @@
+"""ctypes binding of include/pheniqs_amd.h.  Plumbing only: it moves pointers, never computes."""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+RESULT_DTYPE = np.dtype([("index", "<i4"), ("distance", "u1"), ("hq_distance", "u1"), ("status", "u1"),
+                         ("qcfail", "u1"), ("confidence", "<f8")])
+OPTION_DTYPE = np.dtype([("count", "<u8"), ("pf_count", "<u8"), ("accumulated_distance", "<u8"),
+                         ("accumulated_pf_distance", "<u8"), ("low_conditional_confidence_count", "<u8"),
+                         ("low_confidence_count", "<u8"), ("accumulated_confidence", "<f8"),
+                         ("accumulated_pf_confidence", "<f8")])
+
+MODE_LITERAL = 0
+MODE_FAST = 1
+DEVICE_NONE = -1
+
+# every symbol include/pheniqs_amd.h declares
+SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq_get_decoder_info", "phq_set_mode",
+           "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
+           "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
+           "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double")
+
+
+class PheniqsError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("[%d] %s" % (code, message))
+        self.code = code
+
+
+class Layout(ctypes.Structure):
+    _fields_ = [("n_decoder", ctypes.c_int32), ("n_result", ctypes.c_int32), ("plane_width", ctypes.c_int32),
+                ("nucleotide_width", ctypes.c_int32), ("stats_words", ctypes.c_int64),
+                ("input_segment_cardinality", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class DecoderInfo(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_int32) for name in (
+        "kind", "algorithm", "index", "n_barcode", "nucleotide_cardinality", "segment_cardinality",
+        "plane_stride", "plane_prefix", "result_slot", "multiplexing")] + [("stats_offset", ctypes.c_int64)]
+
+
+def library_path() -> str:
+    return os.path.join(HERE, "libpheniqs_amd.so")
+
+
+_library = None
+
+
+def load_library():
+    """Loads the in-tree library.  No fallback: a missing build is an error."""
+    global _library
+    if _library is not None:
+        return _library
+    path = library_path()
+    if not os.path.exists(path):
+        raise PheniqsError(2, "libpheniqs_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`): " + path)
+    L = ctypes.CDLL(path)
+    P, I32, I64, U64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+    L.phq_create.argtypes = [ctypes.c_char_p, I32, ctypes.POINTER(P)]
+    L.phq_destroy.argtypes = [P]
+    L.phq_destroy.restype = None
+    L.phq_last_error.argtypes = [P]
+    L.phq_last_error.restype = ctypes.c_char_p
+    L.phq_get_layout.argtypes = [P, ctypes.POINTER(Layout)]
+    L.phq_get_decoder_info.argtypes = [P, I32, ctypes.POINTER(DecoderInfo)]
+    L.phq_set_mode.argtypes = [P, I32]
+    L.phq_stage_reads.argtypes = [P, I64, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P]
+    L.phq_classify_device.argtypes = [P, I64, I64, I64, P, P, P, P, P, P]
+    L.phq_classify_host.argtypes = [P, I64, P, P, P, P, P]
+    L.phq_host_alloc.argtypes = [U64, ctypes.POINTER(P)]
+    L.phq_host_free.argtypes = [P]
+    L.phq_host_free.restype = None
+    L.phq_stats_reset.argtypes = [P, P]
+    L.phq_stats_device_pointer.argtypes = [P, ctypes.POINTER(P)]
+    L.phq_stats_export.argtypes = [P, P]
+    L.phq_stats_import.argtypes = [P, P]
+    L.phq_stats_merge.argtypes = [P, P]
+    L.phq_stats_allreduce.argtypes = [P, P, P]
+    L.phq_stats_options.argtypes = [P, P, I32, P]
+    L.phq_report_json.argtypes = [P, P, U64, U64, ctypes.POINTER(ctypes.c_char_p)]
+    L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
+    _library = L
+    return L
+
+
+def format_double(value: float, precision: int = 15) -> str:
+    buffer = ctypes.create_string_buffer(64)
+    status = load_library().phq_format_double(value, precision, buffer, 64)
+    if status != 0:
+        raise PheniqsError(status, "phq_format_double")
+    return buffer.value.decode()
+
+
+def _pointer(x) -> Optional[int]:
+    """numpy array -> host address, torch tensor -> data_ptr, int -> as is."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return int(x.data_ptr())
+
+
+class _CudaArray:
+    """Wraps a raw device pointer so torch.as_tensor can adopt it (__cuda_array_interface__)."""
+
+    def __init__(self, pointer: int, words: int, owner):
+        self.__cuda_array_interface__ = {"shape": (words,), "typestr": "<i8", "data": (pointer, False), "version": 2}
+        self._owner = owner
+
+
+class DecoderSet:
+    """One TranscodingDecoder worth of decoders (reference transcode.h:40-77) on one device."""
+
+    def __init__(self, job: Any, device: int = 0):
+        self.lib = load_library()
+        text = job if isinstance(job, str) else json.dumps(job)
+        handle = ctypes.c_void_p()
+        status = self.lib.phq_create(text.encode(), device, ctypes.byref(handle))
+        if status != 0:
+            raise PheniqsError(status, (self.lib.phq_last_error(None) or b"").decode())
+        self.handle = handle
+        self.device = device
+        layout = Layout()
+        self._check(self.lib.phq_get_layout(self.handle, ctypes.byref(layout)))
+        self.n_decoder = layout.n_decoder
+        self.n_result = layout.n_result
+        self.plane_width = layout.plane_width
+        self.nucleotide_width = layout.nucleotide_width
+        self.stats_words = layout.stats_words
+        self.decoders: List[Dict[str, int]] = []
+        for k in range(self.n_decoder):
+            info = DecoderInfo()
+            self._check(self.lib.phq_get_decoder_info(self.handle, k, ctypes.byref(info)))
+            self.decoders.append({name: getattr(info, name) for name, _ in DecoderInfo._fields_})
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.phq_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, status: int):
+        if status != 0:
+            raise PheniqsError(status, (self.lib.phq_last_error(self.handle) or b"").decode())
+
+    def set_mode(self, mode: int):
+        self._check(self.lib.phq_set_mode(self.handle, mode))
+
+    # ---- layout helpers -----------------------------------------------------------------------------
+
+    def planes_from_rows(self, rows: np.ndarray, offsets: Sequence[int]) -> np.ndarray:
+        """Row major observations [n, sum L] (the oracle's staging) -> decoder major planes (flat uint8)."""
+        n = rows.shape[0]
+        out = np.zeros(n * max(self.plane_width, 1), dtype=np.uint8)
+        for d, offset in zip(self.decoders, offsets):
+            if d["plane_stride"] == 0:
+                continue
+            plane = out[n * d["plane_prefix"]: n * (d["plane_prefix"] + d["plane_stride"])].reshape(n, d["plane_stride"])
+            plane[:, :d["nucleotide_cardinality"]] = rows[:, offset: offset + d["nucleotide_cardinality"]]
+        return out
+
+    # ---- extraction -----------------------------------------------------------------------------------
+
+    def stage_reads(self, segments: Sequence[Dict[str, np.ndarray]], flags: Optional[np.ndarray], capacity: Optional[int] = None):
+        """segments[s] = {"code": uint8[], "quality": uint8[], "offset": int64[n], "length": int32[n]}."""
+        n = len(segments[0]["offset"])
+        k = len(segments)
+        capacity = n if capacity is None else capacity
+        base = np.zeros(max(1, capacity * self.plane_width), dtype=np.uint8)
+        quality = np.zeros_like(base)
+        out_flag = np.zeros(max(1, capacity), dtype=np.uint8)
+        kept = np.zeros(max(1, capacity), dtype=np.int64)
+        n_kept = ctypes.c_int64(0)
+        incoming = ctypes.c_uint64(0)
+        incoming_pf = ctypes.c_uint64(0)
+        keep = [np.ascontiguousarray(s["code"], dtype=np.uint8) for s in segments], \
+               [np.ascontiguousarray(s["quality"], dtype=np.uint8) for s in segments], \
+               [np.ascontiguousarray(s["offset"], dtype=np.int64) for s in segments], \
+               [np.ascontiguousarray(s["length"], dtype=np.int32) for s in segments]
+        arrays = [(ctypes.c_void_p * k)(*[a.ctypes.data for a in group]) for group in keep]
+        flags_c = None if flags is None else np.ascontiguousarray(flags, dtype=np.uint8)
+        self._check(self.lib.phq_stage_reads(self.handle, n, k, arrays[0], arrays[1], arrays[2], arrays[3], _pointer(flags_c),
+                                             capacity, base.ctypes.data, quality.ctypes.data, out_flag.ctypes.data,
+                                             kept.ctypes.data, ctypes.byref(n_kept), ctypes.byref(incoming), ctypes.byref(incoming_pf)))
+        return {"base": base, "quality": quality, "flag": out_flag, "kept": kept[:n_kept.value], "n": n_kept.value,
+                "capacity": capacity, "incoming": (incoming.value, incoming_pf.value)}
+
+    # ---- classification -------------------------------------------------------------------------------
+
+    def classify_device(self, capacity: int, first: int, n: int, base, quality, flag, result, word, stream: int = 0):
+        self._check(self.lib.phq_classify_device(self.handle, capacity, first, n, _pointer(base), _pointer(quality),
+                                                 _pointer(flag), _pointer(result), _pointer(word), stream or None))
+
+    def classify_host(self, n: int, base: np.ndarray, quality: np.ndarray, flag: Optional[np.ndarray]):
+        result = np.zeros((max(1, self.n_result), max(1, n)), dtype=RESULT_DTYPE)
+        word = np.zeros(max(1, n), dtype=np.uint32)
+        self._check(self.lib.phq_classify_host(self.handle, n, _pointer(base), _pointer(quality), _pointer(flag),
+                                               result.ctypes.data, word.ctypes.data))
+        return result[:self.n_result, :n], word[:n]
+
+    # ---- statistics -----------------------------------------------------------------------------------
+
+    def stats_reset(self, stream: int = 0):
+        self._check(self.lib.phq_stats_reset(self.handle, stream or None))
+
+    def stats_device_pointer(self) -> int:
+        pointer = ctypes.c_void_p()
+        self._check(self.lib.phq_stats_device_pointer(self.handle, ctypes.byref(pointer)))
+        return pointer.value
+
+    def stats_tensor(self):
+        """The device counter buffer as an int64 torch tensor (for torch.distributed.all_reduce over RCCL)."""
+        import torch
+        return torch.as_tensor(_CudaArray(self.stats_device_pointer(), self.stats_words, self), device="cuda:%d" % self.device)
+
+    def stats_export(self) -> np.ndarray:
+        words = np.zeros(self.stats_words, dtype=np.uint64)
+        self._check(self.lib.phq_stats_export(self.handle, words.ctypes.data))
+        return words
+
+    def stats_import(self, words: np.ndarray):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        assert words.shape == (self.stats_words,)
+        self._check(self.lib.phq_stats_import(self.handle, words.ctypes.data))
+
+    def stats_merge(self, other: "DecoderSet"):
+        self._check(self.lib.phq_stats_merge(self.handle, other.handle))
+
+    def stats_allreduce(self, rccl_comm: int, stream: int = 0):
+        self._check(self.lib.phq_stats_allreduce(self.handle, rccl_comm, stream or None))
+
+    def stats_options(self, words: np.ndarray, decoder: int) -> np.ndarray:
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        option = np.zeros(self.decoders[decoder]["n_barcode"] + 1, dtype=OPTION_DTYPE)
+        self._check(self.lib.phq_stats_options(self.handle, words.ctypes.data, decoder, option.ctypes.data))
+        return option
+
+    def report(self, words: np.ndarray, incoming=(0, 0)) -> str:
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        text = ctypes.c_char_p()
+        self._check(self.lib.phq_report_json(self.handle, words.ctypes.data, incoming[0], incoming[1], ctypes.byref(text)))
+        return text.value.decode()

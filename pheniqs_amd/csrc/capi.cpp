@@ -1,0 +1,214 @@
+// extern "C" surface of libpheniqs_amd.so (declared in include/pheniqs_amd.h).  Exceptions stop here:
+// every entry point converts an Error into its reference ErrorCode (error.h:32-44) and stores the text.
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/pheniqs_amd.h"
+#include "decoder_set.hpp"
+#include "error.hpp"
+#include "stats.hpp"
+
+struct phq_decoder_set {
+    phq::DecoderSet impl;
+    phq_decoder_set(const char* json, int32_t device) : impl(json, device) {}
+};
+
+namespace {
+
+thread_local std::string global_error;
+
+template <typename F>
+int guarded(phq_decoder_set* set, F&& body) {
+    std::string* sink = set ? &set->impl.last_error : &global_error;
+    try {
+        body();
+        return PHQ_OK;
+    } catch(const phq::Error& e) {
+        *sink = e.what();
+        return static_cast<int>(e.code);
+    } catch(const std::bad_alloc&) {
+        *sink = "Out of memory error";
+        return PHQ_OUT_OF_MEMORY_ERROR;
+    } catch(const std::exception& e) {
+        *sink = std::string("Unknown error : ") + e.what();
+        return PHQ_UNKNOWN_ERROR;
+    } catch(...) {
+        *sink = "Unknown error";
+        return PHQ_UNKNOWN_ERROR;
+    }
+}
+
+void require(const void* pointer, const char* name) {
+    if(pointer == nullptr) { throw phq::InternalError(std::string(name) + " is NULL"); }
+}
+
+static_assert(sizeof(phq_result_t) == sizeof(phq::DevResult), "result record layout");
+static_assert(sizeof(phq_result_t) == 16, "result record is 16 bytes");
+
+}  // namespace
+
+extern "C" {
+
+int phq_create(const char* compiled_job_json, int32_t device, phq_decoder_set** out) {
+    if(out != nullptr) { *out = nullptr; }
+    return guarded(nullptr, [&]() {
+        require(compiled_job_json, "compiled_job_json");
+        require(out, "out");
+        *out = new phq_decoder_set(compiled_job_json, device);
+    });
+}
+
+void phq_destroy(phq_decoder_set* set) { delete set; }
+
+const char* phq_last_error(const phq_decoder_set* set) {
+    return set ? set->impl.last_error.c_str() : global_error.c_str();
+}
+
+int phq_get_layout(const phq_decoder_set* set, phq_layout_t* layout) {
+    return guarded(const_cast<phq_decoder_set*>(set), [&]() {
+        require(set, "set"); require(layout, "layout");
+        const phq::JobConfig& job = set->impl.job();
+        std::memset(layout, 0, sizeof(*layout));
+        layout->n_decoder = static_cast<int32_t>(job.decoder.size());
+        layout->n_result = job.result_count;
+        layout->plane_width = job.plane_width;
+        layout->nucleotide_width = job.nucleotide_width;
+        layout->stats_words = job.stats_words;
+        layout->input_segment_cardinality = job.input_segment_cardinality;
+    });
+}
+
+int phq_get_decoder_info(const phq_decoder_set* set, int32_t decoder, phq_decoder_info_t* info) {
+    return guarded(const_cast<phq_decoder_set*>(set), [&]() {
+        require(set, "set"); require(info, "info");
+        const phq::JobConfig& job = set->impl.job();
+        if(decoder < 0 || decoder >= static_cast<int32_t>(job.decoder.size())) { throw phq::InternalError("decoder ordinal out of range"); }
+        const phq::DecoderConfig& d = job.decoder[static_cast<size_t>(decoder)];
+        std::memset(info, 0, sizeof(*info));
+        info->kind = static_cast<int32_t>(d.kind);
+        info->algorithm = static_cast<int32_t>(d.algorithm);
+        info->index = d.index;
+        info->n_barcode = static_cast<int32_t>(d.codec.size());
+        info->nucleotide_cardinality = d.nucleotide_cardinality;
+        info->segment_cardinality = d.segment_cardinality;
+        info->plane_stride = d.plane_stride;
+        info->plane_prefix = d.plane_prefix;
+        info->result_slot = d.result_slot;
+        info->multiplexing = d.multiplexing_classifier ? 1 : 0;
+        info->stats_offset = d.stats_offset;
+    });
+}
+
+int phq_set_mode(phq_decoder_set* set, int32_t mode) {
+    return guarded(set, [&]() { require(set, "set"); set->impl.set_mode(mode); });
+}
+
+int phq_stage_reads(const phq_decoder_set* set, int64_t n_read, int32_t n_segment,
+                    const uint8_t* const* code, const uint8_t* const* quality,
+                    const int64_t* const* offset, const int32_t* const* length, const uint8_t* in_flag,
+                    int64_t batch_capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                    uint8_t* out_flag, int64_t* kept, int64_t* n_kept,
+                    uint64_t* incoming_count, uint64_t* incoming_pf_count) {
+    return guarded(const_cast<phq_decoder_set*>(set), [&]() {
+        require(set, "set"); require(code, "code"); require(quality, "quality"); require(offset, "offset"); require(length, "length");
+        set->impl.stage_reads(n_read, n_segment, code, quality, offset, length, in_flag, batch_capacity, base_planes, quality_planes,
+                              out_flag, kept, n_kept, incoming_count, incoming_pf_count);
+    });
+}
+
+int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                        const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                        phq_result_t* result, uint32_t* word, void* hip_stream) {
+    return guarded(set, [&]() {
+        require(set, "set");
+        set->impl.classify_device(batch_capacity, first_read, n_read, base_planes, quality_planes, flag,
+                                  reinterpret_cast<phq::DevResult*>(result), word, hip_stream);
+    });
+}
+
+int phq_classify_host(phq_decoder_set* set, int64_t n_read,
+                      const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                      phq_result_t* result, uint32_t* word) {
+    return guarded(set, [&]() {
+        require(set, "set");
+        set->impl.classify_host(n_read, base_planes, quality_planes, flag, reinterpret_cast<phq::DevResult*>(result), word);
+    });
+}
+
+int phq_stats_reset(phq_decoder_set* set, void* hip_stream) {
+    return guarded(set, [&]() { require(set, "set"); set->impl.stats_reset(hip_stream); });
+}
+
+int phq_stats_device_pointer(phq_decoder_set* set, uint64_t** device_words) {
+    return guarded(set, [&]() { require(set, "set"); require(device_words, "device_words"); *device_words = set->impl.stats_device_pointer(); });
+}
+
+int phq_stats_export(phq_decoder_set* set, uint64_t* host_words) {
+    return guarded(set, [&]() { require(set, "set"); require(host_words, "host_words"); set->impl.stats_export(host_words); });
+}
+
+int phq_stats_import(phq_decoder_set* set, const uint64_t* host_words) {
+    return guarded(set, [&]() { require(set, "set"); require(host_words, "host_words"); set->impl.stats_import(host_words); });
+}
+
+int phq_stats_merge(phq_decoder_set* dst, phq_decoder_set* src) {
+    return guarded(dst, [&]() {
+        require(dst, "dst"); require(src, "src");
+        const int64_t words = dst->impl.job().stats_words;
+        if(words != src->impl.job().stats_words) { throw phq::ConfigurationError("cannot merge statistics of different jobs"); }
+        std::vector<uint64_t> a(static_cast<size_t>(words)), b(static_cast<size_t>(words));
+        dst->impl.stats_export(a.data());
+        src->impl.stats_export(b.data());
+        for(int64_t i = 0; i < words; ++i) { a[static_cast<size_t>(i)] += b[static_cast<size_t>(i)]; }
+        dst->impl.stats_import(a.data());
+    });
+}
+
+int phq_stats_allreduce(phq_decoder_set* set, void* rccl_comm, void* hip_stream) {
+    return guarded(set, [&]() { require(set, "set"); require(rccl_comm, "rccl_comm"); set->impl.stats_allreduce(rccl_comm, hip_stream); });
+}
+
+int phq_stats_options(phq_decoder_set* set, const uint64_t* host_words, int32_t decoder, phq_option_t* option) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(host_words, "host_words"); require(option, "option");
+        const phq::JobConfig& job = set->impl.job();
+        if(decoder < 0 || decoder >= static_cast<int32_t>(job.decoder.size())) { throw phq::InternalError("decoder ordinal out of range"); }
+        const auto counters = phq::decode_counters(job.decoder[static_cast<size_t>(decoder)], host_words);
+        for(size_t b = 0; b < counters.size(); ++b) {
+            option[b].count = counters[b].count;
+            option[b].pf_count = counters[b].pf_count;
+            option[b].accumulated_distance = counters[b].accumulated_distance;
+            option[b].accumulated_pf_distance = counters[b].accumulated_pf_distance;
+            option[b].low_conditional_confidence_count = counters[b].low_conditional_confidence_count;
+            option[b].low_confidence_count = counters[b].low_confidence_count;
+            option[b].accumulated_confidence = counters[b].accumulated_confidence;
+            option[b].accumulated_pf_confidence = counters[b].accumulated_pf_confidence;
+        }
+    });
+}
+
+int phq_report_json(phq_decoder_set* set, const uint64_t* host_words, uint64_t incoming_count,
+                    uint64_t incoming_pf_count, const char** json) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(host_words, "host_words"); require(json, "json");
+        *json = set->impl.report_json(host_words, incoming_count, incoming_pf_count).c_str();
+    });
+}
+
+int phq_host_alloc(uint64_t bytes, void** pointer) {
+    return guarded(nullptr, [&]() { require(pointer, "pointer"); *pointer = phq::host_alloc(static_cast<size_t>(bytes)); });
+}
+
+void phq_host_free(void* pointer) { phq::host_free(pointer); }
+
+int phq_format_double(double value, int32_t precision, char* buffer, int32_t capacity) {
+    return guarded(nullptr, [&]() {
+        require(buffer, "buffer");
+        const std::string text = phq::format_double(value, precision);
+        if(static_cast<int32_t>(text.size()) + 1 > capacity) { throw phq::OverflowError("buffer too small"); }
+        std::memcpy(buffer, text.c_str(), text.size() + 1);
+    });
+}
+
+}  // extern "C"

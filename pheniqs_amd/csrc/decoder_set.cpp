@@ -1,0 +1,414 @@
+#include "decoder_set.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "error.hpp"
+#include "phred.hpp"
+#include "stats.hpp"
+
+namespace phq {
+
+namespace {
+
+void check(hipError_t status, const char* what) {
+    if(status == hipSuccess) { return; }
+    std::string message = std::string(what) + " : " + hipGetErrorString(status);
+    if(status == hipErrorOutOfMemory) { throw OutOfMemoryError(message); }
+    throw InternalError(message);
+}
+
+// bins whose counters fit a workgroup histogram (12 words of 8 bytes per bin) next to the Phred table
+constexpr int LDS_HISTOGRAM_MAX_BINS = 340;          // 340 * 96 B = 32 KiB
+
+}  // namespace
+
+void* host_alloc(size_t bytes) {
+    void* pointer = nullptr;
+    check(hipHostMalloc(&pointer, bytes, hipHostMallocDefault), "hipHostMalloc");
+    return pointer;
+}
+void host_free(void* pointer) {
+    if(pointer != nullptr) { (void)hipHostFree(pointer); }
+}
+
+DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
+    job_(JobConfig::from_json(Json::parse(compiled_job_json))),
+    device_(device),
+    mode_(MODE_LITERAL),
+    max_blocks_(2048),
+    device_decoder_(nullptr),
+    device_stats_(nullptr),
+    chunk_capacity_(0) {
+    if(device_ >= 0) {
+        try {
+            build_device_images();
+        } catch(...) {
+            release();
+            throw;
+        }
+    }
+}
+
+DecoderSet::~DecoderSet() { release(); }
+
+void DecoderSet::release() {
+    if(device_ >= 0) { (void)hipSetDevice(device_); }
+    for(auto& slot : slot_) {
+        if(slot.stream) { (void)hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)); }
+        (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
+        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word);
+        host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
+        host_free(slot.pinned_result); host_free(slot.pinned_word);
+        if(slot.done) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.done)); }
+        if(slot.stream) { (void)hipStreamDestroy(static_cast<hipStream_t>(slot.stream)); }
+        slot = Slot();
+    }
+    for(void* p : device_allocation_) { (void)hipFree(p); }
+    device_allocation_.clear();
+    device_decoder_ = nullptr;
+    device_stats_ = nullptr;
+}
+
+void DecoderSet::require_device() const {
+    if(device_ < 0) { throw InternalError("this decoder set was created without a device (PHQ_DEVICE_NONE)"); }
+    check(hipSetDevice(device_), "hipSetDevice");
+}
+
+void DecoderSet::set_mode(int32_t mode) {
+    if(mode != MODE_LITERAL && mode != MODE_FAST) { throw ConfigurationError("unknown classification mode " + std::to_string(mode)); }
+    mode_ = mode;
+}
+
+void DecoderSet::build_device_images() {
+    int count = 0;
+    check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+    if(device_ >= count) { throw ConfigurationError("no HIP device " + std::to_string(device_)); }
+    check(hipSetDevice(device_), "hipSetDevice");
+    hipDeviceProp_t properties;
+    check(hipGetDeviceProperties(&properties, device_), "hipGetDeviceProperties");
+    max_blocks_ = properties.multiProcessorCount * 8;      // 8 workgroups of 256 per CU: well past the 256 CUs (guide §6 G11)
+
+    auto upload = [&](const void* source, size_t bytes) -> void* {
+        void* pointer = nullptr;
+        check(hipMalloc(&pointer, bytes > 0 ? bytes : 16), "hipMalloc");
+        device_allocation_.push_back(pointer);
+        if(bytes > 0) { check(hipMemcpy(pointer, source, bytes, hipMemcpyHostToDevice), "hipMemcpy"); }
+        return pointer;
+    };
+
+    const PhredScale& scale = PhredScale::get_instance();
+    const double* device_tpq = static_cast<const double*>(upload(scale.true_positive_quality, sizeof(scale.true_positive_quality)));
+
+    host_decoder_.assign(job_.decoder.size(), DevDecoder());
+    for(size_t k = 0; k < job_.decoder.size(); ++k) {
+        const DecoderConfig& c = job_.decoder[k];
+        DevDecoder& d = host_decoder_[k];
+        std::memset(&d, 0, sizeof(d));
+        d.algorithm = static_cast<int32_t>(c.algorithm);
+        d.kind = static_cast<int32_t>(c.kind);
+        d.n_barcode = static_cast<int32_t>(c.codec.size());
+        d.nucleotide_cardinality = c.nucleotide_cardinality;
+        d.n_segment = c.segment_cardinality;
+        d.n_word = (c.nucleotide_cardinality + 7) / 8;
+        d.plane_stride = c.plane_stride;
+        d.result_slot = c.result_slot;
+        d.multiplexing = c.multiplexing_classifier ? 1 : 0;
+        d.all_strict = c.all_strict ? 1 : 0;
+        d.high_quality_threshold = c.high_quality_threshold;
+        d.high_quality_distance_threshold = c.high_quality_distance_threshold;
+        d.quality_masking_threshold = c.quality_masking_threshold;
+        d.use_lds_histogram = (d.n_barcode + 1) <= LDS_HISTOGRAM_MAX_BINS ? 1 : 0;
+        d.adjusted_noise_probability = c.noise * c.random_barcode_probability;        // pamld.cpp:29
+        d.confidence_threshold = c.confidence_threshold;
+        d.random_barcode_probability = c.random_barcode_probability;
+        d.uniform_base_quality = scale.uniform_base_quality;
+        d.stats_offset = c.stats_offset;
+        d.true_positive_quality = device_tpq;
+        if(c.closed()) {
+            for(int32_t s = 0; s < c.segment_cardinality; ++s) {
+                d.distance_tolerance[s] = s < static_cast<int32_t>(c.distance_tolerance.size()) ? c.distance_tolerance[static_cast<size_t>(s)] : 0;
+                const int32_t begin = c.segment_offset[static_cast<size_t>(s)];
+                const int32_t end = begin + c.barcode_length[static_cast<size_t>(s)];
+                for(int32_t j = begin; j < end; ++j) {
+                    d.segment_mask[s][j >> 3] |= 1u << (4 * (j & 7));
+                    d.full_mask[j >> 3] |= 1u << (4 * (j & 7));
+                }
+                if(end > begin) { d.segment_end_bits |= 1u << (end - 1); }
+            }
+            std::vector<uint32_t> packed(static_cast<size_t>(d.n_barcode) * static_cast<size_t>(d.n_word), 0);
+            std::vector<double> concentration(static_cast<size_t>(d.n_barcode));
+            std::vector<int32_t> index(static_cast<size_t>(d.n_barcode));
+            for(int32_t b = 0; b < d.n_barcode; ++b) {
+                for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
+                    const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
+                    packed[static_cast<size_t>(b) * static_cast<size_t>(d.n_word) + static_cast<size_t>(j >> 3)] |= (code & 0xfu) << (4 * (j & 7));
+                }
+                concentration[static_cast<size_t>(b)] = c.codec[static_cast<size_t>(b)].concentration;
+                index[static_cast<size_t>(b)] = c.codec[static_cast<size_t>(b)].index;
+            }
+            d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
+            d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
+            d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));
+        }
+    }
+    device_decoder_ = static_cast<DevDecoder*>(upload(host_decoder_.data(), host_decoder_.size() * sizeof(DevDecoder)));
+
+    void* stats = nullptr;
+    check(hipMalloc(&stats, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t)), "hipMalloc");
+    device_allocation_.push_back(stats);
+    device_stats_ = static_cast<unsigned long long*>(stats);
+    check(hipMemset(device_stats_, 0, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t)), "hipMemset");
+}
+
+// ---- extraction: Rule::apply over a batch (transform.h:142-169) -----------------------------------------
+
+void DecoderSet::stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* const* code, const uint8_t* const* quality,
+                             const int64_t* const* offset, const int32_t* const* length, const uint8_t* in_flag,
+                             int64_t batch_capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                             uint8_t* out_flag, int64_t* kept, int64_t* n_kept,
+                             uint64_t* incoming_count, uint64_t* incoming_pf_count) const {
+    if(job_.input_segment_cardinality > 0 && n_segment != job_.input_segment_cardinality) {
+        throw ConfigurationError("expected " + std::to_string(job_.input_segment_cardinality) + " input segments but got " + std::to_string(n_segment));
+    }
+    for(const auto& d : job_.decoder) {
+        for(const auto& t : d.transform) {
+            if(t.input_segment_index < 0 || t.input_segment_index >= n_segment) {
+                throw ConfigurationError("invalid input feed reference " + std::to_string(t.input_segment_index) + " in token");
+            }
+        }
+    }
+    int64_t out = 0;
+    uint64_t count = 0;
+    uint64_t pf_count = 0;
+    for(int64_t i = 0; i < n_read; ++i) {
+        const bool qcfail = in_flag != nullptr && (in_flag[i] & 1);
+        ++count;                                                        // transcode.cpp:304-309
+        if(!qcfail) { ++pf_count; }
+        if(job_.filter_incoming_qc_fail && qcfail) { continue; }       // transcode.h:205
+        bool too_short = false;                                         // transcode.h:193-200, from segment 1 on
+        for(int32_t s = 1; s < n_segment && s < static_cast<int32_t>(job_.min_input_length.size()); ++s) {
+            if(length[s][i] < job_.min_input_length[static_cast<size_t>(s)]) { too_short = true; break; }
+        }
+        if(too_short) { continue; }
+        if(out >= batch_capacity) { throw OverflowError("more reads than the batch capacity " + std::to_string(batch_capacity)); }
+
+        for(const auto& d : job_.decoder) {
+            if(d.plane_stride == 0) { continue; }
+            uint8_t* row_code = base_planes + batch_capacity * d.plane_prefix + out * d.plane_stride;
+            uint8_t* row_quality = quality_planes + batch_capacity * d.plane_prefix + out * d.plane_stride;
+            std::memset(row_code, 0, static_cast<size_t>(d.plane_stride));
+            std::memset(row_quality, 0, static_cast<size_t>(d.plane_stride));
+            int32_t filled[MAX_SEGMENT] = {0};
+            for(const auto& t : d.transform) {
+                const int32_t from_length = length[t.input_segment_index][i];
+                const uint8_t* from_code = code[t.input_segment_index] + offset[t.input_segment_index][i];
+                const uint8_t* from_quality = quality[t.input_segment_index] + offset[t.input_segment_index][i];
+                const int32_t start = t.absolute_start(from_length);
+                const int32_t end = t.absolute_end(from_length);
+                const int32_t size = end - start;
+                if(size <= 0) { continue; }
+                const int32_t o = t.output_segment_index;
+                const int32_t room = d.barcode_length[static_cast<size_t>(o)] - filled[o];
+                const int32_t take = size < room ? size : room;
+                uint8_t* to_code = row_code + d.segment_offset[static_cast<size_t>(o)] + filled[o];
+                uint8_t* to_quality = row_quality + d.segment_offset[static_cast<size_t>(o)] + filled[o];
+                if(t.reverse_complement) {
+                    for(int32_t j = 0; j < take; ++j) {
+                        to_code[j] = reverse_complement_bam(from_code[end - j - 1]);
+                        to_quality[j] = from_quality[end - j - 1];
+                    }
+                } else {
+                    std::memcpy(to_code, from_code + start, static_cast<size_t>(take));
+                    std::memcpy(to_quality, from_quality + start, static_cast<size_t>(take));
+                }
+                filled[o] += take;
+            }
+        }
+        if(out_flag != nullptr) { out_flag[out] = qcfail ? 1 : 0; }
+        if(kept != nullptr) { kept[out] = i; }
+        ++out;
+    }
+    if(n_kept != nullptr) { *n_kept = out; }
+    if(incoming_count != nullptr) { *incoming_count += count; }
+    if(incoming_pf_count != nullptr) { *incoming_pf_count += pf_count; }
+}
+
+// ---- classification ------------------------------------------------------------------------------------
+
+void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                                 const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                                 DevResult* result, uint32_t* word, void* stream) {
+    require_device();
+    if(n_read <= 0) { return; }
+    if(first_read < 0 || first_read + n_read > batch_capacity) { throw OverflowError("read range exceeds the batch capacity"); }
+    if(word == nullptr) { throw InternalError("the status word buffer is mandatory"); }
+    if(job_.plane_width > 0 && (base_planes == nullptr || quality_planes == nullptr)) { throw InternalError("observation planes are missing"); }
+    const size_t n_decoder = job_.decoder.size();
+    if(n_decoder == 0) {
+        throw ConfigurationError("the job declares no decoder");
+    }
+    for(size_t k = 0; k < n_decoder; ++k) {
+        const DecoderConfig& c = job_.decoder[k];
+        StageArgs args;
+        args.decoder = device_decoder_ + k;
+        args.n_read = n_read;
+        args.base = c.plane_stride ? base_planes + batch_capacity * c.plane_prefix + first_read * c.plane_stride : nullptr;
+        args.quality = c.plane_stride ? quality_planes + batch_capacity * c.plane_prefix + first_read * c.plane_stride : nullptr;
+        args.input_flag = flag ? flag + first_read : nullptr;
+        args.result = (c.result_slot >= 0 && result != nullptr) ? result + static_cast<int64_t>(c.result_slot) * batch_capacity + first_read : nullptr;
+        args.word = word + first_read;
+        args.stats = device_stats_;
+        args.first_stage = k == 0 ? 1 : 0;
+        args.last_stage = k + 1 == n_decoder ? 1 : 0;
+        check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream)), "kernel launch");
+    }
+}
+
+void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
+    if(chunk_capacity_ >= chunk_capacity && slot_[0].stream != nullptr) { return; }
+    for(auto& slot : slot_) {
+        if(slot.stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)), "hipStreamSynchronize"); }
+        (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
+        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word);
+        host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
+        host_free(slot.pinned_result); host_free(slot.pinned_word);
+        const size_t planes = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
+        const size_t results = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult);
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_base), planes), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_quality), planes), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_flag), static_cast<size_t>(chunk_capacity)), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_result), results), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_word), static_cast<size_t>(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
+        slot.pinned_base = static_cast<uint8_t*>(host_alloc(planes));
+        slot.pinned_quality = static_cast<uint8_t*>(host_alloc(planes));
+        slot.pinned_flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(chunk_capacity)));
+        slot.pinned_result = static_cast<DevResult*>(host_alloc(results));
+        slot.pinned_word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(chunk_capacity) * sizeof(uint32_t)));
+        if(slot.stream == nullptr) {
+            hipStream_t stream;
+            check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+            slot.stream = stream;
+            hipEvent_t event;
+            check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
+            slot.done = event;
+        }
+        slot.busy = false;
+    }
+    chunk_capacity_ = chunk_capacity;
+}
+
+// Host batch -> pinned slot -> device -> pinned slot -> host batch, two slots on two streams so that the
+// copies of one chunk run behind the kernels of the other (the reference's per-read Transcode::pull /
+// Multiplexer::push hand-offs, transcode.cpp:287-316 and multiplex.h:198-222, become two async copies per chunk).
+void DecoderSet::classify_host(int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                               DevResult* result, uint32_t* word) {
+    require_device();
+    if(n_read <= 0) { return; }
+    const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 22);
+    ensure_pipeline(chunk);
+
+    auto drain = [&](Slot& slot) {
+        if(!slot.busy) { return; }
+        check(hipEventSynchronize(static_cast<hipEvent_t>(slot.done)), "hipEventSynchronize");
+        for(const auto& c : job_.decoder) {
+            if(c.result_slot >= 0 && result != nullptr) {
+                std::memcpy(result + static_cast<int64_t>(c.result_slot) * n_read + slot.first,
+                            slot.pinned_result + static_cast<int64_t>(c.result_slot) * chunk_capacity_,
+                            static_cast<size_t>(slot.count) * sizeof(DevResult));
+            }
+        }
+        if(word != nullptr) { std::memcpy(word + slot.first, slot.pinned_word, static_cast<size_t>(slot.count) * sizeof(uint32_t)); }
+        slot.busy = false;
+    };
+
+    int which = 0;
+    for(int64_t first = 0; first < n_read; first += chunk, which ^= 1) {
+        Slot& slot = slot_[which];
+        drain(slot);
+        const int64_t count = std::min(chunk, n_read - first);
+        hipStream_t stream = static_cast<hipStream_t>(slot.stream);
+        for(const auto& c : job_.decoder) {
+            if(c.plane_stride == 0) { continue; }
+            const size_t bytes = static_cast<size_t>(count) * static_cast<size_t>(c.plane_stride);
+            const int64_t source = n_read * c.plane_prefix + first * c.plane_stride;
+            const int64_t target = chunk_capacity_ * c.plane_prefix;
+            std::memcpy(slot.pinned_base + target, base_planes + source, bytes);
+            std::memcpy(slot.pinned_quality + target, quality_planes + source, bytes);
+            check(hipMemcpyAsync(slot.device_base + target, slot.pinned_base + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            check(hipMemcpyAsync(slot.device_quality + target, slot.pinned_quality + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+        }
+        if(flag != nullptr) {
+            std::memcpy(slot.pinned_flag, flag + first, static_cast<size_t>(count));
+            check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+        }
+        classify_device(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
+                        slot.device_result, slot.device_word, stream);
+        for(const auto& c : job_.decoder) {
+            if(c.result_slot >= 0 && result != nullptr) {
+                const int64_t plane = static_cast<int64_t>(c.result_slot) * chunk_capacity_;
+                check(hipMemcpyAsync(slot.pinned_result + plane, slot.device_result + plane, static_cast<size_t>(count) * sizeof(DevResult),
+                                     hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            }
+        }
+        check(hipMemcpyAsync(slot.pinned_word, slot.device_word, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        check(hipEventRecord(static_cast<hipEvent_t>(slot.done), stream), "hipEventRecord");
+        slot.busy = true;
+        slot.first = first;
+        slot.count = count;
+    }
+    drain(slot_[0]);
+    drain(slot_[1]);
+}
+
+// ---- statistics ----------------------------------------------------------------------------------------
+
+void DecoderSet::stats_reset(void* stream) {
+    require_device();
+    check(hipMemsetAsync(device_stats_, 0, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t), static_cast<hipStream_t>(stream)), "hipMemsetAsync");
+}
+
+uint64_t* DecoderSet::stats_device_pointer() {
+    require_device();
+    return reinterpret_cast<uint64_t*>(device_stats_);
+}
+
+void DecoderSet::stats_export(uint64_t* host_words) {
+    require_device();
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    check(hipMemcpy(host_words, device_stats_, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToHost), "hipMemcpy");
+}
+
+void DecoderSet::stats_import(const uint64_t* host_words) {
+    require_device();
+    check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    check(hipMemcpy(device_stats_, host_words, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy");
+}
+
+// RCCL is resolved at first use so that single GPU users never load it.
+void DecoderSet::stats_allreduce(void* rccl_comm, void* stream) {
+    require_device();
+    typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    static all_reduce_t all_reduce = nullptr;
+    if(all_reduce == nullptr) {
+        void* library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if(library == nullptr) { library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); }
+        if(library == nullptr) { throw InternalError(std::string("cannot load librccl.so : ") + dlerror()); }
+        all_reduce = reinterpret_cast<all_reduce_t>(dlsym(library, "ncclAllReduce"));
+        if(all_reduce == nullptr) { throw InternalError("librccl.so has no ncclAllReduce"); }
+    }
+    constexpr int NCCL_UINT64 = 5;     // ncclUint64 (rccl.h ncclDataType_t)
+    constexpr int NCCL_SUM = 0;        // ncclSum
+    const int status = all_reduce(device_stats_, device_stats_, static_cast<size_t>(job_.stats_words), NCCL_UINT64, NCCL_SUM, rccl_comm, static_cast<hipStream_t>(stream));
+    if(status != 0) { throw InternalError("ncclAllReduce failed with code " + std::to_string(status)); }
+}
+
+const std::string& DecoderSet::report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count) {
+    report_ = encode_report(job_, host_words, incoming_count, incoming_pf_count).dump(job_.float_precision);
+    return report_;
+}
+
+}  // namespace phq

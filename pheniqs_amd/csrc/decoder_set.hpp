@@ -1,0 +1,93 @@
+// DecoderSet: the MI355X stand-in for one TranscodingDecoder (reference transcode.h:40-77).
+//
+// It owns what the reference's decoders own — deep copies of the barcode tables, priors and thresholds
+// (classifier.h:68-77) — as immutable device images, plus the device counter buffer that plays the role
+// of every AccumulatingOption.  One set serves one GPU; it is single-caller like the reference's
+// per-thread decoder copies (transcode.cpp:1769-1775).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "device_types.hpp"
+#include "job.hpp"
+#include "json.hpp"
+
+namespace phq {
+
+class DecoderSet {
+public:
+    DecoderSet(const std::string& compiled_job_json, int32_t device);
+    ~DecoderSet();
+    DecoderSet(const DecoderSet&) = delete;
+    DecoderSet& operator=(const DecoderSet&) = delete;
+
+    const JobConfig& job() const { return job_; }
+    int32_t device() const { return device_; }
+    void set_mode(int32_t mode);
+
+    // Rule::apply + pre-filters + incoming counters (see include/pheniqs_amd.h phq_stage_reads)
+    void stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* const* code, const uint8_t* const* quality,
+                     const int64_t* const* offset, const int32_t* const* length, const uint8_t* in_flag,
+                     int64_t batch_capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                     uint8_t* out_flag, int64_t* kept, int64_t* n_kept,
+                     uint64_t* incoming_count, uint64_t* incoming_pf_count) const;
+
+    void classify_device(int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                         const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                         DevResult* result, uint32_t* word, void* stream);
+    void classify_host(int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                       DevResult* result, uint32_t* word);
+
+    void stats_reset(void* stream);
+    uint64_t* stats_device_pointer();
+    void stats_export(uint64_t* host_words);
+    void stats_import(const uint64_t* host_words);
+    void stats_allreduce(void* rccl_comm, void* stream);
+    const std::string& report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count);
+
+    std::string last_error;
+
+private:
+    void require_device() const;
+    void build_device_images();
+    void release();
+    void ensure_pipeline(int64_t chunk_capacity);
+
+    JobConfig job_;
+    int32_t device_;
+    int32_t mode_;
+    int32_t max_blocks_;
+    std::vector<DevDecoder> host_decoder_;      // host copies holding DEVICE table pointers
+    DevDecoder* device_decoder_;                // device array, one per decoder
+    std::vector<void*> device_allocation_;
+    unsigned long long* device_stats_;
+    std::string report_;
+
+    // host staged pipeline (classify_host): two slots of device buffers + pinned bounce buffers
+    struct Slot {
+        uint8_t* device_base = nullptr;
+        uint8_t* device_quality = nullptr;
+        uint8_t* device_flag = nullptr;
+        DevResult* device_result = nullptr;
+        uint32_t* device_word = nullptr;
+        uint8_t* pinned_base = nullptr;
+        uint8_t* pinned_quality = nullptr;
+        uint8_t* pinned_flag = nullptr;
+        DevResult* pinned_result = nullptr;
+        uint32_t* pinned_word = nullptr;
+        void* stream = nullptr;
+        void* done = nullptr;                   // hipEvent_t recorded after the slot's last D2H
+        bool busy = false;
+        int64_t first = 0;
+        int64_t count = 0;
+    };
+    Slot slot_[2];
+    int64_t chunk_capacity_;
+};
+
+void* host_alloc(size_t bytes);   // pinned host memory
+void host_free(void* pointer);
+
+}  // namespace phq

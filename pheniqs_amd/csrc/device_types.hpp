@@ -1,0 +1,91 @@
+// Plain-old-data images shared by the host library and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+namespace phq {
+
+constexpr int DEV_MAX_DECODER = 16;
+constexpr int DEV_MAX_SEGMENT = 8;
+constexpr int DEV_MAX_WORD = 4;          // 8 nucleotides per 32-bit word of 4-bit BAM codes
+constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
+
+// Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]
+// (TranscodingDecoder::count/pf_count, transcode.h:61-64).  Then per decoder, per barcode bin
+// (bin 0 = unclassified), per [qc-fail | pass-filter] half, STAT_FIELDS words.  Every word is a plain
+// sum over reads, so merging threads, streams or GPUs is one integer sum (selector.cpp:68-77).
+// Confidence is accumulated exactly as a 2^-52 fixed point number split in two 26-bit limbs.
+constexpr int STAT_FIELDS = 6;
+constexpr int STAT_WORDS_PER_BIN = 2 * STAT_FIELDS;
+constexpr int STAT_JOB_WORDS = 2;
+constexpr int CONFIDENCE_FRACTION_BITS = 52;
+constexpr int CONFIDENCE_LIMB_BITS = 26;
+enum StatField : int32_t {
+    FIELD_COUNT = 0, FIELD_DISTANCE = 1, FIELD_CONFIDENCE_LOW = 2, FIELD_CONFIDENCE_HIGH = 3,
+    FIELD_LOW_CONDITIONAL_CONFIDENCE = 4, FIELD_LOW_CONFIDENCE = 5
+};
+enum ResultStatus : uint8_t { STATUS_PASS = 0, STATUS_LOW_CONFIDENCE = 1, STATUS_NOISE = 2, STATUS_UNCLASSIFIED = 3 };
+
+// 16-byte per (read, closed decoder) record; layout fixed by include/pheniqs_amd.h phq_result_t
+struct alignas(16) DevResult {
+    int32_t index;
+    uint8_t distance;
+    uint8_t hq_distance;
+    uint8_t status;
+    uint8_t qcfail;
+    double confidence;
+};
+
+// Everything one decoder launch needs besides the read planes.  Lives in device memory, is read only
+// through the constant address space (scalar loads), and is immutable after phq_create.
+struct DevDecoder {
+    int32_t algorithm;                    // phq::Algorithm
+    int32_t kind;                         // phq::Kind
+    int32_t n_barcode;
+    int32_t nucleotide_cardinality;
+    int32_t n_segment;
+    int32_t n_word;                       // ceil(nucleotide_cardinality / 8)
+    int32_t plane_stride;                 // bytes per read in this decoder's observation plane
+    int32_t result_slot;
+    int32_t multiplexing;
+    int32_t all_strict;
+    int32_t high_quality_threshold;
+    int32_t high_quality_distance_threshold;
+    int32_t quality_masking_threshold;
+    int32_t use_lds_histogram;            // bins fit in LDS: workgroup histogram, else global atomics
+    uint32_t segment_end_bits;            // bit j set when position j is the last of its segment
+    int32_t reserved;
+    int32_t distance_tolerance[DEV_MAX_SEGMENT];
+    uint32_t segment_mask[DEV_MAX_SEGMENT][DEV_MAX_WORD];   // nibble flags (bit 4*(j%8) of word j/8) per segment
+    uint32_t full_mask[DEV_MAX_WORD];     // nibble flags of every position
+    double adjusted_noise_probability;    // noise * random barcode probability (pamld.cpp:29)
+    double confidence_threshold;
+    double random_barcode_probability;
+    double uniform_base_quality;          // 10 log10 4                         phred.h:33
+    int64_t stats_offset;                 // first u64 word of this decoder in the counter buffer
+    const uint32_t* barcode_packed;       // n_barcode x n_word words of 4-bit BAM codes
+    const double* concentration;          // n_barcode
+    const int32_t* barcode_index;         // n_barcode
+    const double* true_positive_quality;  // 128 entries, -10 log10(1 - 10^(-q/10)), [0] = 0   phred.cpp:34-38
+};
+
+enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };
+
+// One decoder stage over reads [0, n_read) of its planes.
+struct StageArgs {
+    const DevDecoder* decoder;            // device pointer
+    int64_t n_read;
+    const uint8_t* base;                  // n_read x plane_stride BAM codes (null for passthrough)
+    const uint8_t* quality;               // n_read x plane_stride Phred values, offset removed
+    const uint8_t* input_flag;            // first stage only: bit 0 = incoming QC fail; may be null
+    DevResult* result;                    // n_read records of this decoder; may be null
+    uint32_t* word;                       // channel | qcfail << 31, carried from stage to stage
+    unsigned long long* stats;            // counter buffer
+    int32_t first_stage;                  // initialise word from input_flag
+    int32_t last_stage;                   // count outgoing reads (transcode.h:61-64)
+};
+
+// implemented in the kernel translation units; all return a hipError_t value
+int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream);
+
+}  // namespace phq

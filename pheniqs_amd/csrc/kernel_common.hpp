@@ -1,0 +1,167 @@
+// Device-side pieces shared by every decoder stage kernel (gfx950).
+//
+// A job runs as one launch per decoder, in the order TranscodingDecoder::classify calls its classifiers
+// (reference transcode.h:51-60).  The only state a read carries from one decoder to the next is what
+// the reference keeps on the output Read: the sticky QC-fail flag and channel_index
+// (classifier.h:83-85).  Both live in one 32-bit word per read that every stage reads and rewrites.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "device_types.hpp"
+
+namespace phq {
+
+// Decoder tables are immutable during a launch and every access to them is wave uniform.  Reading
+// them through the constant address space makes hipcc emit scalar loads (s_load_*): the expected
+// barcode bases, priors and thresholds travel in SGPRs and cost no vector instruction.
+#define PHQ_CONSTANT __attribute__((address_space(4)))
+typedef const PHQ_CONSTANT DevDecoder& DecoderRef;
+template <typename T> __device__ __forceinline__ const PHQ_CONSTANT T* constant_cast(const T* p) {
+    return (const PHQ_CONSTANT T*)p;
+}
+
+constexpr int BLOCK = 256;
+
+struct ReadState {
+    bool qcfail;
+    int32_t channel;
+};
+
+// Counter sink: the workgroup histogram in LDS when the decoder's bins fit, global atomics otherwise.
+struct StatSink {
+    unsigned long long* lds;       // histogram base: [0..1] job words, then the decoder's bins
+    unsigned long long* global;    // counter buffer
+};
+
+__device__ __forceinline__ void stat_add(DecoderRef d, const StatSink& sink, int bin, int pf, int field, unsigned long long value) {
+    const int word = bin * STAT_WORDS_PER_BIN + pf * STAT_FIELDS + field;
+    if(d.use_lds_histogram) {
+        atomicAdd(&sink.lds[STAT_JOB_WORDS + word], value);
+    } else {
+        atomicAdd(&sink.global[d.stats_offset + word], value);
+    }
+}
+
+__device__ __forceinline__ void stat_add_confidence(DecoderRef d, const StatSink& sink, int bin, int pf, double confidence) {
+    // exact 2^-52 fixed point in two 26 bit limbs: no word can overflow in a workgroup or in a whole run,
+    // and the sum does not depend on the order reads are visited in
+    const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));
+    stat_add(d, sink, bin, pf, FIELD_CONFIDENCE_LOW, fixed & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
+    stat_add(d, sink, bin, pf, FIELD_CONFIDENCE_HIGH, fixed >> CONFIDENCE_LIMB_BITS);
+}
+
+// Decoder<T>::classify then Classifier<T>::classify: reference decoder.h:68-76, classifier.h:78-86
+__device__ __forceinline__ void decoder_tail(DecoderRef d, const StatSink& sink, ReadState& r, int bin, int distance) {
+    const int pf = r.qcfail ? 0 : 1;
+    if(bin > 0 && distance) {
+        stat_add(d, sink, bin, pf, FIELD_DISTANCE, static_cast<unsigned long long>(distance));
+    }
+    stat_add(d, sink, bin, pf, FIELD_COUNT, 1ull);
+    if(d.multiplexing) {
+        r.channel = bin > 0 ? constant_cast(d.barcode_index)[bin - 1] : 0;
+    }
+}
+
+__device__ __forceinline__ ReadState load_read_state(const StageArgs& args, int64_t i) {
+    ReadState r;
+    if(args.first_stage) {
+        r.qcfail = args.input_flag ? (args.input_flag[i] & 1) != 0 : false;     // transcode.h:207-211
+        r.channel = 0;
+    } else {
+        const uint32_t w = args.word[i];
+        r.qcfail = (w >> 31) != 0;
+        r.channel = static_cast<int32_t>(w & 0x7fffffffu);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void store_read_state(const StageArgs& args, int64_t i, const ReadState& r) {
+    args.word[i] = (static_cast<uint32_t>(r.channel) & 0x7fffffffu) | (r.qcfail ? 0x80000000u : 0u);
+}
+
+__device__ __forceinline__ int histogram_words(DecoderRef d) {
+    return STAT_JOB_WORDS + (d.use_lds_histogram ? (d.n_barcode + 1) * STAT_WORDS_PER_BIN : 0);
+}
+
+__device__ __forceinline__ void histogram_clear(DecoderRef d, unsigned long long* histogram) {
+    const int words = histogram_words(d);
+    for(int i = threadIdx.x; i < words; i += BLOCK) { histogram[i] = 0; }
+}
+
+// TranscodingDecoder::count / pf_count (transcode.h:61-64), one LDS add per wave
+__device__ __forceinline__ void count_outgoing(const StageArgs& args, unsigned long long* histogram, bool active, const ReadState& r) {
+    if(args.last_stage) {
+        const unsigned long long pass = __ballot(active && !r.qcfail);
+        const unsigned long long fail = __ballot(active && r.qcfail);
+        if((threadIdx.x & 63) == 0) {
+            if(fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(__popcll(fail))); }
+            if(pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(__popcll(pass))); }
+        }
+    }
+}
+
+// one global atomic per non zero histogram word per workgroup
+__device__ __forceinline__ void histogram_flush(const StageArgs& args, DecoderRef d, const unsigned long long* histogram) {
+    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += BLOCK) {
+        const unsigned long long v = histogram[i];
+        if(v) { atomicAdd(&args.stats[i], v); }
+    }
+    if(d.use_lds_histogram) {
+        const int words = (d.n_barcode + 1) * STAT_WORDS_PER_BIN;
+        for(int i = threadIdx.x; i < words; i += BLOCK) {
+            const unsigned long long v = histogram[STAT_JOB_WORDS + i];
+            if(v) { atomicAdd(&args.stats[d.stats_offset + i], v); }
+        }
+    }
+}
+
+__device__ __forceinline__ bool strict_code(uint32_t c) {
+    return (c == 1) | (c == 2) | (c == 4) | (c == 8);
+}
+
+// 10^(-sigma/10) = pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * -log2(10)/10):
+// nearest-integer exponent split, degree 13 Taylor polynomial of e^t on |t| <= ln2/2, v_ldexp_f64.
+// Relative error ~1e-14 at sigma ~ 300, far inside the 1e-6 posterior tolerance.
+__device__ __forceinline__ double phred_probability(double sigma) {
+    const double z = sigma * -0.33219280948873623;
+    const double n = __builtin_rint(z);
+    const double t = (z - n) * 0.69314718055994531;
+    double r = 1.6059043836821613e-10;                   // 1/13!
+    r = __builtin_fma(r, t, 2.0876756987868099e-09);     // 1/12!
+    r = __builtin_fma(r, t, 2.5052108385441719e-08);     // 1/11!
+    r = __builtin_fma(r, t, 2.7557319223985891e-07);     // 1/10!
+    r = __builtin_fma(r, t, 2.7557319223985893e-06);     // 1/9!
+    r = __builtin_fma(r, t, 2.4801587301587302e-05);     // 1/8!
+    r = __builtin_fma(r, t, 1.9841269841269841e-04);     // 1/7!
+    r = __builtin_fma(r, t, 1.3888888888888889e-03);     // 1/6!
+    r = __builtin_fma(r, t, 8.3333333333333332e-03);     // 1/5!
+    r = __builtin_fma(r, t, 4.1666666666666664e-02);     // 1/4!
+    r = __builtin_fma(r, t, 1.6666666666666666e-01);     // 1/3!
+    r = __builtin_fma(r, t, 0.5);
+    r = __builtin_fma(r, t, 1.0);
+    r = __builtin_fma(r, t, 1.0);
+    return __builtin_ldexp(r, static_cast<int>(n));
+}
+
+// load the L observed bytes of read i from a plane whose stride is a multiple of 4
+template <int L>
+__device__ __forceinline__ void load_plane_row(const uint8_t* plane, int64_t i, uint8_t (&out)[(L + 3) / 4 * 4]) {
+    constexpr int WORDS = (L + 3) / 4;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(plane + i * (WORDS * 4));
+#pragma unroll
+    for(int w = 0; w < WORDS; ++w) {
+        const uint32_t v = row[w];
+        out[4 * w + 0] = static_cast<uint8_t>(v);
+        out[4 * w + 1] = static_cast<uint8_t>(v >> 8);
+        out[4 * w + 2] = static_cast<uint8_t>(v >> 16);
+        out[4 * w + 3] = static_cast<uint8_t>(v >> 24);
+    }
+}
+
+// kernel entry points by translation unit
+int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+int launch_count(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+
+}  // namespace phq

@@ -1,0 +1,189 @@
+// K2: MdDecoder<T>::classify for one decoder, one read per lane, integer only.
+//
+//   reference mdd.cpp:37-86         exact match first, then the FIRST barcode (index order) whose per segment
+//                                   distance is within tolerance; none -> unclassified + QC fail
+//   reference sequence.h:90-98      distance_from: walks the OBSERVED length
+//   reference sequence.h:321-332    masked_distance_from: quality below the masking threshold is a miss
+//
+// Observed bases and barcodes are 4-bit BAM codes packed 8 per word; a mismatch mask is XOR + nibble
+// fold, a segment distance is a popcount under the segment's nibble mask.
+#include "kernel_common.hpp"
+
+namespace phq {
+namespace {
+
+// bit 4k of the result is set when nibble k of x is non zero
+__device__ __forceinline__ uint32_t nibble_nonzero(uint32_t x) {
+    x |= x >> 1;
+    x |= x >> 2;
+    return x & 0x11111111u;
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats};
+    const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
+    const int n_barcode = d.n_barcode;
+    const int n_segment = d.n_segment;
+    const int n_word = d.n_word;
+    const int L = d.nucleotide_cardinality;
+    const int stride = d.plane_stride;
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + BLOCK - 1) / BLOCK;
+
+    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t i = tile * BLOCK + threadIdx.x;
+        const bool active = i < n;
+        ReadState r{false, 0};
+        if(active) {
+            r = load_read_state(args, i);
+            const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+            const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+            uint32_t observed[W];
+            uint32_t masked[W];      // quality below the masking threshold (sequence.h:324-326)
+            uint32_t counted[W];     // positions inside the observed length of their segment
+#pragma unroll
+            for(int w = 0; w < W; ++w) { observed[w] = 0; masked[w] = 0; counted[w] = 0; }
+            bool seen = false;
+#pragma unroll
+            for(int g = 2 * W - 1; g >= 0; --g) {          // groups of 4 positions = one 32-bit load per plane
+                if(4 * g < L) {
+                    const uint32_t cw = code_row[g];
+                    const uint32_t qw = quality_row[g];
+#pragma unroll
+                    for(int k = 3; k >= 0; --k) {
+                        const int j = 4 * g + k;
+                        if(j < L) {
+                            const uint32_t c = (cw >> (8 * k)) & 0xffu;
+                            const uint32_t q = (qw >> (8 * k)) & 0xffu;
+                            if((d.segment_end_bits >> j) & 1u) { seen = false; }
+                            seen = seen || (c != 0) || (q != 0);
+                            const uint32_t flag = 1u << (4 * (j & 7));
+                            observed[j >> 3] |= (c & 0xfu) << (4 * (j & 7));
+                            if(seen) { counted[j >> 3] |= flag; }
+                            if(static_cast<int>(q) < d.quality_masking_threshold) { masked[j >> 3] |= flag; }
+                        }
+                    }
+                }
+            }
+            bool complete = true;
+#pragma unroll
+            for(int w = 0; w < W; ++w) { complete = complete && (counted[w] == d.full_mask[w]); }
+
+            int exact = -1;
+            int fit = -1;
+            int fit_distance = 0;
+            for(int b = 0; b < n_barcode; ++b) {
+                uint32_t mismatch[W];
+                uint32_t any = 0;
+#pragma unroll
+                for(int w = 0; w < W; ++w) {
+                    mismatch[w] = (w < n_word) ? nibble_nonzero(observed[w] ^ packed[b * n_word + w]) : 0u;
+                    any |= mismatch[w];
+                }
+                // mdd.cpp:44-46: the whole observation equals a barcode (keys are full length, barcode.h:46-56)
+                if(complete && any == 0 && exact < 0) { exact = b; }
+                if(fit < 0) {
+                    int distance = 0;
+                    bool successful = true;
+                    for(int s = 0; s < n_segment; ++s) {
+                        int error = 0;
+#pragma unroll
+                        for(int w = 0; w < W; ++w) {
+                            error += __popc((mismatch[w] | masked[w]) & counted[w] & d.segment_mask[s][w]);
+                        }
+                        if(error > d.distance_tolerance[s]) { successful = false; }
+                        distance += error;
+                    }
+                    if(successful) { fit = b; fit_distance = distance; }
+                }
+            }
+            int bin = 0;
+            int distance = 0;
+            if(exact >= 0) { bin = exact + 1; }
+            else if(fit >= 0) { bin = fit + 1; distance = fit_distance; }
+            uint8_t status = STATUS_PASS;
+            if(bin == 0) { r.qcfail = true; status = STATUS_UNCLASSIFIED; }      // mdd.cpp:82-84
+            decoder_tail(d, sink, r, bin, distance);
+            if(args.result) {
+                DevResult out;
+                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                out.hq_distance = 0;
+                out.status = status;
+                out.qcfail = r.qcfail ? 1 : 0;
+                out.confidence = 0;
+                args.result[i] = out;
+            }
+            store_read_state(args, i, r);
+        }
+        count_outgoing(args, histogram, active, r);
+    }
+    __syncthreads();
+    histogram_flush(args, d, histogram);
+}
+
+// NaiveMolecularDecoder (naive.h:40-45) and the bare Classifier<Barcode> a passthrough decoder is
+// (transcode.cpp:77-80): decoded never leaves `unclassified`, so the stage only counts.
+__global__ __launch_bounds__(BLOCK) void count_kernel(StageArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+    histogram_clear(d, histogram);
+    __syncthreads();
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + BLOCK - 1) / BLOCK;
+    unsigned long long pass_total = 0;
+    unsigned long long fail_total = 0;
+    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t i = tile * BLOCK + threadIdx.x;
+        const bool active = i < n;
+        ReadState r{false, 0};
+        if(active) {
+            r = load_read_state(args, i);
+            if(args.first_stage) { store_read_state(args, i, r); }
+        }
+        pass_total += __popcll(__ballot(active && !r.qcfail));
+        fail_total += __popcll(__ballot(active && r.qcfail));
+        count_outgoing(args, histogram, active, r);
+    }
+    if((threadIdx.x & 63) == 0) {
+        // bin 0, [qc-fail | pass-filter], FIELD_COUNT
+        if(d.use_lds_histogram) {
+            if(fail_total) { atomicAdd(&histogram[STAT_JOB_WORDS + FIELD_COUNT], fail_total); }
+            if(pass_total) { atomicAdd(&histogram[STAT_JOB_WORDS + STAT_FIELDS + FIELD_COUNT], pass_total); }
+        } else {
+            if(fail_total) { atomicAdd(&args.stats[d.stats_offset + FIELD_COUNT], fail_total); }
+            if(pass_total) { atomicAdd(&args.stats[d.stats_offset + STAT_FIELDS + FIELD_COUNT], pass_total); }
+        }
+    }
+    __syncthreads();
+    histogram_flush(args, d, histogram);
+}
+
+}  // namespace
+
+int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    switch(host_decoder.n_word) {
+        case 1: hipLaunchKernelGGL((mdd_kernel<1>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((mdd_kernel<2>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((mdd_kernel<3>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((mdd_kernel<4>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+int launch_count(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    (void)host_decoder;
+    hipLaunchKernelGGL(count_kernel, grid, dim3(BLOCK), lds_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace phq

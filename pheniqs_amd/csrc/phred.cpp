@@ -1,0 +1,34 @@
+#include "phred.hpp"
+
+#include <cmath>
+
+namespace phq {
+
+PhredScale::PhredScale() {
+    uniform_base_quality = 10.0 * std::log10(4);
+    phred_probability_base = std::pow(10.0, -0.1);
+    false_positive_probability[0] = 0;
+    true_positive_probability[0] = 0;
+    true_positive_quality[0] = 0;
+    // same libm calls, same order, as phred.cpp:24-38 so the tables are bit identical on one host
+    for(int q = 1; q < 128; ++q) { false_positive_probability[q] = std::pow(phred_probability_base, q); }
+    for(int q = 1; q < 128; ++q) { true_positive_probability[q] = 1.0 - false_positive_probability[q]; }
+    for(int q = 1; q < 128; ++q) { true_positive_quality[q] = -10.0 * std::log10(true_positive_probability[q]); }
+}
+
+const PhredScale& PhredScale::get_instance() {
+    static const PhredScale instance;
+    return instance;
+}
+
+double PhredScale::substitution_quality(uint8_t expected, uint8_t observed, uint8_t quality) const {
+    const uint8_t q = quality & 0x7f;
+    if(q == 0) { return 0.0; }
+    const bool strict_e = expected == 1 || expected == 2 || expected == 4 || expected == 8;
+    const bool strict_o = observed == 1 || observed == 2 || observed == 4 || observed == 8;
+    if(strict_e && expected == observed) { return true_positive_quality[q]; }
+    if(strict_e && strict_o) { return q; }
+    return uniform_base_quality;
+}
+
+}  // namespace phq

@@ -1,0 +1,34 @@
+// Stage dispatcher: picks the kernel for one decoder and sizes the launch.
+#include "kernel_common.hpp"
+
+namespace phq {
+
+int launch_pamld_literal_l8(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_literal_l16(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_literal_l24(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_literal_l32(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+
+int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    const int L = host_decoder.nucleotide_cardinality;
+    if(L <= 8) { return launch_pamld_literal_l8(args, host_decoder, grid, lds_bytes, stream); }
+    if(L <= 16) { return launch_pamld_literal_l16(args, host_decoder, grid, lds_bytes, stream); }
+    if(L <= 24) { return launch_pamld_literal_l24(args, host_decoder, grid, lds_bytes, stream); }
+    return launch_pamld_literal_l32(args, host_decoder, grid, lds_bytes, stream);
+}
+
+int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream) {
+    (void)mode;
+    if(args.n_read <= 0) { return static_cast<int>(hipSuccess); }
+    const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
+    const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
+    const size_t histogram_bytes = sizeof(unsigned long long) *
+        static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : 0));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch(host_decoder.algorithm) {
+        case 1: return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+        case 2: return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
+        default: return launch_count(args, host_decoder, grid, histogram_bytes, s);
+    }
+}
+
+}  // namespace phq

@@ -1,0 +1,139 @@
+"""Seeded synthetic workloads of the shapes BASELINE.json names.
+
+Barcode sets: distinct random ACGT words with pairwise Hamming distance >= 3, sorted (sorted codec keys
+give index 1..N, reference transcode.cpp:988-1004).  Reads: the true barcode is drawn from the priors,
+or with probability `noise` a uniform random word; per base quality is an Illumina-like mix
+{Q37 80 %, Q25 10 %, Q12 7 %, Q2 3 %}; a base is substituted with probability 10^(-q/10); 0.1 % of
+bases read N at Q2; 3 % of reads carry an incoming QC-fail flag.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import jobspec
+
+BASE_SEED = 20240613
+ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+BAM = np.array([1, 2, 4, 8], dtype=np.uint8)
+QUALITY_VALUES = np.array([37, 25, 12, 2], dtype=np.uint8)
+QUALITY_WEIGHTS = np.array([0.80, 0.10, 0.07, 0.03])
+
+
+def barcode_set(rng: np.random.Generator, count: int, length: int, min_distance: int = 3) -> List[str]:
+    """Rejection sampling of `count` words of `length` nucleotides with pairwise Hamming >= min_distance."""
+    if 4 ** length < count:
+        raise ValueError("cannot draw %d distinct words of length %d" % (count, length))
+    chosen = np.zeros((0, length), dtype=np.uint8)
+    while chosen.shape[0] < count:
+        candidate = rng.integers(0, 4, size=(1, length), dtype=np.uint8)
+        if chosen.shape[0] == 0 or (chosen != candidate).sum(axis=1).min() >= min_distance:
+            chosen = np.concatenate([chosen, candidate])
+    words = sorted("".join("ACGT"[c] for c in row) for row in chosen)
+    return words
+
+
+def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens: Sequence[str], knit: Optional[Sequence[str]] = None,
+                 pairing: str = "product", **extra) -> Dict[str, Any]:
+    """User level decoder spec.  `segments[s]` is the word list of barcode segment s; `product` builds the
+    full combinatorial codec (96 x 96 = 9216 for the dual index shape), `zip` pairs word i with word i."""
+    if pairing == "product":
+        combos = [[w] for w in segments[0]]
+        for words in segments[1:]:
+            combos = [c + [w] for c in combos for w in words]
+    else:
+        combos = [list(c) for c in zip(*segments)]
+    codec = {"@" + "".join(c): {"barcode": c, "concentration": 1} for c in combos}
+    spec = {"algorithm": kind_algorithm, "transform": {"token": list(tokens)}, "codec": codec}
+    if knit:
+        spec["transform"]["knit"] = list(knit)
+    spec.update(extra)
+    return spec
+
+
+def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
+    """Compiled job + generation recipe for BASELINE config C2..C5.  seed = 20240613 + config number."""
+    number = {"C2": 2, "C3": 3, "C4": 4, "C5": 5}[name]
+    rng = np.random.default_rng(BASE_SEED + number)
+    if name == "C2":        # single 8 bp i7 index, 96 barcodes
+        words = barcode_set(rng, 96, 8)
+        spec = {"input segment cardinality": 2,
+                "sample": decoder_spec(algorithm, [words], ["1::8"])}
+    elif name == "C3":      # dual 10 bp i7 + i5, 96 x 96 combinatorial, one sample decoder with two segments
+        i7, i5 = barcode_set(rng, 96, 10), barcode_set(rng, 96, 10)
+        spec = {"input segment cardinality": 3,
+                "sample": decoder_spec(algorithm, [i7, i5], ["1::10", "2::10"])}
+    elif name == "C4":      # sci-RNA-seq: cellular [96 x 10, 96 pairs (10 + 10)] + naive UMI 8
+        a, b, c = barcode_set(rng, 96, 10), barcode_set(rng, 96, 10), barcode_set(rng, 96, 10)
+        spec = {"input segment cardinality": 3,
+                "molecular": [{"algorithm": "naive", "transform": {"token": ["0::8"]}}],
+                "cellular": [decoder_spec(algorithm, [a], ["0:8:18"]),
+                             decoder_spec(algorithm, [b, c], ["1::10", "2::10"], pairing="zip")]}
+    else:                   # C5 SPLiT-seq: cellular [96 x 8] x 3 + 4 x 6 reverse complemented, naive UMI 10
+        r1, r2, r3 = barcode_set(rng, 96, 8), barcode_set(rng, 96, 8), barcode_set(rng, 96, 8)
+        r4 = barcode_set(rng, 4, 6)
+        spec = {"input segment cardinality": 2,
+                "molecular": [{"algorithm": "naive", "transform": {"token": ["1::10"]}}],
+                "cellular": [decoder_spec(algorithm, [r1], ["1:10:18"]),
+                             decoder_spec(algorithm, [r2], ["1:48:56"]),
+                             decoder_spec(algorithm, [r3], ["1:86:94"]),
+                             decoder_spec(algorithm, [r4], ["0::6"], knit=["~0"])]}
+    job = jobspec.compile_job(spec)
+    return job, {"name": name, "seed": BASE_SEED + number}
+
+
+def _codec_arrays(decoder: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:
+    records = list((decoder.get("codec") or {}).values())
+    L = int(decoder["nucleotide cardinality"])
+    if not records:
+        return np.zeros((0, L), dtype=np.uint8), np.zeros(0)
+    text = np.frombuffer("".join("".join(r["barcode"]) for r in records).encode(), dtype=np.uint8).reshape(len(records), L)
+    index = np.zeros(256, dtype=np.uint8)
+    index[ASCII] = np.arange(4, dtype=np.uint8)
+    return index[text], np.array([float(r["concentration"]) for r in records])
+
+
+def generate_rows(job: Dict[str, Any], n: int, seed: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray, List[int]]:
+    """n reads as row major staged observations: (code[n, sum L], quality[n, sum L], flag[n], decoder offsets).
+    Each decoder's observation is generated independently (what Rule::apply would have cut out of the read)."""
+    rng = np.random.default_rng(seed)
+    columns_code, columns_quality, offsets = [], [], []
+    offset = 0
+    for _, decoder in jobspec.iter_decoders(job):
+        L = int(decoder["nucleotide cardinality"])
+        offsets.append(offset)
+        offset += L
+        words, prior = _codec_arrays(decoder)
+        noise = float(decoder.get("noise", 0.01))
+        truth = rng.integers(0, 4, size=(n, L), dtype=np.uint8)            # noise reads and codec-less (UMI) decoders
+        if words.shape[0] > 0:
+            pick = rng.choice(words.shape[0], size=n, p=prior / prior.sum())
+            from_codec = rng.random(n) >= noise
+            truth[from_codec] = words[pick[from_codec]]
+        quality = QUALITY_VALUES[rng.choice(4, size=(n, L), p=QUALITY_WEIGHTS)]
+        error = rng.random((n, L)) < np.power(10.0, -quality.astype(np.float64) / 10.0)
+        shift = rng.integers(1, 4, size=(n, L), dtype=np.uint8)
+        called = np.where(error, (truth + shift) & 3, truth)
+        code = BAM[called]
+        unknown = rng.random((n, L)) < 0.001
+        code[unknown] = 15
+        quality = quality.copy()
+        quality[unknown] = 2
+        columns_code.append(code)
+        columns_quality.append(quality)
+    flag = (rng.random(n) < 0.03).astype(np.uint8)
+    if columns_code:
+        return np.concatenate(columns_code, axis=1), np.concatenate(columns_quality, axis=1), flag, offsets
+    return np.zeros((n, 0), dtype=np.uint8), np.zeros((n, 0), dtype=np.uint8), flag, offsets
+
+
+def algorithmic_bytes_per_read(job: Dict[str, Any]) -> int:
+    """2 * L_total (base + quality) + 1 (input flag) + 16 per PAMLD/MDD decoder + 4 (status word)."""
+    total = 0
+    closed = 0
+    for _, decoder in jobspec.iter_decoders(job):
+        total += int(decoder["nucleotide cardinality"])
+        if decoder["algorithm"] in ("pamld", "mdd"):
+            closed += 1
+    return 2 * total + 1 + 16 * closed + 4

@@ -1,0 +1,203 @@
+"""CPU-side checks of the C ABI library: it loads, exports every declared symbol, parses the compiled job,
+extracts observations like Rule::apply, and writes the report like the reference.  No compute call here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import bdggg
+from pheniqs_amd import DecoderSet, PheniqsError, capi, jobspec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "pheniqs_amd.h")).read()
+    declared = set(re.findall(r"\b(phq_[a-z_]+)\s*\(", header))
+    assert declared == set(capi.SYMBOLS)
+    library = capi.load_library()
+    for name in declared:
+        assert hasattr(library, name), name
+
+
+def test_create_reports_configuration_errors_with_reference_codes():
+    with pytest.raises(PheniqsError) as e:
+        DecoderSet('{"sample": {"algorithm": "bogus", "index": 0}}', device=capi.DEVICE_NONE)
+    assert e.value.code == 3 and "unsupported sample decoder algorithm bogus" in str(e.value)
+    with pytest.raises(PheniqsError) as e:
+        DecoderSet("{ not json", device=capi.DEVICE_NONE)
+    assert e.value.code == 3
+    job = jobspec.compile_job(bdggg.user_job())
+    del job["sample"]["undetermined"]
+    with pytest.raises(PheniqsError) as e:
+        DecoderSet(job, device=capi.DEVICE_NONE)
+    assert "classifier must declare an undetermined element" in str(e.value)      # classifier.cpp:96
+    job = jobspec.compile_job(bdggg.user_job())
+    job["sample"]["transform"]["token"] = ["1:8"]
+    with pytest.raises(PheniqsError) as e:
+        DecoderSet(job, device=capi.DEVICE_NONE)
+    assert "illegal token syntax" in str(e.value)                                   # transform.cpp:166
+    # compute without a device must fail loudly, never fall back
+    host_only = DecoderSet(jobspec.compile_job(bdggg.user_job()), device=capi.DEVICE_NONE)
+    with pytest.raises(PheniqsError):
+        host_only.stats_export()
+
+
+def test_layout_of_reference_compiled_job():
+    """The library consumes the reference's own compiled ontology (valid/compile_annotated.out) unchanged."""
+    s = DecoderSet(json.dumps(bdggg.compiled_reference_job()), device=capi.DEVICE_NONE)
+    assert (s.n_decoder, s.n_result, s.nucleotide_width, s.plane_width) == (3, 2, 24, 24)
+    kinds = [(d["kind"], d["algorithm"], d["n_barcode"], d["result_slot"], d["multiplexing"]) for d in s.decoders]
+    assert kinds == [(0, 1, 5, 0, 1), (1, 3, 0, -1, 0), (2, 1, 5, 1, 0)]
+    assert s.stats_words == 2 + 12 * (6 + 1 + 6)
+
+
+def _segments(reads):
+    out = []
+    for k in range(3):
+        codes = [r["segments"][k]["code"] for r in reads]
+        quals = [r["segments"][k]["quality"] for r in reads]
+        length = np.array([len(c) for c in codes], dtype=np.int32)
+        offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int64)
+        out.append({"code": np.concatenate(codes), "quality": np.concatenate(quals), "offset": offset, "length": length})
+    return out
+
+
+def test_stage_reads_matches_rule_apply_oracle(oracle):
+    job = jobspec.compile_job(bdggg.user_job())
+    reads = bdggg.load_reads(oracle.ascii_to_bam)
+    s = DecoderSet(job, device=capi.DEVICE_NONE)
+    flags = np.array([1 if r["qcfail"] else 0 for r in reads], dtype=np.uint8)
+    staged = s.stage_reads(_segments(reads), flags)
+    assert staged["incoming"] == (250, 243)                     # golden "incoming" block
+    assert staged["n"] == 248                                   # two reads fail min input length [0, 0, 22]
+    kept = [reads[i] for i in staged["kept"]]
+    engine = oracle.OracleJob(job)
+    rows_code, rows_quality = engine.stage([[(x["code"], x["quality"]) for x in r["segments"]] for r in kept])
+    offsets = [engine.decoder_offset(i) for i in range(3)]
+    n = staged["capacity"]
+    for d, offset in zip(s.decoders, offsets):
+        L, stride, prefix = d["nucleotide_cardinality"], d["plane_stride"], d["plane_prefix"]
+        plane_code = staged["base"][n * prefix: n * (prefix + stride)].reshape(n, stride)[:248]
+        plane_quality = staged["quality"][n * prefix: n * (prefix + stride)].reshape(n, stride)[:248]
+        assert np.array_equal(plane_code[:, :L], rows_code[:, offset:offset + L])
+        assert np.array_equal(plane_quality[:, :L], rows_quality[:, offset:offset + L])
+    assert np.array_equal(staged["flag"][:248], flags[staged["kept"]])
+
+
+def test_stage_reads_reverse_complement_negative_tokens_and_short_reads(oracle):
+    spec = {"input segment cardinality": 2,
+            "cellular": [{"algorithm": "pamld", "transform": {"token": ["0:-6:", "1:2:5", "1:-3:"], "knit": ["~0:1", "~2"]},
+                          "codec": {"@A": {"barcode": ["ACGTACGTA", "TTT"]}, "@B": {"barcode": ["CCCCAAAAC", "GGG"]}}}]}
+    job = jobspec.compile_job(spec)
+    rng = np.random.default_rng(7)
+    reads = []
+    for length0, length1 in [(20, 12), (4, 12), (20, 3), (0, 0), (6, 5), (3, 2)]:
+        segs = []
+        for length in (length0, length1):
+            segs.append((BAM[rng.integers(0, 5, size=length)], rng.integers(0, 42, size=length).astype(np.uint8)))
+        reads.append(segs)
+    engine = oracle.OracleJob(job)
+    rows_code, rows_quality = engine.stage(reads)
+    s = DecoderSet(job, device=capi.DEVICE_NONE)
+    segments = []
+    for k in range(2):
+        length = np.array([len(r[k][0]) for r in reads], dtype=np.int32)
+        offset = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int64)
+        segments.append({"code": np.concatenate([r[k][0] for r in reads]), "quality": np.concatenate([r[k][1] for r in reads]),
+                         "offset": offset, "length": length})
+    staged = s.stage_reads(segments, None)
+    n, d = staged["capacity"], s.decoders[0]
+    plane = staged["base"][: n * d["plane_stride"]].reshape(n, d["plane_stride"])
+    assert np.array_equal(plane[:, :12], rows_code)
+    assert not plane[:, 12:].any()
+    plane_q = staged["quality"][: n * d["plane_stride"]].reshape(n, d["plane_stride"])
+    assert np.array_equal(plane_q[:, :12], rows_quality)
+
+
+BAM = np.array([1, 2, 4, 8, 15], dtype=np.uint8)
+
+
+def _words_from_oracle(s, engine):
+    """Encode the oracle's counters in the library's integer counter layout (include/pheniqs_amd.h)."""
+    words = np.zeros(s.stats_words, dtype=np.uint64)
+    count, pf_count = engine.outgoing()
+    words[0], words[1] = count - pf_count, pf_count
+    for k, d in enumerate(s.decoders):
+        option = engine.options(k)
+        for b in range(len(option)):
+            o = option[b]
+            base = d["stats_offset"] + b * 12
+            fail, passed = base, base + 6
+            words[passed + 0] = o["pf_count"]; words[fail + 0] = o["count"] - o["pf_count"]
+            words[passed + 1] = o["accumulated_pf_distance"]; words[fail + 1] = o["accumulated_distance"] - o["accumulated_pf_distance"]
+            total = int(round(float(o["accumulated_confidence"]) * 2 ** 52))
+            passed_fixed = int(round(float(o["accumulated_pf_confidence"]) * 2 ** 52))
+            failed_fixed = total - passed_fixed
+            words[passed + 2], words[passed + 3] = passed_fixed & (2 ** 26 - 1), passed_fixed >> 26
+            words[fail + 2], words[fail + 3] = failed_fixed & (2 ** 26 - 1), failed_fixed >> 26
+            words[fail + 4] = o["low_conditional_confidence_count"]
+            words[fail + 5] = o["low_confidence_count"]
+    return words
+
+
+def test_report_writer_reproduces_golden_report(oracle):
+    """finalize + encode + print_json of the library on the reference run's counters == valid/annotated.err."""
+    job = jobspec.compile_job(bdggg.user_job())
+    reads = bdggg.load_reads(oracle.ascii_to_bam)
+    s = DecoderSet(job, device=capi.DEVICE_NONE)
+    flags = np.array([1 if r["qcfail"] else 0 for r in reads], dtype=np.uint8)
+    staged = s.stage_reads(_segments(reads), flags)
+    kept = [reads[i] for i in staged["kept"]]
+    engine = oracle.OracleJob(job)
+    rows_code, rows_quality = engine.stage([[(x["code"], x["quality"]) for x in r["segments"]] for r in kept])
+    engine.classify(rows_code, rows_quality, flags[staged["kept"]])
+    words = _words_from_oracle(s, engine)
+    for k in range(3):
+        mine, theirs = s.stats_options(words, k), engine.options(k)
+        for name in mine.dtype.names:
+            if name.startswith("accumulated_") and name.endswith("confidence"):
+                assert np.allclose(mine[name], theirs[name], rtol=0, atol=1e-13)
+            else:
+                assert np.array_equal(mine[name], theirs[name]), name
+    text = s.report(words, staged["incoming"])
+    report = json.loads(text)
+    golden = bdggg.golden_report()
+
+    def compare(mine, theirs, path):
+        if isinstance(mine, dict):
+            for key, value in mine.items():
+                assert key in theirs, path + "/" + key
+                compare(value, theirs[key], path + "/" + key)
+        elif isinstance(mine, list):
+            assert len(mine) == len(theirs), path
+            for i, (m, t) in enumerate(zip(mine, theirs)):
+                compare(m, t, "%s[%d]" % (path, i))
+        elif isinstance(theirs, float):
+            assert abs(mine - theirs) <= 1e-15 + 1e-18, (path, mine, theirs)
+        else:
+            assert mine == theirs, (path, mine, theirs)
+
+    compare(report, golden, "")
+    assert set(report.keys()) == set(golden.keys())
+    # layout: sorted keys, 4 space indent, integers bare — same lines as the golden file for a count only block
+    golden_text = open(os.path.join(bdggg.HERE, "annotated.report.json")).read()
+    for block in ("incoming", "outgoing"):
+        pattern = r'    "%s": \{.*?\n    \}' % block
+        assert re.search(pattern, text, re.S).group(0) == re.search(pattern, golden_text, re.S).group(0)
+    mine_lines = [l for l in text.splitlines() if '"estimated' not in l and "average" not in l]
+    assert mine_lines[0] == "{" and mine_lines[-1] == "}"
+
+
+@pytest.mark.parametrize("value,expected", [
+    (0.0, "0.0"), (1.0, "1.0"), (0.972, "0.972"), (0.18 * (1 - 0.015), "0.177299999999999"),
+    (1.0 / 4 ** 8, "0.000015258789062"), (0.951612903225806451, "0.951612903225806"), (248.0, "248.0"),
+    (0.5, "0.5"), (1e-20, "0.0"), (0.049180327868852458, "0.049180327868852"), (123456.789, "123456.789"),
+    (2.0 / 3.0, "0.666666666666666"), (0.1 + 0.2, "0.3"), (1e21, "1e21"), (1.5e22, "1.5e22"), (-0.25, "-0.25"),
+])
+def test_format_double_is_rapidjson_truncation(value, expected):
+    """Values taken from the golden report / compiled job, plus the branches of rapidjson's Prettify."""
+    assert capi.format_double(value, 15) == expected

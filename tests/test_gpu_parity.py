@@ -1,0 +1,352 @@
+"""Parity of the HIP path against the CPU oracle and the reference's golden files, through the C ABI.
+
+Bar (BASELINE.json north_star): decoded index, distance, high quality distance, status, QC fail, channel
+word and every integer counter are bit exact; the PAMLD posterior is within 1e-6 of the reference
+(measured ~1e-14, asserted at 1e-9 so that a regression in the in-kernel 2^x shows up long before the
+contract is at risk); confidence sums agree to 1e-12 relative.
+"""
+import json
+
+import numpy as np
+import pytest
+
+import bdggg
+from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, jobspec, synthetic
+
+pytestmark = pytest.mark.gpu
+
+POSTERIOR_TOLERANCE = 1e-6        # the contract
+POSTERIOR_DESIGN_TOLERANCE = 1e-9
+INTEGER_FIELDS = ("index", "distance", "hq_distance", "status", "qcfail")
+INTEGER_COUNTERS = ("count", "pf_count", "accumulated_distance", "accumulated_pf_distance",
+                    "low_conditional_confidence_count", "low_confidence_count")
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def run_gpu(torch, job, code, quality, flag, offsets, mode=capi.MODE_LITERAL, pieces=1, device_set=None):
+    """Stage rows into decoder planes on the GPU and classify through phq_classify_device."""
+    s = device_set or DecoderSet(job, device=0)
+    s.set_mode(mode)
+    s.stats_reset()
+    n = code.shape[0]
+    base = torch.from_numpy(s.planes_from_rows(code, offsets)).cuda()
+    qual = torch.from_numpy(s.planes_from_rows(quality, offsets)).cuda()
+    flags = torch.from_numpy(np.ascontiguousarray(flag, dtype=np.uint8)).cuda() if flag is not None else None
+    result = torch.zeros(max(1, s.n_result * n) * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    word = torch.full((max(1, n),), -1, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    bounds = np.linspace(0, n, pieces + 1).astype(np.int64)
+    for first, last in zip(bounds[:-1], bounds[1:]):
+        s.classify_device(n, int(first), int(last - first), base, qual, flags, result, word, stream)
+    torch.cuda.synchronize()
+    got = result.cpu().numpy().view(RESULT_DTYPE)[: s.n_result * n].reshape(s.n_result, n)
+    return s, got, word.cpu().numpy().view(np.uint32)[:n], s.stats_export()
+
+
+def assert_parity(oracle, torch, job, code, quality, flag, offsets, **kwargs):
+    engine = oracle.OracleJob(job)
+    expected, expected_word = engine.classify(code, quality, flag)
+    s, got, word, words = run_gpu(torch, job, code, quality, flag, offsets, **kwargs)
+    n = code.shape[0]
+    for slot in range(s.n_result):
+        for name in INTEGER_FIELDS:
+            mismatch = np.nonzero(got[slot][name] != expected[:, slot][name])[0]
+            assert mismatch.size == 0, (slot, name, mismatch[:5], got[slot][mismatch[:5]], expected[mismatch[:5], slot])
+        if n:
+            delta = np.abs(got[slot]["confidence"] - expected[:, slot]["confidence"]).max()
+            assert delta < POSTERIOR_TOLERANCE
+            assert delta < POSTERIOR_DESIGN_TOLERANCE
+    assert np.array_equal(word, expected_word)
+    count, pf_count = engine.outgoing()
+    assert (int(words[0] + words[1]), int(words[1])) == (count, pf_count)
+    for k in range(s.n_decoder):
+        mine, theirs = s.stats_options(words, k), engine.options(k)
+        for name in INTEGER_COUNTERS:
+            assert np.array_equal(mine[name], theirs[name]), (k, name)
+        for name in ("accumulated_confidence", "accumulated_pf_confidence"):
+            assert np.allclose(mine[name], theirs[name], rtol=1e-12, atol=1e-12), (k, name)
+    return s, engine, got, words
+
+
+# ---- the reference's own decode test ----------------------------------------------------------------------
+
+
+def test_bdggg_golden_through_the_gpu(oracle, torch_cuda):
+    """test/BDGGG end to end: FASTQ -> phq_stage_reads -> kernels -> report, against valid/annotated.{out,err}."""
+    job = jobspec.compile_job(bdggg.user_job())
+    reads = bdggg.load_reads(oracle.ascii_to_bam)
+    s = DecoderSet(job, device=0)
+    segments = []
+    for k in range(3):
+        codes = [r["segments"][k]["code"] for r in reads]
+        length = np.array([len(c) for c in codes], dtype=np.int32)
+        segments.append({"code": np.concatenate(codes), "quality": np.concatenate([r["segments"][k]["quality"] for r in reads]),
+                         "offset": np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int64), "length": length})
+    flags = np.array([1 if r["qcfail"] else 0 for r in reads], dtype=np.uint8)
+    staged = s.stage_reads(segments, flags)
+    n = staged["n"]
+    assert n == 248 and staged["capacity"] == 250
+    result, word = s.classify_host(n, _repack(s, staged, n), _repack(s, staged, n, "quality"), staged["flag"][:n])
+    words = s.stats_export()
+
+    records, order = bdggg.golden_records()
+    kept = [reads[i] for i in staged["kept"]]
+    assert [r["name"] for r in kept] == order
+    id_to_index = {"undetermined": 0}
+    for record in job["sample"]["codec"].values():
+        id_to_index[record["barcode"][0]] = record["index"]
+    for i, read in enumerate(kept):
+        tags = records[read["name"]]["tags"]
+        assert id_to_index[tags["RG"].split(":")[-1]] == result[0][i]["index"], read["name"]
+        assert bool(records[read["name"]]["flag"] & 512) == bool(word[i] >> 31), read["name"]
+        for tag, slot in (("XB", 0), ("XC", 1)):
+            confidence = result[slot][i]["confidence"]          # one decoder per type: the type product is the value itself
+            if 0 < confidence < 1:
+                assert tags[tag] == "%g" % float(np.float32(1.0 - confidence)), (read["name"], tag)
+            else:
+                assert tag not in tags
+
+    report = json.loads(s.report(words, staged["incoming"]))
+    golden = bdggg.golden_report()
+
+    def compare(mine, theirs, path):
+        if isinstance(mine, dict):
+            for key, value in mine.items():
+                assert key in theirs, path + "/" + key
+                compare(value, theirs[key], path + "/" + key)
+        elif isinstance(mine, list):
+            assert len(mine) == len(theirs), path
+            for k, (m, t) in enumerate(zip(mine, theirs)):
+                compare(m, t, "%s[%d]" % (path, k))
+        elif isinstance(theirs, float):
+            # 15 truncated decimals in the golden file; our posterior differs from the reference's by ~1e-14
+            assert abs(mine - theirs) <= 1e-12, (path, mine, theirs)
+        else:
+            assert mine == theirs, (path, mine, theirs)
+
+    compare(report, golden, "")
+    assert set(report.keys()) == set(golden.keys())
+
+
+def _repack(s, staged, n, which="base"):
+    """planes laid out for `capacity` reads -> planes laid out for n reads (what phq_classify_host expects)."""
+    capacity = staged["capacity"]
+    out = np.zeros(max(1, n * s.plane_width), dtype=np.uint8)
+    for d in s.decoders:
+        stride, prefix = d["plane_stride"], d["plane_prefix"]
+        if stride:
+            out[n * prefix: n * (prefix + stride)] = staged[which][capacity * prefix: capacity * prefix + n * stride]
+    return out
+
+
+# ---- BASELINE configs at oracle-sized samples ---------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name,algorithm,n", [
+    ("C2", "pamld", 1 << 16), ("C2", "mdd", 1 << 16),
+    ("C3", "pamld", 3000), ("C3", "mdd", 1 << 14),
+    ("C4", "pamld", 1 << 14), ("C4", "mdd", 1 << 14),
+    ("C5", "pamld", 1 << 14), ("C5", "mdd", 1 << 14),
+])
+def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n):
+    job, recipe = synthetic.config_job(name, algorithm)
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+# ---- edge cases the reference's tests do not pin (SURVEY.md §4 gaps, §8a S1-S10) ------------------------------
+
+
+def _small_job(algorithm="pamld", **extra):
+    spec = {"input segment cardinality": 2,
+            "sample": {"algorithm": algorithm, "transform": {"token": ["1::8"]},
+                       "codec": {"@" + w: {"barcode": [w], "concentration": c} for w, c in
+                                 (("AGGCAGAA", .18), ("CGTACTAG", .2), ("GGACTCCT", .22), ("TAAGGCGA", .23), ("TCCTGAGC", .17))}}}
+    spec["sample"].update(extra)
+    return jobspec.compile_job(spec)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 257, 1000])
+def test_empty_and_ragged_batches(oracle, torch_cuda, n):
+    job, recipe = synthetic.config_job("C2")
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 99)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+def test_split_ranges_equal_one_call(oracle, torch_cuda):
+    job, recipe = synthetic.config_job("C5")
+    code, quality, flag, offsets = synthetic.generate_rows(job, 5003, 5)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=7)
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+def test_unknown_bases_zero_quality_and_short_observations(oracle, torch_cuda, algorithm):
+    job = _small_job(algorithm)
+    rng = np.random.default_rng(11)
+    n = 4096
+    code = np.array([1, 2, 4, 8, 15, 0, 3], dtype=np.uint8)[rng.integers(0, 7, size=(n, 8))]
+    quality = rng.integers(0, 45, size=(n, 8)).astype(np.uint8)
+    quality[rng.random((n, 8)) < 0.1] = 0
+    # all N, all Q0, and short observations: zero filled tail
+    code[0] = 15; quality[0] = 2
+    quality[1] = 0
+    for i, keep in enumerate(range(8)):
+        code[10 + i, keep:] = 0
+        quality[10 + i, keep:] = 0
+    code[20] = np.array([1, 4, 4, 2, 1, 4, 1, 0]); quality[20] = np.array([30] * 7 + [0])      # 7 of 8 observed, exact prefix
+    quality[21] = 127
+    quality[22] = 255       # BAM "missing" quality: masked to the table's 128 rows
+    flag = (rng.random(n) < 0.2).astype(np.uint8)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, [0])
+
+
+def test_ties_keep_the_lowest_index(oracle, torch_cuda):
+    """strict '>' from zero.  Uniform priors, uniform qualities: equidistant barcodes tie exactly."""
+    words = ["AAAAAAAA", "AAAACCCC", "CCCCAAAA", "CCCCCCCC", "GGGGGGGG", "TTTTTTTT"]
+    spec = {"input segment cardinality": 1,
+            "sample": {"algorithm": "pamld", "transform": {"token": ["0::8"]},
+                       "codec": {"@" + w: {"barcode": [w]} for w in words}, "confidence threshold": 0.4}}
+    job = jobspec.compile_job(spec)
+    rng = np.random.default_rng(3)
+    n = 2048
+    letters = np.array([1, 2, 4, 8], dtype=np.uint8)
+    code = letters[rng.integers(0, 4, size=(n, 8))]
+    code[:64] = letters[np.array([0, 0, 1, 1, 0, 0, 1, 1])]            # AACCAACC: distance 4 to four barcodes
+    quality = np.full((n, 8), 30, dtype=np.uint8)
+    quality[64:] = np.array([37, 25, 12, 2], dtype=np.uint8)[rng.integers(0, 4, size=(n - 64, 8))]
+    s, engine, got, _ = assert_parity(oracle, torch_cuda, job, code, quality, None, [0])
+    assert set(got[0]["index"][:64]) <= {0, 1}
+
+
+def test_iupac_barcodes_take_the_uniform_branch(oracle, torch_cuda):
+    """barcode letters outside ACGT always cost UNIFORM_BASE_QUALITY (the STRICT=false kernels)."""
+    spec = {"input segment cardinality": 1,
+            "cellular": [{"algorithm": "pamld", "transform": {"token": ["0::6"]},
+                          "codec": {"@a": {"barcode": ["ACNTGA"]}, "@b": {"barcode": ["RCGTAA"]}, "@c": {"barcode": ["TTTTTT"]}}}]}
+    job = jobspec.compile_job(spec)
+    rng = np.random.default_rng(5)
+    n = 4096
+    code = np.array([1, 2, 4, 8, 15], dtype=np.uint8)[rng.integers(0, 5, size=(n, 6))]
+    quality = rng.integers(0, 42, size=(n, 6)).astype(np.uint8)
+    assert_parity(oracle, torch_cuda, job, code, quality, None, [0])
+
+
+def test_mdd_masking_tolerances_and_segments(oracle, torch_cuda):
+    spec = {"input segment cardinality": 2,
+            "sample": {"algorithm": "mdd", "transform": {"token": ["0::8", "1::10"]},
+                       "quality masking threshold": 12, "distance tolerance": [1, 1],
+                       "codec": {"@%d" % i: {"barcode": [a, b]} for i, (a, b) in enumerate(
+                           [("AAAACCCC", "GGGGGTTTTT"), ("CCCCAAAA", "TTTTTGGGGG"), ("GTGTGTGT", "ACACACACAC"), ("TGCATGCA", "CATGCATGCA")])}}}
+    job = jobspec.compile_job(spec)
+    assert job["sample"]["shannon bound"] == [3, 4]
+    rng = np.random.default_rng(9)
+    n = 1 << 14
+    words = np.array([[ord(c) for c in "".join(r["barcode"])] for r in job["sample"]["codec"].values()], dtype=np.uint8)
+    lut = np.zeros(256, dtype=np.uint8); lut[[65, 67, 71, 84]] = [1, 2, 4, 8]
+    code = lut[words[rng.integers(0, 4, size=n)]]
+    flip = rng.random((n, 18)) < 0.06
+    code[flip] = np.array([1, 2, 4, 8, 15], dtype=np.uint8)[rng.integers(0, 5, size=int(flip.sum()))]
+    quality = np.array([37, 25, 12, 11, 2], dtype=np.uint8)[rng.choice(5, size=(n, 18), p=[.7, .1, .1, .05, .05])]
+    short = rng.random(n) < 0.05
+    code[short, 14:18] = 0; quality[short, 14:18] = 0
+    assert_parity(oracle, torch_cuda, job, code, quality, (rng.random(n) < 0.1).astype(np.uint8), [0])
+    job["sample"]["quality masking threshold"] = 0
+    assert_parity(oracle, torch_cuda, job, code, quality, None, [0])
+
+
+def test_decoder_chain_sticky_qcfail_and_passthrough(oracle, torch_cuda):
+    """QC fail set by one decoder feeds the pf counters of every later decoder."""
+    spec = {"input segment cardinality": 2,
+            "sample": _small_job()["sample"],
+            "molecular": [{"algorithm": "naive", "transform": {"token": ["0::6"]}}],
+            "cellular": [dict(_small_job("mdd")["sample"], **{"multiplexing classifier": False}),
+                         dict(_small_job(**{"high quality distance threshold": 1, "high quality threshold": 20,
+                                            "confidence threshold": 0.99})["sample"], **{"multiplexing classifier": False})]}
+    for d in spec["cellular"]:
+        d.pop("index", None)
+    job = jobspec.compile_job({k: v for k, v in spec.items()})
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 14, 21)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+# ---- properties at BASELINE.json's full size -----------------------------------------------------------------
+
+
+def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda):
+    """100 M reads (config C2) built by tiling a pool the oracle can decode in seconds: every counter must be
+    exactly `tiles` times the pool's, and every result record equal to the pool's record."""
+    torch = torch_cuda
+    job, recipe = synthetic.config_job("C2")
+    pool_n, tiles = 1 << 18, 382                                       # 100 139 008 reads
+    code, quality, flag, offsets = synthetic.generate_rows(job, pool_n, recipe["seed"])
+    engine = oracle.OracleJob(job)
+    expected, expected_word = engine.classify(code, quality, flag)
+    s = DecoderSet(job, device=0)
+    n = pool_n * tiles
+    base = torch.from_numpy(s.planes_from_rows(code, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
+    qual = torch.from_numpy(s.planes_from_rows(quality, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
+    flags = torch.from_numpy(flag).cuda().repeat(tiles)
+    result = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    word = torch.zeros(n, dtype=torch.int32, device="cuda")
+    s.classify_device(n, 0, n, base, qual, flags, result, word, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    words = s.stats_export()
+    assert int(words[0] + words[1]) == n
+    mine, theirs = s.stats_options(words, 0), engine.options(0)
+    for name in INTEGER_COUNTERS:
+        assert np.array_equal(mine[name], theirs[name] * tiles), name
+    # idempotence across tiles: every tile's records equal the first tile's, and the first equals the oracle's
+    records = result.view(tiles, pool_n * RESULT_DTYPE.itemsize)
+    assert bool((records == records[0]).all())
+    first = records[0].cpu().numpy().view(RESULT_DTYPE)
+    for name in INTEGER_FIELDS:
+        assert np.array_equal(first[name], expected[:, 0][name]), name
+    assert np.abs(first["confidence"] - expected[:, 0]["confidence"]).max() < POSTERIOR_DESIGN_TOLERANCE
+    assert bool((word.view(tiles, pool_n) == word.view(tiles, pool_n)[0]).all())
+
+
+def test_classify_host_equals_classify_device(oracle, torch_cuda):
+    job, recipe = synthetic.config_job("C4")
+    n = (1 << 22) + 12345                                              # more than one pipeline chunk
+    pool = 1 << 15
+    code, quality, flag, offsets = synthetic.generate_rows(job, pool, 77)
+    engine = oracle.OracleJob(job)
+    expected, expected_word = engine.classify(code, quality, flag)
+    reps = -(-n // pool)
+    code = np.tile(code, (reps, 1))[:n]; quality = np.tile(quality, (reps, 1))[:n]; flag = np.tile(flag, reps)[:n]
+    s = DecoderSet(job, device=0)
+    result, word = s.classify_host(n, s.planes_from_rows(code, offsets), s.planes_from_rows(quality, offsets), flag)
+    index = np.arange(n) % pool
+    for slot in range(s.n_result):
+        for name in INTEGER_FIELDS:
+            assert np.array_equal(result[slot][name], expected[index, slot][name]), (slot, name)
+    assert np.array_equal(word, expected_word[index])
+    words = s.stats_export()
+    assert int(words[0] + words[1]) == n
+
+
+def test_counter_allreduce_over_rccl_single_rank(oracle, torch_cuda):
+    """The counter buffer is exposed as a device tensor; a one rank RCCL all-reduce must leave it unchanged."""
+    import os
+    import torch.distributed as dist
+    torch = torch_cuda
+    job, recipe = synthetic.config_job("C2")
+    code, quality, flag, offsets = synthetic.generate_rows(job, 4096, 1)
+    s, got, word, words = run_gpu(torch, job, code, quality, flag, offsets)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        tensor = s.stats_tensor()
+        assert tensor.dtype == torch.int64 and tensor.numel() == s.stats_words
+        dist.all_reduce(tensor)
+        torch.cuda.synchronize()
+        assert np.array_equal(s.stats_export(), words)
+    finally:
+        dist.destroy_process_group()
