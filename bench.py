@@ -22,33 +22,87 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def profiled_traffic(mode, reads):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_summary.json),
+    scaled to this run's reads per launch.  PMC counters cannot be read from inside the benchmark itself."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+        try:
+            entry = json.load(open(path)).get(mode)
+        except (OSError, ValueError):
+            continue
+        if entry:
+            return entry["traffic_bytes_per_read"] * reads
+    return None
+
+
+def usable_cores():
+    """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(job, code, quality, flag, target_seconds=12.0):
     """The CPU oracle (a port of the reference algorithm, oracle/pheniqs_oracle.c) timed on this host's cores:
-    one private decoder set per thread, counters merged at the end, like the reference's TranscodingThreads."""
+    one private decoder set per thread, like the reference's TranscodingThreads (transcode.cpp:1769-1775).
+    Every thread decodes 64 Ki-read chunks of the pool, starting at its own offset, until the deadline."""
+    import threading
     from oracle import pyoracle
-    cores = os.cpu_count() or 1
-    probe = min(20000, code.shape[0])
+    cores = usable_cores()
+    n = code.shape[0]
+    chunk = min(65536, n)
     engine = pyoracle.OracleJob(job)
+    probe = min(20000, n)
     t0 = time.perf_counter()
     engine.classify(code[:probe], quality[:probe], flag[:probe])
     single = probe / (time.perf_counter() - t0)
-    sample = int(min(code.shape[0], max(probe, single * cores * target_seconds)))
-    bounds = np.linspace(0, sample, cores + 1).astype(np.int64)
     engines = [pyoracle.OracleJob(job) for _ in range(cores)]
+    done = [0] * cores
+    start = threading.Barrier(cores + 1)
 
     def work(k):
-        a, b = bounds[k], bounds[k + 1]
-        return engines[k].classify(code[a:b], quality[a:b], flag[a:b])
+        start.wait()
+        deadline = time.perf_counter() + target_seconds
+        position = (k * chunk) % max(1, n - chunk + 1)
+        while time.perf_counter() < deadline:
+            engines[k].classify(code[position:position + chunk], quality[position:position + chunk], flag[position:position + chunk])
+            done[k] += chunk
+            position = (position + chunk) % max(1, n - chunk + 1)
 
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(cores)]
+    for t in threads:
+        t.start()
+    start.wait()
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as pool:
-        results = list(pool.map(work, range(cores)))
+    for t in threads:
+        t.join()
     elapsed = time.perf_counter() - t0
-    for other in engines[1:]:
-        engines[0].collect(other)
-    return {"value": sample / elapsed / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads of the same C2 pool, %d threads x private decoder set, %.1f s; 1 thread: %.3f Mreads/s" % (
-                sample, cores, elapsed, single / 1e6)}, results, bounds
+    total = sum(done)
+    return {"value": total / elapsed / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
+            "sample": "%d reads (64 Ki-read chunks of the same C2 pool) on %d threads with private decoder sets, %.1f s wall; "
+                      "1 thread alone: %.3f Mreads/s" % (total, cores, elapsed, single / 1e6)}
+
+
+def parity_check(job, code, quality, flag, got, reads):
+    """The first `reads` reads of the batch through the oracle: the GPU records must be the same."""
+    from oracle import pyoracle
+    cores = min(usable_cores(), 64)
+    bounds = np.linspace(0, reads, cores + 1).astype(np.int64)
+    engines = [pyoracle.OracleJob(job) for _ in range(cores)]
+    with ThreadPoolExecutor(cores) as pool:
+        results = list(pool.map(lambda k: engines[k].classify(code[bounds[k]:bounds[k + 1]], quality[bounds[k]:bounds[k + 1]],
+                                                             flag[bounds[k]:bounds[k + 1]])[0], range(cores)))
+    expected = np.concatenate(results)[:, 0]
+    for name in ("index", "distance", "hq_distance", "status", "qcfail"):
+        assert np.array_equal(got[:reads][name], expected[name]), name
+    assert np.abs(got[:reads]["confidence"] - expected["confidence"]).max() < 1e-6
+    return reads
 
 
 def main():
@@ -142,22 +196,13 @@ def main():
                        "reads_per_gpu": n, "pool": pool_n, "barcodes": 96, "barcode_length": 8, "kernel_mode": args.mode,
                        "sharding": "reads x%d, counters merged by one all-reduce per step" % world},
             "roofline": {"bound": "hbm", "achieved": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(args.mode, n),
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read},
         }
         if world == 1 and not args.no_cpu_baseline:
-            baseline, cpu_results, bounds = cpu_baseline(job, code, quality, flag)
-            line["cpu_baseline"] = baseline
-            # the same reads through the GPU path must give the same records
+            line["cpu_baseline"] = cpu_baseline(job, code, quality, flag)
             got = result[: pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)
-            checked = 0
-            for k, (records, _) in enumerate(cpu_results):
-                a, b = int(bounds[k]), int(bounds[k + 1])
-                for name in ("index", "distance", "hq_distance", "status", "qcfail"):
-                    assert np.array_equal(got[a:b][name], records[:, 0][name]), name
-                assert np.abs(got[a:b]["confidence"] - records[:, 0]["confidence"]).max() < 1e-6
-                checked += b - a
-            line["parity_checked_reads"] = checked
+            line["parity_checked_reads"] = parity_check(job, code, quality, flag, got, min(pool_n, 1 << 19))
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -126,6 +126,8 @@ void DecoderSet::build_device_images() {
         d.confidence_threshold = c.confidence_threshold;
         d.random_barcode_probability = c.random_barcode_probability;
         d.uniform_base_quality = scale.uniform_base_quality;
+        d.log2_base_hi = scale.log2_base_hi;
+        d.log2_base_lo = scale.log2_base_lo;
         d.stats_offset = c.stats_offset;
         d.true_positive_quality = device_tpq;
         if(c.closed()) {

@@ -62,6 +62,8 @@ struct DevDecoder {
     double confidence_threshold;
     double random_barcode_probability;
     double uniform_base_quality;          // 10 log10 4                         phred.h:33
+    double log2_base_hi;                  // log2 of the double PHRED_PROBABILITY_BASE (phred.h:34), hi + lo
+    double log2_base_lo;
     int64_t stats_offset;                 // first u64 word of this decoder in the counter buffer
     const uint32_t* barcode_packed;       // n_barcode x n_word words of 4-bit BAM codes
     const double* concentration;          // n_barcode

@@ -120,24 +120,33 @@ __device__ __forceinline__ bool strict_code(uint32_t c) {
     return (c == 1) | (c == 2) | (c == 4) | (c == 8);
 }
 
-// 10^(-sigma/10) = pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * -log2(10)/10):
-// nearest-integer exponent split, degree 13 Taylor polynomial of e^t on |t| <= ln2/2, v_ldexp_f64.
-// Relative error ~1e-14 at sigma ~ 300, far inside the 1e-6 posterior tolerance.
-__device__ __forceinline__ double phred_probability(double sigma) {
-    const double z = sigma * -0.33219280948873623;
-    const double n = __builtin_rint(z);
-    const double t = (z - n) * 0.69314718055994531;
-    double r = 1.6059043836821613e-10;                   // 1/13!
-    r = __builtin_fma(r, t, 2.0876756987868099e-09);     // 1/12!
-    r = __builtin_fma(r, t, 2.5052108385441719e-08);     // 1/11!
-    r = __builtin_fma(r, t, 2.7557319223985891e-07);     // 1/10!
+// pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * log2(base)), base being the
+// DOUBLE the reference holds (fl(10^-0.1), phred.h:34), log2(base) carried as a hi + lo pair.
+// The exponent argument is formed in double-double (one FMA recovers the product's rounding error), so
+// two sums that differ by one ulp — which the reference's Kahan recurrence does produce for the same
+// multiset of costs visited in a different order — still map to different probabilities, ordered the way
+// libm's pow orders them.  floor() keeps the polynomial argument in [0, ln 2): every Horner step is then
+// monotone, so the whole map is.  Degree 17 Taylor, |error| ~ 1 ulp (2.4e-16 measured against glibc pow).
+__device__ __forceinline__ double phred_probability(double sigma, double log2_base_hi, double log2_base_lo) {
+    const double z_hi = sigma * log2_base_hi;
+    const double z_lo = __builtin_fma(sigma, log2_base_hi, -z_hi) + sigma * log2_base_lo;
+    const double n = __builtin_floor(z_hi);
+    const double t = ((z_hi - n) + z_lo) * 0.6931471805599453;
+    double r = 2.8114572543455206e-15;                   // 1/17!
+    r = __builtin_fma(r, t, 4.779477332387385e-14);      // 1/16!
+    r = __builtin_fma(r, t, 7.647163731819816e-13);      // 1/15!
+    r = __builtin_fma(r, t, 1.1470745597729725e-11);     // 1/14!
+    r = __builtin_fma(r, t, 1.6059043836821613e-10);     // 1/13!
+    r = __builtin_fma(r, t, 2.08767569878681e-09);       // 1/12!
+    r = __builtin_fma(r, t, 2.505210838544172e-08);      // 1/11!
+    r = __builtin_fma(r, t, 2.755731922398589e-07);      // 1/10!
     r = __builtin_fma(r, t, 2.7557319223985893e-06);     // 1/9!
-    r = __builtin_fma(r, t, 2.4801587301587302e-05);     // 1/8!
-    r = __builtin_fma(r, t, 1.9841269841269841e-04);     // 1/7!
-    r = __builtin_fma(r, t, 1.3888888888888889e-03);     // 1/6!
-    r = __builtin_fma(r, t, 8.3333333333333332e-03);     // 1/5!
-    r = __builtin_fma(r, t, 4.1666666666666664e-02);     // 1/4!
-    r = __builtin_fma(r, t, 1.6666666666666666e-01);     // 1/3!
+    r = __builtin_fma(r, t, 2.48015873015873e-05);       // 1/8!
+    r = __builtin_fma(r, t, 0.0001984126984126984);      // 1/7!
+    r = __builtin_fma(r, t, 0.001388888888888889);       // 1/6!
+    r = __builtin_fma(r, t, 0.008333333333333333);       // 1/5!
+    r = __builtin_fma(r, t, 0.041666666666666664);       // 1/4!
+    r = __builtin_fma(r, t, 0.16666666666666666);        // 1/3!
     r = __builtin_fma(r, t, 0.5);
     r = __builtin_fma(r, t, 1.0);
     r = __builtin_fma(r, t, 1.0);

@@ -7,7 +7,7 @@
 // "Literal" means sigma_q of every barcode is the reference's Kahan recurrence, operation for
 // operation, in fp64 with contraction off: the argmax (ties included: strict '>' keeps the lowest
 // index) is decided on the same sums the reference decides on.  Only pow() differs (an
-// in-kernel 2^x, ~1e-14 relative), which moves the posterior by ~1e-14.
+// in-kernel 2^x within ~1 ulp of libm's, kernel_common.hpp), which moves the posterior by ~1e-16.
 //
 // Template parameters: L = nucleotide cardinality (fully unrolled), STRICT = every barcode base is
 // one of A, C, G, T (the common case; drops the IUPAC branch from the inner loop).
@@ -37,6 +37,8 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
     const PHQ_CONSTANT double* concentration = constant_cast(d.concentration);
     const int n_barcode = d.n_barcode;
     const double uniform = d.uniform_base_quality;
+    const double log2_base_hi = d.log2_base_hi;
+    const double log2_base_lo = d.log2_base_lo;
     const int64_t n = args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
 
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                     c = (t - sigma_q) - y;
                     sigma_q = t;
                 }
-                const double conditional = phred_probability(sigma_q);
+                const double conditional = phred_probability(sigma_q, log2_base_hi, log2_base_lo);
                 const double p = conditional * concentration[b];
                 const double y = p - compensation;
                 const double t = sigma_p + y;

@@ -7,6 +7,9 @@ namespace phq {
 PhredScale::PhredScale() {
     uniform_base_quality = 10.0 * std::log10(4);
     phred_probability_base = std::pow(10.0, -0.1);
+    const long double log2_base = log2l(static_cast<long double>(phred_probability_base));   // x87 extended: 64 bit mantissa
+    log2_base_hi = static_cast<double>(log2_base);
+    log2_base_lo = static_cast<double>(log2_base - static_cast<long double>(log2_base_hi));
     false_positive_probability[0] = 0;
     true_positive_probability[0] = 0;
     true_positive_quality[0] = 0;

@@ -14,6 +14,8 @@ namespace phq {
 struct PhredScale {
     double uniform_base_quality;            // 10 log10 4
     double phred_probability_base;          // 10^-0.1
+    double log2_base_hi;                    // log2(phred_probability_base) = hi + lo, for the device 2^x
+    double log2_base_lo;
     double false_positive_probability[128];
     double true_positive_probability[128];
     double true_positive_quality[128];
