@@ -149,9 +149,10 @@ int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t fi
                         const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                         phq_result_t* result, uint32_t* word, void* hip_stream);
 
-/* Same call for HOST buffers: chunks the batch, stages through the set's pinned double buffers and
- * overlaps hipMemcpyAsync in both directions with compute.  Blocks until results are in host memory. */
-int phq_classify_host(phq_decoder_set* set, int64_t n_read,
+/* Same call for HOST buffers laid out for batch_capacity reads (what phq_stage_reads fills): decodes
+ * reads [0, n_read), chunk by chunk through the set's pinned double buffers, overlapping hipMemcpyAsync
+ * in both directions with compute.  Blocks until results are in host memory. */
+int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read,
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word);
 

@@ -73,7 +73,7 @@ def load_library():
     L.phq_set_mode.argtypes = [P, I32]
     L.phq_stage_reads.argtypes = [P, I64, I32, P, P, P, P, P, I64, P, P, P, P, P, P, P]
     L.phq_classify_device.argtypes = [P, I64, I64, I64, P, P, P, P, P, P]
-    L.phq_classify_host.argtypes = [P, I64, P, P, P, P, P]
+    L.phq_classify_host.argtypes = [P, I64, I64, P, P, P, P, P]
     L.phq_host_alloc.argtypes = [U64, ctypes.POINTER(P)]
     L.phq_host_free.argtypes = [P]
     L.phq_host_free.restype = None
@@ -205,10 +205,12 @@ class DecoderSet:
         self._check(self.lib.phq_classify_device(self.handle, capacity, first, n, _pointer(base), _pointer(quality),
                                                  _pointer(flag), _pointer(result), _pointer(word), stream or None))
 
-    def classify_host(self, n: int, base: np.ndarray, quality: np.ndarray, flag: Optional[np.ndarray]):
-        result = np.zeros((max(1, self.n_result), max(1, n)), dtype=RESULT_DTYPE)
-        word = np.zeros(max(1, n), dtype=np.uint32)
-        self._check(self.lib.phq_classify_host(self.handle, n, _pointer(base), _pointer(quality), _pointer(flag),
+    def classify_host(self, n: int, base: np.ndarray, quality: np.ndarray, flag: Optional[np.ndarray], capacity: Optional[int] = None):
+        """Host planes laid out for `capacity` reads (default n); decodes the first n."""
+        capacity = n if capacity is None else capacity
+        result = np.zeros((max(1, self.n_result), max(1, capacity)), dtype=RESULT_DTYPE)
+        word = np.zeros(max(1, capacity), dtype=np.uint32)
+        self._check(self.lib.phq_classify_host(self.handle, capacity, n, _pointer(base), _pointer(quality), _pointer(flag),
                                                result.ctypes.data, word.ctypes.data))
         return result[:self.n_result, :n], word[:n]
 

@@ -127,12 +127,12 @@ int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t fi
     });
 }
 
-int phq_classify_host(phq_decoder_set* set, int64_t n_read,
+int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read,
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word) {
     return guarded(set, [&]() {
         require(set, "set");
-        set->impl.classify_host(n_read, base_planes, quality_planes, flag, reinterpret_cast<phq::DevResult*>(result), word);
+        set->impl.classify_host(batch_capacity, n_read, base_planes, quality_planes, flag, reinterpret_cast<phq::DevResult*>(result), word);
     });
 }
 

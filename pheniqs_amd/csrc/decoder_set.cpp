@@ -306,10 +306,11 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
 // Host batch -> pinned slot -> device -> pinned slot -> host batch, two slots on two streams so that the
 // copies of one chunk run behind the kernels of the other (the reference's per-read Transcode::pull /
 // Multiplexer::push hand-offs, transcode.cpp:287-316 and multiplex.h:198-222, become two async copies per chunk).
-void DecoderSet::classify_host(int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                                DevResult* result, uint32_t* word) {
     require_device();
     if(n_read <= 0) { return; }
+    if(n_read > batch_capacity) { throw OverflowError("read count exceeds the batch capacity"); }
     const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 22);
     ensure_pipeline(chunk);
 
@@ -318,7 +319,7 @@ void DecoderSet::classify_host(int64_t n_read, const uint8_t* base_planes, const
         check(hipEventSynchronize(static_cast<hipEvent_t>(slot.done)), "hipEventSynchronize");
         for(const auto& c : job_.decoder) {
             if(c.result_slot >= 0 && result != nullptr) {
-                std::memcpy(result + static_cast<int64_t>(c.result_slot) * n_read + slot.first,
+                std::memcpy(result + static_cast<int64_t>(c.result_slot) * batch_capacity + slot.first,
                             slot.pinned_result + static_cast<int64_t>(c.result_slot) * chunk_capacity_,
                             static_cast<size_t>(slot.count) * sizeof(DevResult));
             }
@@ -336,7 +337,7 @@ void DecoderSet::classify_host(int64_t n_read, const uint8_t* base_planes, const
         for(const auto& c : job_.decoder) {
             if(c.plane_stride == 0) { continue; }
             const size_t bytes = static_cast<size_t>(count) * static_cast<size_t>(c.plane_stride);
-            const int64_t source = n_read * c.plane_prefix + first * c.plane_stride;
+            const int64_t source = batch_capacity * c.plane_prefix + first * c.plane_stride;
             const int64_t target = chunk_capacity_ * c.plane_prefix;
             std::memcpy(slot.pinned_base + target, base_planes + source, bytes);
             std::memcpy(slot.pinned_quality + target, quality_planes + source, bytes);

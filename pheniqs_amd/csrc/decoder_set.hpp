@@ -37,7 +37,7 @@ public:
     void classify_device(int64_t batch_capacity, int64_t first_read, int64_t n_read,
                          const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                          DevResult* result, uint32_t* word, void* stream);
-    void classify_host(int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+    void classify_host(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                        DevResult* result, uint32_t* word);
 
     void stats_reset(void* stream);

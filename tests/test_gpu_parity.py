@@ -92,7 +92,7 @@ def test_bdggg_golden_through_the_gpu(oracle, torch_cuda):
     staged = s.stage_reads(segments, flags)
     n = staged["n"]
     assert n == 248 and staged["capacity"] == 250
-    result, word = s.classify_host(n, _repack(s, staged, n), _repack(s, staged, n, "quality"), staged["flag"][:n])
+    result, word = s.classify_host(n, staged["base"], staged["quality"], staged["flag"], capacity=staged["capacity"])
     words = s.stats_export()
 
     records, order = bdggg.golden_records()
@@ -132,17 +132,6 @@ def test_bdggg_golden_through_the_gpu(oracle, torch_cuda):
 
     compare(report, golden, "")
     assert set(report.keys()) == set(golden.keys())
-
-
-def _repack(s, staged, n, which="base"):
-    """planes laid out for `capacity` reads -> planes laid out for n reads (what phq_classify_host expects)."""
-    capacity = staged["capacity"]
-    out = np.zeros(max(1, n * s.plane_width), dtype=np.uint8)
-    for d in s.decoders:
-        stride, prefix = d["plane_stride"], d["plane_prefix"]
-        if stride:
-            out[n * prefix: n * (prefix + stride)] = staged[which][capacity * prefix: capacity * prefix + n * stride]
-    return out
 
 
 # ---- BASELINE configs at oracle-sized samples ---------------------------------------------------------------
