@@ -42,6 +42,8 @@ DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
     max_blocks_(2048),
     device_decoder_(nullptr),
     device_stats_(nullptr),
+    device_worklist_(nullptr),
+    worklist_capacity_(0),
     chunk_capacity_(0) {
     if(device_ >= 0) {
         try {
@@ -60,7 +62,7 @@ void DecoderSet::release() {
     for(auto& slot : slot_) {
         if(slot.stream) { (void)hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)); }
         (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
-        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word);
+        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word); (void)hipFree(slot.device_worklist);
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
         if(slot.done) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.done)); }
@@ -69,6 +71,9 @@ void DecoderSet::release() {
     }
     for(void* p : device_allocation_) { (void)hipFree(p); }
     device_allocation_.clear();
+    (void)hipFree(device_worklist_);
+    device_worklist_ = nullptr;
+    worklist_capacity_ = 0;
     device_decoder_ = nullptr;
     device_stats_ = nullptr;
 }
@@ -102,6 +107,8 @@ void DecoderSet::build_device_images() {
 
     const PhredScale& scale = PhredScale::get_instance();
     const double* device_tpq = static_cast<const double*>(upload(scale.true_positive_quality, sizeof(scale.true_positive_quality)));
+    const double* device_match = static_cast<const double*>(upload(scale.match_probability, sizeof(scale.match_probability)));
+    const double* device_mismatch = static_cast<const double*>(upload(scale.mismatch_probability, sizeof(scale.mismatch_probability)));
 
     host_decoder_.assign(job_.decoder.size(), DevDecoder());
     for(size_t k = 0; k < job_.decoder.size(); ++k) {
@@ -130,6 +137,9 @@ void DecoderSet::build_device_images() {
         d.log2_base_lo = scale.log2_base_lo;
         d.stats_offset = c.stats_offset;
         d.true_positive_quality = device_tpq;
+        d.match_probability = device_match;
+        d.mismatch_probability = device_mismatch;
+        d.uniform_probability = scale.uniform_probability;
         if(c.closed()) {
             for(int32_t s = 0; s < c.segment_cardinality; ++s) {
                 d.distance_tolerance[s] = s < static_cast<int32_t>(c.distance_tolerance.size()) ? c.distance_tolerance[static_cast<size_t>(s)] : 0;
@@ -253,9 +263,37 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
     if(n_decoder == 0) {
         throw ConfigurationError("the job declares no decoder");
     }
+    uint32_t* worklist = nullptr;
+    if(needs_worklist()) {
+        if(worklist_capacity_ < n_read) {
+            // grown outside of any stream capture; sized for the worst case (every read deferred)
+            check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+            (void)hipFree(device_worklist_);
+            device_worklist_ = nullptr;
+            check(hipMalloc(reinterpret_cast<void**>(&device_worklist_), (static_cast<size_t>(n_read) + 4) * sizeof(uint32_t)), "hipMalloc");
+            worklist_capacity_ = n_read;
+        }
+        worklist = device_worklist_;
+    }
+    run_stages(batch_capacity, first_read, n_read, base_planes, quality_planes, flag, result, word, stream, worklist);
+}
+
+bool DecoderSet::needs_worklist() const {
+    for(const auto& d : host_decoder_) { if(stage_uses_worklist(d, mode_)) { return true; } }
+    return false;
+}
+
+// one launch (two in PHQ_MODE_FAST) per decoder, in TranscodingDecoder::classify order (transcode.h:51-60)
+void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                            const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                            DevResult* result, uint32_t* word, void* stream, uint32_t* worklist) {
+    const size_t n_decoder = job_.decoder.size();
     for(size_t k = 0; k < n_decoder; ++k) {
         const DecoderConfig& c = job_.decoder[k];
         StageArgs args;
+        std::memset(&args, 0, sizeof(args));
+        args.worklist_count = worklist;
+        args.worklist = worklist ? worklist + 4 : nullptr;
         args.decoder = device_decoder_ + k;
         args.n_read = n_read;
         args.base = c.plane_stride ? base_planes + batch_capacity * c.plane_prefix + first_read * c.plane_stride : nullptr;
@@ -275,7 +313,7 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
     for(auto& slot : slot_) {
         if(slot.stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)), "hipStreamSynchronize"); }
         (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
-        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word);
+        (void)hipFree(slot.device_result); (void)hipFree(slot.device_word); (void)hipFree(slot.device_worklist);
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
         const size_t planes = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
@@ -285,6 +323,7 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_flag), static_cast<size_t>(chunk_capacity)), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_result), results), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_word), static_cast<size_t>(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_worklist), (static_cast<size_t>(chunk_capacity) + 4) * sizeof(uint32_t)), "hipMalloc");
         slot.pinned_base = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_quality = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(chunk_capacity)));
@@ -348,8 +387,8 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
             std::memcpy(slot.pinned_flag, flag + first, static_cast<size_t>(count));
             check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
         }
-        classify_device(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
-                        slot.device_result, slot.device_word, stream);
+        run_stages(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
+                   slot.device_result, slot.device_word, stream, slot.device_worklist);
         for(const auto& c : job_.decoder) {
             if(c.result_slot >= 0 && result != nullptr) {
                 const int64_t plane = static_cast<int64_t>(c.result_slot) * chunk_capacity_;

@@ -51,6 +51,10 @@ public:
 
 private:
     void require_device() const;
+    void run_stages(int64_t batch_capacity, int64_t first_read, int64_t n_read,
+                    const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
+                    DevResult* result, uint32_t* word, void* stream, uint32_t* worklist);
+    bool needs_worklist() const;
     void build_device_images();
     void release();
     void ensure_pipeline(int64_t chunk_capacity);
@@ -63,6 +67,8 @@ private:
     DevDecoder* device_decoder_;                // device array, one per decoder
     std::vector<void*> device_allocation_;
     unsigned long long* device_stats_;
+    uint32_t* device_worklist_;                 // read ordinals deferred by the product form kernel + 1 counter word in front
+    int64_t worklist_capacity_;
     std::string report_;
 
     // host staged pipeline (classify_host): two slots of device buffers + pinned bounce buffers
@@ -77,6 +83,7 @@ private:
         uint8_t* pinned_flag = nullptr;
         DevResult* pinned_result = nullptr;
         uint32_t* pinned_word = nullptr;
+        uint32_t* device_worklist = nullptr;
         void* stream = nullptr;
         void* done = nullptr;                   // hipEvent_t recorded after the slot's last D2H
         bool busy = false;

@@ -69,6 +69,9 @@ struct DevDecoder {
     const double* concentration;          // n_barcode
     const int32_t* barcode_index;         // n_barcode
     const double* true_positive_quality;  // 128 entries, -10 log10(1 - 10^(-q/10)), [0] = 0   phred.cpp:34-38
+    const double* match_probability;      // 128 entries, pow(base, true_positive_quality[q]), [0] = 1
+    const double* mismatch_probability;   // 128 entries, pow(base, q), [0] = 1
+    double uniform_probability;           // pow(base, 10 log10 4) ~ 1/4
 };
 
 enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };
@@ -85,9 +88,16 @@ struct StageArgs {
     unsigned long long* stats;            // counter buffer
     int32_t first_stage;                  // initialise word from input_flag
     int32_t last_stage;                   // count outgoing reads (transcode.h:61-64)
+    // Two tier PAMLD (PHQ_MODE_FAST): the product form kernel appends the reads it cannot certify to
+    // `worklist` (read ordinals, *worklist_count entries); the literal kernel then visits exactly those.
+    uint32_t* worklist;
+    uint32_t* worklist_count;
+    int32_t worklist_role;                // 0 none, 1 producer, 2 consumer
+    int32_t reserved;
 };
 
 // implemented in the kernel translation units; all return a hipError_t value
 int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream);
+bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode);
 
 }  // namespace phq

@@ -39,14 +39,17 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
     const double uniform = d.uniform_base_quality;
     const double log2_base_hi = d.log2_base_hi;
     const double log2_base_lo = d.log2_base_lo;
-    const int64_t n = args.n_read;
+    // as the second tier of PHQ_MODE_FAST the kernel visits only the reads the product form kernel deferred
+    const bool consumer = args.worklist_role == 2;
+    const int64_t n = consumer ? static_cast<int64_t>(*args.worklist_count) : args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t i = tile * BLOCK + threadIdx.x;
-        const bool active = i < n;
+        const int64_t k = tile * BLOCK + threadIdx.x;
+        const bool active = k < n;
         ReadState r{false, 0};
         if(active) {
+            const int64_t i = consumer ? static_cast<int64_t>(args.worklist[k]) : k;
             r = load_read_state(args, i);
             uint8_t code[LP];
             uint8_t quality[LP];

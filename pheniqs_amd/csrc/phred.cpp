@@ -17,6 +17,14 @@ PhredScale::PhredScale() {
     for(int q = 1; q < 128; ++q) { false_positive_probability[q] = std::pow(phred_probability_base, q); }
     for(int q = 1; q < 128; ++q) { true_positive_probability[q] = 1.0 - false_positive_probability[q]; }
     for(int q = 1; q < 128; ++q) { true_positive_quality[q] = -10.0 * std::log10(true_positive_probability[q]); }
+    // per position factors of pow(base, sigma) = prod pow(base, cost): what the product form kernel multiplies
+    match_probability[0] = 1;
+    mismatch_probability[0] = 1;
+    for(int q = 1; q < 128; ++q) {
+        match_probability[q] = std::pow(phred_probability_base, true_positive_quality[q]);
+        mismatch_probability[q] = std::pow(phred_probability_base, static_cast<double>(q));
+    }
+    uniform_probability = std::pow(phred_probability_base, uniform_base_quality);
 }
 
 const PhredScale& PhredScale::get_instance() {

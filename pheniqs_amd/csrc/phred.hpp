@@ -19,6 +19,9 @@ struct PhredScale {
     double false_positive_probability[128];
     double true_positive_probability[128];
     double true_positive_quality[128];
+    double match_probability[128];          // pow(base, true_positive_quality[q]): P(observed | expected) for a match
+    double mismatch_probability[128];       // pow(base, q): for a mismatch between two ACGT bases
+    double uniform_probability;             // pow(base, uniform_base_quality): anything involving a base outside ACGT
     static const PhredScale& get_instance();
     double substitution_quality(uint8_t expected, uint8_t observed, uint8_t quality) const;   // phred.h:58-60
 private:

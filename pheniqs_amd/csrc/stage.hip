@@ -16,8 +16,11 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
     return launch_pamld_literal_l32(args, host_decoder, grid, lds_bytes, stream);
 }
 
+bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
+    return mode == MODE_FAST && host_decoder.algorithm == 1 && pamld_lut_supports(host_decoder);
+}
+
 int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream) {
-    (void)mode;
     if(args.n_read <= 0) { return static_cast<int>(hipSuccess); }
     const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
     const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
@@ -25,7 +28,20 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
         static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : 0));
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch(host_decoder.algorithm) {
-        case 1: return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+        case 1:
+            if(stage_uses_worklist(host_decoder, mode)) {
+                // tier 1: product form over every read, deferring the ambiguous ones; tier 2: the literal kernel on those
+                StageArgs producer = args;
+                producer.worklist_role = 1;
+                int status = static_cast<int>(hipMemsetAsync(args.worklist_count, 0, sizeof(uint32_t), s));
+                if(status != 0) { return status; }
+                status = launch_pamld_lut(producer, host_decoder, grid, histogram_bytes, s);
+                if(status != 0) { return status; }
+                StageArgs consumer = args;
+                consumer.worklist_role = 2;
+                return launch_pamld_literal(consumer, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+            }
+            return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
         case 2: return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
         default: return launch_count(args, host_decoder, grid, histogram_bytes, s);
     }

@@ -137,16 +137,33 @@ def test_bdggg_golden_through_the_gpu(oracle, torch_cuda):
 # ---- BASELINE configs at oracle-sized samples ---------------------------------------------------------------
 
 
+MODES = [capi.MODE_LITERAL, capi.MODE_FAST]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name,algorithm,n", [
     ("C2", "pamld", 1 << 16), ("C2", "mdd", 1 << 16),
     ("C3", "pamld", 3000), ("C3", "mdd", 1 << 14),
     ("C4", "pamld", 1 << 14), ("C4", "mdd", 1 << 14),
     ("C5", "pamld", 1 << 14), ("C5", "mdd", 1 << 14),
 ])
-def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n):
+def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n, mode):
+    if algorithm == "mdd" and mode == capi.MODE_FAST:
+        pytest.skip("MDD has a single kernel")
     job, recipe = synthetic.config_job(name, algorithm)
     code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
-    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+
+
+def test_fast_mode_defers_only_a_small_fraction(oracle, torch_cuda):
+    """The product form kernel finishes the clean reads itself; the worklist holds the ambiguous rest."""
+    job, recipe = synthetic.config_job("C2")
+    n = 1 << 18
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
+    confidence = got[0]["confidence"]
+    ambiguous = float(((confidence < 0.8) | (got[0]["status"] == 2)).mean())
+    assert ambiguous < 0.05
 
 
 # ---- edge cases the reference's tests do not pin (SURVEY.md §4 gaps, §8a S1-S10) ------------------------------
@@ -161,21 +178,24 @@ def _small_job(algorithm="pamld", **extra):
     return jobspec.compile_job(spec)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("n", [0, 1, 63, 64, 255, 256, 257, 1000])
-def test_empty_and_ragged_batches(oracle, torch_cuda, n):
+def test_empty_and_ragged_batches(oracle, torch_cuda, n, mode):
     job, recipe = synthetic.config_job("C2")
     code, quality, flag, offsets = synthetic.generate_rows(job, n, 99)
-    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
 
 
-def test_split_ranges_equal_one_call(oracle, torch_cuda):
+@pytest.mark.parametrize("mode", MODES)
+def test_split_ranges_equal_one_call(oracle, torch_cuda, mode):
     job, recipe = synthetic.config_job("C5")
     code, quality, flag, offsets = synthetic.generate_rows(job, 5003, 5)
-    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=7)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=7, mode=mode)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
-def test_unknown_bases_zero_quality_and_short_observations(oracle, torch_cuda, algorithm):
+def test_unknown_bases_zero_quality_and_short_observations(oracle, torch_cuda, algorithm, mode):
     job = _small_job(algorithm)
     rng = np.random.default_rng(11)
     n = 4096
@@ -192,10 +212,11 @@ def test_unknown_bases_zero_quality_and_short_observations(oracle, torch_cuda, a
     quality[21] = 127
     quality[22] = 255       # BAM "missing" quality: masked to the table's 128 rows
     flag = (rng.random(n) < 0.2).astype(np.uint8)
-    assert_parity(oracle, torch_cuda, job, code, quality, flag, [0])
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, [0], mode=mode)
 
 
-def test_ties_keep_the_lowest_index(oracle, torch_cuda):
+@pytest.mark.parametrize("mode", MODES)
+def test_ties_keep_the_lowest_index(oracle, torch_cuda, mode):
     """strict '>' from zero.  Uniform priors, uniform qualities: equidistant barcodes tie exactly."""
     words = ["AAAAAAAA", "AAAACCCC", "CCCCAAAA", "CCCCCCCC", "GGGGGGGG", "TTTTTTTT"]
     spec = {"input segment cardinality": 1,
@@ -209,7 +230,7 @@ def test_ties_keep_the_lowest_index(oracle, torch_cuda):
     code[:64] = letters[np.array([0, 0, 1, 1, 0, 0, 1, 1])]            # AACCAACC: distance 4 to four barcodes
     quality = np.full((n, 8), 30, dtype=np.uint8)
     quality[64:] = np.array([37, 25, 12, 2], dtype=np.uint8)[rng.integers(0, 4, size=(n - 64, 8))]
-    s, engine, got, _ = assert_parity(oracle, torch_cuda, job, code, quality, None, [0])
+    s, engine, got, _ = assert_parity(oracle, torch_cuda, job, code, quality, None, [0], mode=mode)
     assert set(got[0]["index"][:64]) <= {0, 1}
 
 
@@ -223,7 +244,8 @@ def test_iupac_barcodes_take_the_uniform_branch(oracle, torch_cuda):
     n = 4096
     code = np.array([1, 2, 4, 8, 15], dtype=np.uint8)[rng.integers(0, 5, size=(n, 6))]
     quality = rng.integers(0, 42, size=(n, 6)).astype(np.uint8)
-    assert_parity(oracle, torch_cuda, job, code, quality, None, [0])
+    assert_parity(oracle, torch_cuda, job, code, quality, None, [0], mode=capi.MODE_LITERAL)
+    assert_parity(oracle, torch_cuda, job, code, quality, None, [0], mode=capi.MODE_FAST)      # falls back to the literal kernel
 
 
 def test_mdd_masking_tolerances_and_segments(oracle, torch_cuda):
@@ -262,12 +284,14 @@ def test_decoder_chain_sticky_qcfail_and_passthrough(oracle, torch_cuda):
     job = jobspec.compile_job({k: v for k, v in spec.items()})
     code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 14, 21)
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
 
 
 # ---- properties at BASELINE.json's full size -----------------------------------------------------------------
 
 
-def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda):
+@pytest.mark.parametrize("mode", MODES)
+def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda, mode):
     """100 M reads (config C2) built by tiling a pool the oracle can decode in seconds: every counter must be
     exactly `tiles` times the pool's, and every result record equal to the pool's record."""
     torch = torch_cuda
@@ -277,6 +301,7 @@ def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda)
     engine = oracle.OracleJob(job)
     expected, expected_word = engine.classify(code, quality, flag)
     s = DecoderSet(job, device=0)
+    s.set_mode(mode)
     n = pool_n * tiles
     base = torch.from_numpy(s.planes_from_rows(code, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
     qual = torch.from_numpy(s.planes_from_rows(quality, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
@@ -300,8 +325,9 @@ def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda)
     assert bool((word.view(tiles, pool_n) == word.view(tiles, pool_n)[0]).all())
 
 
-def test_classify_host_equals_classify_device(oracle, torch_cuda):
-    job, recipe = synthetic.config_job("C4")
+@pytest.mark.parametrize("mode", MODES)
+def test_classify_host_equals_classify_device(oracle, torch_cuda, mode):
+    job, recipe = synthetic.config_job("C5")
     n = (1 << 22) + 12345                                              # more than one pipeline chunk
     pool = 1 << 15
     code, quality, flag, offsets = synthetic.generate_rows(job, pool, 77)
@@ -310,6 +336,7 @@ def test_classify_host_equals_classify_device(oracle, torch_cuda):
     reps = -(-n // pool)
     code = np.tile(code, (reps, 1))[:n]; quality = np.tile(quality, (reps, 1))[:n]; flag = np.tile(flag, reps)[:n]
     s = DecoderSet(job, device=0)
+    s.set_mode(mode)
     result, word = s.classify_host(n, s.planes_from_rows(code, offsets), s.planes_from_rows(quality, offsets), flag)
     index = np.arange(n) % pool
     for slot in range(s.n_result):
