@@ -162,6 +162,8 @@ void DecoderSet::build_device_images() {
                 concentration[static_cast<size_t>(b)] = c.codec[static_cast<size_t>(b)].concentration;
                 index[static_cast<size_t>(b)] = c.codec[static_cast<size_t>(b)].index;
             }
+            d.uniform_prior = 1;
+            for(double c0 : concentration) { if(c0 != concentration[0]) { d.uniform_prior = 0; } }
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));
@@ -270,12 +272,20 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
             check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
             (void)hipFree(device_worklist_);
             device_worklist_ = nullptr;
-            check(hipMalloc(reinterpret_cast<void**>(&device_worklist_), (static_cast<size_t>(n_read) + 4) * sizeof(uint32_t)), "hipMalloc");
+            check(hipMalloc(reinterpret_cast<void**>(&device_worklist_), worklist_words(n_read) * sizeof(uint32_t)), "hipMalloc");
             worklist_capacity_ = n_read;
         }
         worklist = device_worklist_;
     }
     run_stages(batch_capacity, first_read, n_read, base_planes, quality_planes, flag, result, word, stream, worklist);
+}
+
+// counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
+size_t DecoderSet::worklist_words(int64_t n_read) const {
+    const int64_t tiles = (n_read + 255) / 256;
+    const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
+    const int64_t tiles_per_block = (tiles + grid - 1) / grid;
+    return static_cast<size_t>(max_blocks_) + static_cast<size_t>(grid * tiles_per_block * 256) + 256;
 }
 
 bool DecoderSet::needs_worklist() const {
@@ -292,8 +302,8 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         const DecoderConfig& c = job_.decoder[k];
         StageArgs args;
         std::memset(&args, 0, sizeof(args));
-        args.worklist_count = worklist;
-        args.worklist = worklist ? worklist + 4 : nullptr;
+        args.worklist_count = worklist;                                   // one counter per workgroup ...
+        args.worklist = worklist ? worklist + max_blocks_ : nullptr;      // ... then one segment per workgroup
         args.decoder = device_decoder_ + k;
         args.n_read = n_read;
         args.base = c.plane_stride ? base_planes + batch_capacity * c.plane_prefix + first_read * c.plane_stride : nullptr;
@@ -323,7 +333,7 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_flag), static_cast<size_t>(chunk_capacity)), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_result), results), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_word), static_cast<size_t>(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
-        check(hipMalloc(reinterpret_cast<void**>(&slot.device_worklist), (static_cast<size_t>(chunk_capacity) + 4) * sizeof(uint32_t)), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_worklist), worklist_words(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
         slot.pinned_base = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_quality = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(chunk_capacity)));

@@ -55,6 +55,7 @@ private:
                     const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                     DevResult* result, uint32_t* word, void* stream, uint32_t* worklist);
     bool needs_worklist() const;
+    size_t worklist_words(int64_t n_read) const;
     void build_device_images();
     void release();
     void ensure_pipeline(int64_t chunk_capacity);

@@ -54,7 +54,7 @@ struct DevDecoder {
     int32_t quality_masking_threshold;
     int32_t use_lds_histogram;            // bins fit in LDS: workgroup histogram, else global atomics
     uint32_t segment_end_bits;            // bit j set when position j is the last of its segment
-    int32_t reserved;
+    int32_t uniform_prior;                // every concentration is the same double
     int32_t distance_tolerance[DEV_MAX_SEGMENT];
     uint32_t segment_mask[DEV_MAX_SEGMENT][DEV_MAX_WORD];   // nibble flags (bit 4*(j%8) of word j/8) per segment
     uint32_t full_mask[DEV_MAX_WORD];     // nibble flags of every position
@@ -88,12 +88,14 @@ struct StageArgs {
     unsigned long long* stats;            // counter buffer
     int32_t first_stage;                  // initialise word from input_flag
     int32_t last_stage;                   // count outgoing reads (transcode.h:61-64)
-    // Two tier PAMLD (PHQ_MODE_FAST): the product form kernel appends the reads it cannot certify to
-    // `worklist` (read ordinals, *worklist_count entries); the literal kernel then visits exactly those.
+    // Two tier PAMLD (PHQ_MODE_FAST): workgroup g of the product form kernel appends the reads it cannot
+    // certify to its own segment worklist[g * worklist_stride ...] and leaves their number in
+    // worklist_count[g]; workgroup g of the literal kernel (same grid) then visits exactly those.
+    // No global atomic: one shared counter saturates at ~88 increments per microsecond on this part.
     uint32_t* worklist;
     uint32_t* worklist_count;
     int32_t worklist_role;                // 0 none, 1 producer, 2 consumer
-    int32_t reserved;
+    int32_t worklist_stride;
 };
 
 // implemented in the kernel translation units; all return a hipError_t value

@@ -116,8 +116,9 @@ __device__ __forceinline__ void histogram_flush(const StageArgs& args, DecoderRe
     }
 }
 
+// A, C, G or T: BAM codes 1, 2, 4, 8 (iupac.h:51-56); branch free, bit c of 0b1_0001_0110
 __device__ __forceinline__ bool strict_code(uint32_t c) {
-    return (c == 1) | (c == 2) | (c == 4) | (c == 8);
+    return ((0x116u >> (c & 0xfu)) & 1u) != 0;
 }
 
 // pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * log2(base)), base being the

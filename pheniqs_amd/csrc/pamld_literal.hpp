@@ -39,17 +39,21 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
     const double uniform = d.uniform_base_quality;
     const double log2_base_hi = d.log2_base_hi;
     const double log2_base_lo = d.log2_base_lo;
-    // as the second tier of PHQ_MODE_FAST the kernel visits only the reads the product form kernel deferred
+    // as the second tier of PHQ_MODE_FAST workgroup g visits only the reads workgroup g of the product form
+    // kernel deferred (same grid): its segment of the worklist, worklist_count[g] entries
     const bool consumer = args.worklist_role == 2;
-    const int64_t n = consumer ? static_cast<int64_t>(*args.worklist_count) : args.n_read;
+    const uint32_t* const segment = consumer ? args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride : nullptr;
+    const int64_t n = consumer ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
+    const int64_t tile_first = consumer ? 0 : blockIdx.x;
+    const int64_t tile_step = consumer ? 1 : gridDim.x;
 
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for(int64_t tile = tile_first; tile < tiles; tile += tile_step) {
         const int64_t k = tile * BLOCK + threadIdx.x;
         const bool active = k < n;
         ReadState r{false, 0};
         if(active) {
-            const int64_t i = consumer ? static_cast<int64_t>(args.worklist[k]) : k;
+            const int64_t i = consumer ? static_cast<int64_t>(segment[k]) : k;
             r = load_read_state(args, i);
             uint8_t code[LP];
             uint8_t quality[LP];

@@ -10,11 +10,16 @@
 //   * accumulates sum_b P(r|b) concentration_b and the argmax in fp64.
 // No exp, no Kahan chain: ~16 VALU instructions per (read, barcode) instead of ~75.
 //
-// The result differs from the reference's arithmetic by ~L ulp, far inside the 1e-6 posterior contract, but
-// the reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
-// (pamld_literal.hpp).  A read is therefore only finished here when its winner leads every other barcode by
-// 4x or more and no filter decision is within 1e-9 of its threshold; every other read (noise reads, ambiguous
-// reads: ~1-2 %) is appended to a worklist that the literal kernel decodes right after, on the same stream.
+// The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
+// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-12).  So a read is only FINISHED in
+// this kernel when its winner dominates: the summed probability of every other barcode is at most 2e-6 of the
+// winner's.  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single precision
+// — their ~1e-6 relative error moves the posterior by at most 2e-6 * 1e-6 — while the winner's own probability
+// and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and confidence
+// filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  Every other read (noise
+// reads, reads with a second plausible barcode: a few %) is appended to a worklist that the literal kernel
+// decodes right after, on the same stream.  Single precision tables halve the LDS per workgroup (33 KiB for
+// 8 nt) which doubles the resident waves; the kernel is bound by VALU issue, not by LDS or HBM.
 #include "kernel_common.hpp"
 
 namespace phq {
@@ -29,41 +34,47 @@ __device__ __forceinline__ uint32_t nibble_flags(uint32_t x) {
 
 // Four flags at bits 0,4,8,12 of a 16-bit half word -> a 4-bit index at bits 11..14, by one multiply:
 // 0x924 = 2^11 + 2^8 + 2^5 + 2^2 moves flag k (bit 4k) to bit 11 + k; no two partial products meet.
-constexpr uint32_t GATHER = 0x924u;
-constexpr uint32_t INDEX_MASK = 0x7800u;      // bits 11..14 = table entry * 2048 bytes (256 lanes * 8 bytes)
+// Four flags at bits 0,4,8,12 -> a 4-bit index at bits 10..13 (table entry * 1024 bytes = 256 lanes * 4 bytes)
+constexpr uint32_t GATHER = 0x492u;           // 2^10 + 2^7 + 2^4 + 2^1
+constexpr uint32_t INDEX_MASK = 0x3c00u;
+constexpr double DOMINANCE = 1e-4;            // others <= DOMINANCE * winner, see the header
 
-template <int L>
+template <int L, bool UNIFORM_PRIOR>
 __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
     constexpr int G = (L + 3) / 4;            // groups of 4 positions
     constexpr int LP = (L + 3) / 4 * 4;
     static_assert(L <= 16, "one or two packed words");
+    // static LDS (addresses are compile time constants, so table reads need no base add): the tables and the
+    // two fp64 factor columns; dynamic LDS: the counter histogram, sized per decoder
+    __shared__ float table[G * 16 * BLOCK];                                   // [G * 16][BLOCK]
+    __shared__ double match_probability[128];
+    __shared__ double mismatch_probability[128];
+    __shared__ uint32_t deferred_total;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double* match_probability = reinterpret_cast<double*>(lds_raw);
-    double* mismatch_probability = match_probability + 128;
-    double* table = mismatch_probability + 128;                               // [G * 16][BLOCK]
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(table + G * 16 * BLOCK);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
 
     for(int i = threadIdx.x; i < 128; i += BLOCK) {
         match_probability[i] = d.match_probability[i];
         mismatch_probability[i] = d.mismatch_probability[i];
     }
+    if(threadIdx.x == 0) { deferred_total = 0; }
     histogram_clear(d, histogram);
     __syncthreads();
 
     const StatSink sink{histogram, args.stats};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
     const PHQ_CONSTANT double* concentration = constant_cast(d.concentration);
     const int n_barcode = d.n_barcode;
-    const int n_word = d.n_word;
+    constexpr int W = (G + 1) / 2;            // packed words per barcode
     const double uniform_probability = d.uniform_probability;
     const int64_t n = args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
-    // byte offsets from the start of LDS, so that the compiler folds the constant part into the DS offset field
-    constexpr uint32_t TABLE_BASE = 256 * sizeof(double);
-    constexpr uint32_t GROUP_BYTES = 16 * BLOCK * sizeof(double);
-    constexpr uint32_t ENTRY_BYTES = BLOCK * sizeof(double);
-    const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(double));
+    constexpr uint32_t GROUP_BYTES = 16 * BLOCK * sizeof(float);
+    constexpr uint32_t ENTRY_BYTES = BLOCK * sizeof(float);
+    const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
+    const float prior = UNIFORM_PRIOR ? static_cast<float>(concentration[0]) : 1.0f;
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t i = tile * BLOCK + threadIdx.x;
@@ -78,18 +89,22 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
             load_plane_row<L>(args.quality, i, quality);
 
             // per position factors, the packed observation and the high quality flags
-            double fm[L];
-            double fe[L];
-            uint32_t observed[2] = {0, 0};
-            uint32_t high_quality[2] = {0, 0};
+            float fm[L];
+            float fe[L];
+            uint32_t observed[W];
+            uint32_t high_quality[W];
+#pragma unroll
+            for(int w = 0; w < W; ++w) { observed[w] = 0; high_quality[w] = 0; }
 #pragma unroll
             for(int j = 0; j < L; ++j) {
                 const uint32_t c = code[j];
                 const uint32_t q = quality[j] & 0x7fu;
                 const double u = q ? uniform_probability : 1.0;
                 const bool strict = strict_code(c);
-                fm[j] = strict ? match_probability[q] : u;
-                fe[j] = strict ? mismatch_probability[q] : u;
+                const double m = match_probability[q];
+                const double e = mismatch_probability[q];
+                fm[j] = static_cast<float>(strict ? m : u);
+                fe[j] = static_cast<float>(strict ? e : u);
                 observed[j >> 3] |= (c & 0xfu) << (4 * (j & 7));
                 if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality[j >> 3] |= 1u << (4 * (j & 7)); }
             }
@@ -98,73 +113,81 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
             for(int g = 0; g < G; ++g) {
                 constexpr int FULL = 4;
                 const int base = 4 * g;
-                double lo[4];
-                double hi[4];
+                float lo[4];
+                float hi[4];
                 lo[0] = fm[base];
                 lo[1] = fe[base];
                 lo[2] = lo[0];
                 lo[3] = lo[1];
                 if(base + 1 < L) { lo[0] *= fm[base + 1]; lo[1] *= fm[base + 1]; lo[2] *= fe[base + 1]; lo[3] *= fe[base + 1]; }
-                hi[0] = hi[1] = hi[2] = hi[3] = 1.0;
+                hi[0] = hi[1] = hi[2] = hi[3] = 1.0f;
                 if(base + 2 < L) { hi[0] = fm[base + 2]; hi[1] = fe[base + 2]; hi[2] = hi[0]; hi[3] = hi[1]; }
                 if(base + 3 < L) { hi[0] *= fm[base + 3]; hi[1] *= fm[base + 3]; hi[2] *= fe[base + 3]; hi[3] *= fe[base + 3]; }
                 (void)FULL;
 #pragma unroll
                 for(int m = 0; m < 16; ++m) {
-                    *reinterpret_cast<double*>(lds_raw + TABLE_BASE + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
                 }
             }
 
-            double sigma_p = 0;
-            double best_p = 0;
+            // single precision scan: the maximum, where it is, and the sum of everything BUT the maximum (summing
+            // it apart keeps the small remainder from being rounded away against the winner)
+            float sigma = 0;
+            float best_value = 0;
             int best = -1;
 #pragma unroll 4
             for(int b = 0; b < n_barcode; ++b) {
-                double conditional = 1.0;
+                float conditional = 1.0f;
 #pragma unroll
-                for(int w = 0; w < (G + 1) / 2; ++w) {
-                    const uint32_t flags = nibble_flags(observed[w] ^ packed[b * n_word + w]);
-                    const uint32_t low = __umul24(flags, GATHER) & INDEX_MASK;        // flags 4 and 5 land above bit 14
-                    const double a = *reinterpret_cast<const double*>(lds_raw + TABLE_BASE + (2 * w) * GROUP_BYTES + (low | lane_offset));
+                for(int w = 0; w < W; ++w) {
+                    const uint32_t flags = nibble_flags(observed[w] ^ packed[b * W + w]);
+                    const uint32_t low = __umul24(flags, GATHER) & INDEX_MASK;        // flags 4 and 5 land above bit 13
+                    const float a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (2 * w) * GROUP_BYTES + (low | lane_offset));
                     conditional = (w == 0) ? a : conditional * a;
                     if(2 * w + 1 < G) {
                         const uint32_t high = __umul24(flags >> 16, GATHER) & INDEX_MASK;
-                        conditional *= *reinterpret_cast<const double*>(lds_raw + TABLE_BASE + (2 * w + 1) * GROUP_BYTES + (high | lane_offset));
+                        conditional *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (2 * w + 1) * GROUP_BYTES + (high | lane_offset));
                     }
                 }
-                const double p = conditional * concentration[b];
-                sigma_p += p;
-                if(p > best_p) {
-                    best = b;
-                    best_p = p;
-                }
+                const float p = UNIFORM_PRIOR ? conditional : conditional * static_cast<float>(concentration[b]);
+                sigma += fminf(p, best_value);
+                if(p > best_value) { best = b; }
+                best_value = fmaxf(p, best_value);
             }
 
             if(best < 0) {
                 defer = true;
             } else {
-                // the winner's mask, distances and conditional probability (fp64 product of its own factors)
-                uint32_t flags[2] = {0, 0};
+                // the winner's mask, its distances, and its probability again in fp64 from the fp64 factors
+                uint32_t flags[W];
                 int distance = 0;
                 int hq_distance = 0;
 #pragma unroll
-                for(int w = 0; w < (G + 1) / 2; ++w) {
-                    flags[w] = nibble_flags(observed[w] ^ d.barcode_packed[static_cast<int64_t>(best) * n_word + w]) & d.full_mask[w];
+                for(int w = 0; w < W; ++w) {
+                    flags[w] = nibble_flags(observed[w] ^ d.barcode_packed[static_cast<int64_t>(best) * W + w]) & d.full_mask[w];
                     distance += __popc(flags[w]);
                     hq_distance += __popc(flags[w] & high_quality[w]);
                 }
                 double best_conditional = 1.0;
 #pragma unroll
                 for(int j = 0; j < L; ++j) {
-                    best_conditional *= ((flags[j >> 3] >> (4 * (j & 7))) & 1u) ? fe[j] : fm[j];
+                    const uint32_t c = code[j];
+                    const uint32_t q = quality[j] & 0x7fu;
+                    const double u = q ? uniform_probability : 1.0;
+                    const bool mismatch = ((flags[j >> 3] >> (4 * (j & 7))) & 1u) != 0;
+                    const double m = match_probability[q];
+                    const double e = mismatch_probability[q];
+                    best_conditional *= strict_code(c) ? (mismatch ? e : m) : u;
                 }
-                const double total = sigma_p + d.adjusted_noise_probability;          // pamld.cpp:83-86
+                const double best_p = best_conditional * concentration[best];
+                // everything but the winner, in units of p: only ever compared against and added to much larger terms
+                const double others = static_cast<double>(sigma) * static_cast<double>(prior);
+                const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
                 double confidence = best_p / total;                                       // pamld.cpp:92
-                const double others = sigma_p - best_p;
                 const double noise_margin = best_conditional - d.random_barcode_probability;
                 const double confidence_margin = confidence - d.confidence_threshold;
-                // certificate: a clear winner and no decision within 1e-9 (relative) of its threshold
-                defer = !(others < 0.25 * best_p)
+                // certificate: a dominant winner and no decision within 1e-9 (relative) of its threshold
+                defer = !(others <= DOMINANCE * best_p)
                      || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
                      || !(fabs(confidence_margin) > 1e-9);
                 if(!defer) {
@@ -205,21 +228,28 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                 }
             }
         }
-        // deferred reads: one atomic per wave reserves a run of worklist slots
+        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
         const unsigned long long deferred = __ballot(active && defer);
         if(deferred) {
             const int lane = threadIdx.x & 63;
             uint32_t first = 0;
-            if(lane == 0) { first = atomicAdd(args.worklist_count, static_cast<uint32_t>(__popcll(deferred))); }
+            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
             first = __shfl(first, 0);
             if(active && defer) {
-                args.worklist[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
             }
         }
         count_outgoing(args, histogram, active && !defer, r);
     }
     __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
     histogram_flush(args, d, histogram);
+}
+
+template <int L, bool UNIFORM_PRIOR>
+int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(BLOCK), histogram_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
 }
 
 template <int LO, int HI>
@@ -229,16 +259,8 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            constexpr int G = (LO + 3) / 4;
-            const size_t lds_bytes = (256 + static_cast<size_t>(G) * 16 * BLOCK) * sizeof(double) + histogram_bytes;
-            static bool configured = false;
-            if(!configured) {
-                // more than the default 64 KiB of dynamic LDS for the longer barcodes
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_lut_kernel<LO>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                configured = true;
-            }
-            hipLaunchKernelGGL((pamld_lut_kernel<LO>), grid, dim3(BLOCK), lds_bytes, stream, args);
-            return static_cast<int>(hipGetLastError());
+            return host_decoder.uniform_prior ? launch_one<LO, true>(args, grid, histogram_bytes, stream)
+                                              : launch_one<LO, false>(args, grid, histogram_bytes, stream);
         }
         return launch_range<LO + 1, HI>(args, host_decoder, grid, histogram_bytes, stream);
     }
@@ -247,12 +269,12 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
 }  // namespace
 
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
-    return host_decoder.all_strict && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 12 &&
+    return host_decoder.all_strict && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
            host_decoder.n_barcode > 0;
 }
 
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    return launch_range<1, 12>(args, host_decoder, grid, histogram_bytes, stream);
+    return launch_range<1, 16>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 }  // namespace phq

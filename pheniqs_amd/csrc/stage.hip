@@ -31,13 +31,14 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
         case 1:
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: product form over every read, deferring the ambiguous ones; tier 2: the literal kernel on those
+                // both launches use the same grid: literal workgroup g consumes what product form workgroup g deferred
+                const int64_t tiles_per_block = (tiles + grid.x - 1) / grid.x;
                 StageArgs producer = args;
                 producer.worklist_role = 1;
-                int status = static_cast<int>(hipMemsetAsync(args.worklist_count, 0, sizeof(uint32_t), s));
+                producer.worklist_stride = static_cast<int32_t>(tiles_per_block * BLOCK);
+                int status = launch_pamld_lut(producer, host_decoder, grid, histogram_bytes, s);
                 if(status != 0) { return status; }
-                status = launch_pamld_lut(producer, host_decoder, grid, histogram_bytes, s);
-                if(status != 0) { return status; }
-                StageArgs consumer = args;
+                StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 return launch_pamld_literal(consumer, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }

@@ -16,7 +16,10 @@ from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, jobspec, synthetic
 pytestmark = pytest.mark.gpu
 
 POSTERIOR_TOLERANCE = 1e-6        # the contract
-POSTERIOR_DESIGN_TOLERANCE = 1e-12
+# what the kernels are designed to hold: the literal kernel differs from the oracle only through its 2^x
+# (~1e-16); the product form kernel finishes a read only when everything but the winner weighs < 1e-4 of it,
+# and sums that remainder in single precision (relative error ~5e-7): 1e-4 * 5e-7 = 5e-11
+POSTERIOR_DESIGN_TOLERANCE = {capi.MODE_LITERAL: 1e-12, capi.MODE_FAST: 1e-10}
 INTEGER_FIELDS = ("index", "distance", "hq_distance", "status", "qcfail")
 INTEGER_COUNTERS = ("count", "pf_count", "accumulated_distance", "accumulated_pf_distance",
                     "low_conditional_confidence_count", "low_confidence_count")
@@ -61,7 +64,7 @@ def assert_parity(oracle, torch, job, code, quality, flag, offsets, **kwargs):
         if n:
             delta = np.abs(got[slot]["confidence"] - expected[:, slot]["confidence"]).max()
             assert delta < POSTERIOR_TOLERANCE
-            assert delta < POSTERIOR_DESIGN_TOLERANCE
+            assert delta < POSTERIOR_DESIGN_TOLERANCE[kwargs.get("mode", capi.MODE_LITERAL)], delta
     assert np.array_equal(word, expected_word)
     count, pf_count = engine.outgoing()
     assert (int(words[0] + words[1]), int(words[1])) == (count, pf_count)
@@ -69,8 +72,9 @@ def assert_parity(oracle, torch, job, code, quality, flag, offsets, **kwargs):
         mine, theirs = s.stats_options(words, k), engine.options(k)
         for name in INTEGER_COUNTERS:
             assert np.array_equal(mine[name], theirs[name]), (k, name)
+        tolerance = 1e-12 if kwargs.get("mode", capi.MODE_LITERAL) == capi.MODE_LITERAL else 1e-10
         for name in ("accumulated_confidence", "accumulated_pf_confidence"):
-            assert np.allclose(mine[name], theirs[name], rtol=1e-12, atol=1e-12), (k, name)
+            assert np.allclose(mine[name], theirs[name], rtol=tolerance, atol=tolerance), (k, name)
     return s, engine, got, words
 
 
@@ -321,7 +325,7 @@ def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda,
     first = records[0].cpu().numpy().view(RESULT_DTYPE)
     for name in INTEGER_FIELDS:
         assert np.array_equal(first[name], expected[:, 0][name]), name
-    assert np.abs(first["confidence"] - expected[:, 0]["confidence"]).max() < POSTERIOR_DESIGN_TOLERANCE
+    assert np.abs(first["confidence"] - expected[:, 0]["confidence"]).max() < POSTERIOR_DESIGN_TOLERANCE[mode]
     assert bool((word.view(tiles, pool_n) == word.view(tiles, pool_n)[0]).all())
 
 
