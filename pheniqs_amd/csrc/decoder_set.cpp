@@ -167,6 +167,26 @@ void DecoderSet::build_device_images() {
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));
+            if(c.all_strict && c.nucleotide_cardinality <= 16 && d.n_barcode > 0) {
+                const int32_t padded = (d.n_barcode + 3) / 4 * 4;
+                const bool paired = c.nucleotide_cardinality <= 8;
+                std::vector<uint32_t> packed2(static_cast<size_t>(paired ? padded / 2 : padded), 0);
+                std::vector<float> prior(static_cast<size_t>(padded), 0.0f);
+                for(int32_t b = 0; b < padded; ++b) {
+                    const int32_t source = b < d.n_barcode ? b : 0;          // padding repeats barcode 0; its probability is zeroed
+                    uint32_t word = 0;
+                    for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(source) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        word |= two << (2 * j);
+                    }
+                    if(paired) { packed2[static_cast<size_t>(b >> 1)] |= word << (16 * (b & 1)); }
+                    else { packed2[static_cast<size_t>(b)] = word; }
+                    if(b < d.n_barcode) { prior[static_cast<size_t>(b)] = static_cast<float>(concentration[static_cast<size_t>(b)]); }
+                }
+                d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
+                d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
+            }
         }
     }
     device_decoder_ = static_cast<DevDecoder*>(upload(host_decoder_.data(), host_decoder_.size() * sizeof(DevDecoder)));

@@ -5,58 +5,67 @@
 // ACGT; 1 for q = 0) — reference phred.cpp:44-68, barcode.h:151-163.  So P(r|b) is a product of L factors
 // selected by the mismatch mask of (read, barcode).  The kernel
 //   * builds, per read, one 16 entry table per group of 4 positions (every product of 4 factors), in LDS;
-//   * gets a barcode's mismatch mask with XOR + nibble fold on 4-bit packed bases (scalar barcode operand),
-//     turns each 4 flag group into a table index with one 24-bit multiply, and multiplies the G table entries;
-//   * accumulates sum_b P(r|b) concentration_b and the argmax in fp64.
-// No exp, no Kahan chain: ~16 VALU instructions per (read, barcode) instead of ~75.
+//   * gets mismatch masks with XOR + three fold steps on 2-bit packed bases (scalar barcode operand; for
+//     barcodes of up to 8 nt one 32-bit word carries TWO barcodes), which leaves each group's 4-bit table
+//     index in its own byte, already scaled; one AND-OR makes the LDS address;
+//   * multiplies the G table entries, and folds four barcodes at a time into max / sum / "which group".
+// No exp, no Kahan chain: ~10 VALU instructions per (read, barcode) instead of ~75.  Every VALU instruction
+// costs one quad-cycle on this part whatever its type, so instruction count is the metric.
 //
 // The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
-// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-12).  So a read is only FINISHED in
-// this kernel when its winner dominates: the summed probability of every other barcode is at most 2e-6 of the
-// winner's.  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single precision
-// — their ~1e-6 relative error moves the posterior by at most 2e-6 * 1e-6 — while the winner's own probability
-// and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and confidence
-// filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  Every other read (noise
-// reads, reads with a second plausible barcode: a few %) is appended to a worklist that the literal kernel
-// decodes right after, on the same stream.  Single precision tables halve the LDS per workgroup (33 KiB for
-// 8 nt) which doubles the resident waves; the kernel is bound by VALU issue, not by LDS or HBM.
+// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-9).  So a read is only FINISHED in
+// this kernel when its winner dominates: the summed probability of every other barcode is at most 1e-3 of the
+// winner's (DOMINANCE).  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single
+// precision — their ~5e-7 relative error moves the posterior by at most DOMINANCE * 5e-7 — while the winner's own
+// probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
+// confidence filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  Every other read
+// (noise reads, reads with a second plausible barcode: ~2 %) is appended to a worklist that the literal kernel
+// decodes right after, on the same stream.
 #include "kernel_common.hpp"
 
 namespace phq {
 namespace {
 
-// bit 4k of the result is set when nibble k of x is non zero
-__device__ __forceinline__ uint32_t nibble_flags(uint32_t x) {
-    x |= x >> 1;
-    x |= x >> 2;
-    return x & 0x11111111u;
-}
+constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner, see the header
+constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 
-// Four flags at bits 0,4,8,12 of a 16-bit half word -> a 4-bit index at bits 11..14, by one multiply:
-// 0x924 = 2^11 + 2^8 + 2^5 + 2^2 moves flag k (bit 4k) to bit 11 + k; no two partial products meet.
-// Four flags at bits 0,4,8,12 -> a 4-bit index at bits 10..13 (table entry * 1024 bytes = 256 lanes * 4 bytes)
-constexpr uint32_t GATHER = 0x492u;           // 2^10 + 2^7 + 2^4 + 2^1
-constexpr uint32_t INDEX_MASK = 0x3c00u;
-constexpr double DOMINANCE = 1e-4;            // others <= DOMINANCE * winner, see the header
+// flags at the even bits of x: bit 2j set when the 2-bit field j of x is non zero
+__device__ __forceinline__ uint32_t field_flags(uint32_t x) {
+    return (x | (x >> 1)) & 0x55555555u;
+}
+// Even-bit flags -> per byte, bits 2..5 = the four flags of the byte's positions (table index * 4).
+// With [index][lane] tables of 256 lanes * 4 bytes, byte 1 of the result is directly index * 1024.
+__device__ __forceinline__ uint32_t group_fields(uint32_t flags) {
+    uint32_t pairs = (flags | (flags >> 1)) & 0x33333333u;            // nibble n: bits 0,1 = flags of positions 2n, 2n+1
+    // keep the compiler from proving the two operands disjoint and turning the OR into a quarter rate `* 5`
+    asm volatile("" : "+v"(pairs));
+    return ((pairs << 2) | pairs) & 0x3c3c3c3cu;
+}
 
 template <int L, bool UNIFORM_PRIOR>
 __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
-    constexpr int G = (L + 3) / 4;            // groups of 4 positions
+    constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
     constexpr int LP = (L + 3) / 4 * 4;
-    static_assert(L <= 16, "one or two packed words");
-    // static LDS (addresses are compile time constants, so table reads need no base add): the tables and the
-    // two fp64 factor columns; dynamic LDS: the counter histogram, sized per decoder
-    __shared__ float table[G * 16 * BLOCK];                                   // [G * 16][BLOCK]
-    __shared__ double match_probability[128];
-    __shared__ double mismatch_probability[128];
+    constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
+    constexpr int PER_WORD = PAIRED ? 2 : 1;
+    static_assert(L <= 16, "2-bit codes of one barcode fit one word");
+    // static LDS (compile time addresses): the tables and the factor columns; dynamic LDS: the counter histogram
+    __shared__ float table[G * 16 * BLOCK];                                   // [group][index][lane]
+    __shared__ float match_single[FACTOR_ROWS];
+    __shared__ float mismatch_single[FACTOR_ROWS];
+    __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
     __shared__ uint32_t deferred_total;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
 
-    for(int i = threadIdx.x; i < 128; i += BLOCK) {
-        match_probability[i] = d.match_probability[i];
-        mismatch_probability[i] = d.mismatch_probability[i];
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += BLOCK) {
+        const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        match_single[i] = static_cast<float>(m);
+        mismatch_single[i] = static_cast<float>(e);
+        factor_double[i][0] = m;
+        factor_double[i][1] = e;
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
     histogram_clear(d, histogram);
@@ -64,17 +73,19 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
 
     const StatSink sink{histogram, args.stats};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
-    const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
-    const PHQ_CONSTANT double* concentration = constant_cast(d.concentration);
+    const PHQ_CONSTANT uint32_t* words = constant_cast(d.barcode_packed2);
+    const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
-    constexpr int W = (G + 1) / 2;            // packed words per barcode
-    const double uniform_probability = d.uniform_probability;
     const int64_t n = args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
     constexpr uint32_t GROUP_BYTES = 16 * BLOCK * sizeof(float);
     constexpr uint32_t ENTRY_BYTES = BLOCK * sizeof(float);
+    constexpr uint32_t INDEX_MASK = 0x3c00u;              // index * 1024 at byte 1 of a field word
     const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
-    const float prior = UNIFORM_PRIOR ? static_cast<float>(concentration[0]) : 1.0f;
+    const char* const table_bytes = reinterpret_cast<const char*>(table);
+    uint32_t full_mask = 0;                                // even-bit flags of the L positions
+#pragma unroll
+    for(int j = 0; j < L; ++j) { full_mask |= 1u << (2 * j); }
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int64_t i = tile * BLOCK + threadIdx.x;
@@ -88,30 +99,33 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
             load_plane_row<L>(args.base, i, code);
             load_plane_row<L>(args.quality, i, quality);
 
-            // per position factors, the packed observation and the high quality flags
+            // per position: factor row, single precision factors, 2-bit base, high quality flag
             float fm[L];
             float fe[L];
-            uint32_t observed[W];
-            uint32_t high_quality[W];
+            uint32_t row[(L + 3) / 4];                     // factor rows, 8 bits per position
+            uint32_t observed = 0;                         // 2-bit codes; A,C,G,T = 0..3, anything else arbitrary
+            uint32_t high_quality = 0;                     // even-bit flags
+            uint32_t outside = 0;                          // even-bit flags: not A, C, G or T (mismatches every barcode base)
 #pragma unroll
-            for(int w = 0; w < W; ++w) { observed[w] = 0; high_quality[w] = 0; }
+            for(int w = 0; w < (L + 3) / 4; ++w) { row[w] = 0; }
 #pragma unroll
             for(int j = 0; j < L; ++j) {
                 const uint32_t c = code[j];
                 const uint32_t q = quality[j] & 0x7fu;
-                const double u = q ? uniform_probability : 1.0;
-                const bool strict = strict_code(c);
-                const double m = match_probability[q];
-                const double e = mismatch_probability[q];
-                fm[j] = static_cast<float>(strict ? m : u);
-                fe[j] = static_cast<float>(strict ? e : u);
-                observed[j >> 3] |= (c & 0xfu) << (4 * (j & 7));
-                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality[j >> 3] |= 1u << (4 * (j & 7)); }
+                // a base outside ACGT costs the uniform quality against every barcode base: both factors equal,
+                // so whatever its 2-bit code compares to does not matter (phred.cpp:62-64)
+                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
+                fm[j] = match_single[k];
+                fe[j] = mismatch_single[k];
+                row[j >> 2] |= k << (8 * (j & 3));
+                observed |= ((0x30210u >> (2 * (c & 0xfu))) & 3u) << (2 * j);
+                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality |= 1u << (2 * j); }
+                if(!strict_code(c)) { outside |= 1u << (2 * j); }
             }
+            if(PAIRED) { observed |= observed << 16; }
             // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
 #pragma unroll
             for(int g = 0; g < G; ++g) {
-                constexpr int FULL = 4;
                 const int base = 4 * g;
                 float lo[4];
                 float hi[4];
@@ -123,65 +137,133 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                 hi[0] = hi[1] = hi[2] = hi[3] = 1.0f;
                 if(base + 2 < L) { hi[0] = fm[base + 2]; hi[1] = fe[base + 2]; hi[2] = hi[0]; hi[3] = hi[1]; }
                 if(base + 3 < L) { hi[0] *= fm[base + 3]; hi[1] *= fm[base + 3]; hi[2] *= fe[base + 3]; hi[3] *= fe[base + 3]; }
-                (void)FULL;
 #pragma unroll
                 for(int m = 0; m < 16; ++m) {
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
                 }
             }
 
-            // single precision scan: the maximum, where it is, and the sum of everything BUT the maximum (summing
-            // it apart keeps the small remainder from being rounded away against the winner)
-            float sigma = 0;
-            float best_value = 0;
-            int best = -1;
-#pragma unroll 4
-            for(int b = 0; b < n_barcode; ++b) {
-                float conditional = 1.0f;
+            // conditional probabilities of the PER_WORD barcodes packed in one word
+            auto probabilities_of = [&](uint32_t word, float (&p)[PER_WORD]) {
+                const uint32_t fields = group_fields(field_flags(observed ^ word));
+                // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G): bring it to byte 1
+                const uint32_t up = fields << 8;
+                const uint32_t down = fields >> 8;
+                const uint32_t far = fields >> 16;
 #pragma unroll
-                for(int w = 0; w < W; ++w) {
-                    const uint32_t flags = nibble_flags(observed[w] ^ packed[b * W + w]);
-                    const uint32_t low = __umul24(flags, GATHER) & INDEX_MASK;        // flags 4 and 5 land above bit 13
-                    const float a = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (2 * w) * GROUP_BYTES + (low | lane_offset));
-                    conditional = (w == 0) ? a : conditional * a;
-                    if(2 * w + 1 < G) {
-                        const uint32_t high = __umul24(flags >> 16, GATHER) & INDEX_MASK;
-                        conditional *= *reinterpret_cast<const float*>(reinterpret_cast<const char*>(table) + (2 * w + 1) * GROUP_BYTES + (high | lane_offset));
+                for(int h = 0; h < PER_WORD; ++h) {
+                    float value = 1.0f;
+#pragma unroll
+                    for(int g = 0; g < G; ++g) {
+                        const int byte = (PAIRED ? 2 * h : 0) + g;
+                        const uint32_t source = byte == 0 ? up : byte == 1 ? fields : byte == 2 ? down : far;
+                        const float entry = *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((source & INDEX_MASK) | lane_offset));
+                        value = g == 0 ? entry : value * entry;
+                    }
+                    p[h] = value;
+                }
+            };
+
+            // Single precision scan, four barcodes at a time.  Per group of four: its maximum and its sum.  Across
+            // groups: the running maximum, WHICH group holds it, that group's sum set aside, and the sum of every
+            // other group.  The winning group's own sum is never used — subtracting the winner from it would cancel
+            // — its members are recomputed after the scan, which also names the winner inside the group.
+            float others_sum = 0;          // every group but the one holding the running maximum
+            float held_sum = 0;            // the sum of the group holding the running maximum
+            float best_value = 0;
+            int best_group = -1;
+            auto fold_group = [&](int g, float p0, float p1, float p2, float p3) {
+                const float group_max = fmaxf(fmaxf(p0, p1), fmaxf(p2, p3));
+                const float group_sum = (p0 + p1) + (p2 + p3);
+                const bool takes_over = group_max > best_value;                      // strict: the first group keeps a tie
+                others_sum += takes_over ? held_sum : group_sum;
+                held_sum = takes_over ? group_sum : held_sum;
+                best_group = takes_over ? g : best_group;
+                best_value = fmaxf(best_value, group_max);
+            };
+            auto four_of = [&](int g, float (&p)[4]) {
+                // barcodes 4g .. 4g+3; the table is padded to whole groups, padding is zeroed by the caller
+                if(PAIRED) {
+                    float a[PER_WORD];
+                    float b[PER_WORD];
+                    probabilities_of(words[2 * g], a);
+                    probabilities_of(words[2 * g + 1], b);
+                    p[0] = a[0]; p[1] = a[PER_WORD - 1]; p[2] = b[0]; p[3] = b[PER_WORD - 1];
+                } else {
+#pragma unroll
+                    for(int k = 0; k < 4; ++k) {
+                        float a[PER_WORD];
+                        probabilities_of(words[4 * g + k], a);
+                        p[k] = a[0];
                     }
                 }
-                const float p = UNIFORM_PRIOR ? conditional : conditional * static_cast<float>(concentration[b]);
-                sigma += fminf(p, best_value);
-                if(p > best_value) { best = b; }
-                best_value = fmaxf(p, best_value);
+                if(!UNIFORM_PRIOR) {
+#pragma unroll
+                    for(int k = 0; k < 4; ++k) { p[k] *= prior[4 * g + k]; }         // padded with zeros
+                }
+            };
+            const int n_full = n_barcode >> 2;
+            for(int g = 0; g < n_full; ++g) {
+                float p[4];
+                four_of(g, p);
+                fold_group(g, p[0], p[1], p[2], p[3]);
+            }
+            if(n_barcode & 3) {                                                        // the last, partial group
+                float p[4];
+                four_of(n_full, p);
+#pragma unroll
+                for(int k = 1; k < 4; ++k) { if(4 * n_full + k >= n_barcode) { p[k] = 0.0f; } }
+                fold_group(n_full, p[0], p[1], p[2], p[3]);
+            }
+
+            // inside the winning group: the winner (first of equals) and the sum of the other three
+            int best = -1;
+            uint32_t best_flags = 0;
+            float sigma = others_sum;
+            if(best_group >= 0) {
+                float top = 0;
+                float rest = 0;
+#pragma unroll
+                for(int k = 0; k < 4; ++k) {
+                    const int b = 4 * best_group + k;
+                    if(b < n_barcode) {
+                        const uint32_t word = d.barcode_packed2[PAIRED ? (b >> 1) : b];
+                        const uint32_t flags = field_flags(observed ^ word);
+                        const uint32_t fields = group_fields(flags);
+                        float p = 1.0f;
+#pragma unroll
+                        for(int g = 0; g < G; ++g) {
+                            const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
+                            const uint32_t index = (fields >> shift) & 0x3cu;
+                            p *= *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((index << 8) | lane_offset));
+                        }
+                        if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
+                        rest += fminf(p, top);
+                        if(p > top) {
+                            best = b;
+                            best_flags = ((PAIRED ? (flags >> (16 * (k & 1))) : flags) | outside) & full_mask;
+                        }
+                        top = fmaxf(p, top);
+                    }
+                }
+                sigma += rest;
             }
 
             if(best < 0) {
                 defer = true;
             } else {
-                // the winner's mask, its distances, and its probability again in fp64 from the fp64 factors
-                uint32_t flags[W];
-                int distance = 0;
-                int hq_distance = 0;
-#pragma unroll
-                for(int w = 0; w < W; ++w) {
-                    flags[w] = nibble_flags(observed[w] ^ d.barcode_packed[static_cast<int64_t>(best) * W + w]) & d.full_mask[w];
-                    distance += __popc(flags[w]);
-                    hq_distance += __popc(flags[w] & high_quality[w]);
-                }
+                // the winner's distances and its probability again in fp64 from the fp64 factor rows
+                int distance = __popc(best_flags);
+                int hq_distance = __popc(best_flags & high_quality);
                 double best_conditional = 1.0;
 #pragma unroll
                 for(int j = 0; j < L; ++j) {
-                    const uint32_t c = code[j];
-                    const uint32_t q = quality[j] & 0x7fu;
-                    const double u = q ? uniform_probability : 1.0;
-                    const bool mismatch = ((flags[j >> 3] >> (4 * (j & 7))) & 1u) != 0;
-                    const double m = match_probability[q];
-                    const double e = mismatch_probability[q];
-                    best_conditional *= strict_code(c) ? (mismatch ? e : m) : u;
+                    const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    best_conditional *= factor_double[k][(best_flags >> (2 * j)) & 1u];
                 }
-                const double best_p = best_conditional * concentration[best];
+                const double best_p = best_conditional * d.concentration[best];
                 // everything but the winner, in units of p: only ever compared against and added to much larger terms
-                const double others = static_cast<double>(sigma) * static_cast<double>(prior);
+                const double others = UNIFORM_PRIOR ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma);
                 const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
                 double confidence = best_p / total;                                       // pamld.cpp:92
                 const double noise_margin = best_conditional - d.random_barcode_probability;
@@ -270,7 +352,7 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
 
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
     return host_decoder.all_strict && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
-           host_decoder.n_barcode > 0;
+           host_decoder.n_barcode > 0 && host_decoder.barcode_packed2 != nullptr;
 }
 
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
