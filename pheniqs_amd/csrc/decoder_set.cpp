@@ -178,9 +178,13 @@ void DecoderSet::build_device_images() {
                     for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
                         const uint32_t code = c.barcode_code[static_cast<size_t>(source) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
                         const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
-                        word |= two << (2 * j);
+                        // bit-sliced: byte (2 * (b odd) + j / 4) of the word, low bit at 2 + j % 4, high bit 4 places up (mod 32)
+                        const uint32_t byte = (paired ? 2u * static_cast<uint32_t>(b & 1) : 0u) + static_cast<uint32_t>(j >> 2);
+                        const uint32_t low = 8u * byte + 2u + static_cast<uint32_t>(j & 3);
+                        word |= (two & 1u) << low;
+                        word |= (two >> 1) << ((low + 4u) & 31u);
                     }
-                    if(paired) { packed2[static_cast<size_t>(b >> 1)] |= word << (16 * (b & 1)); }
+                    if(paired) { packed2[static_cast<size_t>(b >> 1)] |= word; }
                     else { packed2[static_cast<size_t>(b)] = word; }
                     if(b < d.n_barcode) { prior[static_cast<size_t>(b)] = static_cast<float>(concentration[static_cast<size_t>(b)]); }
                 }
@@ -302,10 +306,14 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
 size_t DecoderSet::worklist_words(int64_t n_read) const {
-    const int64_t tiles = (n_read + 255) / 256;
-    const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
-    const int64_t tiles_per_block = (tiles + grid - 1) / grid;
-    return static_cast<size_t>(max_blocks_) + static_cast<size_t>(grid * tiles_per_block * 256) + 256;
+    size_t worst = 0;
+    for(int64_t threads : {256, 512}) {          // workgroup sizes the product form kernel uses (stage.hip)
+        const int64_t tiles = (n_read + threads - 1) / threads;
+        const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
+        const int64_t tiles_per_block = (tiles + grid - 1) / grid;
+        worst = std::max(worst, static_cast<size_t>(grid * tiles_per_block * threads));
+    }
+    return static_cast<size_t>(max_blocks_) + worst + 512;
 }
 
 bool DecoderSet::needs_worklist() const {

@@ -72,8 +72,9 @@ struct DevDecoder {
     const double* match_probability;      // 128 entries, pow(base, true_positive_quality[q]), [0] = 1
     const double* mismatch_probability;   // 128 entries, pow(base, q), [0] = 1
     double uniform_probability;           // pow(base, 10 log10 4) ~ 1/4
-    // product form kernel only (ACGT barcodes of up to 16 nt): 2-bit codes A,C,G,T = 0..3, position j at bits
-    // 2j; up to 8 nt two barcodes share a word (even barcode low half); padded to whole groups of 4 barcodes
+    // product form kernel only (ACGT barcodes of up to 16 nt): bit-sliced 2-bit codes A,C,G,T = 0..3, position
+    // 4f + k with its low bit at 8f + 2 + k and its high bit 4 places up, wrapping (pamld_lut.hip); up to 8 nt two
+    // barcodes share a word (even barcode in the low half); padded to whole groups of 4 barcodes
     const uint32_t* barcode_packed2;
     const float* concentration_single;    // padded with zeros to whole groups of 4 barcodes
 };

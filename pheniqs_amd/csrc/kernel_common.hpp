@@ -86,7 +86,7 @@ __device__ __forceinline__ int histogram_words(DecoderRef d) {
 
 __device__ __forceinline__ void histogram_clear(DecoderRef d, unsigned long long* histogram) {
     const int words = histogram_words(d);
-    for(int i = threadIdx.x; i < words; i += BLOCK) { histogram[i] = 0; }
+    for(int i = threadIdx.x; i < words; i += blockDim.x) { histogram[i] = 0; }
 }
 
 // TranscodingDecoder::count / pf_count (transcode.h:61-64), one LDS add per wave
@@ -103,13 +103,13 @@ __device__ __forceinline__ void count_outgoing(const StageArgs& args, unsigned l
 
 // one global atomic per non zero histogram word per workgroup
 __device__ __forceinline__ void histogram_flush(const StageArgs& args, DecoderRef d, const unsigned long long* histogram) {
-    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += BLOCK) {
+    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += blockDim.x) {
         const unsigned long long v = histogram[i];
         if(v) { atomicAdd(&args.stats[i], v); }
     }
     if(d.use_lds_histogram) {
         const int words = (d.n_barcode + 1) * STAT_WORDS_PER_BIN;
-        for(int i = threadIdx.x; i < words; i += BLOCK) {
+        for(int i = threadIdx.x; i < words; i += blockDim.x) {
             const unsigned long long v = histogram[STAT_JOB_WORDS + i];
             if(v) { atomicAdd(&args.stats[d.stats_offset + i], v); }
         }
@@ -174,6 +174,7 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 int launch_count(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool pamld_lut_supports(const DevDecoder& host_decoder);
+int pamld_lut_block(const DevDecoder& host_decoder);       // threads per workgroup of the product form kernel
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 
 }  // namespace phq

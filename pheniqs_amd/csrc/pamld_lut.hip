@@ -5,7 +5,7 @@
 // ACGT; 1 for q = 0) — reference phred.cpp:44-68, barcode.h:151-163.  So P(r|b) is a product of L factors
 // selected by the mismatch mask of (read, barcode).  The kernel
 //   * builds, per read, one 16 entry table per group of 4 positions (every product of 4 factors), in LDS;
-//   * gets mismatch masks with XOR + three fold steps on 2-bit packed bases (scalar barcode operand; for
+//   * gets mismatch masks with XOR + rotate + OR on bit-sliced 2-bit bases (scalar barcode operand; for
 //     barcodes of up to 8 nt one 32-bit word carries TWO barcodes), which leaves each group's 4-bit table
 //     index in its own byte, already scaled; one AND-OR makes the LDS address;
 //   * multiplies the G table entries, and folds four barcodes at a time into max / sum / "which group".
@@ -29,28 +29,40 @@ namespace {
 constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner, see the header
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 
-// flags at the even bits of x: bit 2j set when the 2-bit field j of x is non zero
-__device__ __forceinline__ uint32_t field_flags(uint32_t x) {
-    return (x | (x >> 1)) & 0x55555555u;
-}
-// Even-bit flags -> per byte, bits 2..5 = the four flags of the byte's positions (table index * 4).
-// With [index][lane] tables of 256 lanes * 4 bytes, byte 1 of the result is directly index * 1024.
-__device__ __forceinline__ uint32_t group_fields(uint32_t flags) {
-    uint32_t pairs = (flags | (flags >> 1)) & 0x33333333u;            // nibble n: bits 0,1 = flags of positions 2n, 2n+1
-    // keep the compiler from proving the two operands disjoint and turning the OR into a quarter rate `* 5`
-    asm volatile("" : "+v"(pairs));
-    return ((pairs << 2) | pairs) & 0x3c3c3c3cu;
+// Bit-sliced 2-bit bases (A, C, G, T = 0..3).  Position 4f + k lives in byte f of the word: its low code bit at
+// bit 8f + 2 + k, its high code bit 4 places further up, wrapping (bits 6, 7 of the byte and bits 0, 1 of the next
+// byte; the last byte wraps to bits 0, 1 of the word).  Then for X = observed ^ expected,
+//     X | rotr(X, 4)
+// has, in bits 2..5 of byte f, the four mismatch flags of group f = the table index times 4; byte 1 of that word,
+// masked, is directly index * 1024 = the byte offset of an entry in an [index][256 lanes] table of floats.
+__host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
+__host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
+constexpr uint32_t FIELD_MASK = 0x3c3c3c3cu;
+
+__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
+    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4); bits outside FIELD_MASK are junk
 }
 
+// Workgroup size: the 16 entry tables cost 64 bytes of LDS per lane and group.  Up to 8 nt (2 groups) a 512
+// lane workgroup = two 256 lane half tables of 32 KiB leaves room for two workgroups per CU = 4 waves per SIMD;
+// longer barcodes keep 256 lanes.
+template <int L> struct LutGeometry {
+    static constexpr int G = (L + 3) / 4;
+    static constexpr int THREADS = L <= 8 ? 512 : 256;
+    static constexpr uint32_t GROUP_BYTES = 16 * 256 * sizeof(float);      // one group of one half: [index][256 lanes]
+    static constexpr uint32_t HALF_BYTES = G * GROUP_BYTES;
+};
+
 template <int L, bool UNIFORM_PRIOR>
-__global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
+__global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
     constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
+    constexpr int THREADS = LutGeometry<L>::THREADS;
     constexpr int LP = (L + 3) / 4 * 4;
     constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
     constexpr int PER_WORD = PAIRED ? 2 : 1;
     static_assert(L <= 16, "2-bit codes of one barcode fit one word");
     // static LDS (compile time addresses): the tables and the factor columns; dynamic LDS: the counter histogram
-    __shared__ float table[G * 16 * BLOCK];                                   // [group][index][lane]
+    __shared__ float table[G * 16 * THREADS];                                 // [half][group][index][256 lanes]
     __shared__ float match_single[FACTOR_ROWS];
     __shared__ float mismatch_single[FACTOR_ROWS];
     __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
@@ -59,7 +71,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
 
-    for(int i = threadIdx.x; i < FACTOR_ROWS; i += BLOCK) {
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
         const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
         const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
         match_single[i] = static_cast<float>(m);
@@ -74,25 +86,40 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
     const StatSink sink{histogram, args.stats};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const PHQ_CONSTANT uint32_t* words = constant_cast(d.barcode_packed2);
+    // The packed barcode words as a wave wide table: lane l of register v holds word 64 v + l.  The scan reads
+    // word w with one v_readlane (no memory, no wait: scalar loads share a counter with the LDS reads of the scan
+    // and would serialise with them); the winner's group is fetched per lane with ds_bpermute.
+    constexpr int TABLE_REGISTERS = 4;
+    const int padded_barcodes = (d.n_barcode + 3) & ~3;
+    const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
+    const bool wave_table = n_word <= 64 * TABLE_REGISTERS;
+    uint32_t word_table[TABLE_REGISTERS];
+#pragma unroll
+    for(int v = 0; v < TABLE_REGISTERS; ++v) {
+        const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
+        word_table[v] = (wave_table && w < n_word) ? d.barcode_packed2[w] : 0u;
+    }
     const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
     const int64_t n = args.n_read;
-    const int64_t tiles = (n + BLOCK - 1) / BLOCK;
-    constexpr uint32_t GROUP_BYTES = 16 * BLOCK * sizeof(float);
-    constexpr uint32_t ENTRY_BYTES = BLOCK * sizeof(float);
+    const int64_t tiles = (n + THREADS - 1) / THREADS;
+    constexpr uint32_t GROUP_BYTES = LutGeometry<L>::GROUP_BYTES;
+    constexpr uint32_t ENTRY_BYTES = 256 * sizeof(float);
     constexpr uint32_t INDEX_MASK = 0x3c00u;              // index * 1024 at byte 1 of a field word
-    const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
+    const uint32_t lane_offset = (threadIdx.x >> 8) * LutGeometry<L>::HALF_BYTES + (threadIdx.x & 255u) * static_cast<uint32_t>(sizeof(float));
     const char* const table_bytes = reinterpret_cast<const char*>(table);
-    uint32_t full_mask = 0;                                // even-bit flags of the L positions
+    uint32_t full_mask = 0;                                // the flag bit of each of the L positions
 #pragma unroll
-    for(int j = 0; j < L; ++j) { full_mask |= 1u << (2 * j); }
+    for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t i = tile * BLOCK + threadIdx.x;
-        const bool active = i < n;
+        // every lane stays enabled (the wave wide table is gathered with cross lane reads): lanes past the end
+        // of the batch recompute its last read and are kept from every store and counter
+        const bool active = tile * THREADS + threadIdx.x < n;
+        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
         ReadState r{false, 0};
         bool defer = false;
-        if(active) {
+        {
             r = load_read_state(args, i);
             uint8_t code[LP];
             uint8_t quality[LP];
@@ -103,9 +130,9 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
             float fm[L];
             float fe[L];
             uint32_t row[(L + 3) / 4];                     // factor rows, 8 bits per position
-            uint32_t observed = 0;                         // 2-bit codes; A,C,G,T = 0..3, anything else arbitrary
-            uint32_t high_quality = 0;                     // even-bit flags
-            uint32_t outside = 0;                          // even-bit flags: not A, C, G or T (mismatches every barcode base)
+            uint32_t observed = 0;                         // bit-sliced 2-bit codes; anything outside ACGT arbitrary
+            uint32_t high_quality = 0;                     // flag bits (low_bit of the position)
+            uint32_t outside = 0;                          // flag bits: not A, C, G or T (mismatches every barcode base)
 #pragma unroll
             for(int w = 0; w < (L + 3) / 4; ++w) { row[w] = 0; }
 #pragma unroll
@@ -118,11 +145,12 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                 fm[j] = match_single[k];
                 fe[j] = mismatch_single[k];
                 row[j >> 2] |= k << (8 * (j & 3));
-                observed |= ((0x30210u >> (2 * (c & 0xfu))) & 3u) << (2 * j);
-                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality |= 1u << (2 * j); }
-                if(!strict_code(c)) { outside |= 1u << (2 * j); }
+                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
+                observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality |= 1u << low_bit(j); }
+                if(!strict_code(c)) { outside |= 1u << low_bit(j); }
             }
-            if(PAIRED) { observed |= observed << 16; }
+            if(PAIRED) { observed |= __builtin_amdgcn_alignbit(observed, observed, 16); }     // the same read against both halves
             // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
 #pragma unroll
             for(int g = 0; g < G; ++g) {
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
 
             // conditional probabilities of the PER_WORD barcodes packed in one word
             auto probabilities_of = [&](uint32_t word, float (&p)[PER_WORD]) {
-                const uint32_t fields = group_fields(field_flags(observed ^ word));
+                const uint32_t fields = mismatch_fields(observed ^ word);
                 // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G): bring it to byte 1
                 const uint32_t up = fields << 8;
                 const uint32_t down = fields >> 8;
@@ -181,19 +209,19 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                 best_group = takes_over ? g : best_group;
                 best_value = fmaxf(best_value, group_max);
             };
-            auto four_of = [&](int g, float (&p)[4]) {
+            auto four_of = [&](int g, const uint32_t (&w)[PAIRED ? 2 : 4], float (&p)[4]) {
                 // barcodes 4g .. 4g+3; the table is padded to whole groups, padding is zeroed by the caller
                 if(PAIRED) {
                     float a[PER_WORD];
                     float b[PER_WORD];
-                    probabilities_of(words[2 * g], a);
-                    probabilities_of(words[2 * g + 1], b);
+                    probabilities_of(w[0], a);
+                    probabilities_of(w[1], b);
                     p[0] = a[0]; p[1] = a[PER_WORD - 1]; p[2] = b[0]; p[3] = b[PER_WORD - 1];
                 } else {
 #pragma unroll
                     for(int k = 0; k < 4; ++k) {
                         float a[PER_WORD];
-                        probabilities_of(words[4 * g + k], a);
+                        probabilities_of(w[PAIRED ? 0 : k], a);
                         p[k] = a[0];
                     }
                 }
@@ -202,49 +230,90 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                     for(int k = 0; k < 4; ++k) { p[k] *= prior[4 * g + k]; }         // padded with zeros
                 }
             };
+            constexpr int WORDS_PER_GROUP = PAIRED ? 2 : 4;
+            constexpr int GROUPS_PER_REGISTER = 64 / WORDS_PER_GROUP;
             const int n_full = n_barcode >> 2;
-            for(int g = 0; g < n_full; ++g) {
+            auto scan_group = [&](int g, const uint32_t (&w)[WORDS_PER_GROUP], bool partial) {
                 float p[4];
-                four_of(g, p);
-                fold_group(g, p[0], p[1], p[2], p[3]);
-            }
-            if(n_barcode & 3) {                                                        // the last, partial group
-                float p[4];
-                four_of(n_full, p);
+                four_of(g, w, p);
+                if(partial) {
 #pragma unroll
-                for(int k = 1; k < 4; ++k) { if(4 * n_full + k >= n_barcode) { p[k] = 0.0f; } }
-                fold_group(n_full, p[0], p[1], p[2], p[3]);
+                    for(int k = 1; k < 4; ++k) { if(4 * g + k >= n_barcode) { p[k] = 0.0f; } }
+                }
+                fold_group(g, p[0], p[1], p[2], p[3]);
+            };
+            if(wave_table) {
+#pragma unroll
+                for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                    const int first = v * GROUPS_PER_REGISTER;
+                    const int last = min(n_full, first + GROUPS_PER_REGISTER);
+                    for(int g = first; g < last; ++g) {
+                        uint32_t w[WORDS_PER_GROUP];
+#pragma unroll
+                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
+                            w[k] = __builtin_amdgcn_readlane(word_table[v], (g - first) * WORDS_PER_GROUP + k);
+                        }
+                        scan_group(g, w, false);
+                    }
+                    if((n_barcode & 3) && n_full >= first && n_full < first + GROUPS_PER_REGISTER) {     // the last, partial group
+                        uint32_t w[WORDS_PER_GROUP];
+#pragma unroll
+                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
+                            w[k] = __builtin_amdgcn_readlane(word_table[v], (n_full - first) * WORDS_PER_GROUP + k);
+                        }
+                        scan_group(n_full, w, true);
+                    }
+                }
+            } else {
+                for(int g = 0; g < n_full + ((n_barcode & 3) ? 1 : 0); ++g) {
+                    uint32_t w[WORDS_PER_GROUP];
+#pragma unroll
+                    for(int k = 0; k < WORDS_PER_GROUP; ++k) { w[k] = words[g * WORDS_PER_GROUP + k]; }
+                    scan_group(g, w, g == n_full);
+                }
             }
 
             // inside the winning group: the winner (first of equals) and the sum of the other three
             int best = -1;
             uint32_t best_flags = 0;
             float sigma = others_sum;
-            if(best_group >= 0) {
+            {
+                const int group = best_group < 0 ? 0 : best_group;
                 float top = 0;
                 float rest = 0;
 #pragma unroll
                 for(int k = 0; k < 4; ++k) {
-                    const int b = 4 * best_group + k;
-                    if(b < n_barcode) {
-                        const uint32_t word = d.barcode_packed2[PAIRED ? (b >> 1) : b];
-                        const uint32_t flags = field_flags(observed ^ word);
-                        const uint32_t fields = group_fields(flags);
-                        float p = 1.0f;
+                    const int b = 4 * group + k;
+                    const int w = PAIRED ? (b >> 1) : b;
+                    uint32_t word = 0;
+                    if(wave_table) {
+                        // lane (w & 63) of register (w >> 6): a gather inside the wave
 #pragma unroll
-                        for(int g = 0; g < G; ++g) {
-                            const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
-                            const uint32_t index = (fields >> shift) & 0x3cu;
-                            p *= *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((index << 8) | lane_offset));
+                        for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                            if(64 * v < n_word) {
+                                const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((w & 63) << 2, static_cast<int>(word_table[v])));
+                                word = (w >> 6) == v ? got : word;
+                            }
                         }
-                        if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
-                        rest += fminf(p, top);
-                        if(p > top) {
-                            best = b;
-                            best_flags = ((PAIRED ? (flags >> (16 * (k & 1))) : flags) | outside) & full_mask;
-                        }
-                        top = fmaxf(p, top);
+                    } else {
+                        word = d.barcode_packed2[w];
                     }
+                    const uint32_t fields = mismatch_fields(observed ^ word);
+                    float p = 1.0f;
+#pragma unroll
+                    for(int g = 0; g < G; ++g) {
+                        const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
+                        const uint32_t index = (fields >> shift) & 0x3cu;
+                        p *= *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((index << 8) | lane_offset));
+                    }
+                    if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
+                    if(b >= n_barcode || best_group < 0) { p = 0.0f; }
+                    rest += fminf(p, top);
+                    if(p > top) {
+                        best = b;
+                        best_flags = ((PAIRED ? (fields >> (16 * (k & 1))) : fields) | outside) & full_mask;
+                    }
+                    top = fmaxf(p, top);
                 }
                 sigma += rest;
             }
@@ -259,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
 #pragma unroll
                 for(int j = 0; j < L; ++j) {
                     const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                    best_conditional *= factor_double[k][(best_flags >> (2 * j)) & 1u];
+                    best_conditional *= factor_double[k][(best_flags >> low_bit(j)) & 1u];
                 }
                 const double best_p = best_conditional * d.concentration[best];
                 // everything but the winner, in units of p: only ever compared against and added to much larger terms
@@ -272,7 +341,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
                 defer = !(others <= DOMINANCE * best_p)
                      || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
                      || !(fabs(confidence_margin) > 1e-9);
-                if(!defer) {
+                if(!defer && active) {
                     int bin = best + 1;
                     uint8_t status = STATUS_PASS;
                     if(noise_margin > 0) {                                                // pamld.cpp:96
@@ -330,7 +399,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_lut_kernel(StageArgs args) {
 
 template <int L, bool UNIFORM_PRIOR>
 int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(BLOCK), histogram_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), histogram_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -353,6 +422,10 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
     return host_decoder.all_strict && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
            host_decoder.n_barcode > 0 && host_decoder.barcode_packed2 != nullptr;
+}
+
+int pamld_lut_block(const DevDecoder& host_decoder) {
+    return host_decoder.nucleotide_cardinality <= 8 ? 512 : 256;
 }
 
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {

@@ -32,15 +32,18 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: product form over every read, deferring the ambiguous ones; tier 2: the literal kernel on those
                 // both launches use the same grid: literal workgroup g consumes what product form workgroup g deferred
-                const int64_t tiles_per_block = (tiles + grid.x - 1) / grid.x;
+                const int64_t threads = pamld_lut_block(host_decoder);
+                const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
+                const dim3 wide_grid(static_cast<unsigned>(wide_tiles < max_blocks ? wide_tiles : max_blocks));
+                const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
                 StageArgs producer = args;
                 producer.worklist_role = 1;
-                producer.worklist_stride = static_cast<int32_t>(tiles_per_block * BLOCK);
-                int status = launch_pamld_lut(producer, host_decoder, grid, histogram_bytes, s);
+                producer.worklist_stride = static_cast<int32_t>(tiles_per_block * threads);
+                int status = launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
-                return launch_pamld_literal(consumer, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+                return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
             }
             return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
         case 2: return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
