@@ -113,7 +113,8 @@ def main():
     parser.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     parser.add_argument("--pool", type=int, default=1 << 20, help="distinct synthetic reads tiled to --reads")
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
-    parser.add_argument("--mode", default="literal", choices=["literal", "fast"])
+    parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
+                        help="fast: product form kernel + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     args = parser.parse_args()
 

@@ -113,7 +113,7 @@ const char* phq_last_error(const phq_decoder_set* set);                    /* Er
 
 int phq_get_layout(const phq_decoder_set* set, phq_layout_t* layout);
 int phq_get_decoder_info(const phq_decoder_set* set, int32_t decoder, phq_decoder_info_t* info);
-int phq_set_mode(phq_decoder_set* set, int32_t mode);                      /* PHQ_MODE_* */
+int phq_set_mode(phq_decoder_set* set, int32_t mode);                      /* PHQ_MODE_*, default PHQ_MODE_FAST */
 
 /* ---- extraction -----------------------------------------------------------------------------------
  * Rule::apply(const Read&, Observation&) for every decoder (transform.h:142-169 with

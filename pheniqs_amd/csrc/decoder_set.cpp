@@ -38,7 +38,7 @@ void host_free(void* pointer) {
 DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
     job_(JobConfig::from_json(Json::parse(compiled_job_json))),
     device_(device),
-    mode_(MODE_LITERAL),
+    mode_(MODE_FAST),
     max_blocks_(2048),
     device_decoder_(nullptr),
     device_stats_(nullptr),

@@ -1,427 +1,21 @@
-// K1 (product form): PamlDecoder<T>::classify for reads whose winner is unambiguous.
-//
-// pow(base, sum of costs) = product of pow(base, cost): per read and position there are only two factors,
-// P(match) = pow(base, tpq[q]) and P(mismatch) = pow(base, q) (or pow(base, 10 log10 4) for a base outside
-// ACGT; 1 for q = 0) — reference phred.cpp:44-68, barcode.h:151-163.  So P(r|b) is a product of L factors
-// selected by the mismatch mask of (read, barcode).  The kernel
-//   * builds, per read, one 16 entry table per group of 4 positions (every product of 4 factors), in LDS;
-//   * gets mismatch masks with XOR + rotate + OR on bit-sliced 2-bit bases (scalar barcode operand; for
-//     barcodes of up to 8 nt one 32-bit word carries TWO barcodes), which leaves each group's 4-bit table
-//     index in its own byte, already scaled; one AND-OR makes the LDS address;
-//   * multiplies the G table entries, and folds four barcodes at a time into max / sum / "which group".
-// No exp, no Kahan chain: ~10 VALU instructions per (read, barcode) instead of ~75.  Every VALU instruction
-// costs one quad-cycle on this part whatever its type, so instruction count is the metric.
-//
-// The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
-// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-9).  So a read is only FINISHED in
-// this kernel when its winner dominates: the summed probability of every other barcode is at most 1e-3 of the
-// winner's (DOMINANCE).  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single
-// precision — their ~5e-7 relative error moves the posterior by at most DOMINANCE * 5e-7 — while the winner's own
-// probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
-// confidence filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  Every other read
-// (noise reads, reads with a second plausible barcode: ~2 %) is appended to a worklist that the literal kernel
-// decodes right after, on the same stream.
+// Dispatcher of the product form PAMLD kernels (pamld_lut.hpp), by how many wave wide registers the packed
+// barcode table needs.
 #include "kernel_common.hpp"
 
 namespace phq {
-namespace {
 
-constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner, see the header
-constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
+int launch_pamld_lut_t1(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_lut_t2(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_lut_t4(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 
-// Bit-sliced 2-bit bases (A, C, G, T = 0..3).  Position 4f + k lives in byte f of the word: its low code bit at
-// bit 8f + 2 + k, its high code bit 4 places further up, wrapping (bits 6, 7 of the byte and bits 0, 1 of the next
-// byte; the last byte wraps to bits 0, 1 of the word).  Then for X = observed ^ expected,
-//     X | rotr(X, 4)
-// has, in bits 2..5 of byte f, the four mismatch flags of group f = the table index times 4; byte 1 of that word,
-// masked, is directly index * 1024 = the byte offset of an entry in an [index][256 lanes] table of floats.
-__host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
-__host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
-constexpr uint32_t FIELD_MASK = 0x3c3c3c3cu;
-
-__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
-    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4); bits outside FIELD_MASK are junk
+static int packed_words(const DevDecoder& host_decoder) {
+    const int padded = (host_decoder.n_barcode + 3) & ~3;
+    return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
 }
-
-// Workgroup size: the 16 entry tables cost 64 bytes of LDS per lane and group.  Up to 8 nt (2 groups) a 512
-// lane workgroup = two 256 lane half tables of 32 KiB leaves room for two workgroups per CU = 4 waves per SIMD;
-// longer barcodes keep 256 lanes.
-template <int L> struct LutGeometry {
-    static constexpr int G = (L + 3) / 4;
-    static constexpr int THREADS = L <= 8 ? 512 : 256;
-    static constexpr uint32_t GROUP_BYTES = 16 * 256 * sizeof(float);      // one group of one half: [index][256 lanes]
-    static constexpr uint32_t HALF_BYTES = G * GROUP_BYTES;
-};
-
-template <int L, bool UNIFORM_PRIOR>
-__global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
-    constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
-    constexpr int THREADS = LutGeometry<L>::THREADS;
-    constexpr int LP = (L + 3) / 4 * 4;
-    constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
-    constexpr int PER_WORD = PAIRED ? 2 : 1;
-    static_assert(L <= 16, "2-bit codes of one barcode fit one word");
-    // static LDS (compile time addresses): the tables and the factor columns; dynamic LDS: the counter histogram
-    __shared__ float table[G * 16 * THREADS];                                 // [half][group][index][256 lanes]
-    __shared__ float match_single[FACTOR_ROWS];
-    __shared__ float mismatch_single[FACTOR_ROWS];
-    __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
-    __shared__ uint32_t deferred_total;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
-    DecoderRef d = *constant_cast(args.decoder);
-
-    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
-        const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
-        const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
-        match_single[i] = static_cast<float>(m);
-        mismatch_single[i] = static_cast<float>(e);
-        factor_double[i][0] = m;
-        factor_double[i][1] = e;
-    }
-    if(threadIdx.x == 0) { deferred_total = 0; }
-    histogram_clear(d, histogram);
-    __syncthreads();
-
-    const StatSink sink{histogram, args.stats};
-    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
-    const PHQ_CONSTANT uint32_t* words = constant_cast(d.barcode_packed2);
-    // The packed barcode words as a wave wide table: lane l of register v holds word 64 v + l.  The scan reads
-    // word w with one v_readlane (no memory, no wait: scalar loads share a counter with the LDS reads of the scan
-    // and would serialise with them); the winner's group is fetched per lane with ds_bpermute.
-    constexpr int TABLE_REGISTERS = 4;
-    const int padded_barcodes = (d.n_barcode + 3) & ~3;
-    const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
-    const bool wave_table = n_word <= 64 * TABLE_REGISTERS;
-    uint32_t word_table[TABLE_REGISTERS];
-#pragma unroll
-    for(int v = 0; v < TABLE_REGISTERS; ++v) {
-        const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
-        word_table[v] = (wave_table && w < n_word) ? d.barcode_packed2[w] : 0u;
-    }
-    const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
-    const int n_barcode = d.n_barcode;
-    const int64_t n = args.n_read;
-    const int64_t tiles = (n + THREADS - 1) / THREADS;
-    constexpr uint32_t GROUP_BYTES = LutGeometry<L>::GROUP_BYTES;
-    constexpr uint32_t ENTRY_BYTES = 256 * sizeof(float);
-    constexpr uint32_t INDEX_MASK = 0x3c00u;              // index * 1024 at byte 1 of a field word
-    const uint32_t lane_offset = (threadIdx.x >> 8) * LutGeometry<L>::HALF_BYTES + (threadIdx.x & 255u) * static_cast<uint32_t>(sizeof(float));
-    const char* const table_bytes = reinterpret_cast<const char*>(table);
-    uint32_t full_mask = 0;                                // the flag bit of each of the L positions
-#pragma unroll
-    for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
-
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        // every lane stays enabled (the wave wide table is gathered with cross lane reads): lanes past the end
-        // of the batch recompute its last read and are kept from every store and counter
-        const bool active = tile * THREADS + threadIdx.x < n;
-        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
-        ReadState r{false, 0};
-        bool defer = false;
-        {
-            r = load_read_state(args, i);
-            uint8_t code[LP];
-            uint8_t quality[LP];
-            load_plane_row<L>(args.base, i, code);
-            load_plane_row<L>(args.quality, i, quality);
-
-            // per position: factor row, single precision factors, 2-bit base, high quality flag
-            float fm[L];
-            float fe[L];
-            uint32_t row[(L + 3) / 4];                     // factor rows, 8 bits per position
-            uint32_t observed = 0;                         // bit-sliced 2-bit codes; anything outside ACGT arbitrary
-            uint32_t high_quality = 0;                     // flag bits (low_bit of the position)
-            uint32_t outside = 0;                          // flag bits: not A, C, G or T (mismatches every barcode base)
-#pragma unroll
-            for(int w = 0; w < (L + 3) / 4; ++w) { row[w] = 0; }
-#pragma unroll
-            for(int j = 0; j < L; ++j) {
-                const uint32_t c = code[j];
-                const uint32_t q = quality[j] & 0x7fu;
-                // a base outside ACGT costs the uniform quality against every barcode base: both factors equal,
-                // so whatever its 2-bit code compares to does not matter (phred.cpp:62-64)
-                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
-                fm[j] = match_single[k];
-                fe[j] = mismatch_single[k];
-                row[j >> 2] |= k << (8 * (j & 3));
-                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
-                observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
-                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality |= 1u << low_bit(j); }
-                if(!strict_code(c)) { outside |= 1u << low_bit(j); }
-            }
-            if(PAIRED) { observed |= __builtin_amdgcn_alignbit(observed, observed, 16); }     // the same read against both halves
-            // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
-#pragma unroll
-            for(int g = 0; g < G; ++g) {
-                const int base = 4 * g;
-                float lo[4];
-                float hi[4];
-                lo[0] = fm[base];
-                lo[1] = fe[base];
-                lo[2] = lo[0];
-                lo[3] = lo[1];
-                if(base + 1 < L) { lo[0] *= fm[base + 1]; lo[1] *= fm[base + 1]; lo[2] *= fe[base + 1]; lo[3] *= fe[base + 1]; }
-                hi[0] = hi[1] = hi[2] = hi[3] = 1.0f;
-                if(base + 2 < L) { hi[0] = fm[base + 2]; hi[1] = fe[base + 2]; hi[2] = hi[0]; hi[3] = hi[1]; }
-                if(base + 3 < L) { hi[0] *= fm[base + 3]; hi[1] *= fm[base + 3]; hi[2] *= fe[base + 3]; hi[3] *= fe[base + 3]; }
-#pragma unroll
-                for(int m = 0; m < 16; ++m) {
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
-                }
-            }
-
-            // conditional probabilities of the PER_WORD barcodes packed in one word
-            auto probabilities_of = [&](uint32_t word, float (&p)[PER_WORD]) {
-                const uint32_t fields = mismatch_fields(observed ^ word);
-                // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G): bring it to byte 1
-                const uint32_t up = fields << 8;
-                const uint32_t down = fields >> 8;
-                const uint32_t far = fields >> 16;
-#pragma unroll
-                for(int h = 0; h < PER_WORD; ++h) {
-                    float value = 1.0f;
-#pragma unroll
-                    for(int g = 0; g < G; ++g) {
-                        const int byte = (PAIRED ? 2 * h : 0) + g;
-                        const uint32_t source = byte == 0 ? up : byte == 1 ? fields : byte == 2 ? down : far;
-                        const float entry = *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((source & INDEX_MASK) | lane_offset));
-                        value = g == 0 ? entry : value * entry;
-                    }
-                    p[h] = value;
-                }
-            };
-
-            // Single precision scan, four barcodes at a time.  Per group of four: its maximum and its sum.  Across
-            // groups: the running maximum, WHICH group holds it, that group's sum set aside, and the sum of every
-            // other group.  The winning group's own sum is never used — subtracting the winner from it would cancel
-            // — its members are recomputed after the scan, which also names the winner inside the group.
-            float others_sum = 0;          // every group but the one holding the running maximum
-            float held_sum = 0;            // the sum of the group holding the running maximum
-            float best_value = 0;
-            int best_group = -1;
-            auto fold_group = [&](int g, float p0, float p1, float p2, float p3) {
-                const float group_max = fmaxf(fmaxf(p0, p1), fmaxf(p2, p3));
-                const float group_sum = (p0 + p1) + (p2 + p3);
-                const bool takes_over = group_max > best_value;                      // strict: the first group keeps a tie
-                others_sum += takes_over ? held_sum : group_sum;
-                held_sum = takes_over ? group_sum : held_sum;
-                best_group = takes_over ? g : best_group;
-                best_value = fmaxf(best_value, group_max);
-            };
-            auto four_of = [&](int g, const uint32_t (&w)[PAIRED ? 2 : 4], float (&p)[4]) {
-                // barcodes 4g .. 4g+3; the table is padded to whole groups, padding is zeroed by the caller
-                if(PAIRED) {
-                    float a[PER_WORD];
-                    float b[PER_WORD];
-                    probabilities_of(w[0], a);
-                    probabilities_of(w[1], b);
-                    p[0] = a[0]; p[1] = a[PER_WORD - 1]; p[2] = b[0]; p[3] = b[PER_WORD - 1];
-                } else {
-#pragma unroll
-                    for(int k = 0; k < 4; ++k) {
-                        float a[PER_WORD];
-                        probabilities_of(w[PAIRED ? 0 : k], a);
-                        p[k] = a[0];
-                    }
-                }
-                if(!UNIFORM_PRIOR) {
-#pragma unroll
-                    for(int k = 0; k < 4; ++k) { p[k] *= prior[4 * g + k]; }         // padded with zeros
-                }
-            };
-            constexpr int WORDS_PER_GROUP = PAIRED ? 2 : 4;
-            constexpr int GROUPS_PER_REGISTER = 64 / WORDS_PER_GROUP;
-            const int n_full = n_barcode >> 2;
-            auto scan_group = [&](int g, const uint32_t (&w)[WORDS_PER_GROUP], bool partial) {
-                float p[4];
-                four_of(g, w, p);
-                if(partial) {
-#pragma unroll
-                    for(int k = 1; k < 4; ++k) { if(4 * g + k >= n_barcode) { p[k] = 0.0f; } }
-                }
-                fold_group(g, p[0], p[1], p[2], p[3]);
-            };
-            if(wave_table) {
-#pragma unroll
-                for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                    const int first = v * GROUPS_PER_REGISTER;
-                    const int last = min(n_full, first + GROUPS_PER_REGISTER);
-                    for(int g = first; g < last; ++g) {
-                        uint32_t w[WORDS_PER_GROUP];
-#pragma unroll
-                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (g - first) * WORDS_PER_GROUP + k);
-                        }
-                        scan_group(g, w, false);
-                    }
-                    if((n_barcode & 3) && n_full >= first && n_full < first + GROUPS_PER_REGISTER) {     // the last, partial group
-                        uint32_t w[WORDS_PER_GROUP];
-#pragma unroll
-                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (n_full - first) * WORDS_PER_GROUP + k);
-                        }
-                        scan_group(n_full, w, true);
-                    }
-                }
-            } else {
-                for(int g = 0; g < n_full + ((n_barcode & 3) ? 1 : 0); ++g) {
-                    uint32_t w[WORDS_PER_GROUP];
-#pragma unroll
-                    for(int k = 0; k < WORDS_PER_GROUP; ++k) { w[k] = words[g * WORDS_PER_GROUP + k]; }
-                    scan_group(g, w, g == n_full);
-                }
-            }
-
-            // inside the winning group: the winner (first of equals) and the sum of the other three
-            int best = -1;
-            uint32_t best_flags = 0;
-            float sigma = others_sum;
-            {
-                const int group = best_group < 0 ? 0 : best_group;
-                float top = 0;
-                float rest = 0;
-#pragma unroll
-                for(int k = 0; k < 4; ++k) {
-                    const int b = 4 * group + k;
-                    const int w = PAIRED ? (b >> 1) : b;
-                    uint32_t word = 0;
-                    if(wave_table) {
-                        // lane (w & 63) of register (w >> 6): a gather inside the wave
-#pragma unroll
-                        for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                            if(64 * v < n_word) {
-                                const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((w & 63) << 2, static_cast<int>(word_table[v])));
-                                word = (w >> 6) == v ? got : word;
-                            }
-                        }
-                    } else {
-                        word = d.barcode_packed2[w];
-                    }
-                    const uint32_t fields = mismatch_fields(observed ^ word);
-                    float p = 1.0f;
-#pragma unroll
-                    for(int g = 0; g < G; ++g) {
-                        const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
-                        const uint32_t index = (fields >> shift) & 0x3cu;
-                        p *= *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((index << 8) | lane_offset));
-                    }
-                    if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
-                    if(b >= n_barcode || best_group < 0) { p = 0.0f; }
-                    rest += fminf(p, top);
-                    if(p > top) {
-                        best = b;
-                        best_flags = ((PAIRED ? (fields >> (16 * (k & 1))) : fields) | outside) & full_mask;
-                    }
-                    top = fmaxf(p, top);
-                }
-                sigma += rest;
-            }
-
-            if(best < 0) {
-                defer = true;
-            } else {
-                // the winner's distances and its probability again in fp64 from the fp64 factor rows
-                int distance = __popc(best_flags);
-                int hq_distance = __popc(best_flags & high_quality);
-                double best_conditional = 1.0;
-#pragma unroll
-                for(int j = 0; j < L; ++j) {
-                    const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                    best_conditional *= factor_double[k][(best_flags >> low_bit(j)) & 1u];
-                }
-                const double best_p = best_conditional * d.concentration[best];
-                // everything but the winner, in units of p: only ever compared against and added to much larger terms
-                const double others = UNIFORM_PRIOR ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma);
-                const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
-                double confidence = best_p / total;                                       // pamld.cpp:92
-                const double noise_margin = best_conditional - d.random_barcode_probability;
-                const double confidence_margin = confidence - d.confidence_threshold;
-                // certificate: a dominant winner and no decision within 1e-9 (relative) of its threshold
-                defer = !(others <= DOMINANCE * best_p)
-                     || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
-                     || !(fabs(confidence_margin) > 1e-9);
-                if(!defer && active) {
-                    int bin = best + 1;
-                    uint8_t status = STATUS_PASS;
-                    if(noise_margin > 0) {                                                // pamld.cpp:96
-                        if(confidence_margin > 0) {                                       // pamld.cpp:99
-                            if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) {
-                                r.qcfail = true;
-                            }
-                            stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
-                        } else {
-                            stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
-                            r.qcfail = true;
-                            status = STATUS_LOW_CONFIDENCE;
-                        }
-                    } else {
-                        stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
-                        r.qcfail = true;
-                        bin = 0;
-                        distance = 0;
-                        hq_distance = 0;
-                        confidence = 0;
-                        status = STATUS_NOISE;
-                    }
-                    decoder_tail(d, sink, r, bin, distance);
-                    if(args.result) {
-                        DevResult out;
-                        out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
-                        out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
-                        out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
-                        out.status = status;
-                        out.qcfail = r.qcfail ? 1 : 0;
-                        out.confidence = confidence;
-                        args.result[i] = out;
-                    }
-                    store_read_state(args, i, r);
-                }
-            }
-        }
-        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
-        const unsigned long long deferred = __ballot(active && defer);
-        if(deferred) {
-            const int lane = threadIdx.x & 63;
-            uint32_t first = 0;
-            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
-            first = __shfl(first, 0);
-            if(active && defer) {
-                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
-            }
-        }
-        count_outgoing(args, histogram, active && !defer, r);
-    }
-    __syncthreads();
-    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
-    histogram_flush(args, d, histogram);
-}
-
-template <int L, bool UNIFORM_PRIOR>
-int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), histogram_bytes, stream, args);
-    return static_cast<int>(hipGetLastError());
-}
-
-template <int LO, int HI>
-int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if constexpr(LO > HI) {
-        (void)args; (void)host_decoder; (void)grid; (void)histogram_bytes; (void)stream;
-        return static_cast<int>(hipErrorInvalidValue);
-    } else {
-        if(host_decoder.nucleotide_cardinality == LO) {
-            return host_decoder.uniform_prior ? launch_one<LO, true>(args, grid, histogram_bytes, stream)
-                                              : launch_one<LO, false>(args, grid, histogram_bytes, stream);
-        }
-        return launch_range<LO + 1, HI>(args, host_decoder, grid, histogram_bytes, stream);
-    }
-}
-
-}  // namespace
 
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
     return host_decoder.all_strict && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
-           host_decoder.n_barcode > 0 && host_decoder.barcode_packed2 != nullptr;
+           host_decoder.n_barcode > 0 && packed_words(host_decoder) <= 256 && host_decoder.barcode_packed2 != nullptr;
 }
 
 int pamld_lut_block(const DevDecoder& host_decoder) {
@@ -429,7 +23,10 @@ int pamld_lut_block(const DevDecoder& host_decoder) {
 }
 
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    return launch_range<1, 16>(args, host_decoder, grid, histogram_bytes, stream);
+    const int words = packed_words(host_decoder);
+    if(words <= 64) { return launch_pamld_lut_t1(args, host_decoder, grid, histogram_bytes, stream); }
+    if(words <= 128) { return launch_pamld_lut_t2(args, host_decoder, grid, histogram_bytes, stream); }
+    return launch_pamld_lut_t4(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 }  // namespace phq
