@@ -113,9 +113,13 @@ def main():
     parser.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     parser.add_argument("--pool", type=int, default=1 << 20, help="distinct synthetic reads tiled to --reads")
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
+    parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                        help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration")
     parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
                         help="fast: product form kernel + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--host-staged", type=int, default=0, metavar="READS",
+                        help="also time phq_classify_host (pageable host planes -> pinned -> device -> back) on READS reads")
     args = parser.parse_args()
 
     import torch
@@ -127,7 +131,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
-    job, recipe = synthetic.config_job("C2", args.algorithm)
+    job, recipe = synthetic.config_job(args.config, args.algorithm)
     bytes_per_read = synthetic.algorithmic_bytes_per_read(job)          # 37 for C2
     pool_n = min(args.pool, args.reads)
     tiles = -(-args.reads // pool_n)
@@ -136,11 +140,20 @@ def main():
 
     s = DecoderSet(job, device=local_rank)
     s.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
-    stride = s.decoders[0]["plane_stride"]
-    base = torch.from_numpy(s.planes_from_rows(code, offsets)).to(device).view(pool_n, stride).repeat(tiles, 1)[:n].contiguous().view(-1)
-    qual = torch.from_numpy(s.planes_from_rows(quality, offsets)).to(device).view(pool_n, stride).repeat(tiles, 1)[:n].contiguous().view(-1)
+    def resident_planes(rows):
+        """decoder major planes of the pool, every plane tiled to n reads, concatenated: the layout phq_classify_device takes"""
+        pool_planes = torch.from_numpy(s.planes_from_rows(rows, offsets)).to(device)
+        parts = []
+        for d in s.decoders:
+            stride, prefix = d["plane_stride"], d["plane_prefix"]
+            if stride:
+                parts.append(pool_planes[pool_n * prefix: pool_n * (prefix + stride)].view(pool_n, stride).repeat(tiles, 1)[:n].contiguous().view(-1))
+        return torch.cat(parts) if len(parts) > 1 else parts[0]
+
+    base = resident_planes(code)
+    qual = resident_planes(quality)
     flags = torch.from_numpy(flag).to(device).repeat(tiles)[:n].contiguous()
-    result = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
+    result = torch.zeros(max(1, s.n_result) * n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
     word = torch.zeros(n, dtype=torch.int32, device=device)
     counters = s.stats_tensor()
     stream = torch.cuda.current_stream().cuda_stream
@@ -162,17 +175,22 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    s.profile_enable(True)          # HIP events around every kernel launch, on the launch stream
     pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(pairs[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    kernels = s.profile_collect()
+    s.profile_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))
+    classify_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))        # all kernels of one step
+    dominant = max(kernels, key=lambda name: kernels[name]["ms"])
+    kernel_ms = kernels[dominant]["ms"] / kernels[dominant]["launches"]          # the dominant kernel alone
 
     # size independent check of the last step: counters are a whole number of pool passes (+ remainder)
     words = s.stats_export()
@@ -193,17 +211,35 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if args.algorithm == "pamld" else "u32",
             "data": "synthetic",
-            "config": {"workload": "C2: %d reads per GPU, single 8 bp index, 96 barcodes, %s, inputs resident in HBM" % (n, args.algorithm.upper()),
-                       "reads_per_gpu": n, "pool": pool_n, "barcodes": 96, "barcode_length": 8, "kernel_mode": args.mode,
+            "config": {"workload": "%s: %d reads per GPU, %s, %s, inputs resident in HBM" % (
+                           args.config, n, {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
+                                            "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10"}[args.config],
+                           args.algorithm.upper()),
+                       "reads_per_gpu": n, "pool": pool_n, "kernel_mode": args.mode,
                        "sharding": "reads x%d, counters merged by one all-reduce per step" % world},
             "roofline": {"bound": "hbm", "achieved": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(args.mode, n),
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read},
+                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(dominant, n),
+                         "kernel": dominant, "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read,
+                         "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in kernels.items()},
+                         "classify_ms_per_step": classify_ms},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(job, code, quality, flag)
-            got = result[: pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)
+            got = result[: pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, first pool pass
             line["parity_checked_reads"] = parity_check(job, code, quality, flag, got, min(pool_n, 1 << 19))
+        if args.host_staged:
+            # PCIe inclusive rate; never the headline value
+            m = args.host_staged
+            reps = -(-m // pool_n)
+            host_base = s.planes_from_rows(np.tile(code, (reps, 1))[:m], offsets)
+            host_qual = s.planes_from_rows(np.tile(quality, (reps, 1))[:m], offsets)
+            host_flag = np.tile(flag, reps)[:m].copy()
+            s.classify_host(m, host_base, host_qual, host_flag)            # allocates the pinned slots
+            t0 = time.perf_counter()
+            s.classify_host(m, host_base, host_qual, host_flag)
+            dt = time.perf_counter() - t0
+            line["host_staged"] = {"reads": m, "Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * bytes_per_read / dt / 1e9,
+                                   "note": "pageable host planes, memcpy to pinned slots, 2 streams, results copied back"}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

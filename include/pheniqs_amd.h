@@ -156,6 +156,17 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word);
 
+/* Measurement aid (the reference has no timers): when enabled, every kernel launch of
+ * phq_classify_* is bracketed by HIP events on its own stream.  phq_profile_collect waits for them, returns
+ * the summed milliseconds and the launch count per kernel kind, and forgets them. */
+#define PHQ_KERNEL_PAMLD_PRODUCT    0
+#define PHQ_KERNEL_PAMLD_LITERAL    1
+#define PHQ_KERNEL_MDD              2
+#define PHQ_KERNEL_COUNT            3
+#define PHQ_KERNEL_KINDS            4
+int phq_profile_enable(phq_decoder_set* set, int32_t enable);
+int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNEL_KINDS] */, int64_t* launches /* [PHQ_KERNEL_KINDS] */);
+
 /* Pinned host memory for batches handed to phq_classify_host (hipHostMalloc / hipHostFree). */
 int phq_host_alloc(uint64_t bytes, void** pointer);
 void phq_host_free(void* pointer);

@@ -25,7 +25,8 @@ DEVICE_NONE = -1
 SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq_get_decoder_info", "phq_set_mode",
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
-           "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double")
+           "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
+           "phq_profile_enable", "phq_profile_collect")
 
 
 class PheniqsError(RuntimeError):
@@ -86,6 +87,8 @@ def load_library():
     L.phq_stats_options.argtypes = [P, P, I32, P]
     L.phq_report_json.argtypes = [P, P, U64, U64, ctypes.POINTER(ctypes.c_char_p)]
     L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
+    L.phq_profile_enable.argtypes = [P, I32]
+    L.phq_profile_collect.argtypes = [P, P, P]
     _library = L
     return L
 
@@ -213,6 +216,18 @@ class DecoderSet:
         self._check(self.lib.phq_classify_host(self.handle, capacity, n, _pointer(base), _pointer(quality), _pointer(flag),
                                                result.ctypes.data, word.ctypes.data))
         return result[:self.n_result, :n], word[:n]
+
+    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count")
+
+    def profile_enable(self, enable: bool = True):
+        self._check(self.lib.phq_profile_enable(self.handle, 1 if enable else 0))
+
+    def profile_collect(self) -> Dict[str, Dict[str, float]]:
+        """{kernel kind: {"ms": summed event time, "launches": n}} since the last collect."""
+        ms = (ctypes.c_double * 4)()
+        launches = (ctypes.c_int64 * 4)()
+        self._check(self.lib.phq_profile_collect(self.handle, ms, launches))
+        return {name: {"ms": ms[k], "launches": launches[k]} for k, name in enumerate(self.KERNEL_KINDS) if launches[k]}
 
     # ---- statistics -----------------------------------------------------------------------------------
 

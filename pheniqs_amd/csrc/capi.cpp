@@ -196,6 +196,17 @@ int phq_report_json(phq_decoder_set* set, const uint64_t* host_words, uint64_t i
     });
 }
 
+int phq_profile_enable(phq_decoder_set* set, int32_t enable) {
+    return guarded(set, [&]() { require(set, "set"); set->impl.profile_enable(enable != 0); });
+}
+
+int phq_profile_collect(phq_decoder_set* set, double* milliseconds, int64_t* launches) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(milliseconds, "milliseconds"); require(launches, "launches");
+        set->impl.profile_collect(milliseconds, launches);
+    });
+}
+
 int phq_host_alloc(uint64_t bytes, void** pointer) {
     return guarded(nullptr, [&]() { require(pointer, "pointer"); *pointer = phq::host_alloc(static_cast<size_t>(bytes)); });
 }

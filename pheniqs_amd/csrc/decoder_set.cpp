@@ -21,6 +21,42 @@ void check(hipError_t status, const char* what) {
     throw InternalError(message);
 }
 
+}  // namespace
+
+// hipEventRecord right before and right after each kernel launch, on the launch stream
+struct DecoderSet::EventTimer : LaunchTimer {
+    struct Span { int32_t kind; hipEvent_t start; hipEvent_t stop; };
+    std::vector<Span> spans;
+    void begin(int32_t kind, void* stream) override {
+        Span span{kind, nullptr, nullptr};
+        check(hipEventCreate(&span.start), "hipEventCreate");
+        check(hipEventCreate(&span.stop), "hipEventCreate");
+        check(hipEventRecord(span.start, static_cast<hipStream_t>(stream)), "hipEventRecord");
+        spans.push_back(span);
+    }
+    void end(void* stream) override {
+        check(hipEventRecord(spans.back().stop, static_cast<hipStream_t>(stream)), "hipEventRecord");
+    }
+    void collect(double* milliseconds, int64_t* launches) {
+        for(int k = 0; k < KERNEL_KINDS; ++k) { milliseconds[k] = 0; launches[k] = 0; }
+        for(auto& span : spans) {
+            check(hipEventSynchronize(span.stop), "hipEventSynchronize");
+            float ms = 0;
+            check(hipEventElapsedTime(&ms, span.start, span.stop), "hipEventElapsedTime");
+            milliseconds[span.kind] += ms;
+            launches[span.kind] += 1;
+            (void)hipEventDestroy(span.start);
+            (void)hipEventDestroy(span.stop);
+        }
+        spans.clear();
+    }
+    ~EventTimer() override {
+        for(auto& span : spans) { (void)hipEventDestroy(span.start); (void)hipEventDestroy(span.stop); }
+    }
+};
+
+namespace {
+
 // bins whose counters fit a workgroup histogram (12 words of 8 bytes per bin) next to the Phred table
 constexpr int LDS_HISTOGRAM_MAX_BINS = 340;          // 340 * 96 B = 32 KiB
 
@@ -44,6 +80,7 @@ DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
     device_stats_(nullptr),
     device_worklist_(nullptr),
     worklist_capacity_(0),
+    timer_(nullptr),
     chunk_capacity_(0) {
     if(device_ >= 0) {
         try {
@@ -55,7 +92,23 @@ DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
     }
 }
 
-DecoderSet::~DecoderSet() { release(); }
+DecoderSet::~DecoderSet() {
+    delete timer_;
+    timer_ = nullptr;
+    release();
+}
+
+void DecoderSet::profile_enable(bool enable) {
+    require_device();
+    if(enable && timer_ == nullptr) { timer_ = new EventTimer(); }
+    if(!enable) { delete timer_; timer_ = nullptr; }
+}
+
+void DecoderSet::profile_collect(double* milliseconds, int64_t* launches) {
+    require_device();
+    if(timer_ == nullptr) { throw InternalError("profiling is not enabled"); }
+    timer_->collect(milliseconds, launches);
+}
 
 void DecoderSet::release() {
     if(device_ >= 0) { (void)hipSetDevice(device_); }
@@ -342,7 +395,7 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         args.stats = device_stats_;
         args.first_stage = k == 0 ? 1 : 0;
         args.last_stage = k + 1 == n_decoder ? 1 : 0;
-        check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream)), "kernel launch");
+        check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream, timer_)), "kernel launch");
     }
 }
 

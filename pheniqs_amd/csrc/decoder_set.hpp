@@ -47,6 +47,10 @@ public:
     void stats_allreduce(void* rccl_comm, void* stream);
     const std::string& report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count);
 
+    // HIP event timing of every kernel launch (bench.py roofline): enable, run, then collect sums per kernel kind
+    void profile_enable(bool enable);
+    void profile_collect(double* milliseconds, int64_t* launches);
+
     std::string last_error;
 
 private:
@@ -71,6 +75,8 @@ private:
     uint32_t* device_worklist_;                 // read ordinals deferred by the product form kernel + 1 counter word in front
     int64_t worklist_capacity_;
     std::string report_;
+    struct EventTimer;
+    EventTimer* timer_;
 
     // host staged pipeline (classify_host): two slots of device buffers + pinned bounce buffers
     struct Slot {

@@ -103,8 +103,16 @@ struct StageArgs {
     int32_t worklist_stride;
 };
 
+// Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
+enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_KINDS = 4 };
+struct LaunchTimer {
+    virtual ~LaunchTimer() {}
+    virtual void begin(int32_t kind, void* stream) = 0;
+    virtual void end(void* stream) = 0;
+};
+
 // implemented in the kernel translation units; all return a hipError_t value
-int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream);
+int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer);
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode);
 
 }  // namespace phq

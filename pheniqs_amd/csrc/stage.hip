@@ -20,7 +20,16 @@ bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
     return mode == MODE_FAST && host_decoder.algorithm == 1 && pamld_lut_supports(host_decoder);
 }
 
-int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream) {
+namespace {
+struct Timed {
+    LaunchTimer* timer;
+    void* stream;
+    Timed(LaunchTimer* timer, int32_t kind, void* stream) : timer(timer), stream(stream) { if(timer) { timer->begin(kind, stream); } }
+    ~Timed() { if(timer) { timer->end(stream); } }
+};
+}  // namespace
+
+int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
     if(args.n_read <= 0) { return static_cast<int>(hipSuccess); }
     const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
     const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
@@ -39,15 +48,29 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 StageArgs producer = args;
                 producer.worklist_role = 1;
                 producer.worklist_stride = static_cast<int32_t>(tiles_per_block * threads);
-                int status = launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
+                int status;
+                {
+                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
+                    status = launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
+                }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
+                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
                 return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
             }
-            return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
-        case 2: return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
-        default: return launch_count(args, host_decoder, grid, histogram_bytes, s);
+            {
+                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
+                return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+            }
+        case 2: {
+            Timed timed(timer, KERNEL_MDD, stream);
+            return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
+        }
+        default: {
+            Timed timed(timer, KERNEL_COUNT, stream);
+            return launch_count(args, host_decoder, grid, histogram_bytes, s);
+        }
     }
 }
 
