@@ -45,7 +45,8 @@ extern "C" {
 #define PHQ_STATUS_UNCLASSIFIED     3   /* mdd.cpp:82-84: no barcode within tolerance, QC fail */
 
 #define PHQ_MODE_LITERAL            0   /* every barcode scored with the reference's own Kahan recurrence */
-#define PHQ_MODE_FAST               1   /* product form scoring, near ties re-scored literally */
+#define PHQ_MODE_FAST               1   /* PAMLD: product form scoring, ambiguous reads re-scored literally;
+                                           MDD: exact match lookup, the rest scanned */
 
 #define PHQ_DEVICE_NONE            (-1) /* host only set: configuration, staging, statistics, report */
 
@@ -163,7 +164,8 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
 #define PHQ_KERNEL_PAMLD_LITERAL    1
 #define PHQ_KERNEL_MDD              2
 #define PHQ_KERNEL_COUNT            3
-#define PHQ_KERNEL_KINDS            4
+#define PHQ_KERNEL_MDD_EXACT        4
+#define PHQ_KERNEL_KINDS            5
 int phq_profile_enable(phq_decoder_set* set, int32_t enable);
 int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNEL_KINDS] */, int64_t* launches /* [PHQ_KERNEL_KINDS] */);
 

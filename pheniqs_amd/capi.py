@@ -217,15 +217,15 @@ class DecoderSet:
                                                result.ctypes.data, word.ctypes.data))
         return result[:self.n_result, :n], word[:n]
 
-    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count")
+    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact")
 
     def profile_enable(self, enable: bool = True):
         self._check(self.lib.phq_profile_enable(self.handle, 1 if enable else 0))
 
     def profile_collect(self) -> Dict[str, Dict[str, float]]:
         """{kernel kind: {"ms": summed event time, "launches": n}} since the last collect."""
-        ms = (ctypes.c_double * 4)()
-        launches = (ctypes.c_int64 * 4)()
+        ms = (ctypes.c_double * len(self.KERNEL_KINDS))()
+        launches = (ctypes.c_int64 * len(self.KERNEL_KINDS))()
         self._check(self.lib.phq_profile_collect(self.handle, ms, launches))
         return {name: {"ms": ms[k], "launches": launches[k]} for k, name in enumerate(self.KERNEL_KINDS) if launches[k]}
 

@@ -220,6 +220,31 @@ void DecoderSet::build_device_images() {
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));
+            if(c.all_strict && c.algorithm == Algorithm::MDD && d.n_barcode > 0) {
+                // exact match hash (mdd.cpp:29-31,43-46): keys are the full length barcodes, 2 bits per base
+                uint32_t slots = 16;
+                while(slots < 4u * static_cast<uint32_t>(d.n_barcode)) { slots <<= 1; }
+                std::vector<uint32_t> table(static_cast<size_t>(slots) * 4, 0u);
+                int32_t longest = 1;
+                for(int32_t b = 0; b < d.n_barcode; ++b) {
+                    uint32_t key[2] = {0, 0};
+                    for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        key[j >> 4] |= two << (2 * (j & 15));
+                    }
+                    uint32_t h = (key[0] * 0x9e3779b1u) ^ (key[1] * 0x85ebca77u);
+                    h ^= h >> 15;
+                    int32_t probe = 0;
+                    while(table[static_cast<size_t>((h + static_cast<uint32_t>(probe)) & (slots - 1)) * 4 + 2] != 0u) { ++probe; }
+                    uint32_t* slot = &table[static_cast<size_t>((h + static_cast<uint32_t>(probe)) & (slots - 1)) * 4];
+                    slot[0] = key[0]; slot[1] = key[1]; slot[2] = static_cast<uint32_t>(b + 1);
+                    longest = std::max(longest, probe + 1);
+                }
+                d.exact_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
+                d.exact_slots = slots;
+                d.exact_probes = longest + 1;
+            }
             if(c.all_strict && c.nucleotide_cardinality <= 16 && d.n_barcode > 0) {
                 const int32_t padded = (d.n_barcode + 3) / 4 * 4;
                 const bool paired = c.nucleotide_cardinality <= 8;
@@ -366,7 +391,7 @@ size_t DecoderSet::worklist_words(int64_t n_read) const {
         const int64_t tiles_per_block = (tiles + grid - 1) / grid;
         worst = std::max(worst, static_cast<size_t>(grid * tiles_per_block * threads));
     }
-    return static_cast<size_t>(max_blocks_) + worst + 512;
+    return static_cast<size_t>(max_blocks_) + worst + static_cast<size_t>(max_blocks_) * 1024 + 512;      // + the 4 tile passes of the MDD exact kernel
 }
 
 bool DecoderSet::needs_worklist() const {

@@ -77,6 +77,11 @@ struct DevDecoder {
     // barcodes share a word (even barcode in the low half); padded to whole groups of 4 barcodes
     const uint32_t* barcode_packed2;
     const float* concentration_single;    // padded with zeros to whole groups of 4 barcodes
+    // MDD exact match (mdd.cpp:43-46): open addressing hash of the ACGT barcodes; slot = {key low, key high,
+    // ordinal + 1 (0 = empty), unused}, key = 2 bits per base, position j at bits 2j
+    const uint32_t* exact_table;
+    uint32_t exact_slots;                 // power of two
+    int32_t exact_probes;                 // longest probe sequence + 1
 };
 
 enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };
@@ -104,7 +109,7 @@ struct StageArgs {
 };
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
-enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_KINDS = 4 };
+enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_KINDS = 5 };
 struct LaunchTimer {
     virtual ~LaunchTimer() {}
     virtual void begin(int32_t kind, void* stream) = 0;

@@ -173,6 +173,10 @@ __device__ __forceinline__ void load_plane_row(const uint8_t* plane, int64_t i, 
 int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 int launch_count(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool mdd_scan_supports(const DevDecoder& host_decoder);
+int launch_mdd_scan(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool mdd_exact_supports(const DevDecoder& host_decoder);
+int launch_mdd_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool pamld_lut_supports(const DevDecoder& host_decoder);
 int pamld_lut_block(const DevDecoder& host_decoder);       // threads per workgroup of the product form kernel
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);

@@ -34,17 +34,32 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
     const int n_word = d.n_word;
     const int L = d.nucleotide_cardinality;
     const int stride = d.plane_stride;
-    const int64_t n = args.n_read;
+    // as the second tier of PHQ_MODE_FAST workgroup g visits only the reads the exact match kernel deferred
+    const bool consumer = args.worklist_role == 2;
+    const uint32_t* const segment = consumer ? args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride : nullptr;
+    const int64_t n = consumer ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
+    const int64_t tile_first = consumer ? 0 : blockIdx.x;
+    const int64_t tile_step = consumer ? 1 : gridDim.x;
 
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const int64_t i = tile * BLOCK + threadIdx.x;
-        const bool active = i < n;
+    for(int64_t tile = tile_first; tile < tiles; tile += tile_step) {
+        const int64_t k = tile * BLOCK + threadIdx.x;
+        const bool active = k < n;
         ReadState r{false, 0};
         if(active) {
+            const int64_t i = consumer ? static_cast<int64_t>(segment[k]) : k;
             r = load_read_state(args, i);
             const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
             const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+            // all loads first (the rows are at most 2 W words; words past the plane stride are not touched)
+            uint32_t code_words[2 * W];
+            uint32_t quality_words[2 * W];
+#pragma unroll
+            for(int g = 0; g < 2 * W; ++g) {
+                const bool inside = 4 * g < stride;
+                code_words[g] = inside ? code_row[inside ? g : 0] : 0u;
+                quality_words[g] = inside ? quality_row[inside ? g : 0] : 0u;
+            }
             uint32_t observed[W];
             uint32_t masked[W];      // quality below the masking threshold (sequence.h:324-326)
             uint32_t counted[W];     // positions inside the observed length of their segment
@@ -54,8 +69,8 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
 #pragma unroll
             for(int g = 2 * W - 1; g >= 0; --g) {          // groups of 4 positions = one 32-bit load per plane
                 if(4 * g < L) {
-                    const uint32_t cw = code_row[g];
-                    const uint32_t qw = quality_row[g];
+                    const uint32_t cw = code_words[g];
+                    const uint32_t qw = quality_words[g];
 #pragma unroll
                     for(int k = 3; k >= 0; --k) {
                         const int j = 4 * g + k;
@@ -129,6 +144,131 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
     histogram_flush(args, d, histogram);
 }
 
+// Tier 1 of PHQ_MODE_FAST for MDD: the reference's own first step, "try a perfect match to the full barcode
+// sequence" (mdd.cpp:43-46, an unordered_map keyed by the BAM coded concatenation, mdd.cpp:29-31).  Here: the
+// observation packed 2 bits per base is looked up in an open addressing hash table of the barcodes (built by
+// the host, load factor <= 1/4).  A hit finishes the read — index, distance 0, counters — having read only its
+// bases; everything else (a base outside ACGT, a short observation, no exact match: ~18 % of the C2 reads) goes
+// to the workgroup's worklist segment for the scan kernel.  This kernel is a pure stream: ~30 B per read.
+template <int ROW_WORDS>
+__global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
+    constexpr int READS = 4;                         // reads per lane and pass: independent loads in flight
+    __shared__ uint32_t deferred_total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const int L = d.nucleotide_cardinality;
+    constexpr int stride = 4 * ROW_WORDS;            // = d.plane_stride
+    const uint32_t slot_mask = d.exact_slots - 1u;
+    const uint4* const table = reinterpret_cast<const uint4*>(d.exact_table);
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + BLOCK - 1) / BLOCK;
+
+    for(int64_t tile = static_cast<int64_t>(blockIdx.x) * READS; tile < tiles; tile += static_cast<int64_t>(gridDim.x) * READS) {
+        int64_t index[READS];
+        bool active[READS];
+        ReadState state[READS];
+        uint32_t row[READS][ROW_WORDS];
+        // every load of the pass is issued before the first use: lanes past the end re-read the last read
+        int64_t safe[READS];
+#pragma unroll
+        for(int u = 0; u < READS; ++u) {
+            index[u] = (tile + u) * BLOCK + threadIdx.x;
+            active[u] = index[u] < n;
+            safe[u] = active[u] ? index[u] : n - 1;
+            const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + safe[u] * stride);
+#pragma unroll
+            for(int g = 0; g < ROW_WORDS; ++g) { row[u][g] = code_row[g]; }
+        }
+        // the carried state of the four reads under ONE uniform branch (a branch per read would wait per read)
+        uint32_t carried[READS];
+        if(args.first_stage) {
+            if(args.input_flag) {
+#pragma unroll
+                for(int u = 0; u < READS; ++u) { carried[u] = (args.input_flag[safe[u]] & 1u) << 31; }
+            } else {
+#pragma unroll
+                for(int u = 0; u < READS; ++u) { carried[u] = 0; }
+            }
+        } else {
+#pragma unroll
+            for(int u = 0; u < READS; ++u) { carried[u] = args.word[safe[u]]; }
+        }
+#pragma unroll
+        for(int u = 0; u < READS; ++u) {
+            state[u].qcfail = (carried[u] >> 31) != 0;
+            state[u].channel = static_cast<int32_t>(carried[u] & 0x7fffffffu);
+        }
+        uint32_t key[READS][2];
+        bool valid[READS];
+#pragma unroll
+        for(int u = 0; u < READS; ++u) {
+            key[u][0] = 0; key[u][1] = 0;
+            valid[u] = active[u];
+#pragma unroll
+            for(int j = 0; j < 4 * ROW_WORDS; ++j) {
+                if(j < L) {
+                    const uint32_t c = (row[u][j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    valid[u] = valid[u] && strict_code(c) && c < 16u;
+                    key[u][(j >> 4) & 1] |= ((0x30210u >> (2 * (c & 0xfu))) & 3u) << (2 * (j & 15));
+                }
+            }
+        }
+        int bin[READS];
+#pragma unroll
+        for(int u = 0; u < READS; ++u) {
+            bin[u] = 0;
+            if(valid[u]) {
+                uint32_t h = (key[u][0] * 0x9e3779b1u) ^ (key[u][1] * 0x85ebca77u);
+                h ^= h >> 15;
+                for(int probe = 0; probe < d.exact_probes; ++probe) {
+                    const uint4 entry = table[(h + probe) & slot_mask];
+                    if(entry.z == 0u) { break; }                       // empty slot: not a barcode
+                    if(entry.x == key[u][0] && entry.y == key[u][1]) { bin[u] = static_cast<int>(entry.z); break; }
+                }
+            }
+        }
+#pragma unroll
+        for(int u = 0; u < READS; ++u) {
+            const bool defer = active[u] && bin[u] == 0;
+            if(active[u] && !defer) {
+                decoder_tail(d, sink, state[u], bin[u], 0);
+                if(args.result) {
+                    DevResult out;
+                    out.index = d.barcode_index[bin[u] - 1];
+                    out.distance = 0;
+                    out.hq_distance = 0;
+                    out.status = STATUS_PASS;
+                    out.qcfail = state[u].qcfail ? 1 : 0;
+                    out.confidence = 0;
+                    args.result[index[u]] = out;
+                }
+                store_read_state(args, index[u], state[u]);
+            }
+            const unsigned long long deferred = __ballot(defer);
+            if(deferred) {
+                const int lane = threadIdx.x & 63;
+                uint32_t first = 0;
+                if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+                first = __shfl(first, 0);
+                if(defer) {
+                    segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(index[u]);
+                }
+            }
+            count_outgoing(args, histogram, active[u] && !defer, state[u]);
+        }
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
 // NaiveMolecularDecoder (naive.h:40-45) and the bare Classifier<Barcode> a passthrough decoder is
 // (transcode.cpp:77-80): decoded never leaves `unclassified`, so the stage only counts.
 __global__ __launch_bounds__(BLOCK) void count_kernel(StageArgs args) {
@@ -175,6 +315,25 @@ int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid,
         case 2: hipLaunchKernelGGL((mdd_kernel<2>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
         case 3: hipLaunchKernelGGL((mdd_kernel<3>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
         case 4: hipLaunchKernelGGL((mdd_kernel<4>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+bool mdd_exact_supports(const DevDecoder& host_decoder) {
+    return host_decoder.exact_table != nullptr && host_decoder.exact_slots > 0;
+}
+
+int launch_mdd_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    switch(host_decoder.plane_stride / 4) {
+        case 1: hipLaunchKernelGGL((mdd_exact_kernel<1>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((mdd_exact_kernel<2>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((mdd_exact_kernel<3>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((mdd_exact_kernel<4>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 5: hipLaunchKernelGGL((mdd_exact_kernel<5>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 6: hipLaunchKernelGGL((mdd_exact_kernel<6>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 7: hipLaunchKernelGGL((mdd_exact_kernel<7>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 8: hipLaunchKernelGGL((mdd_exact_kernel<8>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());

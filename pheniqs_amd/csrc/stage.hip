@@ -17,7 +17,9 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 }
 
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
-    return mode == MODE_FAST && host_decoder.algorithm == 1 && pamld_lut_supports(host_decoder);
+    if(mode != MODE_FAST) { return false; }
+    return (host_decoder.algorithm == 1 && pamld_lut_supports(host_decoder)) ||
+           (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
 
 namespace {
@@ -64,6 +66,25 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
+            if(stage_uses_worklist(host_decoder, mode)) {
+                // tier 1: exact match lookup over every read; tier 2: the scan kernel on what it deferred (same grid)
+                // the exact match kernel takes 4 tiles per pass, so a workgroup may own up to 3 tiles more than its share
+                const int64_t tiles_per_block = (tiles + 4 * grid.x - 1) / (4 * grid.x) * 4;
+                StageArgs producer = args;
+                producer.worklist_role = 1;
+                producer.worklist_stride = static_cast<int32_t>(tiles_per_block * BLOCK);
+                int status;
+                {
+                    Timed timed(timer, KERNEL_MDD_EXACT, stream);
+                    status = launch_mdd_exact(producer, host_decoder, grid, histogram_bytes, s);
+                }
+                if(status != 0) { return status; }
+                StageArgs consumer = producer;
+                consumer.worklist_role = 2;
+                Timed timed(timer, KERNEL_MDD, stream);
+                if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, grid, histogram_bytes, s); }
+                return launch_mdd(consumer, host_decoder, grid, histogram_bytes, s);
+            }
             Timed timed(timer, KERNEL_MDD, stream);
             return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
         }

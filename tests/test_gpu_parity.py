@@ -53,6 +53,12 @@ def run_gpu(torch, job, code, quality, flag, offsets, mode=capi.MODE_LITERAL, pi
 
 
 def assert_parity(oracle, torch, job, code, quality, flag, offsets, **kwargs):
+    """Without an explicit mode the case runs in both: PHQ_MODE_LITERAL and PHQ_MODE_FAST (the default)."""
+    if "mode" not in kwargs:
+        out = None
+        for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
+            out = assert_parity(oracle, torch, job, code, quality, flag, offsets, mode=mode, **kwargs)
+        return out
     engine = oracle.OracleJob(job)
     expected, expected_word = engine.classify(code, quality, flag)
     s, got, word, words = run_gpu(torch, job, code, quality, flag, offsets, **kwargs)
@@ -152,8 +158,6 @@ MODES = [capi.MODE_LITERAL, capi.MODE_FAST]
     ("C5", "pamld", 1 << 14), ("C5", "mdd", 1 << 14),
 ])
 def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n, mode):
-    if algorithm == "mdd" and mode == capi.MODE_FAST:
-        pytest.skip("MDD has a single kernel")
     job, recipe = synthetic.config_job(name, algorithm)
     code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
