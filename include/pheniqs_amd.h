@@ -157,6 +157,17 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word);
 
+/* ---- the steps either side of the path -----------------------------------
+ * Transcode::pull + TranscodingThread::run for FASTQ inputs and one SAM text output: n_input synchronised
+ * FASTQ files (plain or gzip), one per input segment (fastq.h:55-78,253-285,427-440; read.h:253-264),
+ * batches of batch_capacity reads through phq_stage_reads and phq_classify_host, then per read the output
+ * segments of the job's `template` (transform.h:190-226) with the tags Read::flush sets (read.h:187-237)
+ * in Auxiliary::encode order (auxiliary.cpp:327-354), printed the way htslib prints SAM.  No header lines
+ * (@HD/@RG/@PG belong to the SAM header model, out of scope).  Counters accumulate in the set; the incoming
+ * counters of Transcode::pull (transcode.cpp:304-309) are added to *incoming_count / *incoming_pf_count. */
+int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char* const* input_path, const char* sam_output_path,
+                               int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
+
 /* Measurement aid (the reference has no timers): when enabled, every kernel launch of
  * phq_classify_* is bracketed by HIP events on its own stream.  phq_profile_collect waits for them, returns
  * the summed milliseconds and the launch count per kernel kind, and forgets them. */

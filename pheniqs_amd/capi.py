@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect")
+           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam")
 
 
 class PheniqsError(RuntimeError):
@@ -87,6 +87,7 @@ def load_library():
     L.phq_stats_options.argtypes = [P, P, I32, P]
     L.phq_report_json.argtypes = [P, P, U64, U64, ctypes.POINTER(ctypes.c_char_p)]
     L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
+    L.phq_transcode_fastq_to_sam.argtypes = [P, I32, P, ctypes.c_char_p, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
     _library = L
@@ -216,6 +217,15 @@ class DecoderSet:
         self._check(self.lib.phq_classify_host(self.handle, capacity, n, _pointer(base), _pointer(quality), _pointer(flag),
                                                result.ctypes.data, word.ctypes.data))
         return result[:self.n_result, :n], word[:n]
+
+    def transcode_fastq_to_sam(self, inputs: Sequence[str], output: str, batch_capacity: int = 1 << 20):
+        """FASTQ files in (one per input segment), SAM records out; returns the incoming (count, pf count)."""
+        paths = (ctypes.c_char_p * len(inputs))(*[p.encode() for p in inputs])
+        incoming = ctypes.c_uint64(0)
+        incoming_pf = ctypes.c_uint64(0)
+        self._check(self.lib.phq_transcode_fastq_to_sam(self.handle, len(inputs), paths, output.encode(), batch_capacity,
+                                                        ctypes.byref(incoming), ctypes.byref(incoming_pf)))
+        return incoming.value, incoming_pf.value
 
     KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact")
 

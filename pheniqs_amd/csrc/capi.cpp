@@ -8,6 +8,7 @@
 #include "decoder_set.hpp"
 #include "error.hpp"
 #include "stats.hpp"
+#include "transcoder.hpp"
 
 struct phq_decoder_set {
     phq::DecoderSet impl;
@@ -204,6 +205,19 @@ int phq_profile_collect(phq_decoder_set* set, double* milliseconds, int64_t* lau
     return guarded(set, [&]() {
         require(set, "set"); require(milliseconds, "milliseconds"); require(launches, "launches");
         set->impl.profile_collect(milliseconds, launches);
+    });
+}
+
+int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char* const* input_path, const char* sam_output_path,
+                               int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(input_path, "input_path"); require(sam_output_path, "sam_output_path");
+        require(incoming_count, "incoming_count"); require(incoming_pf_count, "incoming_pf_count");
+        if(batch_capacity <= 0) { throw phq::InternalError("batch capacity must be positive"); }
+        std::vector<std::string> input;
+        for(int32_t i = 0; i < n_input; ++i) { require(input_path[i], "input_path[i]"); input.emplace_back(input_path[i]); }
+        phq::Transcoder transcoder(set->impl, input, sam_output_path, batch_capacity);
+        transcoder.run(*incoming_count, *incoming_pf_count);
     });
 }
 

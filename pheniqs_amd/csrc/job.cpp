@@ -136,8 +136,8 @@ TokenConfig parse_token(const std::string& pattern) {
 }
 
 // knit syntax `[~]token[:[~]token...]` per observation segment (reference transform.cpp:252-331)
-std::vector<TransformConfig> parse_rule(const Json& decoder, int32_t& output_segment_cardinality) {
-    const Json& rule = require(decoder, "transform");
+std::vector<TransformConfig> parse_rule(const Json& decoder, int32_t& output_segment_cardinality, const char* key = "transform") {
+    const Json& rule = require(decoder, key);
     if(!rule.is_object()) { throw ConfigurationError("element transform must be a dictionary"); }
     const Json& token_node = require(rule, "token");
     if(!token_node.is_array()) { throw ConfigurationError("token element must be an array"); }
@@ -336,6 +336,16 @@ JobConfig JobConfig::from_json(const Json& document) {
     job.filter_incoming_qc_fail = get_bool(document, "filter incoming qc fail", false);
     job.min_input_length = get_int_array(document, "min input length");
     job.float_precision = get_int(document, "float precision", 15);
+    job.input_phred_offset = get_int(document, "input phred offset", 33);
+    job.output_phred_offset = get_int(document, "output phred offset", 33);
+    job.output_segment_cardinality = get_int(document, "output segment cardinality", 0);
+    if(const Json* node = document.find("template")) {
+        if(node->is_object() && node->find("transform") != nullptr) {
+            int32_t segments = 0;
+            job.template_transform = parse_rule(*node, segments);
+            if(job.output_segment_cardinality == 0) { job.output_segment_cardinality = segments; }
+        }
+    }
 
     int32_t multiplexing = 0;
     int32_t column = 0;

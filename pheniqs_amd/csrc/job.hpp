@@ -88,6 +88,10 @@ struct JobConfig {
     bool filter_incoming_qc_fail;
     std::vector<int32_t> min_input_length;
     int32_t float_precision;
+    int32_t input_phred_offset;            // fastq.h:63-77 subtracts it, sequence.h:450-459 adds the output one back
+    int32_t output_phred_offset;
+    int32_t output_segment_cardinality;
+    std::vector<TransformConfig> template_transform;   // TemplateRule (transform.h:172-226); input segment -1/-2/-3 = corrected sample / cellular / molecular barcode
     int32_t plane_width;                  // bytes per read over all observation planes
     int32_t nucleotide_width;             // sum of nucleotide cardinality over all decoders
     int32_t result_count;                 // number of PAMLD / MDD decoders

@@ -374,3 +374,46 @@ def test_counter_allreduce_over_rccl_single_rank(oracle, torch_cuda):
         assert np.array_equal(s.stats_export(), words)
     finally:
         dist.destroy_process_group()
+
+
+# ---- the steps either side of the path: FASTQ in, SAM records out ---------------------
+
+
+@pytest.mark.parametrize("batch_capacity,compressed", [(1 << 16, False), (100, False), (64, True)])
+def test_bdggg_fastq_to_sam_is_the_golden_file(torch_cuda, tmp_path, batch_capacity, compressed):
+    """The reference's own compiled job (valid/compile_annotated.out, unchanged) and its three FASTQ files through
+    phq_transcode_fastq_to_sam: every alignment record of valid/annotated.out, byte for byte.  (The @HD/@RG/@PG
+    header lines belong to the SAM header model, out of scope.)"""
+    import gzip
+    import os
+    import shutil
+    inputs = []
+    for k in (1, 2, 3):
+        source = os.path.join(bdggg.HERE, "BDGGG_s0%d.fastq" % k)
+        if compressed:
+            target = os.path.join(tmp_path, "s0%d.fastq.gz" % k)
+            with open(source, "rb") as a, gzip.open(target, "wb") as b:
+                shutil.copyfileobj(a, b)
+            source = target
+        inputs.append(source)
+    s = DecoderSet(json.dumps(bdggg.compiled_reference_job()), device=0)
+    output = os.path.join(tmp_path, "out.sam")
+    incoming = s.transcode_fastq_to_sam(inputs, output, batch_capacity)
+    assert incoming == (250, 243)
+    golden = [line for line in open(os.path.join(bdggg.HERE, "annotated.out.sam")) if not line.startswith("@")]
+    mine = open(output).readlines()
+    assert len(mine) == len(golden) == 496
+    for a, b in zip(mine, golden):
+        assert a == b
+    # and the report of the same run, against valid/annotated.err
+    report = json.loads(s.report(s.stats_export(), incoming))
+    theirs = bdggg.golden_report()
+    assert report["incoming"] == theirs["incoming"]
+    assert report["outgoing"]["count"] == theirs["outgoing"]["count"] and report["outgoing"]["pf count"] == theirs["outgoing"]["pf count"]
+    for mine_block, their_block in ((report["sample"], theirs["sample"]), (report["cellular"][0], theirs["cellular"][0]), (report["molecular"][0], theirs["molecular"][0])):
+        for key in ("count", "pf count", "classified count", "pf classified count"):
+            assert mine_block[key] == their_block[key]
+        for m, t in zip(mine_block.get("classified", []), their_block.get("classified", [])):
+            assert (m["count"], m["pf count"], m.get("low confidence count"), m.get("low conditional confidence count")) == \
+                   (t["count"], t["pf count"], t.get("low confidence count"), t.get("low conditional confidence count"))
+            assert abs(m["average confidence"] - t["average confidence"]) < 1e-12
