@@ -468,10 +468,21 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
     if(n_read > batch_capacity) { throw OverflowError("read count exceeds the batch capacity"); }
     const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 22);
     ensure_pipeline(chunk);
+    // batches that already live in pinned memory (phq_host_alloc) are copied straight from / to the caller's
+    // buffers; pageable ones bounce through the slot's pinned buffers
+    auto pinned = [](const void* pointer) {
+        if(pointer == nullptr) { return true; }
+        hipPointerAttribute_t attributes;
+        if(hipPointerGetAttributes(&attributes, pointer) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return attributes.type == hipMemoryTypeHost;
+    };
+    const bool direct_in = pinned(base_planes) && pinned(quality_planes) && pinned(flag);
+    const bool direct_out = pinned(result) && pinned(word);
 
     auto drain = [&](Slot& slot) {
         if(!slot.busy) { return; }
         check(hipEventSynchronize(static_cast<hipEvent_t>(slot.done)), "hipEventSynchronize");
+        if(direct_out) { slot.busy = false; return; }
         for(const auto& c : job_.decoder) {
             if(c.result_slot >= 0 && result != nullptr) {
                 std::memcpy(result + static_cast<int64_t>(c.result_slot) * batch_capacity + slot.first,
@@ -494,25 +505,38 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
             const size_t bytes = static_cast<size_t>(count) * static_cast<size_t>(c.plane_stride);
             const int64_t source = batch_capacity * c.plane_prefix + first * c.plane_stride;
             const int64_t target = chunk_capacity_ * c.plane_prefix;
-            std::memcpy(slot.pinned_base + target, base_planes + source, bytes);
-            std::memcpy(slot.pinned_quality + target, quality_planes + source, bytes);
-            check(hipMemcpyAsync(slot.device_base + target, slot.pinned_base + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
-            check(hipMemcpyAsync(slot.device_quality + target, slot.pinned_quality + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            if(direct_in) {
+                check(hipMemcpyAsync(slot.device_base + target, base_planes + source, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_quality + target, quality_planes + source, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            } else {
+                std::memcpy(slot.pinned_base + target, base_planes + source, bytes);
+                std::memcpy(slot.pinned_quality + target, quality_planes + source, bytes);
+                check(hipMemcpyAsync(slot.device_base + target, slot.pinned_base + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_quality + target, slot.pinned_quality + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            }
         }
         if(flag != nullptr) {
-            std::memcpy(slot.pinned_flag, flag + first, static_cast<size_t>(count));
-            check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            if(direct_in) {
+                check(hipMemcpyAsync(slot.device_flag, flag + first, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            } else {
+                std::memcpy(slot.pinned_flag, flag + first, static_cast<size_t>(count));
+                check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            }
         }
         run_stages(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
                    slot.device_result, slot.device_word, stream, slot.device_worklist);
         for(const auto& c : job_.decoder) {
             if(c.result_slot >= 0 && result != nullptr) {
                 const int64_t plane = static_cast<int64_t>(c.result_slot) * chunk_capacity_;
-                check(hipMemcpyAsync(slot.pinned_result + plane, slot.device_result + plane, static_cast<size_t>(count) * sizeof(DevResult),
+                DevResult* target = direct_out ? result + static_cast<int64_t>(c.result_slot) * batch_capacity + first : slot.pinned_result + plane;
+                check(hipMemcpyAsync(target, slot.device_result + plane, static_cast<size_t>(count) * sizeof(DevResult),
                                      hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             }
         }
-        check(hipMemcpyAsync(slot.pinned_word, slot.device_word, static_cast<size_t>(count) * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        if(word != nullptr || !direct_out) {
+            check(hipMemcpyAsync(direct_out ? word + first : slot.pinned_word, slot.device_word, static_cast<size_t>(count) * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        }
         check(hipEventRecord(static_cast<hipEvent_t>(slot.done), stream), "hipEventRecord");
         slot.busy = true;
         slot.first = first;
