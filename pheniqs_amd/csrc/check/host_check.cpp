@@ -1,0 +1,71 @@
+// Host-only self check of the library's CPU side, built with AddressSanitizer + UBSan (make -C pheniqs_amd/csrc asan):
+// JSON reader, compiled job model, PhredScale, statistics model, report writer.  GPU sanitizers are not available
+// on the target pool, so the device code is checked by the oracle parity tests instead.
+//
+// usage: host_check <compiled job json> [more jobs ...]
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <vector>
+
+#include "../error.hpp"
+#include "../job.hpp"
+#include "../json.hpp"
+#include "../phred.hpp"
+#include "../stats.hpp"
+
+static int failures = 0;
+#define CHECK(condition) do { if(!(condition)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #condition); ++failures; } } while(0)
+
+int main(int argc, char** argv) {
+    using namespace phq;
+    const PhredScale& scale = PhredScale::get_instance();
+    CHECK(scale.substitution_quality(1, 1, 30) == scale.true_positive_quality[30]);
+    CHECK(scale.substitution_quality(1, 2, 30) == 30.0);
+    CHECK(scale.substitution_quality(1, 15, 30) == scale.uniform_base_quality);
+    CHECK(scale.substitution_quality(1, 1, 0) == 0.0);
+    CHECK(std::fabs(scale.uniform_probability - 0.25) < 1e-15);
+    CHECK(format_double(0.18 * (1 - 0.015), 15) == "0.177299999999999");
+    CHECK(format_double(1.0 / 65536, 15) == "0.000015258789062");
+    CHECK(format_double(248.0, 15) == "248.0");
+
+    // malformed documents must throw ConfigurationError, never crash
+    const char* broken[] = {"", "{", "{\"a\":", "[1,2", "{\"a\" 1}", "\"unterminated", "{\"sample\": {\"algorithm\": 3}}", "nul", "{\"a\": 1} trailing"};
+    for(const char* text : broken) {
+        bool threw = false;
+        try { JobConfig::from_json(Json::parse(text)); } catch(const Error&) { threw = true; }
+        CHECK(threw || std::string(text) == "{\"a\": 1} trailing");
+    }
+
+    for(int i = 1; i < argc; ++i) {
+        std::ifstream file(argv[i]);
+        std::stringstream content;
+        content << file.rdbuf();
+        try {
+            const Json document = Json::parse(content.str());
+            const JobConfig job = JobConfig::from_json(document);
+            CHECK(!job.decoder.empty());
+            // a deterministic pseudo random counter buffer through decode / finalize / encode
+            std::vector<uint64_t> words(static_cast<size_t>(job.stats_words));
+            uint64_t state = 88172645463325252ull;
+            for(auto& w : words) { state ^= state << 13; state ^= state >> 7; state ^= state << 17; w = state % 100000; }
+            const Json report = encode_report(job, words.data(), 1000000, 990000);
+            const std::string text = report.dump(job.float_precision);
+            const Json again = Json::parse(text);
+            CHECK(again.is_object() && !again.members().empty());
+            // and the all-zero buffer (every guard against division by zero, selector.cpp:78-101,197-214)
+            std::vector<uint64_t> zero(static_cast<size_t>(job.stats_words), 0);
+            CHECK(!encode_report(job, zero.data(), 0, 0).dump(15).empty());
+            std::printf("%s: %zu decoders, %lld counter words, report %zu bytes\n", argv[i], job.decoder.size(),
+                        static_cast<long long>(job.stats_words), text.size());
+        } catch(const Error& e) {
+            std::fprintf(stderr, "%s: %s\n", argv[i], e.what());
+            ++failures;
+        }
+    }
+    if(failures) { std::fprintf(stderr, "%d failure(s)\n", failures); return 1; }
+    std::puts("host check ok");
+    return 0;
+}

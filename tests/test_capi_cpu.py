@@ -201,3 +201,27 @@ def test_report_writer_reproduces_golden_report(oracle):
 def test_format_double_is_rapidjson_truncation(value, expected):
     """Values taken from the golden report / compiled job, plus the branches of rapidjson's Prettify."""
     assert capi.format_double(value, 15) == expected
+
+
+def test_host_side_under_sanitizers(tmp_path):
+    """The library's CPU side (JSON reader, job model, PhredScale, report writer) under ASan + UBSan; GPU
+    sanitizers are not available on the target pool."""
+    import json
+    import os
+    import subprocess
+
+    from pheniqs_amd import synthetic
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
+    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    if built.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
+    paths = [os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "BDGGG", "compile_annotated.json")]
+    for name in ("C2", "C5"):
+        job = synthetic.config_job(name, "mdd")[0]
+        path = tmp_path / (name + ".json")
+        path.write_text(json.dumps(job))
+        paths.append(str(path))
+    ran = subprocess.run([os.path.join(csrc, "build", "host_check_asan")] + paths, capture_output=True, text=True)
+    assert ran.returncode == 0, ran.stdout + ran.stderr
+    assert "host check ok" in ran.stdout
