@@ -176,7 +176,8 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
 #define PHQ_KERNEL_MDD              2
 #define PHQ_KERNEL_COUNT            3
 #define PHQ_KERNEL_MDD_EXACT        4
-#define PHQ_KERNEL_KINDS            5
+#define PHQ_KERNEL_PAMLD_EXACT      5   /* factorised exact tier of combinatorial barcode sets */
+#define PHQ_KERNEL_KINDS            6
 int phq_profile_enable(phq_decoder_set* set, int32_t enable);
 int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNEL_KINDS] */, int64_t* launches /* [PHQ_KERNEL_KINDS] */);
 

@@ -227,7 +227,7 @@ class DecoderSet:
                                                         ctypes.byref(incoming), ctypes.byref(incoming_pf)))
         return incoming.value, incoming_pf.value
 
-    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact")
+    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact", "pamld_exact")
 
     def profile_enable(self, enable: bool = True):
         self._check(self.lib.phq_profile_enable(self.handle, 1 if enable else 0))

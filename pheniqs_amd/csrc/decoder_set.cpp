@@ -269,6 +269,76 @@ void DecoderSet::build_device_images() {
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
             }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
+               c.segment_cardinality >= 2 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
+                // A combinatorial barcode set (every combination of per segment sets, once)?  Then P(r|b) factorises
+                // over the segments and pamld_cross.hpp scans the segments' distinct words instead of the barcodes.
+                const int32_t S = c.segment_cardinality;
+                std::vector<std::vector<uint32_t>> distinct(static_cast<size_t>(S));       // 2 bits per base keys, first appearance order
+                std::vector<int32_t> id(static_cast<size_t>(d.n_barcode) * static_cast<size_t>(S));
+                bool supported = true;
+                int32_t groups = 1;
+                for(int32_t s = 0; s < S && supported; ++s) {
+                    const int32_t begin = c.segment_offset[static_cast<size_t>(s)];
+                    const int32_t length = c.barcode_length[static_cast<size_t>(s)];
+                    if(length < 1 || length > 16) { supported = false; break; }
+                    groups = std::max(groups, (length + 3) / 4);
+                    for(int32_t b = 0; b < d.n_barcode; ++b) {
+                        uint32_t key = 0;
+                        for(int32_t j = 0; j < length; ++j) {
+                            const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(begin + j)];
+                            key |= (code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u) << (2 * j);
+                        }
+                        auto& set = distinct[static_cast<size_t>(s)];
+                        auto found = std::find(set.begin(), set.end(), key);
+                        if(found == set.end()) {
+                            if(set.size() >= static_cast<size_t>(CROSS_MAX_UNIQUE)) { supported = false; break; }
+                            set.push_back(key);
+                            found = set.end() - 1;
+                        }
+                        id[static_cast<size_t>(b) * static_cast<size_t>(S) + static_cast<size_t>(s)] = static_cast<int32_t>(found - set.begin());
+                    }
+                }
+                int64_t combinations = 1;
+                for(int32_t s = 0; s < S && supported; ++s) { combinations *= static_cast<int64_t>(distinct[static_cast<size_t>(s)].size()); }
+                if(supported && combinations == d.n_barcode) {
+                    int32_t stride[CROSS_MAX_SEGMENT] = {0, 0, 0};
+                    int32_t weight = 1;
+                    for(int32_t s = S - 1; s >= 0; --s) { stride[s] = weight; weight *= static_cast<int32_t>(distinct[static_cast<size_t>(s)].size()); }
+                    std::vector<int32_t> ordinal(static_cast<size_t>(d.n_barcode), -1);
+                    for(int32_t b = 0; b < d.n_barcode && supported; ++b) {
+                        int32_t flat = 0;
+                        for(int32_t s = 0; s < S; ++s) { flat += id[static_cast<size_t>(b) * static_cast<size_t>(S) + static_cast<size_t>(s)] * stride[s]; }
+                        if(ordinal[static_cast<size_t>(flat)] >= 0) { supported = false; }      // the same barcode twice
+                        ordinal[static_cast<size_t>(flat)] = b;
+                    }
+                    if(supported) {
+                        std::vector<uint32_t> words(static_cast<size_t>(CROSS_MAX_SEGMENT) * CROSS_MAX_UNIQUE, 0u);
+                        for(int32_t s = 0; s < S; ++s) {
+                            const int32_t length = c.barcode_length[static_cast<size_t>(s)];
+                            const auto& set = distinct[static_cast<size_t>(s)];
+                            for(size_t u = 0; u < set.size(); ++u) {
+                                uint32_t word = 0;
+                                for(int32_t j = 0; j < length; ++j) {
+                                    const uint32_t two = (set[u] >> (2 * j)) & 3u;
+                                    const uint32_t low = 8u * static_cast<uint32_t>(j >> 2) + 2u + static_cast<uint32_t>(j & 3);
+                                    word |= (two & 1u) << low;
+                                    word |= (two >> 1) << ((low + 4u) & 31u);
+                                }
+                                words[static_cast<size_t>(s) * CROSS_MAX_UNIQUE + u] = word;
+                            }
+                            d.cross_start[s] = c.segment_offset[static_cast<size_t>(s)];
+                            d.cross_length[s] = length;
+                            d.cross_unique[s] = static_cast<int32_t>(set.size());
+                            d.cross_stride[s] = stride[s];
+                        }
+                        d.cross_segments = S;
+                        d.cross_groups = groups;
+                        d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
+                        d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
+                    }
+                }
+            }
         }
     }
     device_decoder_ = static_cast<DevDecoder*>(upload(host_decoder_.data(), host_decoder_.size() * sizeof(DevDecoder)));

@@ -9,6 +9,8 @@ constexpr int DEV_MAX_DECODER = 16;
 constexpr int DEV_MAX_SEGMENT = 8;
 constexpr int DEV_MAX_WORD = 4;          // 8 nucleotides per 32-bit word of 4-bit BAM codes
 constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
+constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
+constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
 
 // Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]
 // (TranscodingDecoder::count/pf_count, transcode.h:61-64).  Then per decoder, per barcode bin
@@ -82,6 +84,15 @@ struct DevDecoder {
     const uint32_t* exact_table;
     uint32_t exact_slots;                 // power of two
     int32_t exact_probes;                 // longest probe sequence + 1
+    // factorised PAMLD kernel only: the barcode set is EVERY combination of per segment sets (dual / triple index)
+    int32_t cross_segments;               // 0 = not combinatorial (or not supported), else n_segment
+    int32_t cross_groups;                 // groups of 4 positions of the longest segment
+    int32_t cross_start[CROSS_MAX_SEGMENT];      // first position of the segment in the observation
+    int32_t cross_length[CROSS_MAX_SEGMENT];
+    int32_t cross_unique[CROSS_MAX_SEGMENT];     // distinct words of the segment
+    int32_t cross_stride[CROSS_MAX_SEGMENT];     // mixed radix weight of the segment in cross_ordinal
+    const uint32_t* cross_words;          // [CROSS_MAX_SEGMENT][CROSS_MAX_UNIQUE] bit-sliced 2-bit words, positions relative to the segment
+    const int32_t* cross_ordinal;         // combination -> barcode ordinal
 };
 
 enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };
@@ -109,7 +120,7 @@ struct StageArgs {
 };
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
-enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_KINDS = 5 };
+enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_KINDS = 6 };
 struct LaunchTimer {
     virtual ~LaunchTimer() {}
     virtual void begin(int32_t kind, void* stream) = 0;

@@ -1,0 +1,619 @@
+// K1 (factorised product form): PamlDecoder<T>::classify for a COMBINATORIAL barcode set — every combination
+// of S per segment sets (dual / triple indexing: U1 x U2 [x U3] barcodes), uniform prior.
+//
+//   reference pamld.cpp:37-123     posterior over all barcodes, noise / confidence / high quality filters
+//   reference barcode.h:131-164    P(r|b) = pow(base, sum over ALL segments' positions of the Phred cost)
+//
+// pow(base, sum) factorises over the segments, so for b = (u1, .., uS)
+//     P(r|b)        = P1(u1) * .. * PS(uS)
+//     sum_b P(r|b)  = (sum P1) * .. * (sum PS)
+//     argmax_b      = (argmax P1, .., argmax PS)
+// and U1 + .. + US per segment evaluations replace U1 * .. * US per barcode ones (192 instead of 9 216 for a
+// 96 x 96 dual index).  Each segment is scanned with the machinery of pamld_lut.hpp: per read 16 entry tables
+// of 4-position factor products in LDS, bit-sliced 2-bit bases, X | rotr(X, 4) mismatch fields, the segment's
+// distinct words in a wave wide register read with v_readlane.  The segments reuse the same LDS tables one
+// after the other.
+//
+// A read is FINISHED here only when (pamld_lut.hpp has the argument)
+//   * every segment's best word beats its runner up by more than single precision can blur (1e-4), so the
+//     argmax is certain, and
+//   * either the winner clearly fails the noise filter (then nothing but the argmax matters: the read is
+//     charged to it and leaves unclassified, pamld.cpp:96,113-119), or the winner dominates (everything
+//     else <= 1e-3 of it: the posterior, recomputed in fp64 for the winner, holds ~1e-9) and the confidence
+//     is not within 1e-9 of its threshold.
+// Every other read goes to this workgroup's worklist segment for the literal kernel.
+#pragma once
+
+#include "kernel_common.hpp"
+
+namespace phq {
+namespace cross {
+
+constexpr double DOMINANCE = 1e-3;
+constexpr float RUNNER_UP = 0.9999f;          // second <= RUNNER_UP * top: the argmax of a segment is certain
+constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
+constexpr int THREADS = 256;
+constexpr int TABLE_REGISTERS = CROSS_MAX_UNIQUE / 64;
+
+__host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
+__host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
+
+__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
+    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4)
+}
+
+// G = groups of 4 positions of the longest segment (segments are padded with absent positions: factor 1 either way)
+template <int G, int S>
+__global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
+    constexpr uint32_t GROUP_BYTES = 16 * THREADS * sizeof(float);            // [index][256 lanes]
+    constexpr uint32_t ENTRY_BYTES = THREADS * sizeof(float);
+    constexpr uint32_t INDEX_MASK = 0x3c00u;                                  // index * 1024 at byte 1 of a field word
+    __shared__ float table[G * 16 * THREADS];                                 // [group][index][lane], one segment at a time
+    __shared__ float match_single[FACTOR_ROWS];
+    __shared__ float mismatch_single[FACTOR_ROWS];
+    __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
+    __shared__ uint32_t deferred_total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+        const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        match_single[i] = static_cast<float>(m);
+        mismatch_single[i] = static_cast<float>(e);
+        factor_double[i][0] = m;
+        factor_double[i][1] = e;
+    }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+
+    // per segment, wave uniform: geometry, byte masks of the padded words, flag mask, distinct words
+    uint32_t word_table[S][TABLE_REGISTERS];               // lane l of register v holds distinct word 64 v + l
+    int first_word[S];
+    uint32_t byte_shift[S];
+    uint32_t byte_mask[S][G];
+    uint32_t full_mask[S];
+    int unique[S];
+    int radix[S];
+    const int row_words = d.plane_stride >> 2;
+#pragma unroll
+    for(int s = 0; s < S; ++s) {
+        const int start = d.cross_start[s];
+        const int length = d.cross_length[s];
+        first_word[s] = start >> 2;
+        byte_shift[s] = static_cast<uint32_t>(start & 3);
+        unique[s] = d.cross_unique[s];
+        radix[s] = d.cross_stride[s];
+        full_mask[s] = 0;
+#pragma unroll
+        for(int j = 0; j < 4 * G; ++j) { if(j < length) { full_mask[s] |= 1u << low_bit(j); } }
+#pragma unroll
+        for(int g = 0; g < G; ++g) {
+            const int valid = length - 4 * g;
+            byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
+        }
+#pragma unroll
+        for(int v = 0; v < TABLE_REGISTERS; ++v) {
+            const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
+            word_table[s][v] = w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
+        }
+    }
+
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + THREADS - 1) / THREADS;
+    const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
+    const char* const table_bytes = reinterpret_cast<const char*>(table);
+    const int64_t stride = d.plane_stride;
+
+    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        // every lane stays enabled (cross lane reads of the wave wide tables): lanes past the end of the batch
+        // recompute its last read and are kept from every store and counter
+        const bool active = tile * THREADS + threadIdx.x < n;
+        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        ReadState r = load_read_state(args, i);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+
+        // the padded words of every segment: G + 1 aligned words each, funnel shifted to the segment's first byte
+        uint32_t code_words[S][G];
+        uint32_t quality_words[S][G];
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            uint32_t c[G + 1];
+            uint32_t q[G + 1];
+#pragma unroll
+            for(int k = 0; k <= G; ++k) {
+                const int w = min(first_word[s] + k, row_words - 1);          // never past the row
+                c[k] = code_row[w];
+                q[k] = quality_row[w];
+            }
+#pragma unroll
+            for(int k = 0; k < G; ++k) {
+                code_words[s][k] = __builtin_amdgcn_alignbyte(c[k + 1], c[k], byte_shift[s]) & byte_mask[s][k];
+                quality_words[s][k] = __builtin_amdgcn_alignbyte(q[k + 1], q[k], byte_shift[s]) & byte_mask[s][k];
+            }
+        }
+
+        double best_conditional = 1.0;         // the winner's P(r|b), fp64
+        double winner_product = 1.0;           // the same from the single precision scan
+        double others = 0.0;                   // sum over every other combination of P(r|b)
+        int flat = 0;                          // mixed radix index of the winning combination
+        int distance = 0;
+        int hq_distance = 0;
+        bool certain = true;
+
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            // per position: factor row, single precision factors, 2-bit base, high quality flag
+            float fm[4 * G];
+            float fe[4 * G];
+            uint32_t row[G];
+            uint32_t observed = 0;
+            uint32_t high_quality = 0;
+            uint32_t outside = 0;
+#pragma unroll
+            for(int g = 0; g < G; ++g) { row[g] = 0; }
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t c = (code_words[s][j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q8 = (quality_words[s][j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q = q8 & 0x7fu;
+                // a base outside ACGT costs the uniform quality against every barcode base (phred.cpp:62-64);
+                // an absent position (code 0, quality 0) costs nothing: row 0 holds 1 and 1
+                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
+                fm[j] = match_single[k];
+                fe[j] = mismatch_single[k];
+                row[j >> 2] |= k << (8 * (j & 3));
+                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
+                observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality |= 1u << low_bit(j); }
+                if(!strict_code(c)) { outside |= 1u << low_bit(j); }
+            }
+            // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
+#pragma unroll
+            for(int g = 0; g < G; ++g) {
+                const int base = 4 * g;
+                float lo[4];
+                float hi[4];
+                lo[0] = fm[base] * fm[base + 1];
+                lo[1] = fe[base] * fm[base + 1];
+                lo[2] = fm[base] * fe[base + 1];
+                lo[3] = fe[base] * fe[base + 1];
+                hi[0] = fm[base + 2] * fm[base + 3];
+                hi[1] = fe[base + 2] * fm[base + 3];
+                hi[2] = fm[base + 2] * fe[base + 3];
+                hi[3] = fe[base + 2] * fe[base + 3];
+#pragma unroll
+                for(int m = 0; m < 16; ++m) {
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
+                }
+            }
+
+            // scan the segment's distinct words: maximum (first of equals), runner up, sum of everything but the maximum
+            float top = 0;
+            float second = 0;
+            float rest = 0;
+            int best = -1;
+            auto visit = [&](uint32_t word, int u) {
+                const uint32_t fields = mismatch_fields(observed ^ word);
+                float value = 1.0f;
+#pragma unroll
+                for(int g = 0; g < G; ++g) {
+                    const uint32_t source = g == 0 ? fields << 8 : g == 1 ? fields : g == 2 ? fields >> 8 : fields >> 16;
+                    const float entry = *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((source & INDEX_MASK) | lane_offset));
+                    value = g == 0 ? entry : value * entry;
+                }
+                const float lower = fminf(value, top);
+                rest += lower;
+                second = fmaxf(second, lower);
+                best = value > top ? u : best;
+                top = fmaxf(value, top);
+            };
+#pragma unroll
+            for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                const int last = min(unique[s], 64 * (v + 1));
+#pragma unroll 4
+                for(int u = 64 * v; u < last; ++u) {
+                    visit(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v), u);
+                }
+            }
+
+            if(best < 0) { certain = false; best = 0; }                       // underflow: everything rounded to zero
+            certain = certain && (second <= RUNNER_UP * top);
+            // the winner's word, its mismatch flags, its distances and its probability again in fp64
+            uint32_t word = 0;
+#pragma unroll
+            for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((best & 63) << 2, static_cast<int>(word_table[s][v])));
+                word = (best >> 6) == v ? got : word;
+            }
+            const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
+            distance += __popc(flags);
+            hq_distance += __popc(flags & high_quality);
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                best_conditional *= factor_double[k][(flags >> low_bit(j)) & 1u];
+            }
+            // (winner + others) * (top + rest) - winner * top, every term positive
+            others = others * (static_cast<double>(top) + static_cast<double>(rest)) + winner_product * static_cast<double>(rest);
+            winner_product *= static_cast<double>(top);
+            flat += best * radix[s];
+        }
+
+        bool defer = !certain;
+        {
+            const int best = d.cross_ordinal[flat];
+            const double prior = d.concentration[0];                                  // uniform (pamld_cross_supports)
+            const double best_p = best_conditional * prior;
+            const double total = (best_p + others * prior) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+            double confidence = best_p / total;                                       // pamld.cpp:92
+            const double noise_margin = best_conditional - d.random_barcode_probability;
+            const double confidence_margin = confidence - d.confidence_threshold;
+            const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
+            const bool is_noise = noise_margin <= 0;
+            if(!noise_clear) { defer = true; }
+            if(!is_noise) {
+                // the posterior matters: a dominant winner and no decision within 1e-9 of the threshold
+                if(!(others <= DOMINANCE * best_conditional) || !(fabs(confidence_margin) > 1e-9)) { defer = true; }
+            }
+            if(!defer && active) {
+                int bin = best + 1;
+                uint8_t status = STATUS_PASS;
+                if(!is_noise) {                                                       // pamld.cpp:96
+                    if(confidence_margin > 0) {                                       // pamld.cpp:99
+                        if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) {
+                            r.qcfail = true;
+                        }
+                        stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                    } else {
+                        stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                        r.qcfail = true;
+                        status = STATUS_LOW_CONFIDENCE;
+                    }
+                } else {
+                    stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                    r.qcfail = true;
+                    bin = 0;
+                    distance = 0;
+                    hq_distance = 0;
+                    confidence = 0;
+                    status = STATUS_NOISE;
+                }
+                decoder_tail(d, sink, r, bin, distance);
+                if(args.result) {
+                    DevResult out;
+                    out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                    out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                    out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                    out.status = status;
+                    out.qcfail = r.qcfail ? 1 : 0;
+                    out.confidence = confidence;
+                    args.result[i] = out;
+                }
+                store_read_state(args, i, r);
+            }
+        }
+        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
+        const unsigned long long deferred = __ballot(active && defer);
+        if(deferred) {
+            const int lane = threadIdx.x & 63;
+            uint32_t first = 0;
+            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            first = __shfl(first, 0);
+            if(active && defer) {
+                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+            }
+        }
+        count_outgoing(args, histogram, active && !defer, r);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+// Tier 1.5: the reads the single precision scan could not certify, decided exactly but still factorised.
+//
+// Consumes this workgroup's worklist segment and compacts what it cannot decide either back into the same
+// segment for the literal kernel (in place: a barrier per tile keeps every wave's reads ahead of the writes).
+//   * per segment, every distinct word's P in fp64 (products of the fp64 factor rows): the sum, the maximum and
+//     the list (in LDS, one column per lane) of the words within 1e-10 of the maximum — the only ones the
+//     reference's argmax can fall on: its own P(r|b) = pow(base, Kahan sum) is within ~1e-13 of the exact product;
+//   * the candidates (combinations of near maximal words) are evaluated LITERALLY — the reference's Kahan
+//     recurrence over the barcode's positions and the 2^x of the literal kernel (pamld_literal.hpp) — and
+//     compared the way the reference's loop does: strict '>' in barcode order, so the lowest ordinal among
+//     equal maxima wins;
+//   * sum_b P(r|b) is the product of the per segment fp64 sums (relative error ~1e-15; the reference's Kahan sum
+//     over all barcodes is not reproduced bit for bit, so a confidence within 1e-12 of its threshold is left to
+//     the literal kernel — the only reads it still sees).
+template <int G, int S>
+__global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs args) {
+    __shared__ uint8_t near_list[S * CROSS_MAX_UNIQUE * THREADS];             // [segment][entry][lane] word ordinals
+    __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
+    __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
+    __shared__ uint32_t deferred_total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+        factor_double[i][0] = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        factor_double[i][1] = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
+        cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
+    }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const int64_t n = static_cast<int64_t>(args.worklist_count[blockIdx.x]);
+    const int64_t tiles = (n + THREADS - 1) / THREADS;
+
+    uint32_t word_table[S][TABLE_REGISTERS];
+    int first_word[S];
+    int length[S];
+    uint32_t byte_shift[S];
+    uint32_t byte_mask[S][G];
+    uint32_t full_mask[S];
+    int unique[S];
+    int radix[S];
+    const int row_words = d.plane_stride >> 2;
+#pragma unroll
+    for(int s = 0; s < S; ++s) {
+        const int start = d.cross_start[s];
+        length[s] = d.cross_length[s];
+        first_word[s] = start >> 2;
+        byte_shift[s] = static_cast<uint32_t>(start & 3);
+        unique[s] = d.cross_unique[s];
+        radix[s] = d.cross_stride[s];
+        full_mask[s] = 0;
+#pragma unroll
+        for(int j = 0; j < 4 * G; ++j) { if(j < length[s]) { full_mask[s] |= 1u << low_bit(j); } }
+#pragma unroll
+        for(int g = 0; g < G; ++g) {
+            const int valid = length[s] - 4 * g;
+            byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
+        }
+#pragma unroll
+        for(int v = 0; v < TABLE_REGISTERS; ++v) {
+            const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
+            word_table[s][v] = w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
+        }
+    }
+    const int64_t stride = d.plane_stride;
+    const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
+    const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
+
+    for(int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t k = tile * THREADS + threadIdx.x;
+        const bool active = k < n;
+        const int64_t i = static_cast<int64_t>(segment[active ? k : n - 1]);
+        __syncthreads();                       // every entry of this tile is read before any wave compacts into it
+        ReadState r = load_read_state(args, i);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+
+        uint32_t row_offset[S][4 * G];         // byte offset of the position's factor / cost row
+        uint32_t observed[S];
+        uint32_t outside[S];
+        uint32_t high_quality[S];
+        int near_count[S];                     // entries of this lane's column of near_list
+        double sum_all = 1.0;                  // product of the per segment sums = sum over every barcode of P(r|b)
+        bool defer = false;
+
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            uint32_t c[G + 1];
+            uint32_t q[G + 1];
+#pragma unroll
+            for(int g = 0; g <= G; ++g) {
+                const int w = min(first_word[s] + g, row_words - 1);
+                c[g] = code_row[w];
+                q[g] = quality_row[w];
+            }
+            observed[s] = 0;
+            outside[s] = 0;
+            high_quality[s] = 0;
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t code_word = __builtin_amdgcn_alignbyte(c[(j >> 2) + 1], c[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t quality_word = __builtin_amdgcn_alignbyte(q[(j >> 2) + 1], q[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t code = (code_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q8 = (quality_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t quality = q8 & 0x7fu;
+                const uint32_t row = strict_code(code) ? quality : (quality ? 128u : 0u);
+                row_offset[s][j] = row * 16u;
+                const uint32_t two = (0x30210u >> (2 * (code & 0xfu))) & 3u;
+                observed[s] |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality[s] |= 1u << low_bit(j); }
+                if(!strict_code(code)) { outside[s] |= 1u << low_bit(j); }
+            }
+            auto probability_of = [&](uint32_t word) {
+                const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
+                double p = 1.0;
+#pragma unroll
+                for(int j = 0; j < 4 * G; ++j) {
+                    p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
+                }
+                return p;
+            };
+            double top = 0;
+            double sum = 0;
+#pragma unroll
+            for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                const int last = min(unique[s], 64 * (v + 1));
+                for(int u = 64 * v; u < last; ++u) {
+                    const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
+                    sum += p;
+                    top = fmax(top, p);
+                }
+            }
+            const double threshold = top * (1.0 - 1e-10);
+            int count = 0;
+#pragma unroll
+            for(int v = 0; v < TABLE_REGISTERS; ++v) {
+                const int last = min(unique[s], 64 * (v + 1));
+                for(int u = 64 * v; u < last; ++u) {
+                    const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
+                    if(p >= threshold) {
+                        near_list[(s * CROSS_MAX_UNIQUE + count) * THREADS + threadIdx.x] = static_cast<uint8_t>(u);
+                        ++count;
+                    }
+                }
+            }
+            if(!(top > 0)) { defer = true; count = 0; }
+            near_count[s] = count;
+            sum_all *= sum;
+        }
+
+        // the candidates, literally: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164)
+        int best = 0x7fffffff;
+        double best_conditional = -1.0;
+        uint32_t best_flags[S];
+#pragma unroll
+        for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
+        int choice[S];                         // odometer over the near maximal words, the last segment fastest
+        bool more = true;
+#pragma unroll
+        for(int s = 0; s < S; ++s) { choice[s] = 0; more = more && near_count[s] > 0; }
+        const bool any_candidate = more;
+        while(more) {
+            int flat = 0;
+            uint32_t flags[S];
+            double sigma = 0;
+            double compensation = 0;
+#pragma unroll
+            for(int s = 0; s < S; ++s) {
+                const int u = near_list[(s * CROSS_MAX_UNIQUE + choice[s]) * THREADS + threadIdx.x];
+                flat += u * radix[s];
+                flags[s] = (mismatch_fields(observed[s] ^ d.cross_words[s * CROSS_MAX_UNIQUE + u]) | outside[s]) & full_mask[s];
+#pragma unroll
+                for(int j = 0; j < 4 * G; ++j) {
+                    if(j < length[s]) {
+                        const double x = *reinterpret_cast<const double*>(cost_bytes + (row_offset[s][j] + ((flags[s] >> low_bit(j)) & 1u) * 8u));
+                        const double y = x - compensation;
+                        const double t = sigma + y;
+                        compensation = (t - sigma) - y;
+                        sigma = t;
+                    }
+                }
+            }
+            const int b = d.cross_ordinal[flat];
+            const double conditional = phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
+            if(conditional > best_conditional || (conditional == best_conditional && b < best)) {
+                best = b;
+                best_conditional = conditional;
+#pragma unroll
+                for(int s = 0; s < S; ++s) { best_flags[s] = flags[s]; }
+            }
+            bool carry = true;
+#pragma unroll
+            for(int s = S - 1; s >= 0; --s) {
+                if(carry) {
+                    ++choice[s];
+                    if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
+                }
+            }
+            more = !carry;
+        }
+        if(!any_candidate) { defer = true; best = 0; best_conditional = 0; }
+
+        int distance = 0;
+        int hq_distance = 0;
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            distance += __popc(best_flags[s]);
+            hq_distance += __popc(best_flags[s] & high_quality[s]);
+        }
+        const double prior = d.concentration[0];
+        const double best_p = best_conditional * prior;
+        const double total = sum_all * prior + d.adjusted_noise_probability;        // pamld.cpp:61-86
+        double confidence = best_p / total;                                          // pamld.cpp:92
+        const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
+        if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
+        if(!defer && active) {
+            int bin = best + 1;
+            uint8_t status = STATUS_PASS;
+            if(!is_noise) {
+                if(confidence > d.confidence_threshold) {                            // pamld.cpp:99
+                    if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) {
+                        r.qcfail = true;
+                    }
+                    stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                } else {
+                    stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                    r.qcfail = true;
+                    status = STATUS_LOW_CONFIDENCE;
+                }
+            } else {
+                stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                r.qcfail = true;
+                bin = 0;
+                distance = 0;
+                hq_distance = 0;
+                confidence = 0;
+                status = STATUS_NOISE;
+            }
+            decoder_tail(d, sink, r, bin, distance);
+            if(args.result) {
+                DevResult out;
+                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                out.status = status;
+                out.qcfail = r.qcfail ? 1 : 0;
+                out.confidence = confidence;
+                args.result[i] = out;
+            }
+            store_read_state(args, i, r);
+        }
+        const unsigned long long deferred = __ballot(active && defer);
+        if(deferred) {
+            const int lane = threadIdx.x & 63;
+            uint32_t first = 0;
+            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            first = __shfl(first, 0);
+            if(active && defer) {
+                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+            }
+        }
+        count_outgoing(args, histogram, active && !defer, r);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+template <int S>
+int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+template <int S>
+int launch_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: hipLaunchKernelGGL((pamld_cross_kernel<1, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_kernel<2, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_kernel<3, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_kernel<4, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace cross
+}  // namespace phq

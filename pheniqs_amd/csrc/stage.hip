@@ -18,7 +18,7 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
     if(mode != MODE_FAST) { return false; }
-    return (host_decoder.algorithm == 1 && pamld_lut_supports(host_decoder)) ||
+    return (host_decoder.algorithm == 1 && (pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder))) ||
            (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
 
@@ -43,7 +43,9 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: product form over every read, deferring the ambiguous ones; tier 2: the literal kernel on those
                 // both launches use the same grid: literal workgroup g consumes what product form workgroup g deferred
-                const int64_t threads = pamld_lut_block(host_decoder);
+                // a combinatorial barcode set too large for the per barcode product form goes through the factorised one
+                const bool factorised = !pamld_lut_supports(host_decoder);
+                const int64_t threads = factorised ? BLOCK : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < max_blocks ? wide_tiles : max_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
@@ -53,11 +55,18 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 int status;
                 {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
-                    status = launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
+                    status = factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
+                                        : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
+                if(factorised) {
+                    // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
+                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                    status = launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
+                    if(status != 0) { return status; }
+                }
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
                 return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
             }

@@ -242,6 +242,43 @@ def test_ties_keep_the_lowest_index(oracle, torch_cuda, mode):
     assert set(got[0]["index"][:64]) <= {0, 1}
 
 
+@pytest.mark.parametrize("lengths,counts", [((6, 9), (12, 10)), ((10, 10), (24, 16)), ((4, 7, 5), (5, 6, 4)), ((16, 3), (7, 9)), ((1, 1), (4, 4))])
+def test_combinatorial_sets_factorise(oracle, torch_cuda, lengths, counts):
+    """Dual / triple index sets holding every combination go through the factorised kernel (pamld_cross.hpp) in
+    PHQ_MODE_FAST: unequal segment lengths, segments that start off a 4 byte boundary, N calls, zero qualities,
+    short observations, and uniform qualities (exact ties inside a segment, which must reach the literal kernel)."""
+    rng = np.random.default_rng(sum(lengths) * 131 + sum(counts))
+    segments = [synthetic.barcode_set(rng, c, l, min_distance=3 if l >= 6 else 1) for l, c in zip(lengths, counts)]
+    tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
+    spec = {"input segment cardinality": len(lengths),
+            "sample": synthetic.decoder_spec("pamld", segments, tokens, **{"confidence threshold": 0.9})}
+    job = jobspec.compile_job(spec)
+    n = 1 << 14
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 7)
+    L = sum(lengths)
+    noisy = rng.random((n, L)) < 0.02
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random((n, L)) < 0.02] = 0
+    quality[: n // 8] = 30                                   # uniform qualities: exact ties between equidistant words
+    for i in range(L):                                       # short observations: zero filled tail (SURVEY S1)
+        code[n // 2 + i, i:] = 0
+        quality[n // 2 + i, i:] = 0
+    quality[n // 2 + L] = 255
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 2       # most reads decode
+
+
+def test_paired_sets_that_are_not_combinatorial_stay_exact(oracle, torch_cuda):
+    """A zip paired dual index (word i with word i) is not a cross product: no factorised kernel, same results."""
+    rng = np.random.default_rng(77)
+    a, b = synthetic.barcode_set(rng, 24, 10), synthetic.barcode_set(rng, 24, 10)
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("pamld", [a, b], ["0::10", "1::10"], pairing="zip")}
+    job = jobspec.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 13, 8)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
 def test_iupac_barcodes_take_the_uniform_branch(oracle, torch_cuda):
     """barcode letters outside ACGT always cost UNIFORM_BASE_QUALITY (the STRICT=false kernels)."""
     spec = {"input segment cardinality": 1,
