@@ -42,19 +42,33 @@ __device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
     return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4)
 }
 
+typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
+// bytes of the scan kernel's LDS block in front of the counter histogram: tables, factor columns, worklist counter
+__host__ __device__ constexpr uint32_t scan_fixed_bytes(int groups) {
+    return static_cast<uint32_t>(groups) * 16u * THREADS * 4u + 528u + 528u + FACTOR_ROWS * 16u + 16u;
+}
+
 // G = groups of 4 positions of the longest segment (segments are padded with absent positions: factor 1 either way)
 template <int G, int S>
 __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
     constexpr uint32_t GROUP_BYTES = 16 * THREADS * sizeof(float);            // [index][256 lanes]
     constexpr uint32_t ENTRY_BYTES = THREADS * sizeof(float);
     constexpr uint32_t INDEX_MASK = 0x3c00u;                                  // index * 1024 at byte 1 of a field word
-    __shared__ float table[G * 16 * THREADS];                                 // [group][index][lane], one segment at a time
-    __shared__ float match_single[FACTOR_ROWS];
-    __shared__ float mismatch_single[FACTOR_ROWS];
-    __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
-    __shared__ uint32_t deferred_total;
+    // one hand laid dynamic LDS block at LDS address 0 and no static LDS, as in pamld_lut.hpp: a table address is
+    // (field & mask) | lane offset, one instruction
+    constexpr uint32_t MATCH_AT = G * GROUP_BYTES;
+    constexpr uint32_t MISMATCH_AT = MATCH_AT + 528;
+    constexpr uint32_t FACTOR_AT = MISMATCH_AT + 528;
+    constexpr uint32_t DEFERRED_AT = FACTOR_AT + FACTOR_ROWS * 16;
+    static_assert(DEFERRED_AT + 16 == scan_fixed_bytes(G), "launch_segments sizes the block");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
+    float* const table = reinterpret_cast<float*>(lds_raw);                   // [group][index][lane], one segment at a time
+    float* const match_single = reinterpret_cast<float*>(lds_raw + MATCH_AT);
+    float* const mismatch_single = reinterpret_cast<float*>(lds_raw + MISMATCH_AT);
+    double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + FACTOR_AT);   // [row][0 match | 1 mismatch]
+    uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + DEFERRED_AT);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + DEFERRED_AT + 16);
     DecoderRef d = *constant_cast(args.decoder);
 
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
@@ -107,7 +121,6 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
     const int64_t n = args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
-    const char* const table_bytes = reinterpret_cast<const char*>(table);
     const int64_t stride = d.plane_stride;
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
                     const uint32_t source = g == 0 ? fields << 8 : g == 1 ? fields : g == 2 ? fields >> 8 : fields >> 16;
-                    const float entry = *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((source & INDEX_MASK) | lane_offset));
+                    const float entry = ((LdsFloats)static_cast<uintptr_t>((source & INDEX_MASK) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
                     value = g == 0 ? entry : value * entry;
                 }
                 const float lower = fminf(value, top);
@@ -444,28 +457,24 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                 }
                 return p;
             };
+            // one pass: the sum, the maximum, and a list that always holds every word within 1e-10 of the running
+            // maximum (it is emptied when a new maximum clears the old one by more than that; words that crept in
+            // while the maximum was lower are harmless extras: the literal evaluation below decides)
             double top = 0;
             double sum = 0;
-#pragma unroll
-            for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                const int last = min(unique[s], 64 * (v + 1));
-                for(int u = 64 * v; u < last; ++u) {
-                    const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
-                    sum += p;
-                    top = fmax(top, p);
-                }
-            }
-            const double threshold = top * (1.0 - 1e-10);
             int count = 0;
 #pragma unroll
             for(int v = 0; v < TABLE_REGISTERS; ++v) {
                 const int last = min(unique[s], 64 * (v + 1));
                 for(int u = 64 * v; u < last; ++u) {
                     const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
-                    if(p >= threshold) {
+                    sum += p;
+                    if(p * (1.0 - 1e-10) > top) { count = 0; }
+                    if(p >= top * (1.0 - 1e-10)) {
                         near_list[(s * CROSS_MAX_UNIQUE + count) * THREADS + threadIdx.x] = static_cast<uint8_t>(u);
                         ++count;
                     }
+                    top = fmax(top, p);
                 }
             }
             if(!(top > 0)) { defer = true; count = 0; }
@@ -603,16 +612,28 @@ int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder,
     return static_cast<int>(hipGetLastError());
 }
 
+template <int G, int S>
+int launch_scan(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    static bool prepared = false;                           // more than 64 KiB of dynamic LDS has to be asked for
+    if(!prepared) {
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_cross_kernel<G, S>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if(status != hipSuccess) { return static_cast<int>(status); }
+        prepared = true;
+    }
+    hipLaunchKernelGGL((pamld_cross_kernel<G, S>), grid, dim3(THREADS), scan_fixed_bytes(G) + histogram_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int S>
 int launch_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_kernel<1, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_kernel<2, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_kernel<3, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_kernel<4, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: return launch_scan<1, S>(args, grid, histogram_bytes, stream);
+        case 2: return launch_scan<2, S>(args, grid, histogram_bytes, stream);
+        case 3: return launch_scan<3, S>(args, grid, histogram_bytes, stream);
+        case 4: return launch_scan<4, S>(args, grid, histogram_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
-    return static_cast<int>(hipGetLastError());
 }
 
 }  // namespace cross

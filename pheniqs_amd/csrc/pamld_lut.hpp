@@ -48,12 +48,24 @@ __device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
 // Workgroup size: the 16 entry tables cost 64 bytes of LDS per lane and group.  Up to 8 nt (2 groups) a 512
 // lane workgroup = two 256 lane half tables of 32 KiB leaves room for two workgroups per CU = 4 waves per SIMD;
 // longer barcodes keep 256 lanes.
+//
+// LDS is ONE dynamic block laid out by hand, and the kernel declares no static LDS: the block then starts at LDS
+// address 0 (checked once per workgroup), the tables sit at its front, and a table address is just
+// (field & mask) | lane offset — one v_and_or_b32 — instead of a mask and an add to a base.
 template <int L> struct LutGeometry {
     static constexpr int G = (L + 3) / 4;
     static constexpr int THREADS = L <= 8 ? 512 : 256;
     static constexpr uint32_t GROUP_BYTES = 16 * 256 * sizeof(float);      // one group of one half: [index][256 lanes]
     static constexpr uint32_t HALF_BYTES = G * GROUP_BYTES;
+    static constexpr uint32_t TABLE_AT = 0;                                // [half][group][index][256 lanes] floats
+    static constexpr uint32_t MATCH_AT = TABLE_AT + (THREADS / 256) * HALF_BYTES;   // FACTOR_ROWS floats
+    static constexpr uint32_t MISMATCH_AT = MATCH_AT + 528;                // FACTOR_ROWS floats
+    static constexpr uint32_t FACTOR_AT = MISMATCH_AT + 528;               // FACTOR_ROWS x [match | mismatch] doubles
+    static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 129 * 16;          // one counter
+    static constexpr uint32_t HISTOGRAM_AT = DEFERRED_AT + 16;             // the counter histogram (kernel_common.hpp)
 };
+
+typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 
 template <int L, bool UNIFORM_PRIOR, int TABLE_REGISTERS>
 __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
@@ -63,14 +75,15 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
     constexpr int PER_WORD = PAIRED ? 2 : 1;
     static_assert(L <= 16, "2-bit codes of one barcode fit one word");
-    // static LDS (compile time addresses): the tables and the factor columns; dynamic LDS: the counter histogram
-    __shared__ float table[G * 16 * THREADS];                                 // [half][group][index][256 lanes]
-    __shared__ float match_single[FACTOR_ROWS];
-    __shared__ float mismatch_single[FACTOR_ROWS];
-    __shared__ double factor_double[FACTOR_ROWS][2];                          // [row][0 match | 1 mismatch]
-    __shared__ uint32_t deferred_total;
+    typedef LutGeometry<L> Layout;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
+    float* const table = reinterpret_cast<float*>(lds_raw + Layout::TABLE_AT);
+    float* const match_single = reinterpret_cast<float*>(lds_raw + Layout::MATCH_AT);
+    float* const mismatch_single = reinterpret_cast<float*>(lds_raw + Layout::MISMATCH_AT);
+    double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + Layout::FACTOR_AT);   // [row][0 match | 1 mismatch]
+    uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + Layout::DEFERRED_AT);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::HISTOGRAM_AT);
     DecoderRef d = *constant_cast(args.decoder);
 
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
@@ -106,7 +119,6 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     constexpr uint32_t ENTRY_BYTES = 256 * sizeof(float);
     constexpr uint32_t INDEX_MASK = 0x3c00u;              // index * 1024 at byte 1 of a field word
     const uint32_t lane_offset = (threadIdx.x >> 8) * LutGeometry<L>::HALF_BYTES + (threadIdx.x & 255u) * static_cast<uint32_t>(sizeof(float));
-    const char* const table_bytes = reinterpret_cast<const char*>(table);
     uint32_t full_mask = 0;                                // the flag bit of each of the L positions
 #pragma unroll
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                     for(int g = 0; g < G; ++g) {
                         const int byte = (PAIRED ? 2 * h : 0) + g;
                         const uint32_t source = byte == 0 ? up : byte == 1 ? fields : byte == 2 ? down : far;
-                        const float entry = *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((source & INDEX_MASK) | lane_offset));
+                        const float entry = ((LdsFloats)static_cast<uintptr_t>((source & INDEX_MASK) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
                         value = g == 0 ? entry : value * entry;
                     }
                     p[h] = value;
@@ -206,7 +218,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 others_sum += takes_over ? held_sum : group_sum;
                 held_sum = takes_over ? group_sum : held_sum;
                 best_group = takes_over ? g : best_group;
-                best_value = fmaxf(best_value, group_max);
+                best_value = takes_over ? group_max : best_value;
             };
             auto four_of = [&](int g, const uint32_t (&w)[PAIRED ? 2 : 4], float (&p)[4]) {
                 // barcodes 4g .. 4g+3; the table is padded to whole groups, padding is zeroed by the caller
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                     for(int g = 0; g < G; ++g) {
                         const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
                         const uint32_t index = (fields >> shift) & 0x3cu;
-                        p *= *reinterpret_cast<const float*>(table_bytes + g * GROUP_BYTES + ((index << 8) | lane_offset));
+                        p *= ((LdsFloats)static_cast<uintptr_t>((index << 8) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
                     }
                     if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
                     if(b >= n_barcode || best_group < 0) { p = 0.0f; }
@@ -387,7 +399,15 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 
 template <int L, bool UNIFORM_PRIOR, int TABLE_REGISTERS>
 int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR, TABLE_REGISTERS>), grid, dim3(LutGeometry<L>::THREADS), histogram_bytes, stream, args);
+    const size_t lds_bytes = LutGeometry<L>::HISTOGRAM_AT + histogram_bytes;
+    static bool prepared = false;                           // per instantiation; more than 64 KiB of dynamic LDS has to be asked for
+    if(!prepared) {
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_lut_kernel<L, UNIFORM_PRIOR, TABLE_REGISTERS>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if(status != hipSuccess) { return static_cast<int>(status); }
+        prepared = true;
+    }
+    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR, TABLE_REGISTERS>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

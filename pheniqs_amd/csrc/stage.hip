@@ -36,7 +36,7 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
     const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
     const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
     const size_t histogram_bytes = sizeof(unsigned long long) *
-        static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : 0));
+        static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : STAT_WORDS_PER_BIN));
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch(host_decoder.algorithm) {
         case 1:
