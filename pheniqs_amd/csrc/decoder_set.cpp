@@ -163,6 +163,13 @@ void DecoderSet::build_device_images() {
     const double* device_match = static_cast<const double*>(upload(scale.match_probability, sizeof(scale.match_probability)));
     const double* device_mismatch = static_cast<const double*>(upload(scale.mismatch_probability, sizeof(scale.mismatch_probability)));
 
+    std::vector<double> factor_pairs(129 * 2);
+    for(int k = 0; k < 129; ++k) {
+        factor_pairs[static_cast<size_t>(2 * k)] = k < 128 ? scale.match_probability[k] : scale.uniform_probability;
+        factor_pairs[static_cast<size_t>(2 * k + 1)] = k < 128 ? scale.mismatch_probability[k] : scale.uniform_probability;
+    }
+    const double* device_factor_pairs = static_cast<const double*>(upload(factor_pairs.data(), factor_pairs.size() * sizeof(double)));
+
     host_decoder_.assign(job_.decoder.size(), DevDecoder());
     for(size_t k = 0; k < job_.decoder.size(); ++k) {
         const DecoderConfig& c = job_.decoder[k];
@@ -246,7 +253,7 @@ void DecoderSet::build_device_images() {
                 d.exact_probes = longest + 1;
             }
             if(c.all_strict && c.nucleotide_cardinality <= 16 && d.n_barcode > 0) {
-                const int32_t padded = (d.n_barcode + 3) / 4 * 4;
+                const int32_t padded = (d.n_barcode + 7) / 8 * 8;        // whole blocks of 8 barcodes (pamld_lut.hpp)
                 const bool paired = c.nucleotide_cardinality <= 8;
                 std::vector<uint32_t> packed2(static_cast<size_t>(paired ? padded / 2 : padded), 0);
                 std::vector<float> prior(static_cast<size_t>(padded), 0.0f);
@@ -268,6 +275,27 @@ void DecoderSet::build_device_images() {
                 }
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
+            }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {
+                // two words of bit-sliced 2-bit bases per barcode for the long barcode product form (pamld_wide.hpp)
+                const int32_t padded = (d.n_barcode + 7) / 8 * 8;
+                std::vector<uint32_t> wide(static_cast<size_t>(padded) * 2, 0u);
+                std::vector<float> prior(static_cast<size_t>(padded), 0.0f);
+                for(int32_t b = 0; b < padded; ++b) {
+                    const int32_t source = b < d.n_barcode ? b : 0;          // padding repeats barcode 0; its probability is zeroed
+                    for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(source) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        const uint32_t low = 8u * static_cast<uint32_t>((j >> 2) & 3) + 1u + static_cast<uint32_t>(j & 3);
+                        uint32_t& word = wide[static_cast<size_t>(b) * 2 + static_cast<size_t>(j >> 4)];
+                        word |= (two & 1u) << low;
+                        word |= (two >> 1) << ((low + 4u) & 31u);
+                    }
+                    if(b < d.n_barcode) { prior[static_cast<size_t>(b)] = static_cast<float>(concentration[static_cast<size_t>(b)]); }
+                }
+                d.barcode_wide = static_cast<const uint32_t*>(upload(wide.data(), wide.size() * sizeof(uint32_t)));
+                d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
+                d.factor_pairs = device_factor_pairs;
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
                c.segment_cardinality >= 2 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
@@ -455,7 +483,7 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
 size_t DecoderSet::worklist_words(int64_t n_read) const {
     size_t worst = 0;
-    for(int64_t threads : {256, 512}) {          // workgroup sizes the product form kernel uses (stage.hip)
+    for(int64_t threads : {128, 256, 512}) {     // workgroup sizes the product form kernels use (stage.hip)
         const int64_t tiles = (n_read + threads - 1) / threads;
         const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
         const int64_t tiles_per_block = (tiles + grid - 1) / grid;

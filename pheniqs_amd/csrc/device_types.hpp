@@ -76,14 +76,18 @@ struct DevDecoder {
     double uniform_probability;           // pow(base, 10 log10 4) ~ 1/4
     // product form kernel only (ACGT barcodes of up to 16 nt): bit-sliced 2-bit codes A,C,G,T = 0..3, position
     // 4f + k with its low bit at 8f + 2 + k and its high bit 4 places up, wrapping (pamld_lut.hip); up to 8 nt two
-    // barcodes share a word (even barcode in the low half); padded to whole groups of 4 barcodes
+    // barcodes share a word (even barcode in the low half); padded to whole blocks of 8 barcodes
     const uint32_t* barcode_packed2;
-    const float* concentration_single;    // padded with zeros to whole groups of 4 barcodes
+    const float* concentration_single;    // padded with zeros to whole blocks of 8 barcodes
     // MDD exact match (mdd.cpp:43-46): open addressing hash of the ACGT barcodes; slot = {key low, key high,
     // ordinal + 1 (0 = empty), unused}, key = 2 bits per base, position j at bits 2j
     const uint32_t* exact_table;
     uint32_t exact_slots;                 // power of two
     int32_t exact_probes;                 // longest probe sequence + 1
+    // product form kernel for 17 to 32 nt (pamld_wide.hpp): two words per barcode, position j of a word with its low
+    // bit at 8 (j / 4) + 1 + j % 4 and its high bit 4 places up (wrapping); padded to whole blocks of 8 barcodes
+    const uint32_t* barcode_wide;
+    const double* factor_pairs;           // 129 x [match | mismatch] probabilities, row 128 = a base outside ACGT
     // factorised PAMLD kernel only: the barcode set is EVERY combination of per segment sets (dual / triple index)
     int32_t cross_segments;               // 0 = not combinatorial (or not supported), else n_segment
     int32_t cross_groups;                 // groups of 4 positions of the longest segment

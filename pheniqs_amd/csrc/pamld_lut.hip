@@ -9,7 +9,7 @@ int launch_pamld_lut_t2(const StageArgs&, const DevDecoder&, dim3, size_t, hipSt
 int launch_pamld_lut_t4(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 
 static int packed_words(const DevDecoder& host_decoder) {
-    const int padded = (host_decoder.n_barcode + 3) & ~3;
+    const int padded = (host_decoder.n_barcode + 7) & ~7;     // whole blocks of 8 barcodes
     return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
 }
 

@@ -55,10 +55,18 @@ __device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
 template <int L> struct LutGeometry {
     static constexpr int G = (L + 3) / 4;
     static constexpr int THREADS = L <= 8 ? 512 : 256;
-    static constexpr uint32_t GROUP_BYTES = 16 * 256 * sizeof(float);      // one group of one half: [index][256 lanes]
-    static constexpr uint32_t HALF_BYTES = G * GROUP_BYTES;
-    static constexpr uint32_t TABLE_AT = 0;                                // [half][group][index][256 lanes] floats
-    static constexpr uint32_t MATCH_AT = TABLE_AT + (THREADS / 256) * HALF_BYTES;   // FACTOR_ROWS floats
+    // Table entry (wave w, lane l, group g, index m) lives at byte address
+    //     l << 2  |  g << 8  |  m << 10  |  wave bits in what is left of bits 8, 9 and from bit 14 up
+    // so that byte 1 of the address is a byte of the (masked) mismatch field word OR-ed with a per lane constant:
+    // one v_perm_b32 builds an address, whichever byte of the word the field sits in.  Three groups (9-12 nt)
+    // would leave a quarter of that span unused and cost a workgroup of occupancy: they keep the plain
+    // [group][index][lane] layout, where a field is shifted to byte 1 first.
+    static constexpr bool PERMUTED = G != 3;
+    static constexpr uint32_t GROUP_STEP = PERMUTED ? 256u : 16u * 256u * sizeof(float);
+    static constexpr uint32_t ENTRY_STEP = 256u * sizeof(float);
+    static constexpr uint32_t TABLE_BYTES = (THREADS / 64) * G * 16u * 64u * sizeof(float);
+    static constexpr uint32_t TABLE_AT = 0;
+    static constexpr uint32_t MATCH_AT = TABLE_AT + TABLE_BYTES;           // FACTOR_ROWS floats
     static constexpr uint32_t MISMATCH_AT = MATCH_AT + 528;                // FACTOR_ROWS floats
     static constexpr uint32_t FACTOR_AT = MISMATCH_AT + 528;               // FACTOR_ROWS x [match | mismatch] doubles
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 129 * 16;          // one counter
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     // The packed barcode words as a wave wide table: lane l of register v holds word 64 v + l.  The scan reads
     // word w with one v_readlane (no memory, no wait: scalar loads share a counter with the LDS reads of the scan
     // and would serialise with them); the winner's group is fetched per lane with ds_bpermute.
-    const int padded_barcodes = (d.n_barcode + 3) & ~3;
+    const int padded_barcodes = (d.n_barcode + 7) & ~7;
     const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
     uint32_t word_table[TABLE_REGISTERS];                  // pamld_lut_supports() keeps n_word <= 64 * TABLE_REGISTERS
 #pragma unroll
@@ -115,10 +123,19 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     const int n_barcode = d.n_barcode;
     const int64_t n = args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
-    constexpr uint32_t GROUP_BYTES = LutGeometry<L>::GROUP_BYTES;
-    constexpr uint32_t ENTRY_BYTES = 256 * sizeof(float);
+    constexpr bool PERMUTED = Layout::PERMUTED;
+    constexpr uint32_t GROUP_STEP = Layout::GROUP_STEP;
+    constexpr uint32_t ENTRY_STEP = Layout::ENTRY_STEP;
     constexpr uint32_t INDEX_MASK = 0x3c00u;              // index * 1024 at byte 1 of a field word
-    const uint32_t lane_offset = (threadIdx.x >> 8) * LutGeometry<L>::HALF_BYTES + (threadIdx.x & 255u) * static_cast<uint32_t>(sizeof(float));
+    // this lane's corner of the tables: everything of an entry address but group and index
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave_byte = !PERMUTED ? 0u                                  // bits of byte 1 of the address that name the wave
+                             : G == 1 ? ((wave & 3u) | ((wave >> 2) << 6))
+                             : G == 2 ? (((wave & 1u) << 1) | ((wave >> 1) << 6))
+                             : (wave << 6);
+    const uint32_t lane_low = (threadIdx.x & 63u) << 2;
+    const uint32_t lane_offset = PERMUTED ? (lane_low | (wave_byte << 8)) : threadIdx.x * static_cast<uint32_t>(sizeof(float));
+    const uint32_t wave_bytes = wave_byte * 0x01010101u;
     uint32_t full_mask = 0;                                // the flag bit of each of the L positions
 #pragma unroll
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
@@ -178,15 +195,16 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 if(base + 3 < L) { hi[0] *= fm[base + 3]; hi[1] *= fm[base + 3]; hi[2] *= fe[base + 3]; hi[3] *= fe[base + 3]; }
 #pragma unroll
                 for(int m = 0; m < 16; ++m) {
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_BYTES + m * ENTRY_BYTES + lane_offset) = lo[m & 3] * hi[m >> 2];
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_STEP + m * ENTRY_STEP + lane_offset) = lo[m & 3] * hi[m >> 2];
                 }
             }
 
             // conditional probabilities of the PER_WORD barcodes packed in one word
             auto probabilities_of = [&](uint32_t word, float (&p)[PER_WORD]) {
                 const uint32_t fields = mismatch_fields(observed ^ word);
-                // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G): bring it to byte 1
-                const uint32_t up = fields << 8;
+                // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G)
+                const uint32_t cleaned = (fields & FIELD_MASK) | wave_bytes;             // permuted layout: byte 1 of an address
+                const uint32_t up = fields << 8;                                         // plain layout: the field to byte 1
                 const uint32_t down = fields >> 8;
                 const uint32_t far = fields >> 16;
 #pragma unroll
@@ -195,100 +213,97 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 #pragma unroll
                     for(int g = 0; g < G; ++g) {
                         const int byte = (PAIRED ? 2 * h : 0) + g;
-                        const uint32_t source = byte == 0 ? up : byte == 1 ? fields : byte == 2 ? down : far;
-                        const float entry = ((LdsFloats)static_cast<uintptr_t>((source & INDEX_MASK) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
+                        uint32_t address;
+                        if(PERMUTED) {
+                            // { 0, 0, cleaned.byte[byte], lane_low.byte[0] }
+                            address = __builtin_amdgcn_perm(cleaned, lane_low, 0x0c0c0400u | (static_cast<uint32_t>(byte) << 8));
+                        } else {
+                            const uint32_t source = byte == 0 ? up : byte == 1 ? fields : byte == 2 ? down : far;
+                            address = (source & INDEX_MASK) | lane_offset;
+                        }
+                        const float entry = ((LdsFloats)static_cast<uintptr_t>(address))[g * (GROUP_STEP / sizeof(float))];
                         value = g == 0 ? entry : value * entry;
                     }
                     p[h] = value;
                 }
             };
 
-            // Single precision scan, four barcodes at a time.  Per group of four: its maximum and its sum.  Across
-            // groups: the running maximum, WHICH group holds it, that group's sum set aside, and the sum of every
-            // other group.  The winning group's own sum is never used — subtracting the winner from it would cancel
-            // — its members are recomputed after the scan, which also names the winner inside the group.
-            float others_sum = 0;          // every group but the one holding the running maximum
-            float held_sum = 0;            // the sum of the group holding the running maximum
+            // Single precision scan, eight barcodes at a time.  Per block of eight: its maximum and its sum.  Across
+            // blocks: the running maximum, WHICH block holds it, that block's sum set aside, and the sum of every
+            // other block.  The winning block's own sum is never used — subtracting the winner from it would cancel
+            // — its members are recomputed after the scan, which also names the winner inside the block.
+            constexpr int FOLD = 8;
+            constexpr int WORDS_PER_FOLD = FOLD / PER_WORD;
+            constexpr int FOLDS_PER_REGISTER = 64 / WORDS_PER_FOLD;
+            float others_sum = 0;          // every block but the one holding the running maximum
+            float held_sum = 0;            // the sum of the block holding the running maximum
             float best_value = 0;
-            int best_group = -1;
-            auto fold_group = [&](int g, float p0, float p1, float p2, float p3) {
-                const float group_max = fmaxf(fmaxf(p0, p1), fmaxf(p2, p3));
-                const float group_sum = (p0 + p1) + (p2 + p3);
-                const bool takes_over = group_max > best_value;                      // strict: the first group keeps a tie
-                others_sum += takes_over ? held_sum : group_sum;
-                held_sum = takes_over ? group_sum : held_sum;
-                best_group = takes_over ? g : best_group;
-                best_value = takes_over ? group_max : best_value;
+            int best_fold = -1;
+            auto fold_block = [&](int f, const float (&p)[FOLD]) {
+                const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+                const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+                others_sum += takes_over ? held_sum : block_sum;
+                held_sum = takes_over ? block_sum : held_sum;
+                best_fold = takes_over ? f : best_fold;
+                best_value = takes_over ? block_max : best_value;
             };
-            auto four_of = [&](int g, const uint32_t (&w)[PAIRED ? 2 : 4], float (&p)[4]) {
-                // barcodes 4g .. 4g+3; the table is padded to whole groups, padding is zeroed by the caller
-                if(PAIRED) {
-                    float a[PER_WORD];
-                    float b[PER_WORD];
-                    probabilities_of(w[0], a);
-                    probabilities_of(w[1], b);
-                    p[0] = a[0]; p[1] = a[PER_WORD - 1]; p[2] = b[0]; p[3] = b[PER_WORD - 1];
-                } else {
+            auto scan_block = [&](int f, const uint32_t (&w)[WORDS_PER_FOLD], bool partial) {
+                // barcodes 8f .. 8f+7; the table is padded to whole blocks, the padding's probabilities are zeroed
+                float p[FOLD];
 #pragma unroll
-                    for(int k = 0; k < 4; ++k) {
-                        float a[PER_WORD];
-                        probabilities_of(w[PAIRED ? 0 : k], a);
-                        p[k] = a[0];
-                    }
+                for(int k = 0; k < WORDS_PER_FOLD; ++k) {
+                    float a[PER_WORD];
+                    probabilities_of(w[k], a);
+#pragma unroll
+                    for(int h = 0; h < PER_WORD; ++h) { p[PER_WORD * k + h] = a[h]; }
                 }
                 if(!UNIFORM_PRIOR) {
 #pragma unroll
-                    for(int k = 0; k < 4; ++k) { p[k] *= prior[4 * g + k]; }         // padded with zeros
+                    for(int k = 0; k < FOLD; ++k) { p[k] *= prior[FOLD * f + k]; }     // padded with zeros
                 }
-            };
-            constexpr int WORDS_PER_GROUP = PAIRED ? 2 : 4;
-            constexpr int GROUPS_PER_REGISTER = 64 / WORDS_PER_GROUP;
-            const int n_full = n_barcode >> 2;
-            auto scan_group = [&](int g, const uint32_t (&w)[WORDS_PER_GROUP], bool partial) {
-                float p[4];
-                four_of(g, w, p);
                 if(partial) {
 #pragma unroll
-                    for(int k = 1; k < 4; ++k) { if(4 * g + k >= n_barcode) { p[k] = 0.0f; } }
+                    for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= n_barcode) { p[k] = 0.0f; } }
                 }
-                fold_group(g, p[0], p[1], p[2], p[3]);
+                fold_block(f, p);
             };
+            const int n_full = n_barcode / FOLD;
             {
 #pragma unroll
                 for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                    const int first = v * GROUPS_PER_REGISTER;
-                    const int last = min(n_full, first + GROUPS_PER_REGISTER);
-                    for(int g = first; g < last; ++g) {
-                        uint32_t w[WORDS_PER_GROUP];
+                    const int first = v * FOLDS_PER_REGISTER;
+                    const int last = min(n_full, first + FOLDS_PER_REGISTER);
+                    for(int f = first; f < last; ++f) {
+                        uint32_t w[WORDS_PER_FOLD];
 #pragma unroll
-                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (g - first) * WORDS_PER_GROUP + k);
+                        for(int k = 0; k < WORDS_PER_FOLD; ++k) {
+                            w[k] = __builtin_amdgcn_readlane(word_table[v], (f - first) * WORDS_PER_FOLD + k);
                         }
-                        scan_group(g, w, false);
+                        scan_block(f, w, false);
                     }
-                    if((n_barcode & 3) && n_full >= first && n_full < first + GROUPS_PER_REGISTER) {     // the last, partial group
-                        uint32_t w[WORDS_PER_GROUP];
+                    if((n_barcode % FOLD) && n_full >= first && n_full < first + FOLDS_PER_REGISTER) {     // the last, partial block
+                        uint32_t w[WORDS_PER_FOLD];
 #pragma unroll
-                        for(int k = 0; k < WORDS_PER_GROUP; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (n_full - first) * WORDS_PER_GROUP + k);
+                        for(int k = 0; k < WORDS_PER_FOLD; ++k) {
+                            w[k] = __builtin_amdgcn_readlane(word_table[v], (n_full - first) * WORDS_PER_FOLD + k);
                         }
-                        scan_group(n_full, w, true);
+                        scan_block(n_full, w, true);
                     }
                 }
             }
 
-            // inside the winning group: the winner (first of equals) and the sum of the other three
+            // inside the winning block: the winner (first of equals) and the sum of the other seven
             int best = -1;
             uint32_t best_flags = 0;
             float sigma = others_sum;
             {
-                const int group = best_group < 0 ? 0 : best_group;
+                const int block = best_fold < 0 ? 0 : best_fold;
                 float top = 0;
                 float rest = 0;
 #pragma unroll
-                for(int k = 0; k < 4; ++k) {
-                    const int b = 4 * group + k;
-                    const int w = PAIRED ? (b >> 1) : b;
+                for(int k = 0; k < WORDS_PER_FOLD; ++k) {
+                    const int w = WORDS_PER_FOLD * block + k;
                     uint32_t word = 0;
                     // lane (w & 63) of register (w >> 6): a gather inside the wave
 #pragma unroll
@@ -299,21 +314,21 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                         }
                     }
                     const uint32_t fields = mismatch_fields(observed ^ word);
-                    float p = 1.0f;
+                    float a[PER_WORD];
+                    probabilities_of(word, a);
 #pragma unroll
-                    for(int g = 0; g < G; ++g) {
-                        const int shift = 8 * ((PAIRED ? 2 * (k & 1) : 0) + g);
-                        const uint32_t index = (fields >> shift) & 0x3cu;
-                        p *= ((LdsFloats)static_cast<uintptr_t>((index << 8) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
+                    for(int h = 0; h < PER_WORD; ++h) {
+                        const int b = FOLD * block + PER_WORD * k + h;
+                        float p = a[h];
+                        if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
+                        if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
+                        rest += fminf(p, top);
+                        if(p > top) {
+                            best = b;
+                            best_flags = ((PAIRED ? (fields >> (16 * h)) : fields) | outside) & full_mask;
+                        }
+                        top = fmaxf(p, top);
                     }
-                    if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
-                    if(b >= n_barcode || best_group < 0) { p = 0.0f; }
-                    rest += fminf(p, top);
-                    if(p > top) {
-                        best = b;
-                        best_flags = ((PAIRED ? (fields >> (16 * (k & 1))) : fields) | outside) & full_mask;
-                    }
-                    top = fmaxf(p, top);
                 }
                 sigma += rest;
             }
@@ -427,7 +442,7 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
 }
 
 inline int packed_words(const DevDecoder& host_decoder) {
-    const int padded = (host_decoder.n_barcode + 3) & ~3;
+    const int padded = (host_decoder.n_barcode + 7) & ~7;
     return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
 }
 

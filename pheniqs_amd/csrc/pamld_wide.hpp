@@ -1,0 +1,342 @@
+// K1 (product form, long barcodes): PamlDecoder<T>::classify for ACGT barcodes of 17 to 32 nt — paired dual
+// indices that are NOT every combination of their segments (those factorise: pamld_cross.hpp), long cellular
+// barcodes.  Same method as pamld_lut.hpp, which has the argument and the certificate; what differs:
+//
+//   * a barcode is TWO words of bit-sliced 2-bit bases (16 positions each); position j of a word has its low
+//     code bit at 8 (j / 4) + 1 + j % 4 and its high bit 4 places up (wrapping), so X | rotr(X, 4) leaves
+//     index * 2 of group f in bits 1..4 of byte f;
+//   * 5 to 8 sixteen entry tables per read = 320 to 512 bytes of LDS per lane, so a workgroup is 128 lanes and
+//     the tables are [group][index][128 lanes]: byte 1 of an entry address is (lane >> 6) | index << 1, i.e. a
+//     byte of the masked field word OR-ed with a per lane constant — one v_perm_b32 per address — and the
+//     group is the instruction's immediate offset;
+//   * the packed barcode words and the single precision priors sit in LDS and are read at wave uniform
+//     addresses (one ds_read_b128 serves two barcodes), not in a wave wide register.
+//
+//   reference pamld.cpp:37-123, barcode.h:131-164, phred.cpp:44-68
+#pragma once
+
+#include "kernel_common.hpp"
+
+namespace phq {
+namespace wide {
+
+constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner (pamld_lut.hpp)
+constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
+constexpr int THREADS = 128;
+constexpr int FOLD = 8;                       // barcodes per block of the scan
+constexpr uint32_t FIELD_MASK = 0x1e1e1e1eu;
+
+__host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * ((position >> 2) & 3) + 1u + (position & 3); }
+__host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
+
+__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
+    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4); bits outside FIELD_MASK are junk
+}
+
+typedef __attribute__((address_space(3))) const float* LdsFloats;
+
+// one hand laid dynamic LDS block at LDS address 0 (no static LDS; pamld_lut.hpp)
+struct Layout {
+    uint32_t words_at;        // padded barcodes x 2 words
+    uint32_t prior_at;        // padded barcodes floats
+    uint32_t match_at;
+    uint32_t mismatch_at;
+    uint32_t deferred_at;
+    uint32_t histogram_at;
+};
+constexpr uint32_t GROUP_STEP = 16u * THREADS * sizeof(float);
+constexpr uint32_t ENTRY_STEP = THREADS * sizeof(float);
+__host__ __device__ inline Layout layout_of(int groups, int padded_barcodes) {
+    Layout l;
+    l.words_at = static_cast<uint32_t>(groups) * GROUP_STEP;
+    l.prior_at = l.words_at + static_cast<uint32_t>(padded_barcodes) * 8u;
+    l.match_at = l.prior_at + static_cast<uint32_t>(padded_barcodes) * 4u;
+    l.mismatch_at = l.match_at + 528u;
+    l.deferred_at = l.mismatch_at + 528u;
+    l.histogram_at = l.deferred_at + 16u;
+    return l;
+}
+
+// G = groups of 4 positions = words of the plane row (plane stride = 4 G bytes, zero filled past the barcode)
+template <int G>
+__global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
+    constexpr int WORDS = (G + 3) / 4;        // words of 16 positions: 2
+    static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
+    DecoderRef d = *constant_cast(args.decoder);
+    const int n_barcode = d.n_barcode;
+    const int padded_barcodes = (n_barcode + FOLD - 1) / FOLD * FOLD;
+    const Layout at = layout_of(G, padded_barcodes);
+    float* const table = reinterpret_cast<float*>(lds_raw);
+    uint2* const barcode_words = reinterpret_cast<uint2*>(lds_raw + at.words_at);
+    float* const prior_single = reinterpret_cast<float*>(lds_raw + at.prior_at);
+    float* const match_single = reinterpret_cast<float*>(lds_raw + at.match_at);
+    float* const mismatch_single = reinterpret_cast<float*>(lds_raw + at.mismatch_at);
+    // the fp64 factor rows stay in global memory (20 to 32 cached loads per read, once): with them in LDS three
+    // workgroups of the 20 nt shape would no longer fit a CU
+    const double* const factor_pairs = d.factor_pairs;
+    uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + at.deferred_at);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + at.histogram_at);
+
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+        const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        match_single[i] = static_cast<float>(m);
+        mismatch_single[i] = static_cast<float>(e);
+    }
+    for(int b = threadIdx.x; b < padded_barcodes; b += THREADS) {
+        barcode_words[b] = make_uint2(d.barcode_wide[2 * b], d.barcode_wide[2 * b + 1]);
+        prior_single[b] = d.concentration_single[b];                 // zero for the padding
+    }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const int L = d.nucleotide_cardinality;
+    const bool uniform_prior = d.uniform_prior != 0;
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + THREADS - 1) / THREADS;
+    const uint32_t lane_low = (threadIdx.x & 63u) << 2;                       // byte 0 of an entry address
+    const uint32_t lane_high_bytes = ((threadIdx.x >> 6) & 1u) * 0x01010101u;  // bit 0 of byte 1 of an entry address
+    const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
+    uint32_t full_mask[WORDS];                                                // the flag bit of each of the L positions
+#pragma unroll
+    for(int w = 0; w < WORDS; ++w) { full_mask[w] = 0; }
+#pragma unroll
+    for(int j = 0; j < 4 * G; ++j) { if(j < L) { full_mask[j >> 4] |= 1u << low_bit(j); } }
+
+    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const bool active = tile * THREADS + threadIdx.x < n;
+        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        ReadState r = load_read_state(args, i);
+        bool defer = false;
+        {
+            uint32_t code_words[G];
+            uint32_t quality_words[G];
+            {
+                const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * (4 * G));
+                const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * (4 * G));
+#pragma unroll
+                for(int g = 0; g < G; ++g) { code_words[g] = code_row[g]; quality_words[g] = quality_row[g]; }
+            }
+            // per position: factor row, single precision factors, 2-bit base, high quality flag
+            float fm[4 * G];
+            float fe[4 * G];
+            uint32_t row[G];
+            uint32_t observed[WORDS];
+            uint32_t high_quality[WORDS];
+            uint32_t outside[WORDS];
+#pragma unroll
+            for(int w = 0; w < WORDS; ++w) { observed[w] = 0; high_quality[w] = 0; outside[w] = 0; }
+#pragma unroll
+            for(int g = 0; g < G; ++g) { row[g] = 0; }
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t c = (code_words[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q8 = (quality_words[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q = q8 & 0x7fu;
+                // outside ACGT: the uniform quality against every barcode base (phred.cpp:62-64); absent: row 0 = 1, 1
+                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
+                fm[j] = match_single[k];
+                fe[j] = mismatch_single[k];
+                row[j >> 2] |= k << (8 * (j & 3));
+                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
+                observed[j >> 4] |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality[j >> 4] |= 1u << low_bit(j); }
+                if(!strict_code(c)) { outside[j >> 4] |= 1u << low_bit(j); }
+            }
+            // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
+#pragma unroll
+            for(int g = 0; g < G; ++g) {
+                const int base = 4 * g;
+                float lo[4];
+                float hi[4];
+                lo[0] = fm[base] * fm[base + 1];
+                lo[1] = fe[base] * fm[base + 1];
+                lo[2] = fm[base] * fe[base + 1];
+                lo[3] = fe[base] * fe[base + 1];
+                hi[0] = fm[base + 2] * fm[base + 3];
+                hi[1] = fe[base + 2] * fm[base + 3];
+                hi[2] = fm[base + 2] * fe[base + 3];
+                hi[3] = fe[base + 2] * fe[base + 3];
+#pragma unroll
+                for(int m = 0; m < 16; ++m) {
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_STEP + m * ENTRY_STEP + lane_offset) = lo[m & 3] * hi[m >> 2];
+                }
+            }
+
+            // P(r|b) of one barcode from its two words; also leaves the mismatch fields
+            auto probability_of = [&](const uint2 pair, uint32_t (&fields)[WORDS]) {
+                fields[0] = mismatch_fields(observed[0] ^ pair.x);
+                fields[1] = mismatch_fields(observed[1] ^ pair.y);
+                float value = 1.0f;
+#pragma unroll
+                for(int g = 0; g < G; ++g) {
+                    const uint32_t cleaned = (fields[g >> 2] & FIELD_MASK) | lane_high_bytes;
+                    // { 0, 0, cleaned.byte[g % 4], lane_low.byte[0] }: byte 1 = (lane >> 6) | index << 1
+                    const uint32_t address = __builtin_amdgcn_perm(cleaned, lane_low, 0x0c0c0400u | (static_cast<uint32_t>(g & 3) << 8));
+                    const float entry = ((LdsFloats)static_cast<uintptr_t>(address))[g * (GROUP_STEP / sizeof(float))];
+                    value = g == 0 ? entry : value * entry;
+                }
+                return value;
+            };
+
+            // single precision scan, eight barcodes at a time (pamld_lut.hpp has the bookkeeping's rationale)
+            float others_sum = 0;
+            float held_sum = 0;
+            float best_value = 0;
+            int best_fold = -1;
+            const int n_fold = padded_barcodes / FOLD;
+            for(int f = 0; f < n_fold; ++f) {
+                float p[FOLD];
+#pragma unroll
+                for(int k = 0; k < FOLD; ++k) {
+                    uint32_t fields[WORDS];
+                    p[k] = probability_of(barcode_words[FOLD * f + k], fields);           // wave uniform address
+                }
+                if(!uniform_prior) {
+#pragma unroll
+                    for(int k = 0; k < FOLD; ++k) { p[k] *= prior_single[FOLD * f + k]; }
+                }
+                if(f == n_fold - 1) {
+#pragma unroll
+                    for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= n_barcode) { p[k] = 0.0f; } }
+                }
+                const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+                const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                const bool takes_over = block_max > best_value;                          // strict: the first block keeps a tie
+                others_sum += takes_over ? held_sum : block_sum;
+                held_sum = takes_over ? block_sum : held_sum;
+                best_fold = takes_over ? f : best_fold;
+                best_value = takes_over ? block_max : best_value;
+            }
+
+            // inside the winning block: the winner (first of equals) and the sum of the other seven
+            int best = -1;
+            uint32_t best_flags[WORDS];
+#pragma unroll
+            for(int w = 0; w < WORDS; ++w) { best_flags[w] = 0; }
+            float sigma = others_sum;
+            {
+                const int block = best_fold < 0 ? 0 : best_fold;
+                float top = 0;
+                float rest = 0;
+#pragma unroll
+                for(int k = 0; k < FOLD; ++k) {
+                    const int b = FOLD * block + k;
+                    uint32_t fields[WORDS];
+                    float p = probability_of(barcode_words[b], fields);
+                    if(!uniform_prior) { p *= prior_single[b]; }
+                    if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
+                    rest += fminf(p, top);
+                    if(p > top) {
+                        best = b;
+#pragma unroll
+                        for(int w = 0; w < WORDS; ++w) { best_flags[w] = (fields[w] | outside[w]) & full_mask[w]; }
+                    }
+                    top = fmaxf(p, top);
+                }
+                sigma += rest;
+            }
+
+            if(best < 0) {
+                defer = true;
+            } else {
+                int distance = 0;
+                int hq_distance = 0;
+#pragma unroll
+                for(int w = 0; w < WORDS; ++w) {
+                    distance += __popc(best_flags[w]);
+                    hq_distance += __popc(best_flags[w] & high_quality[w]);
+                }
+                double best_conditional = 1.0;
+#pragma unroll
+                for(int j = 0; j < 4 * G; ++j) {
+                    const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    best_conditional *= factor_pairs[2 * k + ((best_flags[j >> 4] >> low_bit(j)) & 1u)];
+                }
+                const double best_p = best_conditional * d.concentration[best];
+                const double others = uniform_prior ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma);
+                const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+                double confidence = best_p / total;                                       // pamld.cpp:92
+                const double noise_margin = best_conditional - d.random_barcode_probability;
+                const double confidence_margin = confidence - d.confidence_threshold;
+                defer = !(others <= DOMINANCE * best_p)
+                     || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
+                     || !(fabs(confidence_margin) > 1e-9);
+                if(!defer && active) {
+                    int bin = best + 1;
+                    uint8_t status = STATUS_PASS;
+                    if(noise_margin > 0) {                                                // pamld.cpp:96
+                        if(confidence_margin > 0) {                                       // pamld.cpp:99
+                            if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) {
+                                r.qcfail = true;
+                            }
+                            stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                        } else {
+                            stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                            r.qcfail = true;
+                            status = STATUS_LOW_CONFIDENCE;
+                        }
+                    } else {
+                        stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                        r.qcfail = true;
+                        bin = 0;
+                        distance = 0;
+                        hq_distance = 0;
+                        confidence = 0;
+                        status = STATUS_NOISE;
+                    }
+                    decoder_tail(d, sink, r, bin, distance);
+                    if(args.result) {
+                        DevResult out;
+                        out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                        out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                        out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                        out.status = status;
+                        out.qcfail = r.qcfail ? 1 : 0;
+                        out.confidence = confidence;
+                        args.result[i] = out;
+                    }
+                    store_read_state(args, i, r);
+                }
+            }
+        }
+        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
+        const unsigned long long deferred = __ballot(active && defer);
+        if(deferred) {
+            const int lane = threadIdx.x & 63;
+            uint32_t first = 0;
+            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            first = __shfl(first, 0);
+            if(active && defer) {
+                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+            }
+        }
+        count_outgoing(args, histogram, active && !defer, r);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+template <int G>
+int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    static bool prepared = false;                           // more than 64 KiB of dynamic LDS has to be asked for
+    if(!prepared) {
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_wide_kernel<G>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if(status != hipSuccess) { return static_cast<int>(status); }
+        prepared = true;
+    }
+    const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
+    const size_t lds_bytes = layout_of(G, padded).histogram_at + histogram_bytes;
+    hipLaunchKernelGGL((pamld_wide_kernel<G>), grid, dim3(THREADS), lds_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace wide
+}  // namespace phq

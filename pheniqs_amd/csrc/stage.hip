@@ -18,7 +18,7 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
     if(mode != MODE_FAST) { return false; }
-    return (host_decoder.algorithm == 1 && (pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder))) ||
+    return (host_decoder.algorithm == 1 && (pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder) || pamld_wide_supports(host_decoder))) ||
            (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
 
@@ -44,8 +44,10 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 // tier 1: product form over every read, deferring the ambiguous ones; tier 2: the literal kernel on those
                 // both launches use the same grid: literal workgroup g consumes what product form workgroup g deferred
                 // a combinatorial barcode set too large for the per barcode product form goes through the factorised one
-                const bool factorised = !pamld_lut_supports(host_decoder);
-                const int64_t threads = factorised ? BLOCK : pamld_lut_block(host_decoder);
+                // ... and long barcodes that are not combinatorial through the two word product form
+                const bool factorised = !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
+                const bool long_words = !pamld_lut_supports(host_decoder) && !factorised;
+                const int64_t threads = factorised ? BLOCK : long_words ? pamld_wide_block() : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < max_blocks ? wide_tiles : max_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
@@ -56,6 +58,7 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
                     status = factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
+                           : long_words ? launch_pamld_wide(producer, host_decoder, wide_grid, histogram_bytes, s)
                                         : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }

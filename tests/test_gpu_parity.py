@@ -279,6 +279,35 @@ def test_paired_sets_that_are_not_combinatorial_stay_exact(oracle, torch_cuda):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
+@pytest.mark.parametrize("lengths,count,uniform", [((10, 10), 24, True), ((17,), 13, False), ((12, 12), 40, False), ((8, 8, 8, 8), 9, True), ((29,), 130, True)])
+def test_long_barcodes_take_the_two_word_product_form(oracle, torch_cuda, lengths, count, uniform):
+    """ACGT barcodes of 17 to 32 nt that are not combinatorial (zip paired segments, long single words) go through
+    pamld_wide.hpp in PHQ_MODE_FAST: every group count 5..8, barcode counts off the block of 8, priors uniform or
+    not, N calls, zero qualities, short observations, uniform qualities (ties)."""
+    rng = np.random.default_rng(sum(lengths) * 17 + count)
+    segments = [synthetic.barcode_set(rng, count, l, min_distance=3) for l in lengths]
+    rng.shuffle(segments[-1])                                 # the pairing is arbitrary, not sorted against sorted
+    tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
+    decoder = synthetic.decoder_spec("pamld", segments, tokens, pairing="zip", **{"confidence threshold": 0.9})
+    if not uniform:
+        for k, record in enumerate(decoder["codec"].values()):
+            record["concentration"] = 1 + (k % 5)
+    job = jobspec.compile_job({"input segment cardinality": len(lengths), "sample": decoder})
+    n = 1 << 13
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 9)
+    L = sum(lengths)
+    noisy = rng.random((n, L)) < 0.02
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random((n, L)) < 0.02] = 0
+    quality[: n // 8] = 30
+    for i in range(L):
+        code[n // 2 + i, i:] = 0
+        quality[n // 2 + i, i:] = 0
+    quality[n // 2 + L] = 255
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+
+
 def test_iupac_barcodes_take_the_uniform_branch(oracle, torch_cuda):
     """barcode letters outside ACGT always cost UNIFORM_BASE_QUALITY (the STRICT=false kernels)."""
     spec = {"input segment cardinality": 1,
