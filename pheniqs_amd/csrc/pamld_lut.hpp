@@ -66,16 +66,16 @@ template <int L> struct LutGeometry {
     static constexpr uint32_t ENTRY_STEP = 256u * sizeof(float);
     static constexpr uint32_t TABLE_BYTES = (THREADS / 64) * G * 16u * 64u * sizeof(float);
     static constexpr uint32_t TABLE_AT = 0;
-    static constexpr uint32_t MATCH_AT = TABLE_AT + TABLE_BYTES;           // FACTOR_ROWS floats
-    static constexpr uint32_t MISMATCH_AT = MATCH_AT + 528;                // FACTOR_ROWS floats
-    static constexpr uint32_t FACTOR_AT = MISMATCH_AT + 528;               // FACTOR_ROWS x [match | mismatch] doubles
+    static constexpr uint32_t MATCH_AT = TABLE_AT + TABLE_BYTES;           // FACTOR_ROWS x {match, mismatch} floats
+    static constexpr uint32_t FACTOR_AT = MATCH_AT + 1056;                 // FACTOR_ROWS x [match | mismatch] doubles
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 129 * 16;          // one counter
-    static constexpr uint32_t HISTOGRAM_AT = DEFERRED_AT + 16;             // the counter histogram (kernel_common.hpp)
+    static constexpr uint32_t WORDS_AT = DEFERRED_AT + 16;                 // the packed barcode words, up to 256
+    static constexpr uint32_t HISTOGRAM_AT = WORDS_AT + 1024;              // the counter histogram (kernel_common.hpp)
 };
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 
-template <int L, bool UNIFORM_PRIOR, int TABLE_REGISTERS>
+template <int L, bool UNIFORM_PRIOR>
 __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
     constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
     constexpr int THREADS = LutGeometry<L>::THREADS;
@@ -87,8 +87,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float* const table = reinterpret_cast<float*>(lds_raw + Layout::TABLE_AT);
-    float* const match_single = reinterpret_cast<float*>(lds_raw + Layout::MATCH_AT);
-    float* const mismatch_single = reinterpret_cast<float*>(lds_raw + Layout::MISMATCH_AT);
+    float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::MATCH_AT);       // [row] {match, mismatch}
     double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + Layout::FACTOR_AT);   // [row][0 match | 1 mismatch]
     uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + Layout::DEFERRED_AT);
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::HISTOGRAM_AT);
@@ -97,28 +96,25 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
         const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
         const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
-        match_single[i] = static_cast<float>(m);
-        mismatch_single[i] = static_cast<float>(e);
+        factor_single[i] = make_float2(static_cast<float>(m), static_cast<float>(e));
         factor_double[i][0] = m;
         factor_double[i][1] = e;
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
+    uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + Layout::WORDS_AT);
+    {
+        const int padded = (d.n_barcode + 7) & ~7;
+        const int words = PAIRED ? padded >> 1 : padded;
+        for(int w = threadIdx.x; w < words; w += THREADS) { lds_words[w] = d.barcode_packed2[w]; }
+    }
     histogram_clear(d, histogram);
     __syncthreads();
 
     const StatSink sink{histogram, args.stats};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
-    // The packed barcode words as a wave wide table: lane l of register v holds word 64 v + l.  The scan reads
-    // word w with one v_readlane (no memory, no wait: scalar loads share a counter with the LDS reads of the scan
-    // and would serialise with them); the winner's group is fetched per lane with ds_bpermute.
-    const int padded_barcodes = (d.n_barcode + 7) & ~7;
-    const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
-    uint32_t word_table[TABLE_REGISTERS];                  // pamld_lut_supports() keeps n_word <= 64 * TABLE_REGISTERS
-#pragma unroll
-    for(int v = 0; v < TABLE_REGISTERS; ++v) {
-        const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
-        word_table[v] = w < n_word ? d.barcode_packed2[w] : 0u;
-    }
+    // The packed barcode words sit in LDS: the scan reads a block's words at a wave uniform address (scalar loads
+    // would share a counter with the LDS reads of the scan and serialise with them), the winner's block is
+    // read back per lane.
     const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
     const int64_t n = args.n_read;
@@ -136,6 +132,9 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     const uint32_t lane_low = (threadIdx.x & 63u) << 2;
     const uint32_t lane_offset = PERMUTED ? (lane_low | (wave_byte << 8)) : threadIdx.x * static_cast<uint32_t>(sizeof(float));
     const uint32_t wave_bytes = wave_byte * 0x01010101u;
+    // quality >= high quality threshold, byte parallel: (quality & 0x7f) + (128 - threshold) reaches bit 7
+    const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
+    const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
     uint32_t full_mask = 0;                                // the flag bit of each of the L positions
 #pragma unroll
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
@@ -149,34 +148,59 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         bool defer = false;
         {
             r = load_read_state(args, i);
-            uint8_t code[LP];
-            uint8_t quality[LP];
-            load_plane_row<L>(args.base, i, code);
-            load_plane_row<L>(args.quality, i, quality);
+            constexpr int W = (L + 3) / 4;
+            uint32_t code_words[W];
+            uint32_t quality_words[W];
+            {
+                const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * (4 * W));
+                const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * (4 * W));
+#pragma unroll
+                for(int w = 0; w < W; ++w) { code_words[w] = code_row[w]; quality_words[w] = quality_row[w]; }
+            }
 
-            // per position: factor row, single precision factors, 2-bit base, high quality flag
+            // Per position: factor row, 2-bit base, high quality and "outside ACGT" flags — four positions (one plane
+            // word) at a time, byte parallel.  Bit 7 of a byte is its position's flag until two flag planes at a time
+            // (bits 0 and 4 of each byte) are gathered into one byte [plane 1 nibble | plane 0 nibble].
             float fm[L];
             float fe[L];
-            uint32_t row[(L + 3) / 4];                     // factor rows, 8 bits per position
+            uint32_t row[W];                               // factor rows, 8 bits per position
             uint32_t observed = 0;                         // bit-sliced 2-bit codes; anything outside ACGT arbitrary
             uint32_t high_quality = 0;                     // flag bits (low_bit of the position)
             uint32_t outside = 0;                          // flag bits: not A, C, G or T (mismatches every barcode base)
+            auto gather = [](uint32_t planes) {            // bits 8 j and 8 j + 4 -> bits j and 4 + j
+                const uint32_t t = planes | (planes >> 7);
+                return (t | (t >> 14)) & 0xffu;
+            };
 #pragma unroll
-            for(int w = 0; w < (L + 3) / 4; ++w) { row[w] = 0; }
+            for(int w = 0; w < W; ++w) {
+                constexpr uint32_t ALL = 0xffffffffu;
+                const uint32_t valid = (L - 4 * w) >= 4 ? ALL : ((1u << (8 * (L - 4 * w))) - 1u);      // the bytes of positions < L
+                const uint32_t x = code_words[w] & (0x0f0f0f0fu & valid);        // BAM codes
+                const uint32_t q8 = quality_words[w] & valid;
+                const uint32_t q7 = q8 & 0x7f7f7f7fu;                             // the table has 128 rows
+                // A, C, G or T = exactly one bit of the nibble: x != 0 and x & (x - 1) == 0   (iupac.h:51-56)
+                const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
+                const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+                const uint32_t strict_bytes = (strict - (strict >> 7)) | strict;                       // 0xff where strict
+                // a base outside ACGT costs the uniform quality against every barcode base (row 128), nothing at
+                // quality 0 (row 0): both factors equal, whatever its 2-bit code compares to (phred.cpp:62-64)
+                const uint32_t nonzero = (q7 + 0x7f7f7f7fu) & 0x80808080u;
+                row[w] = (q7 & strict_bytes) | (nonzero & ~strict_bytes);
+                // A, C, G, T (1, 2, 4, 8) -> 0..3: the low code bit is bit 1 | bit 3 (plane 0), the high one bit 2 | bit 3 (plane 1)
+                const uint32_t codes = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
+                observed |= __builtin_amdgcn_alignbit(codes, codes, (32 - (8 * w + 2)) & 31);           // rotl: the high nibble of byte 3 wraps
+                // quality >= threshold, for thresholds of 0..128 (pamld_lut_supports): no byte carries into the next
+                const uint32_t high = ((q7 + high_quality_addend) | q8) & 0x80808080u & valid;
+                const uint32_t flags = gather(((~strict & 0x80808080u & valid) >> 7) | (high >> 3));
+                outside |= (flags & 0xfu) << (8 * w + 2);
+                high_quality |= (flags >> 4) << (8 * w + 2);
+            }
 #pragma unroll
             for(int j = 0; j < L; ++j) {
-                const uint32_t c = code[j];
-                const uint32_t q = quality[j] & 0x7fu;
-                // a base outside ACGT costs the uniform quality against every barcode base: both factors equal,
-                // so whatever its 2-bit code compares to does not matter (phred.cpp:62-64)
-                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
-                fm[j] = match_single[k];
-                fe[j] = mismatch_single[k];
-                row[j >> 2] |= k << (8 * (j & 3));
-                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
-                observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
-                if(static_cast<int>(quality[j]) >= d.high_quality_threshold) { high_quality |= 1u << low_bit(j); }
-                if(!strict_code(c)) { outside |= 1u << low_bit(j); }
+                const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const float2 pair = factor_single[k];
+                fm[j] = pair.x;
+                fe[j] = pair.y;
             }
             if(PAIRED) { observed |= __builtin_amdgcn_alignbit(observed, observed, 16); }     // the same read against both halves
             // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
@@ -270,26 +294,26 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             };
             const int n_full = n_barcode / FOLD;
             {
+                // the block's words from LDS at a wave uniform address (a broadcast: one ds_read_b128 brings four
+                // words to every lane; the other waves of the SIMD cover its latency)
+                const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words);
+                constexpr int QUADS = WORDS_PER_FOLD / 4;
+                auto words_of = [&](int f, uint32_t (&w)[WORDS_PER_FOLD]) {
 #pragma unroll
-                for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                    const int first = v * FOLDS_PER_REGISTER;
-                    const int last = min(n_full, first + FOLDS_PER_REGISTER);
-                    for(int f = first; f < last; ++f) {
-                        uint32_t w[WORDS_PER_FOLD];
-#pragma unroll
-                        for(int k = 0; k < WORDS_PER_FOLD; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (f - first) * WORDS_PER_FOLD + k);
-                        }
-                        scan_block(f, w, false);
+                    for(int q = 0; q < QUADS; ++q) {
+                        const uint4 quad = blocks[QUADS * f + q];
+                        w[4 * q] = quad.x; w[4 * q + 1] = quad.y; w[4 * q + 2] = quad.z; w[4 * q + 3] = quad.w;
                     }
-                    if((n_barcode % FOLD) && n_full >= first && n_full < first + FOLDS_PER_REGISTER) {     // the last, partial block
-                        uint32_t w[WORDS_PER_FOLD];
-#pragma unroll
-                        for(int k = 0; k < WORDS_PER_FOLD; ++k) {
-                            w[k] = __builtin_amdgcn_readlane(word_table[v], (n_full - first) * WORDS_PER_FOLD + k);
-                        }
-                        scan_block(n_full, w, true);
-                    }
+                };
+                for(int f = 0; f < n_full; ++f) {
+                    uint32_t w[WORDS_PER_FOLD];
+                    words_of(f, w);
+                    scan_block(f, w, false);
+                }
+                if(n_barcode % FOLD) {                                                   // the last, partial block
+                    uint32_t w[WORDS_PER_FOLD];
+                    words_of(n_full, w);
+                    scan_block(n_full, w, true);
                 }
             }
 
@@ -304,15 +328,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 #pragma unroll
                 for(int k = 0; k < WORDS_PER_FOLD; ++k) {
                     const int w = WORDS_PER_FOLD * block + k;
-                    uint32_t word = 0;
-                    // lane (w & 63) of register (w >> 6): a gather inside the wave
-#pragma unroll
-                    for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                        if(64 * v < n_word) {
-                            const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((w & 63) << 2, static_cast<int>(word_table[v])));
-                            word = (w >> 6) == v ? got : word;
-                        }
-                    }
+                    const uint32_t word = lds_words[w];
                     const uint32_t fields = mismatch_fields(observed ^ word);
                     float a[PER_WORD];
                     probabilities_of(word, a);
@@ -412,32 +428,32 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     histogram_flush(args, d, histogram);
 }
 
-template <int L, bool UNIFORM_PRIOR, int TABLE_REGISTERS>
+template <int L, bool UNIFORM_PRIOR>
 int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t lds_bytes = LutGeometry<L>::HISTOGRAM_AT + histogram_bytes;
     static bool prepared = false;                           // per instantiation; more than 64 KiB of dynamic LDS has to be asked for
     if(!prepared) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_lut_kernel<L, UNIFORM_PRIOR, TABLE_REGISTERS>),
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_lut_kernel<L, UNIFORM_PRIOR>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if(status != hipSuccess) { return static_cast<int>(status); }
         prepared = true;
     }
-    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR, TABLE_REGISTERS>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-// instantiate every nucleotide cardinality of [LO, HI] for one table size and dispatch on the decoder
-template <int LO, int HI, int TABLE_REGISTERS>
+// instantiate every nucleotide cardinality of [LO, HI] and dispatch on the decoder
+template <int LO, int HI>
 int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     if constexpr(LO > HI) {
         (void)args; (void)host_decoder; (void)grid; (void)histogram_bytes; (void)stream;
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            return host_decoder.uniform_prior ? launch_one<LO, true, TABLE_REGISTERS>(args, grid, histogram_bytes, stream)
-                                              : launch_one<LO, false, TABLE_REGISTERS>(args, grid, histogram_bytes, stream);
+            return host_decoder.uniform_prior ? launch_one<LO, true>(args, grid, histogram_bytes, stream)
+                                              : launch_one<LO, false>(args, grid, histogram_bytes, stream);
         }
-        return launch_range<LO + 1, HI, TABLE_REGISTERS>(args, host_decoder, grid, histogram_bytes, stream);
+        return launch_range<LO + 1, HI>(args, host_decoder, grid, histogram_bytes, stream);
     }
 }
 
