@@ -22,11 +22,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def profiled_traffic(mode, reads):
+def profiled_traffic(mode, reads, config="C2", algorithm="pamld", kernel_mode="fast"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_summary.json),
-    scaled to this run's reads per launch.  PMC counters cannot be read from inside the benchmark itself."""
+    scaled to this run's reads per launch.  PMC counters cannot be read from inside the benchmark itself, and the
+    committed summaries are of the headline workload only (C2, PAMLD): null for anything else."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")), reverse=True):
+    if config != "C2" or algorithm != "pamld":
+        return None
+    pattern = "r*_summary.json" if kernel_mode == "fast" else "r*_summary_%s.json" % kernel_mode
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+        if kernel_mode == "fast" and not os.path.basename(path).endswith("_summary.json"):
+            continue
         try:
             entry = json.load(open(path)).get(mode)
         except (OSError, ValueError):
@@ -218,7 +224,7 @@ def main():
                        "reads_per_gpu": n, "pool": pool_n, "kernel_mode": args.mode,
                        "sharding": "reads x%d, counters merged by one all-reduce per step" % world},
             "roofline": {"bound": "hbm", "achieved": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(dominant, n),
+                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(dominant, n, args.config, args.algorithm, args.mode),
                          "kernel": dominant, "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read,
                          "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in kernels.items()},
                          "classify_ms_per_step": classify_ms},

@@ -298,9 +298,10 @@ void DecoderSet::build_device_images() {
                 d.factor_pairs = device_factor_pairs;
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
-               c.segment_cardinality >= 2 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
+               c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
                 // A combinatorial barcode set (every combination of per segment sets, once)?  Then P(r|b) factorises
                 // over the segments and pamld_cross.hpp scans the segments' distinct words instead of the barcodes.
+                // A single segment set is the trivial case: it only uses the exact tier of that file.
                 const int32_t S = c.segment_cardinality;
                 std::vector<std::vector<uint32_t>> distinct(static_cast<size_t>(S));       // 2 bits per base keys, first appearance order
                 std::vector<int32_t> id(static_cast<size_t>(d.n_barcode) * static_cast<size_t>(S));

@@ -187,6 +187,7 @@ int pamld_wide_block();
 int launch_pamld_wide(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_cross_supports(const DevDecoder& host_decoder);
 int launch_pamld_cross(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_exact_supports(const DevDecoder& host_decoder);
 int launch_pamld_cross_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 
 }  // namespace phq

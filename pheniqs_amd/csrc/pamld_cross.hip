@@ -5,6 +5,7 @@ namespace phq {
 
 int launch_pamld_cross_s2(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_cross_s3(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+int launch_pamld_cross_exact_s1(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_cross_exact_s2(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_cross_exact_s3(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 
@@ -21,8 +22,16 @@ int launch_pamld_cross(const StageArgs& args, const DevDecoder& host_decoder, di
     return launch_pamld_cross_s3(args, host_decoder, grid, histogram_bytes, stream);
 }
 
+// the exact tier also serves single segment sets behind the per barcode product form (256 lane workgroups there too)
+bool pamld_exact_supports(const DevDecoder& host_decoder) {
+    return host_decoder.cross_segments >= 1 && host_decoder.cross_segments <= CROSS_MAX_SEGMENT &&
+           host_decoder.cross_groups >= 1 && host_decoder.cross_groups <= 4 &&
+           host_decoder.cross_words != nullptr && host_decoder.cross_ordinal != nullptr;
+}
+
 // tier 1.5: same grid as the producer, consumes and compacts the worklist in place
 int launch_pamld_cross_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if(host_decoder.cross_segments == 1) { return launch_pamld_cross_exact_s1(args, host_decoder, grid, histogram_bytes, stream); }
     if(host_decoder.cross_segments == 2) { return launch_pamld_cross_exact_s2(args, host_decoder, grid, histogram_bytes, stream); }
     return launch_pamld_cross_exact_s3(args, host_decoder, grid, histogram_bytes, stream);
 }

@@ -5,11 +5,11 @@
 // ACGT; 1 for q = 0) — reference phred.cpp:44-68, barcode.h:151-163.  So P(r|b) is a product of L factors
 // selected by the mismatch mask of (read, barcode).  The kernel
 //   * builds, per read, one 16 entry table per group of 4 positions (every product of 4 factors), in LDS;
-//   * gets mismatch masks with XOR + rotate + OR on bit-sliced 2-bit bases (scalar barcode operand; for
-//     barcodes of up to 8 nt one 32-bit word carries TWO barcodes), which leaves each group's 4-bit table
-//     index in its own byte, already scaled; one AND-OR makes the LDS address;
-//   * multiplies the G table entries, and folds four barcodes at a time into max / sum / "which group".
-// No exp, no Kahan chain: ~10 VALU instructions per (read, barcode) instead of ~75.  Every VALU instruction
+//   * gets mismatch masks with XOR + rotate + OR on bit-sliced 2-bit bases (for barcodes of up to 8 nt one
+//     32-bit word carries TWO barcodes), which leaves each group's 4-bit table index in its own byte, already
+//     scaled; one byte permute makes the LDS address;
+//   * multiplies the G table entries, and folds eight barcodes at a time into max / sum / "which block".
+// No exp, no Kahan chain: ~7 VALU instructions per (read, barcode) instead of ~75.  Every VALU instruction
 // costs one quad-cycle on this part whatever its type, so instruction count is the metric.
 //
 // The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
@@ -18,9 +18,11 @@
 // winner's (DOMINANCE).  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single
 // precision — their ~5e-7 relative error moves the posterior by at most DOMINANCE * 5e-7 — while the winner's own
 // probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
-// confidence filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  Every other read
-// (noise reads, reads with a second plausible barcode: ~2 %) is appended to a worklist that the literal kernel
-// decodes right after, on the same stream.
+// confidence filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  A read that clearly
+// fails the noise filter reports nothing but its argmax (pamld.cpp:113-119): it is finished as soon as the runner
+// up is further than single precision can blur (RUNNER_UP).  Every other read (a second plausible barcode, tied
+// noise reads: ~1.4 % of C2) is appended to a worklist that the exact tier (pamld_cross.hpp) and then the literal
+// kernel decode right after, on the same stream.
 #pragma once
 
 #include "kernel_common.hpp"
@@ -29,6 +31,7 @@ namespace phq {
 namespace lut {
 
 constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner, see the header
+constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 
 // Bit-sliced 2-bit bases (A, C, G, T = 0..3).  Position 4f + k lives in byte f of the word: its low code bit at
@@ -262,11 +265,13 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             float others_sum = 0;          // every block but the one holding the running maximum
             float held_sum = 0;            // the sum of the block holding the running maximum
             float best_value = 0;
+            float runner_up = 0;           // the largest block maximum but the running one
             int best_fold = -1;
             auto fold_block = [&](int f, const float (&p)[FOLD]) {
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+                runner_up = fmaxf(runner_up, takes_over ? best_value : block_max);
                 others_sum += takes_over ? held_sum : block_sum;
                 held_sum = takes_over ? block_sum : held_sum;
                 best_fold = takes_over ? f : best_fold;
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             int best = -1;
             uint32_t best_flags = 0;
             float sigma = others_sum;
+            float winner_single = 0;
             {
                 const int block = best_fold < 0 ? 0 : best_fold;
                 float top = 0;
@@ -339,6 +345,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                         if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
                         if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
                         rest += fminf(p, top);
+                        runner_up = fmaxf(runner_up, fminf(p, top));
                         if(p > top) {
                             best = b;
                             best_flags = ((PAIRED ? (fields >> (16 * h)) : fields) | outside) & full_mask;
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                     }
                 }
                 sigma += rest;
+                winner_single = top;
             }
 
             if(best < 0) {
@@ -369,9 +377,13 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 const double noise_margin = best_conditional - d.random_barcode_probability;
                 const double confidence_margin = confidence - d.confidence_threshold;
                 // certificate: a dominant winner and no decision within 1e-9 (relative) of its threshold
-                defer = !(others <= DOMINANCE * best_p)
-                     || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
-                     || !(fabs(confidence_margin) > 1e-9);
+                // a read that clearly fails the noise filter only needs its argmax (it is charged to it and leaves
+                // unclassified, pamld.cpp:96,113-119): the runner up further than single precision can blur;
+                // otherwise the posterior matters: a dominant winner, no decision within 1e-9 of its threshold
+                const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
+                defer = !noise_clear
+                     || (noise_margin <= 0 ? !(runner_up <= RUNNER_UP * winner_single)
+                                           : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
                 if(!defer && active) {
                     int bin = best + 1;
                     uint8_t status = STATUS_PASS;

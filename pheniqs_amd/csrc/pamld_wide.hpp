@@ -21,6 +21,7 @@ namespace phq {
 namespace wide {
 
 constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner (pamld_lut.hpp)
+constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 constexpr int THREADS = 128;
 constexpr int FOLD = 8;                       // barcodes per block of the scan
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
             float others_sum = 0;
             float held_sum = 0;
             float best_value = 0;
+            float runner_up = 0;           // the largest block maximum but the running one
             int best_fold = -1;
             const int n_fold = padded_barcodes / FOLD;
             for(int f = 0; f < n_fold; ++f) {
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                          // strict: the first block keeps a tie
+                runner_up = fmaxf(runner_up, takes_over ? best_value : block_max);
                 others_sum += takes_over ? held_sum : block_sum;
                 held_sum = takes_over ? block_sum : held_sum;
                 best_fold = takes_over ? f : best_fold;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
 #pragma unroll
             for(int w = 0; w < WORDS; ++w) { best_flags[w] = 0; }
             float sigma = others_sum;
+            float winner_single = 0;
             {
                 const int block = best_fold < 0 ? 0 : best_fold;
                 float top = 0;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
                     if(!uniform_prior) { p *= prior_single[b]; }
                     if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
                     rest += fminf(p, top);
+                    runner_up = fmaxf(runner_up, fminf(p, top));
                     if(p > top) {
                         best = b;
 #pragma unroll
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
                     top = fmaxf(p, top);
                 }
                 sigma += rest;
+                winner_single = top;
             }
 
             if(best < 0) {
@@ -264,9 +270,13 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
                 double confidence = best_p / total;                                       // pamld.cpp:92
                 const double noise_margin = best_conditional - d.random_barcode_probability;
                 const double confidence_margin = confidence - d.confidence_threshold;
-                defer = !(others <= DOMINANCE * best_p)
-                     || !(fabs(noise_margin) > 1e-9 * d.random_barcode_probability)
-                     || !(fabs(confidence_margin) > 1e-9);
+                // a read that clearly fails the noise filter only needs its argmax (it is charged to it and leaves
+                // unclassified, pamld.cpp:96,113-119): the runner up further than single precision can blur;
+                // otherwise the posterior matters: a dominant winner, no decision within 1e-9 of its threshold
+                const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
+                defer = !noise_clear
+                     || (noise_margin <= 0 ? !(runner_up <= RUNNER_UP * winner_single)
+                                           : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
                 if(!defer && active) {
                     int bin = best + 1;
                     uint8_t status = STATUS_PASS;

@@ -64,7 +64,7 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
-                if(factorised) {
+                if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
                     status = launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
