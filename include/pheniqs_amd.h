@@ -212,6 +212,18 @@ int phq_report_json(phq_decoder_set* set, const uint64_t* host_words, uint64_t i
  * PHQ_OVERFLOW_ERROR when `capacity` is too small. */
 int phq_format_double(double value, int32_t precision, char* buffer, int32_t capacity);
 
+/* ---- next row f4: the configuration compiler, decoder topics only ----------------------------------------
+ * Replaces, for the sample / molecular / cellular decoders of a job document, Transcode::apply_inheritance
+ * (reference transcode.cpp:329-437: the "decoder" repository and "base" references), compile_transformation
+ * (735-763), compile_decoder_transformation (824-940), compile_decoder (941-1039) and
+ * CodecMetric::compile_barcode_tolerance (metric.h:87-111,216-242): defaults, cardinalities, random barcode
+ * probability, undetermined, barcode index by sorted key, concentration (1 - noise) / sum, BC / ID, shannon
+ * bound and default distance tolerance.  Errors are the reference's ConfigurationError texts (code 3).
+ * phq_create runs it by itself on a document that is not compiled yet.  `*compiled_json` is a NUL terminated
+ * string (doubles printed with round trip digits) owned by the library: release it with phq_free_string. */
+int phq_compile_job(const char* job_json, char** compiled_json);
+void phq_free_string(char* text);
+
 #ifdef __cplusplus
 }
 #endif

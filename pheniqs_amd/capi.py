@@ -26,7 +26,8 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam")
+           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam",
+           "phq_compile_job", "phq_free_string")
 
 
 class PheniqsError(RuntimeError):
@@ -90,8 +91,24 @@ def load_library():
     L.phq_transcode_fastq_to_sam.argtypes = [P, I32, P, ctypes.c_char_p, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
+    L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
+    L.phq_free_string.argtypes = [P]
+    L.phq_free_string.restype = None
     _library = L
     return L
+
+
+def compile_job(job: Dict[str, Any]) -> Dict[str, Any]:
+    """phq_compile_job: the library's configuration compiler (decoder topics) on a user level job document."""
+    L = load_library()
+    out = ctypes.c_void_p()
+    status = L.phq_compile_job(json.dumps(job).encode(), ctypes.byref(out))
+    if status != 0:
+        raise PheniqsError(status, (L.phq_last_error(None) or b"").decode())
+    try:
+        return json.loads(ctypes.string_at(out.value).decode())
+    finally:
+        L.phq_free_string(out)
 
 
 def format_double(value: float, precision: int = 15) -> str:

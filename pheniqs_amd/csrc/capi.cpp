@@ -1,10 +1,12 @@
 // extern "C" surface of libpheniqs_amd.so (declared in include/pheniqs_amd.h).  Exceptions stop here:
 // every entry point converts an Error into its reference ErrorCode (error.h:32-44) and stores the text.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 
 #include "../../include/pheniqs_amd.h"
+#include "compile.hpp"
 #include "decoder_set.hpp"
 #include "error.hpp"
 #include "stats.hpp"
@@ -226,6 +228,22 @@ int phq_host_alloc(uint64_t bytes, void** pointer) {
 }
 
 void phq_host_free(void* pointer) { phq::host_free(pointer); }
+
+int phq_compile_job(const char* job_json, char** compiled_json) {
+    if(compiled_json != nullptr) { *compiled_json = nullptr; }
+    return guarded(nullptr, [&]() {
+        require(job_json, "job_json");
+        require(compiled_json, "compiled_json");
+        const phq::Json document = phq::Json::parse(job_json);
+        const std::string text = (phq::is_compiled_job(document) ? document : phq::compile_job(document)).dump(324);   // no truncation: round trip digits
+        char* out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *compiled_json = out;
+    });
+}
+
+void phq_free_string(char* text) { std::free(text); }
 
 int phq_format_double(double value, int32_t precision, char* buffer, int32_t capacity) {
     return guarded(nullptr, [&]() {

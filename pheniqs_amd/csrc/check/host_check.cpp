@@ -1,5 +1,5 @@
 // Host-only self check of the library's CPU side, built with AddressSanitizer + UBSan (make -C pheniqs_amd/csrc asan):
-// JSON reader, compiled job model, PhredScale, statistics model, report writer.  GPU sanitizers are not available
+// JSON reader, configuration compiler, compiled job model, PhredScale, statistics model, report writer.  GPU sanitizers are not available
 // on the target pool, so the device code is checked by the oracle parity tests instead.
 //
 // usage: host_check <compiled job json> [more jobs ...]
@@ -10,6 +10,7 @@
 #include <sstream>
 #include <vector>
 
+#include "../compile.hpp"
 #include "../error.hpp"
 #include "../job.hpp"
 #include "../json.hpp"
@@ -44,7 +45,12 @@ int main(int argc, char** argv) {
         std::stringstream content;
         content << file.rdbuf();
         try {
-            const Json document = Json::parse(content.str());
+            Json document = Json::parse(content.str());
+            if(!is_compiled_job(document)) {
+                document = compile_job(document);                      // a user level document: repository, bases, defaults
+                CHECK(is_compiled_job(document));
+                CHECK(Json::parse(document.dump(324)).dump(324) == document.dump(324));
+            }
             const JobConfig job = JobConfig::from_json(document);
             CHECK(!job.decoder.empty());
             // a deterministic pseudo random counter buffer through decode / finalize / encode

@@ -1,0 +1,25 @@
+// Configuration compiler, decoder topics only: what turns a user level Pheniqs job document into the compiled
+// ontology the decoders are constructed from (the shape of reference test/BDGGG/valid/compile_annotated.out).
+//
+//   Transcode::apply_inheritance                 transcode.cpp:329-437   decoder repository, "base" references
+//   Transcode::compile_transformation            transcode.cpp:735-763   default knit
+//   Transcode::compile_decoder_transformation    transcode.cpp:824-940   cardinalities, random barcode probability,
+//                                                                        undetermined, length / duplicate checks
+//   Transcode::compile_decoder                   transcode.cpp:941-1039  index, concentration (1 - noise) / sum, BC, ID
+//   CodecMetric::compile_barcode_tolerance       metric.h:87-111,216-242 shannon bound, default distance tolerance
+//   projections "<type>:decoder"                 configuration.json:423-520
+//
+// File imports, IO, SAM header atoms and the command line stay with the caller.
+#pragma once
+
+#include "json.hpp"
+
+namespace phq {
+
+// true when every decoder of the document already went through the compiler
+bool is_compiled_job(const Json& document);
+
+// throws ConfigurationError exactly where the reference does
+Json compile_job(const Json& document);
+
+}  // namespace phq

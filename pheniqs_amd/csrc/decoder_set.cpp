@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "compile.hpp"
 #include "error.hpp"
 #include "phred.hpp"
 #include "stats.hpp"
@@ -71,8 +72,15 @@ void host_free(void* pointer) {
     if(pointer != nullptr) { (void)hipHostFree(pointer); }
 }
 
+// a job document that did not go through the compiler yet (decoder repository, "base" references, no cardinalities)
+// is compiled first, so a user level Pheniqs configuration runs unchanged
+static Json compiled_document(const std::string& text) {
+    Json document = Json::parse(text);
+    return is_compiled_job(document) ? document : compile_job(document);
+}
+
 DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
-    job_(JobConfig::from_json(Json::parse(compiled_job_json))),
+    job_(JobConfig::from_json(compiled_document(compiled_job_json))),
     device_(device),
     mode_(MODE_FAST),
     max_blocks_(2048),

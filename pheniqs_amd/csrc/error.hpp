@@ -24,8 +24,9 @@ enum ErrorCode : int {
 class Error : public std::runtime_error {
 public:
     Error(ErrorCode code, const std::string& name, const std::string& message) :
-        std::runtime_error(name + " : " + message), code(code) {}
+        std::runtime_error(name + " : " + message), code(code), message(message) {}
     const ErrorCode code;
+    const std::string message;        // without the error class prefix (error.h:46-76 keeps them apart too)
 };
 struct InternalError : Error { explicit InternalError(const std::string& m) : Error(INTERNAL_ERROR, "Internal error", m) {} };
 struct ConfigurationError : Error { explicit ConfigurationError(const std::string& m) : Error(CONFIGURATION_ERROR, "Configuration error", m) {} };

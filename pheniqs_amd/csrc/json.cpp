@@ -212,6 +212,13 @@ void Json::set(const std::string& key, Json value) {
     members_.emplace_back(key, std::move(value));
 }
 
+bool Json::erase(const std::string& key) {
+    for(auto it = members_.begin(); it != members_.end(); ++it) {
+        if(it->first == key) { members_.erase(it); return true; }
+    }
+    return false;
+}
+
 void Json::sort_keys() {
     if(type_ == Type::Object) {
         for(auto& member : members_) { member.second.sort_keys(); }

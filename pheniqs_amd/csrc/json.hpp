@@ -42,8 +42,12 @@ public:
     bool is_bool() const { return type_ == Type::Bool; }
 
     const Json* find(const std::string& key) const;
+    Json* find(const std::string& key) { return const_cast<Json*>(static_cast<const Json*>(this)->find(key)); }
     const Members& members() const { return members_; }
+    Members& members() { return members_; }
     const std::vector<Json>& elements() const { return elements_; }
+    std::vector<Json>& elements() { return elements_; }
+    bool erase(const std::string& key);
     bool as_bool() const { return bool_; }
     int64_t as_int() const { return type_ == Type::Real ? static_cast<int64_t>(real_) : int_; }
     double as_double() const { return type_ == Type::Real ? real_ : (unsigned_ ? static_cast<double>(static_cast<uint64_t>(int_)) : static_cast<double>(int_)); }

@@ -38,6 +38,9 @@ COMMON_DEFAULTS: Dict[str, Any] = {
     "corrected quality": 30,
 }
 BARCODE_DEFAULT_CONCENTRATION = 1
+# configuration.json:419-490 "sample:decoder" / "sample:barcode": read group members the sample decoder takes from the
+# job's root and hands to its barcodes (Transcode::compile_topic transcode.cpp:769-800)
+SAMPLE_PROJECTED = ("CN", "DT", "LB", "PG", "PI", "PL", "PM", "SM", "flowcell id", "flowcell lane number")
 
 _TOKEN_RE = re.compile(r"^(s|c|m|[0-9]+):(-?[0-9]+)?:(-?[0-9]+)?$")   # transform.cpp:31
 
@@ -117,12 +120,35 @@ def _shannon_bound(words: List[str], barcode_length: int) -> int:
     return int((min_distance - 1) / 2)    # C integer division truncates toward zero
 
 
-def compile_decoder(spec: Dict[str, Any], kind: str, index: int, input_segment_cardinality: Optional[int] = None) -> Dict[str, Any]:
+def _infer_PU_and_ID(barcode: Dict[str, Any], undetermined: bool) -> None:
+    """Transcode::infer_PU / infer_ID transcode.cpp:1224-1260."""
+    if not isinstance(barcode.get("PU"), str):
+        suffix = "undetermined" if undetermined else "".join(barcode.get("barcode") or [])
+        if suffix:
+            unit = ""
+            if isinstance(barcode.get("flowcell id"), str):
+                unit = barcode["flowcell id"] + ":"
+                if isinstance(barcode.get("flowcell lane number"), int):
+                    unit += "%d:" % barcode["flowcell lane number"]
+            barcode["PU"] = unit + suffix
+    if not isinstance(barcode.get("ID"), str) and isinstance(barcode.get("PU"), str):
+        barcode["ID"] = barcode["PU"]
+
+
+def compile_decoder(spec: Dict[str, Any], kind: str, index: int, input_segment_cardinality: Optional[int] = None,
+                    root: Optional[Dict[str, Any]] = None) -> Dict[str, Any]:
     value = copy.deepcopy(spec)
+    root = root or {}
     value["index"] = index
+    projected = SAMPLE_PROJECTED if kind == "sample" else ()
+    for key in list(COMMON_DEFAULTS) + list(DECODER_DEFAULTS[kind]) + list(projected):
+        if value.get(key) is None and root.get(key) is not None:
+            value[key] = copy.deepcopy(root[key])
     for key, default in {**COMMON_DEFAULTS, **DECODER_DEFAULTS[kind]}.items():
         value.setdefault(key, default)
     algorithm = value["algorithm"]
+    barcode_default = {key: copy.deepcopy(value.get(key, root.get(key))) for key in projected
+                       if value.get(key, root.get(key)) is not None}
 
     # transcode.cpp:735-763
     transform = value.get("transform")
@@ -160,18 +186,21 @@ def compile_decoder(spec: Dict[str, Any], kind: str, index: int, input_segment_c
     # transcode.cpp:867-882, 974-986
     noise = float(value["noise"])
     undetermined = value.setdefault("undetermined", {})
+    for key, default in barcode_default.items():
+        undetermined.setdefault(key, copy.deepcopy(default))
     undetermined["barcode"] = ["=" * n for n in barcode_length]
     undetermined["segment cardinality"] = segment_cardinality
     undetermined["index"] = 0
-    undetermined["concentration"] = noise
     undetermined["algorithm"] = algorithm
-    undetermined.setdefault("ID", "undetermined")
+    _infer_PU_and_ID(undetermined, True)
+    undetermined["concentration"] = noise
 
     codec = value.get("codec")
     if codec:
         # sort_json_value json.cpp:875-893: members are ordered by key before compile_decoder walks them
         ordered = {key: codec[key] for key in sorted(codec)}
         seen = set()
+        unique_id = {undetermined.get("ID")}
         barcode_index = 1
         total_concentration = 0.0
         for key, record in ordered.items():
@@ -186,16 +215,21 @@ def compile_decoder(spec: Dict[str, Any], kind: str, index: int, input_segment_c
             if flat in seen:
                 raise ConfigurationError("duplicate barcode sequence " + flat)
             seen.add(flat)
+            for default_key, default in barcode_default.items():
+                record.setdefault(default_key, copy.deepcopy(default))
             record["segment cardinality"] = segment_cardinality
             record["algorithm"] = algorithm
             record["index"] = barcode_index
+            _infer_PU_and_ID(record, False)
+            if record.get("ID") in unique_id:
+                raise ConfigurationError("duplicate %s barcode" % key)
+            unique_id.add(record.get("ID"))
             record.setdefault("concentration", BARCODE_DEFAULT_CONCENTRATION)
             concentration = float(record["concentration"])
             if concentration < 0:
                 raise ConfigurationError("barcode concentration must be a positive number")
             total_concentration += concentration
             record["BC"] = "-".join(segments)
-            record.setdefault("ID", record["BC"])
             barcode_index += 1
         value["barcode cardinality"] = barcode_index
         if not total_concentration > 0:
@@ -233,9 +267,9 @@ def compile_job(spec: Dict[str, Any]) -> Dict[str, Any]:
             continue
         node = spec[kind]
         if isinstance(node, dict):
-            job[kind] = compile_decoder(node, kind, 0, cardinality)
+            job[kind] = compile_decoder(node, kind, 0, cardinality, job)
         else:
-            job[kind] = [compile_decoder(element, kind, i, cardinality) for i, element in enumerate(node)]
+            job[kind] = [compile_decoder(element, kind, i, cardinality, job) for i, element in enumerate(node)]
     # Transcode::find_multiplexing_decoder transcode.cpp:1087-1223, reduced to its common outcome:
     # an explicitly marked decoder wins, otherwise the sample decoder drives output routing.
     marked = [d for d in iter_decoders(job) if d[1].get("multiplexing classifier")]

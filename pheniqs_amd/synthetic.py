@@ -55,6 +55,12 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
     """Compiled job + generation recipe for BASELINE config C2..C5.  seed = 20240613 + config number."""
     number = {"C2": 2, "C3": 3, "C4": 4, "C5": 5}[name]
+    return jobspec.compile_job(config_spec(name, algorithm)), {"name": name, "seed": BASE_SEED + number}
+
+
+def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
+    """The user level (uncompiled) job document of BASELINE config C2..C5."""
+    number = {"C2": 2, "C3": 3, "C4": 4, "C5": 5}[name]
     rng = np.random.default_rng(BASE_SEED + number)
     if name == "C2":        # single 8 bp i7 index, 96 barcodes
         words = barcode_set(rng, 96, 8)
@@ -79,8 +85,7 @@ def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dic
                              decoder_spec(algorithm, [r2], ["1:48:56"]),
                              decoder_spec(algorithm, [r3], ["1:86:94"]),
                              decoder_spec(algorithm, [r4], ["0::6"], knit=["~0"])]}
-    job = jobspec.compile_job(spec)
-    return job, {"name": name, "seed": BASE_SEED + number}
+    return spec
 
 
 def _codec_arrays(decoder: Dict[str, Any]) -> Tuple[np.ndarray, np.ndarray]:

@@ -33,6 +33,24 @@ def read_fastq(path, ascii_to_bam, phred_offset=33):
     return records
 
 
+def raw_job():
+    """BDGGG_annotated.json as the reference reads it: only its `import` list is resolved here (a file level
+    operation, Job::assemble job.cpp:167-224: what the imported document defines fills in what the importing one
+    does not); the decoder repository and the `base` references are left to the library's compiler."""
+    def fill(base, value):
+        for key, inherited in base.items():
+            if key not in value:
+                value[key] = copy.deepcopy(inherited)
+            elif isinstance(inherited, dict) and isinstance(value[key], dict):
+                fill(inherited, value[key])
+        return value
+
+    annotated = json.load(open(os.path.join(HERE, "BDGGG_annotated.json")))
+    for name in annotated.pop("import", []):
+        fill(json.load(open(os.path.join(HERE, name))), annotated)
+    return annotated
+
+
 def user_job():
     """BDGGG_annotated.json with its import and `base` inheritance resolved by hand
     (Transcode::apply_inheritance transcode.cpp:328-443 is out of scope)."""

@@ -24,8 +24,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_create_reports_configuration_errors_with_reference_codes():
+    job = jobspec.compile_job(bdggg.user_job())
+    job["sample"]["algorithm"] = "bogus"
     with pytest.raises(PheniqsError) as e:
-        DecoderSet('{"sample": {"algorithm": "bogus", "index": 0}}', device=capi.DEVICE_NONE)
+        DecoderSet(job, device=capi.DEVICE_NONE)
     assert e.value.code == 3 and "unsupported sample decoder algorithm bogus" in str(e.value)
     with pytest.raises(PheniqsError) as e:
         DecoderSet("{ not json", device=capi.DEVICE_NONE)
@@ -222,6 +224,9 @@ def test_host_side_under_sanitizers(tmp_path):
         path = tmp_path / (name + ".json")
         path.write_text(json.dumps(job))
         paths.append(str(path))
+    raw = tmp_path / "raw.json"                          # uncompiled: decoder repository and base references
+    raw.write_text(json.dumps(bdggg.raw_job()))
+    paths.append(str(raw))
     ran = subprocess.run([os.path.join(csrc, "build", "host_check_asan")] + paths, capture_output=True, text=True)
     assert ran.returncode == 0, ran.stdout + ran.stderr
     assert "host check ok" in ran.stdout
