@@ -42,6 +42,50 @@ def profiled_traffic(mode, reads, config="C2", algorithm="pamld", kernel_mode="f
     return None
 
 
+def fastq_end_to_end(args, code, quality, flag, n):
+    """Next rows f1 + f2 end to end: synthetic FASTQ text on disk -> phq_transcode_fastq_to_sam -> SAM text
+    (uncompressed, /dev/null).  One file per input segment: a 50 nt template read and the index read; the staged
+    rows of the pool are written back as text, so the decoder sees the same observations as the kernel bench.
+    Host bound (parse and format on the host, classification on the GPU); never the headline value."""
+    import tempfile
+    from pheniqs_amd import DecoderSet, capi, synthetic
+    spec = synthetic.config_spec(args.config, args.algorithm)
+    if args.config != "C2":
+        return {"skipped": "the FASTQ leg writes the two segment C2 layout only"}
+    spec["template"] = {"transform": {"token": ["0::"]}}
+    s = DecoderSet(spec, device=0)
+    s.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
+    rng = np.random.default_rng(7)
+    letters = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)                 # iupac.h BamToAmbiguousAscii
+    pool = code.shape[0]
+    reps = -(-n // pool)
+    index_text = letters[np.tile(code, (reps, 1))[:n]]
+    index_quality = (np.minimum(np.tile(quality, (reps, 1))[:n], 93) + 33).astype(np.uint8)
+    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 50))]
+    template_quality = np.full((n, 50), ord("F"), dtype=np.uint8)
+    filtered = np.tile(flag, reps)[:n]
+    with tempfile.TemporaryDirectory() as directory:
+        paths = []
+        for k, (text, qual) in enumerate(((template, template_quality), (index_text, index_quality))):
+            path = os.path.join(directory, "segment_%d.fastq" % k)
+            with open(path, "wb") as out:
+                for first in range(0, n, 1 << 16):
+                    chunk = []
+                    for i in range(first, min(n, first + (1 << 16))):
+                        chunk.append(b"@M:1:FC:1:1101:%d:%d %d:%s:0:1\n%s\n+\n%s\n" % (
+                            i >> 16, i & 0xffff, k + 1, b"Y" if filtered[i] else b"N", text[i].tobytes(), qual[i].tobytes()))
+                    out.write(b"".join(chunk))
+            paths.append(path)
+        size = sum(os.path.getsize(p) for p in paths)
+        s.transcode_fastq_to_sam(paths, "/dev/null", 1 << 20)                    # warm: allocations, page cache
+        t0 = time.perf_counter()
+        incoming, incoming_pf = s.transcode_fastq_to_sam(paths, "/dev/null", 1 << 20)
+        dt = time.perf_counter() - t0
+    assert incoming == n
+    return {"reads": n, "Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt,
+            "note": "2 uncompressed FASTQ files (50 nt template + 8 nt index) -> SAM text to /dev/null, one reader thread per file"}
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -121,6 +165,8 @@ def main():
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
     parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                         help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration")
+    parser.add_argument("--fastq", type=int, default=0, metavar="N",
+                        help="also time N synthetic reads end to end from FASTQ text to SAM text (next rows f1 + f2)")
     parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
                         help="fast: product form kernel + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
@@ -260,6 +306,8 @@ def main():
             dt = time.perf_counter() - t0
             line["host_staged_pinned"] = {"reads": m, "Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * bytes_per_read / dt / 1e9,
                                           "note": "caller's planes and result buffers pinned: async copies straight from / to them"}
+        if args.fastq:
+            line["fastq_to_sam"] = fastq_end_to_end(args, code, quality, flag, args.fastq)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

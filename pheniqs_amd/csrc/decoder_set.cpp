@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include "compile.hpp"
+#include "host_parallel.hpp"
 #include "error.hpp"
 #include "phred.hpp"
 #include "stats.hpp"
@@ -404,9 +405,12 @@ void DecoderSet::stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* c
             }
         }
     }
+    // pass 1, in order: the pre-filters and the incoming counters decide which reads take a row
     int64_t out = 0;
     uint64_t count = 0;
     uint64_t pf_count = 0;
+    std::vector<int64_t> local_kept;
+    int64_t* const source = kept != nullptr ? kept : (local_kept.resize(static_cast<size_t>(std::min(n_read, batch_capacity))), local_kept.data());
     for(int64_t i = 0; i < n_read; ++i) {
         const bool qcfail = in_flag != nullptr && (in_flag[i] & 1);
         ++count;                                                        // transcode.cpp:304-309
@@ -418,43 +422,49 @@ void DecoderSet::stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* c
         }
         if(too_short) { continue; }
         if(out >= batch_capacity) { throw OverflowError("more reads than the batch capacity " + std::to_string(batch_capacity)); }
-
-        for(const auto& d : job_.decoder) {
-            if(d.plane_stride == 0) { continue; }
-            uint8_t* row_code = base_planes + batch_capacity * d.plane_prefix + out * d.plane_stride;
-            uint8_t* row_quality = quality_planes + batch_capacity * d.plane_prefix + out * d.plane_stride;
-            std::memset(row_code, 0, static_cast<size_t>(d.plane_stride));
-            std::memset(row_quality, 0, static_cast<size_t>(d.plane_stride));
-            int32_t filled[MAX_SEGMENT] = {0};
-            for(const auto& t : d.transform) {
-                const int32_t from_length = length[t.input_segment_index][i];
-                const uint8_t* from_code = code[t.input_segment_index] + offset[t.input_segment_index][i];
-                const uint8_t* from_quality = quality[t.input_segment_index] + offset[t.input_segment_index][i];
-                const int32_t start = t.absolute_start(from_length);
-                const int32_t end = t.absolute_end(from_length);
-                const int32_t size = end - start;
-                if(size <= 0) { continue; }
-                const int32_t o = t.output_segment_index;
-                const int32_t room = d.barcode_length[static_cast<size_t>(o)] - filled[o];
-                const int32_t take = size < room ? size : room;
-                uint8_t* to_code = row_code + d.segment_offset[static_cast<size_t>(o)] + filled[o];
-                uint8_t* to_quality = row_quality + d.segment_offset[static_cast<size_t>(o)] + filled[o];
-                if(t.reverse_complement) {
-                    for(int32_t j = 0; j < take; ++j) {
-                        to_code[j] = reverse_complement_bam(from_code[end - j - 1]);
-                        to_quality[j] = from_quality[end - j - 1];
-                    }
-                } else {
-                    std::memcpy(to_code, from_code + start, static_cast<size_t>(take));
-                    std::memcpy(to_quality, from_quality + start, static_cast<size_t>(take));
-                }
-                filled[o] += take;
-            }
-        }
-        if(out_flag != nullptr) { out_flag[out] = qcfail ? 1 : 0; }
-        if(kept != nullptr) { kept[out] = i; }
+        source[out] = i;
         ++out;
     }
+
+    // pass 2, rows are independent: Rule::apply of every decoder into its plane, a few threads on large batches
+    parallel_ranges(out, 1 << 15, host_threads(), [&](int64_t first, int64_t last, int) {
+        for(int64_t row = first; row < last; ++row) {
+            const int64_t i = source[row];
+            for(const auto& d : job_.decoder) {
+                if(d.plane_stride == 0) { continue; }
+                uint8_t* row_code = base_planes + batch_capacity * d.plane_prefix + row * d.plane_stride;
+                uint8_t* row_quality = quality_planes + batch_capacity * d.plane_prefix + row * d.plane_stride;
+                std::memset(row_code, 0, static_cast<size_t>(d.plane_stride));
+                std::memset(row_quality, 0, static_cast<size_t>(d.plane_stride));
+                int32_t filled[MAX_SEGMENT] = {0};
+                for(const auto& t : d.transform) {
+                    const int32_t from_length = length[t.input_segment_index][i];
+                    const uint8_t* from_code = code[t.input_segment_index] + offset[t.input_segment_index][i];
+                    const uint8_t* from_quality = quality[t.input_segment_index] + offset[t.input_segment_index][i];
+                    const int32_t start = t.absolute_start(from_length);
+                    const int32_t end = t.absolute_end(from_length);
+                    const int32_t size = end - start;
+                    if(size <= 0) { continue; }
+                    const int32_t o = t.output_segment_index;
+                    const int32_t room = d.barcode_length[static_cast<size_t>(o)] - filled[o];
+                    const int32_t take = size < room ? size : room;
+                    uint8_t* to_code = row_code + d.segment_offset[static_cast<size_t>(o)] + filled[o];
+                    uint8_t* to_quality = row_quality + d.segment_offset[static_cast<size_t>(o)] + filled[o];
+                    if(t.reverse_complement) {
+                        for(int32_t j = 0; j < take; ++j) {
+                            to_code[j] = reverse_complement_bam(from_code[end - j - 1]);
+                            to_quality[j] = from_quality[end - j - 1];
+                        }
+                    } else {
+                        std::memcpy(to_code, from_code + start, static_cast<size_t>(take));
+                        std::memcpy(to_quality, from_quality + start, static_cast<size_t>(take));
+                    }
+                    filled[o] += take;
+                }
+            }
+            if(out_flag != nullptr) { out_flag[row] = (in_flag != nullptr && (in_flag[i] & 1)) ? 1 : 0; }
+        }
+    });
     if(n_kept != nullptr) { *n_kept = out; }
     if(incoming_count != nullptr) { *incoming_count += count; }
     if(incoming_pf_count != nullptr) { *incoming_pf_count += pf_count; }

@@ -20,6 +20,7 @@
 #include <thread>
 
 #include "error.hpp"
+#include "host_parallel.hpp"
 
 namespace phq {
 
@@ -100,6 +101,11 @@ struct SegmentBatch {
 };
 
 void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, SegmentBatch& out) {
+    static const std::vector<uint8_t> ascii_table = []() {                  // AsciiToAmbiguousBam, iupac.h:153-171
+        std::vector<uint8_t> table(256);
+        for(int c = 0; c < 256; ++c) { table[static_cast<size_t>(c)] = ascii_to_bam(static_cast<uint8_t>(c)); }
+        return table;
+    }();
     out.clear();
     try {
         const char* data;
@@ -124,11 +130,21 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
             out.offset.push_back(static_cast<int64_t>(out.code.size()));
             out.length.push_back(static_cast<int32_t>(size));
             const size_t sequence_size = size;
-            for(size_t i = 0; i < size; ++i) { out.code.push_back(ascii_to_bam(static_cast<uint8_t>(data[i]))); }
+            {
+                const size_t at = out.code.size();
+                out.code.resize(at + size);
+                uint8_t* to = out.code.data() + at;
+                for(size_t i = 0; i < size; ++i) { to[i] = ascii_table[static_cast<uint8_t>(data[i])]; }
+            }
             if(!stream.line(data, size) || size == 0 || data[0] != '+') { throw SequenceError("malformed FASTQ separator in " + stream.path()); }
             if(!stream.line(data, size)) { throw SequenceError("truncated FASTQ record in " + stream.path()); }
             if(size != sequence_size) { throw SequenceError("sequence and quality differ in length in " + stream.path()); }
-            for(size_t i = 0; i < size; ++i) { out.quality.push_back(static_cast<uint8_t>(data[i] - phred_offset)); }
+            {
+                const size_t at = out.quality.size();
+                out.quality.resize(at + size);
+                uint8_t* to = out.quality.data() + at;
+                for(size_t i = 0; i < size; ++i) { to[i] = static_cast<uint8_t>(data[i] - phred_offset); }
+            }
         }
     } catch(const Error& e) {
         out.error = e.what();
@@ -224,21 +240,33 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
 
-    while(true) {
-        // f1: one reader thread per input file (the reference has one producer thread per feed, feed.h:309-314)
-        {
-            std::vector<std::thread> readers;
-            for(int32_t s = 0; s < n_segment; ++s) {
-                readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(s)]), m.capacity, job.input_phred_offset, std::ref(m.batch[static_cast<size_t>(s)]));
-            }
-            for(auto& t : readers) { t.join(); }
+    // f1: one reader thread per input file (the reference has one producer thread per feed, feed.h:309-314); the
+    // next batch is read while this one is staged, classified and written
+    std::vector<SegmentBatch> ahead(m.batch.size());
+    auto start_readers = [&](std::vector<SegmentBatch>& into) {
+        std::vector<std::thread> readers;
+        for(int32_t s = 0; s < n_segment; ++s) {
+            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(s)]), m.capacity, job.input_phred_offset, std::ref(into[static_cast<size_t>(s)]));
         }
+        return readers;
+    };
+    {
+        auto readers = start_readers(m.batch);
+        for(auto& t : readers) { t.join(); }
+    }
+    const int workers = host_threads();
+    std::vector<std::string> part_text(static_cast<size_t>(workers));
+    while(true) {
         for(const auto& b : m.batch) { if(!b.error.empty()) { throw SequenceError(b.error); } }
         const int64_t n_read = m.batch[0].size();
         for(const auto& b : m.batch) {
             if(b.size() != n_read) { throw SequenceError("input files hold different numbers of records"); }
         }
         if(n_read == 0) { break; }
+        const bool last_batch = n_read < m.capacity;
+        std::vector<std::thread> readers;
+        struct Joiner { std::vector<std::thread>& threads; ~Joiner() { for(auto& t : threads) { if(t.joinable()) { t.join(); } } } } joiner{readers};
+        if(!last_batch) { readers = start_readers(ahead); }
         // Read::validate (read.h:253-264): every segment of a read carries the same identifier
         for(int32_t s = 1; s < n_segment; ++s) {
             const SegmentBatch& a = m.batch[0];
@@ -267,10 +295,12 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                           &incoming_count, &incoming_pf_count);
         m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word);
 
-        // f2: records
-        m.text.clear();
+        // f2: records, a contiguous range of the batch per thread, written in order
+        for(auto& text : part_text) { text.clear(); }
+        parallel_ranges(n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
+        std::string& text = part_text[static_cast<size_t>(part)];
         Text raw[3], corrected[3], out_segment[8];
-        for(int64_t k = 0; k < n_kept; ++k) {
+        for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
             uint32_t distance[3] = {0, 0, 0};
             double confidence[3] = {1, 1, 1};                               // read.h:176-183
@@ -355,30 +385,35 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 if(o == 0) { flag |= 64; }
                 if(n_out > 1 && o == n_out - 1) { flag |= 128; }
                 if(qcfail) { flag |= 512; }
-                m.text.append(lead.name.data() + lead.name_offset[static_cast<size_t>(r)], static_cast<size_t>(lead.name_offset[static_cast<size_t>(r) + 1] - lead.name_offset[static_cast<size_t>(r)]));
-                m.text += '\t'; m.text += std::to_string(flag); m.text += "\t*\t0\t0\t*\t*\t0\t0\t";
-                if(out_segment[o].empty()) { m.text += "*\t*"; }
+                text.append(lead.name.data() + lead.name_offset[static_cast<size_t>(r)], static_cast<size_t>(lead.name_offset[static_cast<size_t>(r) + 1] - lead.name_offset[static_cast<size_t>(r)]));
+                text += '\t'; text += std::to_string(flag); text += "\t*\t0\t0\t*\t*\t0\t0\t";
+                if(out_segment[o].empty()) { text += "*\t*"; }
                 else {
-                    put_sequence(m.text, out_segment[o].code);
-                    m.text += '\t';
-                    put_quality(m.text, out_segment[o].quality, job.output_phred_offset);
+                    put_sequence(text, out_segment[o].code);
+                    text += '\t';
+                    put_quality(text, out_segment[o].quality, job.output_phred_offset);
                 }
-                if(n_out > 2) { m.text += "\tFI:i:" + std::to_string(o + 1) + "\tTC:i:" + std::to_string(n_out); }
-                if(rg != nullptr && !rg->empty()) { m.text += "\tRG:Z:"; m.text += *rg; }
-                if(!raw[0].empty()) { m.text += "\tBC:Z:"; put_sequence(m.text, raw[0].code); m.text += "\tQT:Z:"; put_quality(m.text, raw[0].quality, 33); }
-                if(confidence[0] > 0 && confidence[0] < 1) { m.text += "\tXB:f:"; put_float(m.text, static_cast<float>(1.0 - confidence[0])); }
-                if(!corrected[1].empty()) { m.text += "\tRX:Z:"; put_sequence(m.text, corrected[1].code); m.text += "\tQX:Z:"; put_quality(m.text, corrected[1].quality, 33); }
-                if(!raw[1].empty()) { m.text += "\tOX:Z:"; put_sequence(m.text, raw[1].code); m.text += "\tBZ:Z:"; put_quality(m.text, raw[1].quality, 33); }
-                if(confidence[1] > 0 && confidence[1] < 1) { m.text += "\tXM:f:"; put_float(m.text, static_cast<float>(1.0 - confidence[1])); }
-                if(!corrected[2].empty()) { m.text += "\tCB:Z:"; put_sequence(m.text, corrected[2].code); }
-                if(!raw[2].empty()) { m.text += "\tCR:Z:"; put_sequence(m.text, raw[2].code); m.text += "\tCY:Z:"; put_quality(m.text, raw[2].quality, 33); }
-                if(confidence[2] > 0 && confidence[2] < 1) { m.text += "\tXC:f:"; put_float(m.text, static_cast<float>(1.0 - confidence[2])); }
-                m.text += '\n';
+                if(n_out > 2) { text += "\tFI:i:" + std::to_string(o + 1) + "\tTC:i:" + std::to_string(n_out); }
+                if(rg != nullptr && !rg->empty()) { text += "\tRG:Z:"; text += *rg; }
+                if(!raw[0].empty()) { text += "\tBC:Z:"; put_sequence(text, raw[0].code); text += "\tQT:Z:"; put_quality(text, raw[0].quality, 33); }
+                if(confidence[0] > 0 && confidence[0] < 1) { text += "\tXB:f:"; put_float(text, static_cast<float>(1.0 - confidence[0])); }
+                if(!corrected[1].empty()) { text += "\tRX:Z:"; put_sequence(text, corrected[1].code); text += "\tQX:Z:"; put_quality(text, corrected[1].quality, 33); }
+                if(!raw[1].empty()) { text += "\tOX:Z:"; put_sequence(text, raw[1].code); text += "\tBZ:Z:"; put_quality(text, raw[1].quality, 33); }
+                if(confidence[1] > 0 && confidence[1] < 1) { text += "\tXM:f:"; put_float(text, static_cast<float>(1.0 - confidence[1])); }
+                if(!corrected[2].empty()) { text += "\tCB:Z:"; put_sequence(text, corrected[2].code); }
+                if(!raw[2].empty()) { text += "\tCR:Z:"; put_sequence(text, raw[2].code); text += "\tCY:Z:"; put_quality(text, raw[2].quality, 33); }
+                if(confidence[2] > 0 && confidence[2] < 1) { text += "\tXC:f:"; put_float(text, static_cast<float>(1.0 - confidence[2])); }
+                text += '\n';
             }
             (void)distance;
         }
-        if(!m.text.empty() && std::fwrite(m.text.data(), 1, m.text.size(), m.output) != m.text.size()) { throw IOError("error writing the SAM output"); }
-        if(n_read < m.capacity) { break; }
+        });
+        for(const auto& text : part_text) {
+            if(!text.empty() && std::fwrite(text.data(), 1, text.size(), m.output) != text.size()) { throw IOError("error writing the SAM output"); }
+        }
+        if(last_batch) { break; }
+        for(auto& t : readers) { t.join(); }
+        m.batch.swap(ahead);
     }
     std::fflush(m.output);
 }

@@ -483,3 +483,38 @@ def test_bdggg_fastq_to_sam_is_the_golden_file(torch_cuda, tmp_path, batch_capac
             assert (m["count"], m["pf count"], m.get("low confidence count"), m.get("low conditional confidence count")) == \
                    (t["count"], t["pf count"], t.get("low confidence count"), t.get("low conditional confidence count"))
             assert abs(m["average confidence"] - t["average confidence"]) < 1e-12
+
+
+def test_large_batches_write_the_same_records_in_the_same_order(torch_cuda, tmp_path):
+    """Staging and record formatting split a large batch over host threads, and the next batch is read while the
+    current one is written: the SAM text must not depend on the batch size (small batches take the serial path)."""
+    import os
+    rng = np.random.default_rng(21)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    spec["min input length"] = [0, 6]
+    job = jobspec.compile_job(spec)
+    n = 70001
+    code, quality, flag, _ = synthetic.generate_rows(job, n, 12)
+    letters = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 30))]
+    paths = [os.path.join(tmp_path, "s%d.fastq" % k) for k in (0, 1)]
+    with open(paths[0], "wb") as a, open(paths[1], "wb") as b:
+        for i in range(n):
+            filtered = b"Y" if flag[i] else b"N"
+            keep = 8 if i % 97 else 5                        # a few index reads too short for `min input length`
+            a.write(b"@r%d 1:%s:0:1\n%s\n+\n%s\n" % (i, filtered, template[i].tobytes(), b"F" * 30))
+            b.write(b"@r%d 2:%s:0:1\n%s\n+\n%s\n" % (i, filtered, letters[code[i, :keep]].tobytes(), (quality[i, :keep] + 33).astype(np.uint8).tobytes()))
+    outputs = []
+    for batch_capacity in (4096, 1 << 17):
+        s = DecoderSet(job, device=0)
+        output = os.path.join(tmp_path, "out_%d.sam" % batch_capacity)
+        incoming = s.transcode_fastq_to_sam(paths, output, batch_capacity)
+        assert incoming[0] == n
+        outputs.append((open(output, "rb").read(), s.stats_export()))
+    assert outputs[0][0] == outputs[1][0]
+    assert np.array_equal(outputs[0][1], outputs[1][1])
+    records = outputs[0][0].split(b"\n")
+    kept = n - len(range(0, n, 97))
+    assert len(records) - 1 == 2 * kept
+    assert records[0].startswith(b"r1\t") and records[-2].startswith(b"r%d\t" % (n - 1))
