@@ -255,6 +255,7 @@ void DecoderSet::build_device_images() {
                     while(table[static_cast<size_t>((h + static_cast<uint32_t>(probe)) & (slots - 1)) * 4 + 2] != 0u) { ++probe; }
                     uint32_t* slot = &table[static_cast<size_t>((h + static_cast<uint32_t>(probe)) & (slots - 1)) * 4];
                     slot[0] = key[0]; slot[1] = key[1]; slot[2] = static_cast<uint32_t>(b + 1);
+                    slot[3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);       // Classifier index, saves the kernel a gather
                     longest = std::max(longest, probe + 1);
                 }
                 d.exact_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));

@@ -80,7 +80,7 @@ struct DevDecoder {
     const uint32_t* barcode_packed2;
     const float* concentration_single;    // padded with zeros to whole blocks of 8 barcodes
     // MDD exact match (mdd.cpp:43-46): open addressing hash of the ACGT barcodes; slot = {key low, key high,
-    // ordinal + 1 (0 = empty), unused}, key = 2 bits per base, position j at bits 2j
+    // ordinal + 1 (0 = empty), barcode index}, key = 2 bits per base, position j at bits 2j
     const uint32_t* exact_table;
     uint32_t exact_slots;                 // power of two
     int32_t exact_probes;                 // longest probe sequence + 1

@@ -150,14 +150,21 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
 // the host, load factor <= 1/4).  A hit finishes the read — index, distance 0, counters — having read only its
 // bases; everything else (a base outside ACGT, a short observation, no exact match: ~18 % of the C2 reads) goes
 // to the workgroup's worklist segment for the scan kernel.  This kernel is a pure stream: ~30 B per read.
+constexpr int EXACT_LDS_SLOTS = 1024;                // 16 KiB: codecs of up to 256 barcodes (load factor <= 1/4)
+
 template <int ROW_WORDS>
 __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
     constexpr int READS = 4;                         // reads per lane and pass: independent loads in flight
     __shared__ uint32_t deferred_total;
+    __shared__ uint4 lds_table[EXACT_LDS_SLOTS];      // the hash table, when it fits: a probe is an LDS read, not a trip to L2
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
     if(threadIdx.x == 0) { deferred_total = 0; }
+    const bool table_in_lds = d.exact_slots <= static_cast<uint32_t>(EXACT_LDS_SLOTS);
+    if(table_in_lds) {
+        for(uint32_t slot = threadIdx.x; slot < d.exact_slots; slot += BLOCK) { lds_table[slot] = reinterpret_cast<const uint4*>(d.exact_table)[slot]; }
+    }
     histogram_clear(d, histogram);
     __syncthreads();
 
@@ -221,16 +228,19 @@ __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
             }
         }
         int bin[READS];
+        int32_t barcode_index[READS];                     // the slot's fourth word: Classifier index of the barcode
 #pragma unroll
         for(int u = 0; u < READS; ++u) {
             bin[u] = 0;
+            barcode_index[u] = 0;
             if(valid[u]) {
                 uint32_t h = (key[u][0] * 0x9e3779b1u) ^ (key[u][1] * 0x85ebca77u);
                 h ^= h >> 15;
                 for(int probe = 0; probe < d.exact_probes; ++probe) {
-                    const uint4 entry = table[(h + probe) & slot_mask];
+                    const uint32_t slot = (h + probe) & slot_mask;
+                    const uint4 entry = table_in_lds ? lds_table[slot] : table[slot];
                     if(entry.z == 0u) { break; }                       // empty slot: not a barcode
-                    if(entry.x == key[u][0] && entry.y == key[u][1]) { bin[u] = static_cast<int>(entry.z); break; }
+                    if(entry.x == key[u][0] && entry.y == key[u][1]) { bin[u] = static_cast<int>(entry.z); barcode_index[u] = static_cast<int32_t>(entry.w); break; }
                 }
             }
         }
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
                 decoder_tail(d, sink, state[u], bin[u], 0);
                 if(args.result) {
                     DevResult out;
-                    out.index = d.barcode_index[bin[u] - 1];
+                    out.index = barcode_index[u];
                     out.distance = 0;
                     out.hq_distance = 0;
                     out.status = STATUS_PASS;

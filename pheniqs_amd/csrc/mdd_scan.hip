@@ -19,7 +19,9 @@ namespace {
 __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
 
-template <int ROW_WORDS, int TABLE_REGISTERS>
+// SEGMENTS = barcode segments when 1 or 2 (the per segment tolerance test is then straight line code, no scalar
+// loop over DEV_MAX_SEGMENT per barcode: that loop made the kernel scalar-ALU bound), 0 = any number
+template <int ROW_WORDS, int TABLE_REGISTERS, int SEGMENTS>
 __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
     constexpr int LMAX = 4 * ROW_WORDS;
     constexpr bool PAIRED = ROW_WORDS <= 2;          // plane stride <= 8 bytes <=> up to 8 nt <=> two barcodes per word
@@ -34,7 +36,10 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
     const StatSink sink{histogram, args.stats};
     const int L = d.nucleotide_cardinality;
     const int n_barcode = d.n_barcode;
-    const int n_segment = d.n_segment;
+    const int n_segment = SEGMENTS > 0 ? SEGMENTS : d.n_segment;
+    int tolerance[DEV_MAX_SEGMENT];
+#pragma unroll
+    for(int k = 0; k < DEV_MAX_SEGMENT; ++k) { tolerance[k] = d.distance_tolerance[k]; }
     const int padded_barcodes = (n_barcode + 3) & ~3;
     const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
     uint32_t word_table[TABLE_REGISTERS];            // lane l of register v holds packed word 64 v + l
@@ -108,10 +113,10 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
                 int distance = 0;
                 bool successful = true;
 #pragma unroll
-                for(int s = 0; s < DEV_MAX_SEGMENT; ++s) {                  // unrolled: segment_flags stays in registers
-                    if(s < n_segment) {
+                for(int s = 0; s < (SEGMENTS > 0 ? SEGMENTS : DEV_MAX_SEGMENT); ++s) {     // unrolled: segment_flags stays in registers
+                    if(SEGMENTS > 0 || s < n_segment) {
                         const int error = __popc(flags & (segment_flags[s] << (16 * h)));
-                        successful = successful && error <= d.distance_tolerance[s];
+                        successful = successful && error <= tolerance[s];
                         distance += error;
                     }
                 }
@@ -155,12 +160,19 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
     histogram_flush(args, d, histogram);
 }
 
-template <int ROW_WORDS>
-int launch_rows(const StageArgs& args, int words, dim3 grid, size_t lds_bytes, hipStream_t stream) {
-    if(words <= 64) { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 1>), grid, dim3(BLOCK), lds_bytes, stream, args); }
-    else if(words <= 128) { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 2>), grid, dim3(BLOCK), lds_bytes, stream, args); }
-    else { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 4>), grid, dim3(BLOCK), lds_bytes, stream, args); }
+template <int ROW_WORDS, int SEGMENTS>
+int launch_segments(const StageArgs& args, int words, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    if(words <= 64) { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 1, SEGMENTS>), grid, dim3(BLOCK), lds_bytes, stream, args); }
+    else if(words <= 128) { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 2, SEGMENTS>), grid, dim3(BLOCK), lds_bytes, stream, args); }
+    else { hipLaunchKernelGGL((mdd_scan_kernel<ROW_WORDS, 4, SEGMENTS>), grid, dim3(BLOCK), lds_bytes, stream, args); }
     return static_cast<int>(hipGetLastError());
+}
+
+template <int ROW_WORDS>
+int launch_rows(const StageArgs& args, int words, int segments, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    if(segments == 1) { return launch_segments<ROW_WORDS, 1>(args, words, grid, lds_bytes, stream); }
+    if(segments == 2) { return launch_segments<ROW_WORDS, 2>(args, words, grid, lds_bytes, stream); }
+    return launch_segments<ROW_WORDS, 0>(args, words, grid, lds_bytes, stream);
 }
 
 int packed_words(const DevDecoder& host_decoder) {
@@ -178,10 +190,10 @@ bool mdd_scan_supports(const DevDecoder& host_decoder) {
 int launch_mdd_scan(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     const int words = packed_words(host_decoder);
     switch(host_decoder.plane_stride / 4) {
-        case 1: return launch_rows<1>(args, words, grid, lds_bytes, stream);
-        case 2: return launch_rows<2>(args, words, grid, lds_bytes, stream);
-        case 3: return launch_rows<3>(args, words, grid, lds_bytes, stream);
-        case 4: return launch_rows<4>(args, words, grid, lds_bytes, stream);
+        case 1: return launch_rows<1>(args, words, host_decoder.n_segment, grid, lds_bytes, stream);
+        case 2: return launch_rows<2>(args, words, host_decoder.n_segment, grid, lds_bytes, stream);
+        case 3: return launch_rows<3>(args, words, host_decoder.n_segment, grid, lds_bytes, stream);
+        case 4: return launch_rows<4>(args, words, host_decoder.n_segment, grid, lds_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }
