@@ -503,7 +503,7 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
 size_t DecoderSet::worklist_words(int64_t n_read) const {
     size_t worst = 0;
-    for(int64_t threads : {128, 256, 512}) {     // workgroup sizes the product form kernels use (stage.hip)
+    for(int64_t threads : {128, 192, 256, 512}) {     // workgroup sizes the product form kernels use (stage.hip)
         const int64_t tiles = (n_read + threads - 1) / threads;
         const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
         const int64_t tiles_per_block = (tiles + grid - 1) / grid;

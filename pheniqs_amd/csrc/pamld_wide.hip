@@ -9,7 +9,7 @@ bool pamld_wide_supports(const DevDecoder& host_decoder) {
            host_decoder.n_barcode > 0 && host_decoder.n_barcode <= 256 && host_decoder.use_lds_histogram;
 }
 
-int pamld_wide_block() { return wide::THREADS; }
+int pamld_wide_block(const DevDecoder& host_decoder) { return wide::threads_of(host_decoder.plane_stride / 4); }
 
 int launch_pamld_wide(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.plane_stride / 4) {

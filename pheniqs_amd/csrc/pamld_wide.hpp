@@ -8,7 +8,9 @@
 //   * 5 to 8 sixteen entry tables per read = 320 to 512 bytes of LDS per lane, so a workgroup is 128 lanes and
 //     the tables are [group][index][128 lanes]: byte 1 of an entry address is (lane >> 6) | index << 1, i.e. a
 //     byte of the masked field word OR-ed with a per lane constant — one v_perm_b32 per address — and the
-//     group is the instruction's immediate offset;
+//     group is the instruction's immediate offset.  The 5 group shape (17-20 nt: the 10+10 dual index) takes
+//     192 lanes instead — two workgroups = 12 waves per CU rather than three = 6 — and pays a bit field extract
+//     and a multiply-add per address for its 768 byte entry rows;
 //   * the packed barcode words and the single precision priors sit in LDS and are read at wave uniform
 //     addresses (one ds_read_b128 serves two barcodes), not in a wave wide register.
 //
@@ -23,7 +25,12 @@ namespace wide {
 constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner (pamld_lut.hpp)
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
-constexpr int THREADS = 128;
+template <int G> struct Geometry {
+    static constexpr int THREADS = G == 5 ? 192 : 128;
+    static constexpr uint32_t ENTRY_STEP = THREADS * sizeof(float);
+    static constexpr uint32_t GROUP_STEP = 16u * ENTRY_STEP;
+};
+inline int threads_of(int groups) { return groups == 5 ? 192 : 128; }
 constexpr int FOLD = 8;                       // barcodes per block of the scan
 constexpr uint32_t FIELD_MASK = 0x1e1e1e1eu;
 
@@ -45,11 +52,9 @@ struct Layout {
     uint32_t deferred_at;
     uint32_t histogram_at;
 };
-constexpr uint32_t GROUP_STEP = 16u * THREADS * sizeof(float);
-constexpr uint32_t ENTRY_STEP = THREADS * sizeof(float);
-__host__ __device__ inline Layout layout_of(int groups, int padded_barcodes) {
+__host__ __device__ inline Layout layout_of(int groups, int threads, int padded_barcodes) {
     Layout l;
-    l.words_at = static_cast<uint32_t>(groups) * GROUP_STEP;
+    l.words_at = static_cast<uint32_t>(groups) * 16u * static_cast<uint32_t>(threads) * 4u;
     l.prior_at = l.words_at + static_cast<uint32_t>(padded_barcodes) * 8u;
     l.match_at = l.prior_at + static_cast<uint32_t>(padded_barcodes) * 4u;
     l.mismatch_at = l.match_at + 528u;
@@ -60,7 +65,11 @@ __host__ __device__ inline Layout layout_of(int groups, int padded_barcodes) {
 
 // G = groups of 4 positions = words of the plane row (plane stride = 4 G bytes, zero filled past the barcode)
 template <int G>
-__global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
+__global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageArgs args) {
+    constexpr int THREADS = Geometry<G>::THREADS;
+    constexpr uint32_t GROUP_STEP = Geometry<G>::GROUP_STEP;
+    constexpr uint32_t ENTRY_STEP = Geometry<G>::ENTRY_STEP;
+    constexpr bool PERMUTED = THREADS == 128;
     constexpr int WORDS = (G + 3) / 4;        // words of 16 positions: 2
     static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
     DecoderRef d = *constant_cast(args.decoder);
     const int n_barcode = d.n_barcode;
     const int padded_barcodes = (n_barcode + FOLD - 1) / FOLD * FOLD;
-    const Layout at = layout_of(G, padded_barcodes);
+    const Layout at = layout_of(G, THREADS, padded_barcodes);
     float* const table = reinterpret_cast<float*>(lds_raw);
     uint2* const barcode_words = reinterpret_cast<uint2*>(lds_raw + at.words_at);
     float* const prior_single = reinterpret_cast<float*>(lds_raw + at.prior_at);
@@ -176,9 +185,15 @@ __global__ __launch_bounds__(THREADS) void pamld_wide_kernel(StageArgs args) {
                 float value = 1.0f;
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
-                    const uint32_t cleaned = (fields[g >> 2] & FIELD_MASK) | lane_high_bytes;
-                    // { 0, 0, cleaned.byte[g % 4], lane_low.byte[0] }: byte 1 = (lane >> 6) | index << 1
-                    const uint32_t address = __builtin_amdgcn_perm(cleaned, lane_low, 0x0c0c0400u | (static_cast<uint32_t>(g & 3) << 8));
+                    uint32_t address;
+                    if(PERMUTED) {
+                        const uint32_t cleaned = (fields[g >> 2] & FIELD_MASK) | lane_high_bytes;
+                        // { 0, 0, cleaned.byte[g % 4], lane_low.byte[0] }: byte 1 = (lane >> 6) | index << 1
+                        address = __builtin_amdgcn_perm(cleaned, lane_low, 0x0c0c0400u | (static_cast<uint32_t>(g & 3) << 8));
+                    } else {
+                        const uint32_t index = __builtin_amdgcn_ubfe(fields[g >> 2], 8 * (g & 3) + 1, 4);
+                        address = index * ENTRY_STEP + lane_offset;                         // v_mad_u32_u24
+                    }
                     const float entry = ((LdsFloats)static_cast<uintptr_t>(address))[g * (GROUP_STEP / sizeof(float))];
                     value = g == 0 ? entry : value * entry;
                 }
@@ -343,8 +358,8 @@ int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 gr
         prepared = true;
     }
     const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
-    const size_t lds_bytes = layout_of(G, padded).histogram_at + histogram_bytes;
-    hipLaunchKernelGGL((pamld_wide_kernel<G>), grid, dim3(THREADS), lds_bytes, stream, args);
+    const size_t lds_bytes = layout_of(G, Geometry<G>::THREADS, padded).histogram_at + histogram_bytes;
+    hipLaunchKernelGGL((pamld_wide_kernel<G>), grid, dim3(Geometry<G>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -47,7 +47,7 @@ int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t 
                 // ... and long barcodes that are not combinatorial through the two word product form
                 const bool factorised = !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !pamld_lut_supports(host_decoder) && !factorised;
-                const int64_t threads = factorised ? BLOCK : long_words ? pamld_wide_block() : pamld_lut_block(host_decoder);
+                const int64_t threads = factorised ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < max_blocks ? wide_tiles : max_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
