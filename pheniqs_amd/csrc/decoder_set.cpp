@@ -209,6 +209,7 @@ void DecoderSet::build_device_images() {
         d.match_probability = device_match;
         d.mismatch_probability = device_mismatch;
         d.uniform_probability = scale.uniform_probability;
+        d.factor_pairs = device_factor_pairs;
         if(c.closed()) {
             for(int32_t s = 0; s < c.segment_cardinality; ++s) {
                 d.distance_tolerance[s] = s < static_cast<int32_t>(c.distance_tolerance.size()) ? c.distance_tolerance[static_cast<size_t>(s)] : 0;
@@ -233,6 +234,8 @@ void DecoderSet::build_device_images() {
             }
             d.uniform_prior = 1;
             for(double c0 : concentration) { if(c0 != concentration[0]) { d.uniform_prior = 0; } }
+            d.identity_index = 1;
+            for(int32_t b = 0; b < d.n_barcode; ++b) { if(index[static_cast<size_t>(b)] != b + 1) { d.identity_index = 0; } }
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));

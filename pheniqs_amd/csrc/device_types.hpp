@@ -57,6 +57,7 @@ struct DevDecoder {
     int32_t use_lds_histogram;            // bins fit in LDS: workgroup histogram, else global atomics
     uint32_t segment_end_bits;            // bit j set when position j is the last of its segment
     int32_t uniform_prior;                // every concentration is the same double
+    int32_t identity_index;               // barcode_index[b] == b + 1 for every barcode (the compiler's numbering)
     int32_t distance_tolerance[DEV_MAX_SEGMENT];
     uint32_t segment_mask[DEV_MAX_SEGMENT][DEV_MAX_WORD];   // nibble flags (bit 4*(j%8) of word j/8) per segment
     uint32_t full_mask[DEV_MAX_WORD];     // nibble flags of every position
@@ -121,6 +122,11 @@ struct StageArgs {
     uint32_t* worklist_count;
     int32_t worklist_role;                // 0 none, 1 producer, 2 consumer
     int32_t worklist_stride;
+    // Large codecs (no workgroup histogram): the kernels leave count / distance / confidence of the classified
+    // reads alone and count_results_kernel (counters.hip) builds them from the result records afterwards —
+    // scattered global atomics run at the memory side on this part, ~3.3 of them per read cost as much as the
+    // whole classification
+    int32_t defer_counters;
 };
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.

@@ -34,6 +34,7 @@ struct ReadState {
 struct StatSink {
     unsigned long long* lds;       // histogram base: [0..1] job words, then the decoder's bins
     unsigned long long* global;    // counter buffer
+    bool defer;                    // count / distance / confidence of classified reads are left to count_results_kernel
 };
 
 __device__ __forceinline__ void stat_add(DecoderRef d, const StatSink& sink, int bin, int pf, int field, unsigned long long value) {
@@ -46,6 +47,7 @@ __device__ __forceinline__ void stat_add(DecoderRef d, const StatSink& sink, int
 }
 
 __device__ __forceinline__ void stat_add_confidence(DecoderRef d, const StatSink& sink, int bin, int pf, double confidence) {
+    if(sink.defer) { return; }
     // exact 2^-52 fixed point in two 26 bit limbs: no word can overflow in a workgroup or in a whole run,
     // and the sum does not depend on the order reads are visited in
     const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));
@@ -56,10 +58,12 @@ __device__ __forceinline__ void stat_add_confidence(DecoderRef d, const StatSink
 // Decoder<T>::classify then Classifier<T>::classify: reference decoder.h:68-76, classifier.h:78-86
 __device__ __forceinline__ void decoder_tail(DecoderRef d, const StatSink& sink, ReadState& r, int bin, int distance) {
     const int pf = r.qcfail ? 0 : 1;
-    if(bin > 0 && distance) {
-        stat_add(d, sink, bin, pf, FIELD_DISTANCE, static_cast<unsigned long long>(distance));
+    if(!(sink.defer && bin > 0)) {
+        if(bin > 0 && distance) {
+            stat_add(d, sink, bin, pf, FIELD_DISTANCE, static_cast<unsigned long long>(distance));
+        }
+        stat_add(d, sink, bin, pf, FIELD_COUNT, 1ull);
     }
-    stat_add(d, sink, bin, pf, FIELD_COUNT, 1ull);
     if(d.multiplexing) {
         r.channel = bin > 0 ? constant_cast(d.barcode_index)[bin - 1] : 0;
     }
@@ -175,6 +179,8 @@ __device__ __forceinline__ void load_plane_row(const uint8_t* plane, int64_t i, 
 int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 int launch_count(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool count_results_supports(const DevDecoder& host_decoder);
+int launch_count_results(const StageArgs& args, const DevDecoder& host_decoder, int32_t compute_units, hipStream_t stream);
 bool mdd_scan_supports(const DevDecoder& host_decoder);
 int launch_mdd_scan(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_exact_supports(const DevDecoder& host_decoder);

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
     const int n_barcode = d.n_barcode;
     const int n_segment = d.n_segment;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const int L = d.nucleotide_cardinality;
     constexpr int stride = 4 * ROW_WORDS;            // = d.plane_stride

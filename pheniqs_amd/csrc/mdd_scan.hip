@@ -33,7 +33,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     const int L = d.nucleotide_cardinality;
     const int n_barcode = d.n_barcode;
     const int n_segment = SEGMENTS > 0 ? SEGMENTS : d.n_segment;

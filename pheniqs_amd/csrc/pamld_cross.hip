@@ -13,6 +13,7 @@ int launch_pamld_cross_exact_s3(const StageArgs&, const DevDecoder&, dim3, size_
 // prior, 2 or 3 segments of up to 16 nt, at most CROSS_MAX_UNIQUE distinct words each, every combination present once
 bool pamld_cross_supports(const DevDecoder& host_decoder) {
     return host_decoder.cross_segments >= 2 && host_decoder.cross_segments <= CROSS_MAX_SEGMENT &&
+           host_decoder.high_quality_threshold <= 128 &&               // the byte parallel quality compare of the scan kernel
            host_decoder.cross_groups >= 1 && host_decoder.cross_groups <= 4 &&
            host_decoder.cross_words != nullptr && host_decoder.cross_ordinal != nullptr;
 }

@@ -44,8 +44,8 @@ __device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 // bytes of the scan kernel's LDS block in front of the counter histogram: tables, factor columns, worklist counter
-__host__ __device__ constexpr uint32_t scan_fixed_bytes(int groups) {
-    return static_cast<uint32_t>(groups) * 16u * THREADS * 4u + 528u + 528u + FACTOR_ROWS * 16u + 16u;
+__host__ __device__ constexpr uint32_t scan_fixed_bytes(int groups, int segments) {
+    return static_cast<uint32_t>(groups) * 16u * THREADS * 4u + 1056u + static_cast<uint32_t>(segments) * CROSS_MAX_UNIQUE * 4u + 16u;
 }
 
 // G = groups of 4 positions of the longest segment (segments are padded with absent positions: factor 1 either way)
@@ -56,38 +56,39 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
     constexpr uint32_t INDEX_MASK = 0x3c00u;                                  // index * 1024 at byte 1 of a field word
     // one hand laid dynamic LDS block at LDS address 0 and no static LDS, as in pamld_lut.hpp: a table address is
     // (field & mask) | lane offset, one instruction
-    constexpr uint32_t MATCH_AT = G * GROUP_BYTES;
-    constexpr uint32_t MISMATCH_AT = MATCH_AT + 528;
-    constexpr uint32_t FACTOR_AT = MISMATCH_AT + 528;
-    constexpr uint32_t DEFERRED_AT = FACTOR_AT + FACTOR_ROWS * 16;
-    static_assert(DEFERRED_AT + 16 == scan_fixed_bytes(G), "launch_segments sizes the block");
+    constexpr uint32_t MATCH_AT = G * GROUP_BYTES;                            // FACTOR_ROWS x {match, mismatch} floats
+    constexpr uint32_t WORDS_AT = MATCH_AT + 1056;                            // the segments' distinct words
+    constexpr uint32_t DEFERRED_AT = WORDS_AT + S * CROSS_MAX_UNIQUE * 4;
+    static_assert(DEFERRED_AT + 16 == scan_fixed_bytes(G, S), "launch_segments sizes the block");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float* const table = reinterpret_cast<float*>(lds_raw);                   // [group][index][lane], one segment at a time
-    float* const match_single = reinterpret_cast<float*>(lds_raw + MATCH_AT);
-    float* const mismatch_single = reinterpret_cast<float*>(lds_raw + MISMATCH_AT);
-    double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + FACTOR_AT);   // [row][0 match | 1 mismatch]
+    float2* const factor_single = reinterpret_cast<float2*>(lds_raw + MATCH_AT);
+    uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + WORDS_AT);               // [segment][CROSS_MAX_UNIQUE]
     uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + DEFERRED_AT);
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + DEFERRED_AT + 16);
     DecoderRef d = *constant_cast(args.decoder);
+    // the fp64 factor rows stay in global memory (4 G S cached loads per read, once): with them in LDS a third
+    // workgroup of the 10 + 10 nt shape would not fit a CU
+    const double* const factor_pairs = d.factor_pairs;
 
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
         const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
         const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
-        match_single[i] = static_cast<float>(m);
-        mismatch_single[i] = static_cast<float>(e);
-        factor_double[i][0] = m;
-        factor_double[i][1] = e;
+        factor_single[i] = make_float2(static_cast<float>(m), static_cast<float>(e));
     }
+    for(int w = threadIdx.x; w < S * CROSS_MAX_UNIQUE; w += THREADS) { lds_words[w] = d.cross_words[w]; }      // zero past a segment's words
     if(threadIdx.x == 0) { deferred_total = 0; }
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    // quality >= high quality threshold, byte parallel (pamld_lut.hpp): thresholds of 0..128 (pamld_cross_supports)
+    const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
+    const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
 
-    // per segment, wave uniform: geometry, byte masks of the padded words, flag mask, distinct words
-    uint32_t word_table[S][TABLE_REGISTERS];               // lane l of register v holds distinct word 64 v + l
+    // per segment, wave uniform: geometry, byte masks of the padded words, flag mask
     int first_word[S];
     uint32_t byte_shift[S];
     uint32_t byte_mask[S][G];
@@ -110,11 +111,6 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         for(int g = 0; g < G; ++g) {
             const int valid = length - 4 * g;
             byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
-        }
-#pragma unroll
-        for(int v = 0; v < TABLE_REGISTERS; ++v) {
-            const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
-            word_table[s][v] = w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
         }
     }
 
@@ -162,30 +158,42 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 
 #pragma unroll
         for(int s = 0; s < S; ++s) {
-            // per position: factor row, single precision factors, 2-bit base, high quality flag
+            // per position, four at a time and byte parallel (pamld_lut.hpp): factor row, 2-bit base, flags
             float fm[4 * G];
             float fe[4 * G];
             uint32_t row[G];
             uint32_t observed = 0;
             uint32_t high_quality = 0;
             uint32_t outside = 0;
+            auto gather = [](uint32_t planes) {            // bits 8 j and 8 j + 4 -> bits j and 4 + j
+                const uint32_t t = planes | (planes >> 7);
+                return (t | (t >> 14)) & 0xffu;
+            };
 #pragma unroll
-            for(int g = 0; g < G; ++g) { row[g] = 0; }
+            for(int g = 0; g < G; ++g) {
+                const uint32_t valid = byte_mask[s][g];                              // the bytes of positions inside the segment
+                const uint32_t x = code_words[s][g] & 0x0f0f0f0fu;
+                const uint32_t q8 = quality_words[s][g];
+                const uint32_t q7 = q8 & 0x7f7f7f7fu;
+                const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
+                const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+                const uint32_t strict_bytes = (strict - (strict >> 7)) | strict;
+                // outside ACGT: the uniform quality against every barcode base (row 128), nothing at quality 0 or for
+                // an absent position (row 0 holds 1 and 1)   phred.cpp:62-64
+                const uint32_t nonzero = (q7 + 0x7f7f7f7fu) & 0x80808080u;
+                row[g] = (q7 & strict_bytes) | (nonzero & ~strict_bytes);
+                const uint32_t codes = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
+                observed |= __builtin_amdgcn_alignbit(codes, codes, (32 - (8 * g + 2)) & 31);
+                const uint32_t high = ((q7 + high_quality_addend) | q8) & 0x80808080u & valid;
+                const uint32_t flags = gather(((~strict & 0x80808080u & valid) >> 7) | (high >> 3));
+                outside |= (flags & 0xfu) << (8 * g + 2);
+                high_quality |= (flags >> 4) << (8 * g + 2);
+            }
 #pragma unroll
             for(int j = 0; j < 4 * G; ++j) {
-                const uint32_t c = (code_words[s][j >> 2] >> (8 * (j & 3))) & 0xffu;
-                const uint32_t q8 = (quality_words[s][j >> 2] >> (8 * (j & 3))) & 0xffu;
-                const uint32_t q = q8 & 0x7fu;
-                // a base outside ACGT costs the uniform quality against every barcode base (phred.cpp:62-64);
-                // an absent position (code 0, quality 0) costs nothing: row 0 holds 1 and 1
-                const uint32_t k = strict_code(c) ? q : (q ? 128u : 0u);
-                fm[j] = match_single[k];
-                fe[j] = mismatch_single[k];
-                row[j >> 2] |= k << (8 * (j & 3));
-                const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;                // A,C,G,T (1,2,4,8) -> 0..3
-                observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
-                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality |= 1u << low_bit(j); }
-                if(!strict_code(c)) { outside |= 1u << low_bit(j); }
+                const float2 pair = factor_single[(row[j >> 2] >> (8 * (j & 3))) & 0xffu];
+                fm[j] = pair.x;
+                fe[j] = pair.y;
             }
             // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
 #pragma unroll
@@ -207,12 +215,10 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 }
             }
 
-            // scan the segment's distinct words: maximum (first of equals), runner up, sum of everything but the maximum
-            float top = 0;
-            float second = 0;
-            float rest = 0;
-            int best = -1;
-            auto visit = [&](uint32_t word, int u) {
+            // scan the segment's distinct words eight at a time: the block's maximum and sum; across blocks the
+            // running maximum, which block holds it, that block's sum set aside, the sum of every other block and the
+            // largest maximum of the others (pamld_lut.hpp); then the winner inside its block
+            auto value_of = [&](uint32_t word) {
                 const uint32_t fields = mismatch_fields(observed ^ word);
                 float value = 1.0f;
 #pragma unroll
@@ -221,37 +227,63 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                     const float entry = ((LdsFloats)static_cast<uintptr_t>((source & INDEX_MASK) | lane_offset))[g * (GROUP_BYTES / sizeof(float))];
                     value = g == 0 ? entry : value * entry;
                 }
-                const float lower = fminf(value, top);
-                rest += lower;
-                second = fmaxf(second, lower);
-                best = value > top ? u : best;
-                top = fmaxf(value, top);
+                return value;
             };
+            constexpr int FOLD = 8;
+            const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words + s * CROSS_MAX_UNIQUE);
+            const int n_block = (unique[s] + FOLD - 1) / FOLD;
+            float others_sum = 0;
+            float held_sum = 0;
+            float best_value = 0;
+            float second = 0;
+            int best_block = -1;
+            for(int f = 0; f < n_block; ++f) {
+                const uint4 a = blocks[2 * f];                                      // wave uniform address: a broadcast
+                const uint4 b = blocks[2 * f + 1];
+                float p[FOLD] = {value_of(a.x), value_of(a.y), value_of(a.z), value_of(a.w), value_of(b.x), value_of(b.y), value_of(b.z), value_of(b.w)};
+                if(f == n_block - 1) {
 #pragma unroll
-            for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                const int last = min(unique[s], 64 * (v + 1));
-#pragma unroll 4
-                for(int u = 64 * v; u < last; ++u) {
-                    visit(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v), u);
+                    for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= unique[s]) { p[k] = 0.0f; } }
+                }
+                const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+                const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                const bool takes_over = block_max > best_value;                     // strict: the first block keeps a tie
+                second = fmaxf(second, takes_over ? best_value : block_max);
+                others_sum += takes_over ? held_sum : block_sum;
+                held_sum = takes_over ? block_sum : held_sum;
+                best_block = takes_over ? f : best_block;
+                best_value = takes_over ? block_max : best_value;
+            }
+            float top = 0;
+            float rest = others_sum;
+            int best = -1;
+            uint32_t word = 0;
+            {
+                const int block = best_block < 0 ? 0 : best_block;
+#pragma unroll
+                for(int k = 0; k < FOLD; ++k) {
+                    const int u = FOLD * block + k;
+                    const uint32_t candidate = lds_words[s * CROSS_MAX_UNIQUE + u];
+                    float p = value_of(candidate);
+                    if(u >= unique[s] || best_block < 0) { p = 0.0f; }
+                    const float lower = fminf(p, top);
+                    rest += lower;
+                    second = fmaxf(second, lower);
+                    if(p > top) { best = u; word = candidate; }
+                    top = fmaxf(p, top);
                 }
             }
 
-            if(best < 0) { certain = false; best = 0; }                       // underflow: everything rounded to zero
+            if(best < 0) { certain = false; best = 0; word = lds_words[s * CROSS_MAX_UNIQUE]; }       // underflow: everything rounded to zero
             certain = certain && (second <= RUNNER_UP * top);
-            // the winner's word, its mismatch flags, its distances and its probability again in fp64
-            uint32_t word = 0;
-#pragma unroll
-            for(int v = 0; v < TABLE_REGISTERS; ++v) {
-                const uint32_t got = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute((best & 63) << 2, static_cast<int>(word_table[s][v])));
-                word = (best >> 6) == v ? got : word;
-            }
+            // the winner's mismatch flags, its distances and its probability again in fp64
             const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
             distance += __popc(flags);
             hq_distance += __popc(flags & high_quality);
 #pragma unroll
             for(int j = 0; j < 4 * G; ++j) {
                 const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                best_conditional *= factor_double[k][(flags >> low_bit(j)) & 1u];
+                best_conditional *= factor_pairs[2 * k + ((flags >> low_bit(j)) & 1u)];
             }
             // (winner + others) * (top + rest) - winner * top, every term positive
             others = others * (static_cast<double>(top) + static_cast<double>(rest)) + winner_product * static_cast<double>(rest);
@@ -364,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const int64_t n = static_cast<int64_t>(args.worklist_count[blockIdx.x]);
     const int64_t tiles = (n + THREADS - 1) / THREADS;
@@ -621,7 +653,7 @@ int launch_scan(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStr
         if(status != hipSuccess) { return static_cast<int>(status); }
         prepared = true;
     }
-    hipLaunchKernelGGL((pamld_cross_kernel<G, S>), grid, dim3(THREADS), scan_fixed_bytes(G) + histogram_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_cross_kernel<G, S>), grid, dim3(THREADS), scan_fixed_bytes(G, S) + histogram_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
 
     constexpr int W = (L + 7) / 8;
     constexpr int LP = (L + 3) / 4 * 4;
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
     const PHQ_CONSTANT double* concentration = constant_cast(d.concentration);
     const int n_barcode = d.n_barcode;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     // The packed barcode words sit in LDS: the scan reads a block's words at a wave uniform address (scalar loads
     // would share a counter with the LDS reads of the scan and serialise with them), the winner's block is

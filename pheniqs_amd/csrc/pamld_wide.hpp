@@ -103,7 +103,7 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats};
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const int L = d.nucleotide_cardinality;
     const bool uniform_prior = d.uniform_prior != 0;

@@ -31,7 +31,21 @@ struct Timed {
 };
 }  // namespace
 
-int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
+int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer);
+
+int launch_stage(const StageArgs& caller_args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
+    if(caller_args.n_read <= 0) { return static_cast<int>(hipSuccess); }
+    // a large codec: the classifying kernels leave the classified reads' counters to count_results_kernel
+    StageArgs args = caller_args;
+    args.defer_counters = (host_decoder.algorithm == 1 || host_decoder.algorithm == 2) && args.result != nullptr &&
+                          count_results_supports(host_decoder) ? 1 : 0;
+    const int status = launch_classifier(args, host_decoder, mode, max_blocks, stream, timer);
+    if(status != 0 || !args.defer_counters) { return status; }
+    Timed timed(timer, KERNEL_COUNT, stream);
+    return launch_count_results(args, host_decoder, max_blocks / 8, static_cast<hipStream_t>(stream));
+}
+
+int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
     if(args.n_read <= 0) { return static_cast<int>(hipSuccess); }
     const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
     const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
