@@ -310,7 +310,7 @@ void DecoderSet::build_device_images() {
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
                 d.factor_pairs = device_factor_pairs;
             }
-            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
+            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && d.uniform_prior) || c.algorithm == Algorithm::MDD) && d.n_barcode > 1 &&
                c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
                 // A combinatorial barcode set (every combination of per segment sets, once)?  Then P(r|b) factorises
                 // over the segments and pamld_cross.hpp scans the segments' distinct words instead of the barcodes.
@@ -376,6 +376,8 @@ void DecoderSet::build_device_images() {
                         }
                         d.cross_segments = S;
                         d.cross_groups = groups;
+                        d.cross_identity = 1;
+                        for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
                     }

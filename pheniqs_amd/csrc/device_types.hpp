@@ -92,6 +92,7 @@ struct DevDecoder {
     // factorised PAMLD kernel only: the barcode set is EVERY combination of per segment sets (dual / triple index)
     int32_t cross_segments;               // 0 = not combinatorial (or not supported), else n_segment
     int32_t cross_groups;                 // groups of 4 positions of the longest segment
+    int32_t cross_identity;               // cross_ordinal is the identity: barcodes in lexicographic order of the segment ordinals
     int32_t cross_start[CROSS_MAX_SEGMENT];      // first position of the segment in the observation
     int32_t cross_length[CROSS_MAX_SEGMENT];
     int32_t cross_unique[CROSS_MAX_SEGMENT];     // distinct words of the segment

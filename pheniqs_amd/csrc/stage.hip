@@ -109,6 +109,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 consumer.worklist_role = 2;
                 Timed timed(timer, KERNEL_MDD, stream);
                 if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, grid, histogram_bytes, s); }
+                if(mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, grid, histogram_bytes, s); }
                 return launch_mdd(consumer, host_decoder, grid, histogram_bytes, s);
             }
             Timed timed(timer, KERNEL_MDD, stream);

@@ -268,6 +268,30 @@ def test_combinatorial_sets_factorise(oracle, torch_cuda, lengths, counts):
     assert int((got[0]["status"] == 0).sum()) > n // 2       # most reads decode
 
 
+@pytest.mark.parametrize("lengths,counts,masking", [((6, 9), (12, 10), 0), ((10, 10), (24, 16), 15), ((4, 7, 5), (5, 6, 4), 0), ((16, 3), (7, 9), 10)])
+def test_combinatorial_sets_factorise_under_mdd(oracle, torch_cuda, lengths, counts, masking):
+    """The first barcode, in index order, whose every segment is within tolerance is (first fit of segment 1, ..):
+    mdd_cross.hip scans the segments' distinct words.  Quality masking, N calls, short observations (the distance
+    walks the OBSERVED length), tolerances at the Shannon bound and above what any word reaches."""
+    rng = np.random.default_rng(sum(lengths) * 7 + sum(counts) + masking)
+    segments = [synthetic.barcode_set(rng, c, l, min_distance=3 if l >= 6 else 1) for l, c in zip(lengths, counts)]
+    tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
+    spec = {"input segment cardinality": len(lengths),
+            "sample": synthetic.decoder_spec("mdd", segments, tokens, **{"quality masking threshold": masking})}
+    job = jobspec.compile_job(spec)
+    n = 1 << 14
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 11)
+    L = sum(lengths)
+    noisy = rng.random((n, L)) < 0.03
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random((n, L)) < 0.02] = 0
+    for i in range(L):
+        code[n // 2 + i, i:] = 0
+        quality[n // 2 + i, i:] = 0
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 4           # masked qualities count as mismatches: fewer reads fit
+
+
 def test_paired_sets_that_are_not_combinatorial_stay_exact(oracle, torch_cuda):
     """A zip paired dual index (word i with word i) is not a cross product: no factorised kernel, same results."""
     rng = np.random.default_rng(77)
