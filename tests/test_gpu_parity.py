@@ -542,3 +542,35 @@ def test_large_batches_write_the_same_records_in_the_same_order(torch_cuda, tmp_
     kept = n - len(range(0, n, 97))
     assert len(records) - 1 == 2 * kept
     assert records[0].startswith(b"r1\t") and records[-2].startswith(b"r%d\t" % (n - 1))
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+def test_large_codec_counters_in_a_chain_with_sticky_qcfail(oracle, torch_cuda, algorithm):
+    """A codec too large for the workgroup histogram (its classified reads are counted from the result records by
+    count_results_kernel) in front of and behind small codecs: pass filter / QC fail halves follow the sticky flag
+    (SURVEY S3), the high quality distance filter and the incoming flags."""
+    rng = np.random.default_rng(5)
+    big = [synthetic.barcode_set(rng, 24, 8), synthetic.barcode_set(rng, 16, 8)]           # 384 combinations
+    small = synthetic.barcode_set(rng, 24, 8)
+    options = {"high quality distance threshold": 2, "high quality threshold": 20} if algorithm == "pamld" else {}
+    spec = {"input segment cardinality": 4,
+            "sample": synthetic.decoder_spec(algorithm, [small], ["0::8"], **options),
+            "molecular": [{"algorithm": "naive", "transform": {"token": ["3::6"]}}],
+            "cellular": [synthetic.decoder_spec(algorithm, big, ["1::8", "2::8"], **options),
+                         synthetic.decoder_spec(algorithm, [small], ["0::8"])]}
+    job = jobspec.compile_job(spec)
+    n = 30000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 4)
+    flag = (rng.random(n) < 0.3).astype(np.uint8)
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=3)
+    options_big = s.stats_options(words, 2)
+    assert int(options_big["count"][1:].sum()) > n // 2 and int(options_big["pf_count"][1:].sum()) < int(options_big["count"][1:].sum())
+
+
+def test_high_quality_threshold_beyond_the_byte_parallel_compare(oracle, torch_cuda):
+    """Thresholds above 128 are outside the product form kernels' byte parallel quality compare: those decoders
+    take the literal kernel, with the same results."""
+    job = _small_job("pamld", **{"high quality threshold": 200, "high quality distance threshold": 1})
+    code, quality, flag, offsets = synthetic.generate_rows(job, 4096, 2)
+    quality[:64] = 255
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
