@@ -224,6 +224,16 @@ int phq_format_double(double value, int32_t precision, char* buffer, int32_t cap
 int phq_compile_job(const char* job_json, char** compiled_json);
 void phq_free_string(char* text);
 
+/* ---- next row f3: the prior estimator ---------------------------------------------------------------------
+ * Replaces Transcode::apply_prior_adjustment (reference transcode.cpp:1888-1941) -> Classifier<T>::adjust_prior
+ * (classifier.h:125-160): a copy of `job_json` (the user level or the compiled document of this decoder set; its
+ * decoder repository and `base` references are resolved first, as Transcode::assemble does) in which every
+ * decoder's "noise" is its estimated noise prior and every codec record's "concentration" the
+ * estimated concentration prior of its barcode, from the counters in `host_words` (phq_stats_export / merge /
+ * allreduce).  Printed like the report: keys sorted, doubles truncated at `float precision` decimals.
+ * Release `*adjusted_json` with phq_free_string. */
+int phq_adjust_prior(phq_decoder_set* set, const uint64_t* host_words, const char* job_json, char** adjusted_json);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
            "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam",
-           "phq_compile_job", "phq_free_string")
+           "phq_compile_job", "phq_free_string", "phq_adjust_prior")
 
 
 class PheniqsError(RuntimeError):
@@ -94,6 +94,7 @@ def load_library():
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
     L.phq_free_string.restype = None
+    L.phq_adjust_prior.argtypes = [P, P, ctypes.c_char_p, ctypes.POINTER(P)]
     _library = L
     return L
 
@@ -243,6 +244,16 @@ class DecoderSet:
         self._check(self.lib.phq_transcode_fastq_to_sam(self.handle, len(inputs), paths, output.encode(), batch_capacity,
                                                         ctypes.byref(incoming), ctypes.byref(incoming_pf)))
         return incoming.value, incoming_pf.value
+
+    def adjust_prior(self, words: np.ndarray, job: Dict[str, Any]) -> Dict[str, Any]:
+        """phq_adjust_prior: `job` with estimated noise / concentration priors from the counters in `words`."""
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        out = ctypes.c_void_p()
+        self._check(self.lib.phq_adjust_prior(self.handle, words.ctypes.data, json.dumps(job).encode(), ctypes.byref(out)))
+        try:
+            return json.loads(ctypes.string_at(out.value).decode())
+        finally:
+            self.lib.phq_free_string(out)
 
     KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact", "pamld_exact")
 

@@ -245,6 +245,19 @@ int phq_compile_job(const char* job_json, char** compiled_json) {
 
 void phq_free_string(char* text) { std::free(text); }
 
+int phq_adjust_prior(phq_decoder_set* set, const uint64_t* host_words, const char* job_json, char** adjusted_json) {
+    if(adjusted_json != nullptr) { *adjusted_json = nullptr; }
+    return guarded(set, [&]() {
+        require(set, "set"); require(host_words, "host_words"); require(job_json, "job_json"); require(adjusted_json, "adjusted_json");
+        const phq::JobConfig& job = set->impl.job();
+        const std::string text = phq::adjust_prior(job, host_words, phq::assemble_job(phq::Json::parse(job_json))).dump(job.float_precision);
+        char* out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *adjusted_json = out;
+    });
+}
+
 int phq_format_double(double value, int32_t precision, char* buffer, int32_t capacity) {
     return guarded(nullptr, [&]() {
         require(buffer, "buffer");

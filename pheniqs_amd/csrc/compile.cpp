@@ -429,6 +429,33 @@ bool is_compiled_job(const Json& document) {
     return true;
 }
 
+Json assemble_job(const Json& document) {
+    if(!document.is_object()) { throw ConfigurationError("job document must be a dictionary"); }
+    Json job = document;
+    apply_repository_inheritance(job);
+    const Json repository = job.find("decoder") != nullptr ? *job.find("decoder") : Json();
+    for(const char* topic : TOPICS) {
+        Json* node = job.find(topic);
+        if(node == nullptr || node->is_null()) { continue; }
+        try {
+            if(node->is_object()) { apply_decoder_inheritance(repository.is_null() ? nullptr : &repository, *node); }
+            else if(node->is_array()) {
+                int32_t index = 0;
+                for(auto& element : node->elements()) {
+                    try { apply_decoder_inheritance(repository.is_null() ? nullptr : &repository, element); }
+                    catch(ConfigurationError& error) { throw ConfigurationError(std::string(topic) + " decoder at " + std::to_string(index) + " : " + error.message); }
+                    ++index;
+                }
+            }
+        } catch(ConfigurationError& error) {
+            if(error.message.compare(0, std::string(topic).size(), topic) == 0) { throw; }
+            throw ConfigurationError(std::string(topic) + " decoder : " + error.message);
+        }
+    }
+    job.erase("decoder");
+    return job;
+}
+
 Json compile_job(const Json& document) {
     if(!document.is_object()) { throw ConfigurationError("job document must be a dictionary"); }
     Json job = document;

@@ -19,6 +19,10 @@ namespace phq {
 // true when every decoder of the document already went through the compiler
 bool is_compiled_job(const Json& document);
 
+// Transcode::assemble (transcode.cpp:323-349) without the file imports: the decoder repository and the `base`
+// references resolved, the repository removed.  This is the "instruction" the prior estimator rewrites.
+Json assemble_job(const Json& document);
+
 // throws ConfigurationError exactly where the reference does
 Json compile_job(const Json& document);
 

@@ -1,5 +1,7 @@
 #include "stats.hpp"
 
+#include "error.hpp"
+
 #include <cmath>
 
 namespace phq {
@@ -199,6 +201,57 @@ Json encode_report(const JobConfig& job, const uint64_t* words, uint64_t incomin
     if(!cellular.elements().empty()) { report.set("cellular", cellular); }
     report.sort_keys();                                                     // transcode.cpp:1862 sort_json_value
     return report;
+}
+
+namespace {
+
+void adjust_decoder(const DecoderConfig& decoder, const uint64_t* words, Json& node) {
+    if(!node.is_object()) { return; }
+    const std::vector<OptionCounters> option = decode_counters(decoder, words);
+    SelectorFinal selector;
+    std::vector<OptionFinal> final_option;
+    finalize_decoder(decoder, option, selector, final_option);
+    node.set("noise", Json::real(selector.estimated_noise_prior));
+    Json* codec = node.find("codec");
+    if(codec == nullptr || !codec->is_object()) { return; }
+    for(auto& member : codec->members()) {
+        const Json* segments = member.second.find("barcode");
+        if(segments == nullptr || !segments->is_array()) { continue; }
+        for(size_t b = 0; b < decoder.codec.size(); ++b) {
+            const auto& mine = decoder.codec[b].segment;
+            bool same = mine.size() == segments->elements().size();
+            for(size_t k = 0; same && k < mine.size(); ++k) {
+                same = segments->elements()[k].is_string() && segments->elements()[k].as_string() == mine[k];
+            }
+            if(same) { member.second.set("concentration", Json::real(final_option[b + 1].estimated_concentration_prior)); break; }
+        }
+    }
+}
+
+}  // namespace
+
+Json adjust_prior(const JobConfig& job, const uint64_t* words, const Json& document) {
+    if(!document.is_object()) { throw ConfigurationError("job document must be a dictionary"); }
+    Json adjusted = document;
+    size_t k = 0;
+    for(const char* topic : {"sample", "molecular", "cellular"}) {              // the order of job.decoder (transcode.h:51-60)
+        Json* node = adjusted.find(topic);
+        if(node == nullptr || node->is_null()) { continue; }
+        if(node->is_object()) {
+            if(k >= job.decoder.size()) { throw ConfigurationError("the document has more decoders than the decoder set"); }
+            adjust_decoder(job.decoder[k], words, *node);
+            ++k;
+        } else if(node->is_array()) {
+            for(auto& element : node->elements()) {
+                if(k >= job.decoder.size()) { throw ConfigurationError("the document has more decoders than the decoder set"); }
+                adjust_decoder(job.decoder[k], words, element);
+                ++k;
+            }
+        }
+    }
+    if(k != job.decoder.size()) { throw ConfigurationError("the document does not hold the decoders of the decoder set"); }
+    adjusted.sort_keys();
+    return adjusted;
 }
 
 }  // namespace phq

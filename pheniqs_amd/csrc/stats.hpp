@@ -74,4 +74,9 @@ Json encode_decoder(const DecoderConfig& decoder, const std::vector<OptionCounte
 // whole report: incoming (if count > 0), outgoing, sample, molecular, cellular; keys sorted
 Json encode_report(const JobConfig& job, const uint64_t* words, uint64_t incoming_count, uint64_t incoming_pf_count);
 
+// Classifier<T>::adjust_prior over a job document (classifier.h:125-160, Transcode::apply_prior_adjustment
+// transcode.cpp:1910-1941): every decoder's "noise" becomes its estimated noise prior and every codec record's
+// "concentration" the estimated concentration prior of the barcode with the same segments; keys sorted
+Json adjust_prior(const JobConfig& job, const uint64_t* words, const Json& document);
+
 }  // namespace phq

@@ -185,6 +185,22 @@ def test_report_writer_reproduces_golden_report(oracle):
 
     compare(report, golden, "")
     assert set(report.keys()) == set(golden.keys())
+
+    # the prior estimator (phq_adjust_prior, classifier.h:125-160) on the user level document (its repository and
+    # `base` references are resolved first, like Transcode::assemble) writes the report's estimated priors back,
+    # at 15 truncated decimals like the report
+    raw = bdggg.raw_job()
+    adjusted = s.adjust_prior(words, raw)
+    assert set(adjusted.keys()) == set(raw.keys()) - {"decoder"} and "base" not in adjusted["sample"]
+    for mine_node, theirs_node in ((adjusted["sample"], golden["sample"]), (adjusted["cellular"][0], golden["cellular"][0])):
+        assert mine_node["noise"] == theirs_node["estimated noise"]
+        by_barcode = {tuple(r["barcode"]): r for r in theirs_node["classified"]}
+        assert set(mine_node["codec"]) == set(raw["sample"]["codec"])
+        for key, record in mine_node["codec"].items():
+            barcode = tuple(raw["decoder"]["BDGGG_sample"]["codec"][key]["barcode"])
+            assert record["concentration"] == by_barcode[barcode]["estimated concentration"], key
+            assert record["LB"] == raw["sample"]["codec"][key]["LB"]
+    assert adjusted["molecular"][0]["noise"] == 0
     # layout: sorted keys, 4 space indent, integers bare — same lines as the golden file for a count only block
     golden_text = open(os.path.join(bdggg.HERE, "annotated.report.json")).read()
     for block in ("incoming", "outgoing"):
