@@ -247,8 +247,8 @@ __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
 #pragma unroll
         for(int u = 0; u < READS; ++u) {
             const bool defer = active[u] && bin[u] == 0;
+            if(active[u] && !defer) { decoder_tail(d, sink, state[u], bin[u], 0); }
             if(active[u] && !defer) {
-                decoder_tail(d, sink, state[u], bin[u], 0);
                 if(args.result) {
                     DevResult out;
                     out.index = barcode_index[u];
@@ -257,9 +257,11 @@ __global__ __launch_bounds__(BLOCK) void mdd_exact_kernel(StageArgs args) {
                     out.status = STATUS_PASS;
                     out.qcfail = state[u].qcfail ? 1 : 0;
                     out.confidence = 0;
-                    args.result[index[u]] = out;
+                    stream_result(&args.result[index[u]], out);
                 }
-                store_read_state(args, index[u], state[u]);
+                stream_read_state(args, index[u], state[u]);
+            } else if(active[u]) {
+                stream_placeholder(args, index[u], state[u]);                      // the scan kernel overwrites it
             }
             const unsigned long long deferred = __ballot(defer);
             if(deferred) {

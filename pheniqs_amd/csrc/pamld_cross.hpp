@@ -339,9 +339,11 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                     out.status = status;
                     out.qcfail = r.qcfail ? 1 : 0;
                     out.confidence = confidence;
-                    args.result[i] = out;
+                    stream_result(&args.result[i], out);
                 }
-                store_read_state(args, i, r);
+                stream_read_state(args, i, r);
+            } else if(active) {
+                stream_placeholder(args, i, r);                                   // the next tier overwrites it
             }
         }
         // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment

@@ -416,9 +416,11 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                         out.status = status;
                         out.qcfail = r.qcfail ? 1 : 0;
                         out.confidence = confidence;
-                        args.result[i] = out;
+                        stream_result(&args.result[i], out);
                     }
-                    store_read_state(args, i, r);
+                    stream_read_state(args, i, r);
+                } else if(active) {
+                    stream_placeholder(args, i, r);                                   // the next tier overwrites it
                 }
             }
         }

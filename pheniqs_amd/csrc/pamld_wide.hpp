@@ -324,9 +324,11 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
                         out.status = status;
                         out.qcfail = r.qcfail ? 1 : 0;
                         out.confidence = confidence;
-                        args.result[i] = out;
+                        stream_result(&args.result[i], out);
                     }
-                    store_read_state(args, i, r);
+                    stream_read_state(args, i, r);
+                } else if(active) {
+                    stream_placeholder(args, i, r);                                   // the next tier overwrites it
                 }
             }
         }
