@@ -78,13 +78,8 @@ bool count_results_supports(const DevDecoder& host_decoder) {
 }
 
 int launch_count_results(const StageArgs& args, const DevDecoder& host_decoder, int32_t compute_units, hipStream_t stream) {
-    static bool prepared = false;
-    if(!prepared) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&count_results_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if(status != hipSuccess) { return static_cast<int>(status); }
-        prepared = true;
-    }
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&count_results_kernel, prepared)) { return status; }
     const int64_t by_reads = (args.n_read + READS_PER_WORKGROUP - 1) / READS_PER_WORKGROUP;
     const int64_t blocks = std::max<int64_t>(std::min<int64_t>(compute_units, (args.n_read + COUNT_THREADS - 1) / COUNT_THREADS), by_reads);
     const size_t lds_bytes = static_cast<size_t>(host_decoder.n_barcode + 1) * 16;

@@ -6,6 +6,8 @@
 // (classifier.h:83-85).  Both live in one 32-bit word per read that every stage reads and rewrites.
 #pragma once
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include "device_types.hpp"
@@ -193,6 +195,21 @@ __device__ __forceinline__ void load_plane_row(const uint8_t* plane, int64_t i, 
         out[4 * w + 2] = static_cast<uint8_t>(v >> 16);
         out[4 * w + 3] = static_cast<uint8_t>(v >> 24);
     }
+}
+
+// More than 64 KiB of dynamic LDS has to be asked for, once per kernel and device (one process may drive several
+// devices through several decoder sets, from several threads).
+template <typename Kernel>
+inline int allow_large_lds(Kernel kernel, std::atomic<uint64_t>& done) {
+    int device = 0;
+    if(hipGetDevice(&device) != hipSuccess) { return static_cast<int>(hipErrorInvalidDevice); }
+    const uint64_t bit = 1ull << (static_cast<unsigned>(device) & 63u);
+    if((done.load(std::memory_order_acquire) & bit) == 0) {
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if(status != hipSuccess) { return static_cast<int>(status); }
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    return 0;
 }
 
 // kernel entry points by translation unit

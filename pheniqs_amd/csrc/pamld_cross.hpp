@@ -648,13 +648,8 @@ int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder,
 
 template <int G, int S>
 int launch_scan(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    static bool prepared = false;                           // more than 64 KiB of dynamic LDS has to be asked for
-    if(!prepared) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_cross_kernel<G, S>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if(status != hipSuccess) { return static_cast<int>(status); }
-        prepared = true;
-    }
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_cross_kernel<G, S>, prepared)) { return status; }
     hipLaunchKernelGGL((pamld_cross_kernel<G, S>), grid, dim3(THREADS), scan_fixed_bytes(G, S) + histogram_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }

@@ -445,13 +445,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 template <int L, bool UNIFORM_PRIOR>
 int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t lds_bytes = LutGeometry<L>::HISTOGRAM_AT + histogram_bytes;
-    static bool prepared = false;                           // per instantiation; more than 64 KiB of dynamic LDS has to be asked for
-    if(!prepared) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_lut_kernel<L, UNIFORM_PRIOR>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if(status != hipSuccess) { return static_cast<int>(status); }
-        prepared = true;
-    }
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_lut_kernel<L, UNIFORM_PRIOR>, prepared)) { return status; }
     hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }

@@ -352,13 +352,8 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
 
 template <int G>
 int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    static bool prepared = false;                           // more than 64 KiB of dynamic LDS has to be asked for
-    if(!prepared) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(&pamld_wide_kernel<G>),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if(status != hipSuccess) { return static_cast<int>(status); }
-        prepared = true;
-    }
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_wide_kernel<G>, prepared)) { return status; }
     const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
     const size_t lds_bytes = layout_of(G, Geometry<G>::THREADS, padded).histogram_at + histogram_bytes;
     hipLaunchKernelGGL((pamld_wide_kernel<G>), grid, dim3(Geometry<G>::THREADS), lds_bytes, stream, args);
