@@ -165,6 +165,8 @@ def main():
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
     parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                         help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration")
+    parser.add_argument("--priors", default="uniform", choices=["uniform", "estimated"],
+                        help="estimated: barcode priors that differ (what a prior estimation pass leaves), not the BASELINE shape")
     parser.add_argument("--fastq", type=int, default=0, metavar="N",
                         help="also time N synthetic reads end to end from FASTQ text to SAM text (next rows f1 + f2)")
     parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
@@ -184,6 +186,14 @@ def main():
     device = torch.device("cuda", local_rank)
 
     job, recipe = synthetic.config_job(args.config, args.algorithm)
+    if args.priors == "estimated":
+        from pheniqs_amd import jobspec
+        spec = synthetic.config_spec(args.config, args.algorithm)
+        spread = np.random.default_rng(3)
+        for _, decoder in jobspec.iter_decoders(spec):
+            for record in (decoder.get("codec") or {}).values():
+                record["concentration"] = float(10 ** spread.uniform(-0.5, 0.5))
+        job = jobspec.compile_job(spec)
     bytes_per_read = synthetic.algorithmic_bytes_per_read(job)          # 37 for C2
     pool_n = min(args.pool, args.reads)
     tiles = -(-args.reads // pool_n)

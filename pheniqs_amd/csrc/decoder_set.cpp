@@ -310,8 +310,8 @@ void DecoderSet::build_device_images() {
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
                 d.factor_pairs = device_factor_pairs;
             }
-            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && d.uniform_prior) || c.algorithm == Algorithm::MDD) && d.n_barcode > 1 &&
-               c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
+            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || c.segment_cardinality == 2)) || c.algorithm == Algorithm::MDD) &&
+               d.n_barcode > 1 && c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
                 // A combinatorial barcode set (every combination of per segment sets, once)?  Then P(r|b) factorises
                 // over the segments and pamld_cross.hpp scans the segments' distinct words instead of the barcodes.
                 // A single segment set is the trivial case: it only uses the exact tier of that file.
@@ -380,6 +380,21 @@ void DecoderSet::build_device_images() {
                         for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
+                        if(!d.uniform_prior) {
+                            // priors that differ between the barcodes: by combination, single precision, for the weighted scans
+                            std::vector<float> by_combination(ordinal.size());
+                            std::vector<double> by_combination_double(ordinal.size());
+                            double largest = 0;
+                            for(size_t flat = 0; flat < ordinal.size(); ++flat) {
+                                const double prior = concentration[static_cast<size_t>(ordinal[flat])];
+                                by_combination[flat] = static_cast<float>(prior);
+                                by_combination_double[flat] = prior;
+                                largest = std::max(largest, prior);
+                            }
+                            d.cross_prior = static_cast<const float*>(upload(by_combination.data(), by_combination.size() * sizeof(float)));
+                            d.cross_prior_double = static_cast<const double*>(upload(by_combination_double.data(), by_combination_double.size() * sizeof(double)));
+                            d.cross_prior_max = largest * (1.0 + 1e-6);          // covers the rounding of the single precision copies
+                        }
                     }
                 }
             }

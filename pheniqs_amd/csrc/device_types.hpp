@@ -99,6 +99,9 @@ struct DevDecoder {
     int32_t cross_stride[CROSS_MAX_SEGMENT];     // mixed radix weight of the segment in cross_ordinal
     const uint32_t* cross_words;          // [CROSS_MAX_SEGMENT][CROSS_MAX_UNIQUE] bit-sliced 2-bit words, positions relative to the segment
     const int32_t* cross_ordinal;         // combination -> barcode ordinal
+    const float* cross_prior;             // combination -> prior, single precision (two segment codecs with priors that differ)
+    const double* cross_prior_double;     // the same, double precision
+    double cross_prior_max;               // the largest prior
 };
 
 enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };

@@ -49,8 +49,17 @@ __host__ __device__ constexpr uint32_t scan_fixed_bytes(int groups, int segments
 }
 
 // G = groups of 4 positions of the longest segment (segments are padded with absent positions: factor 1 either way)
-template <int G, int S>
+//
+// WEIGHTED (two segments only): the priors differ between the barcodes (estimated priors, phq_adjust_prior), so the
+// sum over the barcodes does not factorise.  Three scans instead of two: segment 0 plain, which names u0; segment 1
+// with every word weighted by prior[u0][.], which names u1 and gives the exact rest of ROW u0; segment 0 again
+// weighted by prior[.][u1], the exact rest of COLUMN u1 (and u0 must win again).  What lies in neither is bounded
+// by the largest prior times the two plain rests and has to be negligible (1e-9 of the winner) for the read to be
+// finished here.
+template <int G, int S, bool WEIGHTED>
 __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
+    static_assert(!WEIGHTED || S == 2, "weighted scans are for two segment codecs");
+    constexpr int PASSES = WEIGHTED ? 3 : S;
     constexpr uint32_t GROUP_BYTES = 16 * THREADS * sizeof(float);            // [index][256 lanes]
     constexpr uint32_t ENTRY_BYTES = THREADS * sizeof(float);
     constexpr uint32_t INDEX_MASK = 0x3c00u;                                  // index * 1024 at byte 1 of a field word
@@ -155,9 +164,20 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         int distance = 0;
         int hq_distance = 0;
         bool certain = true;
+        // weighted scans: what each pass leaves for the combination below
+        float pass_top[PASSES];                // the winner's value (weighted in the weighted passes)
+        float pass_plain[PASSES];              // the winner's P, without the weight
+        float pass_rest[PASSES];               // the sum of the other words (weighted in the weighted passes)
+        float pass_second[PASSES];             // the runner up (weighted in the weighted passes)
+        float pass_plain_sum[PASSES];          // the plain sum over every word of the segment
+        int pass_best[PASSES];
 
 #pragma unroll
-        for(int s = 0; s < S; ++s) {
+        for(int pass = 0; pass < PASSES; ++pass) {
+            const int s = pass == 2 ? 0 : pass;
+            const bool weigh = WEIGHTED && pass > 0;
+            // the weight of word u of this pass: prior[u * radix[s] + the other segment's winner * its radix]
+            const float* const weights = WEIGHTED ? d.cross_prior + (weigh ? pass_best[pass == 1 ? 0 : 1] * radix[1 - s] : 0) : nullptr;
             // per position, four at a time and byte parallel (pamld_lut.hpp): factor row, 2-bit base, flags
             float fm[4 * G];
             float fe[4 * G];
@@ -236,6 +256,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             float held_sum = 0;
             float best_value = 0;
             float second = 0;
+            float plain_sum = 0;
             int best_block = -1;
             for(int f = 0; f < n_block; ++f) {
                 const uint4 a = blocks[2 * f];                                      // wave uniform address: a broadcast
@@ -244,6 +265,13 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 if(f == n_block - 1) {
 #pragma unroll
                     for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= unique[s]) { p[k] = 0.0f; } }
+                }
+                if(WEIGHTED) {
+                    plain_sum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    if(weigh) {
+#pragma unroll
+                        for(int k = 0; k < FOLD; ++k) { p[k] *= weights[min(FOLD * f + k, unique[s] - 1) * radix[s]]; }
+                    }
                 }
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 best_value = takes_over ? block_max : best_value;
             }
             float top = 0;
+            float top_plain = 0;
             float rest = others_sum;
             int best = -1;
             uint32_t word = 0;
@@ -264,39 +293,67 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 for(int k = 0; k < FOLD; ++k) {
                     const int u = FOLD * block + k;
                     const uint32_t candidate = lds_words[s * CROSS_MAX_UNIQUE + u];
-                    float p = value_of(candidate);
+                    const float plain = value_of(candidate);
+                    float p = weigh ? plain * weights[min(u, unique[s] - 1) * radix[s]] : plain;
                     if(u >= unique[s] || best_block < 0) { p = 0.0f; }
                     const float lower = fminf(p, top);
                     rest += lower;
                     second = fmaxf(second, lower);
-                    if(p > top) { best = u; word = candidate; }
+                    if(p > top) { best = u; word = candidate; top_plain = plain; }
                     top = fmaxf(p, top);
                 }
             }
 
             if(best < 0) { certain = false; best = 0; word = lds_words[s * CROSS_MAX_UNIQUE]; }       // underflow: everything rounded to zero
-            certain = certain && (second <= RUNNER_UP * top);
-            // the winner's mismatch flags, its distances and its probability again in fp64
-            const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
-            distance += __popc(flags);
-            hq_distance += __popc(flags & high_quality);
+            pass_top[pass] = top;
+            pass_plain[pass] = top_plain;
+            pass_rest[pass] = rest;
+            pass_second[pass] = second;
+            pass_plain_sum[pass] = plain_sum;
+            pass_best[pass] = best;
+            if(pass < S) {
+                if(!WEIGHTED) { certain = certain && (second <= RUNNER_UP * top); }
+                // the winner's mismatch flags, its distances and its probability again in fp64
+                const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
+                distance += __popc(flags);
+                hq_distance += __popc(flags & high_quality);
 #pragma unroll
-            for(int j = 0; j < 4 * G; ++j) {
-                const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                best_conditional *= factor_pairs[2 * k + ((flags >> low_bit(j)) & 1u)];
+                for(int j = 0; j < 4 * G; ++j) {
+                    const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                    best_conditional *= factor_pairs[2 * k + ((flags >> low_bit(j)) & 1u)];
+                }
+                // (winner + others) * (top + rest) - winner * top, every term positive
+                others = others * (static_cast<double>(top) + static_cast<double>(rest)) + winner_product * static_cast<double>(rest);
+                winner_product *= static_cast<double>(top);
+                flat += best * radix[s];
             }
-            // (winner + others) * (top + rest) - winner * top, every term positive
-            others = others * (static_cast<double>(top) + static_cast<double>(rest)) + winner_product * static_cast<double>(rest);
-            winner_product *= static_cast<double>(top);
-            flat += best * radix[s];
         }
 
         bool defer = !certain;
         {
             const int best = d.cross_ordinal[flat];
-            const double prior = d.concentration[0];                                  // uniform (pamld_cross_supports)
+            const double prior = WEIGHTED ? d.concentration[best] : d.concentration[0];
             const double best_p = best_conditional * prior;
-            const double total = (best_p + others * prior) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+            if(WEIGHTED) {
+                // the winner (u0, u1): P0 = pass_top[0], P1 = pass_plain[1]; its row and its column are exact, the
+                // rest is bounded.  `others` becomes the sum of prior_b P(r|b) over every other barcode, in units of p.
+                const double p0 = pass_top[0];
+                const double p1 = pass_plain[1];
+                const double winner = static_cast<double>(pass_top[1]) * p0;                   // prior * P0 * P1, single precision
+                const double row_rest = p0 * static_cast<double>(pass_rest[1]);                // u0 fixed, u1 elsewhere
+                const double column_rest = p1 * static_cast<double>(pass_rest[2]);             // u1 fixed, u0 elsewhere
+                // the plain rest of segment 1, bounded: the difference of two single precision sums plus their rounding
+                const double plain_rest = fmax(static_cast<double>(pass_plain_sum[1]) - p1, 0.0) + 2e-7 * static_cast<double>(pass_plain_sum[1]);
+                const double elsewhere = d.cross_prior_max * static_cast<double>(pass_rest[0]) * plain_rest;
+                others = row_rest + column_rest + 0.5 * elsewhere;                             // the midpoint of [0, elsewhere]
+                // the argmax: the column scan must name u0 again, and nothing in the row, the column or elsewhere
+                // may come within single precision of the winner
+                const double runner_up = fmax(fmax(p0 * static_cast<double>(pass_second[1]), p1 * static_cast<double>(pass_second[2])),
+                                              d.cross_prior_max * static_cast<double>(pass_second[0]) * plain_rest);
+                if(pass_best[2] != pass_best[0] || !(winner > 0) || !(runner_up <= static_cast<double>(RUNNER_UP) * winner) ||
+                   !(elsewhere <= 4e-10 * winner)) { defer = true; }
+            }
+            const double total = (best_p + (WEIGHTED ? others : others * prior)) + d.adjusted_noise_probability;   // pamld.cpp:61-86
             double confidence = best_p / total;                                       // pamld.cpp:92
             const double noise_margin = best_conditional - d.random_barcode_probability;
             const double confidence_margin = confidence - d.confidence_threshold;
@@ -305,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             if(!noise_clear) { defer = true; }
             if(!is_noise) {
                 // the posterior matters: a dominant winner and no decision within 1e-9 of the threshold
-                if(!(others <= DOMINANCE * best_conditional) || !(fabs(confidence_margin) > 1e-9)) { defer = true; }
+                if(!(others <= DOMINANCE * (WEIGHTED ? best_p : best_conditional)) || !(fabs(confidence_margin) > 1e-9)) { defer = true; }
             }
             if(!defer && active) {
                 int bin = best + 1;
@@ -435,6 +492,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
         }
     }
     const int64_t stride = d.plane_stride;
+    constexpr bool weighted = false;           // priors that differ: pamld_cross_exact_weighted_kernel
+    constexpr double near = 1.0 - 1e-10;
     const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
     const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
 
@@ -453,6 +512,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
         uint32_t high_quality[S];
         int near_count[S];                     // entries of this lane's column of near_list
         double sum_all = 1.0;                  // product of the per segment sums = sum over every barcode of P(r|b)
+        double listed_all = 1.0;               // the same over the listed words only
         bool defer = false;
 
 #pragma unroll
@@ -496,6 +556,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             // while the maximum was lower are harmless extras: the literal evaluation below decides)
             double top = 0;
             double sum = 0;
+            double listed = 0;                     // the sum over the listed words
             int count = 0;
 #pragma unroll
             for(int v = 0; v < TABLE_REGISTERS; ++v) {
@@ -503,10 +564,11 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                 for(int u = 64 * v; u < last; ++u) {
                     const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
                     sum += p;
-                    if(p * (1.0 - 1e-10) > top) { count = 0; }
-                    if(p >= top * (1.0 - 1e-10)) {
+                    if(p * near > top) { count = 0; listed = 0; }
+                    if(p >= top * near) {
                         near_list[(s * CROSS_MAX_UNIQUE + count) * THREADS + threadIdx.x] = static_cast<uint8_t>(u);
                         ++count;
+                        listed += p;
                     }
                     top = fmax(top, p);
                 }
@@ -514,29 +576,54 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             if(!(top > 0)) { defer = true; count = 0; }
             near_count[s] = count;
             sum_all *= sum;
+            listed_all *= listed;
         }
 
-        // the candidates, literally: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164)
-        int best = 0x7fffffff;
-        double best_conditional = -1.0;
-        uint32_t best_flags[S];
+        // walk the combinations of listed words, the last segment fastest
+        auto for_each_combination = [&](auto&& body) {
+            int choice[S];
+            bool more = true;
 #pragma unroll
-        for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
-        int choice[S];                         // odometer over the near maximal words, the last segment fastest
-        bool more = true;
+            for(int s = 0; s < S; ++s) { choice[s] = 0; more = more && near_count[s] > 0; }
+            while(more) {
+                int flat = 0;
+                uint32_t flags[S];
 #pragma unroll
-        for(int s = 0; s < S; ++s) { choice[s] = 0; more = more && near_count[s] > 0; }
-        const bool any_candidate = more;
-        while(more) {
-            int flat = 0;
-            uint32_t flags[S];
+                for(int s = 0; s < S; ++s) {
+                    const int u = near_list[(s * CROSS_MAX_UNIQUE + choice[s]) * THREADS + threadIdx.x];
+                    flat += u * radix[s];
+                    flags[s] = (mismatch_fields(observed[s] ^ d.cross_words[s * CROSS_MAX_UNIQUE + u]) | outside[s]) & full_mask[s];
+                }
+                body(flat, flags);
+                bool carry = true;
+#pragma unroll
+                for(int s = S - 1; s >= 0; --s) {
+                    if(carry) {
+                        ++choice[s];
+                        if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
+                    }
+                }
+                more = !carry;
+            }
+        };
+        // P(r|b) of a combination as the product of the fp64 factor rows
+        auto product_of = [&](const uint32_t (&flags)[S]) {
+            double p = 1.0;
+#pragma unroll
+            for(int s = 0; s < S; ++s) {
+#pragma unroll
+                for(int j = 0; j < 4 * G; ++j) {
+                    p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags[s] >> low_bit(j)) & 1u) * 8u));
+                }
+            }
+            return p;
+        };
+        // ... and literally: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164)
+        auto literal_of = [&](const uint32_t (&flags)[S]) {
             double sigma = 0;
             double compensation = 0;
 #pragma unroll
             for(int s = 0; s < S; ++s) {
-                const int u = near_list[(s * CROSS_MAX_UNIQUE + choice[s]) * THREADS + threadIdx.x];
-                flat += u * radix[s];
-                flags[s] = (mismatch_fields(observed[s] ^ d.cross_words[s * CROSS_MAX_UNIQUE + u]) | outside[s]) & full_mask[s];
 #pragma unroll
                 for(int j = 0; j < 4 * G; ++j) {
                     if(j < length[s]) {
@@ -548,25 +635,45 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                     }
                 }
             }
+            return phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
+        };
+
+        int best = 0x7fffffff;
+        double best_conditional = -1.0;
+        double best_p = -1.0;                  // prior * P(r|b) of the winner, literal
+        double weighted_sum = 0;               // sum over the listed combinations of prior * P(r|b)
+        uint32_t best_flags[S];
+#pragma unroll
+        for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
+        bool any_candidate = true;
+#pragma unroll
+        for(int s = 0; s < S; ++s) { any_candidate = any_candidate && near_count[s] > 0; }
+        double weighted_top = 0;
+        if(weighted) {
+            for_each_combination([&](int flat, const uint32_t (&flags)[S]) {
+                const double p = product_of(flags) * d.concentration[d.cross_ordinal[flat]];
+                weighted_sum += p;
+                weighted_top = fmax(weighted_top, p);
+            });
+            // what the lists leave out, at most: every unlisted combination at the largest prior
+            const double left_out = d.cross_prior_max * (sum_all - listed_all);
+            if(!(left_out <= 1e-12 * (weighted_sum + d.adjusted_noise_probability)) || !(weighted_top > 0)) { defer = true; }
+        }
+        for_each_combination([&](int flat, const uint32_t (&flags)[S]) {
             const int b = d.cross_ordinal[flat];
-            const double conditional = phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
-            if(conditional > best_conditional || (conditional == best_conditional && b < best)) {
+            const double prior = d.concentration[b];
+            if(weighted && !(product_of(flags) * prior >= weighted_top * (1.0 - 1e-10))) { return; }      // cannot be the argmax
+            const double conditional = literal_of(flags);
+            const double p = conditional * prior;                                  // pamld.cpp:66
+            if(p > best_p || (p == best_p && b < best)) {                          // strict '>' in barcode order
                 best = b;
+                best_p = p;
                 best_conditional = conditional;
 #pragma unroll
                 for(int s = 0; s < S; ++s) { best_flags[s] = flags[s]; }
             }
-            bool carry = true;
-#pragma unroll
-            for(int s = S - 1; s >= 0; --s) {
-                if(carry) {
-                    ++choice[s];
-                    if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
-                }
-            }
-            more = !carry;
-        }
-        if(!any_candidate) { defer = true; best = 0; best_conditional = 0; }
+        });
+        if(!any_candidate || best == 0x7fffffff) { defer = true; best = 0; best_conditional = 0; best_p = 0; }
 
         int distance = 0;
         int hq_distance = 0;
@@ -575,9 +682,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             distance += __popc(best_flags[s]);
             hq_distance += __popc(best_flags[s] & high_quality[s]);
         }
-        const double prior = d.concentration[0];
-        const double best_p = best_conditional * prior;
-        const double total = sum_all * prior + d.adjusted_noise_probability;        // pamld.cpp:61-86
+        const double total = (weighted ? weighted_sum : sum_all * d.concentration[0]) + d.adjusted_noise_probability;   // pamld.cpp:61-86
         double confidence = best_p / total;                                          // pamld.cpp:92
         const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
         if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
@@ -634,6 +739,313 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     histogram_flush(args, d, histogram);
 }
 
+// Tier 1.5 for two segment codecs whose priors differ between the barcodes: sum_b prior_b P(r|b) is the bilinear
+// form  sum_u0 P0[u0] * (sum_u1 prior[u0][u1] P1[u1]),  in fp64, over the words that matter: every lane keeps
+// in LDS a list of the words of each segment within 1e-15 of the segment's maximum (the others cannot move the
+// sum by 1e-12 nor be the argmax; what they could add is bounded and checked), with the P of those of segment 1,
+// and walks list against list — per lane lists, so a wave runs as many rounds as its longest lists.  The combinations within 1e-10 of the largest prior * P0 * P1 are
+// evaluated literally and compared in barcode order, as in pamld_cross_exact_kernel.
+constexpr int WEIGHTED_THREADS = 64;
+constexpr int WEIGHTED_LIST = CROSS_MAX_UNIQUE;   // a lane can keep every word of segment 0
+constexpr int WEIGHTED_SHORT = 64;                // ... and this many of segment 1 with their P; more go to the literal kernel
+
+template <int G>
+__global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_kernel(StageArgs args) {
+    constexpr int S = 2;
+    __shared__ double listed_value[WEIGHTED_SHORT * WEIGHTED_THREADS];        // [entry][lane] P1 of the listed words of segment 1
+    __shared__ uint8_t listed_word[WEIGHTED_SHORT * WEIGHTED_THREADS];        // [entry][lane] their ordinals
+    __shared__ uint8_t significant[WEIGHTED_LIST * WEIGHTED_THREADS];         // [entry][lane] words of segment 0 that matter
+    __shared__ double factor_double[FACTOR_ROWS][2];
+    __shared__ double cost_double[FACTOR_ROWS][2];
+    __shared__ uint32_t deferred_total;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += WEIGHTED_THREADS) {
+        factor_double[i][0] = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        factor_double[i][1] = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
+        cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
+    }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const int64_t n = static_cast<int64_t>(args.worklist_count[blockIdx.x]);
+    const int64_t tiles = (n + WEIGHTED_THREADS - 1) / WEIGHTED_THREADS;
+    int first_word[S];
+    int length[S];
+    uint32_t byte_shift[S];
+    uint32_t byte_mask[S][G];
+    uint32_t full_mask[S];
+    int unique[S];
+    int radix[S];
+    const int row_words = d.plane_stride >> 2;
+#pragma unroll
+    for(int s = 0; s < S; ++s) {
+        const int start = d.cross_start[s];
+        length[s] = d.cross_length[s];
+        first_word[s] = start >> 2;
+        byte_shift[s] = static_cast<uint32_t>(start & 3);
+        unique[s] = d.cross_unique[s];
+        radix[s] = d.cross_stride[s];
+        full_mask[s] = 0;
+#pragma unroll
+        for(int j = 0; j < 4 * G; ++j) { if(j < length[s]) { full_mask[s] |= 1u << low_bit(j); } }
+#pragma unroll
+        for(int g = 0; g < G; ++g) {
+            const int valid = length[s] - 4 * g;
+            byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
+        }
+    }
+    const int64_t stride = d.plane_stride;
+    const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
+    const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
+    const uint32_t* const words0 = d.cross_words;
+    const uint32_t* const words1 = d.cross_words + CROSS_MAX_UNIQUE;
+    const PHQ_CONSTANT int32_t* const ordinal = constant_cast(d.cross_ordinal);
+
+    for(int64_t tile = 0; tile < tiles; ++tile) {
+        const int64_t k = tile * WEIGHTED_THREADS + threadIdx.x;
+        const bool active = k < n;
+        const int64_t i = static_cast<int64_t>(segment[active ? k : n - 1]);
+        __syncthreads();                       // every entry of this tile is read before the wave compacts into it
+        ReadState r = load_read_state(args, i);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+
+        uint32_t row_offset[S][4 * G];
+        uint32_t observed[S];
+        uint32_t outside[S];
+        uint32_t high_quality[S];
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            uint32_t c[G + 1];
+            uint32_t q[G + 1];
+#pragma unroll
+            for(int g = 0; g <= G; ++g) {
+                const int w = min(first_word[s] + g, row_words - 1);
+                c[g] = code_row[w];
+                q[g] = quality_row[w];
+            }
+            observed[s] = 0; outside[s] = 0; high_quality[s] = 0;
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t code_word = __builtin_amdgcn_alignbyte(c[(j >> 2) + 1], c[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t quality_word = __builtin_amdgcn_alignbyte(q[(j >> 2) + 1], q[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t code = (code_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q8 = (quality_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t quality = q8 & 0x7fu;
+                const uint32_t row = strict_code(code) ? quality : (quality ? 128u : 0u);
+                row_offset[s][j] = row * 16u;
+                const uint32_t two = (0x30210u >> (2 * (code & 0xfu))) & 3u;
+                observed[s] |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality[s] |= 1u << low_bit(j); }
+                if(!strict_code(code)) { outside[s] |= 1u << low_bit(j); }
+            }
+        }
+        auto flags_of = [&](auto which, uint32_t word) {
+            constexpr int s = decltype(which)::value;
+            return (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
+        };
+        auto product_of = [&](auto which, uint32_t flags) {
+            constexpr int s = decltype(which)::value;
+            double p = 1.0;
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
+            }
+            return p;
+        };
+        const std::integral_constant<int, 0> zero;
+        const std::integral_constant<int, 1> one;
+
+        // both segments: sum and maximum
+        double sum1 = 0;
+        double top1 = 0;
+        int first1 = 0;
+        for(int u1 = 0; u1 < unique[1]; ++u1) {
+            const double p = product_of(one, flags_of(one, words1[u1]));
+            sum1 += p;
+            if(p > top1) { top1 = p; first1 = u1; }
+        }
+        double top0 = 0;
+        double sum0 = 0;
+        int first0 = 0;
+        for(int u0 = 0; u0 < unique[0]; ++u0) {
+            const double p = product_of(zero, flags_of(zero, words0[u0]));
+            sum0 += p;
+            if(p > top0) { top0 = p; first0 = u0; }
+        }
+        // A read no barcode of which can pass the noise filter (every P(r|b) <= top0 * top1 < the random barcode
+        // probability, the literal values being within 1e-13 of these products) reports nothing but its argmax: then
+        // only words that can still beat the pair of the two maxima are listed — prior P0 P1 >= prior_tt top0 top1
+        // needs P0 >= top0 * prior_tt / largest prior, and the same for P1 — and no sum is taken.  Otherwise: every
+        // word within 1e-15 of its segment's maximum, the only ones that can move the sum by 1e-12 or be the argmax.
+        const double prior_of_tops = d.cross_prior_double[first0 * radix[0] + first1 * radix[1]];
+        const bool only_argmax = top0 * top1 < d.random_barcode_probability * (1.0 - 1e-9) && prior_of_tops > 0;
+        const double keep = only_argmax ? (prior_of_tops / d.cross_prior_max) * (1.0 - 1e-9) : 1e-15;
+        bool defer = !(top0 > 0) || !(top1 > 0);
+        double listed0 = 0;
+        int count0 = 0;
+        for(int u0 = 0; u0 < unique[0]; ++u0) {
+            const double p = product_of(zero, flags_of(zero, words0[u0]));
+            if(p >= top0 * keep && p > 0) {
+                significant[count0 * WEIGHTED_THREADS + threadIdx.x] = static_cast<uint8_t>(u0);
+                ++count0;
+                listed0 += p;
+            }
+        }
+        double listed1 = 0;
+        int count1 = 0;
+        for(int u1 = 0; u1 < unique[1]; ++u1) {
+            const double p = product_of(one, flags_of(one, words1[u1]));
+            if(p >= top1 * keep && p > 0) {
+                if(count1 < WEIGHTED_SHORT) {
+                    listed_value[count1 * WEIGHTED_THREADS + threadIdx.x] = p;
+                    listed_word[count1 * WEIGHTED_THREADS + threadIdx.x] = static_cast<uint8_t>(u1);
+                    ++count1;
+                    listed1 += p;
+                } else {
+                    defer = true;
+                }
+            }
+        }
+        // the bilinear form over the listed words, and the largest prior * P0 * P1
+        double weighted_sum = 0;
+        double weighted_top = 0;
+        for(int k0 = 0; k0 < count0; ++k0) {
+            const int u0 = significant[k0 * WEIGHTED_THREADS + threadIdx.x];
+            const double p0 = product_of(zero, flags_of(zero, words0[u0]));
+            const double* const prior_row = d.cross_prior_double + u0 * radix[0];
+            double row_sum = 0;
+            double row_top = 0;
+            for(int k1 = 0; k1 < count1; ++k1) {
+                const int u1 = listed_word[k1 * WEIGHTED_THREADS + threadIdx.x];
+                const double p = prior_row[u1 * radix[1]] * listed_value[k1 * WEIGHTED_THREADS + threadIdx.x];
+                row_sum += p;
+                row_top = fmax(row_top, p);
+            }
+            weighted_sum += p0 * row_sum;
+            weighted_top = fmax(weighted_top, p0 * row_top);
+        }
+        // what the lists leave out, at most: the unlisted mass at the largest prior
+        const double left_out = d.cross_prior_max * (fmax(sum0 * sum1 - listed0 * listed1, 0.0) + 1e-15 * sum0 * sum1);
+        if(!(weighted_top > 0)) { defer = true; }
+        if(!only_argmax && !(left_out <= 1e-12 * (weighted_sum + d.adjusted_noise_probability))) { defer = true; }
+
+        // the combinations within 1e-10 of the largest, literally (barcode.h:131-164), in barcode order
+        int best = 0x7fffffff;
+        double best_conditional = -1.0;
+        double best_p = -1.0;
+        uint32_t best_flags[S] = {0, 0};
+        if(!defer) {
+            const double floor = weighted_top * (1.0 - 1e-10);
+            for(int k0 = 0; k0 < count0; ++k0) {
+                const int u0 = significant[k0 * WEIGHTED_THREADS + threadIdx.x];
+                const uint32_t flags0 = flags_of(zero, words0[u0]);
+                const double p0 = product_of(zero, flags0);
+                const double* const prior_row = d.cross_prior_double + u0 * radix[0];
+                for(int k1 = 0; k1 < count1; ++k1) {
+                    const int u1 = listed_word[k1 * WEIGHTED_THREADS + threadIdx.x];
+                    const double prior = prior_row[u1 * radix[1]];
+                    if(!(prior * listed_value[k1 * WEIGHTED_THREADS + threadIdx.x] * p0 >= floor)) { continue; }
+                    const int b = ordinal[u0 * radix[0] + u1 * radix[1]];
+                    const uint32_t flags1 = flags_of(one, words1[u1]);
+                    double sigma = 0;
+                    double compensation = 0;
+#pragma unroll
+                    for(int s = 0; s < S; ++s) {
+                        const uint32_t flags = s == 0 ? flags0 : flags1;
+#pragma unroll
+                        for(int j = 0; j < 4 * G; ++j) {
+                            if(j < length[s]) {
+                                const double x = *reinterpret_cast<const double*>(cost_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
+                                const double y = x - compensation;
+                                const double t = sigma + y;
+                                compensation = (t - sigma) - y;
+                                sigma = t;
+                            }
+                        }
+                    }
+                    const double conditional = phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
+                    const double p = conditional * prior;                      // pamld.cpp:66
+                    if(p > best_p || (p == best_p && b < best)) {              // strict '>' in barcode order
+                        best = b; best_p = p; best_conditional = conditional;
+                        best_flags[0] = flags0; best_flags[1] = flags1;
+                    }
+                }
+            }
+        }
+        if(best == 0x7fffffff) { defer = true; best = 0; best_conditional = 0; best_p = 0; }
+
+        int distance = __popc(best_flags[0]) + __popc(best_flags[1]);
+        int hq_distance = __popc(best_flags[0] & high_quality[0]) + __popc(best_flags[1] & high_quality[1]);
+        const double total = weighted_sum + d.adjusted_noise_probability;            // pamld.cpp:61-86
+        double confidence = best_p / total;                                          // pamld.cpp:92
+        const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
+        if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
+        if(!defer && active) {
+            int bin = best + 1;
+            uint8_t status = STATUS_PASS;
+            if(!is_noise) {
+                if(confidence > d.confidence_threshold) {                            // pamld.cpp:99
+                    if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) { r.qcfail = true; }
+                    stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                } else {
+                    stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                    r.qcfail = true;
+                    status = STATUS_LOW_CONFIDENCE;
+                }
+            } else {
+                stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                r.qcfail = true;
+                bin = 0; distance = 0; hq_distance = 0; confidence = 0;
+                status = STATUS_NOISE;
+            }
+            decoder_tail(d, sink, r, bin, distance);
+            if(args.result) {
+                DevResult out;
+                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                out.status = status;
+                out.qcfail = r.qcfail ? 1 : 0;
+                out.confidence = confidence;
+                args.result[i] = out;
+            }
+            store_read_state(args, i, r);
+        }
+        const unsigned long long deferred = __ballot(active && defer);
+        if(deferred) {
+            const int lane = threadIdx.x & 63;
+            uint32_t first = 0;
+            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            first = __shfl(first, 0);
+            if(active && defer) {
+                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+            }
+        }
+        count_outgoing(args, histogram, active && !defer, r);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_weighted_kernel<1>), grid, dim3(WEIGHTED_THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_weighted_kernel<2>), grid, dim3(WEIGHTED_THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_weighted_kernel<3>), grid, dim3(WEIGHTED_THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_weighted_kernel<4>), grid, dim3(WEIGHTED_THREADS), histogram_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int S>
 int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
@@ -646,21 +1058,21 @@ int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder,
     return static_cast<int>(hipGetLastError());
 }
 
-template <int G, int S>
+template <int G, int S, bool WEIGHTED>
 int launch_scan(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_cross_kernel<G, S>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_cross_kernel<G, S>), grid, dim3(THREADS), scan_fixed_bytes(G, S) + histogram_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_cross_kernel<G, S, WEIGHTED>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_cross_kernel<G, S, WEIGHTED>), grid, dim3(THREADS), scan_fixed_bytes(G, S) + histogram_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int S>
+template <int S, bool WEIGHTED>
 int launch_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: return launch_scan<1, S>(args, grid, histogram_bytes, stream);
-        case 2: return launch_scan<2, S>(args, grid, histogram_bytes, stream);
-        case 3: return launch_scan<3, S>(args, grid, histogram_bytes, stream);
-        case 4: return launch_scan<4, S>(args, grid, histogram_bytes, stream);
+        case 1: return launch_scan<1, S, WEIGHTED>(args, grid, histogram_bytes, stream);
+        case 2: return launch_scan<2, S, WEIGHTED>(args, grid, histogram_bytes, stream);
+        case 3: return launch_scan<3, S, WEIGHTED>(args, grid, histogram_bytes, stream);
+        case 4: return launch_scan<4, S, WEIGHTED>(args, grid, histogram_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }

@@ -268,6 +268,32 @@ def test_combinatorial_sets_factorise(oracle, torch_cuda, lengths, counts):
     assert int((got[0]["status"] == 0).sum()) > n // 2       # most reads decode
 
 
+@pytest.mark.parametrize("lengths,counts", [((10, 10), (24, 16)), ((6, 9), (12, 10)), ((8, 8), (40, 3)), ((16, 3), (7, 9))])
+def test_combinatorial_sets_with_priors_that_differ(oracle, torch_cuda, lengths, counts):
+    """Estimated priors (phq_adjust_prior) differ from barcode to barcode: the sum over a dual index codec no longer
+    factorises.  The weighted scans (row and column of the winner exact, the rest bounded) and the weighted exact
+    tier must reproduce the oracle: priors over two orders of magnitude, a few barcodes at zero."""
+    rng = np.random.default_rng(sum(lengths) * 3 + sum(counts))
+    segments = [synthetic.barcode_set(rng, c, l, min_distance=3 if l >= 6 else 1) for l, c in zip(lengths, counts)]
+    tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
+    decoder = synthetic.decoder_spec("pamld", segments, tokens, **{"confidence threshold": 0.9})
+    for k, record in enumerate(decoder["codec"].values()):
+        record["concentration"] = 0 if k % 37 == 5 else float(10 ** rng.uniform(-1, 1))
+    job = jobspec.compile_job({"input segment cardinality": len(lengths), "sample": decoder})
+    n = 1 << 14
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 13)
+    L = sum(lengths)
+    noisy = rng.random((n, L)) < 0.02
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random((n, L)) < 0.02] = 0
+    quality[: n // 8] = 30
+    for i in range(L):
+        code[n // 2 + i, i:] = 0
+        quality[n // 2 + i, i:] = 0
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+
+
 @pytest.mark.parametrize("lengths,counts,masking", [((6, 9), (12, 10), 0), ((10, 10), (24, 16), 15), ((4, 7, 5), (5, 6, 4), 0), ((16, 3), (7, 9), 10)])
 def test_combinatorial_sets_factorise_under_mdd(oracle, torch_cuda, lengths, counts, masking):
     """The first barcode, in index order, whose every segment is within tolerance is (first fit of segment 1, ..):
