@@ -83,7 +83,7 @@ def fastq_end_to_end(args, code, quality, flag, n):
         dt = time.perf_counter() - t0
     assert incoming == n
     return {"reads": n, "Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt,
-            "note": "2 uncompressed FASTQ files (50 nt template + 8 nt index) -> SAM text to /dev/null, one reader thread per file"}
+            "note": "2 uncompressed FASTQ files (50 nt template + 8 nt index) -> SAM text to /dev/null; per file one reader thread indexing lines + decoding threads, formatting on the host threads, a batch read ahead"}
 
 
 def usable_cores():

@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -27,42 +29,71 @@ namespace phq {
 namespace {
 
 // one input file, plain or gzip (gzread reads both), 4 line FASTQ records
+//
+// A batch is read in two steps: the reader thread pulls bytes and indexes line starts until it holds the lines of
+// `capacity` records (memchr speed), then the records are decoded — name, Illumina filter flag, ASCII -> BAM codes,
+// quality - offset — on a few threads over contiguous record ranges (two passes: sizes, then a prefix sum places
+// every thread's output).  The reference decodes under the feed lock, one record at a time (feed.h:320-333).
 class FastqStream {
 public:
     explicit FastqStream(const std::string& path) : path_(path), begin_(0), end_(0), eof_(false) {
         file_ = gzopen(path.c_str(), "rb");
         if(file_ == nullptr) { throw IOError("could not open " + path + " for reading"); }
         gzbuffer(file_, 1 << 20);
-        buffer_.resize(1 << 22);
+        buffer_.resize(1 << 24);
     }
     ~FastqStream() { if(file_) { gzclose(file_); } }
     FastqStream(const FastqStream&) = delete;
     FastqStream& operator=(const FastqStream&) = delete;
 
-    bool line(const char*& data, size_t& size) {
-        while(true) {
-            const char* start = buffer_.data() + begin_;
-            const void* newline = std::memchr(start, '\n', end_ - begin_);
-            if(newline != nullptr) {
-                data = start;
-                size = static_cast<const char*>(newline) - start;
-                begin_ += size + 1;
-                if(size > 0 && data[size - 1] == '\r') { --size; }
-                return true;
+    // the next up to `capacity` records: line[4 i + k] = (offset, size) of line k of record i inside data()
+    int64_t index_records(int64_t capacity, std::vector<std::pair<size_t, uint32_t>>& line) {
+        line.clear();
+        size_t scan = begin_;
+        const size_t wanted = static_cast<size_t>(capacity) * 4;
+        while(line.size() < wanted) {
+            const char* start = buffer_.data() + scan;
+            const void* newline = scan < end_ ? std::memchr(start, '\n', end_ - scan) : nullptr;
+            if(newline == nullptr) {
+                if(eof_) {
+                    if(scan < end_) {                                          // last line without a newline
+                        push(line, scan, end_ - scan);
+                        scan = end_;
+                    }
+                    break;
+                }
+                // more bytes: keep what is not consumed yet at the front (offsets already taken stay valid: they are
+                // relative to begin_, rebased below)
+                const size_t shift = begin_;
+                refill();
+                scan -= shift;
+                for(auto& l : line) { l.first -= shift; }
+                continue;
             }
-            if(eof_) {
-                if(begin_ == end_) { return false; }
-                data = start;
-                size = end_ - begin_;
-                begin_ = end_;
-                return true;
-            }
-            refill();
+            const size_t size = static_cast<const char*>(newline) - start;
+            push(line, scan, size);
+            scan += size + 1;
         }
+        const size_t records = line.size() / 4;
+        if(line.size() % 4 != 0) {
+            if(eof_ && scan == end_) { throw SequenceError("truncated FASTQ record in " + path_); }
+            line.resize(records * 4);
+        }
+        consumed_ = records > 0 ? line[records * 4 - 1].first + line[records * 4 - 1].second + 1 : scan;
+        if(records * 4 == line.size() && line.size() < wanted) { consumed_ = scan; }      // end of input: trailing blank lines too
+        if(consumed_ > end_) { consumed_ = end_; }
+        return static_cast<int64_t>(records);
     }
+    void release() { begin_ = consumed_; }                 // the indexed records have been decoded
+    const char* data() const { return buffer_.data(); }
     const std::string& path() const { return path_; }
 
 private:
+    void push(std::vector<std::pair<size_t, uint32_t>>& line, size_t offset, size_t size) {
+        if(size > 0 && buffer_[offset + size - 1] == '\r') { --size; }
+        if(size == 0 && line.size() % 4 == 0) { return; }                      // blank line between records
+        line.emplace_back(offset, static_cast<uint32_t>(size));
+    }
     void refill() {
         if(begin_ > 0) {
             std::memmove(buffer_.data(), buffer_.data() + begin_, end_ - begin_);
@@ -80,6 +111,7 @@ private:
     std::vector<char> buffer_;
     size_t begin_;
     size_t end_;
+    size_t consumed_ = 0;
     bool eof_;
 };
 
@@ -91,6 +123,7 @@ struct SegmentBatch {
     std::vector<uint8_t> qcfail;
     std::vector<char> name;              // concatenated, name_offset[i] .. name_offset[i + 1]
     std::vector<int64_t> name_offset;
+    std::vector<std::pair<size_t, uint32_t>> line;
     std::string error;
     void clear() {
         code.clear(); quality.clear(); offset.clear(); length.clear(); qcfail.clear(); name.clear();
@@ -100,7 +133,7 @@ struct SegmentBatch {
     int64_t size() const { return static_cast<int64_t>(length.size()); }
 };
 
-void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, SegmentBatch& out) {
+void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, int32_t threads, SegmentBatch& out) {
     static const std::vector<uint8_t> ascii_table = []() {                  // AsciiToAmbiguousBam, iupac.h:153-171
         std::vector<uint8_t> table(256);
         for(int c = 0; c < 256; ++c) { table[static_cast<size_t>(c)] = ascii_to_bam(static_cast<uint8_t>(c)); }
@@ -108,46 +141,84 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
     }();
     out.clear();
     try {
-        const char* data;
-        size_t size;
-        while(out.size() < capacity) {
-            if(!stream.line(data, size)) { break; }
-            if(size == 0) { continue; }
-            if(data[0] != '@') { throw SequenceError("malformed FASTQ record in " + stream.path()); }
-            // kseq: name up to the first whitespace, comment after it
+        const int64_t n = stream.index_records(capacity, out.line);
+        const char* const data = stream.data();
+        const auto& line = out.line;
+        // name up to the first whitespace (kseq), comment after it
+        auto name_end_of = [&](int64_t i) {
+            const char* header = data + line[static_cast<size_t>(4 * i)].first;
+            const size_t size = line[static_cast<size_t>(4 * i)].second;
             size_t name_end = 1;
-            while(name_end < size && data[name_end] != ' ' && data[name_end] != '\t') { ++name_end; }
-            out.name.insert(out.name.end(), data + 1, data + name_end);
-            out.name_offset.push_back(static_cast<int64_t>(out.name.size()));
-            // Illumina comment `segment:filtered:control:barcode` (fastq.h:219-285): filtered == 'Y' sets QC fail
-            bool qcfail = false;
-            size_t p = name_end < size ? name_end + 1 : size;
-            while(p < size && data[p] != ':') { ++p; }
-            if(p + 1 < size) { qcfail = data[p + 1] == 'Y'; }
-            out.qcfail.push_back(qcfail ? 1 : 0);
-
-            if(!stream.line(data, size)) { throw SequenceError("truncated FASTQ record in " + stream.path()); }
-            out.offset.push_back(static_cast<int64_t>(out.code.size()));
-            out.length.push_back(static_cast<int32_t>(size));
-            const size_t sequence_size = size;
-            {
-                const size_t at = out.code.size();
-                out.code.resize(at + size);
-                uint8_t* to = out.code.data() + at;
-                for(size_t i = 0; i < size; ++i) { to[i] = ascii_table[static_cast<uint8_t>(data[i])]; }
+            while(name_end < size && header[name_end] != ' ' && header[name_end] != '\t') { ++name_end; }
+            return name_end;
+        };
+        // pass 1: validate, sizes per thread range
+        const int parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(threads, (n + (1 << 14) - 1) >> 14)));
+        std::vector<int64_t> sequence_bytes(static_cast<size_t>(parts) + 1, 0), name_bytes(static_cast<size_t>(parts) + 1, 0);
+        out.offset.resize(static_cast<size_t>(n));
+        out.length.resize(static_cast<size_t>(n));
+        out.qcfail.resize(static_cast<size_t>(n));
+        out.name_offset.resize(static_cast<size_t>(n) + 1);
+        parallel_ranges(n, 1 << 14, parts, [&](int64_t first, int64_t last, int part) {
+            int64_t bases = 0;
+            int64_t names = 0;
+            for(int64_t i = first; i < last; ++i) {
+                const auto& header = line[static_cast<size_t>(4 * i)];
+                const auto& sequence = line[static_cast<size_t>(4 * i + 1)];
+                const auto& separator = line[static_cast<size_t>(4 * i + 2)];
+                const auto& quality = line[static_cast<size_t>(4 * i + 3)];
+                if(header.second == 0 || data[header.first] != '@') { throw SequenceError("malformed FASTQ record in " + stream.path()); }
+                if(separator.second == 0 || data[separator.first] != '+') { throw SequenceError("malformed FASTQ separator in " + stream.path()); }
+                if(quality.second != sequence.second) { throw SequenceError("sequence and quality differ in length in " + stream.path()); }
+                out.length[static_cast<size_t>(i)] = static_cast<int32_t>(sequence.second);
+                bases += sequence.second;
+                names += static_cast<int64_t>(name_end_of(i)) - 1;
             }
-            if(!stream.line(data, size) || size == 0 || data[0] != '+') { throw SequenceError("malformed FASTQ separator in " + stream.path()); }
-            if(!stream.line(data, size)) { throw SequenceError("truncated FASTQ record in " + stream.path()); }
-            if(size != sequence_size) { throw SequenceError("sequence and quality differ in length in " + stream.path()); }
-            {
-                const size_t at = out.quality.size();
-                out.quality.resize(at + size);
-                uint8_t* to = out.quality.data() + at;
-                for(size_t i = 0; i < size; ++i) { to[i] = static_cast<uint8_t>(data[i] - phred_offset); }
-            }
+            sequence_bytes[static_cast<size_t>(part) + 1] = bases;
+            name_bytes[static_cast<size_t>(part) + 1] = names;
+        });
+        for(int part = 0; part < parts; ++part) {
+            sequence_bytes[static_cast<size_t>(part) + 1] += sequence_bytes[static_cast<size_t>(part)];
+            name_bytes[static_cast<size_t>(part) + 1] += name_bytes[static_cast<size_t>(part)];
         }
-    } catch(const Error& e) {
+        out.code.resize(static_cast<size_t>(sequence_bytes[static_cast<size_t>(parts)]));
+        out.quality.resize(out.code.size());
+        out.name.resize(static_cast<size_t>(name_bytes[static_cast<size_t>(parts)]));
+        out.name_offset[static_cast<size_t>(n)] = name_bytes[static_cast<size_t>(parts)];
+        // pass 2: decode into place
+        parallel_ranges(n, 1 << 14, parts, [&](int64_t first, int64_t last, int part) {
+            int64_t at = sequence_bytes[static_cast<size_t>(part)];
+            int64_t name_at = name_bytes[static_cast<size_t>(part)];
+            for(int64_t i = first; i < last; ++i) {
+                const char* header = data + line[static_cast<size_t>(4 * i)].first;
+                const size_t header_size = line[static_cast<size_t>(4 * i)].second;
+                const size_t name_end = name_end_of(i);
+                std::memcpy(out.name.data() + name_at, header + 1, name_end - 1);
+                out.name_offset[static_cast<size_t>(i)] = name_at;
+                name_at += static_cast<int64_t>(name_end) - 1;
+                // Illumina comment `segment:filtered:control:barcode` (fastq.h:219-285): filtered == 'Y' sets QC fail
+                bool qcfail = false;
+                size_t p = name_end < header_size ? name_end + 1 : header_size;
+                while(p < header_size && header[p] != ':') { ++p; }
+                if(p + 1 < header_size) { qcfail = header[p + 1] == 'Y'; }
+                out.qcfail[static_cast<size_t>(i)] = qcfail ? 1 : 0;
+                const size_t size = line[static_cast<size_t>(4 * i + 1)].second;
+                const char* sequence = data + line[static_cast<size_t>(4 * i + 1)].first;
+                const char* quality = data + line[static_cast<size_t>(4 * i + 3)].first;
+                out.offset[static_cast<size_t>(i)] = at;
+                uint8_t* to_code = out.code.data() + at;
+                uint8_t* to_quality = out.quality.data() + at;
+                for(size_t k = 0; k < size; ++k) { to_code[k] = ascii_table[static_cast<uint8_t>(sequence[k])]; }
+                for(size_t k = 0; k < size; ++k) { to_quality[k] = static_cast<uint8_t>(quality[k] - phred_offset); }
+                at += static_cast<int64_t>(size);
+            }
+        });
+        stream.release();
+    } catch(const std::exception& e) {
         out.error = e.what();
+        if(out.error.empty()) { out.error = "error reading " + stream.path(); }
+        out.code.clear(); out.quality.clear(); out.offset.clear(); out.length.clear(); out.qcfail.clear(); out.name.clear();
+        out.name_offset.assign(1, 0);
     }
 }
 
@@ -163,10 +234,17 @@ struct Text {
 };
 
 void put_sequence(std::string& out, const std::vector<uint8_t>& code) {
-    for(uint8_t c : code) { out.push_back(bam_to_ascii(c)); }
+    static const char table[] = "=ACMGRSVTWYHKDBN";                        // BamToAmbiguousAscii, iupac.h:62-79
+    const size_t at = out.size();
+    out.resize(at + code.size());
+    char* to = &out[at];
+    for(size_t i = 0; i < code.size(); ++i) { to[i] = table[code[i] & 0xf]; }
 }
 void put_quality(std::string& out, const std::vector<uint8_t>& quality, int32_t phred_offset) {
-    for(uint8_t q : quality) { out.push_back(static_cast<char>(q + phred_offset)); }
+    const size_t at = out.size();
+    out.resize(at + quality.size());
+    char* to = &out[at];
+    for(size_t i = 0; i < quality.size(); ++i) { to[i] = static_cast<char>(quality[i] + phred_offset); }
 }
 void put_float(std::string& out, float value) {
     char scratch[48];
@@ -240,13 +318,27 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
 
+    // barcode index -> ordinal in tag_array order, per decoder
+    std::vector<std::vector<int>> ordinal_by_index(job.decoder.size());
+    for(size_t k = 0; k < job.decoder.size(); ++k) {
+        int32_t largest = 0;
+        for(const auto& b : job.decoder[k].codec) { largest = std::max(largest, b.index); }
+        ordinal_by_index[k].assign(static_cast<size_t>(largest) + 1, -1);
+        for(size_t b = 0; b < job.decoder[k].codec.size(); ++b) {
+            int& slot = ordinal_by_index[k][static_cast<size_t>(job.decoder[k].codec[b].index)];
+            if(slot < 0) { slot = static_cast<int>(b); }                        // the first of equals, as the scan did
+        }
+    }
+
     // f1: one reader thread per input file (the reference has one producer thread per feed, feed.h:309-314); the
     // next batch is read while this one is staged, classified and written
     std::vector<SegmentBatch> ahead(m.batch.size());
+    // decoding threads per file: the files are read concurrently and the previous batch is being formatted meanwhile
+    const int32_t parse_threads = std::max(1, host_threads() / (2 * std::max(1, n_segment)));
     auto start_readers = [&](std::vector<SegmentBatch>& into) {
         std::vector<std::thread> readers;
         for(int32_t s = 0; s < n_segment; ++s) {
-            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(s)]), m.capacity, job.input_phred_offset, std::ref(into[static_cast<size_t>(s)]));
+            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(s)]), m.capacity, job.input_phred_offset, parse_threads, std::ref(into[static_cast<size_t>(s)]));
         }
         return readers;
     };
@@ -256,6 +348,12 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     }
     const int workers = host_threads();
     std::vector<std::string> part_text(static_cast<size_t>(workers));
+    // PHQ_TRANSCODE_TRACE=1: wall time per phase on stderr at the end of the run
+    const bool trace = std::getenv("PHQ_TRANSCODE_TRACE") != nullptr;
+    double phase[6] = {0, 0, 0, 0, 0, 0};      // validate, stage, classify, format, write, wait for the readers
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double mark = now();
+    auto lap = [&](int k) { const double t = now(); phase[k] += t - mark; mark = t; };
     while(true) {
         for(const auto& b : m.batch) { if(!b.error.empty()) { throw SequenceError(b.error); } }
         const int64_t n_read = m.batch[0].size();
@@ -289,16 +387,20 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             offset[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].offset.data();
             length[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].length.data();
         }
+        lap(0);
         int64_t n_kept = 0;
         m.set.stage_reads(n_read, n_segment, code.data(), quality.data(), offset.data(), length.data(),
                           m.batch[static_cast<size_t>(leader)].qcfail.data(), m.capacity, m.base, m.quality, m.flag, m.kept.data(), &n_kept,
                           &incoming_count, &incoming_pf_count);
+        lap(1);
         m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word);
+        lap(2);
 
         // f2: records, a contiguous range of the batch per thread, written in order
         for(auto& text : part_text) { text.clear(); }
         parallel_ranges(n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
         std::string& text = part_text[static_cast<size_t>(part)];
+        text.reserve(static_cast<size_t>(last_kept - first_kept) * 256);
         Text raw[3], corrected[3], out_segment[8];
         for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
@@ -316,7 +418,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 // the decoded barcode: ordinal in tag_array order, -1 = unclassified
                 int ordinal = -1;
                 if(res != nullptr && res->index > 0) {
-                    for(size_t b = 0; b < d.codec.size(); ++b) { if(d.codec[b].index == res->index) { ordinal = static_cast<int>(b); break; } }
+                    const auto& by_index = ordinal_by_index[static_cast<size_t>(&d - job.decoder.data())];
+                    if(static_cast<size_t>(res->index) < by_index.size()) { ordinal = by_index[static_cast<size_t>(res->index)]; }
                 }
                 for(int32_t s = 0; s < d.segment_cardinality; ++s) {
                     const int32_t so = d.segment_offset[static_cast<size_t>(s)];
@@ -408,14 +511,21 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             (void)distance;
         }
         });
+        lap(3);
         for(const auto& text : part_text) {
             if(!text.empty() && std::fwrite(text.data(), 1, text.size(), m.output) != text.size()) { throw IOError("error writing the SAM output"); }
         }
+        lap(4);
         if(last_batch) { break; }
         for(auto& t : readers) { t.join(); }
+        lap(5);
         m.batch.swap(ahead);
     }
     std::fflush(m.output);
+    if(trace) {
+        std::fprintf(stderr, "transcode phases (s): validate %.3f stage %.3f classify %.3f format %.3f write %.3f wait for readers %.3f\n",
+                     phase[0], phase[1], phase[2], phase[3], phase[4], phase[5]);
+    }
 }
 
 }  // namespace phq
