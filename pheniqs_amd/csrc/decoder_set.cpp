@@ -380,18 +380,26 @@ void DecoderSet::build_device_images() {
                         for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
-                        if(!d.uniform_prior) {
+                        if(!d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD) {
                             // priors that differ between the barcodes: by combination, single precision, for the weighted scans
-                            std::vector<float> by_combination(ordinal.size());
+                            const size_t n0 = distinct[0].size();
+                            const size_t n1 = distinct[1].size();
+                            std::vector<float> by_combination(n0 * CROSS_MAX_UNIQUE, 0.0f);            // [u0][u1], rows zero padded
+                            std::vector<float> transposed(n1 * CROSS_MAX_UNIQUE, 0.0f);                // [u1][u0]
                             std::vector<double> by_combination_double(ordinal.size());
                             double largest = 0;
-                            for(size_t flat = 0; flat < ordinal.size(); ++flat) {
-                                const double prior = concentration[static_cast<size_t>(ordinal[flat])];
-                                by_combination[flat] = static_cast<float>(prior);
-                                by_combination_double[flat] = prior;
-                                largest = std::max(largest, prior);
+                            for(size_t u0 = 0; u0 < n0; ++u0) {
+                                for(size_t u1 = 0; u1 < n1; ++u1) {
+                                    const size_t flat = u0 * static_cast<size_t>(stride[0]) + u1 * static_cast<size_t>(stride[1]);
+                                    const double prior = concentration[static_cast<size_t>(ordinal[flat])];
+                                    by_combination[u0 * CROSS_MAX_UNIQUE + u1] = static_cast<float>(prior);
+                                    transposed[u1 * CROSS_MAX_UNIQUE + u0] = static_cast<float>(prior);
+                                    by_combination_double[flat] = prior;
+                                    largest = std::max(largest, prior);
+                                }
                             }
                             d.cross_prior = static_cast<const float*>(upload(by_combination.data(), by_combination.size() * sizeof(float)));
+                            d.cross_prior_transposed = static_cast<const float*>(upload(transposed.data(), transposed.size() * sizeof(float)));
                             d.cross_prior_double = static_cast<const double*>(upload(by_combination_double.data(), by_combination_double.size() * sizeof(double)));
                             d.cross_prior_max = largest * (1.0 + 1e-6);          // covers the rounding of the single precision copies
                         }

@@ -99,7 +99,8 @@ struct DevDecoder {
     int32_t cross_stride[CROSS_MAX_SEGMENT];     // mixed radix weight of the segment in cross_ordinal
     const uint32_t* cross_words;          // [CROSS_MAX_SEGMENT][CROSS_MAX_UNIQUE] bit-sliced 2-bit words, positions relative to the segment
     const int32_t* cross_ordinal;         // combination -> barcode ordinal
-    const float* cross_prior;             // combination -> prior, single precision (two segment codecs with priors that differ)
+    const float* cross_prior;             // [word of segment 0][CROSS_MAX_UNIQUE] priors, single precision, zero padded
+    const float* cross_prior_transposed;  // [word of segment 1][CROSS_MAX_UNIQUE], the same transposed
     const double* cross_prior_double;     // the same, double precision
     double cross_prior_max;               // the largest prior
 };

@@ -176,8 +176,11 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         for(int pass = 0; pass < PASSES; ++pass) {
             const int s = pass == 2 ? 0 : pass;
             const bool weigh = WEIGHTED && pass > 0;
-            // the weight of word u of this pass: prior[u * radix[s] + the other segment's winner * its radix]
-            const float* const weights = WEIGHTED ? d.cross_prior + (weigh ? pass_best[pass == 1 ? 0 : 1] * radix[1 - s] : 0) : nullptr;
+            // the weights of this pass, contiguous and zero padded to CROSS_MAX_UNIQUE: the row of the winner of
+            // segment 0 (pass 1) or, from the transposed copy, the column of the winner of segment 1 (pass 2)
+            const float* const weights = !WEIGHTED ? nullptr
+                                       : pass == 1 ? d.cross_prior + pass_best[0] * CROSS_MAX_UNIQUE
+                                       : pass == 2 ? d.cross_prior_transposed + pass_best[1] * CROSS_MAX_UNIQUE : d.cross_prior;
             // per position, four at a time and byte parallel (pamld_lut.hpp): factor row, 2-bit base, flags
             float fm[4 * G];
             float fe[4 * G];
@@ -269,8 +272,12 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 if(WEIGHTED) {
                     plain_sum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                     if(weigh) {
-#pragma unroll
-                        for(int k = 0; k < FOLD; ++k) { p[k] *= weights[min(FOLD * f + k, unique[s] - 1) * radix[s]]; }
+                        {
+                            const float4 low = *reinterpret_cast<const float4*>(weights + FOLD * f);
+                            const float4 high = *reinterpret_cast<const float4*>(weights + FOLD * f + 4);
+                            p[0] *= low.x; p[1] *= low.y; p[2] *= low.z; p[3] *= low.w;
+                            p[4] *= high.x; p[5] *= high.y; p[6] *= high.z; p[7] *= high.w;
+                        }
                     }
                 }
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                     const int u = FOLD * block + k;
                     const uint32_t candidate = lds_words[s * CROSS_MAX_UNIQUE + u];
                     const float plain = value_of(candidate);
-                    float p = weigh ? plain * weights[min(u, unique[s] - 1) * radix[s]] : plain;
+                    float p = weigh ? plain * weights[u] : plain;
                     if(u >= unique[s] || best_block < 0) { p = 0.0f; }
                     const float lower = fminf(p, top);
                     rest += lower;
@@ -747,7 +754,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
 // evaluated literally and compared in barcode order, as in pamld_cross_exact_kernel.
 constexpr int WEIGHTED_THREADS = 64;
 constexpr int WEIGHTED_LIST = CROSS_MAX_UNIQUE;   // a lane can keep every word of segment 0
-constexpr int WEIGHTED_SHORT = 64;                // ... and this many of segment 1 with their P; more go to the literal kernel
+constexpr int WEIGHTED_SHORT = 32;                // ... and this many of segment 1 with their P; more go to the literal kernel
 
 template <int G>
 __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_kernel(StageArgs args) {
