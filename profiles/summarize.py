@@ -32,10 +32,11 @@ def kind_of(name):
 
 
 def first(directory, pattern):
-    found = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True))
+    """The newest match: a directory may hold the output of earlier runs too."""
+    found = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True), key=os.path.getmtime)
     if not found:
         raise SystemExit("no %s under %s" % (pattern, directory))
-    return found[0]
+    return found[-1]
 
 
 def counter_average(directory, counter):
