@@ -82,7 +82,6 @@ template <int L, bool UNIFORM_PRIOR>
 __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
     constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
     constexpr int THREADS = LutGeometry<L>::THREADS;
-    constexpr int LP = (L + 3) / 4 * 4;
     constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
     constexpr int PER_WORD = PAIRED ? 2 : 1;
     static_assert(L <= 16, "2-bit codes of one barcode fit one word");
@@ -261,7 +260,6 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             // — its members are recomputed after the scan, which also names the winner inside the block.
             constexpr int FOLD = 8;
             constexpr int WORDS_PER_FOLD = FOLD / PER_WORD;
-            constexpr int FOLDS_PER_REGISTER = 64 / WORDS_PER_FOLD;
             float others_sum = 0;          // every block but the one holding the running maximum
             float held_sum = 0;            // the sum of the block holding the running maximum
             float best_value = 0;
@@ -466,10 +464,6 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
     }
 }
 
-inline int packed_words(const DevDecoder& host_decoder) {
-    const int padded = (host_decoder.n_barcode + 7) & ~7;
-    return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
-}
 
 }  // namespace lut
 }  // namespace phq
