@@ -600,3 +600,30 @@ def test_high_quality_threshold_beyond_the_byte_parallel_compare(oracle, torch_c
     code, quality, flag, offsets = synthetic.generate_rows(job, 4096, 2)
     quality[:64] = 255
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+@pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (12, 33), (16, 256), (16, 260), (32, 5)])
+def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
+    """The smallest and the largest codecs each kernel family takes, and the first sizes past them (which fall back
+    to the next family): one barcode, one nucleotide, 512 barcodes of 8 nt in 256 packed words, 256 of 16 nt."""
+    rng = np.random.default_rng(length * 1000 + count)
+    words = synthetic.barcode_set(rng, count, length, min_distance=1 if length < 6 or count > 200 else 3)
+    job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec(algorithm, [words], ["0::%d" % length])})
+    n = 4096
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 3)
+    code[rng.random((n, length)) < 0.01] = 15
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+@pytest.mark.parametrize("counts", [(128, 3), (129, 3), (2, 128)])
+def test_combinatorial_size_extremes(oracle, torch_cuda, algorithm, counts):
+    """128 distinct words per segment is what the factorised kernels keep; one more and the codec takes the general
+    kernels (384 / 387 / 256 barcodes, all past the workgroup histogram)."""
+    rng = np.random.default_rng(sum(counts))
+    segments = [synthetic.barcode_set(rng, counts[0], 8, min_distance=1), synthetic.barcode_set(rng, counts[1], 8, min_distance=1)]
+    job = jobspec.compile_job({"input segment cardinality": 2, "sample": synthetic.decoder_spec(algorithm, segments, ["0::8", "1::8"])})
+    n = 4096
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 6)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
