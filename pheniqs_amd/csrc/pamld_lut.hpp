@@ -142,7 +142,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
 
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        // every lane stays enabled (the wave wide table is gathered with cross lane reads): lanes past the end
+        // every lane stays enabled (one code path, whole wave LDS traffic): lanes past the end
         // of the batch recompute its last read and are kept from every store and counter
         const bool active = tile * THREADS + threadIdx.x < n;
         const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
