@@ -220,6 +220,8 @@ bool count_results_supports(const DevDecoder& host_decoder);
 int launch_count_results(const StageArgs& args, const DevDecoder& host_decoder, int32_t compute_units, hipStream_t stream);
 bool mdd_scan_supports(const DevDecoder& host_decoder);
 int launch_mdd_scan(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool mdd_fused_supports(const DevDecoder& host_decoder);
+int launch_mdd_fused(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_cross_supports(const DevDecoder& host_decoder);
 int launch_mdd_cross(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_exact_supports(const DevDecoder& host_decoder);

@@ -92,6 +92,11 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
+            if(mode == MODE_FAST && mdd_fused_supports(host_decoder)) {
+                // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
+                Timed timed(timer, KERNEL_MDD, stream);
+                return launch_mdd_fused(args, host_decoder, grid, histogram_bytes, s);
+            }
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: exact match lookup over every read; tier 2: the scan kernel on what it deferred (same grid)
                 // the exact match kernel takes 4 tiles per pass, so a workgroup may own up to 3 tiles more than its share
