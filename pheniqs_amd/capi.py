@@ -60,6 +60,13 @@ def load_library():
     global _library
     if _library is not None:
         return _library
+    # One HIP runtime per process: PyTorch ships its own copy of libamdhip64 and has to get it in first.  If this
+    # library pulled the system copy in first and torch then initialised its own, the second one to touch the device
+    # reported "no ROCm-capable device" (seen on the MI355X pool).  torch is plumbing here, never required.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise PheniqsError(2, "libpheniqs_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`): " + path)
