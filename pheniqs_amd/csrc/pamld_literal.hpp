@@ -6,8 +6,8 @@
 //
 // "Literal" means sigma_q of every barcode is the reference's Kahan recurrence, operation for
 // operation, in fp64 with contraction off: the argmax (ties included: strict '>' keeps the lowest
-// index) is decided on the same sums the reference decides on.  Only pow() differs (an
-// in-kernel 2^x within ~1 ulp of libm's, kernel_common.hpp), which moves the posterior by ~1e-16.
+// index) is decided on the same sums the reference decides on.  Only pow() differs (in-kernel
+// 2^x, kernel_common.hpp: ~0.502 ulp where the argmax is decided, ~1 ulp in the sum), which moves the posterior by ~1e-16.
 //
 // Template parameters: L = nucleotide cardinality (fully unrolled), STRICT = every barcode base is
 // one of A, C, G, T (the common case; drops the IUPAC branch from the inner loop).
@@ -80,8 +80,15 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
             double best_p = 0;
             double best_conditional = 0;
             int best = -1;
-#pragma unroll 2
-            for(int b = 0; b < n_barcode; ++b) {
+            // Every barcode's probability within ~1 ulp (phred_probability_fast) for the sum.  The argmax needs the
+            // carefully rounded power only where two barcodes come within 1e-15 of each other at the top with Kahan sums
+            // that are NOT the same double (equal sums are equal powers under any pow: the first keeps the tie): the
+            // same multiset of costs summed in another order, ~1 read in 10 000.  Those reads take a second walk.
+            double running = 0;                 // the largest quickly rounded probability so far
+            int near_index = 0;                 // the barcode that holds it (the first of equals)
+            double near_sigma = 0;
+            bool ambiguous = false;
+            auto kahan_of = [&](int b) {
                 uint32_t expected[W];
 #pragma unroll
                 for(int w = 0; w < W; ++w) { expected[w] = packed[b * W + w]; }
@@ -99,16 +106,37 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                     c = (t - sigma_q) - y;
                     sigma_q = t;
                 }
-                const double conditional = phred_probability(sigma_q, log2_base_hi, log2_base_lo);
-                const double p = conditional * concentration[b];
+                return sigma_q;
+            };
+#pragma unroll 2
+            for(int b = 0; b < n_barcode; ++b) {
+                const double sigma_q = kahan_of(b);
+                const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
                 const double y = p - compensation;
                 const double t = sigma_p + y;
                 compensation = (t - sigma_p) - y;
                 sigma_p = t;
-                if(p > best_p) {
-                    best = b;
-                    best_p = p;
-                    best_conditional = conditional;
+                const bool clears = p * (1.0 - 1e-15) > running;                    // a new maximum well above the old one
+                const bool close = !clears && p >= running * (1.0 - 1e-15) && p > 0;
+                if(clears) { near_index = b; near_sigma = sigma_q; ambiguous = false; }
+                ambiguous = ambiguous || (close && sigma_q != near_sigma);
+                running = p > running ? p : running;
+            }
+            if(!ambiguous) {
+                if(running > 0) {
+                    best = near_index;
+                    best_conditional = phred_probability(near_sigma, log2_base_hi, log2_base_lo);
+                    best_p = best_conditional * concentration[near_index];
+                }
+            } else {
+                for(int b = 0; b < n_barcode; ++b) {
+                    const double sigma_q = kahan_of(b);
+                    const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
+                    if(p >= running * (1.0 - 1e-15)) {
+                        const double conditional = phred_probability(sigma_q, log2_base_hi, log2_base_lo);
+                        const double careful = conditional * concentration[b];
+                        if(careful > best_p) { best = b; best_p = careful; best_conditional = conditional; }     // strict: the lowest index keeps a tie
+                    }
                 }
             }
             {

@@ -14,7 +14,7 @@
 //
 // The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
 // (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-9).  So a read is only FINISHED in
-// this kernel when its winner dominates: the summed probability of every other barcode is at most 1e-3 of the
+// this kernel when its winner dominates: the summed probability of every other barcode is at most 5e-4 of the
 // winner's (DOMINANCE).  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single
 // precision — their ~5e-7 relative error moves the posterior by at most DOMINANCE * 5e-7 — while the winner's own
 // probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
@@ -30,8 +30,9 @@
 namespace phq {
 namespace lut {
 
-constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner, see the header
+constexpr double DOMINANCE = 5e-4;            // others <= DOMINANCE * winner, see the header
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
+constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 
 // Bit-sliced 2-bit bases (A, C, G, T = 0..3).  Position 4f + k lives in byte f of the word: its low code bit at
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 // otherwise the posterior matters: a dominant winner, no decision within 1e-9 of its threshold
                 const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
                 defer = !noise_clear
-                     || (noise_margin <= 0 ? !(runner_up <= RUNNER_UP * winner_single)
+                     || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
                                            : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
                 if(!defer && active) {
                     int bin = best + 1;

@@ -22,8 +22,9 @@
 namespace phq {
 namespace wide {
 
-constexpr double DOMINANCE = 1e-3;            // others <= DOMINANCE * winner (pamld_lut.hpp)
+constexpr double DOMINANCE = 5e-4;            // others <= DOMINANCE * winner (pamld_lut.hpp)
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
+constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 template <int G> struct Geometry {
     static constexpr int THREADS = G == 5 ? 192 : 128;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
                 // otherwise the posterior matters: a dominant winner, no decision within 1e-9 of its threshold
                 const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
                 defer = !noise_clear
-                     || (noise_margin <= 0 ? !(runner_up <= RUNNER_UP * winner_single)
+                     || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
                                            : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
                 if(!defer && active) {
                     int bin = best + 1;

@@ -7,9 +7,15 @@ namespace phq {
 PhredScale::PhredScale() {
     uniform_base_quality = 10.0 * std::log10(4);
     phred_probability_base = std::pow(10.0, -0.1);
-    const long double log2_base = log2l(static_cast<long double>(phred_probability_base));   // x87 extended: 64 bit mantissa
+    // log2 of the DOUBLE the reference holds, to 106 bits.  For fl(10^-0.1) = 0x1.96b230bcdc434p-1 (what glibc's pow
+    // returns) the pair is a constant computed once with 80 digit arithmetic; any other value of the base falls back
+    // to the 64 bit mantissa of the host's log2l (the low word then only has 11 good bits).
+    const long double log2_base = log2l(static_cast<long double>(phred_probability_base));
     log2_base_hi = static_cast<double>(log2_base);
     log2_base_lo = static_cast<double>(log2_base - static_cast<long double>(log2_base_hi));
+    if(phred_probability_base == 0x1.96b230bcdc434p-1 && log2_base_hi == -0x1.542a5a12e1c5bp-2) {
+        log2_base_lo = -0x1.7d4a7c345d92fp-58;
+    }
     false_positive_probability[0] = 0;
     true_positive_probability[0] = 0;
     true_positive_quality[0] = 0;

@@ -242,7 +242,8 @@ def test_ties_keep_the_lowest_index(oracle, torch_cuda, mode):
     assert set(got[0]["index"][:64]) <= {0, 1}
 
 
-@pytest.mark.parametrize("lengths,counts", [((6, 9), (12, 10)), ((10, 10), (24, 16)), ((4, 7, 5), (5, 6, 4)), ((16, 3), (7, 9)), ((1, 1), (4, 4))])
+@pytest.mark.parametrize("lengths,counts", [((6, 9), (12, 10)), ((10, 10), (24, 16)), ((4, 7, 5), (5, 6, 4)), ((16, 3), (7, 9)), ((1, 1), (4, 4)),
+                                            ((7, 10, 4), (16, 14, 14)), ((12, 3, 9), (6, 9, 5))])
 def test_combinatorial_sets_factorise(oracle, torch_cuda, lengths, counts):
     """Dual / triple index sets holding every combination go through the factorised kernel (pamld_cross.hpp) in
     PHQ_MODE_FAST: unequal segment lengths, segments that start off a 4 byte boundary, N calls, zero qualities,

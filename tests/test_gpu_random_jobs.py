@@ -1,0 +1,73 @@
+"""Randomised jobs against the oracle: codec shapes, priors, thresholds and read quality drawn at random, both
+kernel modes.  A fixed seed list keeps the default run short; PHQ_STRESS_SEEDS=first:last widens it."""
+import os
+
+import numpy as np
+import pytest
+
+from pheniqs_amd import jobspec, synthetic
+from test_gpu_parity import assert_parity, torch_cuda  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _seeds():
+    text = os.environ.get("PHQ_STRESS_SEEDS", "0:12")
+    first, last = (int(x) for x in text.split(":"))
+    return list(range(first, last))
+
+
+def _random_decoder(rng, algorithm, kind):
+    segments = int(rng.choice([1, 1, 1, 2, 2, 3]))
+    lengths = [int(rng.integers(1, 13)) for _ in range(segments)]
+    while sum(lengths) > 32:
+        lengths[int(rng.integers(0, segments))] = 4
+    combinatorial = segments > 1 and rng.random() < 0.6
+    if combinatorial:
+        counts = [int(min(rng.integers(2, 20), 4 ** l)) for l in lengths]
+        words = [synthetic.barcode_set(rng, c, l, min_distance=1) for c, l in zip(counts, lengths)]
+        pairing = "product"
+    else:
+        count = int(min(rng.integers(1, 120), 4 ** min(lengths)))
+        words = [synthetic.barcode_set(rng, count, l, min_distance=1) for l in lengths]
+        for w in words[1:]:
+            rng.shuffle(w)
+        pairing = "zip"
+    options = {"confidence threshold": float(rng.choice([0.5, 0.9, 0.95, 0.99])),
+               "noise": float(rng.choice([0.0, 0.01, 0.05])),
+               "high quality threshold": int(rng.choice([0, 20, 30, 41])),
+               "high quality distance threshold": int(rng.choice([0, 0, 1, 2])),
+               "quality masking threshold": int(rng.choice([0, 0, 10, 25]))}
+    decoder = synthetic.decoder_spec(algorithm, words, ["%d::%d" % (k, l) for k, l in enumerate(lengths)], pairing=pairing, **options)
+    if algorithm == "mdd" and rng.random() < 0.5:
+        decoder["distance tolerance"] = None
+    if rng.random() < 0.5:
+        for record in decoder["codec"].values():
+            record["concentration"] = float(10 ** rng.uniform(-1, 1))
+    return decoder, len(lengths)
+
+
+@pytest.mark.parametrize("seed", _seeds())
+def test_random_job(oracle, torch_cuda, seed):
+    rng = np.random.default_rng(1000 + seed)
+    algorithm = "pamld" if seed % 2 == 0 else "mdd"
+    sample, n_input = _random_decoder(rng, algorithm, "sample")
+    spec = {"input segment cardinality": n_input, "sample": sample}
+    if rng.random() < 0.5:
+        cellular, needed = _random_decoder(rng, str(rng.choice(["pamld", "mdd"])), "cellular")
+        spec["cellular"] = [cellular]
+        spec["input segment cardinality"] = max(n_input, needed)
+    if rng.random() < 0.3:
+        spec["molecular"] = [{"algorithm": "naive", "transform": {"token": ["0::4"]}}]
+    job = jobspec.compile_job(spec)
+    n = 6000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, seed)
+    width = code.shape[1]
+    noisy = rng.random((n, width)) < 0.03
+    code[noisy] = np.array([15, 0, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=int(noisy.sum()))]
+    quality[rng.random((n, width)) < 0.03] = 0
+    quality[: n // 10] = int(rng.choice([2, 12, 30, 40]))            # uniform qualities: exact ties
+    for i in range(min(width, 40)):
+        code[n // 2 + i, i:] = 0
+        quality[n // 2 + i, i:] = 0
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=int(rng.integers(1, 4)))
