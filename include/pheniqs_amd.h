@@ -162,11 +162,28 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
  * FASTQ files (plain or gzip), one per input segment (fastq.h:55-78,253-285,427-440; read.h:253-264),
  * batches of batch_capacity reads through phq_stage_reads and phq_classify_host, then per read the output
  * segments of the job's `template` (transform.h:190-226) with the tags Read::flush sets (read.h:187-237)
- * in Auxiliary::encode order (auxiliary.cpp:327-354), printed the way htslib prints SAM.  No header lines
- * (@HD/@RG/@PG belong to the SAM header model, out of scope).  Counters accumulate in the set; the incoming
+ * in Auxiliary::encode order (auxiliary.cpp:327-354), printed the way htslib prints SAM, after the header
+ * lines the reference writes: @HD VN:1.0 SO:unknown GO:query, one @RG per barcode of the sample decoder
+ * (atom.cpp:454-472,906-965; transcode.cpp:1679-1700) and a @PG line naming this library (the reference's own
+ * test drops @PG before comparing, test/BDGGG/function.sh:29).  Counters accumulate in the set; the incoming
  * counters of Transcode::pull (transcode.cpp:304-309) are added to *incoming_count / *incoming_pf_count. */
 int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char* const* input_path, const char* sam_output_path,
                                int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
+
+/* The same run driven by the job's own IO directives, what `pheniqs mux --config job.json` does for FASTQ and SAM text
+ * (transcode.cpp:500-557,683-733 input; 1261-1417 output; multiplex.h:198-240 routing):
+ *   input   `input` URLs under `base input url`, plain or gzip FASTQ; a URL stated k times is ONE interleaved feed
+ *           whose consecutive records are k segments of a read (transcode.cpp:693-701).
+ *   output  every barcode of the multiplexing decoder (and its undetermined) is a channel; its `output` — own,
+ *           else the decoder's, else the root's, else /dev/stdout — names one URL per output segment (a single URL
+ *           is repeated, pad_url_array_by_key), under `base output url`.  A read goes to the channel of its decoded
+ *           barcode (classifier.h:83-85) unless the channel sets `filter outgoing qc fail` and the read failed.
+ *           Format by `?format=` or extension: fastq / fq -> FASTQ records with the Illumina comment
+ *           `segment:Y|N:0:raw sample barcode` (fastq.h:144-194), anything else SAM text; `.gz` or
+ *           `?compression=gz` -> gzip (one member per batch part, compressed on all host threads).
+ * BAM / CRAM (htslib) and bz2 / xz are refused with a configuration error; QC accumulators are not collected.
+ * Records keep the input order inside every file. */
+int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
 
 /* Measurement aid (the reference has no timers): when enabled, every kernel launch of
  * phq_classify_* is bracketed by HIP events on its own stream.  phq_profile_collect waits for them, returns

@@ -218,7 +218,16 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
         if(batch_capacity <= 0) { throw phq::InternalError("batch capacity must be positive"); }
         std::vector<std::string> input;
         for(int32_t i = 0; i < n_input; ++i) { require(input_path[i], "input_path[i]"); input.emplace_back(input_path[i]); }
-        phq::Transcoder transcoder(set->impl, input, sam_output_path, batch_capacity);
+        phq::Transcoder transcoder(set->impl, phq::TranscodePlan::explicit_files(set->impl.job(), input, sam_output_path), batch_capacity);
+        transcoder.run(*incoming_count, *incoming_pf_count);
+    });
+}
+
+int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(incoming_count, "incoming_count"); require(incoming_pf_count, "incoming_pf_count");
+        if(batch_capacity <= 0) { throw phq::InternalError("batch capacity must be positive"); }
+        phq::Transcoder transcoder(set->impl, phq::TranscodePlan::from_job(set->impl.job()), batch_capacity);
         transcoder.run(*incoming_count, *incoming_pf_count);
     });
 }

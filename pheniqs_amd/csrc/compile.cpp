@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "error.hpp"
+#include "url.hpp"
 
 namespace phq {
 
@@ -415,6 +416,110 @@ bool decoder_is_compiled(const Json& decoder) {
            decoder.find("index") != nullptr && decoder.find("barcode length") != nullptr && decoder.find("base") == nullptr;
 }
 
+// The IO directives: Transcode::compile_input (transcode.cpp:500-557, explicit layout 683-733), compile_template
+// (1419-1445) and compile_output (1261-1417) as far as FASTQ / SAM text feeds go.  Input paths go under `base input
+// url`; a job without a template routes every input segment to the output verbatim; `output` and `filter outgoing qc
+// fail` project from the root through the multiplexing decoder onto each of its barcodes (projections
+// "multiplex:decoder" / "multiplex:barcode", configuration.json:453-463), output paths go under `base output url`, a
+// single output path is repeated for every output segment.
+std::string string_member(const Json& value, const char* key) {
+    const Json* found = value.find(key);
+    return found != nullptr && found->is_string() ? found->as_string() : std::string();
+}
+
+void relocate_array(Json& array, const std::string& base) {
+    if(!array.is_array()) { throw ConfigurationError("URL array element must be an array"); }
+    for(auto& element : array.elements()) {
+        if(element.is_null()) { throw ConfigurationError("URL element is null"); }
+        if(!element.is_string()) { throw ConfigurationError("URL element must be a string"); }
+        Url url = Url::parse(element.as_string());
+        url.relocate_child(base);
+        element = Json::string(url.encoded());
+    }
+}
+
+Json* multiplexing_decoder_of(Json& job) {
+    for(const char* topic : TOPICS) {
+        Json* node = job.find(topic);
+        if(node == nullptr) { continue; }
+        auto is_marked = [](const Json& d) { const Json* m = d.find("multiplexing classifier"); return m != nullptr && m->is_bool() && m->as_bool(); };
+        if(node->is_object()) { if(is_marked(*node)) { return node; } }
+        else if(node->is_array()) { for(auto& element : node->elements()) { if(is_marked(element)) { return &element; } } }
+    }
+    return nullptr;
+}
+
+void compile_io(Json& job, int32_t input_segment_cardinality) {
+    if(Json* input = job.find("input")) {
+        if(!input->is_null()) { relocate_array(*input, string_member(job, "base input url")); }
+    }
+
+    // compile_template
+    if(job.find("template") == nullptr || job.find("template")->is_null()) { job.set("template", Json::object()); }
+    Json& pattern = *job.find("template");
+    if(!pattern.is_object()) { throw ConfigurationError("template element must be a dictionary"); }
+    if(pattern.find("transform") == nullptr || pattern.find("transform")->is_null()) { pattern.set("transform", Json::object()); }
+    Json& transform = *pattern.find("transform");
+    if(!transform.is_object()) { throw ConfigurationError("template transform element must be a dictionary"); }
+    if(transform.find("token") == nullptr) {
+        if(input_segment_cardinality < 0) { return; }            // nothing states the input layout: classification only
+        Json token = Json::array();
+        for(int32_t i = 0; i < input_segment_cardinality; ++i) { token.push(Json::string(std::to_string(i) + "::")); }
+        transform.set("token", token);
+    }
+    const Json& token = *transform.find("token");
+    if(!token.is_array()) { throw ConfigurationError("transform token element is not an array"); }
+    const Json* knit = transform.find("knit");
+    if(knit == nullptr || knit->is_null() || (knit->is_array() && knit->elements().empty())) {
+        Json observation = Json::array();
+        for(size_t i = 0; i < token.elements().size(); ++i) { observation.push(Json::string(std::to_string(i))); }
+        transform.set("knit", observation);
+    }
+    const int32_t output_segment_cardinality = static_cast<int32_t>(transform.find("knit")->elements().size());
+    job.set("output segment cardinality", Json::integer(output_segment_cardinality));
+
+    // compile_output; a job that names no output writes SAM to the standard output (configuration.json:13-15)
+    if(job.find("output") == nullptr || job.find("output")->is_null()) {
+        Json standard = Json::array();
+        standard.push(Json::string("/dev/stdout"));
+        job.set("output", standard);
+    }
+    Json* decoder = multiplexing_decoder_of(job);
+    if(decoder == nullptr) { return; }
+    auto inherit = [](Json& to, const Json& from, const char* key) {
+        const Json* own = to.find(key);
+        if(own != nullptr && !own->is_null()) { return; }
+        const Json* parent = from.find(key);
+        if(parent != nullptr && !parent->is_null()) { to.set(key, *parent); }
+    };
+    for(const char* key : {"base output url", "filter outgoing qc fail", "enable quality control", "output"}) { inherit(*decoder, job, key); }
+    const std::string base = string_member(*decoder, "base output url");
+    std::vector<Json*> channel;
+    if(Json* undetermined = decoder->find("undetermined")) { if(undetermined->is_object()) { channel.push_back(undetermined); } }
+    if(Json* codec = decoder->find("codec")) {
+        if(codec->is_object()) { for(auto& member : codec->members()) { if(member.second.is_object()) { channel.push_back(&member.second); } } }
+    }
+    for(Json* record : channel) {
+        for(const char* key : {"filter outgoing qc fail", "enable quality control", "output"}) { inherit(*record, *decoder, key); }
+        record->set("TC", Json::integer(output_segment_cardinality));
+        Json* output = record->find("output");
+        if(output == nullptr || output->is_null()) { continue; }
+        relocate_array(*output, base);
+        for(const auto& element : output->elements()) {
+            const Url url = Url::parse(element.as_string());
+            if(url.is_stdin()) { throw ConfigurationError("output stream can not be set to standard input"); }
+            if(url.is_stderr()) { throw ConfigurationError("output stream can not be set to standard error"); }
+        }
+        // pad_url_array_by_key, transcode.cpp:1446-1460
+        const size_t stated = output->elements().size();
+        if(stated > 0 && static_cast<int32_t>(stated) != output_segment_cardinality) {
+            if(stated != 1) { throw ConfigurationError("incorrect number of output URLs in channel"); }
+            const Json first = output->elements().front();
+            while(static_cast<int32_t>(output->elements().size()) < output_segment_cardinality) { output->push(first); }
+        }
+    }
+}
+
 }  // namespace
 
 bool is_compiled_job(const Json& document) {
@@ -518,6 +623,7 @@ Json compile_job(const Json& document) {
     }
     set_default(job, "filter incoming qc fail", Json::boolean(false));
     set_default(job, "leading segment index", Json::integer(0));
+    compile_io(job, input_segment_cardinality);
     return job;
 }
 

@@ -79,6 +79,18 @@ bool get_bool(const Json& node, const char* key, bool fallback) {
     if(!v->is_bool()) { throw ConfigurationError(std::string(key) + " element must be a boolean"); }
     return v->as_bool();
 }
+std::vector<std::string> get_string_array(const Json& node, const char* key) {
+    std::vector<std::string> out;
+    const Json* found = node.find(key);
+    if(found == nullptr || found->is_null()) { return out; }
+    if(!found->is_array()) { throw ConfigurationError(std::string(key) + " element must be an array"); }
+    for(const auto& e : found->elements()) {
+        if(!e.is_string()) { throw ConfigurationError(std::string(key) + " element must be an array of strings"); }
+        out.push_back(e.as_string());
+    }
+    return out;
+}
+
 std::vector<int32_t> get_int_array(const Json& node, const char* key) {
     std::vector<int32_t> out;
     const Json* v = node.find(key);
@@ -193,6 +205,12 @@ BarcodeConfig parse_barcode(const std::string& key, const Json& node, int32_t se
     barcode.concentration = get_double(node, "concentration", 0);
     const Json* id = node.find("ID");
     if(id != nullptr && id->is_string()) { barcode.id = id->as_string(); }
+    for(const char* tag : {"ID", "BC", "CN", "DS", "DT", "FO", "KS", "LB", "PG", "PI", "PL", "PM", "PU", "SM"}) {
+        const Json* field = node.find(tag);
+        if(field != nullptr && field->is_string() && !field->as_string().empty()) { barcode.read_group.emplace_back(tag, field->as_string()); }
+    }
+    barcode.output = get_string_array(node, "output");
+    barcode.filter_outgoing_qc_fail = get_bool(node, "filter outgoing qc fail", false);
     const Json* segments = node.find("barcode");
     if(segments != nullptr && !segments->is_null()) {
         if(!segments->is_array() || static_cast<int32_t>(segments->elements().size()) != segment_cardinality) {
@@ -347,13 +365,19 @@ JobConfig JobConfig::from_json(const Json& document) {
         }
     }
 
+    job.input = get_string_array(document, "input");
+    job.output = get_string_array(document, "output");
+    job.platform = "ILLUMINA";
+    if(const Json* platform = document.find("platform")) { if(platform->is_string()) { job.platform = platform->as_string(); } }
+    job.multiplexing_decoder = -1;
+
     int32_t multiplexing = 0;
     int32_t column = 0;
     int32_t nucleotides = 0;
     int32_t slot = 0;
     int64_t word = STAT_JOB_WORDS;
     for(auto& d : job.decoder) {
-        if(d.multiplexing_classifier) { ++multiplexing; }
+        if(d.multiplexing_classifier) { ++multiplexing; job.multiplexing_decoder = static_cast<int32_t>(&d - job.decoder.data()); }
         d.plane_stride = (d.nucleotide_cardinality + 3) / 4 * 4;
         d.plane_prefix = column;
         column += d.plane_stride;

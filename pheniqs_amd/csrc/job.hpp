@@ -48,6 +48,9 @@ struct BarcodeConfig {
     double concentration;
     std::vector<std::string> segment;     // IUPAC text per segment
     std::string id;
+    std::vector<std::pair<std::string, std::string>> read_group;   // the @RG fields of the record in HeadRGAtom::encode order (atom.cpp:906-965)
+    std::vector<std::string> output;      // one URL per output segment when this barcode is a channel of the multiplexer
+    bool filter_outgoing_qc_fail;
 };
 
 struct DecoderConfig {
@@ -96,6 +99,10 @@ struct JobConfig {
     int32_t nucleotide_width;             // sum of nucleotide cardinality over all decoders
     int32_t result_count;                 // number of PAMLD / MDD decoders
     int64_t stats_words;                  // u64 words in the counter buffer
+    std::vector<std::string> input;        // one URL per input segment; a URL stated k times is one interleaved feed (transcode.cpp:693-701)
+    std::vector<std::string> output;       // root level fallback for a job without a multiplexing decoder
+    std::string platform;                  // "ILLUMINA" by default (configuration.json:375): decides the FASTQ comment (fastq.h:176-194)
+    int32_t multiplexing_decoder;          // position in `decoder`, -1 when none is marked
 
     static JobConfig from_json(const Json& document);
 };

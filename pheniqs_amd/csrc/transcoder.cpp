@@ -1,15 +1,20 @@
-// Transcoder: the steps either side of the classification path for FASTQ in / SAM text out
+// Transcoder: the steps either side of the classification path for FASTQ in / FASTQ or SAM text out
 // (SURVEY.md §8f rows f1 and f2), host side C++.
 //
 //   f1  FASTQ -> batch      FastqRecord::decode (fastq.h:55-78: ASCII -> BAM code, quality - phred offset),
 //                           Illumina comment filter flag (fastq.h:253-285), Read::validate name sync
-//                           (read.h:253-264); one reader thread per input file; then DecoderSet::stage_reads.
+//                           (read.h:253-264); one reader thread per input feed, a path stated k times in `input`
+//                           being one interleaved feed of resolution k (transcode.cpp:693-701); then
+//                           DecoderSet::stage_reads.
 //   f2  results -> records  the per type accumulators and barcode strings the decoder wrappers leave on the
 //                           output Read (pamld.cpp:133-180, mdd.cpp:96-138, naive.h:40-45, read.h:269-348),
 //                           TemplateRule::apply (transform.h:190-226), Read::flush (read.h:187-237),
-//                           Auxiliary::encode tag order (auxiliary.cpp:327-354), SAM text as htslib prints it.
+//                           Auxiliary::encode tag order (auxiliary.cpp:327-354), SAM text as htslib prints it,
+//                           FASTQ records (fastq.h:144-194), @HD / @RG / @PG header lines (atom.cpp:454-472,906-965),
+//                           Multiplexer::push: the channel of the multiplexing decoder's barcode decides the
+//                           output feeds (multiplex.h:198-240), optionally without QC failed reads.
 //
-// Out of scope here: BAM/CRAM, SAM header atoms (@HD/@RG/@PG), split outputs per channel, QC histograms.
+// Out of scope here: BAM/CRAM (htslib), bz2 / xz, QC histograms.
 #include "transcoder.hpp"
 
 #include <zlib.h>
@@ -252,53 +257,236 @@ void put_float(std::string& out, float value) {
     out += scratch;
 }
 
+// one input segment of the batch: record i of the segment is record i * stride + slot of its feed's batch
+struct SegmentView {
+    const SegmentBatch* feed = nullptr;
+    int32_t stride = 1;
+    int32_t slot = 0;
+    std::vector<int64_t> offset_copy;       // contiguous copies for stage_reads, interleaved feeds only
+    std::vector<int32_t> length_copy;
+    std::vector<uint8_t> qcfail_copy;
+    int64_t size() const { return feed->size() / stride; }
+    size_t at(int64_t i) const { return static_cast<size_t>(i) * static_cast<size_t>(stride) + static_cast<size_t>(slot); }
+    void bind(const SegmentBatch& batch, int32_t resolution, int32_t position) {
+        feed = &batch; stride = resolution; slot = position;
+        offset_copy.clear(); length_copy.clear(); qcfail_copy.clear();
+        if(stride > 1) {
+            const int64_t n = size();
+            offset_copy.resize(static_cast<size_t>(n)); length_copy.resize(static_cast<size_t>(n)); qcfail_copy.resize(static_cast<size_t>(n));
+            for(int64_t i = 0; i < n; ++i) {
+                offset_copy[static_cast<size_t>(i)] = batch.offset[at(i)];
+                length_copy[static_cast<size_t>(i)] = batch.length[at(i)];
+                qcfail_copy[static_cast<size_t>(i)] = batch.qcfail[at(i)];
+            }
+        }
+    }
+    const int64_t* offsets() const { return stride > 1 ? offset_copy.data() : feed->offset.data(); }
+    const int32_t* lengths() const { return stride > 1 ? length_copy.data() : feed->length.data(); }
+    const uint8_t* qcfails() const { return stride > 1 ? qcfail_copy.data() : feed->qcfail.data(); }
+    const char* name(int64_t i) const { return feed->name.data() + feed->name_offset[at(i)]; }
+    size_t name_size(int64_t i) const { return static_cast<size_t>(feed->name_offset[at(i) + 1] - feed->name_offset[at(i)]); }
+};
+
+// one gzip member per call: members concatenate into a valid gzip stream, so the parts of a batch compress in parallel
+void gzip_member(const std::string& text, int level, std::string& out) {
+    z_stream stream;
+    std::memset(&stream, 0, sizeof(stream));
+    if(deflateInit2(&stream, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { throw InternalError("deflateInit2 failed"); }
+    out.resize(deflateBound(&stream, static_cast<uLong>(text.size())) + 32);
+    stream.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text.data()));
+    stream.avail_in = static_cast<uInt>(text.size());
+    stream.next_out = reinterpret_cast<Bytef*>(&out[0]);
+    stream.avail_out = static_cast<uInt>(out.size());
+    const int status = deflate(&stream, Z_FINISH);
+    const size_t produced = out.size() - stream.avail_out;
+    deflateEnd(&stream);
+    if(status != Z_STREAM_END) { throw InternalError("deflate failed"); }
+    out.resize(produced);
+}
+
+struct OutputSink {
+    TranscodePlan::OutputFeed feed;
+    std::FILE* file = nullptr;
+    bool owns = false;
+    bool wrote = false;
+    void open() {
+        if(feed.path == "-" || feed.path == "/dev/stdout") { file = stdout; }
+        else {
+            file = std::fopen(feed.path.c_str(), "wb");
+            owns = true;
+            if(file == nullptr) { throw IOError("could not open " + feed.path + " for writing"); }
+        }
+    }
+    void write(const std::string& bytes) {
+        if(!bytes.empty() && std::fwrite(bytes.data(), 1, bytes.size(), file) != bytes.size()) { throw IOError("error writing " + feed.path); }
+        wrote = wrote || !bytes.empty();
+    }
+    void close() {
+        if(file != nullptr) {
+            if(feed.gzip && !wrote) {                        // an empty channel is still a valid gzip file
+                std::string member;
+                try { gzip_member(std::string(), feed.level, member); std::fwrite(member.data(), 1, member.size(), file); } catch(...) {}
+            }
+            std::fflush(file);
+            if(owns) { std::fclose(file); }
+            file = nullptr;
+        }
+    }
+};
+
+FileFormat output_format_of(const Url& url, const std::string& path) {
+    switch(url.format) {
+        case FileFormat::FASTQ: case FileFormat::SAM: return url.format;
+        case FileFormat::UNKNOWN: case FileFormat::NONE: return FileFormat::SAM;                  // "default output format": "sam" (configuration.json:7)
+        case FileFormat::BAM: case FileFormat::CRAM: throw ConfigurationError("BAM and CRAM output need htslib: " + path);
+        default: throw ConfigurationError("unknown output format " + path);                      // transcode.cpp:1752
+    }
+}
+
 }  // namespace
+
+TranscodePlan TranscodePlan::from_job(const JobConfig& job) {
+    TranscodePlan plan;
+    plan.sam_header = true;
+    // compile_explicit_input: unique URLs in order of first appearance, resolution = times stated
+    if(job.input.empty()) { throw ConfigurationError("the job states no input"); }
+    for(const auto& encoded : job.input) {
+        const Url url = Url::parse(encoded);
+        if(url.format != FileFormat::UNKNOWN && url.format != FileFormat::FASTQ) {
+            throw ConfigurationError("only FASTQ input is supported (SAM, BAM and CRAM need htslib): " + url.path);
+        }
+        int32_t feed = -1;
+        for(size_t f = 0; f < plan.input_feed.size(); ++f) { if(plan.input_feed[f].path == url.path) { feed = static_cast<int32_t>(f); } }
+        if(feed < 0) {
+            feed = static_cast<int32_t>(plan.input_feed.size());
+            plan.input_feed.push_back({url.path, 0});
+        }
+        plan.input_segment.emplace_back(feed, plan.input_feed[static_cast<size_t>(feed)].resolution++);
+    }
+
+    // compile_output: the channels of the multiplexing decoder, or one channel for everything
+    std::vector<const BarcodeConfig*> record;
+    if(job.multiplexing_decoder >= 0) {
+        const DecoderConfig& d = job.decoder[static_cast<size_t>(job.multiplexing_decoder)];
+        record.push_back(&d.undetermined);
+        for(const auto& b : d.codec) { record.push_back(&b); }
+    }
+    bool any = !job.output.empty();
+    for(const auto* r : record) { any = any || !r->output.empty(); }
+    const std::vector<std::string> fallback = any ? job.output : std::vector<std::string>{"/dev/stdout"};     // configuration.json:13-15
+    const int32_t n_out = job.output_segment_cardinality;
+    auto add_channel = [&](const std::vector<std::string>& stated, bool filter) {
+        Channel channel;
+        channel.filter_outgoing_qc_fail = filter;
+        std::vector<std::string> output = stated;
+        if(output.size() == 1) { output.resize(static_cast<size_t>(n_out), output.front()); }               // pad_url_array_by_key
+        if(!output.empty() && static_cast<int32_t>(output.size()) != n_out) { throw ConfigurationError("incorrect number of output URLs in channel"); }
+        std::vector<int32_t> stated_in_channel(plan.output_feed.size(), 0);
+        for(const auto& encoded : output) {
+            const Url url = Url::parse(encoded);
+            if(url.is_stdin()) { throw ConfigurationError("output stream can not be set to standard input"); }
+            if(url.is_stderr()) { throw ConfigurationError("output stream can not be set to standard error"); }
+            int32_t feed = -1;
+            for(size_t f = 0; f < plan.output_feed.size(); ++f) { if(plan.output_feed[f].path == url.path) { feed = static_cast<int32_t>(f); } }
+            if(feed < 0) {
+                feed = static_cast<int32_t>(plan.output_feed.size());
+                const FileCompression compression = url.compression();
+                if(compression == FileCompression::BZ2 || compression == FileCompression::XZ) { throw ConfigurationError("bz2 and xz output are not supported: " + url.path); }
+                const bool gzip = compression == FileCompression::GZIP || compression == FileCompression::BGZF;
+                plan.output_feed.push_back({url.path, output_format_of(url, url.path), gzip, url.compression_level >= 0 ? url.compression_level : 5, 0});
+                stated_in_channel.push_back(0);
+            }
+            ++stated_in_channel[static_cast<size_t>(feed)];
+            channel.feed_by_segment.push_back(feed);
+        }
+        for(size_t f = 0; f < stated_in_channel.size(); ++f) {                                               // transcode.cpp:1383-1393
+            if(stated_in_channel[f] == 0) { continue; }
+            int32_t& resolution = plan.output_feed[f].resolution;
+            if(resolution == 0) { resolution = stated_in_channel[f]; }
+            else if(resolution != stated_in_channel[f]) { throw ConfigurationError("inconsistent resolution for " + plan.output_feed[f].path); }
+        }
+        plan.channel.push_back(channel);
+    };
+    if(record.empty()) { add_channel(fallback, false); }
+    for(const auto* r : record) { add_channel(r->output.empty() ? fallback : r->output, r->filter_outgoing_qc_fail); }
+    return plan;
+}
+
+TranscodePlan TranscodePlan::explicit_files(const JobConfig& job, const std::vector<std::string>& input, const std::string& sam_output) {
+    TranscodePlan plan;
+    plan.sam_header = true;
+    for(size_t s = 0; s < input.size(); ++s) {
+        plan.input_feed.push_back({input[s], 1});
+        plan.input_segment.emplace_back(static_cast<int32_t>(s), 0);
+    }
+    plan.output_feed.push_back({sam_output, FileFormat::SAM, false, 5, job.output_segment_cardinality});
+    size_t channels = 1;
+    if(job.multiplexing_decoder >= 0) { channels += job.decoder[static_cast<size_t>(job.multiplexing_decoder)].codec.size(); }
+    Channel channel;
+    channel.filter_outgoing_qc_fail = false;
+    channel.feed_by_segment.assign(static_cast<size_t>(job.output_segment_cardinality), 0);
+    plan.channel.assign(channels, channel);
+    return plan;
+}
 
 struct Transcoder::Impl {
     DecoderSet& set;
+    TranscodePlan plan;
     std::vector<std::unique_ptr<FastqStream>> stream;
-    std::FILE* output;
-    bool owns_output;
+    std::vector<OutputSink> sink;
     int64_t capacity;
-    std::vector<SegmentBatch> batch;
+    std::vector<SegmentBatch> batch;              // per input feed
     uint8_t* base;
     uint8_t* quality;
     uint8_t* flag;
     DevResult* result;
     uint32_t* word;
     std::vector<int64_t> kept;
-    std::string text;
 
-    Impl(DecoderSet& set) : set(set), output(nullptr), owns_output(false), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
+    Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
         host_free(base); host_free(quality); host_free(flag); host_free(result); host_free(word);
-        if(output && owns_output) { std::fclose(output); }
+        for(auto& s : sink) { s.close(); }
     }
 };
 
-Transcoder::Transcoder(DecoderSet& set, const std::vector<std::string>& input, const std::string& sam_output, int64_t batch_capacity) :
-    impl_(new Impl(set)) {
-    const JobConfig& job = set.job();
-    if(job.input_segment_cardinality > 0 && static_cast<int32_t>(input.size()) != job.input_segment_cardinality) {
-        throw ConfigurationError("expected " + std::to_string(job.input_segment_cardinality) + " input files");
+Transcoder::Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch_capacity) :
+    impl_(new Impl(set, plan)) {
+    try {
+        const JobConfig& job = set.job();
+        if(job.input_segment_cardinality > 0 && static_cast<int32_t>(plan.input_segment.size()) != job.input_segment_cardinality) {
+            throw ConfigurationError("expected " + std::to_string(job.input_segment_cardinality) + " input files");
+        }
+        if(job.template_transform.empty()) { throw ConfigurationError("the job has no template transform"); }
+        for(const auto& t : job.template_transform) {
+            if(t.input_segment_index >= static_cast<int32_t>(plan.input_segment.size())) {
+                throw ConfigurationError("invalid input feed reference " + std::to_string(t.input_segment_index) + " in token");     // transcode.cpp:1284-1288
+            }
+        }
+        for(const auto& channel : plan.channel) {
+            if(!channel.feed_by_segment.empty() && static_cast<int32_t>(channel.feed_by_segment.size()) != job.output_segment_cardinality) {
+                throw ConfigurationError("incorrect number of output URLs in channel");
+            }
+        }
+        for(const auto& feed : plan.input_feed) { impl_->stream.emplace_back(new FastqStream(feed.path)); }
+        for(const auto& feed : plan.output_feed) {
+            impl_->sink.emplace_back();
+            impl_->sink.back().feed = feed;
+            impl_->sink.back().open();
+        }
+        impl_->capacity = batch_capacity;
+        impl_->batch.resize(plan.input_feed.size());
+        const size_t planes = static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.plane_width, 4));
+        impl_->base = static_cast<uint8_t*>(host_alloc(planes));
+        impl_->quality = static_cast<uint8_t*>(host_alloc(planes));
+        impl_->flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(batch_capacity)));
+        impl_->result = static_cast<DevResult*>(host_alloc(static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)));
+        impl_->word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(batch_capacity) * sizeof(uint32_t)));
+        impl_->kept.resize(static_cast<size_t>(batch_capacity));
+    } catch(...) {
+        delete impl_;
+        throw;
     }
-    if(job.template_transform.empty()) { throw ConfigurationError("the job has no template transform"); }
-    for(const auto& path : input) { impl_->stream.emplace_back(new FastqStream(path)); }
-    if(sam_output == "-" || sam_output == "/dev/stdout") { impl_->output = stdout; }
-    else {
-        impl_->output = std::fopen(sam_output.c_str(), "wb");
-        impl_->owns_output = true;
-        if(impl_->output == nullptr) { throw IOError("could not open " + sam_output + " for writing"); }
-    }
-    impl_->capacity = batch_capacity;
-    impl_->batch.resize(input.size());
-    const size_t planes = static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.plane_width, 4));
-    impl_->base = static_cast<uint8_t*>(host_alloc(planes));
-    impl_->quality = static_cast<uint8_t*>(host_alloc(planes));
-    impl_->flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(batch_capacity)));
-    impl_->result = static_cast<DevResult*>(host_alloc(static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)));
-    impl_->word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(batch_capacity) * sizeof(uint32_t)));
-    impl_->kept.resize(static_cast<size_t>(batch_capacity));
 }
 
 Transcoder::~Transcoder() { delete impl_; }
@@ -306,15 +494,37 @@ Transcoder::~Transcoder() { delete impl_; }
 void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     Impl& m = *impl_;
     const JobConfig& job = m.set.job();
-    const int32_t n_segment = static_cast<int32_t>(m.stream.size());
+    const TranscodePlan& plan = m.plan;
+    const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
+    const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
+    const int32_t n_sink = static_cast<int32_t>(m.sink.size());
     const int32_t leader = job.leading_segment_index;
+    const bool illumina_comment = job.platform == "ILLUMINA" || job.platform == "ELEMENT";       // fastq.h:176-194
 
     // the read group of every sample barcode: decode_tag_id_by_index (classifier.cpp:79-98)
     std::vector<std::string> rg_by_index;
+    std::string header = "@HD\tVN:1.0\tSO:unknown\tGO:query\n";                                  // atom.cpp:454-472, the values of transcode.cpp:1661-1667
     for(const auto& d : job.decoder) {
         if(d.kind == Kind::SAMPLE) {
             rg_by_index.push_back(d.undetermined.id);
             for(const auto& b : d.codec) { rg_by_index.push_back(b.id); }
+            // load_output (transcode.cpp:1679-1700): every read group of the sample decoder on every output
+            auto put_read_group = [&](const BarcodeConfig& b) {
+                if(b.id.empty()) { return; }
+                header += "@RG";
+                for(const auto& field : b.read_group) { header += "\t" + field.first + ":" + field.second; }
+                header += "\n";
+            };
+            put_read_group(d.undetermined);
+            for(const auto& b : d.codec) { put_read_group(b); }
+        }
+    }
+    header += "@PG\tID:pheniqs_amd\tPN:pheniqs_amd\tVN:1\n";
+    if(plan.sam_header) {
+        for(auto& sink : m.sink) {
+            if(sink.feed.format != FileFormat::SAM) { continue; }
+            if(sink.feed.gzip) { std::string member; gzip_member(header, sink.feed.level, member); sink.write(member); }
+            else { sink.write(header); }
         }
     }
 
@@ -330,15 +540,16 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
 
-    // f1: one reader thread per input file (the reference has one producer thread per feed, feed.h:309-314); the
+    // f1: one reader thread per input feed (the reference has one producer thread per feed, feed.h:309-314); the
     // next batch is read while this one is staged, classified and written
     std::vector<SegmentBatch> ahead(m.batch.size());
-    // decoding threads per file: the files are read concurrently and the previous batch is being formatted meanwhile
-    const int32_t parse_threads = std::max(1, host_threads() / (2 * std::max(1, n_segment)));
+    // decoding threads per feed: the feeds are read concurrently and the previous batch is being formatted meanwhile
+    const int32_t parse_threads = std::max(1, host_threads() / (2 * std::max(1, n_feed)));
     auto start_readers = [&](std::vector<SegmentBatch>& into) {
         std::vector<std::thread> readers;
-        for(int32_t s = 0; s < n_segment; ++s) {
-            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(s)]), m.capacity, job.input_phred_offset, parse_threads, std::ref(into[static_cast<size_t>(s)]));
+        for(int32_t f = 0; f < n_feed; ++f) {
+            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(f)]), m.capacity * plan.input_feed[static_cast<size_t>(f)].resolution,
+                                 job.input_phred_offset, parse_threads, std::ref(into[static_cast<size_t>(f)]));
         }
         return readers;
     };
@@ -347,7 +558,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& t : readers) { t.join(); }
     }
     const int workers = host_threads();
-    std::vector<std::string> part_text(static_cast<size_t>(workers));
+    std::vector<std::string> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
+    std::vector<std::string> part_packed(part_text.size());
+    std::vector<SegmentView> view(static_cast<size_t>(n_segment));
     // PHQ_TRANSCODE_TRACE=1: wall time per phase on stderr at the end of the run
     const bool trace = std::getenv("PHQ_TRANSCODE_TRACE") != nullptr;
     double phase[6] = {0, 0, 0, 0, 0, 0};      // validate, stage, classify, format, write, wait for the readers
@@ -356,9 +569,18 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     auto lap = [&](int k) { const double t = now(); phase[k] += t - mark; mark = t; };
     while(true) {
         for(const auto& b : m.batch) { if(!b.error.empty()) { throw SequenceError(b.error); } }
-        const int64_t n_read = m.batch[0].size();
-        for(const auto& b : m.batch) {
-            if(b.size() != n_read) { throw SequenceError("input files hold different numbers of records"); }
+        for(int32_t f = 0; f < n_feed; ++f) {
+            if(m.batch[static_cast<size_t>(f)].size() % plan.input_feed[static_cast<size_t>(f)].resolution != 0) {
+                throw SequenceError("interleaved input " + plan.input_feed[static_cast<size_t>(f)].path + " ends inside a read");
+            }
+        }
+        for(int32_t s = 0; s < n_segment; ++s) {
+            const auto& where = plan.input_segment[static_cast<size_t>(s)];
+            view[static_cast<size_t>(s)].bind(m.batch[static_cast<size_t>(where.first)], plan.input_feed[static_cast<size_t>(where.first)].resolution, where.second);
+        }
+        const int64_t n_read = view[0].size();
+        for(const auto& v : view) {
+            if(v.size() != n_read) { throw SequenceError("input files hold different numbers of records"); }
         }
         if(n_read == 0) { break; }
         const bool last_batch = n_read < m.capacity;
@@ -367,14 +589,13 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         if(!last_batch) { readers = start_readers(ahead); }
         // Read::validate (read.h:253-264): every segment of a read carries the same identifier
         for(int32_t s = 1; s < n_segment; ++s) {
-            const SegmentBatch& a = m.batch[0];
-            const SegmentBatch& b = m.batch[static_cast<size_t>(s)];
+            const SegmentView& a = view[0];
+            const SegmentView& b = view[static_cast<size_t>(s)];
             for(int64_t i = 0; i < n_read; ++i) {
-                const int64_t la = a.name_offset[static_cast<size_t>(i) + 1] - a.name_offset[static_cast<size_t>(i)];
-                const int64_t lb = b.name_offset[static_cast<size_t>(i) + 1] - b.name_offset[static_cast<size_t>(i)];
-                if(la != lb || std::memcmp(a.name.data() + a.name_offset[static_cast<size_t>(i)], b.name.data() + b.name_offset[static_cast<size_t>(i)], static_cast<size_t>(la)) != 0) {
-                    throw SequenceError("read out of sync " + std::string(b.name.data() + b.name_offset[static_cast<size_t>(i)], static_cast<size_t>(lb)) + " and " +
-                                        std::string(a.name.data() + a.name_offset[static_cast<size_t>(i)], static_cast<size_t>(la)));
+                const size_t la = a.name_size(i);
+                const size_t lb = b.name_size(i);
+                if(la != lb || std::memcmp(a.name(i), b.name(i), la) != 0) {
+                    throw SequenceError("read out of sync " + std::string(b.name(i), lb) + " and " + std::string(a.name(i), la));
                 }
             }
         }
@@ -382,15 +603,15 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         std::vector<const int64_t*> offset(static_cast<size_t>(n_segment));
         std::vector<const int32_t*> length(static_cast<size_t>(n_segment));
         for(int32_t s = 0; s < n_segment; ++s) {
-            code[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].code.data();
-            quality[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].quality.data();
-            offset[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].offset.data();
-            length[static_cast<size_t>(s)] = m.batch[static_cast<size_t>(s)].length.data();
+            code[static_cast<size_t>(s)] = view[static_cast<size_t>(s)].feed->code.data();
+            quality[static_cast<size_t>(s)] = view[static_cast<size_t>(s)].feed->quality.data();
+            offset[static_cast<size_t>(s)] = view[static_cast<size_t>(s)].offsets();
+            length[static_cast<size_t>(s)] = view[static_cast<size_t>(s)].lengths();
         }
         lap(0);
         int64_t n_kept = 0;
         m.set.stage_reads(n_read, n_segment, code.data(), quality.data(), offset.data(), length.data(),
-                          m.batch[static_cast<size_t>(leader)].qcfail.data(), m.capacity, m.base, m.quality, m.flag, m.kept.data(), &n_kept,
+                          view[static_cast<size_t>(leader)].qcfails(), m.capacity, m.base, m.quality, m.flag, m.kept.data(), &n_kept,
                           &incoming_count, &incoming_pf_count);
         lap(1);
         m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word);
@@ -398,10 +619,12 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
 
         // f2: records, a contiguous range of the batch per thread, written in order
         for(auto& text : part_text) { text.clear(); }
+        for(auto& text : part_packed) { text.clear(); }
         parallel_ranges(n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
-        std::string& text = part_text[static_cast<size_t>(part)];
-        text.reserve(static_cast<size_t>(last_kept - first_kept) * 256);
+        std::string* const text_of_sink = &part_text[static_cast<size_t>(part) * static_cast<size_t>(n_sink)];
+        if(n_sink == 1) { text_of_sink[0].reserve(static_cast<size_t>(last_kept - first_kept) * 256); }
         Text raw[3], corrected[3], out_segment[8];
+        std::string tags;
         for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
             uint32_t distance[3] = {0, 0, 0};
@@ -409,6 +632,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             for(auto& t : raw) { t.clear(); }
             for(auto& t : corrected) { t.clear(); }
             const std::string* rg = nullptr;
+            size_t channel_index = 0;                                        // classifier.h:83-85
             for(const auto& d : job.decoder) {
                 const int kind = static_cast<int>(d.kind);
                 if(d.plane_stride == 0) { continue; }
@@ -421,6 +645,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     const auto& by_index = ordinal_by_index[static_cast<size_t>(&d - job.decoder.data())];
                     if(static_cast<size_t>(res->index) < by_index.size()) { ordinal = by_index[static_cast<size_t>(res->index)]; }
                 }
+                if(d.multiplexing_classifier) { channel_index = static_cast<size_t>(ordinal + 1); }
                 for(int32_t s = 0; s < d.segment_cardinality; ++s) {
                     const int32_t so = d.segment_offset[static_cast<size_t>(s)];
                     int32_t len = d.barcode_length[static_cast<size_t>(s)];
@@ -456,6 +681,13 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 }
                 if(d.kind == Kind::SAMPLE) { rg = &rg_by_index[static_cast<size_t>(ordinal + 1)]; }
             }
+            (void)distance;
+
+            // Multiplexer::push -> Channel::push (multiplex.h:198-240)
+            const bool qcfail = (m.word[k] >> 31) != 0;
+            if(channel_index >= plan.channel.size()) { channel_index = 0; }
+            const TranscodePlan::Channel& channel = plan.channel[channel_index];
+            if(channel.feed_by_segment.empty() || (channel.filter_outgoing_qc_fail && qcfail)) { continue; }
 
             // TemplateRule::apply (transform.h:190-226)
             const int32_t n_out = job.output_segment_cardinality;
@@ -466,8 +698,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     const Text& from = corrected[t.input_segment_index == -1 ? 0 : t.input_segment_index == -2 ? 2 : 1];
                     fc = from.code.data(); fq = from.quality.data(); flen = static_cast<int32_t>(from.code.size());
                 } else {
-                    const SegmentBatch& b = m.batch[static_cast<size_t>(t.input_segment_index)];
-                    fc = b.code.data() + b.offset[static_cast<size_t>(r)]; fq = b.quality.data() + b.offset[static_cast<size_t>(r)]; flen = b.length[static_cast<size_t>(r)];
+                    const SegmentView& v = view[static_cast<size_t>(t.input_segment_index)];
+                    const size_t at = v.at(r);
+                    fc = v.feed->code.data() + v.feed->offset[at]; fq = v.feed->quality.data() + v.feed->offset[at]; flen = v.feed->length[at];
                 }
                 const int32_t start = t.absolute_start(flen);
                 const int32_t end = t.absolute_end(flen);
@@ -479,16 +712,45 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 }
             }
 
-            // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354) + SAM text
-            const bool qcfail = (m.word[k] >> 31) != 0;
-            const SegmentBatch& lead = m.batch[static_cast<size_t>(leader)];
+            // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
+            tags.clear();
+            if(rg != nullptr && !rg->empty()) { tags += "\tRG:Z:"; tags += *rg; }
+            if(!raw[0].empty()) { tags += "\tBC:Z:"; put_sequence(tags, raw[0].code); tags += "\tQT:Z:"; put_quality(tags, raw[0].quality, 33); }
+            if(confidence[0] > 0 && confidence[0] < 1) { tags += "\tXB:f:"; put_float(tags, static_cast<float>(1.0 - confidence[0])); }
+            if(!corrected[1].empty()) { tags += "\tRX:Z:"; put_sequence(tags, corrected[1].code); tags += "\tQX:Z:"; put_quality(tags, corrected[1].quality, 33); }
+            if(!raw[1].empty()) { tags += "\tOX:Z:"; put_sequence(tags, raw[1].code); tags += "\tBZ:Z:"; put_quality(tags, raw[1].quality, 33); }
+            if(confidence[1] > 0 && confidence[1] < 1) { tags += "\tXM:f:"; put_float(tags, static_cast<float>(1.0 - confidence[1])); }
+            if(!corrected[2].empty()) { tags += "\tCB:Z:"; put_sequence(tags, corrected[2].code); }
+            if(!raw[2].empty()) { tags += "\tCR:Z:"; put_sequence(tags, raw[2].code); tags += "\tCY:Z:"; put_quality(tags, raw[2].quality, 33); }
+            if(confidence[2] > 0 && confidence[2] < 1) { tags += "\tXC:f:"; put_float(tags, static_cast<float>(1.0 - confidence[2])); }
+
+            const SegmentView& lead = view[static_cast<size_t>(leader)];
             for(int32_t o = 0; o < n_out; ++o) {
+                const int32_t to_sink = channel.feed_by_segment[static_cast<size_t>(o)];
+                std::string& text = text_of_sink[to_sink];
+                if(m.sink[static_cast<size_t>(to_sink)].feed.format == FileFormat::FASTQ) {
+                    // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
+                    text += '@';
+                    text.append(lead.name(r), lead.name_size(r));
+                    text += ' ';
+                    if(illumina_comment) {
+                        text += std::to_string(o + 1);
+                        text += qcfail ? ":Y:0:" : ":N:0:";
+                        put_sequence(text, raw[0].code);
+                    }
+                    text += '\n';
+                    put_sequence(text, out_segment[o].code);
+                    text += "\n+\n";
+                    put_quality(text, out_segment[o].quality, job.output_phred_offset);
+                    text += '\n';
+                    continue;
+                }
                 int flag = 4 | 8;                                             // BAM_FUNMAP | BAM_FMUNMAP (read.h:134-135)
                 if(n_out > 1) { flag |= 1; }
                 if(o == 0) { flag |= 64; }
                 if(n_out > 1 && o == n_out - 1) { flag |= 128; }
                 if(qcfail) { flag |= 512; }
-                text.append(lead.name.data() + lead.name_offset[static_cast<size_t>(r)], static_cast<size_t>(lead.name_offset[static_cast<size_t>(r) + 1] - lead.name_offset[static_cast<size_t>(r)]));
+                text.append(lead.name(r), lead.name_size(r));
                 text += '\t'; text += std::to_string(flag); text += "\t*\t0\t0\t*\t*\t0\t0\t";
                 if(out_segment[o].empty()) { text += "*\t*"; }
                 else {
@@ -497,23 +759,22 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     put_quality(text, out_segment[o].quality, job.output_phred_offset);
                 }
                 if(n_out > 2) { text += "\tFI:i:" + std::to_string(o + 1) + "\tTC:i:" + std::to_string(n_out); }
-                if(rg != nullptr && !rg->empty()) { text += "\tRG:Z:"; text += *rg; }
-                if(!raw[0].empty()) { text += "\tBC:Z:"; put_sequence(text, raw[0].code); text += "\tQT:Z:"; put_quality(text, raw[0].quality, 33); }
-                if(confidence[0] > 0 && confidence[0] < 1) { text += "\tXB:f:"; put_float(text, static_cast<float>(1.0 - confidence[0])); }
-                if(!corrected[1].empty()) { text += "\tRX:Z:"; put_sequence(text, corrected[1].code); text += "\tQX:Z:"; put_quality(text, corrected[1].quality, 33); }
-                if(!raw[1].empty()) { text += "\tOX:Z:"; put_sequence(text, raw[1].code); text += "\tBZ:Z:"; put_quality(text, raw[1].quality, 33); }
-                if(confidence[1] > 0 && confidence[1] < 1) { text += "\tXM:f:"; put_float(text, static_cast<float>(1.0 - confidence[1])); }
-                if(!corrected[2].empty()) { text += "\tCB:Z:"; put_sequence(text, corrected[2].code); }
-                if(!raw[2].empty()) { text += "\tCR:Z:"; put_sequence(text, raw[2].code); text += "\tCY:Z:"; put_quality(text, raw[2].quality, 33); }
-                if(confidence[2] > 0 && confidence[2] < 1) { text += "\tXC:f:"; put_float(text, static_cast<float>(1.0 - confidence[2])); }
+                text += tags;
                 text += '\n';
             }
-            (void)distance;
+        }
+        for(int32_t f = 0; f < n_sink; ++f) {
+            if(m.sink[static_cast<size_t>(f)].feed.gzip && !text_of_sink[f].empty()) {
+                gzip_member(text_of_sink[f], m.sink[static_cast<size_t>(f)].feed.level, part_packed[static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f)]);
+            }
         }
         });
         lap(3);
-        for(const auto& text : part_text) {
-            if(!text.empty() && std::fwrite(text.data(), 1, text.size(), m.output) != text.size()) { throw IOError("error writing the SAM output"); }
+        for(int part = 0; part < workers; ++part) {
+            for(int32_t f = 0; f < n_sink; ++f) {
+                const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
+                m.sink[static_cast<size_t>(f)].write(m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at]);
+            }
         }
         lap(4);
         if(last_batch) { break; }
@@ -521,7 +782,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         lap(5);
         m.batch.swap(ahead);
     }
-    std::fflush(m.output);
+    for(auto& sink : m.sink) { sink.close(); }
     if(trace) {
         std::fprintf(stderr, "transcode phases (s): validate %.3f stage %.3f classify %.3f format %.3f write %.3f wait for readers %.3f\n",
                      phase[0], phase[1], phase[2], phase[3], phase[4], phase[5]);

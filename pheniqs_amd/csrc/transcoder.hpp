@@ -1,19 +1,46 @@
-// FASTQ in -> classification -> SAM text out, around one DecoderSet.
+// FASTQ in -> classification -> FASTQ / SAM text out, around one DecoderSet.
 #pragma once
 
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "decoder_set.hpp"
+#include "url.hpp"
 
 namespace phq {
 
+// What Transcode::compile_input / compile_output leave in `feed` and on the channels (transcode.cpp:683-733,1261-1417):
+// the input feeds with their resolution, the output feeds, and for every channel of the multiplexing decoder the
+// feed each output segment is pushed to (multiplex.h:198-240).
+struct TranscodePlan {
+    struct InputFeed { std::string path; int32_t resolution; };
+    struct OutputFeed {
+        std::string path;
+        FileFormat format;
+        bool gzip;
+        int32_t level;
+        int32_t resolution;                                    // output segments of one read pushed to this feed
+    };
+    struct Channel { std::vector<int32_t> feed_by_segment; bool filter_outgoing_qc_fail; };
+
+    std::vector<InputFeed> input_feed;
+    std::vector<std::pair<int32_t, int32_t>> input_segment;    // (feed, slot inside its resolution) per input segment
+    std::vector<OutputFeed> output_feed;
+    std::vector<Channel> channel;                              // 0 = undetermined, then the codec of the multiplexing decoder in order
+    bool sam_header;
+
+    // the job's own `input` and per channel `output` directives
+    static TranscodePlan from_job(const JobConfig& job);
+    // one FASTQ file per input segment, every channel into one SAM file ("-" = stdout)
+    static TranscodePlan explicit_files(const JobConfig& job, const std::vector<std::string>& input, const std::string& sam_output);
+};
+
 class Transcoder {
 public:
-    // one input path per input segment (plain or gzip FASTQ); sam_output "-" = stdout
-    Transcoder(DecoderSet& set, const std::vector<std::string>& input, const std::string& sam_output, int64_t batch_capacity);
+    Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch_capacity);
     ~Transcoder();
     Transcoder(const Transcoder&) = delete;
     Transcoder& operator=(const Transcoder&) = delete;

@@ -49,10 +49,59 @@ def test_reference_compile_of_bdggg_is_reproduced():
     assert ours["sample"]["multiplexing classifier"] is True
 
 
+def test_io_directives_of_the_reference_compile_are_reproduced():
+    """valid/compile_annotated.out: `input` under `base input url`, the template's default knit and the output segment
+    cardinality, and on every channel of the multiplexing decoder `TC` and one output URL per output segment
+    (transcode.cpp:500-557,1261-1417,1419-1460).  The reference appends the canonical query (?format=..): paths compared."""
+    reference = bdggg.compiled_reference_job()
+    ours = capi.compile_job(bdggg.raw_job())
+    path = lambda url: url.split("?")[0]
+    assert [path(u) for u in ours["input"]] == [path(u) for u in reference["input"]]
+    assert ours["template"] == reference["template"]
+    assert ours["output segment cardinality"] == reference["output segment cardinality"] == 2
+    records = [(reference["sample"]["undetermined"], ours["sample"]["undetermined"])]
+    records += [(reference["sample"]["codec"][key], ours["sample"]["codec"][key]) for key in reference["sample"]["codec"]]
+    for theirs, mine in records:
+        assert mine["TC"] == theirs["TC"] == 2
+        assert [path(u) for u in mine["output"]] == [path(u) for u in theirs["output"]] == ["/dev/stdout", "/dev/stdout"]
+    # relative outputs go under the base, a single URL is repeated per output segment, several must match the count
+    raw = bdggg.raw_job()
+    raw["output"] = ["all.sam"]
+    raw["sample"]["codec"]["@AGGCAGAA"]["output"] = ["a_1.fastq.gz", "/tmp/a_2.fastq.gz"]
+    ours = capi.compile_job(raw)
+    assert ours["sample"]["codec"]["@AGGCAGAA"]["output"] == ["test/BDGGG/a_1.fastq.gz", "/tmp/a_2.fastq.gz"]
+    assert ours["sample"]["codec"]["@CGTACTAG"]["output"] == ["test/BDGGG/all.sam"] * 2
+    assert ours["sample"]["undetermined"]["output"] == ["test/BDGGG/all.sam"] * 2
+    raw["sample"]["codec"]["@AGGCAGAA"]["output"] = ["a", "b", "c"]
+    with pytest.raises(PheniqsError) as caught:
+        capi.compile_job(raw)
+    assert "incorrect number of output URLs in channel" in str(caught.value)
+    # a job without a template routes every input segment to the output verbatim
+    raw = bdggg.raw_job()
+    del raw["template"]
+    ours = capi.compile_job(raw)
+    assert ours["template"] == {"transform": {"token": ["0::", "1::", "2::"], "knit": ["0", "1", "2"]}}
+    assert ours["output segment cardinality"] == 3 and ours["sample"]["undetermined"]["TC"] == 3
+
+
+def _without_io(job):
+    """The Python restatement stops at the decoder topics: drop what the IO step adds (covered by the test above)."""
+    for key in ("output", "output segment cardinality", "template"):
+        job.pop(key, None)
+    for topic in ("sample", "molecular", "cellular"):
+        for decoder in ([job[topic]] if isinstance(job.get(topic), dict) else job.get(topic, [])):
+            if decoder.get("multiplexing classifier"):
+                decoder.pop("output", None)
+                for record in [decoder.get("undetermined", {})] + list(decoder.get("codec", {}).values()):
+                    record.pop("output", None)
+                    record.pop("TC", None)
+    return job
+
+
 @pytest.mark.parametrize("name,algorithm", [("C2", "pamld"), ("C3", "pamld"), ("C4", "mdd"), ("C5", "pamld")])
 def test_equals_the_python_restatement(name, algorithm):
     spec = synthetic.config_spec(name, algorithm)
-    assert capi.compile_job(spec) == jobspec.compile_job(spec)          # doubles bit for bit: round trip digits
+    assert _without_io(capi.compile_job(spec)) == jobspec.compile_job(spec)          # doubles bit for bit: round trip digits
 
 
 def test_compiled_documents_pass_through_and_create_compiles_by_itself():
@@ -95,6 +144,7 @@ def test_decoder_repository_and_base_references():
             "cellular": [{"algorithm": "mdd", "noise": 0.05, "confidence threshold": 0.99,
                           "transform": {"token": ["1::8"]}, "codec": copy.deepcopy(codec)}]}
     expected = jobspec.compile_job(flat)
+    job = _without_io(job)
     assert job["sample"] == expected["sample"] and job["cellular"] == expected["cellular"]
 
 

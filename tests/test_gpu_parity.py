@@ -6,12 +6,13 @@ word and every integer counter are bit exact; the PAMLD posterior is within 1e-6
 contract is at risk); confidence sums agree to 1e-12 relative.
 """
 import json
+import os
 
 import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, jobspec, synthetic
+from pheniqs_amd import DecoderSet, PheniqsError, RESULT_DTYPE, capi, jobspec, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -499,8 +500,8 @@ def test_counter_allreduce_over_rccl_single_rank(oracle, torch_cuda):
 @pytest.mark.parametrize("batch_capacity,compressed", [(1 << 16, False), (100, False), (64, True)])
 def test_bdggg_fastq_to_sam_is_the_golden_file(torch_cuda, tmp_path, batch_capacity, compressed):
     """The reference's own compiled job (valid/compile_annotated.out, unchanged) and its three FASTQ files through
-    phq_transcode_fastq_to_sam: every alignment record of valid/annotated.out, byte for byte.  (The @HD/@RG/@PG
-    header lines belong to the SAM header model, out of scope.)"""
+    phq_transcode_fastq_to_sam: valid/annotated.out byte for byte, header lines included.  (@PG names the program
+    and its command line; the reference's own test drops it before comparing, test/BDGGG/function.sh:29.)"""
     import gzip
     import os
     import shutil
@@ -517,9 +518,9 @@ def test_bdggg_fastq_to_sam_is_the_golden_file(torch_cuda, tmp_path, batch_capac
     output = os.path.join(tmp_path, "out.sam")
     incoming = s.transcode_fastq_to_sam(inputs, output, batch_capacity)
     assert incoming == (250, 243)
-    golden = [line for line in open(os.path.join(bdggg.HERE, "annotated.out.sam")) if not line.startswith("@")]
-    mine = open(output).readlines()
-    assert len(mine) == len(golden) == 496
+    golden = open(os.path.join(bdggg.HERE, "annotated.out.sam")).readlines()
+    mine = [line for line in open(output) if not line.startswith("@PG")]
+    assert len(mine) == len(golden) == 496 + 7
     for a, b in zip(mine, golden):
         assert a == b
     # and the report of the same run, against valid/annotated.err
@@ -565,10 +566,144 @@ def test_large_batches_write_the_same_records_in_the_same_order(torch_cuda, tmp_
         outputs.append((open(output, "rb").read(), s.stats_export()))
     assert outputs[0][0] == outputs[1][0]
     assert np.array_equal(outputs[0][1], outputs[1][1])
-    records = outputs[0][0].split(b"\n")
+    records = [line for line in outputs[0][0].split(b"\n") if not line.startswith(b"@")]
     kept = n - len(range(0, n, 97))
     assert len(records) - 1 == 2 * kept
     assert records[0].startswith(b"r1\t") and records[-2].startswith(b"r%d\t" % (n - 1))
+
+
+def _bdggg_job_with_io(tmp_path, **changes):
+    """BDGGG_annotated.json as a user writes it (imports resolved, nothing compiled), reading the committed FASTQ files
+    and writing under tmp_path."""
+    job = bdggg.raw_job()
+    job["base input url"] = bdggg.HERE
+    job["base output url"] = str(tmp_path)
+    job.update(changes)
+    return job
+
+
+def _golden_sam_records():
+    """valid/annotated.out: (header lines, [(name, flag, sequence, quality, {tag: value}) per record])."""
+    header, records = [], []
+    for line in open(os.path.join(bdggg.HERE, "annotated.out.sam")):
+        if line.startswith("@"):
+            header.append(line)
+            continue
+        field = line.rstrip("\n").split("\t")
+        tags = {t[:2]: t[5:] for t in field[11:]}
+        records.append((field[0], int(field[1]), field[9], field[10], tags))
+    return header, records
+
+
+def test_job_directives_user_level_config_to_the_golden_file(torch_cuda, tmp_path):
+    """phq_transcode_job: the user level configuration unchanged but for the directories — compiled by the library,
+    `input` under `base input url`, a single `output` path under `base output url` repeated for both output segments —
+    gives valid/annotated.out byte for byte."""
+    job = _bdggg_job_with_io(tmp_path, output=["out.sam"])
+    s = DecoderSet(json.dumps(job), device=0)
+    assert s.transcode_job(100) == (250, 243)
+    golden = open(os.path.join(bdggg.HERE, "annotated.out.sam")).readlines()
+    mine = [line for line in open(os.path.join(tmp_path, "out.sam")) if not line.startswith("@PG")]
+    assert mine == golden
+
+
+def test_job_directives_interleaved_input_feed(torch_cuda, tmp_path):
+    """A path stated three times in `input` is ONE feed whose consecutive records are the three segments of a read
+    (transcode.cpp:693-701): the same output as from the three separate files; a feed that ends inside a read and
+    segments out of sync are sequence errors."""
+    sources = [open(os.path.join(bdggg.HERE, "BDGGG_s0%d.fastq" % k)).read().split("\n") for k in (1, 2, 3)]
+    n = min(len(lines) // 4 for lines in sources)
+    path = os.path.join(tmp_path, "interleaved.fastq")
+    with open(path, "w") as out:
+        for i in range(n):
+            for lines in sources:
+                out.write("\n".join(lines[4 * i:4 * i + 4]) + "\n")
+    job = _bdggg_job_with_io(tmp_path, input=[path, path, path], output=["out.sam?format=sam"])
+    s = DecoderSet(json.dumps(job), device=0)
+    assert s.transcode_job(64) == (250, 243)
+    golden = open(os.path.join(bdggg.HERE, "annotated.out.sam")).readlines()
+    mine = [line for line in open(os.path.join(tmp_path, "out.sam")) if not line.startswith("@PG")]
+    assert mine == golden
+    # one record short: the feed ends inside a read
+    with open(path, "w") as out:
+        for i in range(10):
+            for k, lines in enumerate(sources):
+                if i == 9 and k == 2: break
+                out.write("\n".join(lines[4 * i:4 * i + 4]) + "\n")
+    with pytest.raises(PheniqsError) as caught:
+        DecoderSet(json.dumps(job), device=0).transcode_job(64)
+    assert "ends inside a read" in str(caught.value)
+    # the second segment of read 5 taken from read 6: identifiers no longer agree
+    with open(path, "w") as out:
+        for i in range(10):
+            for k, lines in enumerate(sources):
+                at = 4 * (i + 1 if (i == 5 and k == 1) else i)
+                out.write("\n".join(lines[at:at + 4]) + "\n")
+    with pytest.raises(PheniqsError) as caught:
+        DecoderSet(json.dumps(job), device=0).transcode_job(64)
+    assert "out of sync" in str(caught.value)
+
+
+def test_job_directives_split_fastq_outputs_by_channel(torch_cuda, tmp_path):
+    """Multiplexer::push (multiplex.h:198-240): every sample barcode is a channel with its own files.  Two gzip FASTQ
+    files per barcode (one per output segment), the undetermined reads interleaved into one plain FASTQ file, one
+    barcode as SAM, one barcode without QC failed reads.  Expected records are derived from valid/annotated.out: the
+    read group names the channel, the FASTQ comment is `segment:Y|N:0:BC` (fastq.h:176-194)."""
+    import gzip
+    job = _bdggg_job_with_io(tmp_path)
+    codec = job["sample"]["codec"]
+    for key in codec:
+        codec[key]["output"] = ["%s_s1.fastq.gz" % key[1:], "%s_s2.fastq.gz" % key[1:]]
+    codec["@CGTACTAG"]["output"] = ["CGTACTAG.sam"]
+    codec["@GGACTCCT"]["filter outgoing qc fail"] = True
+    job["sample"]["undetermined"] = {"output": ["undetermined.fq"]}
+    s = DecoderSet(json.dumps(job), device=0)
+    assert s.transcode_job(77) == (250, 243)
+
+    header, records = _golden_sam_records()
+    def fastq(record):
+        name, flag, sequence, quality, tags = record
+        return "@%s %d:%s:0:%s\n%s\n+\n%s\n" % (name, 1 if flag & 64 else 2, "Y" if flag & 512 else "N", tags.get("BC", ""), sequence, quality)
+    by_group = {}
+    for record in records:
+        by_group.setdefault(record[4]["RG"].split(":")[-1], []).append(record)
+    assert set(by_group) == {"undetermined", "AGGCAGAA", "CGTACTAG", "GGACTCCT", "TAAGGCGA", "TCCTGAGC"}
+    for barcode in ("AGGCAGAA", "GGACTCCT", "TAAGGCGA", "TCCTGAGC"):
+        for segment, bit in ((1, 64), (2, 128)):
+            expected = "".join(fastq(r) for r in by_group[barcode] if r[1] & bit and not (barcode == "GGACTCCT" and r[1] & 512))
+            assert gzip.open(os.path.join(tmp_path, "%s_s%d.fastq.gz" % (barcode, segment)), "rt").read() == expected, (barcode, segment)
+    assert any(r[1] & 512 for r in by_group["GGACTCCT"])                      # the filter had something to drop
+    assert open(os.path.join(tmp_path, "undetermined.fq")).read() == "".join(fastq(r) for r in by_group["undetermined"])
+    sam = [line for line in open(os.path.join(tmp_path, "CGTACTAG.sam")) if not line.startswith("@PG")]
+    golden = [line for line in open(os.path.join(bdggg.HERE, "annotated.out.sam")) if line.startswith("@") or "RG:Z:BDGGG:1:CGTACTAG" in line]
+    assert sam == golden
+    # counters do not depend on where the reads are written
+    report = json.loads(s.report(s.stats_export(), (250, 243)))
+    assert report["outgoing"] == bdggg.golden_report()["outgoing"]
+
+
+def test_job_directives_errors(torch_cuda, tmp_path):
+    """Configuration errors of compile_output (transcode.cpp:1337-1345,1446-1460,1383-1393) and formats that need htslib."""
+    def run(**changes):
+        job = _bdggg_job_with_io(tmp_path, **changes)
+        DecoderSet(json.dumps(job), device=0).transcode_job(64)
+    for changes, text in (({"output": ["a.sam", "b.sam", "c.sam"]}, "incorrect number of output URLs in channel"),
+                          ({"output": ["/dev/stdin"]}, "output stream can not be set to standard input"),
+                          ({"output": ["/dev/stderr"]}, "output stream can not be set to standard error"),
+                          ({"output": ["out.bam"]}, "htslib"),
+                          ({"output": ["out.fastq.bz2"]}, "not supported"),
+                          ({"input": ["a.bam", "BDGGG_s02.fastq", "BDGGG_s03.fastq"]}, "only FASTQ input"),
+                          ({"input": ["missing.fastq", "BDGGG_s02.fastq", "BDGGG_s03.fastq"]}, "could not open")):
+        with pytest.raises(PheniqsError) as caught:
+            run(**changes)
+        assert text in str(caught.value), (changes, str(caught.value))
+    job = _bdggg_job_with_io(tmp_path)
+    job["sample"]["codec"]["@AGGCAGAA"]["output"] = ["x.fastq", "x.fastq"]
+    job["sample"]["codec"]["@CGTACTAG"]["output"] = ["x.fastq", "y.fastq"]
+    job["output"] = ["rest.sam"]
+    with pytest.raises(PheniqsError) as caught:
+        DecoderSet(json.dumps(job), device=0).transcode_job(64)
+    assert "inconsistent resolution" in str(caught.value)
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
