@@ -28,6 +28,7 @@
 
 #include "error.hpp"
 #include "host_parallel.hpp"
+#include "text_format.hpp"
 
 namespace phq {
 
@@ -227,35 +228,33 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
     }
 }
 
+// a barcode accumulator of the output read (raw or corrected, per type): at most the nucleotide width of the job
 struct Text {
     std::vector<uint8_t> code;
     std::vector<uint8_t> quality;
-    void clear() { code.clear(); quality.clear(); }
-    bool empty() const { return code.empty(); }
+    int32_t size = 0;
+    void allocate(int32_t capacity) { code.resize(static_cast<size_t>(capacity)); quality.resize(static_cast<size_t>(capacity)); }
+    void clear() { size = 0; }
+    bool empty() const { return size == 0; }
     void append(const uint8_t* c, const uint8_t* q, int32_t n) {
-        code.insert(code.end(), c, c + n);
-        quality.insert(quality.end(), q, q + n);
+        std::memcpy(code.data() + size, c, static_cast<size_t>(n));
+        std::memcpy(quality.data() + size, q, static_cast<size_t>(n));
+        size += n;
     }
+    void push(uint8_t c, uint8_t q) { code[static_cast<size_t>(size)] = c; quality[static_cast<size_t>(size)] = q; ++size; }
 };
 
-void put_sequence(std::string& out, const std::vector<uint8_t>& code) {
-    static const char table[] = "=ACMGRSVTWYHKDBN";                        // BamToAmbiguousAscii, iupac.h:62-79
-    const size_t at = out.size();
-    out.resize(at + code.size());
-    char* to = &out[at];
-    for(size_t i = 0; i < code.size(); ++i) { to[i] = table[code[i] & 0xf]; }
+const char BAM_TO_ASCII[] = "=ACMGRSVTWYHKDBN";                              // BamToAmbiguousAscii, iupac.h:62-79
+inline char* put_sequence(char* to, const uint8_t* code, int32_t n) {
+    for(int32_t i = 0; i < n; ++i) { to[i] = BAM_TO_ASCII[code[i] & 0xf]; }
+    return to + n;
 }
-void put_quality(std::string& out, const std::vector<uint8_t>& quality, int32_t phred_offset) {
-    const size_t at = out.size();
-    out.resize(at + quality.size());
-    char* to = &out[at];
-    for(size_t i = 0; i < quality.size(); ++i) { to[i] = static_cast<char>(quality[i] + phred_offset); }
+inline char* put_quality(char* to, const uint8_t* quality, int32_t n, int32_t phred_offset) {
+    for(int32_t i = 0; i < n; ++i) { to[i] = static_cast<char>(quality[i] + phred_offset); }
+    return to + n;
 }
-void put_float(std::string& out, float value) {
-    char scratch[48];
-    std::snprintf(scratch, sizeof(scratch), "%g", static_cast<double>(value));     // htslib kputd/ksprintf "%g"
-    out += scratch;
-}
+inline char* put_sequence(char* to, const Text& text) { return put_sequence(to, text.code.data(), text.size); }
+inline char* put_quality(char* to, const Text& text, int32_t phred_offset) { return put_quality(to, text.quality.data(), text.size, phred_offset); }
 
 // one input segment of the batch: record i of the segment is record i * stride + slot of its feed's batch
 struct SegmentView {
@@ -288,20 +287,22 @@ struct SegmentView {
 };
 
 // one gzip member per call: members concatenate into a valid gzip stream, so the parts of a batch compress in parallel
-void gzip_member(const std::string& text, int level, std::string& out) {
+void gzip_member(const char* text, size_t size, int level, ByteBuffer& out) {
     z_stream stream;
     std::memset(&stream, 0, sizeof(stream));
     if(deflateInit2(&stream, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { throw InternalError("deflateInit2 failed"); }
-    out.resize(deflateBound(&stream, static_cast<uLong>(text.size())) + 32);
-    stream.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text.data()));
-    stream.avail_in = static_cast<uInt>(text.size());
-    stream.next_out = reinterpret_cast<Bytef*>(&out[0]);
-    stream.avail_out = static_cast<uInt>(out.size());
+    out.clear();
+    const size_t bound = deflateBound(&stream, static_cast<uLong>(size)) + 32;
+    char* to = out.reserve(bound);
+    stream.next_in = reinterpret_cast<Bytef*>(const_cast<char*>(text));
+    stream.avail_in = static_cast<uInt>(size);
+    stream.next_out = reinterpret_cast<Bytef*>(to);
+    stream.avail_out = static_cast<uInt>(bound);
     const int status = deflate(&stream, Z_FINISH);
-    const size_t produced = out.size() - stream.avail_out;
+    const size_t produced = bound - stream.avail_out;
     deflateEnd(&stream);
     if(status != Z_STREAM_END) { throw InternalError("deflate failed"); }
-    out.resize(produced);
+    out.size = produced;
 }
 
 struct OutputSink {
@@ -317,15 +318,15 @@ struct OutputSink {
             if(file == nullptr) { throw IOError("could not open " + feed.path + " for writing"); }
         }
     }
-    void write(const std::string& bytes) {
-        if(!bytes.empty() && std::fwrite(bytes.data(), 1, bytes.size(), file) != bytes.size()) { throw IOError("error writing " + feed.path); }
-        wrote = wrote || !bytes.empty();
+    void write(const char* bytes, size_t size) {
+        if(size > 0 && std::fwrite(bytes, 1, size, file) != size) { throw IOError("error writing " + feed.path); }
+        wrote = wrote || size > 0;
     }
     void close() {
         if(file != nullptr) {
             if(feed.gzip && !wrote) {                        // an empty channel is still a valid gzip file
-                std::string member;
-                try { gzip_member(std::string(), feed.level, member); std::fwrite(member.data(), 1, member.size(), file); } catch(...) {}
+                ByteBuffer member;
+                try { gzip_member("", 0, feed.level, member); std::fwrite(member.data.get(), 1, member.size, file); } catch(...) {}
             }
             std::fflush(file);
             if(owns) { std::fclose(file); }
@@ -523,8 +524,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     if(plan.sam_header) {
         for(auto& sink : m.sink) {
             if(sink.feed.format != FileFormat::SAM) { continue; }
-            if(sink.feed.gzip) { std::string member; gzip_member(header, sink.feed.level, member); sink.write(member); }
-            else { sink.write(header); }
+            if(sink.feed.gzip) { ByteBuffer member; gzip_member(header.data(), header.size(), sink.feed.level, member); sink.write(member.data.get(), member.size); }
+            else { sink.write(header.data(), header.size()); }
         }
     }
 
@@ -558,8 +559,29 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& t : readers) { t.join(); }
     }
     const int workers = host_threads();
-    std::vector<std::string> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
-    std::vector<std::string> part_packed(part_text.size());
+    std::vector<ByteBuffer> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
+    std::vector<ByteBuffer> part_packed(part_text.size());
+    // the tokens of every output segment, the widest tag block, the flag column per (output segment, QC fail)
+    const int32_t n_out = job.output_segment_cardinality;
+    std::vector<std::vector<int32_t>> token_of_output(static_cast<size_t>(n_out));
+    for(size_t t = 0; t < job.template_transform.size(); ++t) { token_of_output[static_cast<size_t>(job.template_transform[t].output_segment_index)].push_back(static_cast<int32_t>(t)); }
+    size_t rg_widest = 0;
+    for(const auto& id : rg_by_index) { rg_widest = std::max(rg_widest, id.size()); }
+    const int32_t barcode_capacity = job.nucleotide_width + 8;
+    const size_t tag_capacity = rg_widest + 8 * static_cast<size_t>(barcode_capacity) + 256;
+    std::vector<std::string> flag_text(static_cast<size_t>(n_out) * 2);
+    for(int32_t o = 0; o < n_out; ++o) {
+        for(int failed = 0; failed < 2; ++failed) {
+            int flag = 4 | 8;                                                 // BAM_FUNMAP | BAM_FMUNMAP (read.h:134-135)
+            if(n_out > 1) { flag |= 1; }
+            if(o == 0) { flag |= 64; }
+            if(n_out > 1 && o == n_out - 1) { flag |= 128; }
+            if(failed) { flag |= 512; }
+            std::string& text = flag_text[static_cast<size_t>(o) * 2 + static_cast<size_t>(failed)];
+            text = "\t" + std::to_string(flag) + "\t*\t0\t0\t*\t*\t0\t0\t";
+            // FI and TC go in front of the other tags when there are more than two segments (auxiliary.cpp:324-329)
+        }
+    }
     std::vector<SegmentView> view(static_cast<size_t>(n_segment));
     // PHQ_TRANSCODE_TRACE=1: wall time per phase on stderr at the end of the run
     const bool trace = std::getenv("PHQ_TRANSCODE_TRACE") != nullptr;
@@ -588,15 +610,28 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         struct Joiner { std::vector<std::thread>& threads; ~Joiner() { for(auto& t : threads) { if(t.joinable()) { t.join(); } } } } joiner{readers};
         if(!last_batch) { readers = start_readers(ahead); }
         // Read::validate (read.h:253-264): every segment of a read carries the same identifier
-        for(int32_t s = 1; s < n_segment; ++s) {
-            const SegmentView& a = view[0];
-            const SegmentView& b = view[static_cast<size_t>(s)];
-            for(int64_t i = 0; i < n_read; ++i) {
-                const size_t la = a.name_size(i);
-                const size_t lb = b.name_size(i);
-                if(la != lb || std::memcmp(a.name(i), b.name(i), la) != 0) {
-                    throw SequenceError("read out of sync " + std::string(b.name(i), lb) + " and " + std::string(a.name(i), la));
-                }
+        if(n_segment > 1) {
+            try {
+                parallel_ranges(n_read, 1 << 14, host_threads(), [&](int64_t first, int64_t last, int) {
+                    const SegmentView& a = view[0];
+                    for(int32_t s = 1; s < n_segment; ++s) {
+                        const SegmentView& b = view[static_cast<size_t>(s)];
+                        for(int64_t i = first; i < last; ++i) {
+                            const size_t la = a.name_size(i);
+                            const size_t lb = b.name_size(i);
+                            if(la != lb || std::memcmp(a.name(i), b.name(i), la) != 0) {
+                                throw SequenceError("read out of sync " + std::string(b.name(i), lb) + " and " + std::string(a.name(i), la));
+                            }
+                        }
+                    }
+                });
+            } catch(const Error&) {
+                throw;
+            } catch(const std::exception& e) {                 // from a worker thread: the text with its class prefix
+                std::string text = e.what();
+                const std::string prefix = "Sequence error : ";
+                if(text.compare(0, prefix.size(), prefix) == 0) { text.erase(0, prefix.size()); }
+                throw SequenceError(text);
             }
         }
         std::vector<const uint8_t*> code(static_cast<size_t>(n_segment)), quality(static_cast<size_t>(n_segment));
@@ -621,10 +656,13 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& text : part_text) { text.clear(); }
         for(auto& text : part_packed) { text.clear(); }
         parallel_ranges(n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
-        std::string* const text_of_sink = &part_text[static_cast<size_t>(part) * static_cast<size_t>(n_sink)];
-        if(n_sink == 1) { text_of_sink[0].reserve(static_cast<size_t>(last_kept - first_kept) * 256); }
-        Text raw[3], corrected[3], out_segment[8];
-        std::string tags;
+        ByteBuffer* const text_of_sink = &part_text[static_cast<size_t>(part) * static_cast<size_t>(n_sink)];
+        Text raw[3], corrected[3];
+        for(auto& t : raw) { t.allocate(barcode_capacity); }
+        for(auto& t : corrected) { t.allocate(barcode_capacity); }
+        std::vector<char> tags(tag_capacity);
+        struct Piece { const uint8_t* code; const uint8_t* quality; int32_t size; bool reverse_complement; };
+        std::vector<Piece> piece(job.template_transform.size());
         for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
             uint32_t distance[3] = {0, 0, 0};
@@ -656,12 +694,12 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                         // append_to_corrected_*_barcode_sequence -> append_corrected (sequence.h:382-398), S9 quirk kept:
                         // the "was this base corrected" test reads the observation at the DESTINATION length
                         Text& to = corrected[kind];
-                        const int32_t dest = static_cast<int32_t>(to.code.size());
+                        const int32_t dest = to.size;
+                        const uint8_t* const expected = ordinal >= 0 ? d.barcode_code.data() + static_cast<size_t>(ordinal) * static_cast<size_t>(d.nucleotide_cardinality) + static_cast<size_t>(so) : nullptr;
                         for(int32_t i = 0; i < len; ++i) {
-                            const uint8_t fixed = ordinal >= 0 ? d.barcode_code[static_cast<size_t>(ordinal) * static_cast<size_t>(d.nucleotide_cardinality) + static_cast<size_t>(so + i)] : 0;
+                            const uint8_t fixed = expected != nullptr ? expected[i] : 0;
                             const uint8_t probe = (dest + i) < len ? oc[so + dest + i] : 0;
-                            to.code.push_back(fixed);
-                            to.quality.push_back((probe == fixed || fixed == 0) ? oq[so + i] : static_cast<uint8_t>(d.corrected_quality));
+                            to.push(fixed, (probe == fixed || fixed == 0) ? oq[so + i] : static_cast<uint8_t>(d.corrected_quality));
                         }
                     }
                 }
@@ -689,83 +727,102 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             const TranscodePlan::Channel& channel = plan.channel[channel_index];
             if(channel.feed_by_segment.empty() || (channel.filter_outgoing_qc_fail && qcfail)) { continue; }
 
-            // TemplateRule::apply (transform.h:190-226)
-            const int32_t n_out = job.output_segment_cardinality;
-            for(int32_t o = 0; o < n_out; ++o) { out_segment[o].clear(); }
-            for(const auto& t : job.template_transform) {
+            // TemplateRule::apply (transform.h:190-226): where every token's bases are
+            for(size_t t = 0; t < job.template_transform.size(); ++t) {
+                const TransformConfig& token = job.template_transform[t];
                 const uint8_t* fc; const uint8_t* fq; int32_t flen;
-                if(t.input_segment_index < 0) {
-                    const Text& from = corrected[t.input_segment_index == -1 ? 0 : t.input_segment_index == -2 ? 2 : 1];
-                    fc = from.code.data(); fq = from.quality.data(); flen = static_cast<int32_t>(from.code.size());
+                if(token.input_segment_index < 0) {
+                    const Text& from = corrected[token.input_segment_index == -1 ? 0 : token.input_segment_index == -2 ? 2 : 1];
+                    fc = from.code.data(); fq = from.quality.data(); flen = from.size;
                 } else {
-                    const SegmentView& v = view[static_cast<size_t>(t.input_segment_index)];
+                    const SegmentView& v = view[static_cast<size_t>(token.input_segment_index)];
                     const size_t at = v.at(r);
                     fc = v.feed->code.data() + v.feed->offset[at]; fq = v.feed->quality.data() + v.feed->offset[at]; flen = v.feed->length[at];
                 }
-                const int32_t start = t.absolute_start(flen);
-                const int32_t end = t.absolute_end(flen);
-                Text& to = out_segment[t.output_segment_index];
-                if(end - start > 0) {
-                    if(t.reverse_complement) {
-                        for(int32_t i = 0; i < end - start; ++i) { to.code.push_back(reverse_complement_bam(fc[end - i - 1])); to.quality.push_back(fq[end - i - 1]); }
-                    } else { to.append(fc + start, fq + start, end - start); }
-                }
+                const int32_t start = token.absolute_start(flen);
+                const int32_t end = token.absolute_end(flen);
+                piece[t] = Piece{fc + start, fq + start, end - start > 0 ? end - start : 0, token.reverse_complement};
             }
 
             // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
-            tags.clear();
-            if(rg != nullptr && !rg->empty()) { tags += "\tRG:Z:"; tags += *rg; }
-            if(!raw[0].empty()) { tags += "\tBC:Z:"; put_sequence(tags, raw[0].code); tags += "\tQT:Z:"; put_quality(tags, raw[0].quality, 33); }
-            if(confidence[0] > 0 && confidence[0] < 1) { tags += "\tXB:f:"; put_float(tags, static_cast<float>(1.0 - confidence[0])); }
-            if(!corrected[1].empty()) { tags += "\tRX:Z:"; put_sequence(tags, corrected[1].code); tags += "\tQX:Z:"; put_quality(tags, corrected[1].quality, 33); }
-            if(!raw[1].empty()) { tags += "\tOX:Z:"; put_sequence(tags, raw[1].code); tags += "\tBZ:Z:"; put_quality(tags, raw[1].quality, 33); }
-            if(confidence[1] > 0 && confidence[1] < 1) { tags += "\tXM:f:"; put_float(tags, static_cast<float>(1.0 - confidence[1])); }
-            if(!corrected[2].empty()) { tags += "\tCB:Z:"; put_sequence(tags, corrected[2].code); }
-            if(!raw[2].empty()) { tags += "\tCR:Z:"; put_sequence(tags, raw[2].code); tags += "\tCY:Z:"; put_quality(tags, raw[2].quality, 33); }
-            if(confidence[2] > 0 && confidence[2] < 1) { tags += "\tXC:f:"; put_float(tags, static_cast<float>(1.0 - confidence[2])); }
+            char* tag_end = tags.data();
+            if(rg != nullptr && !rg->empty()) { tag_end = put_literal(tag_end, "\tRG:Z:"); tag_end = put_bytes(tag_end, rg->data(), rg->size()); }
+            if(!raw[0].empty()) { tag_end = put_literal(tag_end, "\tBC:Z:"); tag_end = put_sequence(tag_end, raw[0]); tag_end = put_literal(tag_end, "\tQT:Z:"); tag_end = put_quality(tag_end, raw[0], 33); }
+            if(confidence[0] > 0 && confidence[0] < 1) { tag_end = put_literal(tag_end, "\tXB:f:"); tag_end = put_float_g(tag_end, static_cast<float>(1.0 - confidence[0])); }
+            if(!corrected[1].empty()) { tag_end = put_literal(tag_end, "\tRX:Z:"); tag_end = put_sequence(tag_end, corrected[1]); tag_end = put_literal(tag_end, "\tQX:Z:"); tag_end = put_quality(tag_end, corrected[1], 33); }
+            if(!raw[1].empty()) { tag_end = put_literal(tag_end, "\tOX:Z:"); tag_end = put_sequence(tag_end, raw[1]); tag_end = put_literal(tag_end, "\tBZ:Z:"); tag_end = put_quality(tag_end, raw[1], 33); }
+            if(confidence[1] > 0 && confidence[1] < 1) { tag_end = put_literal(tag_end, "\tXM:f:"); tag_end = put_float_g(tag_end, static_cast<float>(1.0 - confidence[1])); }
+            if(!corrected[2].empty()) { tag_end = put_literal(tag_end, "\tCB:Z:"); tag_end = put_sequence(tag_end, corrected[2]); }
+            if(!raw[2].empty()) { tag_end = put_literal(tag_end, "\tCR:Z:"); tag_end = put_sequence(tag_end, raw[2]); tag_end = put_literal(tag_end, "\tCY:Z:"); tag_end = put_quality(tag_end, raw[2], 33); }
+            if(confidence[2] > 0 && confidence[2] < 1) { tag_end = put_literal(tag_end, "\tXC:f:"); tag_end = put_float_g(tag_end, static_cast<float>(1.0 - confidence[2])); }
+            const size_t tag_size = static_cast<size_t>(tag_end - tags.data());
 
             const SegmentView& lead = view[static_cast<size_t>(leader)];
+            const char* const name = lead.name(r);
+            const size_t name_size = lead.name_size(r);
             for(int32_t o = 0; o < n_out; ++o) {
                 const int32_t to_sink = channel.feed_by_segment[static_cast<size_t>(o)];
-                std::string& text = text_of_sink[to_sink];
+                ByteBuffer& buffer = text_of_sink[to_sink];
+                const auto& tokens = token_of_output[static_cast<size_t>(o)];
+                size_t bases = 0;
+                for(const int32_t t : tokens) { bases += static_cast<size_t>(piece[static_cast<size_t>(t)].size); }
+                char* to = buffer.reserve(name_size + 2 * bases + tag_size + static_cast<size_t>(raw[0].size) + 128);
+                auto put_bases = [&](char* at) {
+                    for(const int32_t t : tokens) {
+                        const Piece& p = piece[static_cast<size_t>(t)];
+                        if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = BAM_TO_ASCII[reverse_complement_bam(p.code[p.size - i - 1]) & 0xf]; } at += p.size; }
+                        else { at = put_sequence(at, p.code, p.size); }
+                    }
+                    return at;
+                };
+                auto put_qualities = [&](char* at) {
+                    for(const int32_t t : tokens) {
+                        const Piece& p = piece[static_cast<size_t>(t)];
+                        if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality[p.size - i - 1] + job.output_phred_offset); } at += p.size; }
+                        else { at = put_quality(at, p.quality, p.size, job.output_phred_offset); }
+                    }
+                    return at;
+                };
                 if(m.sink[static_cast<size_t>(to_sink)].feed.format == FileFormat::FASTQ) {
                     // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
-                    text += '@';
-                    text.append(lead.name(r), lead.name_size(r));
-                    text += ' ';
+                    *to++ = '@';
+                    to = put_bytes(to, name, name_size);
+                    *to++ = ' ';
                     if(illumina_comment) {
-                        text += std::to_string(o + 1);
-                        text += qcfail ? ":Y:0:" : ":N:0:";
-                        put_sequence(text, raw[0].code);
+                        to = put_unsigned(to, static_cast<uint32_t>(o + 1));
+                        to = qcfail ? put_literal(to, ":Y:0:") : put_literal(to, ":N:0:");
+                        to = put_sequence(to, raw[0]);
                     }
-                    text += '\n';
-                    put_sequence(text, out_segment[o].code);
-                    text += "\n+\n";
-                    put_quality(text, out_segment[o].quality, job.output_phred_offset);
-                    text += '\n';
+                    *to++ = '\n';
+                    to = put_bases(to);
+                    to = put_literal(to, "\n+\n");
+                    to = put_qualities(to);
+                    *to++ = '\n';
+                    buffer.commit(to);
                     continue;
                 }
-                int flag = 4 | 8;                                             // BAM_FUNMAP | BAM_FMUNMAP (read.h:134-135)
-                if(n_out > 1) { flag |= 1; }
-                if(o == 0) { flag |= 64; }
-                if(n_out > 1 && o == n_out - 1) { flag |= 128; }
-                if(qcfail) { flag |= 512; }
-                text.append(lead.name(r), lead.name_size(r));
-                text += '\t'; text += std::to_string(flag); text += "\t*\t0\t0\t*\t*\t0\t0\t";
-                if(out_segment[o].empty()) { text += "*\t*"; }
+                const std::string& columns = flag_text[static_cast<size_t>(o) * 2 + (qcfail ? 1 : 0)];
+                to = put_bytes(to, name, name_size);
+                to = put_bytes(to, columns.data(), columns.size());
+                if(bases == 0) { to = put_literal(to, "*\t*"); }
                 else {
-                    put_sequence(text, out_segment[o].code);
-                    text += '\t';
-                    put_quality(text, out_segment[o].quality, job.output_phred_offset);
+                    to = put_bases(to);
+                    *to++ = '\t';
+                    to = put_qualities(to);
                 }
-                if(n_out > 2) { text += "\tFI:i:" + std::to_string(o + 1) + "\tTC:i:" + std::to_string(n_out); }
-                text += tags;
-                text += '\n';
+                if(n_out > 2) {
+                    to = put_literal(to, "\tFI:i:"); to = put_unsigned(to, static_cast<uint32_t>(o + 1));
+                    to = put_literal(to, "\tTC:i:"); to = put_unsigned(to, static_cast<uint32_t>(n_out));
+                }
+                to = put_bytes(to, tags.data(), tag_size);
+                *to++ = '\n';
+                buffer.commit(to);
             }
         }
         for(int32_t f = 0; f < n_sink; ++f) {
             if(m.sink[static_cast<size_t>(f)].feed.gzip && !text_of_sink[f].empty()) {
-                gzip_member(text_of_sink[f], m.sink[static_cast<size_t>(f)].feed.level, part_packed[static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f)]);
+                gzip_member(text_of_sink[f].data.get(), text_of_sink[f].size, m.sink[static_cast<size_t>(f)].feed.level,
+                            part_packed[static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f)]);
             }
         }
         });
@@ -773,7 +830,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(int part = 0; part < workers; ++part) {
             for(int32_t f = 0; f < n_sink; ++f) {
                 const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
-                m.sink[static_cast<size_t>(f)].write(m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at]);
+                const ByteBuffer& bytes = m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at];
+                m.sink[static_cast<size_t>(f)].write(bytes.data.get(), bytes.size);
             }
         }
         lap(4);
