@@ -16,6 +16,8 @@
 #include "../json.hpp"
 #include "../phred.hpp"
 #include "../stats.hpp"
+#include "../text_format.hpp"
+#include "../url.hpp"
 
 static int failures = 0;
 #define CHECK(condition) do { if(!(condition)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #condition); ++failures; } } while(0)
@@ -31,6 +33,46 @@ int main(int argc, char** argv) {
     CHECK(format_double(0.18 * (1 - 0.015), 15) == "0.177299999999999");
     CHECK(format_double(1.0 / 65536, 15) == "0.000015258789062");
     CHECK(format_double(248.0, 15) == "248.0");
+
+    // the SAM float tag writer against printf("%g"): random magnitudes, neighbours of short decimals, sixth digit halves
+    {
+        uint64_t state = 88172645463325252ull;
+        auto next = [&]() { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state; };
+        auto same = [](float value) {
+            char mine[64], theirs[64];
+            *put_float_g(mine, value) = 0;
+            std::snprintf(theirs, sizeof(theirs), "%g", static_cast<double>(value));
+            return std::string(mine) == theirs;
+        };
+        for(int i = 0; i < 400000; ++i) {
+            const double exponent = -24.0 * static_cast<double>(next() >> 11) / 9007199254740992.0;
+            CHECK(same(static_cast<float>(std::pow(10.0, exponent))));
+        }
+        for(int k = -21; k <= 0; ++k) {
+            for(int m = 1; m < 300; ++m) {
+                const float value = static_cast<float>(m * std::pow(10.0, k - 2));
+                CHECK(same(value)); CHECK(same(std::nextafterf(value, 0.0f))); CHECK(same(std::nextafterf(value, 2.0f)));
+            }
+            const float half = static_cast<float>(100000.5 * std::pow(10.0, k - 5));
+            CHECK(same(half)); CHECK(same(std::nextafterf(half, 0.0f))); CHECK(same(std::nextafterf(half, 2.0f)));
+        }
+        CHECK(same(0.999999f)); CHECK(same(0.99999994f)); CHECK(same(1e-4f)); CHECK(same(9.99999e-5f)); CHECK(same(1.0f)); CHECK(same(0.0f)); CHECK(same(1e-30f));
+    }
+    // file references: extension and query (url.cpp:280-417)
+    {
+        const Url a = Url::parse("out/reads_s1.fastq.gz");
+        CHECK(a.format == FileFormat::FASTQ && a.compression() == FileCompression::GZIP && a.path == "out/reads_s1.fastq.gz");
+        const Url b = Url::parse("/dev/stdout?format=sam&compression=none");
+        CHECK(b.format == FileFormat::SAM && b.compression() == FileCompression::NONE && b.is_stdout() && b.path == "/dev/stdout");
+        Url c = Url::parse("x.fq?compression=gz&level=7&unknown=1");
+        CHECK(c.format == FileFormat::FASTQ && c.compression() == FileCompression::GZIP && c.compression_level == 7);
+        c.relocate_child("base/dir");
+        CHECK(c.path == "base/dir/x.fq" && c.encoded() == "base/dir/x.fq?compression=gz&level=7&unknown=1");
+        Url d = Url::parse("/abs/y.bam");
+        d.relocate_child("base");
+        CHECK(d.path == "/abs/y.bam" && d.format == FileFormat::BAM);
+        CHECK(Url::parse("plain").format == FileFormat::UNKNOWN && Url::parse("a.b").format == FileFormat::UNKNOWN);
+    }
 
     // malformed documents must throw ConfigurationError, never crash
     const char* broken[] = {"", "{", "{\"a\":", "[1,2", "{\"a\" 1}", "\"unterminated", "{\"sample\": {\"algorithm\": 3}}", "nul", "{\"a\": 1} trailing"};
