@@ -45,9 +45,14 @@ __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (posi
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
 constexpr uint32_t FIELD_MASK = 0x3c3c3c3cu;
 
-__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
-    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4); bits outside FIELD_MASK are junk
-}
+// In LDS and in the registers of a read the two code bits live in two PLANE words instead: the low bits of all
+// positions in one word, the high bits — moved 4 places down, to the same bits 2..5 of each byte — in another, every
+// other bit zero.  The mismatch fields of a word are then
+//     (observed_low ^ expected_low) | (observed_high ^ expected_high)
+// with nothing to mask, and what is OR-ed into the unused bits of observed_low (the wave's share of the table address)
+// comes through unchanged: two instructions (v_xor_b32, v_bitop3_b32) per word instead of four.
+__device__ __forceinline__ uint32_t low_plane(uint32_t sliced) { return sliced & FIELD_MASK; }
+__device__ __forceinline__ uint32_t high_plane(uint32_t sliced) { return __builtin_amdgcn_alignbit(sliced, sliced, 4) & FIELD_MASK; }
 
 // Workgroup size: the 16 entry tables cost 64 bytes of LDS per lane and group.  Up to 8 nt (2 groups) a 512
 // lane workgroup = two 256 lane half tables of 32 KiB leaves room for two workgroups per CU = 4 waves per SIMD;
@@ -73,8 +78,8 @@ template <int L> struct LutGeometry {
     static constexpr uint32_t MATCH_AT = TABLE_AT + TABLE_BYTES;           // FACTOR_ROWS x {match, mismatch} floats
     static constexpr uint32_t FACTOR_AT = MATCH_AT + 1056;                 // FACTOR_ROWS x [match | mismatch] doubles
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 129 * 16;          // one counter
-    static constexpr uint32_t WORDS_AT = DEFERRED_AT + 16;                 // the packed barcode words, up to 256
-    static constexpr uint32_t HISTOGRAM_AT = WORDS_AT + 1024;              // the counter histogram (kernel_common.hpp)
+    static constexpr uint32_t WORDS_AT = DEFERRED_AT + 16;                 // the barcode words, up to 256, as two planes
+    static constexpr uint32_t HISTOGRAM_AT = WORDS_AT + 2048;              // the counter histogram (kernel_common.hpp)
 };
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
@@ -104,11 +109,18 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         factor_double[i][1] = e;
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
+    // per block of 8 barcodes: the low plane words of the block, then its high plane words
     uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + Layout::WORDS_AT);
+    constexpr int BLOCK_WORDS = 8 / PER_WORD;
     {
         const int padded = (d.n_barcode + 7) & ~7;
         const int words = PAIRED ? padded >> 1 : padded;
-        for(int w = threadIdx.x; w < words; w += THREADS) { lds_words[w] = d.barcode_packed2[w]; }
+        for(int w = threadIdx.x; w < words; w += THREADS) {
+            const uint32_t sliced = d.barcode_packed2[w];
+            const int at = 2 * BLOCK_WORDS * (w / BLOCK_WORDS) + (w % BLOCK_WORDS);
+            lds_words[at] = low_plane(sliced);
+            lds_words[at + BLOCK_WORDS] = high_plane(sliced);
+        }
     }
     histogram_clear(d, histogram);
     __syncthreads();
@@ -206,6 +218,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 fe[j] = pair.y;
             }
             if(PAIRED) { observed |= __builtin_amdgcn_alignbit(observed, observed, 16); }     // the same read against both halves
+            const uint32_t observed_high = high_plane(observed);
+            const uint32_t observed_low = low_plane(observed) | (PERMUTED ? wave_bytes : 0u);   // + the wave's address bits
             // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match)
 #pragma unroll
             for(int g = 0; g < G; ++g) {
@@ -227,10 +241,10 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             }
 
             // conditional probabilities of the PER_WORD barcodes packed in one word
-            auto probabilities_of = [&](uint32_t word, float (&p)[PER_WORD]) {
-                const uint32_t fields = mismatch_fields(observed ^ word);
+            auto probabilities_of = [&](uint32_t low_word, uint32_t high_word, float (&p)[PER_WORD]) {
                 // byte k of `fields` carries index * 4 of group (k mod G) of barcode (k / G)
-                const uint32_t cleaned = (fields & FIELD_MASK) | wave_bytes;             // permuted layout: byte 1 of an address
+                const uint32_t fields = (observed_low ^ low_word) | (observed_high ^ high_word);
+                const uint32_t cleaned = fields;                                         // permuted layout: byte 1 of an address
                 const uint32_t up = fields << 8;                                         // plain layout: the field to byte 1
                 const uint32_t down = fields >> 8;
                 const uint32_t far = fields >> 16;
@@ -270,19 +284,21 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
-                runner_up = fmaxf(runner_up, takes_over ? best_value : block_max);
+                // the larger of the old runner up and whichever of (old maximum, this block's maximum) does not lead
+                // now: runner_up <= best_value always holds, so that is the median of the three (one v_med3_f32)
+                runner_up = __builtin_amdgcn_fmed3f(best_value, block_max, runner_up);
                 others_sum += takes_over ? held_sum : block_sum;
                 held_sum = takes_over ? block_sum : held_sum;
                 best_fold = takes_over ? f : best_fold;
                 best_value = takes_over ? block_max : best_value;
             };
-            auto scan_block = [&](int f, const uint32_t (&w)[WORDS_PER_FOLD], bool partial) {
+            auto scan_block = [&](int f, const uint32_t (&w)[2 * WORDS_PER_FOLD], bool partial) {
                 // barcodes 8f .. 8f+7; the table is padded to whole blocks, the padding's probabilities are zeroed
                 float p[FOLD];
 #pragma unroll
                 for(int k = 0; k < WORDS_PER_FOLD; ++k) {
                     float a[PER_WORD];
-                    probabilities_of(w[k], a);
+                    probabilities_of(w[k], w[WORDS_PER_FOLD + k], a);
 #pragma unroll
                     for(int h = 0; h < PER_WORD; ++h) { p[PER_WORD * k + h] = a[h]; }
                 }
@@ -301,59 +317,76 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 // the block's words from LDS at a wave uniform address (a broadcast: one ds_read_b128 brings four
                 // words to every lane; the other waves of the SIMD cover its latency)
                 const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words);
-                constexpr int QUADS = WORDS_PER_FOLD / 4;
-                auto words_of = [&](int f, uint32_t (&w)[WORDS_PER_FOLD]) {
+                constexpr int QUADS = 2 * WORDS_PER_FOLD / 4;
+                auto words_of = [&](int f, uint32_t (&w)[2 * WORDS_PER_FOLD]) {
 #pragma unroll
                     for(int q = 0; q < QUADS; ++q) {
                         const uint4 quad = blocks[QUADS * f + q];
                         w[4 * q] = quad.x; w[4 * q + 1] = quad.y; w[4 * q + 2] = quad.z; w[4 * q + 3] = quad.w;
                     }
                 };
+#pragma unroll 2
                 for(int f = 0; f < n_full; ++f) {
-                    uint32_t w[WORDS_PER_FOLD];
+                    uint32_t w[2 * WORDS_PER_FOLD];
                     words_of(f, w);
                     scan_block(f, w, false);
                 }
                 if(n_barcode % FOLD) {                                                   // the last, partial block
-                    uint32_t w[WORDS_PER_FOLD];
+                    uint32_t w[2 * WORDS_PER_FOLD];
                     words_of(n_full, w);
                     scan_block(n_full, w, true);
                 }
             }
 
-            // inside the winning block: the winner (first of equals) and the sum of the other seven
+            // Inside the winning block: the winner (first of equals) and the sum of the other seven.  The scan left the
+            // block's maximum (best_value) and its sum (held_sum); the same instructions give the same eight values
+            // again, so the winner is the first member EQUAL to best_value, the rest is the sum of the members that are
+            // not (no subtraction from the block sum, which would cancel).  Two members equal to the maximum make
+            // held_sum at least twice the maximum (floating point addition is monotone): such a read — or one whose rest
+            // of the block outweighs the winner anyway — is handed on by raising the runner up to the winner.
             int best = -1;
             uint32_t best_flags = 0;
             float sigma = others_sum;
-            float winner_single = 0;
+            const float winner_single = best_value;
             {
                 const int block = best_fold < 0 ? 0 : best_fold;
-                float top = 0;
-                float rest = 0;
+                float p[FOLD];
 #pragma unroll
                 for(int k = 0; k < WORDS_PER_FOLD; ++k) {
-                    const int w = WORDS_PER_FOLD * block + k;
-                    const uint32_t word = lds_words[w];
-                    const uint32_t fields = mismatch_fields(observed ^ word);
                     float a[PER_WORD];
-                    probabilities_of(word, a);
+                    probabilities_of(lds_words[2 * WORDS_PER_FOLD * block + k], lds_words[2 * WORDS_PER_FOLD * block + WORDS_PER_FOLD + k], a);
 #pragma unroll
                     for(int h = 0; h < PER_WORD; ++h) {
                         const int b = FOLD * block + PER_WORD * k + h;
-                        float p = a[h];
-                        if(!UNIFORM_PRIOR) { p *= d.concentration_single[b]; }
-                        if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
-                        rest += fminf(p, top);
-                        runner_up = fmaxf(runner_up, fminf(p, top));
-                        if(p > top) {
-                            best = b;
-                            best_flags = ((PAIRED ? (fields >> (16 * h)) : fields) | outside) & full_mask;
-                        }
-                        top = fmaxf(p, top);
+                        float value = a[h];
+                        if(!UNIFORM_PRIOR) { value *= d.concentration_single[b]; }
+                        p[PER_WORD * k + h] = value;
                     }
                 }
-                sigma += rest;
-                winner_single = top;
+                if(n_barcode % FOLD) {                           // the padding of a partial last block, as the scan zeroes it
+                    const int limit = n_barcode - FOLD * block;
+#pragma unroll
+                    for(int k = 1; k < FOLD; ++k) { p[k] = k < limit ? p[k] : 0.0f; }
+                }
+                int within = -1;
+                float q[FOLD];
+#pragma unroll
+                for(int k = FOLD - 1; k >= 0; --k) {
+                    const bool is_top = p[k] == best_value;
+                    within = is_top ? k : within;
+                    q[k] = is_top ? 0.0f : p[k];
+                }
+                const float rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                const float second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+                const bool crowded = held_sum >= 2.0f * best_value;
+                runner_up = fmaxf(runner_up, crowded ? best_value : second);
+                sigma += crowded ? best_value : rest;
+                if(best_fold >= 0 && best_value > 0.0f && within >= 0) {
+                    best = FOLD * block + within;
+                    const int at = 2 * WORDS_PER_FOLD * block + within / PER_WORD;
+                    const uint32_t fields = (observed_low ^ lds_words[at]) | (observed_high ^ lds_words[at + WORDS_PER_FOLD]);
+                    best_flags = ((PAIRED ? (fields >> (16 * (best & 1))) : fields) | outside) & full_mask;
+                }
             }
 
             if(best < 0) {
