@@ -42,11 +42,14 @@ __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(
 __device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
     return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4)
 }
+// the two code bits in two plane words, every other bit zero (pamld_lut.hpp): fields = (lo ^ lo') | (hi ^ hi')
+__device__ __forceinline__ uint32_t low_plane(uint32_t sliced) { return sliced & 0x3c3c3c3cu; }
+__device__ __forceinline__ uint32_t high_plane(uint32_t sliced) { return __builtin_amdgcn_alignbit(sliced, sliced, 4) & 0x3c3c3c3cu; }
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 // bytes of the scan kernel's LDS block in front of the counter histogram: tables, factor columns, worklist counter
 __host__ __device__ constexpr uint32_t scan_fixed_bytes(int groups, int segments) {
-    return static_cast<uint32_t>(groups) * 16u * THREADS * 4u + 1056u + static_cast<uint32_t>(segments) * CROSS_MAX_UNIQUE * 4u + 16u;
+    return static_cast<uint32_t>(groups) * 16u * THREADS * 4u + 1056u + 2u * static_cast<uint32_t>(segments) * CROSS_MAX_UNIQUE * 4u + 16u;
 }
 
 // G = groups of 4 positions of the longest segment (segments are padded with absent positions: factor 1 either way)
@@ -68,13 +71,14 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
     // (field & mask) | lane offset, one instruction
     constexpr uint32_t MATCH_AT = G * GROUP_BYTES;                            // FACTOR_ROWS x {match, mismatch} floats
     constexpr uint32_t WORDS_AT = MATCH_AT + 1056;                            // the segments' distinct words
-    constexpr uint32_t DEFERRED_AT = WORDS_AT + S * CROSS_MAX_UNIQUE * 4;
+    constexpr uint32_t DEFERRED_AT = WORDS_AT + 2 * S * CROSS_MAX_UNIQUE * 4;  // two planes per word
     static_assert(DEFERRED_AT + 16 == scan_fixed_bytes(G, S), "launch_segments sizes the block");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float* const table = reinterpret_cast<float*>(lds_raw);                   // [group][index][lane], one segment at a time
     float2* const factor_single = reinterpret_cast<float2*>(lds_raw + MATCH_AT);
-    uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + WORDS_AT);               // [segment][CROSS_MAX_UNIQUE]
+    // [segment][block of 8 words][low plane words | high plane words]
+    uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + WORDS_AT);
     uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + DEFERRED_AT);
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + DEFERRED_AT + 16);
     DecoderRef d = *constant_cast(args.decoder);
@@ -87,7 +91,12 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
         factor_single[i] = make_float2(static_cast<float>(m), static_cast<float>(e));
     }
-    for(int w = threadIdx.x; w < S * CROSS_MAX_UNIQUE; w += THREADS) { lds_words[w] = d.cross_words[w]; }      // zero past a segment's words
+    for(int w = threadIdx.x; w < S * CROSS_MAX_UNIQUE; w += THREADS) {                                        // zero past a segment's words
+        const uint32_t sliced = d.cross_words[w];
+        const int at = 16 * (w / 8) + (w % 8);
+        lds_words[at] = low_plane(sliced);
+        lds_words[at + 8] = high_plane(sliced);
+    }
     if(threadIdx.x == 0) { deferred_total = 0; }
     histogram_clear(d, histogram);
     __syncthreads();
@@ -242,8 +251,10 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             // scan the segment's distinct words eight at a time: the block's maximum and sum; across blocks the
             // running maximum, which block holds it, that block's sum set aside, the sum of every other block and the
             // largest maximum of the others (pamld_lut.hpp); then the winner inside its block
-            auto value_of = [&](uint32_t word) {
-                const uint32_t fields = mismatch_fields(observed ^ word);
+            const uint32_t observed_low = low_plane(observed);
+            const uint32_t observed_high = high_plane(observed);
+            auto value_of = [&](uint32_t low_word, uint32_t high_word) {
+                const uint32_t fields = (observed_low ^ low_word) | (observed_high ^ high_word);
                 float value = 1.0f;
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
@@ -254,7 +265,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 return value;
             };
             constexpr int FOLD = 8;
-            const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words + s * CROSS_MAX_UNIQUE);
+            const uint32_t* const segment_words = lds_words + 2 * s * CROSS_MAX_UNIQUE;
+            const uint4* const blocks = reinterpret_cast<const uint4*>(segment_words);
             const int n_block = (unique[s] + FOLD - 1) / FOLD;
             float others_sum = 0;
             float held_sum = 0;
@@ -262,57 +274,74 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             float second = 0;
             float plain_sum = 0;
             int best_block = -1;
-            for(int f = 0; f < n_block; ++f) {
-                const uint4 a = blocks[2 * f];                                      // wave uniform address: a broadcast
-                const uint4 b = blocks[2 * f + 1];
-                float p[FOLD] = {value_of(a.x), value_of(a.y), value_of(a.z), value_of(a.w), value_of(b.x), value_of(b.y), value_of(b.z), value_of(b.w)};
+            auto values_of_block = [&](int f, float (&p)[FOLD], float (&plain)[FOLD]) {
+                const uint4 a = blocks[4 * f];                                      // wave uniform address: a broadcast
+                const uint4 b = blocks[4 * f + 1];
+                const uint4 c = blocks[4 * f + 2];                                  // the high planes of the same eight words
+                const uint4 e = blocks[4 * f + 3];
+                plain[0] = value_of(a.x, c.x); plain[1] = value_of(a.y, c.y); plain[2] = value_of(a.z, c.z); plain[3] = value_of(a.w, c.w);
+                plain[4] = value_of(b.x, e.x); plain[5] = value_of(b.y, e.y); plain[6] = value_of(b.z, e.z); plain[7] = value_of(b.w, e.w);
                 if(f == n_block - 1) {
 #pragma unroll
-                    for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= unique[s]) { p[k] = 0.0f; } }
+                    for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= unique[s]) { plain[k] = 0.0f; } }
                 }
-                if(WEIGHTED) {
-                    plain_sum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-                    if(weigh) {
-                        {
-                            const float4 low = *reinterpret_cast<const float4*>(weights + FOLD * f);
-                            const float4 high = *reinterpret_cast<const float4*>(weights + FOLD * f + 4);
-                            p[0] *= low.x; p[1] *= low.y; p[2] *= low.z; p[3] *= low.w;
-                            p[4] *= high.x; p[5] *= high.y; p[6] *= high.z; p[7] *= high.w;
-                        }
-                    }
+#pragma unroll
+                for(int k = 0; k < FOLD; ++k) { p[k] = plain[k]; }
+                if(weigh) {
+                    const float4 low = *reinterpret_cast<const float4*>(weights + FOLD * f);
+                    const float4 high = *reinterpret_cast<const float4*>(weights + FOLD * f + 4);
+                    p[0] *= low.x; p[1] *= low.y; p[2] *= low.z; p[3] *= low.w;
+                    p[4] *= high.x; p[5] *= high.y; p[6] *= high.z; p[7] *= high.w;
                 }
+            };
+            for(int f = 0; f < n_block; ++f) {
+                float p[FOLD];
+                float plain[FOLD];
+                values_of_block(f, p, plain);
+                if(WEIGHTED) { plain_sum += ((plain[0] + plain[1]) + (plain[2] + plain[3])) + ((plain[4] + plain[5]) + (plain[6] + plain[7])); }
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                     // strict: the first block keeps a tie
-                second = fmaxf(second, takes_over ? best_value : block_max);
+                second = __builtin_amdgcn_fmed3f(best_value, block_max, second);    // second <= best_value: the median (pamld_lut.hpp)
                 others_sum += takes_over ? held_sum : block_sum;
                 held_sum = takes_over ? block_sum : held_sum;
                 best_block = takes_over ? f : best_block;
                 best_value = takes_over ? block_max : best_value;
             }
-            float top = 0;
+            // Inside the winning block (pamld_lut.hpp): the same instructions give the same eight values again, the
+            // winner is the first member EQUAL to the maximum the scan found, the rest is the sum of the members that are
+            // not.  Two members equal to the maximum: the block's sum less that rest is twice the maximum, not once; such a
+            // read is handed on by raising the runner up to the winner.
+            const float top = best_value;
             float top_plain = 0;
             float rest = others_sum;
             int best = -1;
-            uint32_t word = 0;
+            uint32_t flags_of_best = 0;
             {
                 const int block = best_block < 0 ? 0 : best_block;
+                float p[FOLD];
+                float plain[FOLD];
+                values_of_block(block, p, plain);
+                int within = -1;
+                float q[FOLD];
 #pragma unroll
-                for(int k = 0; k < FOLD; ++k) {
-                    const int u = FOLD * block + k;
-                    const uint32_t candidate = lds_words[s * CROSS_MAX_UNIQUE + u];
-                    const float plain = value_of(candidate);
-                    float p = weigh ? plain * weights[u] : plain;
-                    if(u >= unique[s] || best_block < 0) { p = 0.0f; }
-                    const float lower = fminf(p, top);
-                    rest += lower;
-                    second = fmaxf(second, lower);
-                    if(p > top) { best = u; word = candidate; top_plain = plain; }
-                    top = fmaxf(p, top);
+                for(int k = FOLD - 1; k >= 0; --k) {
+                    const bool is_top = p[k] == best_value;
+                    within = is_top ? k : within;
+                    top_plain = is_top ? plain[k] : top_plain;
+                    q[k] = is_top ? 0.0f : p[k];
                 }
+                const float inner_rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                const float inner_second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+                const bool crowded = held_sum - inner_rest >= 1.5f * best_value;   // the block's sum holds the maximum twice
+                second = fmaxf(second, crowded ? best_value : inner_second);
+                rest += crowded ? best_value : inner_rest;
+                if(best_block >= 0 && best_value > 0.0f && within >= 0) { best = FOLD * block + within; }
+                const int at = 16 * (best < 0 ? 0 : best / 8) + (best < 0 ? 0 : best % 8);
+                flags_of_best = (observed_low ^ segment_words[at]) | (observed_high ^ segment_words[at + 8]);
             }
 
-            if(best < 0) { certain = false; best = 0; word = lds_words[s * CROSS_MAX_UNIQUE]; }       // underflow: everything rounded to zero
+            if(best < 0) { certain = false; best = 0; }       // underflow: everything rounded to zero (flags_of_best is word 0's)
             pass_top[pass] = top;
             pass_plain[pass] = top_plain;
             pass_rest[pass] = rest;
@@ -322,7 +351,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             if(pass < S) {
                 if(!WEIGHTED) { certain = certain && top >= SMALLEST_CERTAIN && (second <= RUNNER_UP * top); }
                 // the winner's mismatch flags, its distances and its probability again in fp64
-                const uint32_t flags = (mismatch_fields(observed ^ word) | outside) & full_mask[s];
+                const uint32_t flags = (flags_of_best | outside) & full_mask[s];
                 distance += __popc(flags);
                 hq_distance += __popc(flags & high_quality);
 #pragma unroll

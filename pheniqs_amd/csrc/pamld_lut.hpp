@@ -341,9 +341,9 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             // Inside the winning block: the winner (first of equals) and the sum of the other seven.  The scan left the
             // block's maximum (best_value) and its sum (held_sum); the same instructions give the same eight values
             // again, so the winner is the first member EQUAL to best_value, the rest is the sum of the members that are
-            // not (no subtraction from the block sum, which would cancel).  Two members equal to the maximum make
-            // held_sum at least twice the maximum (floating point addition is monotone): such a read — or one whose rest
-            // of the block outweighs the winner anyway — is handed on by raising the runner up to the winner.
+            // not (no subtraction from the block sum, which would cancel).  Two members equal to the maximum: the block's
+            // sum less that rest is then twice the maximum, not once (the rest is at most seven times the maximum, so
+            // single precision tells 1 from 2 easily); such a read is handed on by raising the runner up to the winner.
             int best = -1;
             uint32_t best_flags = 0;
             float sigma = others_sum;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 }
                 const float rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
                 const float second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
-                const bool crowded = held_sum >= 2.0f * best_value;
+                const bool crowded = held_sum - rest >= 1.5f * best_value;         // the block's sum holds the maximum twice
                 runner_up = fmaxf(runner_up, crowded ? best_value : second);
                 sigma += crowded ? best_value : rest;
                 if(best_fold >= 0 && best_value > 0.0f && within >= 0) {

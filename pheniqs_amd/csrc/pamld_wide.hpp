@@ -38,15 +38,16 @@ constexpr uint32_t FIELD_MASK = 0x1e1e1e1eu;
 __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * ((position >> 2) & 3) + 1u + (position & 3); }
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
 
-__device__ __forceinline__ uint32_t mismatch_fields(uint32_t x) {
-    return x | __builtin_amdgcn_alignbit(x, x, 4);                  // x | rotr(x, 4); bits outside FIELD_MASK are junk
-}
+// the two code bits in two plane words, every other bit zero (pamld_lut.hpp): fields = (lo ^ lo') | (hi ^ hi'), and
+// what is OR-ed into the unused bits of the observed low plane (a lane's share of the table address) rides along
+__device__ __forceinline__ uint32_t low_plane(uint32_t sliced) { return sliced & FIELD_MASK; }
+__device__ __forceinline__ uint32_t high_plane(uint32_t sliced) { return __builtin_amdgcn_alignbit(sliced, sliced, 4) & FIELD_MASK; }
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;
 
 // one hand laid dynamic LDS block at LDS address 0 (no static LDS; pamld_lut.hpp)
 struct Layout {
-    uint32_t words_at;        // padded barcodes x 2 words
+    uint32_t words_at;        // padded barcodes x 2 words x 2 planes
     uint32_t prior_at;        // padded barcodes floats
     uint32_t match_at;
     uint32_t mismatch_at;
@@ -56,7 +57,7 @@ struct Layout {
 __host__ __device__ inline Layout layout_of(int groups, int threads, int padded_barcodes) {
     Layout l;
     l.words_at = static_cast<uint32_t>(groups) * 16u * static_cast<uint32_t>(threads) * 4u;
-    l.prior_at = l.words_at + static_cast<uint32_t>(padded_barcodes) * 8u;
+    l.prior_at = l.words_at + static_cast<uint32_t>(padded_barcodes) * 16u;
     l.match_at = l.prior_at + static_cast<uint32_t>(padded_barcodes) * 4u;
     l.mismatch_at = l.match_at + 528u;
     l.deferred_at = l.mismatch_at + 528u;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
     const int padded_barcodes = (n_barcode + FOLD - 1) / FOLD * FOLD;
     const Layout at = layout_of(G, THREADS, padded_barcodes);
     float* const table = reinterpret_cast<float*>(lds_raw);
-    uint2* const barcode_words = reinterpret_cast<uint2*>(lds_raw + at.words_at);
+    uint4* const barcode_words = reinterpret_cast<uint4*>(lds_raw + at.words_at);        // {low 0, low 1, high 0, high 1}
     float* const prior_single = reinterpret_cast<float*>(lds_raw + at.prior_at);
     float* const match_single = reinterpret_cast<float*>(lds_raw + at.match_at);
     float* const mismatch_single = reinterpret_cast<float*>(lds_raw + at.mismatch_at);
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
         mismatch_single[i] = static_cast<float>(e);
     }
     for(int b = threadIdx.x; b < padded_barcodes; b += THREADS) {
-        barcode_words[b] = make_uint2(d.barcode_wide[2 * b], d.barcode_wide[2 * b + 1]);
+        const uint32_t first = d.barcode_wide[2 * b];
+        const uint32_t second = d.barcode_wide[2 * b + 1];
+        barcode_words[b] = make_uint4(low_plane(first), low_plane(second), high_plane(first), high_plane(second));
         prior_single[b] = d.concentration_single[b];                 // zero for the padding
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
@@ -179,18 +182,24 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
                 }
             }
 
-            // P(r|b) of one barcode from its two words; also leaves the mismatch fields
-            auto probability_of = [&](const uint2 pair, uint32_t (&fields)[WORDS]) {
-                fields[0] = mismatch_fields(observed[0] ^ pair.x);
-                fields[1] = mismatch_fields(observed[1] ^ pair.y);
+            uint32_t observed_low[WORDS];
+            uint32_t observed_high[WORDS];
+#pragma unroll
+            for(int w = 0; w < WORDS; ++w) {
+                observed_low[w] = low_plane(observed[w]) | (PERMUTED ? lane_high_bytes : 0u);
+                observed_high[w] = high_plane(observed[w]);
+            }
+            // P(r|b) of one barcode from its plane words; also leaves the mismatch fields
+            auto probability_of = [&](const uint4 quad, uint32_t (&fields)[WORDS]) {
+                fields[0] = (observed_low[0] ^ quad.x) | (observed_high[0] ^ quad.z);
+                fields[1] = (observed_low[1] ^ quad.y) | (observed_high[1] ^ quad.w);
                 float value = 1.0f;
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
                     uint32_t address;
                     if(PERMUTED) {
-                        const uint32_t cleaned = (fields[g >> 2] & FIELD_MASK) | lane_high_bytes;
-                        // { 0, 0, cleaned.byte[g % 4], lane_low.byte[0] }: byte 1 = (lane >> 6) | index << 1
-                        address = __builtin_amdgcn_perm(cleaned, lane_low, 0x0c0c0400u | (static_cast<uint32_t>(g & 3) << 8));
+                        // { 0, 0, fields.byte[g % 4], lane_low.byte[0] }: byte 1 = (lane >> 6) | index << 1
+                        address = __builtin_amdgcn_perm(fields[g >> 2], lane_low, 0x0c0c0400u | (static_cast<uint32_t>(g & 3) << 8));
                     } else {
                         const uint32_t index = __builtin_amdgcn_ubfe(fields[g >> 2], 8 * (g & 3) + 1, 4);
                         address = index * ENTRY_STEP + lane_offset;                         // v_mad_u32_u24
@@ -208,12 +217,11 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
             float runner_up = 0;           // the largest block maximum but the running one
             int best_fold = -1;
             const int n_fold = padded_barcodes / FOLD;
-            for(int f = 0; f < n_fold; ++f) {
-                float p[FOLD];
+            auto values_of_block = [&](int f, float (&p)[FOLD]) {
 #pragma unroll
                 for(int k = 0; k < FOLD; ++k) {
                     uint32_t fields[WORDS];
-                    p[k] = probability_of(barcode_words[FOLD * f + k], fields);           // wave uniform address
+                    p[k] = probability_of(barcode_words[FOLD * f + k], fields);           // wave uniform address in the scan
                 }
                 if(!uniform_prior) {
 #pragma unroll
@@ -223,45 +231,52 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
 #pragma unroll
                     for(int k = 1; k < FOLD; ++k) { if(FOLD * f + k >= n_barcode) { p[k] = 0.0f; } }
                 }
+            };
+            for(int f = 0; f < n_fold; ++f) {
+                float p[FOLD];
+                values_of_block(f, p);
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                          // strict: the first block keeps a tie
-                runner_up = fmaxf(runner_up, takes_over ? best_value : block_max);
+                runner_up = __builtin_amdgcn_fmed3f(best_value, block_max, runner_up);   // runner_up <= best_value: the median
                 others_sum += takes_over ? held_sum : block_sum;
                 held_sum = takes_over ? block_sum : held_sum;
                 best_fold = takes_over ? f : best_fold;
                 best_value = takes_over ? block_max : best_value;
             }
 
-            // inside the winning block: the winner (first of equals) and the sum of the other seven
+            // inside the winning block (pamld_lut.hpp): the winner is the first member EQUAL to the maximum the scan
+            // found, the rest the sum of the members that are not; two members equal to the maximum show in the block's
+            // sum and hand the read on
             int best = -1;
             uint32_t best_flags[WORDS];
 #pragma unroll
             for(int w = 0; w < WORDS; ++w) { best_flags[w] = 0; }
             float sigma = others_sum;
-            float winner_single = 0;
+            const float winner_single = best_value;
             {
                 const int block = best_fold < 0 ? 0 : best_fold;
-                float top = 0;
-                float rest = 0;
+                float p[FOLD];
+                values_of_block(block, p);
+                int within = -1;
+                float q[FOLD];
 #pragma unroll
-                for(int k = 0; k < FOLD; ++k) {
-                    const int b = FOLD * block + k;
-                    uint32_t fields[WORDS];
-                    float p = probability_of(barcode_words[b], fields);
-                    if(!uniform_prior) { p *= prior_single[b]; }
-                    if(b >= n_barcode || best_fold < 0) { p = 0.0f; }
-                    rest += fminf(p, top);
-                    runner_up = fmaxf(runner_up, fminf(p, top));
-                    if(p > top) {
-                        best = b;
-#pragma unroll
-                        for(int w = 0; w < WORDS; ++w) { best_flags[w] = (fields[w] | outside[w]) & full_mask[w]; }
-                    }
-                    top = fmaxf(p, top);
+                for(int k = FOLD - 1; k >= 0; --k) {
+                    const bool is_top = p[k] == best_value;
+                    within = is_top ? k : within;
+                    q[k] = is_top ? 0.0f : p[k];
                 }
-                sigma += rest;
-                winner_single = top;
+                const float rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                const float second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+                const bool crowded = held_sum - rest >= 1.5f * best_value;               // the block's sum holds the maximum twice
+                runner_up = fmaxf(runner_up, crowded ? best_value : second);
+                sigma += crowded ? best_value : rest;
+                if(best_fold >= 0 && best_value > 0.0f && within >= 0) {
+                    best = FOLD * block + within;
+                    const uint4 quad = barcode_words[best];
+                    best_flags[0] = (((observed_low[0] ^ quad.x) | (observed_high[0] ^ quad.z)) | outside[0]) & full_mask[0];
+                    best_flags[1] = (((observed_low[1] ^ quad.y) | (observed_high[1] ^ quad.w)) | outside[1]) & full_mask[1];
+                }
             }
 
             if(best < 0) {
