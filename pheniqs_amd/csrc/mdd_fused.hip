@@ -21,8 +21,11 @@
 namespace phq {
 namespace {
 
-constexpr int READS = 4;                             // reads per lane and pass of the exact phase
-constexpr int RING = 1280;                           // ring capacity: at most 255 left over + 1024 pushed per pass
+// Reads per lane and pass of the exact phase.  The ring's size follows from it, and the ring is most of the kernel's
+// LDS: 4 reads (30 KiB of ring, 3 workgroups per CU) measured 2.24 ms per 100 M C2 reads, 2 reads (18 KiB, 4
+// workgroups) 1.95 ms, 1 read (12 KiB, 5 workgroups, but one load in flight per lane) 2.15 ms.
+constexpr int READS = 2;
+constexpr int RING = 768;                            // ring capacity: at most 255 left over + READS x 256 pushed per pass
 constexpr int FUSED_LDS_SLOTS = 1024;                // hash table slots kept in LDS
 constexpr int FUSED_LDS_WORDS = 256;                 // packed barcode words kept in LDS
 
