@@ -22,10 +22,12 @@ namespace phq {
 namespace {
 
 // Reads per lane and pass of the exact phase.  The ring's size follows from it, and the ring is most of the kernel's
-// LDS: 4 reads (30 KiB of ring, 3 workgroups per CU) measured 2.24 ms per 100 M C2 reads, 2 reads (18 KiB, 4
-// workgroups) 1.95 ms, 1 read (12 KiB, 5 workgroups, but one load in flight per lane) 2.15 ms.
-constexpr int READS = 2;
-constexpr int RING = 768;                            // ring capacity: at most 255 left over + READS x 256 pushed per pass
+// LDS, which decides how many workgroups share a CU; this kernel lives on loads and waves in flight.  Per 100 M C2
+// reads: 4 reads per lane with the 16 byte hash slots and the 12 word histogram bins of the other kernels (48 KiB,
+// 3 workgroups per CU) 2.24 ms; 2 reads (4 workgroups) 1.95 ms; with 8 byte slots and the compact histogram below
+// 2 reads (26 KiB, 6 workgroups) 1.92 ms, 3 reads (5 workgroups) 1.67-1.85 ms, 4 reads (38 KiB, 4 workgroups) 1.68 ms.
+constexpr int READS = 4;
+constexpr int RING = 1280;                           // ring capacity: at most 255 left over + READS x 256 pushed per pass
 constexpr int FUSED_LDS_SLOTS = 1024;                // hash table slots kept in LDS
 constexpr int FUSED_LDS_WORDS = 256;                 // packed barcode words kept in LDS
 
@@ -37,7 +39,6 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
     constexpr int LMAX = 4 * ROW_WORDS;
     constexpr bool PAIRED = ROW_WORDS <= 2;          // up to 8 nt: two barcodes per packed word
     constexpr int stride = 4 * ROW_WORDS;
-    __shared__ __attribute__((aligned(16))) uint32_t packed[FUSED_LDS_WORDS];
     __shared__ uint32_t ring_index[RING];
     __shared__ uint32_t ring_state[RING];
     __shared__ uint32_t ring_code[RING][ROW_WORDS];
@@ -45,21 +46,46 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
     __shared__ uint32_t ring_tail;                   // entries ever pushed
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     DecoderRef d = *constant_cast(args.decoder);
-    uint4* const table = reinterpret_cast<uint4*>(lds_raw);                  // the hash table, exact_slots entries, then the histogram
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + static_cast<size_t>(d.exact_slots) * sizeof(uint4));
-
+    // The dynamic block, sized by the codec (fused_lds_bytes): everything here is kept small because the kernel's LDS
+    // decides how many workgroups share a CU, and this kernel lives on waves in flight.
+    //   hash table   exact_slots x {key, ordinal + 1}: 8 bytes, a key of up to 16 nt is one word
+    //   index        the Classifier index of every barcode (what the 16 byte slots of mdd_exact_kernel carry)
+    //   packed       the bit-sliced barcode words of the scan
+    //   histogram    count and distance only, per bin and [QC fail | pass filter]: 4 words per bin instead of 12
     const int L = d.nucleotide_cardinality;
     const int n_barcode = d.n_barcode;
     const int n_segment = SEGMENTS > 0 ? SEGMENTS : d.n_segment;
     const int padded_barcodes = (n_barcode + 7) & ~7;
     const int n_word = PAIRED ? padded_barcodes >> 1 : padded_barcodes;
-    for(uint32_t slot = threadIdx.x; slot < d.exact_slots; slot += BLOCK) { table[slot] = reinterpret_cast<const uint4*>(d.exact_table)[slot]; }
+    uint2* const table = reinterpret_cast<uint2*>(lds_raw);
+    int32_t* const index_of = reinterpret_cast<int32_t*>(lds_raw + static_cast<size_t>(d.exact_slots) * sizeof(uint2));
+    uint32_t* const packed = reinterpret_cast<uint32_t*>(index_of + padded_barcodes);                     // 16 byte aligned: slots and padding are multiples of 8
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(packed + n_word);
+    const int compact_bins = d.use_lds_histogram ? n_barcode + 1 : 1;                                      // bin 0 always (kernel_common.hpp)
+    for(uint32_t slot = threadIdx.x; slot < d.exact_slots; slot += BLOCK) {
+        const uint4 entry = reinterpret_cast<const uint4*>(d.exact_table)[slot];
+        table[slot] = make_uint2(entry.x, entry.z);
+    }
+    for(int b = threadIdx.x; b < padded_barcodes; b += BLOCK) { index_of[b] = b < n_barcode ? d.barcode_index[b] : 0; }
     for(int w = threadIdx.x; w < n_word; w += BLOCK) { packed[w] = d.barcode_packed2[w]; }
     if(threadIdx.x == 0) { ring_tail = 0; }
-    histogram_clear(d, histogram);
+    for(int w = threadIdx.x; w < STAT_JOB_WORDS + 4 * compact_bins; w += BLOCK) { histogram[w] = 0; }
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
+    // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86) on the compact histogram
+    const bool defer_counters = args.defer_counters != 0;
+    auto add = [&](int bin, int pf, int field, unsigned long long value) {                                 // field 0 = count, 1 = distance
+        if(d.use_lds_histogram || bin == 0) { atomicAdd(&histogram[STAT_JOB_WORDS + 4 * bin + 2 * pf + field], value); }
+        else { atomicAdd(&args.stats[d.stats_offset + bin * STAT_WORDS_PER_BIN + pf * STAT_FIELDS + (field ? FIELD_DISTANCE : FIELD_COUNT)], value); }
+    };
+    auto tail_of = [&](ReadState& r, int bin, int distance) {
+        const int pf = r.qcfail ? 0 : 1;
+        if(!(defer_counters && bin > 0)) {
+            if(bin > 0 && distance) { add(bin, pf, 1, static_cast<unsigned long long>(distance)); }
+            add(bin, pf, 0, 1ull);
+        }
+        if(d.multiplexing) { r.channel = bin > 0 ? index_of[bin - 1] : 0; }
+    };
     const uint32_t slot_mask = d.exact_slots - 1u;
     int tolerance[DEV_MAX_SEGMENT];
 #pragma unroll
@@ -146,10 +172,10 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
         uint8_t status = STATUS_PASS;
         if(bin == 0) { r.qcfail = true; status = STATUS_UNCLASSIFIED; }          // mdd.cpp:82-84
         if(active) {
-            decoder_tail(d, sink, r, bin, distance);
+            tail_of(r, bin, distance);
             if(args.result) {
                 DevResult out;
-                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.index = bin > 0 ? index_of[bin - 1] : 0;
                 out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
                 out.hq_distance = 0;
                 out.status = status;
@@ -214,14 +240,14 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
                 uint32_t h = (key[0] * 0x9e3779b1u) ^ (key[1] * 0x85ebca77u);
                 h ^= h >> 15;
                 for(int probe = 0; probe < d.exact_probes; ++probe) {
-                    const uint4 entry = table[(h + probe) & slot_mask];
-                    if(entry.z == 0u) { break; }                       // empty slot: not a barcode
-                    if(entry.x == key[0] && entry.y == key[1]) { bin = static_cast<int>(entry.z); barcode_index = static_cast<int32_t>(entry.w); break; }
+                    const uint2 entry = table[(h + probe) & slot_mask];
+                    if(entry.y == 0u) { break; }                       // empty slot: not a barcode
+                    if(entry.x == key[0]) { bin = static_cast<int>(entry.y); barcode_index = index_of[bin - 1]; break; }     // key[1] == 0 up to 16 nt
                 }
             }
             const bool defer = active[u] && bin == 0;
             if(active[u] && !defer) {
-                decoder_tail(d, sink, state, bin, 0);
+                tail_of(state, bin, 0);
                 if(args.result) {
                     DevResult out;
                     out.index = barcode_index;
@@ -269,7 +295,25 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
         if(tail - head > 0) { scan_ring(head, tail - head); }
     }
     __syncthreads();
-    histogram_flush(args, d, histogram);
+    // one global atomic per non zero word per workgroup, back in the counter buffer's layout
+    for(int w = threadIdx.x; w < STAT_JOB_WORDS; w += BLOCK) {
+        const unsigned long long v = histogram[w];
+        if(v) { atomicAdd(&args.stats[w], v); }
+    }
+    for(int w = threadIdx.x; w < 4 * compact_bins; w += BLOCK) {
+        const unsigned long long v = histogram[STAT_JOB_WORDS + w];
+        const int bin = w >> 2;
+        const int pf = (w >> 1) & 1;
+        if(v) { atomicAdd(&args.stats[d.stats_offset + bin * STAT_WORDS_PER_BIN + pf * STAT_FIELDS + ((w & 1) ? FIELD_DISTANCE : FIELD_COUNT)], v); }
+    }
+}
+
+// bytes of the kernel's dynamic LDS block (the layout at the top of the kernel)
+size_t fused_lds_bytes(const DevDecoder& host_decoder) {
+    const size_t padded = static_cast<size_t>((host_decoder.n_barcode + 7) & ~7);
+    const size_t words = host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
+    const size_t bins = host_decoder.use_lds_histogram ? static_cast<size_t>(host_decoder.n_barcode) + 1 : 1;
+    return static_cast<size_t>(host_decoder.exact_slots) * 8 + padded * 4 + words * 4 + (STAT_JOB_WORDS + 4 * bins) * 8;
 }
 
 template <int ROW_WORDS>
@@ -291,11 +335,12 @@ bool mdd_fused_supports(const DevDecoder& host_decoder) {
 }
 
 int launch_mdd_fused(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    (void)lds_bytes;                                     // the generic histogram's size: this kernel keeps a compact one
     switch(host_decoder.plane_stride / 4) {
-        case 1: return launch_rows<1>(args, host_decoder.n_segment, grid, lds_bytes + host_decoder.exact_slots * 16, stream);
-        case 2: return launch_rows<2>(args, host_decoder.n_segment, grid, lds_bytes + host_decoder.exact_slots * 16, stream);
-        case 3: return launch_rows<3>(args, host_decoder.n_segment, grid, lds_bytes + host_decoder.exact_slots * 16, stream);
-        case 4: return launch_rows<4>(args, host_decoder.n_segment, grid, lds_bytes + host_decoder.exact_slots * 16, stream);
+        case 1: return launch_rows<1>(args, host_decoder.n_segment, grid, fused_lds_bytes(host_decoder), stream);
+        case 2: return launch_rows<2>(args, host_decoder.n_segment, grid, fused_lds_bytes(host_decoder), stream);
+        case 3: return launch_rows<3>(args, host_decoder.n_segment, grid, fused_lds_bytes(host_decoder), stream);
+        case 4: return launch_rows<4>(args, host_decoder.n_segment, grid, fused_lds_bytes(host_decoder), stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }
