@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "compile.hpp"
@@ -157,7 +158,9 @@ void DecoderSet::build_device_images() {
     check(hipSetDevice(device_), "hipSetDevice");
     hipDeviceProp_t properties;
     check(hipGetDeviceProperties(&properties, device_), "hipGetDeviceProperties");
-    max_blocks_ = properties.multiProcessorCount * 8;      // 8 workgroups of 256 per CU: well past the 256 CUs (guide §6 G11)
+    // the largest grid of any stage kernel, 16 workgroups per CU; stage.hip picks each kernel's own share of it
+    // (well past the 256 CUs either way, guide §6 G11)
+    max_blocks_ = properties.multiProcessorCount * GRID_BLOCKS_PER_CU;
 
     auto upload = [&](const void* source, size_t bytes) -> void* {
         void* pointer = nullptr;
@@ -530,13 +533,9 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
 size_t DecoderSet::worklist_words(int64_t n_read) const {
-    size_t worst = 0;
-    for(int64_t threads : {128, 192, 256, 512}) {     // workgroup sizes the product form kernels use (stage.hip)
-        const int64_t tiles = (n_read + threads - 1) / threads;
-        const int64_t grid = std::min<int64_t>(std::max<int64_t>(tiles, 1), max_blocks_);
-        const int64_t tiles_per_block = (tiles + grid - 1) / grid;
-        worst = std::max(worst, static_cast<size_t>(grid * tiles_per_block * threads));
-    }
+    // whatever the grid (at most max_blocks_ workgroups of at most 512 lanes): grid * ceil(tiles / grid) * threads
+    // is less than n_read + (grid + 1) * threads
+    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 512;
     return static_cast<size_t>(max_blocks_) + worst + static_cast<size_t>(max_blocks_) * 1024 + 512;      // + the 4 tile passes of the MDD exact kernel
 }
 

@@ -20,6 +20,18 @@ constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
 constexpr int STAT_FIELDS = 6;
 constexpr int STAT_WORDS_PER_BIN = 2 * STAT_FIELDS;
 constexpr int STAT_JOB_WORDS = 2;
+
+// Grid sizes, in workgroups per CU (the kernels are persistent: grid stride over tiles).  max_blocks = 16 per CU is
+// what DecoderSet sizes the worklist for; each stage kernel takes the share that measured best on MI355X — more
+// workgroups even out the tail, fewer amortise a kernel's set up (its LDS tables) over more tiles:
+//   product form PAMLD (pamld_lut.hpp) 12: C2 28.3 (8) -> 29.0 (12) -> 28.6 (16) Greads/s
+//   fused MDD (mdd_fused.hip)          16: C2 55.4 (8) -> 57.6 (12) -> 60.2 (16) Greads/s
+//   factorised / wide PAMLD, the rest   8: C3 8.02 (8) -> 7.73 (12) -> 7.49 (16) Greads/s
+constexpr int GRID_BLOCKS_PER_CU = 16;
+constexpr int GRID_SHARE_LUT = 12;
+constexpr int GRID_SHARE_MDD_FUSED = 16;
+constexpr int GRID_SHARE_DEFAULT = 8;
+
 constexpr int CONFIDENCE_FRACTION_BITS = 52;
 constexpr int CONFIDENCE_LIMB_BITS = 26;
 enum StatField : int32_t {

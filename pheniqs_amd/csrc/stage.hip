@@ -1,4 +1,6 @@
 // Stage dispatcher: picks the kernel for one decoder and sizes the launch.
+#include <algorithm>
+
 #include "kernel_common.hpp"
 
 namespace phq {
@@ -42,13 +44,16 @@ int launch_stage(const StageArgs& caller_args, const DevDecoder& host_decoder, i
     const int status = launch_classifier(args, host_decoder, mode, max_blocks, stream, timer);
     if(status != 0 || !args.defer_counters) { return status; }
     Timed timed(timer, KERNEL_COUNT, stream);
-    return launch_count_results(args, host_decoder, max_blocks / 8, static_cast<hipStream_t>(stream));
+    return launch_count_results(args, host_decoder, max_blocks / GRID_BLOCKS_PER_CU, static_cast<hipStream_t>(stream));      // one workgroup per CU
 }
 
 int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
     if(args.n_read <= 0) { return static_cast<int>(hipSuccess); }
     const int64_t tiles = (args.n_read + BLOCK - 1) / BLOCK;
-    const dim3 grid(static_cast<unsigned>(tiles < max_blocks ? tiles : max_blocks));
+    const int64_t cus = max_blocks / GRID_BLOCKS_PER_CU > 0 ? max_blocks / GRID_BLOCKS_PER_CU : 1;
+    auto share = [&](int blocks_per_cu) { return std::min<int64_t>(max_blocks, cus * blocks_per_cu); };
+    const int64_t default_blocks = share(GRID_SHARE_DEFAULT);
+    const dim3 grid(static_cast<unsigned>(tiles < default_blocks ? tiles : default_blocks));
     const size_t histogram_bytes = sizeof(unsigned long long) *
         static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : STAT_WORDS_PER_BIN));
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -63,7 +68,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool long_words = !pamld_lut_supports(host_decoder) && !factorised;
                 const int64_t threads = factorised ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
-                const dim3 wide_grid(static_cast<unsigned>(wide_tiles < max_blocks ? wide_tiles : max_blocks));
+                const int64_t product_blocks = (factorised || long_words) ? default_blocks : share(GRID_SHARE_LUT);
+                const dim3 wide_grid(static_cast<unsigned>(wide_tiles < product_blocks ? wide_tiles : product_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
                 StageArgs producer = args;
                 producer.worklist_role = 1;
@@ -95,7 +101,9 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
             if(mode == MODE_FAST && mdd_fused_supports(host_decoder)) {
                 // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
                 Timed timed(timer, KERNEL_MDD, stream);
-                return launch_mdd_fused(args, host_decoder, grid, histogram_bytes, s);
+                const int64_t fused_blocks = share(GRID_SHARE_MDD_FUSED);
+                const dim3 fused_grid(static_cast<unsigned>(tiles < fused_blocks ? tiles : fused_blocks));
+                return launch_mdd_fused(args, host_decoder, fused_grid, histogram_bytes, s);
             }
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: exact match lookup over every read; tier 2: the scan kernel on what it deferred (same grid)
