@@ -28,8 +28,8 @@ namespace {
 // 2 reads (26 KiB, 6 workgroups) 1.92 ms, 3 reads (5 workgroups) 1.67-1.85 ms, 4 reads (38 KiB, 4 workgroups) 1.68 ms.
 constexpr int READS = 4;
 constexpr int RING = 1280;                           // ring capacity: at most 255 left over + READS x 256 pushed per pass
-constexpr int FUSED_LDS_SLOTS = 1024;                // hash table slots kept in LDS
-constexpr int FUSED_LDS_WORDS = 256;                 // packed barcode words kept in LDS
+constexpr int FUSED_LDS_SLOTS = 2048;                // hash table slots kept in LDS (8 bytes each): codecs of up to 512 barcodes
+constexpr int FUSED_LDS_WORDS = 512;                 // packed barcode words kept in LDS
 
 __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
@@ -330,7 +330,8 @@ int launch_rows(const StageArgs& args, int segments, dim3 grid, size_t lds_bytes
 bool mdd_fused_supports(const DevDecoder& host_decoder) {
     const int padded = (host_decoder.n_barcode + 7) & ~7;
     const int words = host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
-    return host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder) && mdd_scan_supports(host_decoder) &&
+    return host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder) && host_decoder.all_strict && host_decoder.barcode_packed2 != nullptr &&
+           host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
            host_decoder.exact_slots <= static_cast<uint32_t>(FUSED_LDS_SLOTS) && words <= FUSED_LDS_WORDS;
 }
 

@@ -11,11 +11,11 @@ static int packed_words(const DevDecoder& host_decoder) {
     return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
 }
 
-// ACGT barcodes of up to 16 nt whose packed words fit the kernel's 1 KiB of LDS; the byte parallel quality
+// ACGT barcodes of up to 16 nt and at most 512 packed words (LUT_MAX_WORDS: their two planes take 4 KiB of LDS); the byte parallel quality
 // compare of the kernel covers thresholds up to 128
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
     return host_decoder.all_strict && host_decoder.high_quality_threshold <= 128 && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
-           host_decoder.n_barcode > 0 && packed_words(host_decoder) <= 256 && host_decoder.barcode_packed2 != nullptr;
+           host_decoder.n_barcode > 0 && packed_words(host_decoder) <= 512 && host_decoder.barcode_packed2 != nullptr;
 }
 
 int pamld_lut_block(const DevDecoder& host_decoder) {

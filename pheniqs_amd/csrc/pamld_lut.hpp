@@ -78,9 +78,16 @@ template <int L> struct LutGeometry {
     static constexpr uint32_t MATCH_AT = TABLE_AT + TABLE_BYTES;           // FACTOR_ROWS x {match, mismatch} floats
     static constexpr uint32_t FACTOR_AT = MATCH_AT + 1056;                 // FACTOR_ROWS x [match | mismatch] doubles
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 129 * 16;          // one counter
-    static constexpr uint32_t WORDS_AT = DEFERRED_AT + 16;                 // the barcode words, up to 256, as two planes
-    static constexpr uint32_t HISTOGRAM_AT = WORDS_AT + 2048;              // the counter histogram (kernel_common.hpp)
+    static constexpr uint32_t WORDS_AT = DEFERRED_AT + 16;                 // the barcode words, as two planes: words_bytes()
+    // ... then the counter histogram (kernel_common.hpp).  The words region is as long as the codec needs: two
+    // workgroups of the 8 nt shape fit a CU with a few KiB to spare, which a fixed 4 KiB region would use up.
+    static constexpr int PER_WORD = L <= 8 ? 2 : 1;
+    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) {
+        return static_cast<uint32_t>(((n_barcode + 7) & ~7) / PER_WORD) * 2u * 4u;          // a multiple of 32
+    }
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }
 };
+constexpr int LUT_MAX_WORDS = 512;                // packed words of a codec: 1 024 barcodes of up to 8 nt, 512 of 9 to 16 nt
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 
@@ -98,8 +105,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::MATCH_AT);       // [row] {match, mismatch}
     double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + Layout::FACTOR_AT);   // [row][0 match | 1 mismatch]
     uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + Layout::DEFERRED_AT);
-    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::HISTOGRAM_AT);
     DecoderRef d = *constant_cast(args.decoder);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::histogram_at(d.n_barcode));
 
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
         const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
@@ -475,8 +482,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 }
 
 template <int L, bool UNIFORM_PRIOR>
-int launch_one(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t lds_bytes = LutGeometry<L>::HISTOGRAM_AT + histogram_bytes;
+int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    const size_t lds_bytes = LutGeometry<L>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
     if(const int status = allow_large_lds(&pamld_lut_kernel<L, UNIFORM_PRIOR>, prepared)) { return status; }
     hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
@@ -491,8 +498,8 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            return host_decoder.uniform_prior ? launch_one<LO, true>(args, grid, histogram_bytes, stream)
-                                              : launch_one<LO, false>(args, grid, histogram_bytes, stream);
+            return host_decoder.uniform_prior ? launch_one<LO, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)
+                                              : launch_one<LO, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
         }
         return launch_range<LO + 1, HI>(args, host_decoder, grid, histogram_bytes, stream);
     }

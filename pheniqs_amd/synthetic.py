@@ -52,15 +52,20 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
     return spec
 
 
+# BASELINE.json's C2..C5 plus two shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
+# 8 + 8 nt in one two segment sample decoder (not every combination: pair i is word i of each list)
+CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7}
+
+
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
     """Compiled job + generation recipe for BASELINE config C2..C5.  seed = 20240613 + config number."""
-    number = {"C2": 2, "C3": 3, "C4": 4, "C5": 5}[name]
+    number = CONFIG_NUMBER[name]
     return jobspec.compile_job(config_spec(name, algorithm)), {"name": name, "seed": BASE_SEED + number}
 
 
 def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
     """The user level (uncompiled) job document of BASELINE config C2..C5."""
-    number = {"C2": 2, "C3": 3, "C4": 4, "C5": 5}[name]
+    number = CONFIG_NUMBER[name]
     rng = np.random.default_rng(BASE_SEED + number)
     if name == "C2":        # single 8 bp i7 index, 96 barcodes
         words = barcode_set(rng, 96, 8)
@@ -76,6 +81,11 @@ def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
                 "molecular": [{"algorithm": "naive", "transform": {"token": ["0::8"]}}],
                 "cellular": [decoder_spec(algorithm, [a], ["0:8:18"]),
                              decoder_spec(algorithm, [b, c], ["1::10", "2::10"], pairing="zip")]}
+    elif name in ("U96", "U384"):      # unique dual index pairs, i7 + i5 of 8 nt each
+        pairs = 96 if name == "U96" else 384
+        i7, i5 = barcode_set(rng, pairs, 8), barcode_set(rng, pairs, 8)
+        spec = {"input segment cardinality": 3,
+                "sample": decoder_spec(algorithm, [i7, i5], ["1::8", "2::8"], pairing="zip")}
     else:                   # C5 SPLiT-seq: cellular [96 x 8] x 3 + 4 x 6 reverse complemented, naive UMI 10
         r1, r2, r3 = barcode_set(rng, 96, 8), barcode_set(rng, 96, 8), barcode_set(rng, 96, 8)
         r4 = barcode_set(rng, 4, 6)

@@ -739,10 +739,12 @@ def test_high_quality_threshold_beyond_the_byte_parallel_compare(oracle, torch_c
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
-@pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (12, 33), (16, 256), (16, 260), (32, 5)])
+@pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (8, 1024), (8, 1030), (12, 33),
+                                          (16, 256), (16, 260), (16, 512), (16, 515), (32, 5)])
 def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     """The smallest and the largest codecs each kernel family takes, and the first sizes past them (which fall back
-    to the next family): one barcode, one nucleotide, 512 barcodes of 8 nt in 256 packed words, 256 of 16 nt."""
+    to the next family): one barcode, one nucleotide, 1 024 barcodes of 8 nt in 512 packed words, 512 of 16 nt; 512 /
+    256 were the limits of the first version and stay as cases."""
     rng = np.random.default_rng(length * 1000 + count)
     words = synthetic.barcode_set(rng, count, length, min_distance=1 if length < 6 or count > 200 else 3)
     job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec(algorithm, [words], ["0::%d" % length])})
@@ -750,6 +752,17 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     code, quality, flag, offsets = synthetic.generate_rows(job, n, 3)
     code[rng.random((n, length)) < 0.01] = 15
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+@pytest.mark.parametrize("name", ["U96", "U384"])
+def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
+    """96 / 384 PAIRS of 8 + 8 nt in one two segment decoder (not every combination): the 16 nt product form / fused
+    kernels, 384 pairs past the workgroup histogram (counters rebuilt from the records)."""
+    job, recipe = synthetic.config_job(name, algorithm)
+    n = 20000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=2)
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
