@@ -755,12 +755,13 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
-@pytest.mark.parametrize("name", ["U96", "U384"])
+@pytest.mark.parametrize("name", ["U96", "U384", "V384", "S384"])
 def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
     """96 / 384 PAIRS of 8 + 8 nt in one two segment decoder (not every combination): the 16 nt product form / fused
-    kernels, 384 pairs past the workgroup histogram (counters rebuilt from the records)."""
+    kernels, 384 pairs past the workgroup histogram (counters rebuilt from the records); 384 pairs of 10 + 10 nt (the
+    two word product form kernel) and 384 single 8 nt indexes."""
     job, recipe = synthetic.config_job(name, algorithm)
-    n = 20000
+    n = 20000 if name != "V384" else 12000
     code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=2)
 
