@@ -185,6 +185,16 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
  * Records keep the input order inside every file. */
 int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
 
+/* What phq_transcode_job would open, without opening it: the counterpart of the `feed` section the reference's compile
+ * step leaves in the job (transcode.cpp:683-733 "input feed" / "input feed by segment", 1373-1413 "output feed") and of
+ * the channels' output routing (multiplex.h:198-240).  *plan_json (release with phq_free_string):
+ *   {"input feed": [{index, url, resolution}], "input feed by segment": [[feed, position in its resolution]],
+ *    "output feed": [{index, url, format fastq|sam, compression none|gz, compression level, resolution}],
+ *    "channel": [{index (0 = undetermined, then the multiplexing decoder's barcodes in order),
+ *                 "output feed by segment": [feed per output segment, empty = discarded], "filter outgoing qc fail"}]}
+ * The same configuration errors as phq_transcode_job; needs no device. */
+int phq_transcode_plan(phq_decoder_set* set, char** plan_json);
+
 /* Measurement aid (the reference has no timers): when enabled, every kernel launch of
  * phq_classify_* is bracketed by HIP events on its own stream.  phq_profile_collect waits for them, returns
  * the summed milliseconds and the launch count per kernel kind, and forgets them. */

@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job",
+           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
            "phq_compile_job", "phq_free_string", "phq_adjust_prior")
 
 
@@ -97,6 +97,7 @@ def load_library():
     L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
     L.phq_transcode_fastq_to_sam.argtypes = [P, I32, P, ctypes.c_char_p, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
     L.phq_transcode_job.argtypes = [P, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
+    L.phq_transcode_plan.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
@@ -259,6 +260,15 @@ class DecoderSet:
         incoming_pf = ctypes.c_uint64(0)
         self._check(self.lib.phq_transcode_job(self.handle, batch_capacity, ctypes.byref(incoming), ctypes.byref(incoming_pf)))
         return incoming.value, incoming_pf.value
+
+    def transcode_plan(self) -> Dict[str, Any]:
+        """phq_transcode_plan: the feeds and channel routing phq_transcode_job would use (no device needed)."""
+        out = ctypes.c_void_p()
+        self._check(self.lib.phq_transcode_plan(self.handle, ctypes.byref(out)))
+        try:
+            return json.loads(ctypes.string_at(out.value).decode())
+        finally:
+            self.lib.phq_free_string(out)
 
     def adjust_prior(self, words: np.ndarray, job: Dict[str, Any]) -> Dict[str, Any]:
         """phq_adjust_prior: `job` with estimated noise / concentration priors from the counters in `words`."""

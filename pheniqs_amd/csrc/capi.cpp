@@ -254,6 +254,61 @@ int phq_compile_job(const char* job_json, char** compiled_json) {
 
 void phq_free_string(char* text) { std::free(text); }
 
+int phq_transcode_plan(phq_decoder_set* set, char** plan_json) {
+    if(plan_json != nullptr) { *plan_json = nullptr; }
+    return guarded(set, [&]() {
+        require(set, "set"); require(plan_json, "plan_json");
+        const phq::TranscodePlan plan = phq::TranscodePlan::from_job(set->impl.job());
+        phq::Json document = phq::Json::object();
+        phq::Json input_feed = phq::Json::array();
+        for(size_t f = 0; f < plan.input_feed.size(); ++f) {
+            phq::Json feed = phq::Json::object();
+            feed.set("index", phq::Json::integer(static_cast<int64_t>(f)));
+            feed.set("url", phq::Json::string(plan.input_feed[f].path));
+            feed.set("resolution", phq::Json::integer(plan.input_feed[f].resolution));
+            input_feed.push(feed);
+        }
+        phq::Json by_segment = phq::Json::array();
+        for(const auto& where : plan.input_segment) {
+            phq::Json pair = phq::Json::array();
+            pair.push(phq::Json::integer(where.first));
+            pair.push(phq::Json::integer(where.second));
+            by_segment.push(pair);
+        }
+        phq::Json output_feed = phq::Json::array();
+        for(size_t f = 0; f < plan.output_feed.size(); ++f) {
+            const auto& from = plan.output_feed[f];
+            phq::Json feed = phq::Json::object();
+            feed.set("index", phq::Json::integer(static_cast<int64_t>(f)));
+            feed.set("url", phq::Json::string(from.path));
+            feed.set("format", phq::Json::string(from.format == phq::FileFormat::FASTQ ? "fastq" : "sam"));
+            feed.set("compression", phq::Json::string(from.gzip ? "gz" : "none"));
+            feed.set("compression level", phq::Json::integer(from.level));
+            feed.set("resolution", phq::Json::integer(from.resolution));
+            output_feed.push(feed);
+        }
+        phq::Json channel = phq::Json::array();
+        for(size_t c = 0; c < plan.channel.size(); ++c) {
+            phq::Json record = phq::Json::object();
+            record.set("index", phq::Json::integer(static_cast<int64_t>(c)));
+            phq::Json feeds = phq::Json::array();
+            for(const int32_t f : plan.channel[c].feed_by_segment) { feeds.push(phq::Json::integer(f)); }
+            record.set("output feed by segment", feeds);
+            record.set("filter outgoing qc fail", phq::Json::boolean(plan.channel[c].filter_outgoing_qc_fail));
+            channel.push(record);
+        }
+        document.set("input feed", input_feed);
+        document.set("input feed by segment", by_segment);
+        document.set("output feed", output_feed);
+        document.set("channel", channel);
+        const std::string text = document.dump(15);
+        char* out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *plan_json = out;
+    });
+}
+
 int phq_adjust_prior(phq_decoder_set* set, const uint64_t* host_words, const char* job_json, char** adjusted_json) {
     if(adjusted_json != nullptr) { *adjusted_json = nullptr; }
     return guarded(set, [&]() {

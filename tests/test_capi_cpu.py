@@ -210,6 +210,67 @@ def test_report_writer_reproduces_golden_report(oracle):
     assert mine_lines[0] == "{" and mine_lines[-1] == "}"
 
 
+def _io_job(**changes):
+    job = bdggg.raw_job()
+    job["base input url"] = "/data/in"
+    job["base output url"] = "/data/out"
+    job.update(changes)
+    return job
+
+
+def test_transcode_plan_of_the_reference_job():
+    """phq_transcode_plan on the reference's own compiled job: the feeds of its `feed` section (valid/compile_annotated.out:
+    three FASTQ inputs of resolution 1, one SAM output of resolution 2) and every channel routed to that output."""
+    reference = bdggg.compiled_reference_job()
+    plan = DecoderSet(json.dumps(reference), device=capi.DEVICE_NONE).transcode_plan()
+    theirs = reference["feed"]
+    assert [(f["url"], f["resolution"]) for f in plan["input feed"]] == [(f["url"].split("?")[0], f["resolution"]) for f in theirs["input feed"]]
+    assert plan["input feed by segment"] == [[0, 0], [1, 0], [2, 0]]
+    assert [(f["url"], f["format"], f["compression"], f["resolution"]) for f in plan["output feed"]] == \
+           [(f["url"].split("?")[0], "sam", "none", f["resolution"]) for f in theirs["output feed"]] == [("/dev/stdout", "sam", "none", 2)]
+    assert len(plan["channel"]) == 6 and all(c["output feed by segment"] == [0, 0] and not c["filter outgoing qc fail"] for c in plan["channel"])
+
+
+def test_transcode_plan_feeds_channels_and_errors():
+    """Interleaved input (a URL stated k times = one feed of resolution k, transcode.cpp:693-701), outputs per channel with
+    their formats and compression by extension or query (url.cpp:280-417), the consistency checks of compile_output."""
+    job = _io_job(input=["lane1.fastq.gz", "lane1.fastq.gz", "index.fq"], output=["rest.sam"])
+    codec = job["sample"]["codec"]
+    codec["@AGGCAGAA"]["output"] = ["a_1.fastq.gz", "a_2.fastq.gz"]
+    codec["@CGTACTAG"]["output"] = ["b.fq?compression=gz&level=7"]
+    codec["@GGACTCCT"]["output"] = ["/abs/c.txt?format=fastq"]
+    codec["@GGACTCCT"]["filter outgoing qc fail"] = True
+    plan = DecoderSet(json.dumps(job), device=capi.DEVICE_NONE).transcode_plan()
+    assert plan["input feed"] == [{"index": 0, "url": "/data/in/lane1.fastq.gz", "resolution": 2}, {"index": 1, "url": "/data/in/index.fq", "resolution": 1}]
+    assert plan["input feed by segment"] == [[0, 0], [0, 1], [1, 0]]
+    feeds = {f["url"]: f for f in plan["output feed"]}
+    assert (feeds["/data/out/rest.sam"]["format"], feeds["/data/out/rest.sam"]["compression"], feeds["/data/out/rest.sam"]["resolution"]) == ("sam", "none", 2)
+    assert (feeds["/data/out/a_1.fastq.gz"]["format"], feeds["/data/out/a_1.fastq.gz"]["compression"], feeds["/data/out/a_1.fastq.gz"]["resolution"]) == ("fastq", "gz", 1)
+    assert (feeds["/data/out/b.fq"]["format"], feeds["/data/out/b.fq"]["compression"], feeds["/data/out/b.fq"]["compression level"], feeds["/data/out/b.fq"]["resolution"]) == ("fastq", "gz", 7, 2)
+    assert (feeds["/abs/c.txt"]["format"], feeds["/abs/c.txt"]["resolution"]) == ("fastq", 2)
+    channel = plan["channel"]                                  # undetermined, then the codec in key order
+    rest = feeds["/data/out/rest.sam"]["index"]
+    assert channel[0]["output feed by segment"] == [rest, rest]
+    assert channel[1]["output feed by segment"] == [feeds["/data/out/a_1.fastq.gz"]["index"], feeds["/data/out/a_2.fastq.gz"]["index"]]
+    assert channel[2]["output feed by segment"] == [feeds["/data/out/b.fq"]["index"]] * 2
+    assert channel[3]["filter outgoing qc fail"] and not channel[4]["filter outgoing qc fail"]
+    assert channel[4]["output feed by segment"] == [rest, rest] == channel[5]["output feed by segment"]
+    for changes, text in (({"output": ["a.sam", "b.sam", "c.sam"]}, "incorrect number of output URLs in channel"),
+                          ({"output": ["/dev/stdin"]}, "output stream can not be set to standard input"),
+                          ({"output": ["out.cram"]}, "htslib"),
+                          ({"output": ["out.fastq.xz"]}, "not supported"),
+                          ({"input": ["a.bam", "b.fastq", "c.fastq"]}, "only FASTQ input")):
+        with pytest.raises(PheniqsError) as caught:
+            DecoderSet(json.dumps(_io_job(**changes)), device=capi.DEVICE_NONE).transcode_plan()
+        assert text in str(caught.value), (changes, str(caught.value))
+    job = _io_job(output=["rest.sam"])
+    job["sample"]["codec"]["@AGGCAGAA"]["output"] = ["x.fastq", "x.fastq"]
+    job["sample"]["codec"]["@CGTACTAG"]["output"] = ["x.fastq", "y.fastq"]
+    with pytest.raises(PheniqsError) as caught:
+        DecoderSet(json.dumps(job), device=capi.DEVICE_NONE).transcode_plan()
+    assert "inconsistent resolution" in str(caught.value)
+
+
 @pytest.mark.parametrize("value,expected", [
     (0.0, "0.0"), (1.0, "1.0"), (0.972, "0.972"), (0.18 * (1 - 0.015), "0.177299999999999"),
     (1.0 / 4 ** 8, "0.000015258789062"), (0.951612903225806451, "0.951612903225806"), (248.0, "248.0"),
