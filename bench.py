@@ -163,7 +163,7 @@ def main():
     parser.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     parser.add_argument("--pool", type=int, default=1 << 20, help="distinct synthetic reads tiled to --reads")
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
-    parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "U96", "U384", "V384", "S384"],
+    parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "U96", "U384", "V384", "S384", "S192"],
                         help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration (U96 / U384: unique dual index pairs, not in BASELINE.json)")
     parser.add_argument("--priors", default="uniform", choices=["uniform", "estimated"],
                         help="estimated: barcode priors that differ (what a prior estimation pass leaves), not the BASELINE shape")
@@ -277,7 +277,7 @@ def main():
                            args.config, n, {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
                                             "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10",
                                             "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
-                                            "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes"}[args.config],
+                                            "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}[args.config],
                            args.algorithm.upper()),
                        "reads_per_gpu": n, "pool": pool_n, "kernel_mode": args.mode,
                        "sharding": "reads x%d, counters merged by one all-reduce per step" % world},

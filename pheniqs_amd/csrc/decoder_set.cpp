@@ -248,6 +248,22 @@ void DecoderSet::build_device_images() {
             for(double c0 : concentration) { if(c0 != concentration[0]) { d.uniform_prior = 0; } }
             d.identity_index = 1;
             for(int32_t b = 0; b < d.n_barcode; ++b) { if(index[static_cast<size_t>(b)] != b + 1) { d.identity_index = 0; } }
+            // The product form PAMLD kernel (pamld_lut.hpp) lives on two workgroups per CU, and its per read tables
+            // leave little LDS: a workgroup histogram that would cost it a workgroup is not worth it — the counters of
+            // classified reads are then rebuilt from the result records (count_results_kernel), as for large codecs.
+            // Measured at 192 barcodes of 8 nt: 12.1 -> 13.7 Greads/s.
+            if(c.algorithm == Algorithm::PAMLD && c.all_strict && c.nucleotide_cardinality <= 16 && d.identity_index && d.use_lds_histogram) {
+                const size_t groups = static_cast<size_t>(c.nucleotide_cardinality + 3) / 4;
+                const size_t threads = c.nucleotide_cardinality <= 8 ? 512 : 256;
+                const size_t padded = static_cast<size_t>((d.n_barcode + 7) & ~7);
+                const size_t fixed = (threads / 64) * groups * 16 * 64 * 4 + 3120 + 16 + (c.nucleotide_cardinality <= 8 ? padded / 2 : padded) * 8;
+                const size_t with_histogram = fixed + (STAT_JOB_WORDS + static_cast<size_t>(d.n_barcode + 1) * STAT_WORDS_PER_BIN) * 8;
+                const size_t without = fixed + (STAT_JOB_WORDS + STAT_WORDS_PER_BIN) * 8;
+                constexpr size_t LDS_PER_CU = 160 * 1024;
+                // ... when it is the second workgroup that is lost; a third gains less than the extra pass costs (C4's 10 nt
+                // decoder: 4.56 -> 4.41 Greads/s)
+                if(LDS_PER_CU / with_histogram < 2 && LDS_PER_CU / without >= 2) { d.use_lds_histogram = 0; }
+            }
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));

@@ -54,7 +54,7 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
 
 # BASELINE.json's C2..C5 plus two shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
 # 8 + 8 nt in one two segment sample decoder (not every combination: pair i is word i of each list)
-CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9}
+CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10}
 
 
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
@@ -90,9 +90,9 @@ def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
         i7, i5 = barcode_set(rng, 384, 10), barcode_set(rng, 384, 10)
         spec = {"input segment cardinality": 3,
                 "sample": decoder_spec(algorithm, [i7, i5], ["1::10", "2::10"], pairing="zip")}
-    elif name == "S384":               # 384 single 8 nt indexes
+    elif name in ("S384", "S192"):     # 384 / 192 single 8 nt indexes
         spec = {"input segment cardinality": 2,
-                "sample": decoder_spec(algorithm, [barcode_set(rng, 384, 8)], ["1::8"])}
+                "sample": decoder_spec(algorithm, [barcode_set(rng, 384 if name == "S384" else 192, 8)], ["1::8"])}
     else:                   # C5 SPLiT-seq: cellular [96 x 8] x 3 + 4 x 6 reverse complemented, naive UMI 10
         r1, r2, r3 = barcode_set(rng, 96, 8), barcode_set(rng, 96, 8), barcode_set(rng, 96, 8)
         r4 = barcode_set(rng, 4, 6)
