@@ -193,7 +193,7 @@ def main():
         for _, decoder in jobspec.iter_decoders(spec):
             for record in (decoder.get("codec") or {}).values():
                 record["concentration"] = float(10 ** spread.uniform(-0.5, 0.5))
-        job = jobspec.compile_job(spec)
+        job = capi.compile_job(spec)
     bytes_per_read = synthetic.algorithmic_bytes_per_read(job)          # 37 for C2
     pool_n = min(args.pool, args.reads)
     tiles = -(-args.reads // pool_n)
