@@ -145,7 +145,9 @@ int phq_stage_reads(const phq_decoder_set* set, int64_t n_read, int32_t n_segmen
  * (classifier.h:83-85) | final QC fail << 31 and is also the scratch that carries the sticky QC-fail
  * flag from decoder to decoder, so it must not be NULL.  flag may be NULL (no incoming QC fail).
  * The call only enqueues work on `hip_stream` (a hipStream_t, NULL = default stream); counters
- * accumulate in the set's device counter buffer. */
+ * accumulate in the set's device counter buffer.  n_read is at most 2^31 - 2^20 per call (read ordinals travel in
+ * 32 bits between the kernels of a stage): PHQ_OVERFLOW_ERROR beyond that, classify a larger batch in pieces
+ * with first_read. */
 int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t first_read, int64_t n_read,
                         const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                         phq_result_t* result, uint32_t* word, void* hip_stream);

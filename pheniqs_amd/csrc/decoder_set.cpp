@@ -535,6 +535,8 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
     require_device();
     if(n_read <= 0) { return; }
     if(first_read < 0 || first_read + n_read > batch_capacity) { throw OverflowError("read range exceeds the batch capacity"); }
+    // worklists, ring entries and the worklist stride hold read ordinals of one call in 32 (31) bits
+    if(n_read > (int64_t(1) << 31) - (int64_t(1) << 20)) { throw OverflowError("more than 2^31 reads in one call: classify the batch in pieces"); }
     if(word == nullptr) { throw InternalError("the status word buffer is mandatory"); }
     if(job_.plane_width > 0 && (base_planes == nullptr || quality_planes == nullptr)) { throw InternalError("observation planes are missing"); }
     const size_t n_decoder = job_.decoder.size();
