@@ -82,11 +82,13 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
             int best = -1;
             // Every barcode's probability within ~1 ulp (phred_probability_fast) for the sum.  The argmax needs the
             // carefully rounded power only where two barcodes come within 1e-15 of each other at the top with Kahan sums
-            // that are NOT the same double (equal sums are equal powers under any pow: the first keeps the tie): the
-            // same multiset of costs summed in another order, ~1 read in 10 000.  Those reads take a second walk.
+            // (or priors) that are NOT the same double — equal sums and priors are equal products under any pow: the
+            // first keeps the tie —: the same multiset of costs summed in another order, ~1 read in 10 000.  Those reads
+            // take a second walk.
             double running = 0;                 // the largest quickly rounded probability so far
             int near_index = 0;                 // the barcode that holds it (the first of equals)
             double near_sigma = 0;
+            double near_prior = 0;
             bool ambiguous = false;
             auto kahan_of = [&](int b) {
                 uint32_t expected[W];
@@ -111,22 +113,29 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
 #pragma unroll 2
             for(int b = 0; b < n_barcode; ++b) {
                 const double sigma_q = kahan_of(b);
-                const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
+                const double prior = concentration[b];
+                const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * prior;
                 const double y = p - compensation;
                 const double t = sigma_p + y;
                 compensation = (t - sigma_p) - y;
                 sigma_p = t;
                 const bool clears = p * (1.0 - 1e-15) > running;                    // a new maximum well above the old one
                 const bool close = !clears && p >= running * (1.0 - 1e-15) && p > 0;
-                if(clears) { near_index = b; near_sigma = sigma_q; ambiguous = false; }
-                ambiguous = ambiguous || (close && sigma_q != near_sigma);
+                if(clears) { near_index = b; near_sigma = sigma_q; near_prior = prior; ambiguous = false; }
+                ambiguous = ambiguous || (close && (sigma_q != near_sigma || prior != near_prior));
                 running = p > running ? p : running;
             }
+            // best_summand: the winner's term as it entered the sum.  The reference's posterior divides one of the
+            // summands by the sum (pamld.cpp:61-92), so two tied barcodes and no noise give exactly 1/2; dividing the
+            // carefully rounded power by a sum of quickly rounded ones would miss that by an ulp and flip a decision
+            // that sits exactly on the threshold.
+            double best_summand = 0;
             if(!ambiguous) {
                 if(running > 0) {
                     best = near_index;
                     best_conditional = phred_probability(near_sigma, log2_base_hi, log2_base_lo);
                     best_p = best_conditional * concentration[near_index];
+                    best_summand = running;
                 }
             } else {
                 for(int b = 0; b < n_barcode; ++b) {
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                     if(p >= running * (1.0 - 1e-15)) {
                         const double conditional = phred_probability(sigma_q, log2_base_hi, log2_base_lo);
                         const double careful = conditional * concentration[b];
-                        if(careful > best_p) { best = b; best_p = careful; best_conditional = conditional; }     // strict: the lowest index keeps a tie
+                        if(careful > best_p) { best = b; best_p = careful; best_conditional = conditional; best_summand = p; }     // strict: the lowest index keeps a tie
                     }
                 }
             }
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                 }
             }
 
-            double confidence = best_p / sigma_p;                                  // pamld.cpp:92
+            double confidence = best_summand / sigma_p;                            // pamld.cpp:92
             int bin = best + 1;
             uint8_t status = STATUS_PASS;
             if(best_conditional > d.random_barcode_probability) {                 // pamld.cpp:96

@@ -28,7 +28,9 @@ def _random_decoder(rng, algorithm, kind):
         words = [synthetic.barcode_set(rng, c, l, min_distance=1) for c, l in zip(counts, lengths)]
         pairing = "product"
     else:
-        count = int(min(rng.integers(1, 120), 4 ** min(lengths)))
+        # mostly small codecs; one in seven past the workgroup histogram sizes (117.., 341..) up to 600 barcodes
+        limit = 600 if (rng.random() < 0.15 and min(lengths) >= 5) else 120
+        count = int(min(rng.integers(1, limit), 4 ** min(lengths)))
         words = [synthetic.barcode_set(rng, count, l, min_distance=1) for l in lengths]
         for w in words[1:]:
             rng.shuffle(w)
@@ -60,7 +62,8 @@ def test_random_job(oracle, torch_cuda, seed):
     if rng.random() < 0.3:
         spec["molecular"] = [{"algorithm": "naive", "transform": {"token": ["0::4"]}}]
     job = jobspec.compile_job(spec)
-    n = 6000
+    largest = max(len(d.get("codec") or {}) for _, d in jobspec.iter_decoders(job))
+    n = 6000 if largest <= 150 else 2500
     code, quality, flag, offsets = synthetic.generate_rows(job, n, seed)
     width = code.shape[1]
     noisy = rng.random((n, width)) < 0.03
