@@ -35,6 +35,14 @@ def _random_decoder(rng, algorithm, kind):
         for w in words[1:]:
             rng.shuffle(w)
         pairing = "zip"
+    if rng.random() < 0.1:                                            # a few barcode letters outside ACGT
+        for w in words:
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, len(w)))
+                j = int(rng.integers(0, len(w[k])))
+                changed = w[k][:j] + str(rng.choice(list("NRYKMSWBDHV"))) + w[k][j + 1:]
+                if changed not in w:
+                    w[k] = changed
     options = {"confidence threshold": float(rng.choice([0.5, 0.9, 0.95, 0.99])),
                "noise": float(rng.choice([0.0, 0.01, 0.05])),
                "high quality threshold": int(rng.choice([0, 20, 30, 41])),
@@ -69,6 +77,8 @@ def test_random_job(oracle, torch_cuda, seed):
     noisy = rng.random((n, width)) < 0.03
     code[noisy] = np.array([15, 0, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=int(noisy.sum()))]
     quality[rng.random((n, width)) < 0.03] = 0
+    wild = rng.random((n, width)) < 0.01
+    quality[wild] = rng.integers(0, 256, size=int(wild.sum())).astype(np.uint8)      # anything a byte can hold
     quality[: n // 10] = int(rng.choice([2, 12, 30, 40]))            # uniform qualities: exact ties
     for i in range(min(width, 40)):
         code[n // 2 + i, i:] = 0
