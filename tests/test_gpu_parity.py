@@ -754,6 +754,29 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
+@pytest.mark.parametrize("length", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 32])
+def test_reads_without_information_sit_on_the_noise_threshold(oracle, torch_cuda, length):
+    """A read of N bases (or of bases outside ACGT) costs the uniform quality at every position against every barcode:
+    P(r|b) = pow(base, L * 10 log10 4), mathematically 4^-L = the default random barcode probability, and the noise
+    filter `P > rbp` (pamld.cpp:96) is decided by the last bit of pow().  Index reads of all N are common in real
+    runs, so the in-kernel power must round these arguments the way libm does — for every length, and for partial
+    N runs and quality 0 positions around them."""
+    rng = np.random.default_rng(length)
+    count = min(12, 4 ** length)
+    words = synthetic.barcode_set(rng, count, length, min_distance=1)
+    job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length], noise=0.02)})
+    n = 4096
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 5)
+    code[: n // 4] = 15                                                     # all N
+    quality[: n // 4] = rng.choice([2, 12, 25, 37, 40], size=(n // 4, 1)).astype(np.uint8)
+    code[n // 4: n // 2] = rng.choice([15, 3, 5, 6, 7, 9, 14], size=(n // 4, length)).astype(np.uint8)      # nothing in ACGT
+    some = rng.random((n // 4, length)) < 0.5                                # N runs among real bases
+    block = code[n // 2: 3 * n // 4]
+    block[some] = 15
+    quality[n // 8: n // 4][rng.random((n // 8, length)) < 0.3] = 0          # quality 0 positions cost nothing
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+
+
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("name", ["U96", "U384", "V384", "S384"])
 def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
