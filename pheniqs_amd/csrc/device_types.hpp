@@ -31,6 +31,7 @@ constexpr int GRID_BLOCKS_PER_CU = 16;
 constexpr int GRID_SHARE_LUT = 12;
 constexpr int GRID_SHARE_MDD_FUSED = 16;
 constexpr int GRID_SHARE_DEFAULT = 8;
+constexpr int EXACT_GROUP_MAX = 16;      // worklist segments one workgroup of the exact PAMLD tier visits, at most (StageArgs::worklist_group)
 
 constexpr int CONFIDENCE_FRACTION_BITS = 52;
 constexpr int CONFIDENCE_LIMB_BITS = 26;
@@ -139,6 +140,11 @@ struct StageArgs {
     uint32_t* worklist_count;
     int32_t worklist_role;                // 0 none, 1 producer, 2 consumer
     int32_t worklist_stride;
+    // The exact tier (pamld_cross_exact_kernel) runs fewer, fuller workgroups: workgroup c visits the segments
+    // [c * worklist_group, (c + 1) * worklist_group) below worklist_segments as one list, and compacts what it leaves
+    // back into each read's own segment, so the literal tier keeps its one segment per workgroup.
+    int32_t worklist_segments;            // segments the producer wrote = its grid
+    int32_t worklist_group;               // segments per workgroup of the exact tier (1 elsewhere)
     // Large codecs (no workgroup histogram): the kernels leave count / distance / confidence of the classified
     // reads alone and count_results_kernel (counters.hip) builds them from the result records afterwards —
     // scattered global atomics run at the memory side on this part, ~3.3 of them per read cost as much as the

@@ -477,7 +477,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     __shared__ uint8_t near_list[S * CROSS_MAX_UNIQUE * THREADS];             // [segment][entry][lane] word ordinals
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
-    __shared__ uint32_t deferred_total;
+    __shared__ uint32_t group_start[EXACT_GROUP_MAX + 1];                     // prefix sums of the group's segment counts
+    __shared__ uint32_t group_kept[EXACT_GROUP_MAX];                          // reads left in each segment for the literal tier
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
@@ -488,13 +489,25 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
         cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
         cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
     }
-    if(threadIdx.x == 0) { deferred_total = 0; }
+    // the segments of this workgroup, as one list
+    const int group = args.worklist_group < 1 ? 1 : (args.worklist_group > EXACT_GROUP_MAX ? EXACT_GROUP_MAX : args.worklist_group);
+    const int first_segment = static_cast<int>(blockIdx.x) * group;
+    const int n_segment_here = min(group, args.worklist_segments - first_segment);
+    if(threadIdx.x == 0) {
+        uint32_t total = 0;
+        for(int s = 0; s < EXACT_GROUP_MAX; ++s) {
+            group_start[s] = total;
+            group_kept[s] = 0;
+            if(s < n_segment_here) { total += args.worklist_count[first_segment + s]; }
+        }
+        group_start[EXACT_GROUP_MAX] = total;
+    }
     histogram_clear(d, histogram);
     __syncthreads();
 
     const StatSink sink{histogram, args.stats, args.defer_counters != 0};
-    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
-    const int64_t n = static_cast<int64_t>(args.worklist_count[blockIdx.x]);
+    uint32_t* const segments = args.worklist + static_cast<int64_t>(first_segment) * args.worklist_stride;
+    const int64_t n = static_cast<int64_t>(group_start[EXACT_GROUP_MAX]);
     const int64_t tiles = (n + THREADS - 1) / THREADS;
 
     uint32_t word_table[S][TABLE_REGISTERS];
@@ -537,7 +550,13 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     for(int64_t tile = 0; tile < tiles; ++tile) {
         const int64_t k = tile * THREADS + threadIdx.x;
         const bool active = k < n;
-        const int64_t i = static_cast<int64_t>(segment[active ? k : n - 1]);
+        // entry k of the list: in which segment, and where in it
+        const uint32_t at = static_cast<uint32_t>(active ? k : n - 1);
+        int home = 0;
+#pragma unroll
+        for(int s = 1; s < EXACT_GROUP_MAX; ++s) { home += at >= group_start[s] ? 1 : 0; }       // starts are non decreasing
+        uint32_t* const segment = segments + static_cast<int64_t>(home) * args.worklist_stride;
+        const int64_t i = static_cast<int64_t>(segment[at - group_start[home]]);
         __syncthreads();                       // every entry of this tile is read before any wave compacts into it
         ReadState r = load_read_state(args, i);
         const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
@@ -759,20 +778,17 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             }
             store_read_state(args, i, r);
         }
-        const unsigned long long deferred = __ballot(active && defer);
-        if(deferred) {
-            const int lane = threadIdx.x & 63;
-            uint32_t first = 0;
-            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
-            first = __shfl(first, 0);
-            if(active && defer) {
-                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
-            }
+        // what is left goes back to the front of the read's own segment (few reads: one LDS atomic each); a segment
+        // never holds more leftovers than entries already read from it, and this tile's entries were read before the
+        // barrier at its top
+        if(active && defer) {
+            const uint32_t slot = atomicAdd(&group_kept[home], 1u);
+            segment[slot] = static_cast<uint32_t>(i);
         }
         count_outgoing(args, histogram, active && !defer, r);
     }
     __syncthreads();
-    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    if(static_cast<int>(threadIdx.x) < n_segment_here) { args.worklist_count[first_segment + threadIdx.x] = group_kept[threadIdx.x]; }
     histogram_flush(args, d, histogram);
 }
 
