@@ -42,6 +42,25 @@ def profiled_traffic(mode, reads, config="C2", algorithm="pamld", kernel_mode="f
     return None
 
 
+def measured_copy_bandwidth(torch, device):
+    """the practical HBM ceiling of this node next to the 8 TB/s the roofline is priced against — a
+    device to device copy of 1 GiB, bytes read + bytes written per second (torch's copy kernel, HIP events)."""
+    words = 1 << 28
+    source = torch.empty(words, dtype=torch.int32, device=device).fill_(1)
+    target = torch.empty_like(source)
+    for _ in range(2):
+        target.copy_(source)
+    begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    begin.record()
+    repeats = 10
+    for _ in range(repeats):
+        target.copy_(source)
+    end.record()
+    torch.cuda.synchronize(device)
+    return 2 * 4 * words * repeats / (begin.elapsed_time(end) * 1e-3) / 1e9
+
+
 def fastq_end_to_end(args, code, quality, flag, n):
     """Next rows f1 + f2 end to end: synthetic FASTQ text on disk -> phq_transcode_fastq_to_sam -> SAM text
     (uncompressed, /dev/null).  One file per input segment: a 50 nt template read and the index read; the staged
@@ -284,6 +303,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(dominant, n, args.config, args.algorithm, args.mode),
                          "kernel": dominant, "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read,
+                         "measured_copy_GBs": measured_copy_bandwidth(torch, device) if world == 1 else None,
                          "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in kernels.items()},
                          "classify_ms_per_step": classify_ms},
         }
