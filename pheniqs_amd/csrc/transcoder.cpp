@@ -122,8 +122,10 @@ private:
 };
 
 struct SegmentBatch {
-    std::vector<uint8_t> code;
+    std::vector<uint8_t> code;           // BAM codes / Phred values: only for feeds a decoder token reads (stage_reads)
     std::vector<uint8_t> quality;
+    std::vector<char> text;              // the same bases as the output prints them (BamToAmbiguousAscii of the code) and the
+    std::vector<char> quality_text;      // qualities at the output Phred offset: only for feeds the template reads
     std::vector<int64_t> offset;
     std::vector<int32_t> length;
     std::vector<uint8_t> qcfail;
@@ -132,17 +134,26 @@ struct SegmentBatch {
     std::vector<std::pair<size_t, uint32_t>> line;
     std::string error;
     void clear() {
-        code.clear(); quality.clear(); offset.clear(); length.clear(); qcfail.clear(); name.clear();
+        code.clear(); quality.clear(); text.clear(); quality_text.clear(); offset.clear(); length.clear(); qcfail.clear(); name.clear();
         name_offset.assign(1, 0);
         error.clear();
     }
     int64_t size() const { return static_cast<int64_t>(length.size()); }
 };
 
-void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, int32_t threads, SegmentBatch& out) {
+// what a feed's batch has to hold: codes for the decoders' tokens, printable text for the template's
+struct FeedNeeds { bool codes; bool text; int32_t output_phred_offset; };
+
+void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, int32_t threads, FeedNeeds needs, SegmentBatch& out) {
     static const std::vector<uint8_t> ascii_table = []() {                  // AsciiToAmbiguousBam, iupac.h:153-171
         std::vector<uint8_t> table(256);
         for(int c = 0; c < 256; ++c) { table[static_cast<size_t>(c)] = ascii_to_bam(static_cast<uint8_t>(c)); }
+        return table;
+    }();
+    // ... followed by BamToAmbiguousAscii (iupac.h:62-79): the letter the reference prints for what it read
+    static const std::vector<char> canonical_table = []() {
+        std::vector<char> table(256);
+        for(int c = 0; c < 256; ++c) { table[static_cast<size_t>(c)] = bam_to_ascii(ascii_to_bam(static_cast<uint8_t>(c))); }
         return table;
     }();
     out.clear();
@@ -187,8 +198,9 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
             sequence_bytes[static_cast<size_t>(part) + 1] += sequence_bytes[static_cast<size_t>(part)];
             name_bytes[static_cast<size_t>(part) + 1] += name_bytes[static_cast<size_t>(part)];
         }
-        out.code.resize(static_cast<size_t>(sequence_bytes[static_cast<size_t>(parts)]));
-        out.quality.resize(out.code.size());
+        const size_t total_bases = static_cast<size_t>(sequence_bytes[static_cast<size_t>(parts)]);
+        if(needs.codes) { out.code.resize(total_bases); out.quality.resize(total_bases); }
+        if(needs.text) { out.text.resize(total_bases); out.quality_text.resize(total_bases); }
         out.name.resize(static_cast<size_t>(name_bytes[static_cast<size_t>(parts)]));
         out.name_offset[static_cast<size_t>(n)] = name_bytes[static_cast<size_t>(parts)];
         // pass 2: decode into place
@@ -212,10 +224,20 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
                 const char* sequence = data + line[static_cast<size_t>(4 * i + 1)].first;
                 const char* quality = data + line[static_cast<size_t>(4 * i + 3)].first;
                 out.offset[static_cast<size_t>(i)] = at;
-                uint8_t* to_code = out.code.data() + at;
-                uint8_t* to_quality = out.quality.data() + at;
-                for(size_t k = 0; k < size; ++k) { to_code[k] = ascii_table[static_cast<uint8_t>(sequence[k])]; }
-                for(size_t k = 0; k < size; ++k) { to_quality[k] = static_cast<uint8_t>(quality[k] - phred_offset); }
+                if(needs.codes) {
+                    uint8_t* to_code = out.code.data() + at;
+                    uint8_t* to_quality = out.quality.data() + at;
+                    for(size_t k = 0; k < size; ++k) { to_code[k] = ascii_table[static_cast<uint8_t>(sequence[k])]; }
+                    for(size_t k = 0; k < size; ++k) { to_quality[k] = static_cast<uint8_t>(quality[k] - phred_offset); }
+                }
+                if(needs.text) {
+                    // what FastqRecord::decode then ::encode make of the record (fastq.h:55-78,144-171), in one step
+                    char* to_text = out.text.data() + at;
+                    char* to_quality = out.quality_text.data() + at;
+                    for(size_t k = 0; k < size; ++k) { to_text[k] = canonical_table[static_cast<uint8_t>(sequence[k])]; }
+                    if(needs.output_phred_offset == phred_offset) { std::memcpy(to_quality, quality, size); }
+                    else { for(size_t k = 0; k < size; ++k) { to_quality[k] = static_cast<char>(static_cast<uint8_t>(quality[k] - phred_offset) + needs.output_phred_offset); } }
+                }
                 at += static_cast<int64_t>(size);
             }
         });
@@ -223,7 +245,7 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
     } catch(const std::exception& e) {
         out.error = e.what();
         if(out.error.empty()) { out.error = "error reading " + stream.path(); }
-        out.code.clear(); out.quality.clear(); out.offset.clear(); out.length.clear(); out.qcfail.clear(); out.name.clear();
+        out.code.clear(); out.quality.clear(); out.text.clear(); out.quality_text.clear(); out.offset.clear(); out.length.clear(); out.qcfail.clear(); out.name.clear();
         out.name_offset.assign(1, 0);
     }
 }
@@ -546,11 +568,22 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     std::vector<SegmentBatch> ahead(m.batch.size());
     // decoding threads per feed: the feeds are read concurrently and the previous batch is being formatted meanwhile
     const int32_t parse_threads = std::max(1, host_threads() / (2 * std::max(1, n_feed)));
+    // what each feed's batches must hold: BAM codes where a decoder token reads one of its segments (stage_reads),
+    // printable text where the template does; a template-only feed (the biological reads) is never turned into codes
+    std::vector<FeedNeeds> needs(static_cast<size_t>(n_feed), FeedNeeds{false, false, job.output_phred_offset});
+    for(const auto& d : job.decoder) {
+        for(const auto& t : d.transform) {
+            if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].codes = true; }
+        }
+    }
+    for(const auto& t : job.template_transform) {
+        if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].text = true; }
+    }
     auto start_readers = [&](std::vector<SegmentBatch>& into) {
         std::vector<std::thread> readers;
         for(int32_t f = 0; f < n_feed; ++f) {
             readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(f)]), m.capacity * plan.input_feed[static_cast<size_t>(f)].resolution,
-                                 job.input_phred_offset, parse_threads, std::ref(into[static_cast<size_t>(f)]));
+                                 job.input_phred_offset, parse_threads, needs[static_cast<size_t>(f)], std::ref(into[static_cast<size_t>(f)]));
         }
         return readers;
     };
@@ -558,6 +591,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         auto readers = start_readers(m.batch);
         for(auto& t : readers) { t.join(); }
     }
+    // the complement of a printed base, for `~` tokens of the template over printable text (iupac.h:107-124)
+    char complement_text[256];
+    for(int c = 0; c < 256; ++c) { complement_text[c] = bam_to_ascii(reverse_complement_bam(ascii_to_bam(static_cast<uint8_t>(c)))); }
     const int workers = host_threads();
     std::vector<ByteBuffer> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
     std::vector<ByteBuffer> part_packed(part_text.size());
@@ -661,7 +697,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& t : raw) { t.allocate(barcode_capacity); }
         for(auto& t : corrected) { t.allocate(barcode_capacity); }
         std::vector<char> tags(tag_capacity);
-        struct Piece { const uint8_t* code; const uint8_t* quality; int32_t size; bool reverse_complement; };
+        // a token's bases: BAM codes and Phred values (a corrected barcode) or printable text (an input segment)
+        struct Piece { const uint8_t* code; const uint8_t* quality; const char* text; const char* quality_text; int32_t size; bool reverse_complement; };
         std::vector<Piece> piece(job.template_transform.size());
         for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
@@ -730,18 +767,19 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             // TemplateRule::apply (transform.h:190-226): where every token's bases are
             for(size_t t = 0; t < job.template_transform.size(); ++t) {
                 const TransformConfig& token = job.template_transform[t];
-                const uint8_t* fc; const uint8_t* fq; int32_t flen;
+                const uint8_t* fc = nullptr; const uint8_t* fq = nullptr; const char* ft = nullptr; const char* fqt = nullptr; int32_t flen;
                 if(token.input_segment_index < 0) {
                     const Text& from = corrected[token.input_segment_index == -1 ? 0 : token.input_segment_index == -2 ? 2 : 1];
                     fc = from.code.data(); fq = from.quality.data(); flen = from.size;
                 } else {
                     const SegmentView& v = view[static_cast<size_t>(token.input_segment_index)];
                     const size_t at = v.at(r);
-                    fc = v.feed->code.data() + v.feed->offset[at]; fq = v.feed->quality.data() + v.feed->offset[at]; flen = v.feed->length[at];
+                    ft = v.feed->text.data() + v.feed->offset[at]; fqt = v.feed->quality_text.data() + v.feed->offset[at]; flen = v.feed->length[at];
                 }
                 const int32_t start = token.absolute_start(flen);
                 const int32_t end = token.absolute_end(flen);
-                piece[t] = Piece{fc + start, fq + start, end - start > 0 ? end - start : 0, token.reverse_complement};
+                piece[t] = Piece{fc ? fc + start : nullptr, fq ? fq + start : nullptr, ft ? ft + start : nullptr, fqt ? fqt + start : nullptr,
+                                 end - start > 0 ? end - start : 0, token.reverse_complement};
             }
 
             // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
@@ -770,7 +808,10 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 auto put_bases = [&](char* at) {
                     for(const int32_t t : tokens) {
                         const Piece& p = piece[static_cast<size_t>(t)];
-                        if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = BAM_TO_ASCII[reverse_complement_bam(p.code[p.size - i - 1]) & 0xf]; } at += p.size; }
+                        if(p.text != nullptr) {
+                            if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = complement_text[static_cast<uint8_t>(p.text[p.size - i - 1])]; } at += p.size; }
+                            else { at = put_bytes(at, p.text, static_cast<size_t>(p.size)); }
+                        } else if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = BAM_TO_ASCII[reverse_complement_bam(p.code[p.size - i - 1]) & 0xf]; } at += p.size; }
                         else { at = put_sequence(at, p.code, p.size); }
                     }
                     return at;
@@ -778,7 +819,10 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 auto put_qualities = [&](char* at) {
                     for(const int32_t t : tokens) {
                         const Piece& p = piece[static_cast<size_t>(t)];
-                        if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality[p.size - i - 1] + job.output_phred_offset); } at += p.size; }
+                        if(p.quality_text != nullptr) {
+                            if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = p.quality_text[p.size - i - 1]; } at += p.size; }
+                            else { at = put_bytes(at, p.quality_text, static_cast<size_t>(p.size)); }
+                        } else if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality[p.size - i - 1] + job.output_phred_offset); } at += p.size; }
                         else { at = put_quality(at, p.quality, p.size, job.output_phred_offset); }
                     }
                     return at;
