@@ -3,6 +3,7 @@
 // on the target pool, so the device code is checked by the oracle parity tests instead.
 //
 // usage: host_check <compiled job json> [more jobs ...]
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -108,6 +109,39 @@ int main(int argc, char** argv) {
             CHECK(!encode_report(job, zero.data(), 0, 0).dump(15).empty());
             std::printf("%s: %zu decoders, %lld counter words, report %zu bytes\n", argv[i], job.decoder.size(),
                         static_cast<long long>(job.stats_words), text.size());
+            // the same document with bytes flipped, dropped or doubled: a configuration error or a job, never a crash
+            // (sanitizers watching); structural damage is the common case, valid JSON with a wrong type the other one
+            {
+                const std::string original = content.str();
+                uint64_t fuzz = 1442695040888963407ull + static_cast<uint64_t>(i);
+                auto next = [&]() { fuzz ^= fuzz << 13; fuzz ^= fuzz >> 7; fuzz ^= fuzz << 17; return fuzz; };
+                int accepted = 0;
+                for(int round = 0; round < 400; ++round) {
+                    std::string mutated = original;
+                    const int edits = 1 + static_cast<int>(next() % 3);
+                    for(int e = 0; e < edits && !mutated.empty(); ++e) {
+                        const size_t at = static_cast<size_t>(next() % mutated.size());
+                        switch(next() % 5) {
+                            case 0: mutated[at] = static_cast<char>(next() % 96 + 32); break;
+                            case 1: mutated.erase(at, 1 + static_cast<size_t>(next() % 8)); break;
+                            case 2: mutated.insert(at, mutated.substr(at, 1 + static_cast<size_t>(next() % 16))); break;
+                            case 3: mutated[at] = "{}[],:\"0-9nulltruefalse"[next() % 24]; break;
+                            default: mutated.replace(at, std::min<size_t>(4, mutated.size() - at), "null"); break;
+                        }
+                    }
+                    try {
+                        Json damaged = Json::parse(mutated);
+                        if(!is_compiled_job(damaged)) { damaged = compile_job(damaged); }
+                        const JobConfig survivor = JobConfig::from_json(damaged);
+                        std::vector<uint64_t> none(static_cast<size_t>(survivor.stats_words), 0);
+                        (void)encode_report(survivor, none.data(), 0, 0).dump(15);
+                        ++accepted;
+                    } catch(const Error&) {
+                    } catch(const std::exception&) {
+                    }
+                }
+                std::printf("%s: 400 damaged copies, %d still a job\n", argv[i], accepted);
+            }
         } catch(const Error& e) {
             std::fprintf(stderr, "%s: %s\n", argv[i], e.what());
             ++failures;
