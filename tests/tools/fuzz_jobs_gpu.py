@@ -62,6 +62,32 @@ def main():
         s.close()
     print("fuzz: %d documents, %d refused, %d created and classified" % (rounds, refused, created))
 
+    # damaged FASTQ text through the transcoder: a sequence / IO error or records, never a crash
+    import tempfile
+    job = json.dumps(bdggg.compiled_reference_job())
+    originals = [open(os.path.join(bdggg.HERE, "BDGGG_s0%d.fastq" % k), "rb").read().decode("latin-1") for k in (1, 2, 3)]
+    finished = failed = 0
+    with tempfile.TemporaryDirectory() as directory:
+        for k in range(max(rounds // 10, 20)):
+            paths = []
+            victim = rng.randrange(3)
+            for f, text in enumerate(originals):
+                if f == victim:
+                    text = damaged(text, rng)
+                    if rng.random() < 0.3:
+                        text = text[:rng.randrange(len(text))]                    # truncated
+                path = os.path.join(directory, "s%d.fastq" % f)
+                open(path, "wb").write(text.encode("latin-1"))
+                paths.append(path)
+            s = DecoderSet(job, device=0)
+            try:
+                s.transcode_fastq_to_sam(paths, os.path.join(directory, "out.sam"), rng.choice([7, 64, 1 << 16]))
+                finished += 1
+            except PheniqsError:
+                failed += 1
+            s.close()
+    print("fuzz: FASTQ files, %d runs finished, %d stopped with an error" % (finished, failed))
+
 
 if __name__ == "__main__":
     main()
