@@ -434,6 +434,43 @@ void DecoderSet::build_device_images() {
                     }
                 }
             }
+            if(d.cross_segments == 0 && c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
+               d.n_barcode <= EXACT_SINGLE_UNIQUE && c.nucleotide_cardinality >= 1 && c.nucleotide_cardinality <= 16) {
+                // Not every combination of per segment sets (unique dual index PAIRS), or more distinct words than the
+                // factorised kernels keep: the exact tier still serves the codec with its whole barcode — the segments
+                // one after the other, up to 16 nt — taken as ONE word per barcode, EXACT_SINGLE_UNIQUE of them at most.
+                std::vector<uint32_t> words(static_cast<size_t>(EXACT_SINGLE_UNIQUE), 0u);
+                std::vector<int32_t> ordinal(static_cast<size_t>(d.n_barcode));
+                std::vector<uint32_t> seen;
+                bool distinct_words = true;
+                for(int32_t b = 0; b < d.n_barcode && distinct_words; ++b) {
+                    uint32_t word = 0;
+                    uint32_t key = 0;
+                    for(int32_t j = 0; j < c.nucleotide_cardinality; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(c.nucleotide_cardinality) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        const uint32_t low = 8u * static_cast<uint32_t>(j >> 2) + 2u + static_cast<uint32_t>(j & 3);
+                        word |= (two & 1u) << low;
+                        word |= (two >> 1) << ((low + 4u) & 31u);
+                        key |= two << (2 * j);
+                    }
+                    if(std::find(seen.begin(), seen.end(), key) != seen.end()) { distinct_words = false; }      // the same barcode twice
+                    seen.push_back(key);
+                    words[static_cast<size_t>(b)] = word;
+                    ordinal[static_cast<size_t>(b)] = b;
+                }
+                if(distinct_words) {
+                    d.cross_start[0] = 0;
+                    d.cross_length[0] = c.nucleotide_cardinality;
+                    d.cross_unique[0] = d.n_barcode;
+                    d.cross_stride[0] = 1;
+                    d.cross_segments = 1;
+                    d.cross_groups = (c.nucleotide_cardinality + 3) / 4;
+                    d.cross_identity = 1;
+                    d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
+                    d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
+                }
+            }
         }
     }
     device_decoder_ = static_cast<DevDecoder*>(upload(host_decoder_.data(), host_decoder_.size() * sizeof(DevDecoder)));

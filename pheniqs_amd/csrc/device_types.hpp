@@ -11,6 +11,7 @@ constexpr int DEV_MAX_WORD = 4;          // 8 nucleotides per 32-bit word of 4-b
 constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
+constexpr int EXACT_SINGLE_UNIQUE = 512; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
 
 // Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]
 // (TranscodingDecoder::count/pf_count, transcode.h:61-64).  Then per decoder, per barcode bin

@@ -24,6 +24,8 @@
 // Every other read goes to this workgroup's worklist segment for the literal kernel.
 #pragma once
 
+#include <type_traits>
+
 #include "kernel_common.hpp"
 
 namespace phq {
@@ -35,6 +37,7 @@ constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a top well inside the n
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 constexpr int THREADS = 256;
 constexpr int TABLE_REGISTERS = CROSS_MAX_UNIQUE / 64;
+constexpr int EXACT_SINGLE_LIST = 64;            // list entries per lane of the long single segment exact tier
 
 __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
@@ -472,9 +475,17 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 //   * sum_b P(r|b) is the product of the per segment fp64 sums (relative error ~1e-15; the reference's Kahan sum
 //     over all barcodes is not reproduced bit for bit, so a confidence within 1e-12 of its threshold is left to
 //     the literal kernel — the only reads it still sees).
-template <int G, int S>
+// UNIQUE = distinct words a segment may hold: CROSS_MAX_UNIQUE for the combinatorial sets; a single segment set (a
+// codec that is not combinatorial, its barcode taken as one word of up to 16 nt) may hold EXACT_SINGLE_UNIQUE, its
+// lists then stop at EXACT_SINGLE_LIST entries and a read with more words that close to the maximum (ties of a read
+// without information) goes on to the literal kernel.
+template <int G, int S, int UNIQUE>
 __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs args) {
-    __shared__ uint8_t near_list[S * CROSS_MAX_UNIQUE * THREADS];             // [segment][entry][lane] word ordinals
+    static_assert(UNIQUE == CROSS_MAX_UNIQUE || S == 1, "long word lists are for single segment sets");
+    constexpr int UNIQUE_REGISTERS = UNIQUE / 64;
+    constexpr int LIST = UNIQUE == CROSS_MAX_UNIQUE ? CROSS_MAX_UNIQUE : EXACT_SINGLE_LIST;
+    typedef typename std::conditional<(UNIQUE > 256), uint16_t, uint8_t>::type Ordinal;
+    __shared__ Ordinal near_list[S * LIST * THREADS];                         // [segment][entry][lane] word ordinals
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
     __shared__ uint32_t group_start[EXACT_GROUP_MAX + 1];                     // prefix sums of the group's segment counts
@@ -510,7 +521,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     const int64_t n = static_cast<int64_t>(group_start[EXACT_GROUP_MAX]);
     const int64_t tiles = (n + THREADS - 1) / THREADS;
 
-    uint32_t word_table[S][TABLE_REGISTERS];
+    uint32_t word_table[S][UNIQUE_REGISTERS];
     int first_word[S];
     int length[S];
     uint32_t byte_shift[S];
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
         }
 #pragma unroll
-        for(int v = 0; v < TABLE_REGISTERS; ++v) {
+        for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
             const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
             word_table[s][v] = w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
         }
@@ -614,22 +625,25 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             double sum = 0;
             double listed = 0;                     // the sum over the listed words
             int count = 0;
+            bool overflow = false;
 #pragma unroll
-            for(int v = 0; v < TABLE_REGISTERS; ++v) {
+            for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
                 const int last = min(unique[s], 64 * (v + 1));
                 for(int u = 64 * v; u < last; ++u) {
                     const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
                     sum += p;
-                    if(p * near > top) { count = 0; listed = 0; }
+                    if(p * near > top) { count = 0; listed = 0; overflow = false; }
                     if(p >= top * near) {
-                        near_list[(s * CROSS_MAX_UNIQUE + count) * THREADS + threadIdx.x] = static_cast<uint8_t>(u);
-                        ++count;
+                        if(LIST >= UNIQUE || count < LIST) {
+                            near_list[(s * LIST + count) * THREADS + threadIdx.x] = static_cast<Ordinal>(u);
+                            ++count;
+                        } else { overflow = true; }
                         listed += p;
                     }
                     top = fmax(top, p);
                 }
             }
-            if(!(top > 0)) { defer = true; count = 0; }
+            if(!(top > 0) || overflow) { defer = true; count = 0; }
             near_count[s] = count;
             sum_all *= sum;
             listed_all *= listed;
@@ -646,7 +660,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                 uint32_t flags[S];
 #pragma unroll
                 for(int s = 0; s < S; ++s) {
-                    const int u = near_list[(s * CROSS_MAX_UNIQUE + choice[s]) * THREADS + threadIdx.x];
+                    const int u = near_list[(s * LIST + choice[s]) * THREADS + threadIdx.x];
                     flat += u * radix[s];
                     flags[s] = (mismatch_fields(observed[s] ^ d.cross_words[s * CROSS_MAX_UNIQUE + u]) | outside[s]) & full_mask[s];
                 }
@@ -1099,13 +1113,25 @@ inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_d
     return static_cast<int>(hipGetLastError());
 }
 
+// a single segment set of more than CROSS_MAX_UNIQUE words
+inline int launch_exact_single_long(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int S>
 int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());
