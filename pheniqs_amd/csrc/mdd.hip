@@ -19,7 +19,10 @@ __device__ __forceinline__ uint32_t nibble_nonzero(uint32_t x) {
     return x & 0x11111111u;
 }
 
-template <int W>
+// SEGMENTS: the number of barcode segments when it is 1 or 2 (their masks and tolerances then live in registers and
+// the per segment loop unrolls; with a run time segment count every barcode costs indexed scalar loads — measured on
+// the 10 + 10 nt decoder of C4: 5.6 ms per 50 M reads), 0 = any.
+template <int W, int SEGMENTS>
 __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
@@ -30,10 +33,20 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
     const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     const PHQ_CONSTANT uint32_t* packed = constant_cast(d.barcode_packed);
     const int n_barcode = d.n_barcode;
-    const int n_segment = d.n_segment;
+    const int n_segment = SEGMENTS > 0 ? SEGMENTS : d.n_segment;
     const int n_word = d.n_word;
     const int L = d.nucleotide_cardinality;
     const int stride = d.plane_stride;
+    uint32_t segment_mask[SEGMENTS > 0 ? SEGMENTS : 1][W];
+    int tolerance[SEGMENTS > 0 ? SEGMENTS : 1];
+    if(SEGMENTS > 0) {
+#pragma unroll
+        for(int s = 0; s < SEGMENTS; ++s) {
+            tolerance[s] = d.distance_tolerance[s];
+#pragma unroll
+            for(int w = 0; w < W; ++w) { segment_mask[s][w] = d.segment_mask[s][w]; }
+        }
+    }
     // as the second tier of PHQ_MODE_FAST workgroup g visits only the reads the exact match kernel deferred
     const bool consumer = args.worklist_role == 2;
     const uint32_t* const segment = consumer ? args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride : nullptr;
@@ -107,14 +120,25 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
                 if(fit < 0) {
                     int distance = 0;
                     bool successful = true;
-                    for(int s = 0; s < n_segment; ++s) {
-                        int error = 0;
+                    if(SEGMENTS > 0) {
 #pragma unroll
-                        for(int w = 0; w < W; ++w) {
-                            error += __popc((mismatch[w] | masked[w]) & counted[w] & d.segment_mask[s][w]);
+                        for(int s = 0; s < SEGMENTS; ++s) {
+                            int error = 0;
+#pragma unroll
+                            for(int w = 0; w < W; ++w) { error += __popc((mismatch[w] | masked[w]) & counted[w] & segment_mask[s][w]); }
+                            if(error > tolerance[s]) { successful = false; }
+                            distance += error;
                         }
-                        if(error > d.distance_tolerance[s]) { successful = false; }
-                        distance += error;
+                    } else {
+                        for(int s = 0; s < n_segment; ++s) {
+                            int error = 0;
+#pragma unroll
+                            for(int w = 0; w < W; ++w) {
+                                error += __popc((mismatch[w] | masked[w]) & counted[w] & d.segment_mask[s][w]);
+                            }
+                            if(error > d.distance_tolerance[s]) { successful = false; }
+                            distance += error;
+                        }
                     }
                     if(successful) { fit = b; fit_distance = distance; }
                 }
@@ -322,13 +346,19 @@ __global__ __launch_bounds__(BLOCK) void count_kernel(StageArgs args) {
 }  // namespace
 
 int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    const int segments = host_decoder.n_segment == 1 || host_decoder.n_segment == 2 ? host_decoder.n_segment : 0;
+#define PHQ_LAUNCH_MDD(W) \
+    if(segments == 1) { hipLaunchKernelGGL((mdd_kernel<W, 1>), grid, dim3(BLOCK), lds_bytes, stream, args); } \
+    else if(segments == 2) { hipLaunchKernelGGL((mdd_kernel<W, 2>), grid, dim3(BLOCK), lds_bytes, stream, args); } \
+    else { hipLaunchKernelGGL((mdd_kernel<W, 0>), grid, dim3(BLOCK), lds_bytes, stream, args); }
     switch(host_decoder.n_word) {
-        case 1: hipLaunchKernelGGL((mdd_kernel<1>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((mdd_kernel<2>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((mdd_kernel<3>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((mdd_kernel<4>), grid, dim3(BLOCK), lds_bytes, stream, args); break;
+        case 1: PHQ_LAUNCH_MDD(1) break;
+        case 2: PHQ_LAUNCH_MDD(2) break;
+        case 3: PHQ_LAUNCH_MDD(3) break;
+        case 4: PHQ_LAUNCH_MDD(4) break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
+#undef PHQ_LAUNCH_MDD
     return static_cast<int>(hipGetLastError());
 }
 
