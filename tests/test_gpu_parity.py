@@ -754,6 +754,43 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
+def test_many_decoders_and_many_segments(oracle, torch_cuda):
+    """The widest job the library takes: 16 decoders (DEV_MAX_DECODER) of every algorithm in one chain — the sticky QC
+    fail flag and the channel index travel through all of them — among them barcodes of 5 and 8 segments
+    (DEV_MAX_SEGMENT) under MDD and under PAMLD."""
+    rng = np.random.default_rng(16)
+    def words(count, length):
+        return synthetic.barcode_set(rng, count, length, min_distance=1 if length < 5 else 2)
+    five = [words(6, 3) for _ in range(5)]
+    eight = [words(5, 2) for _ in range(8)]
+    for w in five[1:] + eight[1:]:
+        rng.shuffle(w)
+    cellular = [synthetic.decoder_spec("mdd", five, ["0:%d:%d" % (3 * k, 3 * k + 3) for k in range(5)], pairing="zip"),
+                synthetic.decoder_spec("pamld", eight, ["1:%d:%d" % (2 * k, 2 * k + 2) for k in range(8)], pairing="zip"),
+                synthetic.decoder_spec("pamld", [words(40, 8)], ["0:15:23"], **{"high quality distance threshold": 1, "high quality threshold": 20}),
+                synthetic.decoder_spec("mdd", [words(30, 6)], ["1:16:22"], **{"quality masking threshold": 12}),
+                synthetic.decoder_spec("pamld", [words(7, 4), words(9, 4)], ["0:23:27", "1:22:26"]),
+                synthetic.decoder_spec("mdd", [words(7, 4), words(9, 4)], ["0:27:31", "1:26:30"]),
+                synthetic.decoder_spec("mdd", [words(2, 1)], ["0:6:7"]),
+                synthetic.decoder_spec("pamld", [words(12, 12)], ["0:31:43"]),
+                synthetic.decoder_spec("mdd", [words(12, 20)], ["1:30:50"])]
+    molecular = [{"algorithm": "naive", "transform": {"token": ["0::6"]}},
+                 synthetic.decoder_spec("pamld", [words(16, 5)], ["1::5"]),
+                 synthetic.decoder_spec("mdd", [words(16, 5)], ["0:5:10"]),
+                 {"algorithm": "naive", "transform": {"token": ["1:5:9"]}},
+                 synthetic.decoder_spec("pamld", [words(20, 18)], ["0:40:58"]),
+                 synthetic.decoder_spec("mdd", [words(3, 9)], ["1:50:59"])]
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("pamld", [words(24, 8)], ["0:7:15"]),
+            "cellular": cellular, "molecular": molecular}
+    job = jobspec.compile_job(spec)
+    assert 1 + len(job["cellular"]) + len(job["molecular"]) == 16
+    n = 5000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 8)
+    flag = (rng.random(n) < 0.2).astype(np.uint8)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=2)
+
+
 @pytest.mark.parametrize("length", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 32])
 def test_reads_without_information_sit_on_the_noise_threshold(oracle, torch_cuda, length):
     """A read of N bases (or of bases outside ACGT) costs the uniform quality at every position against every barcode:
