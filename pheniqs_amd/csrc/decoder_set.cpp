@@ -434,7 +434,7 @@ void DecoderSet::build_device_images() {
                     }
                 }
             }
-            if(d.cross_segments == 0 && c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && d.n_barcode > 1 &&
+            if(d.cross_segments == 0 && c.all_strict && c.algorithm == Algorithm::PAMLD && d.n_barcode > 1 &&
                d.n_barcode <= EXACT_SINGLE_UNIQUE && c.nucleotide_cardinality >= 1 && c.nucleotide_cardinality <= 16) {
                 // Not every combination of per segment sets (unique dual index PAIRS), or more distinct words than the
                 // factorised kernels keep: the exact tier still serves the codec with its whole barcode — the segments

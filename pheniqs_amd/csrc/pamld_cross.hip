@@ -32,7 +32,7 @@ int launch_pamld_cross(const StageArgs& args, const DevDecoder& host_decoder, di
 // the exact tier also serves single segment sets behind the per barcode product form (256 lane workgroups there too)
 bool pamld_exact_supports(const DevDecoder& host_decoder) {
     return host_decoder.cross_segments >= 1 && host_decoder.cross_segments <= CROSS_MAX_SEGMENT &&
-           (host_decoder.uniform_prior || (host_decoder.cross_segments == 2 && host_decoder.cross_prior != nullptr)) &&
+           (host_decoder.uniform_prior || host_decoder.cross_segments == 1 || (host_decoder.cross_segments == 2 && host_decoder.cross_prior != nullptr)) &&
            host_decoder.cross_groups >= 1 && host_decoder.cross_groups <= 4 &&
            host_decoder.cross_words != nullptr && host_decoder.cross_ordinal != nullptr;
 }
@@ -43,7 +43,7 @@ bool pamld_exact_supports(const DevDecoder& host_decoder) {
 // per workgroup.  Per 1 M / 4 M / 16 M C2 reads this tier took 0.099 / 0.147 / 0.149 ms with one segment per workgroup,
 // 0.046 / 0.048 / 0.081 ms grouped.
 int launch_pamld_cross_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(!host_decoder.uniform_prior) { return launch_pamld_cross_exact_weighted_s2(args, host_decoder, grid, histogram_bytes, stream); }
+    if(!host_decoder.uniform_prior && host_decoder.cross_segments != 1) { return launch_pamld_cross_exact_weighted_s2(args, host_decoder, grid, histogram_bytes, stream); }
     StageArgs grouped = args;
     grouped.worklist_segments = static_cast<int32_t>(grid.x);
     // about 1.5 % of the reads reach this tier: group segments until a workgroup can expect a tile's worth of them; a

@@ -479,9 +479,12 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 // codec that is not combinatorial, its barcode taken as one word of up to 16 nt) may hold EXACT_SINGLE_UNIQUE, its
 // lists then stop at EXACT_SINGLE_LIST entries and a read with more words that close to the maximum (ties of a read
 // without information) goes on to the literal kernel.
-template <int G, int S, int UNIQUE>
+// PRIORS (single segment sets only): the barcodes' priors differ, every word's probability carries its prior through
+// the sum, the maximum and the list, as the reference's loop does (pamld.cpp:66-79).
+template <int G, int S, int UNIQUE, bool PRIORS>
 __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs args) {
     static_assert(UNIQUE == CROSS_MAX_UNIQUE || S == 1, "long word lists are for single segment sets");
+    static_assert(!PRIORS || S == 1, "priors by word are for single segment sets");
     constexpr int UNIQUE_REGISTERS = UNIQUE / 64;
     constexpr int LIST = UNIQUE == CROSS_MAX_UNIQUE ? CROSS_MAX_UNIQUE : EXACT_SINGLE_LIST;
     typedef typename std::conditional<(UNIQUE > 256), uint16_t, uint8_t>::type Ordinal;
@@ -630,7 +633,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
                 const int last = min(unique[s], 64 * (v + 1));
                 for(int u = 64 * v; u < last; ++u) {
-                    const double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
+                    double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
+                    if(PRIORS) { p *= d.concentration[d.cross_ordinal[u]]; }            // wave uniform: scalar loads
                     sum += p;
                     if(p * near > top) { count = 0; listed = 0; overflow = false; }
                     if(p >= top * near) {
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             distance += __popc(best_flags[s]);
             hq_distance += __popc(best_flags[s] & high_quality[s]);
         }
-        const double total = (weighted ? weighted_sum : sum_all * d.concentration[0]) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+        const double total = (weighted ? weighted_sum : PRIORS ? sum_all : sum_all * d.concentration[0]) + d.adjusted_noise_probability;   // pamld.cpp:61-86
         double confidence = best_p / total;                                          // pamld.cpp:92
         const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
         if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
@@ -1113,13 +1117,14 @@ inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_d
     return static_cast<int>(hipGetLastError());
 }
 
-// a single segment set of more than CROSS_MAX_UNIQUE words
-inline int launch_exact_single_long(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+// a single segment set: more than CROSS_MAX_UNIQUE words and / or priors that differ
+template <int UNIQUE, bool PRIORS>
+int launch_exact_single(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, 1, EXACT_SINGLE_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());
@@ -1128,10 +1133,10 @@ inline int launch_exact_single_long(const StageArgs& args, const DevDecoder& hos
 template <int S>
 int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S, CROSS_MAX_UNIQUE>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
         default: return static_cast<int>(hipErrorInvalidValue);
     }
     return static_cast<int>(hipGetLastError());

@@ -4,7 +4,12 @@
 namespace phq {
 
 int launch_pamld_cross_exact_s1(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(host_decoder.cross_unique[0] > CROSS_MAX_UNIQUE) { return cross::launch_exact_single_long(args, host_decoder, grid, histogram_bytes, stream); }
+    const bool many = host_decoder.cross_unique[0] > CROSS_MAX_UNIQUE;
+    if(!host_decoder.uniform_prior) {
+        return many ? cross::launch_exact_single<EXACT_SINGLE_UNIQUE, true>(args, host_decoder, grid, histogram_bytes, stream)
+                    : cross::launch_exact_single<CROSS_MAX_UNIQUE, true>(args, host_decoder, grid, histogram_bytes, stream);
+    }
+    if(many) { return cross::launch_exact_single<EXACT_SINGLE_UNIQUE, false>(args, host_decoder, grid, histogram_bytes, stream); }
     return cross::launch_exact_segments<1>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
