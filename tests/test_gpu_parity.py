@@ -243,6 +243,28 @@ def test_ties_keep_the_lowest_index(oracle, torch_cuda, mode):
     assert set(got[0]["index"][:64]) <= {0, 1}
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("priors", [(1, 1, 1, 1, 1, 1), (1, 2, 2, 1, 1, 1), (3, 1, 1, 3.0000000000000004, 1, 1), (1, 1, 1e-9, 1, 1, 1)])
+def test_ties_and_priors(oracle, torch_cuda, mode, priors):
+    """Equidistant barcodes under uniform qualities have the same conditional probability: the prior decides the argmax
+    (pamld.cpp:66-79), the lowest index among equal products, and a prior one ulp larger wins.  With a confidence
+    threshold of exactly 1/2 and two tied barcodes the posterior sits on the threshold (strict '>': low confidence)."""
+    words = ["AAAAAAAA", "AAAACCCC", "CCCCAAAA", "CCCCCCCC", "GGGGGGGG", "TTTTTTTT"]
+    spec = {"input segment cardinality": 1,
+            "sample": {"algorithm": "pamld", "transform": {"token": ["0::8"]}, "noise": 0.0, "confidence threshold": 0.5,
+                       "codec": {"@" + w: {"barcode": [w], "concentration": float(c)} for w, c in zip(words, priors)}}}
+    job = jobspec.compile_job(spec)
+    rng = np.random.default_rng(4)
+    n = 2048
+    letters = np.array([1, 2, 4, 8], dtype=np.uint8)
+    code = letters[rng.integers(0, 4, size=(n, 8))]
+    code[:64] = letters[np.array([0, 0, 1, 1, 0, 0, 1, 1])]            # AACCAACC: distance 4 to the first four barcodes
+    code[64:128] = letters[np.array([0, 0, 0, 0, 0, 0, 1, 1])]         # AAAAAACC: distance 2 to the first two
+    quality = np.full((n, 8), 30, dtype=np.uint8)
+    quality[128:] = np.array([37, 25, 12, 2], dtype=np.uint8)[rng.integers(0, 4, size=(n - 128, 8))]
+    assert_parity(oracle, torch_cuda, job, code, quality, None, [0], mode=mode)
+
+
 @pytest.mark.parametrize("lengths,counts", [((6, 9), (12, 10)), ((10, 10), (24, 16)), ((4, 7, 5), (5, 6, 4)), ((16, 3), (7, 9)), ((1, 1), (4, 4)),
                                             ((7, 10, 4), (16, 14, 14)), ((12, 3, 9), (6, 9, 5))])
 def test_combinatorial_sets_factorise(oracle, torch_cuda, lengths, counts):
