@@ -52,15 +52,16 @@ public:
     FastqStream(const FastqStream&) = delete;
     FastqStream& operator=(const FastqStream&) = delete;
 
-    // the next up to `capacity` records: line[4 i + k] = (offset, size) of line k of record i inside data()
-    int64_t index_records(int64_t capacity, std::vector<std::pair<size_t, uint32_t>>& line) {
+    // the next up to `capacity` records: line[4 i + k] = (offset, size) of line k of record i inside data().
+    // Line ends are found on `threads` threads over slices of the buffered bytes (a memchr per 40 byte line costs
+    // more in call overhead than in scanning), about as many bytes at a time as the lines still wanted should take.
+    int64_t index_records(int64_t capacity, int32_t threads, std::vector<std::pair<size_t, uint32_t>>& line) {
         line.clear();
-        size_t scan = begin_;
+        size_t scan = begin_;                       // first byte that belongs to no line yet
+        size_t searched = begin_;                   // bytes before this hold no unseen line end
         const size_t wanted = static_cast<size_t>(capacity) * 4;
         while(line.size() < wanted) {
-            const char* start = buffer_.data() + scan;
-            const void* newline = scan < end_ ? std::memchr(start, '\n', end_ - scan) : nullptr;
-            if(newline == nullptr) {
+            if(searched >= end_) {
                 if(eof_) {
                     if(scan < end_) {                                          // last line without a newline
                         push(line, scan, end_ - scan);
@@ -73,12 +74,21 @@ public:
                 const size_t shift = begin_;
                 refill();
                 scan -= shift;
+                searched -= shift;
                 for(auto& l : line) { l.first -= shift; }
                 continue;
             }
-            const size_t size = static_cast<const char*>(newline) - start;
-            push(line, scan, size);
-            scan += size + 1;
+            const size_t missing = wanted - line.size();
+            const size_t guess = static_cast<size_t>(static_cast<double>(missing) * bytes_per_line_ * 1.02) + 4096;
+            const size_t until = std::min(end_, searched + guess);
+            find_line_ends(searched, until, threads);
+            for(const size_t newline : line_end_) {
+                if(line.size() >= wanted) { break; }
+                push(line, scan, newline - scan);
+                scan = newline + 1;
+            }
+            if(line.size() >= wanted) { break; }
+            searched = until;
         }
         const size_t records = line.size() / 4;
         if(line.size() % 4 != 0) {
@@ -88,6 +98,7 @@ public:
         consumed_ = records > 0 ? line[records * 4 - 1].first + line[records * 4 - 1].second + 1 : scan;
         if(records * 4 == line.size() && line.size() < wanted) { consumed_ = scan; }      // end of input: trailing blank lines too
         if(consumed_ > end_) { consumed_ = end_; }
+        if(records > 0 && consumed_ > begin_) { bytes_per_line_ = static_cast<double>(consumed_ - begin_) / static_cast<double>(records * 4); }
         return static_cast<int64_t>(records);
     }
     void release() { begin_ = consumed_; }                 // the indexed records have been decoded
@@ -95,6 +106,28 @@ public:
     const std::string& path() const { return path_; }
 
 private:
+    // offsets of every '\n' in [first, last), in order, into line_end_
+    void find_line_ends(size_t first, size_t last, int32_t threads) {
+        line_end_.clear();
+        const int64_t bytes = static_cast<int64_t>(last - first);
+        static const int index_threads = []() { const char* text = std::getenv("PHQ_INDEX_THREADS"); return text ? std::max(1, std::atoi(text)) : 0; }();      // measurement aid
+        const int parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(index_threads > 0 ? index_threads : threads, bytes >> 20)));
+        if(static_cast<int>(part_end_.size()) < parts) { part_end_.resize(static_cast<size_t>(parts)); }
+        const char* const bytes_at = buffer_.data();
+        parallel_ranges(bytes, 1 << 20, parts, [&](int64_t from, int64_t to, int part) {
+            std::vector<size_t>& found = part_end_[static_cast<size_t>(part)];
+            found.clear();
+            const char* at = bytes_at + first + from;
+            const char* const stop = bytes_at + first + to;
+            while(at < stop) {
+                const void* newline = std::memchr(at, '\n', static_cast<size_t>(stop - at));
+                if(newline == nullptr) { break; }
+                found.push_back(static_cast<size_t>(static_cast<const char*>(newline) - bytes_at));
+                at = static_cast<const char*>(newline) + 1;
+            }
+        });
+        for(int part = 0; part < parts; ++part) { line_end_.insert(line_end_.end(), part_end_[static_cast<size_t>(part)].begin(), part_end_[static_cast<size_t>(part)].end()); }
+    }
     void push(std::vector<std::pair<size_t, uint32_t>>& line, size_t offset, size_t size) {
         if(size > 0 && buffer_[offset + size - 1] == '\r') { --size; }
         if(size == 0 && line.size() % 4 == 0) { return; }                      // blank line between records
@@ -119,6 +152,9 @@ private:
     size_t end_;
     size_t consumed_ = 0;
     bool eof_;
+    double bytes_per_line_ = 64;                     // of the previous batch: how far to look for the lines of the next
+    std::vector<size_t> line_end_;
+    std::vector<std::vector<size_t>> part_end_;
 };
 
 struct SegmentBatch {
@@ -158,7 +194,7 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
     }();
     out.clear();
     try {
-        const int64_t n = stream.index_records(capacity, out.line);
+        const int64_t n = stream.index_records(capacity, threads, out.line);
         const char* const data = stream.data();
         const auto& line = out.line;
         // name up to the first whitespace (kseq), comment after it
