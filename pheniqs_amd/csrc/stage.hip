@@ -20,7 +20,7 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
     if(mode != MODE_FAST) { return false; }
-    return (host_decoder.algorithm == 1 && (pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder) || pamld_wide_supports(host_decoder))) ||
+    return (host_decoder.algorithm == 1 && (pamld_tiny_supports(host_decoder) || pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder) || pamld_wide_supports(host_decoder))) ||
            (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
 
@@ -64,9 +64,11 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // both launches use the same grid: literal workgroup g consumes what product form workgroup g deferred
                 // a combinatorial barcode set too large for the per barcode product form goes through the factorised one
                 // ... and long barcodes that are not combinatorial through the two word product form
-                const bool factorised = !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
-                const bool long_words = !pamld_lut_supports(host_decoder) && !factorised;
-                const int64_t threads = factorised ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
+                // ... and a codec of a handful of barcodes through the kernel without tables (pamld_tiny.hip)
+                const bool tiny = pamld_tiny_supports(host_decoder);
+                const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
+                const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
+                const int64_t threads = (tiny || factorised) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 const int64_t product_blocks = (factorised || long_words) ? default_blocks : share(GRID_SHARE_LUT);
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < product_blocks ? wide_tiles : product_blocks));
@@ -77,7 +79,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 int status;
                 {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
-                    status = factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
+                    status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
+                           : factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : long_words ? launch_pamld_wide(producer, host_decoder, wide_grid, histogram_bytes, s)
                                         : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 }
