@@ -206,7 +206,8 @@ int phq_transcode_plan(phq_decoder_set* set, char** plan_json);
 #define PHQ_KERNEL_COUNT            3
 #define PHQ_KERNEL_MDD_EXACT        4
 #define PHQ_KERNEL_PAMLD_EXACT      5   /* factorised exact tier of combinatorial barcode sets */
-#define PHQ_KERNEL_KINDS            6
+#define PHQ_KERNEL_PAMLD_NEAR       6   /* neighbour list tier in front of the product form kernel */
+#define PHQ_KERNEL_KINDS            7
 int phq_profile_enable(phq_decoder_set* set, int32_t enable);
 int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNEL_KINDS] */, int64_t* launches /* [PHQ_KERNEL_KINDS] */);
 

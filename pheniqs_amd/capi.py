@@ -280,7 +280,7 @@ class DecoderSet:
         finally:
             self.lib.phq_free_string(out)
 
-    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact", "pamld_exact")
+    KERNEL_KINDS = ("pamld_product", "pamld_literal", "mdd", "count", "mdd_exact", "pamld_exact", "pamld_near")
 
     def profile_enable(self, enable: bool = True):
         self._check(self.lib.phq_profile_enable(self.handle, 1 if enable else 0))

@@ -317,6 +317,65 @@ void DecoderSet::build_device_images() {
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
             }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.nucleotide_cardinality >= 5 && c.nucleotide_cardinality <= 8 &&
+               d.n_barcode > NEAR_LIST && d.n_barcode <= NEAR_MAX_BARCODES) {
+                // neighbour list tier (pamld_near.hpp): the nearest barcode of every possible word, and per barcode the
+                // bit planes of the NEAR_LIST barcodes nearest to it with what bounds the others
+                const int32_t L = c.nucleotide_cardinality;
+                const int32_t N = d.n_barcode;
+                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
+                for(int32_t b = 0; b < N; ++b) {
+                    for(int32_t j = 0; j < L; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
+                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
+                    }
+                }
+                auto distance = [&](uint32_t low_a, uint32_t high_a, uint32_t low_b, uint32_t high_b) {
+                    return __builtin_popcount((low_a ^ low_b) | (high_a ^ high_b));
+                };
+                std::vector<uint16_t> nearest(static_cast<size_t>(1) << 16, 0);
+                const uint32_t position_mask = (1u << L) - 1u;
+                for(uint32_t key = 0; key < (1u << 16); ++key) {
+                    const uint32_t key_low = key & 0xffu & position_mask;
+                    const uint32_t key_high = (key >> 8) & position_mask;
+                    int best = 0, best_distance = 99;
+                    for(int32_t b = 0; b < N; ++b) {
+                        const int dist = distance(key_low, key_high, low[static_cast<size_t>(b)], high[static_cast<size_t>(b)]);
+                        if(dist < best_distance) { best_distance = dist; best = b; }
+                    }
+                    nearest[key] = static_cast<uint16_t>(best);
+                }
+                std::vector<uint32_t> record(static_cast<size_t>(N) * NEAR_RECORD_WORDS, 0u);
+                int32_t usable = 0;
+                std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
+                for(int32_t b = 0; b < N; ++b) {
+                    for(int32_t o = 0; o < N; ++o) {
+                        order[static_cast<size_t>(o)] = {o == b ? -1 : distance(low[static_cast<size_t>(b)], high[static_cast<size_t>(b)], low[static_cast<size_t>(o)], high[static_cast<size_t>(o)]), o};
+                    }
+                    std::sort(order.begin(), order.end());               // b itself first, then by (distance, ordinal)
+                    uint32_t* out = &record[static_cast<size_t>(b) * NEAR_RECORD_WORDS];
+                    for(int32_t k = 0; k < NEAR_LIST; ++k) {
+                        const int32_t o = order[static_cast<size_t>(k)].second;
+                        out[2 * (k / 4)] |= low[static_cast<size_t>(o)] << (8 * (k % 4));
+                        out[2 * (k / 4) + 1] |= high[static_cast<size_t>(o)] << (8 * (k % 4));
+                    }
+                    // the first barcode not listed sets the radius, at most 5 (the kernel forms its bounds for 4 and 5)
+                    const int radius = std::min(order[static_cast<size_t>(NEAR_LIST)].first, 5);
+                    int at_radius = 0;
+                    for(int32_t k = NEAR_LIST; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
+                    const float cnt_r = static_cast<float>(at_radius);
+                    const float cnt_rest = static_cast<float>(N - NEAR_LIST - at_radius);
+                    out[8] = static_cast<uint32_t>(radius);
+                    std::memcpy(&out[9], &cnt_r, sizeof(float));
+                    std::memcpy(&out[10], &cnt_rest, sizeof(float));
+                    if(radius >= 4) { ++usable; }
+                }
+                d.near_table = static_cast<const uint16_t*>(upload(nearest.data(), nearest.size() * sizeof(uint16_t)));
+                d.near_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                d.near_ready = 2 * usable >= N ? 1 : 0;                  // a denser set leaves the kernel nothing to finish
+            }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {
                 // two words of bit-sliced 2-bit bases per barcode for the long barcode product form (pamld_wide.hpp)
                 const int32_t padded = (d.n_barcode + 7) / 8 * 8;

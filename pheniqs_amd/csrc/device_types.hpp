@@ -11,7 +11,10 @@ constexpr int DEV_MAX_WORD = 4;          // 8 nucleotides per 32-bit word of 4-b
 constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
-constexpr int EXACT_SINGLE_UNIQUE = 512; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
+constexpr int EXACT_SINGLE_UNIQUE = 512;
+constexpr int NEAR_LIST = 16;             // barcodes the neighbour list kernel scores per read (pamld_near.hpp)
+constexpr int NEAR_RECORD_WORDS = 12;
+constexpr int NEAR_MAX_BARCODES = 1024; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
 
 // Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]
 // (TranscodingDecoder::count/pf_count, transcode.h:61-64).  Then per decoder, per barcode bin
@@ -94,6 +97,15 @@ struct DevDecoder {
     // barcodes share a word (even barcode in the low half); padded to whole blocks of 8 barcodes
     const uint32_t* barcode_packed2;
     const float* concentration_single;    // padded with zeros to whole blocks of 8 barcodes
+    // neighbour list kernel only (pamld_near.hpp; ACGT barcodes of 5 to 8 nt, uniform priors): near_table[key] = the
+    // barcode nearest to the word whose 2-bit codes are key (low code bits of positions 0..7 in bits 0..7, high code
+    // bits in bits 8..15; Hamming distance, lowest ordinal on ties), 4^8 entries; near_record[c] = NEAR_RECORD_WORDS
+    // words: the 16 barcodes {c, the 15 nearest to c} as 4 x {low plane word, high plane word} (byte b of a plane
+    // word = barcode 4 g + b, bit j = position j), then the radius (distance from c of the nearest barcode not listed,
+    // at most 5), the number of barcodes not listed at that distance and further away (two floats), and padding
+    const uint16_t* near_table;
+    const uint32_t* near_record;
+    int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
     // MDD exact match (mdd.cpp:43-46): open addressing hash of the ACGT barcodes; slot = {key low, key high,
     // ordinal + 1 (0 = empty), barcode index}, key = 2 bits per base, position j at bits 2j
     const uint32_t* exact_table;
@@ -154,7 +166,7 @@ struct StageArgs {
 };
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
-enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_KINDS = 6 };
+enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_PAMLD_NEAR = 6, KERNEL_KINDS = 7 };
 struct LaunchTimer {
     virtual ~LaunchTimer() {}
     virtual void begin(int32_t kind, void* stream) = 0;

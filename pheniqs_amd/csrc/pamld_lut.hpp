@@ -91,7 +91,10 @@ constexpr int LUT_MAX_WORDS = 512;                // packed words of a codec: 1 
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 
-template <int L, bool UNIFORM_PRIOR>
+// CONSUMER: instead of every read of the batch, the kernel visits the reads an earlier tier (pamld_near.hpp) left in
+// this workgroup's worklist segment, and compacts what it defers itself back into the same segment (in place: a
+// barrier per tile keeps every wave's reads of the list ahead of the writes).
+template <int L, bool UNIFORM_PRIOR, bool CONSUMER>
 __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(StageArgs args) {
     constexpr int G = (L + 3) / 4;            // groups of 4 positions = bytes of the field word
     constexpr int THREADS = LutGeometry<L>::THREADS;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     // read back per lane.
     const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
-    const int64_t n = args.n_read;
+    const int64_t n = CONSUMER ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     constexpr bool PERMUTED = Layout::PERMUTED;
     constexpr uint32_t GROUP_STEP = Layout::GROUP_STEP;
@@ -161,11 +164,15 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 #pragma unroll
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
 
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for(int64_t tile = CONSUMER ? 0 : blockIdx.x; tile < tiles; tile += CONSUMER ? 1 : gridDim.x) {
         // every lane stays enabled (one code path, whole wave LDS traffic): lanes past the end
         // of the batch recompute its last read and are kept from every store and counter
         const bool active = tile * THREADS + threadIdx.x < n;
-        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        if(CONSUMER) {
+            i = static_cast<int64_t>(segment[i]);
+            __syncthreads();                   // every entry of this tile is read before any wave compacts into it
+        }
         ReadState r{false, 0};
         bool defer = false;
         {
@@ -481,12 +488,12 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     histogram_flush(args, d, histogram);
 }
 
-template <int L, bool UNIFORM_PRIOR>
+template <int L, bool UNIFORM_PRIOR, bool CONSUMER>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t lds_bytes = LutGeometry<L>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_lut_kernel<L, UNIFORM_PRIOR>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_lut_kernel<L, UNIFORM_PRIOR, CONSUMER>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_lut_kernel<L, UNIFORM_PRIOR, CONSUMER>), grid, dim3(LutGeometry<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
@@ -498,8 +505,12 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            return host_decoder.uniform_prior ? launch_one<LO, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)
-                                              : launch_one<LO, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+            if constexpr(LO >= 5 && LO <= 8) {
+                // the lengths the neighbour list kernel (pamld_near.hpp) takes, uniform priors: this kernel behind it
+                if(args.worklist_role == 2) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
+            }
+            return host_decoder.uniform_prior ? launch_one<LO, true, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)
+                                              : launch_one<LO, false, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
         }
         return launch_range<LO + 1, HI>(args, host_decoder, grid, histogram_bytes, stream);
     }

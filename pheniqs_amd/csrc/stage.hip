@@ -66,6 +66,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // ... and long barcodes that are not combinatorial through the two word product form
                 // ... and a codec of a handful of barcodes through the kernel without tables (pamld_tiny.hip)
                 const bool tiny = pamld_tiny_supports(host_decoder);
+                const bool listed = !tiny && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 const int64_t threads = (tiny || factorised) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
@@ -77,7 +78,17 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.worklist_role = 1;
                 producer.worklist_stride = static_cast<int32_t>(tiles_per_block * threads);
                 int status;
-                {
+                if(listed) {
+                    {
+                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
+                        status = launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s);
+                    }
+                    if(status != 0) { return status; }
+                    StageArgs middle = producer;
+                    middle.worklist_role = 2;
+                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
+                    status = launch_pamld_lut(middle, host_decoder, wide_grid, histogram_bytes, s);
+                } else {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
                     status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)

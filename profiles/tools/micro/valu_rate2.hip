@@ -1,0 +1,117 @@
+// Issue rate of vector instructions on gfx950 by opcode: cycles per wave-instruction per SIMD at 4 waves per SIMD,
+// in shader cycles (s_memtime), independent of the clock the chip holds.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define REP16(x) x x x x x x x x x x x x x x x x
+#define I4(op, a, b, c, d) asm volatile(op : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(k0), "v"(k1), "s"(s0));
+
+template <int KIND>
+__global__ void rate_kernel(unsigned long long* out, int loops, unsigned seed) {
+    unsigned a0 = threadIdx.x + seed, a1 = a0 * 3u, a2 = a0 * 5u, a3 = a0 * 7u;
+    unsigned k0 = a0 * 11u, k1 = a0 * 13u;
+    unsigned long long s0 = 0x5555aaaa5555aaaaull ^ seed;
+    float f0 = a0 * 1e-9f, f1 = a1 * 1e-9f, f2 = a2 * 1e-9f, f3 = a3 * 1e-9f;
+    float g0 = 1.0f + k0 * 1e-12f, g1 = 1.0f - k1 * 1e-12f;
+    double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    float2v p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f1, f0}, p3 = {f3, f2}, q0 = {g0, g1};
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for(int l = 0; l < loops; ++l) {
+#define INT4(op) REP16(asm volatile(op " %0, %0, %4\n" op " %1, %1, %5\n" op " %2, %2, %4\n" op " %3, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));)
+#define INT4_3(op) REP16(asm volatile(op " %0, %0, %4, %5\n" op " %1, %1, %5, %4\n" op " %2, %2, %4, %5\n" op " %3, %3, %5, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));)
+#define F4(op) REP16(asm volatile(op " %0, %0, %4\n" op " %1, %1, %5\n" op " %2, %2, %4\n" op " %3, %3, %5" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(g0), "v"(g1));)
+#define F4_3(op) REP16(asm volatile(op " %0, %0, %4, %5\n" op " %1, %1, %5, %4\n" op " %2, %2, %4, %5\n" op " %3, %3, %5, %4" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(g0), "v"(g1));)
+#define P4(op) REP16(asm volatile(op " %0, %0, %4\n" op " %1, %1, %4\n" op " %2, %2, %4\n" op " %3, %3, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q0));)
+#define P4_3(op) REP16(asm volatile(op " %0, %0, %4, %4\n" op " %1, %1, %4, %4\n" op " %2, %2, %4, %4\n" op " %3, %3, %4, %4" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(q0));)
+        if(KIND == 0) { INT4("v_xor_b32") }
+        else if(KIND == 1) { INT4("v_and_b32") }
+        else if(KIND == 2) { INT4("v_or_b32") }
+        else if(KIND == 3) { INT4("v_add_u32") }
+        else if(KIND == 4) { INT4("v_sub_u32") }
+        else if(KIND == 5) { INT4("v_lshlrev_b32") }
+        else if(KIND == 6) { INT4("v_lshrrev_b32") }
+        else if(KIND == 7) { INT4("v_mul_u32_u24") }
+        else if(KIND == 8) { INT4("v_min_u32") }
+        else if(KIND == 9) { INT4_3("v_lshl_or_b32") }
+        else if(KIND == 10) { INT4_3("v_lshl_add_u32") }
+        else if(KIND == 11) { INT4_3("v_add3_u32") }
+        else if(KIND == 12) { INT4_3("v_or3_b32") }
+        else if(KIND == 13) { INT4_3("v_and_or_b32") }
+        else if(KIND == 14) { INT4_3("v_perm_b32") }
+        else if(KIND == 15) { INT4_3("v_alignbit_b32") }
+        else if(KIND == 16) { INT4_3("v_bfe_u32") }
+        else if(KIND == 17) { INT4_3("v_bfi_b32") }
+        else if(KIND == 18) { INT4_3("v_mad_u32_u24") }
+        else if(KIND == 19) { INT4_3("v_sad_u8") }
+        else if(KIND == 20) { INT4("v_bcnt_u32_b32") }
+        else if(KIND == 21) { INT4("v_mul_lo_u32") }
+        else if(KIND == 22) { INT4_3("v_min3_u32") }
+        else if(KIND == 23) { REP16(asm volatile("v_bitop3_b32 %0, %0, %4, %5 bitop3:0x36\n v_bitop3_b32 %1, %1, %5, %4 bitop3:0x36\n v_bitop3_b32 %2, %2, %4, %5 bitop3:0x36\n v_bitop3_b32 %3, %3, %5, %4 bitop3:0x36" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));) }
+        else if(KIND == 24) { REP16(asm volatile("v_cndmask_b32_e64 %0, %0, %4, %6\n v_cndmask_b32_e64 %1, %1, %5, %6\n v_cndmask_b32_e64 %2, %2, %4, %6\n v_cndmask_b32_e64 %3, %3, %5, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1), "s"(s0));) }
+        else if(KIND == 25) { REP16(asm volatile("v_cmp_gt_u32_e64 %6, %0, %4\n v_cmp_gt_u32_e64 %6, %1, %5\n v_cmp_gt_u32_e64 %6, %2, %4\n v_cmp_gt_u32_e64 %6, %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1), "s"(s0));) }
+        else if(KIND == 26) { REP16(asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %5\n v_mov_b32 %2, %4\n v_mov_b32 %3, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));) }
+        else if(KIND == 30) { F4("v_add_f32") }
+        else if(KIND == 31) { F4("v_mul_f32") }
+        else if(KIND == 32) { F4("v_max_f32") }
+        else if(KIND == 33) { F4_3("v_fma_f32") }
+        else if(KIND == 34) { F4_3("v_max3_f32") }
+        else if(KIND == 35) { F4_3("v_med3_f32") }
+        else if(KIND == 36) { F4("v_ldexp_f32") }
+        else if(KIND == 37) { REP16(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %4\n v_cvt_f32_u32 %3, %5" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(k0), "v"(k1));) }
+        else if(KIND == 38) { REP16(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3));) }
+        else if(KIND == 39) { REP16(asm volatile("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %5, %4\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %5, %4" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(g0), "v"(g1));) }
+        else if(KIND == 40) { P4("v_pk_mul_f32") }
+        else if(KIND == 41) { P4("v_pk_add_f32") }
+        else if(KIND == 42) { P4_3("v_pk_fma_f32") }
+        else if(KIND == 50) { REP16(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(s0));) }
+        else if(KIND == 51) { REP16(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(s0));) }
+        else if(KIND == 52) { REP16(asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(s0));) }
+        else if(KIND == 53) { REP16(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %4\n v_cvt_f64_f32 %3, %5" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(g0), "v"(g1));) }
+        else if(KIND == 54) { REP16(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %4\n v_cvt_f32_f64 %3, %5" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3) : "v"(d0), "v"(d1));) }
+        else if(KIND == 55) { REP16(asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        else if(KIND == 56) { REP16(asm volatile("v_max_f64 %0, %0, %4\n v_max_f64 %1, %1, %4\n v_max_f64 %2, %2, %4\n v_max_f64 %3, %3, %4" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(s0));) }
+        else if(KIND == 57) { REP16(asm volatile("v_lshlrev_b64 %0, 3, %0\n v_lshlrev_b64 %1, 3, %1\n v_lshlrev_b64 %2, 3, %2\n v_lshlrev_b64 %3, 3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        else if(KIND == 60) { REP16(asm volatile("v_readlane_b32 %4, %0, 3\n v_readlane_b32 %4, %1, 5\n v_readlane_b32 %4, %2, 7\n v_readlane_b32 %4, %3, 9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(seed));) }
+        else if(KIND == 61) { REP16(asm volatile("v_mov_b32_dpp %0, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %5 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));) }
+        else if(KIND == 62) { REP16(asm volatile("v_and_b32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %1, %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %2, %2, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n v_and_b32_sdwa %3, %3, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(k0), "v"(k1));) }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    unsigned r = a0 ^ a1 ^ a2 ^ a3 ^ seed;
+    float f = f0 + f1 + f2 + f3 + p0.x + p1.y + p2.x + p3.y;
+    double d = d0 + d1 + d2 + d3;
+    if(r == 0x12345u && f == 1.5f && d == 2.5) out[1] = 1;
+    if(threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+}
+
+template <int KIND> void run(const char* name) {
+    unsigned long long* out; (void)hipMalloc(&out, 16);
+    const int loops = 1000, per_loop = 64, waves_per_simd = 4;
+    const int threads = 256, blocks = 256 * waves_per_simd;
+    rate_kernel<KIND><<<blocks, threads>>>(out, 10, 1);
+    (void)hipDeviceSynchronize();
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a);
+    rate_kernel<KIND><<<blocks, threads>>>(out, loops, 1);
+    (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    unsigned long long cycles = 0; (void)hipMemcpy(&cycles, out, 8, hipMemcpyDeviceToHost);
+    const double instr_per_simd = double(loops) * per_loop * waves_per_simd;
+    printf("%-18s %.2f shader cycles per wave-instruction per SIMD  (%.3f ms, clock %.2f GHz)\n", name, cycles / instr_per_simd, ms, cycles / (ms * 1e6));
+    (void)hipFree(out);
+}
+
+int main() {
+    run<0>("v_xor_b32"); run<1>("v_and_b32"); run<2>("v_or_b32"); run<3>("v_add_u32"); run<4>("v_sub_u32");
+    run<5>("v_lshlrev_b32"); run<6>("v_lshrrev_b32"); run<7>("v_mul_u32_u24"); run<8>("v_min_u32");
+    run<9>("v_lshl_or_b32"); run<10>("v_lshl_add_u32"); run<11>("v_add3_u32"); run<12>("v_or3_b32"); run<13>("v_and_or_b32");
+    run<14>("v_perm_b32"); run<15>("v_alignbit_b32"); run<16>("v_bfe_u32"); run<17>("v_bfi_b32"); run<18>("v_mad_u32_u24");
+    run<19>("v_sad_u8"); run<20>("v_bcnt_u32_b32"); run<21>("v_mul_lo_u32"); run<22>("v_min3_u32"); run<23>("v_bitop3_b32");
+    run<24>("v_cndmask_b32_e64"); run<25>("v_cmp_gt_u32_e64"); run<26>("v_mov_b32");
+    run<30>("v_add_f32"); run<31>("v_mul_f32"); run<32>("v_max_f32"); run<33>("v_fma_f32"); run<34>("v_max3_f32"); run<35>("v_med3_f32");
+    run<36>("v_ldexp_f32"); run<37>("v_cvt_f32_u32"); run<38>("v_rcp_f32"); run<39>("v_fmac_f32");
+    run<40>("v_pk_mul_f32"); run<41>("v_pk_add_f32"); run<42>("v_pk_fma_f32");
+    run<50>("v_mul_f64"); run<51>("v_add_f64"); run<52>("v_fma_f64"); run<53>("v_cvt_f64_f32"); run<54>("v_cvt_f32_f64"); run<55>("v_rcp_f64"); run<56>("v_max_f64"); run<57>("v_lshlrev_b64");
+    run<60>("v_readlane_b32"); run<61>("v_mov_b32_dpp"); run<62>("v_and_b32_sdwa");
+    return 0;
+}
