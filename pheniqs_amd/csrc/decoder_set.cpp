@@ -370,6 +370,7 @@ void DecoderSet::build_device_images() {
                     out[8] = static_cast<uint32_t>(radius);
                     std::memcpy(&out[9], &cnt_r, sizeof(float));
                     std::memcpy(&out[10], &cnt_rest, sizeof(float));
+                    out[11] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
                     if(radius >= 4) { ++usable; }
                 }
                 d.near_table = static_cast<const uint16_t*>(upload(nearest.data(), nearest.size() * sizeof(uint16_t)));

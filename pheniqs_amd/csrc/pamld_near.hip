@@ -6,7 +6,7 @@ namespace phq {
 bool pamld_near_supports(const DevDecoder& host_decoder) {
     return pamld_lut_supports(host_decoder) && host_decoder.near_ready != 0 && host_decoder.uniform_prior != 0 &&
            host_decoder.nucleotide_cardinality >= 5 && host_decoder.nucleotide_cardinality <= 8 &&
-           host_decoder.plane_stride == 8 && host_decoder.n_barcode > NEAR_LIST &&
+           host_decoder.plane_stride == 8 && host_decoder.n_barcode > NEAR_LIST && host_decoder.use_lds_histogram != 0 &&
            near::Layout::histogram_at(host_decoder.n_barcode) + 8u * (STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN : STAT_WORDS_PER_BIN)) <= 160u * 1024u;
 }
 

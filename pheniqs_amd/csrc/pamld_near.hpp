@@ -74,7 +74,10 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
     return __builtin_amdgcn_bitop3_b32(a, mask, c, 0xEA);
 }
 
-template <int L>
+// STATE: where a read's carried state comes from — 0 the first stage of a job without input flags (nothing to load),
+// 1 the first stage with flag bytes, 2 a later stage (the status word).  A template parameter so that the loads of
+// the prefetch sit in straight line code: behind a branch the compiler can no longer count them and waits for all.
+template <int L, int STATE>
 __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -95,7 +98,6 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     histogram_clear(d, histogram);
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const uint16_t* const nearest = d.near_table;
     const int64_t n = args.n_read;
@@ -109,16 +111,38 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     const double confidence_threshold = d.confidence_threshold;
     constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);     // the bytes of positions 4 .. L - 1
 
+    // A tile's inputs are fetched one tile ahead — behind this tile's table lookup, so that waiting for the lookup does
+    // not wait for them (vector memory operations complete in issue order) — through a scalar tile base and a 32-bit
+    // lane offset.  Lanes past the end of the batch recompute its last read and are kept from every store and counter.
+    struct Inputs { uint32_t code0, code1, quality0, quality1, state; };
+    auto fetch = [&](int64_t tile, Inputs& in) {
+        const int64_t first = tile * THREADS;
+        const uint32_t last = static_cast<uint32_t>(min(static_cast<int64_t>(THREADS), n - first)) - 1u;
+        const uint32_t at = min(threadIdx.x, last);
+        const uint2 code = *reinterpret_cast<const uint2*>(args.base + first * 8 + at * 8u);
+        const uint2 quality = *reinterpret_cast<const uint2*>(args.quality + first * 8 + at * 8u);
+        in.code0 = code.x; in.code1 = code.y; in.quality0 = quality.x; in.quality1 = quality.y;
+        if(STATE == 1) { in.state = static_cast<uint32_t>(args.input_flag[first + at]); }      // transcode.h:207-211
+        else if(STATE == 2) { in.state = args.word[first + at]; }
+        else { in.state = 0; }
+    };
+    Inputs next;
+    fetch(min(static_cast<int64_t>(blockIdx.x), tiles - 1), next);
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the loop is entered with nothing in flight, so that its first wait is the one of its back edge
+    uint32_t pending_slot = 0xffffffffu;       // this lane's worklist entry of the previous tile, not stored yet
+    uint32_t pending_read = 0;
+    const int hq_threshold = d.high_quality_distance_threshold;
+    const bool multiplexing = d.multiplexing != 0;
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        const bool active = tile * THREADS + threadIdx.x < n;
-        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
-        ReadState r = load_read_state(args, i);
-        uint32_t code0, code1, quality0, quality1;
-        {
-            const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * 8);
-            const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * 8);
-            code0 = code_row[0]; code1 = code_row[1]; quality0 = quality_row[0]; quality1 = quality_row[1];
-        }
+        const Inputs in = next;
+        const int64_t first = tile * THREADS;
+        const bool active = first + threadIdx.x < n;
+        const uint32_t at = active ? threadIdx.x : static_cast<uint32_t>(n - 1 - first);
+        const int64_t i = first + at;
+        ReadState r;
+        if(STATE != 2) { r.qcfail = (in.state & 1u) != 0; r.channel = 0; }
+        else { r.qcfail = (in.state >> 31) != 0; r.channel = static_cast<int32_t>(in.state & 0x7fffffffu); }
+        const uint32_t code0 = in.code0, code1 = in.code1, quality0 = in.quality0, quality1 = in.quality1;
         // BAM codes, four positions per word.  A, C, G or T = exactly one bit of the nibble (iupac.h:51-56); a read
         // with anything else goes to the next tier.
         const uint32_t x0 = code0 & 0x0f0f0f0fu;
@@ -137,7 +161,9 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
         const uint32_t low8 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x1 << 3) | (x1 << 1)) & 0x10101010u));
         const uint32_t high8 = gather((((x0 >> 2) | (x0 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
         const uint32_t key = low8 | (high8 << 8);
+        if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }     // the previous tile's deferred reads
         const uint32_t c = nearest[key];                                          // the barcode nearest to this word
+        fetch(min(tile + gridDim.x, tiles - 1), next);                           // past the last tile: that tile again, unused
         const uint32_t observed_low = low8 * 0x01010101u;                        // the read against four barcodes at a time
         const uint32_t observed_high = high8 * 0x01010101u;
         const uint32_t q0 = quality0 & 0x7f7f7f7fu;                              // the table has 128 rows
@@ -260,59 +286,88 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
                               x_listed <= LISTED_MAX && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
                               fabs(confidence_margin) > 2e-9;
         const bool defer = !finished;
-        if(finished && active) {
-            const int bin = static_cast<int>(c) + 1;
-            const int distance = k;
-            const int hq_distance = __popc(mismatches & high_quality);
-            uint8_t status = STATUS_PASS;
-            if(confidence_margin > 0) {                                       // pamld.cpp:99
-                if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) { r.qcfail = true; }
-                stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
-            } else {
-                stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
-                r.qcfail = true;
-                status = STATUS_LOW_CONFIDENCE;
-            }
-            decoder_tail(d, sink, r, bin, distance);
-            if(args.result) {
-                DevResult out;
-                out.index = d.barcode_index[bin - 1];
-                out.distance = static_cast<uint8_t>(distance);
-                out.hq_distance = static_cast<uint8_t>(hq_distance);
-                out.status = status;
-                out.qcfail = r.qcfail ? 1 : 0;
-                out.confidence = confidence;
-                stream_result(&args.result[i], out);
-            }
-            stream_read_state(args, i, r);
-        } else if(active) {
-            stream_placeholder(args, i, r);                                   // the next tier overwrites it
+
+        // Outcome.  Every lane stores a record and a status word in straight line code — the real ones when the read is
+        // finished, the placeholder the next tier overwrites when it is not; a lane past the end of the batch stores its
+        // (last) read's again — so that the compiler can count these two stores at the wait for the prefetched inputs.
+        const uint32_t index = meta.w;                                              // barcode_index[c]
+        const uint32_t hq_distance = static_cast<uint32_t>(__popc(mismatches & high_quality));
+        const bool confident = confidence_margin > 0;                               // pamld.cpp:99
+        const bool qcfail = r.qcfail || !confident || (hq_threshold > 0 && static_cast<int>(hq_distance) >= hq_threshold);
+        const bool qcfail_out = finished ? qcfail : r.qcfail;
+        {
+            typedef uint32_t vector4 __attribute__((ext_vector_type(4)));
+            const uint32_t detail = static_cast<uint32_t>(k) | (hq_distance << 8) | ((confident ? STATUS_PASS : STATUS_LOW_CONFIDENCE) << 16);
+            vector4 out;
+            out.x = finished ? index : 0u;
+            out.y = (finished ? detail : (static_cast<uint32_t>(STATUS_UNCLASSIFIED) << 16)) | (qcfail_out ? 1u << 24 : 0u);
+            out.z = finished ? static_cast<uint32_t>(__double2loint(confidence)) : 0u;
+            out.w = finished ? static_cast<uint32_t>(__double2hiint(confidence)) : 0u;
+            __builtin_nontemporal_store(out, reinterpret_cast<vector4*>(reinterpret_cast<char*>(args.result) + first * 16 + at * 16u));
+            const uint32_t channel = (finished && multiplexing) ? index : static_cast<uint32_t>(r.channel);
+            __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
         }
-        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
+        r.qcfail = qcfail_out;
+        if(finished && active) {
+            // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86), workgroup histogram
+            const uint32_t word = STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + (qcfail ? 0u : static_cast<uint32_t>(STAT_FIELDS));
+            uint32_t* const low_words = reinterpret_cast<uint32_t*>(histogram);      // a workgroup's counts and distances stay below 2^32
+            if(confident) {
+                if(!args.defer_counters) {
+                    atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
+                    if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }
+                    // round(confidence * 2^52) as the mantissa of 1 + confidence (a confidence of exactly 1 carries into
+                    // the exponent, which the subtraction turns into bit 52), split in two 26 bit limbs
+                    const double shifted = confidence + 1.0;
+                    const uint32_t fixed_low = static_cast<uint32_t>(__double2loint(shifted));
+                    const uint32_t fixed_high = static_cast<uint32_t>(__double2hiint(shifted)) - 0x3ff00000u;
+                    atomicAdd(&histogram[word + FIELD_CONFIDENCE_LOW], static_cast<unsigned long long>(fixed_low & 0x3ffffffu));
+                    atomicAdd(&histogram[word + FIELD_CONFIDENCE_HIGH], static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
+                }
+            } else {
+                atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u);      // qc-fail half (pamld.cpp:104-106)
+                if(!args.defer_counters) {
+                    atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
+                    if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }
+                }
+            }
+        }
+        // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment; the store
+        // itself waits for the next tile (in front of its prefetch: see above)
         const unsigned long long deferred = __ballot(active && defer);
+        pending_slot = 0xffffffffu;
         if(deferred) {
             const int lane = threadIdx.x & 63;
-            uint32_t first = 0;
-            if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
-            first = __shfl(first, 0);
+            uint32_t run = 0;
+            if(lane == 0) { run = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            run = __shfl(run, 0);
             if(active && defer) {
-                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+                pending_slot = run + __popcll(deferred & ((1ull << lane) - 1ull));
+                pending_read = static_cast<uint32_t>(i);
             }
         }
         count_outgoing(args, histogram, active && !defer, r);
     }
+    if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }
     __syncthreads();
     if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
     histogram_flush(args, d, histogram);
 }
 
-template <int L>
-int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+template <int L, int STATE>
+int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t lds_bytes = Layout::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_near_kernel<L>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_near_kernel<L>), grid, dim3(THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_near_kernel<L, STATE>), grid, dim3(THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
+}
+
+template <int L>
+int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if(!args.first_stage) { return launch_state<L, 2>(args, n_barcode, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<L, 1>(args, n_barcode, grid, histogram_bytes, stream)
+                           : launch_state<L, 0>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 }  // namespace near

@@ -66,7 +66,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // ... and long barcodes that are not combinatorial through the two word product form
                 // ... and a codec of a handful of barcodes through the kernel without tables (pamld_tiny.hip)
                 const bool tiny = pamld_tiny_supports(host_decoder);
-                const bool listed = !tiny && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
+                const bool listed = !tiny && args.result != nullptr && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 const int64_t threads = (tiny || factorised) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
