@@ -659,8 +659,22 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 size_t DecoderSet::worklist_words(int64_t n_read) const {
     // whatever the grid (at most max_blocks_ workgroups of at most 512 lanes): grid * ceil(tiles / grid) * threads
     // is less than n_read + (grid + 1) * threads
+    return worklist_entries(n_read) + carry_words(n_read);
+}
+
+size_t DecoderSet::worklist_entries(int64_t n_read) const {
     const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 512;
     return static_cast<size_t>(max_blocks_) + worst + static_cast<size_t>(max_blocks_) * 1024 + 512;      // + the 4 tile passes of the MDD exact kernel
+}
+
+// the inputs of deferred reads beside the first quarter of every worklist segment (StageArgs::carry), for jobs with a
+// decoder the neighbour list tier takes
+size_t DecoderSet::carry_words(int64_t n_read) const {
+    bool any = false;
+    for(const auto& d : host_decoder_) { if(d.near_ready) { any = true; } }
+    if(!any) { return 0; }
+    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 512;
+    return CARRY_PLANES * (worst / 4 + static_cast<size_t>(max_blocks_) * 512);
 }
 
 bool DecoderSet::needs_worklist() const {
@@ -679,6 +693,7 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         std::memset(&args, 0, sizeof(args));
         args.worklist_count = worklist;                                   // one counter per workgroup ...
         args.worklist = worklist ? worklist + max_blocks_ : nullptr;      // ... then one segment per workgroup
+        args.carry = (worklist && carry_words(n_read) > 0) ? worklist + worklist_entries(n_read) : nullptr;       // stage.hip sets the stride
         args.decoder = device_decoder_ + k;
         args.n_read = n_read;
         args.base = c.plane_stride ? base_planes + batch_capacity * c.plane_prefix + first_read * c.plane_stride : nullptr;

@@ -60,6 +60,8 @@ private:
                     DevResult* result, uint32_t* word, void* stream, uint32_t* worklist);
     bool needs_worklist() const;
     size_t worklist_words(int64_t n_read) const;
+    size_t worklist_entries(int64_t n_read) const;
+    size_t carry_words(int64_t n_read) const;
     void build_device_images();
     void release();
     void ensure_pipeline(int64_t chunk_capacity);

@@ -33,6 +33,7 @@ constexpr int STAT_JOB_WORDS = 2;
 //   factorised / wide PAMLD, the rest   8: C3 8.02 (8) -> 7.73 (12) -> 7.49 (16) Greads/s
 constexpr int GRID_BLOCKS_PER_CU = 16;
 constexpr int GRID_SHARE_LUT = 12;
+constexpr int GRID_SHARE_NEAR = 12;        // the neighbour list tier and the tiers behind it
 constexpr int GRID_SHARE_MDD_FUSED = 16;
 constexpr int GRID_SHARE_DEFAULT = 8;
 constexpr int EXACT_GROUP_MAX = 16;      // worklist segments one workgroup of the exact PAMLD tier visits, at most (StageArgs::worklist_group)
@@ -163,7 +164,15 @@ struct StageArgs {
     // scattered global atomics run at the memory side on this part, ~3.3 of them per read cost as much as the
     // whole classification
     int32_t defer_counters;
+    // The neighbour list tier (pamld_near.hpp) hands the reads it defers to the product form kernel WITH their inputs:
+    // beside entry e < carry_stride of workgroup g's worklist segment, plane p (0, 1 the code words, 2, 3 the quality
+    // words, 4 the carried state: flag byte or status word) holds its word at carry[(g * 5 + p) * carry_stride + e],
+    // so that the consumer reads whole lines instead of gathering 8 byte rows from HBM.  Entries past carry_stride
+    // (a quarter of the segment, a multiple of 512) are gathered as before.
+    uint32_t* carry;
+    int32_t carry_stride;
 };
+constexpr int CARRY_PLANES = 5;
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
 enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_PAMLD_NEAR = 6, KERNEL_KINDS = 7 };

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
     const int64_t n = CONSUMER ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
+    const uint32_t carry_stride = (CONSUMER && args.carry) ? static_cast<uint32_t>(args.carry_stride) : 0u;
+    const uint32_t* const carry = args.carry + static_cast<int64_t>(blockIdx.x) * CARRY_PLANES * carry_stride;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     constexpr bool PERMUTED = Layout::PERMUTED;
     constexpr uint32_t GROUP_STEP = Layout::GROUP_STEP;
@@ -169,18 +171,31 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         // of the batch recompute its last read and are kept from every store and counter
         const bool active = tile * THREADS + threadIdx.x < n;
         int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        uint32_t carried[CARRY_PLANES];
+        bool is_carried = false;               // the producer left this entry's inputs beside it (StageArgs::carry)
         if(CONSUMER) {
-            i = static_cast<int64_t>(segment[i]);
+            const int64_t entry = i;
+            i = static_cast<int64_t>(segment[entry]);
+            is_carried = (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
+            if(is_carried) {
+#pragma unroll
+                for(int plane = 0; plane < CARRY_PLANES; ++plane) { carried[plane] = carry[plane * carry_stride + entry]; }
+            }
             __syncthreads();                   // every entry of this tile is read before any wave compacts into it
         }
         ReadState r{false, 0};
         bool defer = false;
         {
-            r = load_read_state(args, i);
             constexpr int W = (L + 3) / 4;
             uint32_t code_words[W];
             uint32_t quality_words[W];
-            {
+            if(CONSUMER && is_carried) {
+                if(args.first_stage) { r.qcfail = (carried[4] & 1u) != 0; r.channel = 0; }
+                else { r.qcfail = (carried[4] >> 31) != 0; r.channel = static_cast<int32_t>(carried[4] & 0x7fffffffu); }
+                code_words[0] = carried[0]; quality_words[0] = carried[2];
+                if(W > 1) { code_words[W > 1 ? 1 : 0] = carried[1]; quality_words[W > 1 ? 1 : 0] = carried[3]; }
+            } else {
+                r = load_read_state(args, i);
                 const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * (4 * W));
                 const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * (4 * W));
 #pragma unroll

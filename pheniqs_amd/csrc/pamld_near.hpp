@@ -131,6 +131,9 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the loop is entered with nothing in flight, so that its first wait is the one of its back edge
     uint32_t pending_slot = 0xffffffffu;       // this lane's worklist entry of the previous tile, not stored yet
     uint32_t pending_read = 0;
+    uint32_t pending_input[CARRY_PLANES] = {0, 0, 0, 0, 0};
+    const uint32_t carry_stride = args.carry ? static_cast<uint32_t>(args.carry_stride) : 0u;
+    uint32_t* const carry = args.carry + static_cast<int64_t>(blockIdx.x) * CARRY_PLANES * carry_stride;
     const int hq_threshold = d.high_quality_distance_threshold;
     const bool multiplexing = d.multiplexing != 0;
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -161,7 +164,13 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
         const uint32_t low8 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x1 << 3) | (x1 << 1)) & 0x10101010u));
         const uint32_t high8 = gather((((x0 >> 2) | (x0 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
         const uint32_t key = low8 | (high8 << 8);
-        if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }     // the previous tile's deferred reads
+        if(pending_slot != 0xffffffffu) {                                         // the previous tile's deferred reads
+            segment[pending_slot] = pending_read;
+            if(pending_slot < carry_stride) {
+#pragma unroll
+                for(int plane = 0; plane < CARRY_PLANES; ++plane) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+            }
+        }
         const uint32_t c = nearest[key];                                          // the barcode nearest to this word
         fetch(min(tile + gridDim.x, tiles - 1), next);                           // past the last tile: that tile again, unused
         const uint32_t observed_low = low8 * 0x01010101u;                        // the read against four barcodes at a time
@@ -344,11 +353,18 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
             if(active && defer) {
                 pending_slot = run + __popcll(deferred & ((1ull << lane) - 1ull));
                 pending_read = static_cast<uint32_t>(i);
+                pending_input[0] = code0; pending_input[1] = code1; pending_input[2] = quality0; pending_input[3] = quality1; pending_input[4] = in.state;
             }
         }
         count_outgoing(args, histogram, active && !defer, r);
     }
-    if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }
+    if(pending_slot != 0xffffffffu) {
+        segment[pending_slot] = pending_read;
+        if(pending_slot < carry_stride) {
+#pragma unroll
+            for(int plane = 0; plane < CARRY_PLANES; ++plane) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+        }
+    }
     __syncthreads();
     if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
     histogram_flush(args, d, histogram);

@@ -1,5 +1,6 @@
 // Stage dispatcher: picks the kernel for one decoder and sizes the launch.
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernel_common.hpp"
 
@@ -71,12 +72,16 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 const int64_t threads = (tiny || factorised) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
-                const int64_t product_blocks = (factorised || long_words) ? default_blocks : share(GRID_SHARE_LUT);
+                static const int near_share = std::getenv("PHQ_GRID_SHARE_NEAR") ? std::atoi(std::getenv("PHQ_GRID_SHARE_NEAR")) : GRID_SHARE_NEAR;
+                const int64_t product_blocks = (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < product_blocks ? wide_tiles : product_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
                 StageArgs producer = args;
                 producer.worklist_role = 1;
                 producer.worklist_stride = static_cast<int32_t>(tiles_per_block * threads);
+                // the deferred reads' inputs travel beside the first quarter of a segment (device_types.hpp, StageArgs::carry)
+                producer.carry_stride = (listed && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
+                if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
                 if(listed) {
                     {

@@ -72,6 +72,13 @@ unlisted_at_radius = np.array([(bd[b, order[b, LIST:]] == radius[b]).sum() for b
 import os
 if os.environ.get("CLASS_BOUND", "1") == "1":
     U = A * boost * (unlisted_at_radius[c] * top + (N - LIST - unlisted_at_radius[c]) * top2)
+elif os.environ.get("CLASS_BOUND") == "3":
+    top3 = np.ones(n)
+    for i in range(L):
+        take = (i < need + 2) | (rs[:, i] > 1.0)
+        top3 *= np.where(take, np.where(rs[:, i] > 0, rs[:, i], 1.0), 1.0)
+    at_next = np.array([(bd[b, order[b, LIST:]] == radius[b] + 1).sum() for b in range(N)])
+    U = A * boost * (unlisted_at_radius[c] * top + at_next[c] * top2 + (N - LIST - unlisted_at_radius[c] - at_next[c]) * top3)
 elif os.environ.get("CLASS_BOUND") == "oracle":
     U = true_rest.copy()
 else:
