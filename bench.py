@@ -5,7 +5,14 @@ Workload (BASELINE.json configs[1], "C2"): 100 M synthetic reads, one 8 bp index
 inputs resident in HBM before the timed region.  One step = one pass of the hot path over the whole batch
 (TranscodingDecoder::classify for every read + the end of run counter merge).  With N GPUs every rank
 decodes its own 100 M reads (weak scaling, no data path collective) and the integer counter buffer is merged
-by one RCCL all-reduce per step.
+by one RCCL all-reduce per step.  `python bench.py --gpus N` without a torchrun environment starts the N ranks
+itself (fresh child processes, before this process has touched a GPU).
+
+Besides the contract line's fields the JSON line carries, from the same run: `roofline` (dominant kernel, HIP events
+on the launch stream; `step_frac` = the whole step against the same roofline), `cpu_baseline`, and by default three
+more legs next to the kernel only `value` (kernel only, staged and end to end side by side):
+`staged` (pinned host planes through phq_classify_host, PCIe inclusive), `fastq_to_sam` (FASTQ text to SAM text and
+report only) and `shapes` (C3 at full size, C5, MDD on C2), each with its own whole step roofline fraction.
 """
 import argparse
 import json
@@ -61,16 +68,38 @@ def measured_copy_bandwidth(torch, device):
     return 2 * 4 * words * repeats / (begin.elapsed_time(end) * 1e-3) / 1e9
 
 
+def write_fastq(path, segment_number, text, quality, filtered):
+    """Fixed width FASTQ records written from numpy byte arrays: '@M:1:FC:1:1101:<7 digits>:<5 digits> k:Y|N:0:1'."""
+    n, length = text.shape
+    name = np.frombuffer(b"@M:1:FC:1:1101:0000000:00000 %d:N:0:1\n" % segment_number, dtype=np.uint8)
+    record = np.empty((n, name.size + length + 1 + 2 + length + 1), dtype=np.uint8)
+    record[:, :name.size] = name
+    ordinal = np.arange(n, dtype=np.int64)
+    high, low = ordinal >> 16, ordinal & 0xffff
+    for digit in range(7):
+        record[:, 15 + 6 - digit] = 48 + (high // 10 ** digit) % 10
+    for digit in range(5):
+        record[:, 23 + 4 - digit] = 48 + (low // 10 ** digit) % 10
+    record[:, 31] = np.where(filtered != 0, ord("Y"), ord("N"))
+    at = name.size
+    record[:, at:at + length] = text
+    record[:, at + length] = 10
+    record[:, at + length + 1] = ord("+")
+    record[:, at + length + 2] = 10
+    record[:, at + length + 3:at + 2 * length + 3] = quality
+    record[:, -1] = 10
+    record.tofile(path)
+
+
 def fastq_end_to_end(args, code, quality, flag, n):
     """Next rows f1 + f2 end to end: synthetic FASTQ text on disk -> phq_transcode_fastq_to_sam -> SAM text
-    (uncompressed, /dev/null).  One file per input segment: a 50 nt template read and the index read; the staged
-    rows of the pool are written back as text, so the decoder sees the same observations as the kernel bench.
-    Host bound (parse and format on the host, classification on the GPU); never the headline value."""
+    (uncompressed, to a file in the temporary directory) and the same input report only (output /dev/null: nothing is
+    formatted, reference feed.h:105 NullFeed).  One file per input segment: a 50 nt template read and the index read;
+    the staged rows of the pool are written back as text, so the decoder sees the same observations as the kernel
+    bench.  Host bound (parse and format on the host, classification on the GPU); never the headline value."""
     import tempfile
     from pheniqs_amd import DecoderSet, capi, synthetic
-    spec = synthetic.config_spec(args.config, args.algorithm)
-    if args.config != "C2":
-        return {"skipped": "the FASTQ leg writes the two segment C2 layout only"}
+    spec = synthetic.config_spec("C2", args.algorithm)
     spec["template"] = {"transform": {"token": ["0::"]}}
     s = DecoderSet(spec, device=0)
     s.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
@@ -80,29 +109,30 @@ def fastq_end_to_end(args, code, quality, flag, n):
     reps = -(-n // pool)
     index_text = letters[np.tile(code, (reps, 1))[:n]]
     index_quality = (np.minimum(np.tile(quality, (reps, 1))[:n], 93) + 33).astype(np.uint8)
-    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 50))]
+    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 50), dtype=np.uint8)]
     template_quality = np.full((n, 50), ord("F"), dtype=np.uint8)
     filtered = np.tile(flag, reps)[:n]
-    with tempfile.TemporaryDirectory() as directory:
+    out = {"reads": n, "cores": usable_cores()}
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as directory:
         paths = []
         for k, (text, qual) in enumerate(((template, template_quality), (index_text, index_quality))):
             path = os.path.join(directory, "segment_%d.fastq" % k)
-            with open(path, "wb") as out:
-                for first in range(0, n, 1 << 16):
-                    chunk = []
-                    for i in range(first, min(n, first + (1 << 16))):
-                        chunk.append(b"@M:1:FC:1:1101:%d:%d %d:%s:0:1\n%s\n+\n%s\n" % (
-                            i >> 16, i & 0xffff, k + 1, b"Y" if filtered[i] else b"N", text[i].tobytes(), qual[i].tobytes()))
-                    out.write(b"".join(chunk))
+            write_fastq(path, k + 1, text, qual, filtered)
             paths.append(path)
         size = sum(os.path.getsize(p) for p in paths)
-        s.transcode_fastq_to_sam(paths, "/dev/null", 1 << 20)                    # warm: allocations, page cache
-        t0 = time.perf_counter()
-        incoming, incoming_pf = s.transcode_fastq_to_sam(paths, "/dev/null", 1 << 20)
-        dt = time.perf_counter() - t0
-    assert incoming == n
-    return {"reads": n, "Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt,
-            "note": "2 uncompressed FASTQ files (50 nt template + 8 nt index) -> SAM text to /dev/null; per file one reader thread indexing lines + decoding threads, formatting on the host threads, a batch read ahead"}
+        for name, target in (("sam_text", os.path.join(directory, "out.sam")), ("report_only", "/dev/null")):
+            s.transcode_fastq_to_sam(paths, target, 1 << 20)                    # warm: allocations, page cache
+            t0 = time.perf_counter()
+            incoming, incoming_pf = s.transcode_fastq_to_sam(paths, target, 1 << 20)
+            dt = time.perf_counter() - t0
+            assert incoming == n
+            out[name] = {"Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt}
+            if target != "/dev/null":
+                out[name]["sam_MB/s"] = os.path.getsize(target) / dt / 1e6
+    s.close()
+    out["note"] = ("2 uncompressed FASTQ files in memory backed storage (50 nt template + 8 nt index) -> SAM text file / report only "
+                   "(/dev/null: records are not formatted); host threads parse and format, the GPU classifies")
+    return out
 
 
 def usable_cores():
@@ -174,6 +204,102 @@ def parity_check(job, code, quality, flag, got, reads):
     return reads
 
 
+CONFIG_TEXT = {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
+               "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10",
+               "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
+               "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}
+
+
+class Workload:
+    """One job shape resident in HBM: decoder set, tiled planes, result buffers."""
+
+    def __init__(self, torch, device, local_rank, rank, config, algorithm, mode, reads, pool, priors="uniform"):
+        from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, synthetic
+        self.torch, self.device = torch, device
+        self.job, recipe = synthetic.config_job(config, algorithm)
+        if priors == "estimated":
+            from pheniqs_amd import jobspec
+            spec = synthetic.config_spec(config, algorithm)
+            spread = np.random.default_rng(3)
+            for _, decoder in jobspec.iter_decoders(spec):
+                for record in (decoder.get("codec") or {}).values():
+                    record["concentration"] = float(10 ** spread.uniform(-0.5, 0.5))
+            self.job = capi.compile_job(spec)
+        self.bytes_per_read = synthetic.algorithmic_bytes_per_read(self.job)          # 37 for C2 (SURVEY.md §8d)
+        self.n = reads
+        self.pool_n = min(pool, reads)
+        tiles = -(-reads // self.pool_n)
+        self.code, self.quality, self.flag, self.offsets = synthetic.generate_rows(self.job, self.pool_n, recipe["seed"] + 1000 * rank)
+        s = self.set = DecoderSet(self.job, device=local_rank)
+        s.set_mode(capi.MODE_FAST if mode == "fast" else capi.MODE_LITERAL)
+
+        def resident_planes(rows):
+            """decoder major planes of the pool, every plane tiled to n reads, concatenated: the layout phq_classify_device takes"""
+            pool_planes = torch.from_numpy(s.planes_from_rows(rows, self.offsets)).to(device)
+            parts = []
+            for d in s.decoders:
+                stride, prefix = d["plane_stride"], d["plane_prefix"]
+                if stride:
+                    parts.append(pool_planes[self.pool_n * prefix: self.pool_n * (prefix + stride)].view(self.pool_n, stride).repeat(tiles, 1)[:reads].contiguous().view(-1))
+            return torch.cat(parts) if len(parts) > 1 else parts[0]
+
+        self.base = resident_planes(self.code)
+        self.qual = resident_planes(self.quality)
+        self.flags = torch.from_numpy(self.flag).to(device).repeat(tiles)[:reads].contiguous()
+        self.result = torch.zeros(max(1, s.n_result) * reads * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.word = torch.zeros(reads, dtype=torch.int32, device=device)
+        self.counters = s.stats_tensor()
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def step(self, events=None):
+        from pheniqs_amd import distributed
+        self.set.stats_reset(self.stream)
+        if events is not None:
+            events[0].record()
+        self.set.classify_device(self.n, 0, self.n, self.base, self.qual, self.flags, self.result, self.word, self.stream)
+        if events is not None:
+            events[1].record()
+        distributed.allreduce_counters(self.counters)
+
+    def measure(self, steps, warmup, world, barrier):
+        """W untimed steps, then exactly K timed ones between barriers; per kernel HIP event times of the timed steps."""
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        barrier()
+        self.set.profile_enable(True)          # HIP events around every kernel launch, on the launch stream
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(pairs[k])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        kernels = self.set.profile_collect()
+        self.set.profile_enable(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t.item())
+        classify_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))        # all kernels of one step
+        # the dominant kernel KIND: all its launches of one step together (a job with several decoders launches it
+        # once per decoder; the bytes below are the whole job's)
+        dominant = max(kernels, key=lambda name: kernels[name]["ms"])
+        kernel_ms = kernels[dominant]["ms"] / steps
+        words = self.set.stats_export()
+        total = int(words[0] + words[1])
+        assert total == self.n * world, (total, self.n, world)                    # every read counted once
+        bytes_per_step = self.bytes_per_read * self.n
+        return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
+                "kernels": kernels, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
+                "launches_per_step": kernels[dominant]["launches"] / steps,
+                "achieved_GBs": bytes_per_step / (kernel_ms * 1e-3) / 1e9, "step_GBs": bytes_per_step / (classify_ms * 1e-3) / 1e9}
+
+    def close(self):
+        self.set.close()
+        del self.base, self.qual, self.flags, self.result, self.word, self.counters
+        self.torch.cuda.empty_cache()
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -182,167 +308,139 @@ def main():
     parser.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
     parser.add_argument("--pool", type=int, default=1 << 20, help="distinct synthetic reads tiled to --reads")
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
-    parser.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5", "U96", "U384", "V384", "S384", "S192"],
+    parser.add_argument("--config", default="C2", choices=sorted(CONFIG_TEXT),
                         help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration (U96 / U384: unique dual index pairs, not in BASELINE.json)")
     parser.add_argument("--priors", default="uniform", choices=["uniform", "estimated"],
                         help="estimated: barcode priors that differ (what a prior estimation pass leaves), not the BASELINE shape")
-    parser.add_argument("--fastq", type=int, default=0, metavar="N",
-                        help="also time N synthetic reads end to end from FASTQ text to SAM text (next rows f1 + f2)")
+    parser.add_argument("--fastq", type=int, default=4_000_000, metavar="N",
+                        help="reads of the FASTQ text -> SAM text / report only leg (next rows f1 + f2); 0 = skip")
     parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
-                        help="fast: product form kernel + literal kernel on the ambiguous reads; literal: literal kernel on every read")
+                        help="fast: neighbour list / product form kernels + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
-    parser.add_argument("--host-staged", type=int, default=0, metavar="READS",
-                        help="also time phq_classify_host (pageable host planes -> pinned -> device -> back) on READS reads")
+    parser.add_argument("--host-staged", type=int, default=16_000_000, metavar="READS",
+                        help="reads of the phq_classify_host leg (host planes -> pinned -> device -> back); 0 = skip")
+    parser.add_argument("--no-extra-legs", action="store_true", help="only the contract line: no staged / fastq_to_sam / shapes blocks")
     args = parser.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # N ranks of this same script, one per GPU (torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).
+        # Children, not exec: this process has not touched a GPU and never will.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(command).returncode)
+
     import torch
-    from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, distributed, synthetic
+    from pheniqs_amd import RESULT_DTYPE, distributed
 
     rank, local_rank, world = distributed.initialise("nccl")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-
-    job, recipe = synthetic.config_job(args.config, args.algorithm)
-    if args.priors == "estimated":
-        from pheniqs_amd import jobspec
-        spec = synthetic.config_spec(args.config, args.algorithm)
-        spread = np.random.default_rng(3)
-        for _, decoder in jobspec.iter_decoders(spec):
-            for record in (decoder.get("codec") or {}).values():
-                record["concentration"] = float(10 ** spread.uniform(-0.5, 0.5))
-        job = capi.compile_job(spec)
-    bytes_per_read = synthetic.algorithmic_bytes_per_read(job)          # 37 for C2
-    pool_n = min(args.pool, args.reads)
-    tiles = -(-args.reads // pool_n)
-    n = args.reads
-    code, quality, flag, offsets = synthetic.generate_rows(job, pool_n, recipe["seed"] + 1000 * rank)
-
-    s = DecoderSet(job, device=local_rank)
-    s.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
-    def resident_planes(rows):
-        """decoder major planes of the pool, every plane tiled to n reads, concatenated: the layout phq_classify_device takes"""
-        pool_planes = torch.from_numpy(s.planes_from_rows(rows, offsets)).to(device)
-        parts = []
-        for d in s.decoders:
-            stride, prefix = d["plane_stride"], d["plane_prefix"]
-            if stride:
-                parts.append(pool_planes[pool_n * prefix: pool_n * (prefix + stride)].view(pool_n, stride).repeat(tiles, 1)[:n].contiguous().view(-1))
-        return torch.cat(parts) if len(parts) > 1 else parts[0]
-
-    base = resident_planes(code)
-    qual = resident_planes(quality)
-    flags = torch.from_numpy(flag).to(device).repeat(tiles)[:n].contiguous()
-    result = torch.zeros(max(1, s.n_result) * n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
-    word = torch.zeros(n, dtype=torch.int32, device=device)
-    counters = s.stats_tensor()
-    stream = torch.cuda.current_stream().cuda_stream
+    extra_legs = world == 1 and not args.no_extra_legs and args.config == "C2" and args.algorithm == "pamld" and args.priors == "uniform"
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def step(events=None):
-        s.stats_reset(stream)
-        if events is not None:
-            events[0].record()
-        s.classify_device(n, 0, n, base, qual, flags, result, word, stream)
-        if events is not None:
-            events[1].record()
-        distributed.allreduce_counters(counters)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    s.profile_enable(True)          # HIP events around every kernel launch, on the launch stream
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(pairs[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernels = s.profile_collect()
-    s.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    classify_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))        # all kernels of one step
-    dominant = max(kernels, key=lambda name: kernels[name]["ms"])
-    kernel_ms = kernels[dominant]["ms"] / kernels[dominant]["launches"]          # the dominant kernel alone
-
-    # size independent check of the last step: counters are a whole number of pool passes (+ remainder)
-    words = s.stats_export()
-    total = int(words[0] + words[1])
-    assert total == n * world, (total, n, world)
+    w = Workload(torch, device, local_rank, rank, args.config, args.algorithm, args.mode, args.reads, args.pool, args.priors)
+    m = w.measure(args.steps, args.warmup, world, barrier)
+    n = w.n
 
     if rank == 0:
         line = {
             "metric": "Mreads/s decoded (PAMLD, 96-plex 8bp)" if args.algorithm == "pamld" else "Mreads/s decoded (MDD, 96-plex 8bp)",
-            "value": n * world * args.steps / elapsed / 1e6,
+            "value": m["Mreads/s"],
             "unit": "Mreads/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": m["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64" if args.algorithm == "pamld" else "u32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d reads per GPU, %s, %s, inputs resident in HBM" % (
-                           args.config, n, {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
-                                            "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10",
-                                            "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
-                                            "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}[args.config],
-                           args.algorithm.upper()),
-                       "reads_per_gpu": n, "pool": pool_n, "kernel_mode": args.mode,
+            "config": {"workload": "%s: %d reads per GPU, %s, %s, inputs resident in HBM" % (args.config, n, CONFIG_TEXT[args.config], args.algorithm.upper()),
+                       "reads_per_gpu": n, "pool": w.pool_n, "kernel_mode": args.mode,
                        "sharding": "reads x%d, counters merged by one all-reduce per step" % world},
-            "roofline": {"bound": "hbm", "achieved": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bytes_per_read * n / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": profiled_traffic(dominant, n, args.config, args.algorithm, args.mode),
-                         "kernel": dominant, "kernel_ms": kernel_ms, "algorithmic_bytes_per_read": bytes_per_read,
+            # the dominant kernel kind (all its launches of a step) against the HBM roofline; step_frac: the whole step
+            "roofline": {"bound": "hbm", "achieved": m["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": m["achieved_GBs"] / HBM_PEAK_GBS, "traffic": profiled_traffic(m["dominant"], n, args.config, args.algorithm, args.mode),
+                         "kernel": m["dominant"], "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches_per_step"],
+                         "algorithmic_bytes_per_read": w.bytes_per_read,
+                         "step_achieved": m["step_GBs"], "step_frac": m["step_GBs"] / HBM_PEAK_GBS,
                          "measured_copy_GBs": measured_copy_bandwidth(torch, device) if world == 1 else None,
-                         "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in kernels.items()},
-                         "classify_ms_per_step": classify_ms},
+                         "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in m["kernels"].items()},
+                         "classify_ms_per_step": m["classify_ms"]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(job, code, quality, flag)
-            got = result[: pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, first pool pass
-            line["parity_checked_reads"] = parity_check(job, code, quality, flag, got, min(pool_n, 1 << 19))
-        if args.host_staged:
-            # PCIe inclusive rate; never the headline value
-            m = args.host_staged
-            reps = -(-m // pool_n)
-            host_base = s.planes_from_rows(np.tile(code, (reps, 1))[:m], offsets)
-            host_qual = s.planes_from_rows(np.tile(quality, (reps, 1))[:m], offsets)
-            host_flag = np.tile(flag, reps)[:m].copy()
-            s.classify_host(m, host_base, host_qual, host_flag)            # allocates the pinned slots
-            t0 = time.perf_counter()
-            s.classify_host(m, host_base, host_qual, host_flag)
-            dt = time.perf_counter() - t0
-            line["host_staged"] = {"reads": m, "Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * bytes_per_read / dt / 1e9,
-                                   "note": "pageable host planes, memcpy to pinned slots, 2 streams, results copied back"}
-            # the same batch in pinned memory end to end (phq_host_alloc): no bounce copy on either side
-            pinned = {}
-            for name, array in (("base", host_base), ("qual", host_qual), ("flag", host_flag)):
-                pinned[name] = torch.from_numpy(array).pin_memory()
-            out_result = torch.zeros(max(1, s.n_result) * m * RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
-            out_word = torch.zeros(m, dtype=torch.int32).pin_memory()
-            call = lambda: s._check(s.lib.phq_classify_host(s.handle, m, m, pinned["base"].data_ptr(), pinned["qual"].data_ptr(),
-                                                            pinned["flag"].data_ptr(), out_result.data_ptr(), out_word.data_ptr()))
-            call()
-            t0 = time.perf_counter()
-            call()
-            dt = time.perf_counter() - t0
-            line["host_staged_pinned"] = {"reads": m, "Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * bytes_per_read / dt / 1e9,
-                                          "note": "caller's planes and result buffers pinned: async copies straight from / to them"}
-        if args.fastq:
+            line["cpu_baseline"] = cpu_baseline(w.job, w.code, w.quality, w.flag)
+            got = w.result[: w.pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, first pool pass
+            line["parity_checked_reads"] = parity_check(w.job, w.code, w.quality, w.flag, got, min(w.pool_n, 1 << 19))
+        if world == 1 and args.host_staged and (extra_legs or "--host-staged" in " ".join(sys.argv)):
+            line["staged"] = host_staged(torch, w, args.host_staged)
+        code, quality, flag = w.code, w.quality, w.flag
+        w.close()
+        if world == 1 and args.fastq and (extra_legs or "--fastq" in " ".join(sys.argv)):
             line["fastq_to_sam"] = fastq_end_to_end(args, code, quality, flag, args.fastq)
+        if extra_legs:
+            # the other BASELINE shapes that fit one GPU, kernel only like `value`, fewer steps
+            line["shapes"] = {}
+            for name, config, algorithm, reads in (("C3_pamld", "C3", "pamld", 100_000_000), ("C5_pamld", "C5", "pamld", 50_000_000),
+                                                   ("C4_pamld", "C4", "pamld", 50_000_000), ("C2_mdd", "C2", "mdd", 100_000_000)):
+                shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool)
+                sm = shape.measure(5, 2, 1, barrier)
+                line["shapes"][name] = {"workload": "%s: %d reads, %s, %s" % (config, reads, CONFIG_TEXT[config], algorithm.upper()),
+                                        "Mreads/s": sm["Mreads/s"], "ms_per_step": sm["ms_per_step"], "algorithmic_bytes_per_read": shape.bytes_per_read,
+                                        "step_frac": sm["step_GBs"] / HBM_PEAK_GBS, "dominant_kernel": sm["dominant"],
+                                        "dominant_kernel_frac": sm["achieved_GBs"] / HBM_PEAK_GBS,
+                                        "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in sm["kernels"].items()}}
+                shape.close()
         print(json.dumps(line))
+    else:
+        w.close()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def host_staged(torch, w, m):
+    """PCIe inclusive rates of phq_classify_host on m reads of the workload; never the headline value."""
+    from pheniqs_amd import RESULT_DTYPE
+    s = w.set
+    reps = -(-m // w.pool_n)
+    host_base = s.planes_from_rows(np.tile(w.code, (reps, 1))[:m], w.offsets)
+    host_qual = s.planes_from_rows(np.tile(w.quality, (reps, 1))[:m], w.offsets)
+    host_flag = np.tile(w.flag, reps)[:m].copy()
+    out = {"reads": m}
+    s.classify_host(m, host_base, host_qual, host_flag)            # allocates the pinned slots
+    t0 = time.perf_counter()
+    s.classify_host(m, host_base, host_qual, host_flag)
+    dt = time.perf_counter() - t0
+    out["pageable"] = {"Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * w.bytes_per_read / dt / 1e9,
+                       "note": "pageable host planes, memcpy to pinned slots, 2 streams, results copied back"}
+    # the same batch in pinned memory end to end (phq_host_alloc): no bounce copy on either side
+    pinned = {}
+    for name, array in (("base", host_base), ("qual", host_qual), ("flag", host_flag)):
+        pinned[name] = torch.from_numpy(array).pin_memory()
+    out_result = torch.zeros(max(1, s.n_result) * m * RESULT_DTYPE.itemsize, dtype=torch.uint8).pin_memory()
+    out_word = torch.zeros(m, dtype=torch.int32).pin_memory()
+    call = lambda: s._check(s.lib.phq_classify_host(s.handle, m, m, pinned["base"].data_ptr(), pinned["qual"].data_ptr(),
+                                                    pinned["flag"].data_ptr(), out_result.data_ptr(), out_word.data_ptr()))
+    call()
+    t0 = time.perf_counter()
+    call()
+    dt = time.perf_counter() - t0
+    out["pinned"] = {"Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * w.bytes_per_read / dt / 1e9,
+                     "step_frac_of_pcie_63GBs": m * w.bytes_per_read / dt / 1e9 / 63.0,
+                     "note": "caller's planes and result buffers pinned: async copies straight from / to them"}
+    return out
 
 
 if __name__ == "__main__":
