@@ -159,6 +159,19 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word);
 
+/* The per type accumulators of the output Read that Read::flush turns into XB / XM / XC (read.h:152-165,187-199):
+ * for reads [0, n_read) of HOST result planes laid out for batch_capacity reads (what phq_classify_host fills, or a
+ * copy of the device planes), distance[3 * i + kind] and confidence[3 * i + kind], kind = PHQ_KIND_SAMPLE /
+ * MOLECULAR / CELLULAR, as the decoders' wrappers leave them after the last decoder:
+ *   PAMLD   sample: distance += edit_distance, confidence updated (x 1 -> c, else x *= c)   pamld.cpp:133-140
+ *           cellular / molecular: the same when classified, else confidence = 0 and the cellular distance
+ *           reset to 0 (set_molecular_distance ADDS its argument: read.h:319-321)        pamld.cpp:149-160,169-180
+ *   MDD     sample: distance += edit_distance; cellular / molecular: += when classified, else the CELLULAR
+ *           distance is reset, by both wrappers (mdd.cpp:118,136); confidence stays 1     mdd.cpp:96-138
+ * Either output may be NULL.  A host side loop over the records; needs no device. */
+int phq_summarize(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const phq_result_t* result,
+                  uint32_t* distance, double* confidence);
+
 /* ---- the steps either side of the path -----------------------------------
  * Transcode::pull + TranscodingThread::run for FASTQ inputs and one SAM text output: n_input synchronised
  * FASTQ files (plain or gzip), one per input segment (fastq.h:55-78,253-285,427-440; read.h:253-264),

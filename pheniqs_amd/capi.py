@@ -25,7 +25,7 @@ DEVICE_NONE = -1
 SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq_get_decoder_info", "phq_set_mode",
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
-           "phq_stats_allreduce", "phq_stats_options", "phq_report_json", "phq_format_double",
+           "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
            "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
            "phq_compile_job", "phq_free_string", "phq_adjust_prior")
 
@@ -92,6 +92,7 @@ def load_library():
     L.phq_stats_import.argtypes = [P, P]
     L.phq_stats_merge.argtypes = [P, P]
     L.phq_stats_allreduce.argtypes = [P, P, P]
+    L.phq_summarize.argtypes = [P, ctypes.c_int64, ctypes.c_int64, P, P, P]
     L.phq_stats_options.argtypes = [P, P, I32, P]
     L.phq_report_json.argtypes = [P, P, U64, U64, ctypes.POINTER(ctypes.c_char_p)]
     L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
@@ -319,6 +320,17 @@ class DecoderSet:
 
     def stats_merge(self, other: "DecoderSet"):
         self._check(self.lib.phq_stats_merge(self.handle, other.handle))
+
+    def summarize(self, result: np.ndarray, n_read: Optional[int] = None):
+        """Per type accumulators (distance[n, 3] uint32, confidence[n, 3] float64; kind order sample, molecular,
+        cellular) of host result planes shaped (n_result, batch_capacity)."""
+        result = np.ascontiguousarray(result, dtype=RESULT_DTYPE).reshape(max(1, self.n_result), -1) if self.n_result else np.zeros((1, n_read or 0), dtype=RESULT_DTYPE)
+        capacity = result.shape[1]
+        n = capacity if n_read is None else n_read
+        distance = np.zeros((n, 3), dtype=np.uint32)
+        confidence = np.zeros((n, 3), dtype=np.float64)
+        self._check(self.lib.phq_summarize(self.handle, capacity, n, result.ctypes.data, distance.ctypes.data, confidence.ctypes.data))
+        return distance, confidence
 
     def stats_allreduce(self, rccl_comm: int, stream: int = 0):
         self._check(self.lib.phq_stats_allreduce(self.handle, rccl_comm, stream or None))

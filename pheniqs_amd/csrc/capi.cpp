@@ -172,6 +172,13 @@ int phq_stats_allreduce(phq_decoder_set* set, void* rccl_comm, void* hip_stream)
     return guarded(set, [&]() { require(set, "set"); require(rccl_comm, "rccl_comm"); set->impl.stats_allreduce(rccl_comm, hip_stream); });
 }
 
+int phq_summarize(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const phq_result_t* result, uint32_t* distance, double* confidence) {
+    return guarded(set, [&]() {
+        require(set, "set");
+        set->impl.summarize(batch_capacity, n_read, reinterpret_cast<const phq::DevResult*>(result), distance, confidence);
+    });
+}
+
 int phq_stats_options(phq_decoder_set* set, const uint64_t* host_words, int32_t decoder, phq_option_t* option) {
     return guarded(set, [&]() {
         require(set, "set"); require(host_words, "host_words"); require(option, "option");

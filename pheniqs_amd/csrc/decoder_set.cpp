@@ -872,6 +872,43 @@ void DecoderSet::stats_allreduce(void* rccl_comm, void* stream) {
     if(status != 0) { throw InternalError("ncclAllReduce failed with code " + std::to_string(status)); }
 }
 
+// Read::update_* / set_* as the decoders' wrappers call them, after the last decoder (pamld.cpp:133-180, mdd.cpp:96-138)
+void summarize_read(const JobConfig& job, const DevResult* result, int64_t batch_capacity, int64_t k, uint32_t (&distance)[3], double (&confidence)[3]) {
+    for(int t = 0; t < 3; ++t) { distance[t] = 0; confidence[t] = 1; }               // read.h:176-183
+    for(const auto& d : job.decoder) {
+        if(d.result_slot < 0) { continue; }                                          // naive / passthrough: raw barcode only
+        const DevResult& res = result[static_cast<int64_t>(d.result_slot) * batch_capacity + k];
+        const int kind = static_cast<int>(d.kind);
+        const bool classified = res.index > 0;
+        if(d.algorithm == Algorithm::PAMLD) {
+            if(d.kind == Kind::SAMPLE || classified) {
+                distance[kind] += res.distance;
+                confidence[kind] = confidence[kind] == 1 ? res.confidence : confidence[kind] * res.confidence;     // read.h:279-285
+            } else {
+                confidence[kind] = 0;
+                if(d.kind == Kind::CELLULAR) { distance[kind] = 0; }                  // read.h:319-321: the molecular setter adds
+            }
+        } else {
+            if(d.kind == Kind::SAMPLE || classified) { distance[kind] += res.distance; }
+            else { distance[static_cast<int>(Kind::CELLULAR)] = 0; }                   // mdd.cpp:118,136: both reset the cellular one
+        }
+    }
+}
+
+void DecoderSet::summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const {
+    if(n_read < 0 || n_read > batch_capacity) { throw OverflowError("read range exceeds the batch capacity"); }
+    if(result == nullptr && job_.result_count > 0) { throw InternalError("result planes are missing"); }
+    for(int64_t k = 0; k < n_read; ++k) {
+        uint32_t d[3];
+        double c[3];
+        summarize_read(job_, result, batch_capacity, k, d, c);
+        for(int t = 0; t < 3; ++t) {
+            if(distance) { distance[3 * k + t] = d[t]; }
+            if(confidence) { confidence[3 * k + t] = c[t]; }
+        }
+    }
+}
+
 const std::string& DecoderSet::report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count) {
     report_ = encode_report(job_, host_words, incoming_count, incoming_pf_count).dump(job_.float_precision);
     return report_;

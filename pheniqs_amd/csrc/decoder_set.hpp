@@ -45,6 +45,7 @@ public:
     void stats_export(uint64_t* host_words);
     void stats_import(const uint64_t* host_words);
     void stats_allreduce(void* rccl_comm, void* stream);
+    void summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const;
     const std::string& report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count);
 
     // HIP event timing of every kernel launch (bench.py roofline): enable, run, then collect sums per kernel kind
@@ -105,5 +106,8 @@ private:
 
 void* host_alloc(size_t bytes);   // pinned host memory
 void host_free(void* pointer);
+
+// the per type accumulators of one read (read.h:152-165) from its result records; shared with the transcoder
+void summarize_read(const JobConfig& job, const DevResult* result, int64_t batch_capacity, int64_t k, uint32_t (&distance)[3], double (&confidence)[3]);
 
 }  // namespace phq

@@ -779,22 +779,10 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     }
                 }
                 if(res == nullptr) { continue; }                             // naive / passthrough: raw barcode only
-                const bool classified = res->index > 0;
-                if(d.algorithm == Algorithm::PAMLD) {
-                    if(d.kind == Kind::SAMPLE || classified) {               // pamld.cpp:133-140,149-160,169-180
-                        distance[kind] += res->distance;
-                        confidence[kind] = confidence[kind] == 1 ? res->confidence : confidence[kind] * res->confidence;
-                    } else {
-                        confidence[kind] = 0;
-                        if(d.kind == Kind::CELLULAR) { distance[kind] = 0; }   // read.h:319-321 adds for molecular
-                    }
-                } else {                                                     // mdd.cpp:96-138
-                    if(d.kind == Kind::SAMPLE || classified) { distance[kind] += res->distance; }
-                    else { distance[static_cast<int>(Kind::CELLULAR)] = 0; }
-                }
                 if(d.kind == Kind::SAMPLE) { rg = &rg_by_index[static_cast<size_t>(ordinal + 1)]; }
             }
-            (void)distance;
+            // the per type accumulators as the wrappers leave them (pamld.cpp:133-180, mdd.cpp:96-138): phq_summarize's loop
+            summarize_read(job, m.result, m.capacity, k, distance, confidence);
 
             // Multiplexer::push -> Channel::push (multiplex.h:198-240)
             const bool qcfail = (m.word[k] >> 31) != 0;
