@@ -218,10 +218,9 @@ class Workload:
         self.torch, self.device = torch, device
         self.job, recipe = synthetic.config_job(config, algorithm)
         if priors == "estimated":
-            from pheniqs_amd import jobspec
             spec = synthetic.config_spec(config, algorithm)
             spread = np.random.default_rng(3)
-            for _, decoder in jobspec.iter_decoders(spec):
+            for _, decoder in synthetic.iter_decoders(spec):
                 for record in (decoder.get("codec") or {}).values():
                     record["concentration"] = float(10 ** spread.uniform(-0.5, 0.5))
             self.job = capi.compile_job(spec)

@@ -265,6 +265,14 @@ int phq_format_double(double value, int32_t precision, char* buffer, int32_t cap
  * phq_create runs it by itself on a document that is not compiled yet.  `*compiled_json` is a NUL terminated
  * string (doubles printed with round trip digits) owned by the library: release it with phq_free_string. */
 int phq_compile_job(const char* job_json, char** compiled_json);
+
+/* Job::read_instruction_document (job.cpp:163-224): the job document at `path` with its `import` list resolved, as
+ * JSON text for phq_create / phq_compile_job.  Imported documents are loaded the same way, depth first, a path only
+ * the first time it is met; relative paths are taken against the directory of the importing document (a leading ~ is
+ * the home directory); a later import takes precedence over an earlier one and the importing document over all of
+ * them (merge_json_value, json.cpp:780-803).  So reference test/BDGGG/BDGGG_annotated.json runs as it is.  A document
+ * handed over as text may carry `import` too: its paths are then relative to the working directory. */
+int phq_load_job(const char* path, char** job_json);
 void phq_free_string(char* text);
 
 /* ---- next row f3: the prior estimator ---------------------------------------------------------------------

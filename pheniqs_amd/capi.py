@@ -27,7 +27,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
            "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
-           "phq_compile_job", "phq_free_string", "phq_adjust_prior")
+           "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior")
 
 
 class PheniqsError(RuntimeError):
@@ -102,6 +102,7 @@ def load_library():
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
+    L.phq_load_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
     L.phq_free_string.restype = None
     L.phq_adjust_prior.argtypes = [P, P, ctypes.c_char_p, ctypes.POINTER(P)]
@@ -114,6 +115,19 @@ def compile_job(job: Dict[str, Any]) -> Dict[str, Any]:
     L = load_library()
     out = ctypes.c_void_p()
     status = L.phq_compile_job(json.dumps(job).encode(), ctypes.byref(out))
+    if status != 0:
+        raise PheniqsError(status, (L.phq_last_error(None) or b"").decode())
+    try:
+        return json.loads(ctypes.string_at(out.value).decode())
+    finally:
+        L.phq_free_string(out)
+
+
+def load_job(path: str) -> Dict[str, Any]:
+    """phq_load_job: a job document file with its `import` list resolved (job.cpp:163-224)."""
+    L = load_library()
+    out = ctypes.c_void_p()
+    status = L.phq_load_job(os.fspath(path).encode(), ctypes.byref(out))
     if status != 0:
         raise PheniqsError(status, (L.phq_last_error(None) or b"").decode())
     try:

@@ -259,6 +259,19 @@ int phq_compile_job(const char* job_json, char** compiled_json) {
     });
 }
 
+int phq_load_job(const char* path, char** job_json) {
+    if(job_json != nullptr) { *job_json = nullptr; }
+    return guarded(nullptr, [&]() {
+        require(path, "path");
+        require(job_json, "job_json");
+        const std::string text = phq::load_job_document(path).dump(324);
+        char* out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *job_json = out;
+    });
+}
+
 void phq_free_string(char* text) { std::free(text); }
 
 int phq_transcode_plan(phq_decoder_set* set, char** plan_json) {

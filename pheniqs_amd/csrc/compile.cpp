@@ -2,6 +2,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <set>
 #include <string>
@@ -536,7 +538,7 @@ bool is_compiled_job(const Json& document) {
 
 Json assemble_job(const Json& document) {
     if(!document.is_object()) { throw ConfigurationError("job document must be a dictionary"); }
-    Json job = document;
+    Json job = document.find("import") != nullptr ? resolve_imports(document, ".") : document;      // a document in memory: imports relative to the working directory
     apply_repository_inheritance(job);
     const Json repository = job.find("decoder") != nullptr ? *job.find("decoder") : Json();
     for(const char* topic : TOPICS) {
@@ -563,7 +565,7 @@ Json assemble_job(const Json& document) {
 
 Json compile_job(const Json& document) {
     if(!document.is_object()) { throw ConfigurationError("job document must be a dictionary"); }
-    Json job = document;
+    Json job = document.find("import") != nullptr ? resolve_imports(document, ".") : document;      // a document in memory: imports relative to the working directory
     apply_repository_inheritance(job);
     const Json repository = job.find("decoder") != nullptr ? *job.find("decoder") : Json();
 
@@ -625,6 +627,107 @@ Json compile_job(const Json& document) {
     set_default(job, "leading segment index", Json::integer(0));
     compile_io(job, input_segment_cardinality);
     return job;
+}
+
+// ---- file imports (job.cpp:163-224, json.cpp:780-803) ---------------------------------------------------------
+
+namespace {
+
+// merge_json_value(base, ontology): members of `base` that `ontology` lacks are copied in, shared dictionaries recurse
+void merge_json(const Json& base, Json& ontology) {
+    if(base.is_null()) { return; }
+    if(ontology.is_null()) { ontology = base; return; }
+    if(!base.is_object()) { return; }
+    if(!ontology.is_object()) { throw ConfigurationError("element is not a dictionary"); }
+    for(const auto& member : base.members()) {
+        Json* mine = ontology.find(member.first);
+        if(mine != nullptr) {
+            try { merge_json(member.second, *mine); }
+            catch(ConfigurationError& error) { throw ConfigurationError(member.first + " " + error.message); }
+        } else {
+            ontology.set(member.first, member.second);
+        }
+    }
+}
+
+std::string directory_of(const std::string& path) {
+    const size_t slash = path.find_last_of('/');
+    return slash == std::string::npos ? std::string(".") : (slash == 0 ? std::string("/") : path.substr(0, slash));
+}
+
+// lexical normal form of a path (no file system access): what tells two spellings of one import apart
+std::string normal_path(const std::string& path) {
+    std::vector<std::string> part;
+    const bool absolute = !path.empty() && path[0] == '/';
+    size_t at = 0;
+    while(at <= path.size()) {
+        const size_t next = std::min(path.find('/', at), path.size());
+        const std::string piece = path.substr(at, next - at);
+        if(piece == "..") { if(!part.empty() && part.back() != "..") { part.pop_back(); } else if(!absolute) { part.push_back(piece); } }
+        else if(!piece.empty() && piece != ".") { part.push_back(piece); }
+        at = next + 1;
+    }
+    std::string out = absolute ? "/" : "";
+    for(size_t k = 0; k < part.size(); ++k) { out += (k ? "/" : "") + part[k]; }
+    return out.empty() ? std::string(".") : out;
+}
+
+std::string expand_home(const std::string& path) {
+    if(!path.empty() && path[0] == '~' && (path.size() == 1 || path[1] == '/')) {
+        const char* home = std::getenv("HOME");
+        if(home != nullptr) { return std::string(home) + path.substr(1); }
+    }
+    return path;
+}
+
+Json load_with_import(const std::string& path, std::vector<std::string>& visited);
+
+Json resolve(Json document, const std::string& directory, std::vector<std::string>& visited) {
+    if(!document.is_object()) { throw ConfigurationError("instruction root must be a dictionary"); }
+    const Json* import = document.find("import");
+    if(import != nullptr) {
+        if(!import->is_array()) { throw ConfigurationError("import element must be an array of paths"); }
+        Json aggregated;
+        for(const auto& record : import->elements()) {
+            if(!record.is_string()) { throw ConfigurationError("import element must be an array of paths"); }
+            std::string path = expand_home(record.as_string());
+            if(path.empty() || path[0] != '/') { path = directory + "/" + path; }     // relative to the importing document
+            path = normal_path(path);
+            // a path is only visited once, the first time a depth first walk meets it: no cyclical imports
+            if(std::find(visited.begin(), visited.end(), path) == visited.end()) {
+                Json imported = load_with_import(path, visited);
+                merge_json(aggregated, imported);                                        // the later import wins
+                aggregated = std::move(imported);
+            }
+        }
+        merge_json(aggregated, document);                                                // the importing document wins
+        document.erase("import");
+    }
+    return document;
+}
+
+Json load_with_import(const std::string& path, std::vector<std::string>& visited) {
+    std::FILE* file = std::fopen(path.c_str(), "rb");
+    if(file == nullptr) { throw ConfigurationError("unable to read instruction file from " + path); }
+    std::string text;
+    char buffer[1 << 16];
+    size_t got;
+    while((got = std::fread(buffer, 1, sizeof(buffer), file)) > 0) { text.append(buffer, got); }
+    std::fclose(file);
+    visited.push_back(path);
+    return resolve(Json::parse(text), directory_of(path), visited);
+}
+
+}  // namespace
+
+Json load_job_document(const std::string& path) {
+    std::vector<std::string> visited;
+    return load_with_import(normal_path(expand_home(path)), visited);
+}
+
+Json resolve_imports(Json document, const std::string& directory) {
+    std::vector<std::string> visited;
+    return resolve(std::move(document), directory.empty() ? std::string(".") : directory, visited);
 }
 
 }  // namespace phq

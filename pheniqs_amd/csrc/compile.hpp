@@ -9,7 +9,9 @@
 //   CodecMetric::compile_barcode_tolerance       metric.h:87-111,216-242 shannon bound, default distance tolerance
 //   projections "<type>:decoder"                 configuration.json:423-520
 //
-// File imports, IO, SAM header atoms and the command line stay with the caller.
+//   Job::load_instruction_with_import            job.cpp:167-224         `import`: documents merged depth first
+//
+// SAM header atoms and the command line stay with the caller.
 #pragma once
 
 #include "json.hpp"
@@ -25,5 +27,15 @@ Json assemble_job(const Json& document);
 
 // throws ConfigurationError exactly where the reference does
 Json compile_job(const Json& document);
+
+// Job::read_instruction_document (job.cpp:163-224): the document at `path` with its `import` list resolved — every
+// imported document is loaded the same way (depth first, a path only the first time it is met), relative paths
+// against the directory of the importing document; a later import takes precedence over an earlier one and the
+// importing document over all of them (merge_json_value, json.cpp:780-803: what the base defines fills in what the
+// document does not; a dictionary cannot fill a member that is not one).  The `import` member is removed.
+Json load_job_document(const std::string& path);
+
+// the same for a document that is already in memory; its imports are relative to `directory`
+Json resolve_imports(Json document, const std::string& directory);
 
 }  // namespace phq

@@ -12,7 +12,23 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import capi, jobspec
+from . import capi
+
+TOPICS = ("sample", "molecular", "cellular")
+
+
+def iter_decoders(job: Dict[str, Any]):
+    """(kind, decoder) in the order TranscodingDecoder::classify runs them: transcode.h:51-60."""
+    for kind in TOPICS:
+        node = job.get(kind)
+        if node is None:
+            continue
+        if isinstance(node, dict):
+            yield kind, node
+        else:
+            for element in node:
+                yield kind, element
+
 
 BASE_SEED = 20240613
 ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -60,7 +76,7 @@ CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384"
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
     """Compiled job + generation recipe for BASELINE config C2..C5.  seed = 20240613 + config number."""
     number = CONFIG_NUMBER[name]
-    # compiled by the library's own configuration compiler (phq_compile_job); jobspec.py is its independent Python
+    # compiled by the library's own configuration compiler (phq_compile_job); tests/jobspec.py is its independent Python
     # restatement, which the tests hold against it
     return capi.compile_job(config_spec(name, algorithm)), {"name": name, "seed": BASE_SEED + number}
 
@@ -124,7 +140,7 @@ def generate_rows(job: Dict[str, Any], n: int, seed: int) -> Tuple[np.ndarray, n
     rng = np.random.default_rng(seed)
     columns_code, columns_quality, offsets = [], [], []
     offset = 0
-    for _, decoder in jobspec.iter_decoders(job):
+    for _, decoder in iter_decoders(job):
         L = int(decoder["nucleotide cardinality"])
         offsets.append(offset)
         offset += L
@@ -156,7 +172,7 @@ def algorithmic_bytes_per_read(job: Dict[str, Any]) -> int:
     """2 * L_total (base + quality) + 1 (input flag) + 16 per PAMLD/MDD decoder + 4 (status word)."""
     total = 0
     closed = 0
-    for _, decoder in jobspec.iter_decoders(job):
+    for _, decoder in iter_decoders(job):
         total += int(decoder["nucleotide cardinality"])
         if decoder["algorithm"] in ("pamld", "mdd"):
             closed += 1

@@ -34,21 +34,11 @@ def read_fastq(path, ascii_to_bam, phred_offset=33):
 
 
 def raw_job():
-    """BDGGG_annotated.json as the reference reads it: only its `import` list is resolved here (a file level
-    operation, Job::assemble job.cpp:167-224: what the imported document defines fills in what the importing one
-    does not); the decoder repository and the `base` references are left to the library's compiler."""
-    def fill(base, value):
-        for key, inherited in base.items():
-            if key not in value:
-                value[key] = copy.deepcopy(inherited)
-            elif isinstance(inherited, dict) and isinstance(value[key], dict):
-                fill(inherited, value[key])
-        return value
-
-    annotated = json.load(open(os.path.join(HERE, "BDGGG_annotated.json")))
-    for name in annotated.pop("import", []):
-        fill(json.load(open(os.path.join(HERE, name))), annotated)
-    return annotated
+    """BDGGG_annotated.json as the reference reads it: the file itself, its `import` of BDGGG_interleave.json resolved
+    by the library (phq_load_job = Job::read_instruction_document, job.cpp:163-224); the decoder repository and the
+    `base` references are left to the library's compiler."""
+    from pheniqs_amd import capi
+    return capi.load_job(os.path.join(HERE, "BDGGG_annotated.json"))
 
 
 def user_job():

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import DecoderSet, PheniqsError, capi, jobspec
+from pheniqs_amd import DecoderSet, PheniqsError, capi
+import jobspec
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -2,7 +2,7 @@
 
 Pinned to the reference's own compiled ontology of test/BDGGG (valid/compile_annotated.out, committed as
 tests/golden/BDGGG/compile_annotated.json) and cross checked against the independent Python restatement the
-tests and bench use (pheniqs_amd/jobspec.py).  No GPU.
+tests and bench use (tests/jobspec.py).  No GPU.
 """
 import copy
 import json
@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import DecoderSet, PheniqsError, capi, jobspec, synthetic
+from pheniqs_amd import DecoderSet, PheniqsError, capi, synthetic
+import jobspec
 
 
 def test_reference_compile_of_bdggg_is_reproduced():

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import DecoderSet, PheniqsError, RESULT_DTYPE, capi, jobspec, synthetic
+from pheniqs_amd import DecoderSet, PheniqsError, RESULT_DTYPE, capi, synthetic
+import jobspec
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import jobspec
+import jobspec
 
 
 @pytest.fixture(scope="module")

@@ -112,7 +112,7 @@ def test_chain_end_to_end_sam_tags_follow_the_oracle(oracle, tmp_path, algorithm
     XB / XM / XC (Read::flush, read.h:187-199: 1 - the type's confidence product, as a float), the raw barcodes BC /
     OX / CR and the corrected ones RX / CB of every record are what the oracle's records and per type accumulators
     say.  Under MDD no confidence is ever set, so no X? tag may appear (mdd.cpp:96-138)."""
-    from pheniqs_amd import jobspec
+    import jobspec
     noise = 0.3
     job = chain_job(algorithm, noise)
     n = 30011
