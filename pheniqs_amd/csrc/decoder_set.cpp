@@ -141,6 +141,7 @@ void DecoderSet::release() {
         if(slot.stream) { (void)hipStreamDestroy(static_cast<hipStream_t>(slot.stream)); }
         slot = Slot();
     }
+    release_host_stage();
     for(void* p : device_allocation_) { (void)hipFree(p); }
     device_allocation_.clear();
     (void)hipFree(device_worklist_);
@@ -893,6 +894,25 @@ void summarize_read(const JobConfig& job, const DevResult* result, int64_t batch
             else { distance[static_cast<int>(Kind::CELLULAR)] = 0; }                   // mdd.cpp:118,136: both reset the cellular one
         }
     }
+}
+
+const DecoderSet::HostStage& DecoderSet::host_stage(int64_t capacity) {
+    if(host_stage_.capacity < capacity) {
+        release_host_stage();
+        const size_t planes = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
+        host_stage_.base = static_cast<uint8_t*>(host_alloc(planes));
+        host_stage_.quality = static_cast<uint8_t*>(host_alloc(planes));
+        host_stage_.flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(capacity)));
+        host_stage_.result = static_cast<DevResult*>(host_alloc(static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult)));
+        host_stage_.word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(capacity) * sizeof(uint32_t)));
+        host_stage_.capacity = capacity;
+    }
+    return host_stage_;
+}
+
+void DecoderSet::release_host_stage() {
+    host_free(host_stage_.base); host_free(host_stage_.quality); host_free(host_stage_.flag); host_free(host_stage_.result); host_free(host_stage_.word);
+    host_stage_ = HostStage();
 }
 
 void DecoderSet::summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const {

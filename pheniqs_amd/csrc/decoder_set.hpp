@@ -46,6 +46,11 @@ public:
     void stats_import(const uint64_t* host_words);
     void stats_allreduce(void* rccl_comm, void* stream);
     void summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const;
+    // pinned host planes for the transcoder's batches, kept by the set from one run to the next (pinning tens of
+    // megabytes costs more than classifying a batch)
+    struct HostStage { int64_t capacity = 0; uint8_t* base = nullptr; uint8_t* quality = nullptr; uint8_t* flag = nullptr; DevResult* result = nullptr; uint32_t* word = nullptr; };
+    const HostStage& host_stage(int64_t capacity);
+    void release_host_stage();
     const std::string& report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count);
 
     // HIP event timing of every kernel launch (bench.py roofline): enable, run, then collect sums per kernel kind
@@ -75,6 +80,7 @@ private:
     DevDecoder* device_decoder_;                // device array, one per decoder
     std::vector<void*> device_allocation_;
     unsigned long long* device_stats_;
+    HostStage host_stage_;
     uint32_t* device_worklist_;                 // read ordinals deferred by the product form kernel + 1 counter word in front
     int64_t worklist_capacity_;
     std::string report_;

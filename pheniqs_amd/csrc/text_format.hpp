@@ -50,9 +50,11 @@ inline char* put_float_g(char* to, float value) {
     if(!(d >= 1e-20 && d < 1.0)) {
         return to + std::snprintf(to, 32, "%g", d);
     }
-    int binary_exponent = 0;
-    const double fraction = std::frexp(d, &binary_exponent);                 // d = fraction * 2^e, fraction in [0.5, 1)
-    const uint64_t mantissa = static_cast<uint64_t>(std::ldexp(fraction, 24));   // exact: a float has 24 significant bits
+    // a normal float (1e-20 is far above the subnormals): 24 bit mantissa and binary exponent straight from its bits
+    uint32_t bits;
+    std::memcpy(&bits, &value, sizeof(bits));
+    const int binary_exponent = static_cast<int>((bits >> 23) & 0xffu) - 126;   // d = fraction * 2^e, fraction in [0.5, 1)
+    const uint64_t mantissa = (bits & 0x7fffffu) | 0x800000u;                   // fraction * 2^24
     const int shift = 24 - binary_exponent;                                   // d = mantissa / 2^shift, shift in [24, 91]
     static const unsigned __int128 power_of_ten[27] = {
         (unsigned __int128)1ull, (unsigned __int128)10ull, (unsigned __int128)100ull, (unsigned __int128)1000ull, (unsigned __int128)10000ull,
@@ -65,7 +67,9 @@ inline char* put_float_g(char* to, float value) {
         (unsigned __int128)10000000000000000000ull * 1000u, (unsigned __int128)10000000000000000000ull * 10000u,
         (unsigned __int128)10000000000000000000ull * 100000u, (unsigned __int128)10000000000000000000ull * 1000000u,
         (unsigned __int128)10000000000000000000ull * 10000000u};
-    int exponent = static_cast<int>(std::floor(std::log10(d)));              // may be one off next to a power of ten
+    // floor(log10(d)) from the binary exponent, 2^(e-1) <= d < 2^e: (e - 1) log10(2) rounded down is at most one too
+    // small, the loop below settles it
+    int exponent = ((binary_exponent - 1) * 78913) >> 18;
     uint64_t digits = 0;
     for(int attempt = 0; attempt < 3; ++attempt) {
         const int scale = 5 - exponent;                                       // 6 .. 25 for the accepted range (+-1)

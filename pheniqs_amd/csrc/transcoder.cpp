@@ -17,14 +17,22 @@
 // Out of scope here: BAM/CRAM (htslib), bz2 / xz, QC histograms.
 #include "transcoder.hpp"
 
+#include <fcntl.h>
+#include <immintrin.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
+#include <type_traits>
 
 #include "error.hpp"
 #include "host_parallel.hpp"
@@ -34,6 +42,37 @@ namespace phq {
 
 namespace {
 
+// std::vector whose resize() leaves trivially constructible elements uninitialised: the batch arrays below are
+// written in full by the parallel passes right after they are sized, and a value initialising resize would first
+// touch (and zero) hundreds of megabytes on the one thread that calls it
+template <typename T, typename A = std::allocator<T>>
+class default_init_allocator : public A {
+    typedef std::allocator_traits<A> traits;
+public:
+    template <typename U> struct rebind { typedef default_init_allocator<U, typename traits::template rebind_alloc<U>> other; };
+    using A::A;
+    // large blocks on 2 MiB boundaries and marked for transparent huge pages: a fresh batch array of a hundred
+    // megabytes then takes fifty page faults instead of twenty five thousand
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if(bytes >= (size_t(4) << 20)) {
+            const size_t huge = size_t(2) << 20;
+            void* block = nullptr;
+            if(::posix_memalign(&block, huge, (bytes + huge - 1) / huge * huge) != 0) { throw std::bad_alloc(); }
+            ::madvise(block, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+            return static_cast<T*>(block);
+        }
+        void* block = std::malloc(bytes ? bytes : 1);
+        if(block == nullptr) { throw std::bad_alloc(); }
+        return static_cast<T*>(block);
+    }
+    void deallocate(T* pointer, size_t) noexcept { std::free(pointer); }
+    template <typename U> void construct(U* pointer) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new(static_cast<void*>(pointer)) U; }
+    template <typename U, typename... Args> void construct(U* pointer, Args&&... args) { traits::construct(static_cast<A&>(*this), pointer, std::forward<Args>(args)...); }
+};
+template <typename T> using Bare = std::vector<T, default_init_allocator<T>>;
+struct Line { size_t first; uint32_t second; };          // where a line starts in the stream's bytes, and its length
+
 // one input file, plain or gzip (gzread reads both), 4 line FASTQ records
 //
 // A batch is read in two steps: the reader thread pulls bytes and indexes line starts until it holds the lines of
@@ -42,20 +81,46 @@ namespace {
 // every thread's output).  The reference decodes under the feed lock, one record at a time (feed.h:320-333).
 class FastqStream {
 public:
-    explicit FastqStream(const std::string& path) : path_(path), begin_(0), end_(0), eof_(false) {
-        file_ = gzopen(path.c_str(), "rb");
-        if(file_ == nullptr) { throw IOError("could not open " + path + " for reading"); }
-        gzbuffer(file_, 1 << 20);
-        buffer_.resize(1 << 24);
+    // A plain (not gzip) regular file is mapped: its bytes are read where they lie, a batch's lines are located on
+    // several threads straight in the mapping, and records may keep pointing into it for the whole run (SegmentBatch
+    // borrows the printable text instead of copying it).  Anything else goes through gzread as before.
+    explicit FastqStream(const std::string& path) : path_(path), file_(nullptr), map_(nullptr), map_size_(0), begin_(0), end_(0), eof_(false) {
+        const int descriptor = ::open(path.c_str(), O_RDONLY);
+        if(descriptor < 0) { throw IOError("could not open " + path + " for reading"); }
+        struct stat status;
+        unsigned char magic[2] = {0, 0};
+        const bool regular = ::fstat(descriptor, &status) == 0 && S_ISREG(status.st_mode);
+        const bool zipped = regular && ::pread(descriptor, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if(regular && !zipped && status.st_size > 0 && std::getenv("PHQ_NO_MMAP") == nullptr) {
+            void* mapped = ::mmap(nullptr, static_cast<size_t>(status.st_size), PROT_READ, MAP_PRIVATE, descriptor, 0);
+            if(mapped != MAP_FAILED) {
+                map_ = static_cast<const char*>(mapped);
+                map_size_ = static_cast<size_t>(status.st_size);
+                ::madvise(mapped, map_size_, MADV_SEQUENTIAL);
+                end_ = map_size_;
+                eof_ = true;
+            }
+        }
+        ::close(descriptor);
+        if(map_ == nullptr) {
+            file_ = gzopen(path.c_str(), "rb");
+            if(file_ == nullptr) { throw IOError("could not open " + path + " for reading"); }
+            gzbuffer(file_, 1 << 20);
+            buffer_.resize(1 << 24);
+        }
     }
-    ~FastqStream() { if(file_) { gzclose(file_); } }
+    ~FastqStream() {
+        if(file_) { gzclose(file_); }
+        if(map_) { ::munmap(const_cast<char*>(map_), map_size_); }
+    }
+    bool mapped() const { return map_ != nullptr; }
     FastqStream(const FastqStream&) = delete;
     FastqStream& operator=(const FastqStream&) = delete;
 
     // the next up to `capacity` records: line[4 i + k] = (offset, size) of line k of record i inside data().
     // Line ends are found on `threads` threads over slices of the buffered bytes (a memchr per 40 byte line costs
     // more in call overhead than in scanning), about as many bytes at a time as the lines still wanted should take.
-    int64_t index_records(int64_t capacity, int32_t threads, std::vector<std::pair<size_t, uint32_t>>& line) {
+    int64_t index_records(int64_t capacity, int32_t threads, Bare<Line>& line) {
         line.clear();
         size_t scan = begin_;                       // first byte that belongs to no line yet
         size_t searched = begin_;                   // bytes before this hold no unseen line end
@@ -82,10 +147,34 @@ public:
             const size_t guess = static_cast<size_t>(static_cast<double>(missing) * bytes_per_line_ * 1.02) + 4096;
             const size_t until = std::min(end_, searched + guess);
             find_line_ends(searched, until, threads);
-            for(const size_t newline : line_end_) {
-                if(line.size() >= wanted) { break; }
-                push(line, scan, newline - scan);
-                scan = newline + 1;
+            // the lines between consecutive newlines, filled in place on several threads; a blank line (tolerated
+            // between records) or a carriage return sends the window through the serial loop below instead
+            const size_t take = std::min(line_end_.size(), wanted - line.size());
+            bool filled = false;
+            if(take >= (1u << 16)) {
+                const size_t base = line.size();
+                line.resize(base + take);
+                std::vector<char> plain(static_cast<size_t>(std::max(1, threads)), 1);
+                const char* const bytes_at = data();
+                const size_t first_start = scan;
+                parallel_ranges(static_cast<int64_t>(take), 1 << 16, threads, [&](int64_t from, int64_t to, int part) {
+                    for(int64_t k = from; k < to; ++k) {
+                        const size_t start = k == 0 ? first_start : line_end_[static_cast<size_t>(k) - 1] + 1;
+                        const size_t stop = line_end_[static_cast<size_t>(k)];
+                        if(stop == start || bytes_at[stop - 1] == '\r') { plain[static_cast<size_t>(part)] = 0; }
+                        line[base + static_cast<size_t>(k)] = Line{start, static_cast<uint32_t>(stop - start)};
+                    }
+                });
+                filled = std::find(plain.begin(), plain.end(), 0) == plain.end();
+                if(filled) { scan = line_end_[take - 1] + 1; }
+                else { line.resize(base); }
+            }
+            if(!filled) {
+                for(const size_t newline : line_end_) {
+                    if(line.size() >= wanted) { break; }
+                    push(line, scan, newline - scan);
+                    scan = newline + 1;
+                }
             }
             if(line.size() >= wanted) { break; }
             searched = until;
@@ -102,7 +191,7 @@ public:
         return static_cast<int64_t>(records);
     }
     void release() { begin_ = consumed_; }                 // the indexed records have been decoded
-    const char* data() const { return buffer_.data(); }
+    const char* data() const { return map_ ? map_ : buffer_.data(); }
     const std::string& path() const { return path_; }
 
 private:
@@ -113,25 +202,57 @@ private:
         static const int index_threads = []() { const char* text = std::getenv("PHQ_INDEX_THREADS"); return text ? std::max(1, std::atoi(text)) : 0; }();      // measurement aid
         const int parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(index_threads > 0 ? index_threads : threads, bytes >> 20)));
         if(static_cast<int>(part_end_.size()) < parts) { part_end_.resize(static_cast<size_t>(parts)); }
-        const char* const bytes_at = buffer_.data();
+        const char* const bytes_at = data();
         parallel_ranges(bytes, 1 << 20, parts, [&](int64_t from, int64_t to, int part) {
-            std::vector<size_t>& found = part_end_[static_cast<size_t>(part)];
+            Bare<size_t>& found = part_end_[static_cast<size_t>(part)];
             found.clear();
             const char* at = bytes_at + first + from;
             const char* const stop = bytes_at + first + to;
-            while(at < stop) {
-                const void* newline = std::memchr(at, '\n', static_cast<size_t>(stop - at));
-                if(newline == nullptr) { break; }
-                found.push_back(static_cast<size_t>(static_cast<const char*>(newline) - bytes_at));
-                at = static_cast<const char*>(newline) + 1;
+            // room for a line end every 8 bytes, grown when a stretch of shorter lines needs it
+            found.resize(static_cast<size_t>(stop - at) / 8 + 64);
+            size_t count = 0;
+            if(have_avx2) { count = scan_newlines_avx2(at, stop, bytes_at, found); }
+            else {
+                while(at < stop) {
+                    const void* newline = std::memchr(at, '\n', static_cast<size_t>(stop - at));
+                    if(newline == nullptr) { break; }
+                    if(count == found.size()) { found.resize(found.size() * 2); }
+                    found[count++] = static_cast<size_t>(static_cast<const char*>(newline) - bytes_at);
+                    at = static_cast<const char*>(newline) + 1;
+                }
             }
+            found.resize(count);
         });
         for(int part = 0; part < parts; ++part) { line_end_.insert(line_end_.end(), part_end_[static_cast<size_t>(part)].begin(), part_end_[static_cast<size_t>(part)].end()); }
     }
-    void push(std::vector<std::pair<size_t, uint32_t>>& line, size_t offset, size_t size) {
-        if(size > 0 && buffer_[offset + size - 1] == '\r') { --size; }
+    // every '\n' of [at, stop): 32 bytes per compare (a memchr per 40 byte line spends its time in call overhead)
+    __attribute__((target("avx2"))) static size_t scan_newlines_avx2(const char* at, const char* stop, const char* origin, Bare<size_t>& found) {
+        size_t count = 0;
+        const __m256i newline = _mm256_set1_epi8('\n');
+        while(at + 32 <= stop) {
+            uint32_t mask = static_cast<uint32_t>(_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(at)), newline)));
+            if(mask != 0) {
+                if(count + 32 > found.size()) { found.resize(found.size() * 2); }
+                const size_t base = static_cast<size_t>(at - origin);
+                while(mask != 0) {
+                    found[count++] = base + static_cast<size_t>(__builtin_ctz(mask));
+                    mask &= mask - 1;
+                }
+            }
+            at += 32;
+        }
+        for(; at < stop; ++at) {
+            if(*at == '\n') {
+                if(count == found.size()) { found.resize(found.size() * 2); }
+                found[count++] = static_cast<size_t>(at - origin);
+            }
+        }
+        return count;
+    }
+    void push(Bare<Line>& line, size_t offset, size_t size) {
+        if(size > 0 && data()[offset + size - 1] == '\r') { --size; }
         if(size == 0 && line.size() % 4 == 0) { return; }                      // blank line between records
-        line.emplace_back(offset, static_cast<uint32_t>(size));
+        line.push_back(Line{offset, static_cast<uint32_t>(size)});
     }
     void refill() {
         if(begin_ > 0) {
@@ -147,31 +268,42 @@ private:
     }
     std::string path_;
     gzFile file_;
+    const char* map_;
+    size_t map_size_;
     std::vector<char> buffer_;
     size_t begin_;
     size_t end_;
     size_t consumed_ = 0;
     bool eof_;
     double bytes_per_line_ = 64;                     // of the previous batch: how far to look for the lines of the next
-    std::vector<size_t> line_end_;
-    std::vector<std::vector<size_t>> part_end_;
+    Bare<size_t> line_end_;
+    std::vector<Bare<size_t>> part_end_;
+    const bool have_avx2 = __builtin_cpu_supports("avx2") != 0;
 };
 
 struct SegmentBatch {
-    std::vector<uint8_t> code;           // BAM codes / Phred values: only for feeds a decoder token reads (stage_reads)
-    std::vector<uint8_t> quality;
-    std::vector<char> text;              // the same bases as the output prints them (BamToAmbiguousAscii of the code) and the
-    std::vector<char> quality_text;      // qualities at the output Phred offset: only for feeds the template reads
-    std::vector<int64_t> offset;
-    std::vector<int32_t> length;
-    std::vector<uint8_t> qcfail;
-    std::vector<char> name;              // concatenated, name_offset[i] .. name_offset[i + 1]
-    std::vector<int64_t> name_offset;
-    std::vector<std::pair<size_t, uint32_t>> line;
+    Bare<uint8_t> code;           // BAM codes / Phred values: only for feeds a decoder token reads (stage_reads)
+    Bare<uint8_t> quality;
+    Bare<char> text;              // the same bases as the output prints them (BamToAmbiguousAscii of the code) and the
+    Bare<char> quality_text;      // qualities at the output Phred offset: only for feeds the template reads
+    Bare<int64_t> offset;
+    Bare<int32_t> length;
+    Bare<uint8_t> qcfail;
+    Bare<char> name;              // concatenated, name_offset[i] .. name_offset[i + 1]
+    Bare<int64_t> name_offset;
+    Bare<Line> line;
+    // a feed read from a mapped file lends its bytes instead: record i's bases and qualities as the file holds them
+    // start at source + source_sequence[i] / source_quality[i]; the printable form (BamToAmbiguousAscii of the code, the
+    // output Phred offset) is made while the record is written
+    const char* source = nullptr;
+    Bare<uint64_t> source_sequence;
+    Bare<uint64_t> source_quality;
+    int32_t quality_shift = 0;           // output Phred offset - input Phred offset
     std::string error;
     void clear() {
         code.clear(); quality.clear(); text.clear(); quality_text.clear(); offset.clear(); length.clear(); qcfail.clear(); name.clear();
         name_offset.assign(1, 0);
+        source = nullptr; source_sequence.clear(); source_quality.clear();
         error.clear();
     }
     int64_t size() const { return static_cast<int64_t>(length.size()); }
@@ -235,8 +367,15 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
             name_bytes[static_cast<size_t>(part) + 1] += name_bytes[static_cast<size_t>(part)];
         }
         const size_t total_bases = static_cast<size_t>(sequence_bytes[static_cast<size_t>(parts)]);
+        const bool lend = needs.text && stream.mapped();
         if(needs.codes) { out.code.resize(total_bases); out.quality.resize(total_bases); }
-        if(needs.text) { out.text.resize(total_bases); out.quality_text.resize(total_bases); }
+        if(needs.text && !lend) { out.text.resize(total_bases); out.quality_text.resize(total_bases); }
+        if(lend) {
+            out.source = data;
+            out.source_sequence.resize(static_cast<size_t>(n));
+            out.source_quality.resize(static_cast<size_t>(n));
+            out.quality_shift = needs.output_phred_offset - phred_offset;
+        }
         out.name.resize(static_cast<size_t>(name_bytes[static_cast<size_t>(parts)]));
         out.name_offset[static_cast<size_t>(n)] = name_bytes[static_cast<size_t>(parts)];
         // pass 2: decode into place
@@ -266,7 +405,10 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
                     for(size_t k = 0; k < size; ++k) { to_code[k] = ascii_table[static_cast<uint8_t>(sequence[k])]; }
                     for(size_t k = 0; k < size; ++k) { to_quality[k] = static_cast<uint8_t>(quality[k] - phred_offset); }
                 }
-                if(needs.text) {
+                if(lend) {
+                    out.source_sequence[static_cast<size_t>(i)] = line[static_cast<size_t>(4 * i + 1)].first;
+                    out.source_quality[static_cast<size_t>(i)] = line[static_cast<size_t>(4 * i + 3)].first;
+                } else if(needs.text) {
                     // what FastqRecord::decode then ::encode make of the record (fastq.h:55-78,144-171), in one step
                     char* to_text = out.text.data() + at;
                     char* to_quality = out.quality_text.data() + at;
@@ -365,30 +507,65 @@ void gzip_member(const char* text, size_t size, int level, ByteBuffer& out) {
 
 struct OutputSink {
     TranscodePlan::OutputFeed feed;
-    std::FILE* file = nullptr;
+    int descriptor = -1;
     bool owns = false;
     bool wrote = false;
+    bool null = false;                 // /dev/null: nothing is formatted for it (reference feed.h:105 NullFeed, transcode.cpp:1634,1753)
+    bool seekable = false;             // a regular file: the parts of a batch are written in place concurrently
+    uint64_t position = 0;
     void open() {
-        if(feed.path == "-" || feed.path == "/dev/stdout") { file = stdout; }
+        if(feed.path == "/dev/null") { null = true; return; }
+        if(feed.path == "-" || feed.path == "/dev/stdout") { std::fflush(stdout); descriptor = STDOUT_FILENO; }
         else {
-            file = std::fopen(feed.path.c_str(), "wb");
+            descriptor = ::open(feed.path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
             owns = true;
-            if(file == nullptr) { throw IOError("could not open " + feed.path + " for writing"); }
+            if(descriptor < 0) { throw IOError("could not open " + feed.path + " for writing"); }
+            struct stat status;
+            seekable = ::fstat(descriptor, &status) == 0 && S_ISREG(status.st_mode);
+        }
+    }
+    // `size` bytes at `at` (a seekable sink) or at the end of the stream
+    void put(const char* bytes, size_t size, uint64_t at) {
+        while(size > 0) {
+            const ssize_t done = seekable ? ::pwrite(descriptor, bytes, size, static_cast<off_t>(at)) : ::write(descriptor, bytes, size);
+            if(done < 0) { if(errno == EINTR) { continue; } throw IOError("error writing " + feed.path); }
+            bytes += done; size -= static_cast<size_t>(done); at += static_cast<uint64_t>(done);
         }
     }
     void write(const char* bytes, size_t size) {
-        if(size > 0 && std::fwrite(bytes, 1, size, file) != size) { throw IOError("error writing " + feed.path); }
-        wrote = wrote || size > 0;
+        if(null || size == 0) { return; }
+        put(bytes, size, position);
+        position += size;
+        wrote = true;
     }
+    // room for `size` bytes the workers copy into place themselves: the file grows and the new range is mapped (writes
+    // to one file serialise on its lock whichever thread makes them; stores into a shared mapping do not)
+    char* window = nullptr;
+    size_t window_size = 0;
+    uint64_t window_base = 0;
+    char* map_more(size_t size) {
+        const uint64_t at = position;
+        const uint64_t page = static_cast<uint64_t>(::sysconf(_SC_PAGESIZE));
+        window_base = at / page * page;
+        window_size = static_cast<size_t>(at + size - window_base);
+        if(::ftruncate(descriptor, static_cast<off_t>(at + size)) != 0) { throw IOError("error writing " + feed.path); }
+        void* mapped = ::mmap(nullptr, window_size, PROT_READ | PROT_WRITE, MAP_SHARED, descriptor, static_cast<off_t>(window_base));
+        if(mapped == MAP_FAILED) { window = nullptr; return nullptr; }
+        window = static_cast<char*>(mapped);
+        position += size;
+        wrote = wrote || size > 0;
+        return window + (at - window_base);
+    }
+    void unmap() { if(window != nullptr) { ::munmap(window, window_size); window = nullptr; } }
+    uint64_t reserve(size_t size) { const uint64_t at = position; position += size; wrote = wrote || size > 0; return at; }
     void close() {
-        if(file != nullptr) {
+        if(descriptor >= 0) {
             if(feed.gzip && !wrote) {                        // an empty channel is still a valid gzip file
                 ByteBuffer member;
-                try { gzip_member("", 0, feed.level, member); std::fwrite(member.data.get(), 1, member.size, file); } catch(...) {}
+                try { gzip_member("", 0, feed.level, member); write(member.data.get(), member.size); } catch(...) {}
             }
-            std::fflush(file);
-            if(owns) { std::fclose(file); }
-            file = nullptr;
+            if(owns) { ::close(descriptor); }
+            descriptor = -1;
         }
     }
 };
@@ -504,8 +681,7 @@ struct Transcoder::Impl {
 
     Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
-        host_free(base); host_free(quality); host_free(flag); host_free(result); host_free(word);
-        for(auto& s : sink) { s.close(); }
+        for(auto& s : sink) { s.close(); }      // the staging planes belong to the set (DecoderSet::host_stage)
     }
 };
 
@@ -535,12 +711,8 @@ Transcoder::Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch
         }
         impl_->capacity = batch_capacity;
         impl_->batch.resize(plan.input_feed.size());
-        const size_t planes = static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.plane_width, 4));
-        impl_->base = static_cast<uint8_t*>(host_alloc(planes));
-        impl_->quality = static_cast<uint8_t*>(host_alloc(planes));
-        impl_->flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(batch_capacity)));
-        impl_->result = static_cast<DevResult*>(host_alloc(static_cast<size_t>(batch_capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)));
-        impl_->word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(batch_capacity) * sizeof(uint32_t)));
+        const DecoderSet::HostStage& stage = set.host_stage(batch_capacity);
+        impl_->base = stage.base; impl_->quality = stage.quality; impl_->flag = stage.flag; impl_->result = stage.result; impl_->word = stage.word;
         impl_->kept.resize(static_cast<size_t>(batch_capacity));
     } catch(...) {
         delete impl_;
@@ -552,6 +724,7 @@ Transcoder::~Transcoder() { delete impl_; }
 
 void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     Impl& m = *impl_;
+    const double run_begin = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     const JobConfig& job = m.set.job();
     const TranscodePlan& plan = m.plan;
     const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
@@ -599,6 +772,19 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
 
+    // NullFeed (reference feed.h:105; transcode.cpp:1634,1753): a channel whose every URL is /dev/null takes its reads
+    // without a record being assembled; when no channel writes anything the whole formatting step is skipped
+    std::vector<char> channel_silent(plan.channel.size(), 0);
+    bool all_silent = true;
+    for(size_t c = 0; c < plan.channel.size(); ++c) {
+        bool silent = true;
+        for(const int32_t f : plan.channel[c].feed_by_segment) { silent = silent && m.sink[static_cast<size_t>(f)].null; }
+        channel_silent[c] = silent ? 1 : 0;
+        all_silent = all_silent && silent;
+    }
+    const DecoderConfig* const multiplexer = job.multiplexing_decoder >= 0 ? &job.decoder[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
+    const std::vector<int>* const multiplexer_ordinal = multiplexer ? &ordinal_by_index[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
+
     // f1: one reader thread per input feed (the reference has one producer thread per feed, feed.h:309-314); the
     // next batch is read while this one is staged, classified and written
     std::vector<SegmentBatch> ahead(m.batch.size());
@@ -615,6 +801,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
     for(const auto& t : job.template_transform) {
+        if(all_silent) { break; }                 // nothing is written: no feed needs its printable text
         if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].text = true; }
     }
     auto start_readers = [&](std::vector<SegmentBatch>& into) {
@@ -629,9 +816,14 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         auto readers = start_readers(m.batch);
         for(auto& t : readers) { t.join(); }
     }
+    const double first_read_end = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // the complement of a printed base, for `~` tokens of the template over printable text (iupac.h:107-124)
     char complement_text[256];
-    for(int c = 0; c < 256; ++c) { complement_text[c] = bam_to_ascii(reverse_complement_bam(ascii_to_bam(static_cast<uint8_t>(c)))); }
+    char canonical_text[256];              // BamToAmbiguousAscii of AsciiToAmbiguousBam: what the reference prints for what it read
+    for(int c = 0; c < 256; ++c) {
+        complement_text[c] = bam_to_ascii(reverse_complement_bam(ascii_to_bam(static_cast<uint8_t>(c))));
+        canonical_text[c] = bam_to_ascii(ascii_to_bam(static_cast<uint8_t>(c)));
+    }
     const int workers = host_threads();
     std::vector<ByteBuffer> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
     std::vector<ByteBuffer> part_packed(part_text.size());
@@ -729,17 +921,25 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         // f2: records, a contiguous range of the batch per thread, written in order
         for(auto& text : part_text) { text.clear(); }
         for(auto& text : part_packed) { text.clear(); }
-        parallel_ranges(n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
+        parallel_ranges(all_silent ? 0 : n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
         ByteBuffer* const text_of_sink = &part_text[static_cast<size_t>(part) * static_cast<size_t>(n_sink)];
         Text raw[3], corrected[3];
         for(auto& t : raw) { t.allocate(barcode_capacity); }
         for(auto& t : corrected) { t.allocate(barcode_capacity); }
         std::vector<char> tags(tag_capacity);
         // a token's bases: BAM codes and Phred values (a corrected barcode) or printable text (an input segment)
-        struct Piece { const uint8_t* code; const uint8_t* quality; const char* text; const char* quality_text; int32_t size; bool reverse_complement; };
+        struct Piece { const uint8_t* code; const uint8_t* quality; const char* text; const char* quality_text; int32_t size; bool reverse_complement; bool lent; int32_t quality_shift; };
         std::vector<Piece> piece(job.template_transform.size());
         for(int64_t k = first_kept; k < last_kept; ++k) {
             const int64_t r = m.kept[static_cast<size_t>(k)];
+            if(multiplexer != nullptr && multiplexer->result_slot >= 0) {
+                // the channel is known from the multiplexing decoder's record alone: a silent one needs nothing else
+                const DevResult& res = m.result[static_cast<int64_t>(multiplexer->result_slot) * m.capacity + k];
+                size_t early = 0;
+                if(res.index > 0 && static_cast<size_t>(res.index) < multiplexer_ordinal->size()) { early = static_cast<size_t>((*multiplexer_ordinal)[static_cast<size_t>(res.index)] + 1); }
+                if(early >= plan.channel.size()) { early = 0; }
+                if(channel_silent[early] || plan.channel[early].feed_by_segment.empty()) { continue; }
+            } else if(channel_silent[0]) { continue; }
             uint32_t distance[3] = {0, 0, 0};
             double confidence[3] = {1, 1, 1};                               // read.h:176-183
             for(auto& t : raw) { t.clear(); }
@@ -794,18 +994,23 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             for(size_t t = 0; t < job.template_transform.size(); ++t) {
                 const TransformConfig& token = job.template_transform[t];
                 const uint8_t* fc = nullptr; const uint8_t* fq = nullptr; const char* ft = nullptr; const char* fqt = nullptr; int32_t flen;
+                bool lent = false; int32_t quality_shift = 0;
                 if(token.input_segment_index < 0) {
                     const Text& from = corrected[token.input_segment_index == -1 ? 0 : token.input_segment_index == -2 ? 2 : 1];
                     fc = from.code.data(); fq = from.quality.data(); flen = from.size;
                 } else {
                     const SegmentView& v = view[static_cast<size_t>(token.input_segment_index)];
                     const size_t at = v.at(r);
-                    ft = v.feed->text.data() + v.feed->offset[at]; fqt = v.feed->quality_text.data() + v.feed->offset[at]; flen = v.feed->length[at];
+                    if(v.feed->source != nullptr) {                       // lent by a mapped file: made printable while it is copied
+                        ft = v.feed->source + v.feed->source_sequence[at]; fqt = v.feed->source + v.feed->source_quality[at];
+                        lent = true; quality_shift = v.feed->quality_shift;
+                    } else { ft = v.feed->text.data() + v.feed->offset[at]; fqt = v.feed->quality_text.data() + v.feed->offset[at]; }
+                    flen = v.feed->length[at];
                 }
                 const int32_t start = token.absolute_start(flen);
                 const int32_t end = token.absolute_end(flen);
                 piece[t] = Piece{fc ? fc + start : nullptr, fq ? fq + start : nullptr, ft ? ft + start : nullptr, fqt ? fqt + start : nullptr,
-                                 end - start > 0 ? end - start : 0, token.reverse_complement};
+                                 end - start > 0 ? end - start : 0, token.reverse_complement, lent, quality_shift};
             }
 
             // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
@@ -836,6 +1041,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                         const Piece& p = piece[static_cast<size_t>(t)];
                         if(p.text != nullptr) {
                             if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = complement_text[static_cast<uint8_t>(p.text[p.size - i - 1])]; } at += p.size; }
+                            else if(p.lent) { for(int32_t i = 0; i < p.size; ++i) { at[i] = canonical_text[static_cast<uint8_t>(p.text[i])]; } at += p.size; }
                             else { at = put_bytes(at, p.text, static_cast<size_t>(p.size)); }
                         } else if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = BAM_TO_ASCII[reverse_complement_bam(p.code[p.size - i - 1]) & 0xf]; } at += p.size; }
                         else { at = put_sequence(at, p.code, p.size); }
@@ -846,7 +1052,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     for(const int32_t t : tokens) {
                         const Piece& p = piece[static_cast<size_t>(t)];
                         if(p.quality_text != nullptr) {
-                            if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = p.quality_text[p.size - i - 1]; } at += p.size; }
+                            if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality_text[p.size - i - 1] + p.quality_shift); } at += p.size; }
+                            else if(p.quality_shift != 0) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality_text[i] + p.quality_shift); } at += p.size; }
                             else { at = put_bytes(at, p.quality_text, static_cast<size_t>(p.size)); }
                         } else if(p.reverse_complement) { for(int32_t i = 0; i < p.size; ++i) { at[i] = static_cast<char>(p.quality[p.size - i - 1] + job.output_phred_offset); } at += p.size; }
                         else { at = put_quality(at, p.quality, p.size, job.output_phred_offset); }
@@ -897,11 +1104,38 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
         });
         lap(3);
-        for(int part = 0; part < workers; ++part) {
+        // the parts in order; on a regular file every part goes to its place on its own thread
+        {
+            std::vector<char*> place(part_text.size(), nullptr);
+            bool concurrent = false;
             for(int32_t f = 0; f < n_sink; ++f) {
-                const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
-                const ByteBuffer& bytes = m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at];
-                m.sink[static_cast<size_t>(f)].write(bytes.data.get(), bytes.size);
+                OutputSink& sink = m.sink[static_cast<size_t>(f)];
+                if(sink.null) { continue; }
+                size_t total = 0;
+                for(int part = 0; part < workers; ++part) {
+                    const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
+                    total += (sink.feed.gzip ? part_packed[at] : part_text[at]).size;
+                }
+                char* window = (sink.seekable && total >= (1u << 20)) ? sink.map_more(total) : nullptr;
+                for(int part = 0; part < workers; ++part) {
+                    const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
+                    const ByteBuffer& bytes = sink.feed.gzip ? part_packed[at] : part_text[at];
+                    if(bytes.size == 0) { continue; }
+                    if(window != nullptr) { place[at] = window; window += bytes.size; concurrent = true; }
+                    else { sink.write(bytes.data.get(), bytes.size); }
+                }
+            }
+            if(concurrent) {
+                parallel_ranges(workers, 1, workers, [&](int64_t first_part, int64_t last_part, int) {
+                    for(int64_t part = first_part; part < last_part; ++part) {
+                        for(int32_t f = 0; f < n_sink; ++f) {
+                            const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
+                            const ByteBuffer& bytes = m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at];
+                            if(place[at] != nullptr) { std::memcpy(place[at], bytes.data.get(), bytes.size); }
+                        }
+                    }
+                });
+                for(auto& sink : m.sink) { sink.unmap(); }
             }
         }
         lap(4);
@@ -912,8 +1146,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     }
     for(auto& sink : m.sink) { sink.close(); }
     if(trace) {
-        std::fprintf(stderr, "transcode phases (s): validate %.3f stage %.3f classify %.3f format %.3f write %.3f wait for readers %.3f\n",
-                     phase[0], phase[1], phase[2], phase[3], phase[4], phase[5]);
+        std::fprintf(stderr, "transcode phases (s): first batch read %.3f | validate %.3f stage %.3f classify %.3f format %.3f write %.3f wait for readers %.3f | run %.3f\n",
+                     first_read_end - run_begin, phase[0], phase[1], phase[2], phase[3], phase[4], phase[5], now() - run_begin);
     }
 }
 
