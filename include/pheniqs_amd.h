@@ -147,7 +147,10 @@ int phq_stage_reads(const phq_decoder_set* set, int64_t n_read, int32_t n_segmen
  * The call only enqueues work on `hip_stream` (a hipStream_t, NULL = default stream); counters
  * accumulate in the set's device counter buffer.  n_read is at most 2^31 - 2^20 per call (read ordinals travel in
  * 32 bits between the kernels of a stage): PHQ_OVERFLOW_ERROR beyond that, classify a larger batch in pieces
- * with first_read. */
+ * with first_read.  The scratch the kernels of one call hand reads through (worklists, counters) belongs to the
+ * set: calls on ONE stream are ordered by the stream; a call on a different stream than the previous call's first
+ * waits, on the device, for that call's kernels (hipStreamWaitEvent) — correct from any stream, concurrent on none.
+ * A host that wants two batches in flight uses two sets (or phq_classify_host, which owns two slots). */
 int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t first_read, int64_t n_read,
                         const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                         phq_result_t* result, uint32_t* word, void* hip_stream);

@@ -142,6 +142,7 @@ void DecoderSet::release() {
         slot = Slot();
     }
     release_host_stage();
+    if(order_event_) { (void)hipEventDestroy(static_cast<hipEvent_t>(order_event_)); order_event_ = nullptr; order_pending_ = false; }
     for(void* p : device_allocation_) { (void)hipFree(p); }
     device_allocation_.clear();
     (void)hipFree(device_worklist_);
@@ -653,7 +654,23 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
         }
         worklist = device_worklist_;
     }
+    // The worklist, the carry region and the per workgroup counters in front of them belong to the set, not to the
+    // call: two calls on two streams must not run at once.  A call on another stream than the previous one first waits
+    // (on the device) for that one's kernels; calls on one stream are ordered by the stream itself.
+    if(order_event_ == nullptr) {
+        hipEvent_t event;
+        check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
+        order_event_ = event;
+    }
+    if(order_pending_ && last_stream_ != stream) {
+        check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(order_event_), 0), "hipStreamWaitEvent");
+    }
     run_stages(batch_capacity, first_read, n_read, base_planes, quality_planes, flag, result, word, stream, worklist);
+    if(worklist != nullptr) {
+        check(hipEventRecord(static_cast<hipEvent_t>(order_event_), static_cast<hipStream_t>(stream)), "hipEventRecord");
+        order_pending_ = true;
+        last_stream_ = stream;
+    }
 }
 
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
@@ -717,6 +734,9 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         (void)hipFree(slot.device_result); (void)hipFree(slot.device_word); (void)hipFree(slot.device_worklist);
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
+        // nothing of the old buffers is left in the slot should an allocation below throw (release() frees what it finds)
+        { Slot fresh; fresh.stream = slot.stream; fresh.done = slot.done; slot = fresh; }
+        chunk_capacity_ = 0;
         const size_t planes = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
         const size_t results = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult);
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_base), planes), "hipMalloc");

@@ -81,6 +81,9 @@ private:
     std::vector<void*> device_allocation_;
     unsigned long long* device_stats_;
     HostStage host_stage_;
+    void* order_event_ = nullptr;               // recorded behind the kernels of the last phq_classify_device call
+    void* last_stream_ = nullptr;
+    bool order_pending_ = false;
     uint32_t* device_worklist_;                 // read ordinals deferred by the product form kernel + 1 counter word in front
     int64_t worklist_capacity_;
     std::string report_;

@@ -35,4 +35,16 @@ struct SequenceError : Error { explicit SequenceError(const std::string& m) : Er
 struct OverflowError : Error { explicit OverflowError(const std::string& m) : Error(OVERFLOW_ERROR, "Overflow error", m) {} };
 struct IOError : Error { explicit IOError(const std::string& m) : Error(IO_ERROR, "IO error", m) {} };
 
+// the error of class `code` again (a worker thread hands its failure over as a code and a text)
+[[noreturn]] inline void throw_error(int code, const std::string& message) {
+    switch(code) {
+        case CONFIGURATION_ERROR: throw ConfigurationError(message);
+        case OUT_OF_MEMORY_ERROR: throw OutOfMemoryError(message);
+        case IO_ERROR: throw IOError(message);
+        case SEQUENCE_ERROR: throw SequenceError(message);
+        case OVERFLOW_ERROR: throw OverflowError(message);
+        default: throw InternalError(message);
+    }
+}
+
 }  // namespace phq

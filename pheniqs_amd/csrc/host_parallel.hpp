@@ -13,6 +13,8 @@
 
 #include <sched.h>
 
+#include "error.hpp"
+
 namespace phq {
 
 // threads the process may really use: PHQ_HOST_THREADS, else the affinity mask capped by the cgroup CPU quota, at most 32
@@ -47,16 +49,24 @@ void parallel_ranges(int64_t n, int64_t grain, int parts, F&& f) {
     parts = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(parts, (n + grain - 1) / grain)));
     if(parts == 1) { f(static_cast<int64_t>(0), n, 0); return; }
     std::vector<std::thread> workers;
+    // a worker's failure crosses to the caller as (error class, text): an IO error stays an IO error
     std::vector<std::string> failure(static_cast<size_t>(parts));
+    std::vector<int> failure_code(static_cast<size_t>(parts), 0);
     for(int part = 0; part < parts; ++part) {
         const int64_t begin = n * part / parts;
         const int64_t end = n * (part + 1) / parts;
         workers.emplace_back([&, begin, end, part]() {
-            try { f(begin, end, part); } catch(const std::exception& e) { failure[static_cast<size_t>(part)] = e.what(); if(failure[static_cast<size_t>(part)].empty()) { failure[static_cast<size_t>(part)] = "error"; } }
+            try { f(begin, end, part); }
+            catch(const Error& e) { failure_code[static_cast<size_t>(part)] = e.code; failure[static_cast<size_t>(part)] = e.message.empty() ? std::string("error") : e.message; }
+            catch(const std::exception& e) { failure[static_cast<size_t>(part)] = e.what(); if(failure[static_cast<size_t>(part)].empty()) { failure[static_cast<size_t>(part)] = "error"; } }
         });
     }
     for(auto& worker : workers) { worker.join(); }
-    for(const auto& text : failure) { if(!text.empty()) { throw std::runtime_error(text); } }
+    for(size_t part = 0; part < failure.size(); ++part) {
+        if(failure[part].empty()) { continue; }
+        if(failure_code[part] != 0) { throw_error(failure_code[part], failure[part]); }
+        throw std::runtime_error(failure[part]);
+    }
 }
 
 }  // namespace phq

@@ -300,17 +300,19 @@ struct SegmentBatch {
     Bare<uint64_t> source_quality;
     int32_t quality_shift = 0;           // output Phred offset - input Phred offset
     std::string error;
+    int error_code = 0;                  // its class (error.hpp): a read error stays an IO error
     void clear() {
         code.clear(); quality.clear(); text.clear(); quality_text.clear(); offset.clear(); length.clear(); qcfail.clear(); name.clear();
         name_offset.assign(1, 0);
         source = nullptr; source_sequence.clear(); source_quality.clear();
         error.clear();
+        error_code = 0;
     }
     int64_t size() const { return static_cast<int64_t>(length.size()); }
 };
 
 // what a feed's batch has to hold: codes for the decoders' tokens, printable text for the template's
-struct FeedNeeds { bool codes; bool text; int32_t output_phred_offset; };
+struct FeedNeeds { bool codes; bool text; int32_t output_phred_offset; bool illumina_comment; };
 
 void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_offset, int32_t threads, FeedNeeds needs, SegmentBatch& out) {
     static const std::vector<uint8_t> ascii_table = []() {                  // AsciiToAmbiguousBam, iupac.h:153-171
@@ -390,10 +392,14 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
                 out.name_offset[static_cast<size_t>(i)] = name_at;
                 name_at += static_cast<int64_t>(name_end) - 1;
                 // Illumina comment `segment:filtered:control:barcode` (fastq.h:219-285): filtered == 'Y' sets QC fail
+                // ... on the platforms whose comment has that form only (ILLUMINA, ELEMENT: fastq.h:100-126); any other
+                // platform leaves the flag alone
                 bool qcfail = false;
-                size_t p = name_end < header_size ? name_end + 1 : header_size;
-                while(p < header_size && header[p] != ':') { ++p; }
-                if(p + 1 < header_size) { qcfail = header[p + 1] == 'Y'; }
+                if(needs.illumina_comment) {
+                    size_t p = name_end < header_size ? name_end + 1 : header_size;
+                    while(p < header_size && header[p] != ':') { ++p; }
+                    if(p + 1 < header_size) { qcfail = header[p + 1] == 'Y'; }
+                }
                 out.qcfail[static_cast<size_t>(i)] = qcfail ? 1 : 0;
                 const size_t size = line[static_cast<size_t>(4 * i + 1)].second;
                 const char* sequence = data + line[static_cast<size_t>(4 * i + 1)].first;
@@ -421,8 +427,10 @@ void read_segment_batch(FastqStream& stream, int64_t capacity, int32_t phred_off
         });
         stream.release();
     } catch(const std::exception& e) {
-        out.error = e.what();
-        if(out.error.empty()) { out.error = "error reading " + stream.path(); }
+        const Error* const classified = dynamic_cast<const Error*>(&e);
+        out.error = classified ? classified->message : std::string(e.what());
+        out.error_code = classified ? static_cast<int>(classified->code) : static_cast<int>(SEQUENCE_ERROR);
+        if(out.error.empty()) { out.error = "error reading " + stream.path(); out.error_code = IO_ERROR; }
         out.code.clear(); out.quality.clear(); out.text.clear(); out.quality_text.clear(); out.offset.clear(); out.length.clear(); out.qcfail.clear(); out.name.clear();
         out.name_offset.assign(1, 0);
     }
@@ -794,7 +802,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     if(const char* text = std::getenv("PHQ_PARSE_THREADS")) { parse_threads = std::max(1, std::atoi(text)); }      // measurement aid
     // what each feed's batches must hold: BAM codes where a decoder token reads one of its segments (stage_reads),
     // printable text where the template does; a template-only feed (the biological reads) is never turned into codes
-    std::vector<FeedNeeds> needs(static_cast<size_t>(n_feed), FeedNeeds{false, false, job.output_phred_offset});
+    std::vector<FeedNeeds> needs(static_cast<size_t>(n_feed), FeedNeeds{false, false, job.output_phred_offset, illumina_comment});
     for(const auto& d : job.decoder) {
         for(const auto& t : d.transform) {
             if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].codes = true; }
@@ -856,7 +864,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     double mark = now();
     auto lap = [&](int k) { const double t = now(); phase[k] += t - mark; mark = t; };
     while(true) {
-        for(const auto& b : m.batch) { if(!b.error.empty()) { throw SequenceError(b.error); } }
+        for(const auto& b : m.batch) { if(!b.error.empty()) { throw_error(b.error_code, b.error); } }
         for(int32_t f = 0; f < n_feed; ++f) {
             if(m.batch[static_cast<size_t>(f)].size() % plan.input_feed[static_cast<size_t>(f)].resolution != 0) {
                 throw SequenceError("interleaved input " + plan.input_feed[static_cast<size_t>(f)].path + " ends inside a read");

@@ -16,7 +16,8 @@ import json
 import os
 import sys
 
-KINDS = (("pamld_product", ("pamld_lut_kernel", "pamld_cross_kernel", "pamld_wide_kernel")),
+KINDS = (("pamld_near", ("pamld_near_kernel",)),
+         ("pamld_product", ("pamld_lut_kernel", "pamld_cross_kernel", "pamld_wide_kernel")),
          ("pamld_exact", ("pamld_cross_exact_kernel",)),
          ("pamld_literal", ("pamld_literal_kernel",)),
          ("mdd_exact", ("mdd_exact_kernel",)),
