@@ -319,12 +319,16 @@ void DecoderSet::build_device_images() {
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
             }
-            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.nucleotide_cardinality >= 5 && c.nucleotide_cardinality <= 8 &&
-               d.n_barcode > NEAR_LIST && d.n_barcode <= NEAR_MAX_BARCODES) {
-                // neighbour list tier (pamld_near.hpp): the nearest barcode of every possible word, and per barcode the
-                // bit planes of the NEAR_LIST barcodes nearest to it with what bounds the others
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
+               d.n_barcode > near_list(c.nucleotide_cardinality) && d.n_barcode <= NEAR_MAX_BARCODES) {
+                // neighbour list tier (pamld_near.hpp): the barcode of every word at most one mismatch away from one, and
+                // per barcode the bit planes of the barcodes nearest to it with what bounds the others
                 const int32_t L = c.nucleotide_cardinality;
                 const int32_t N = d.n_barcode;
+                const int32_t list = near_list(L);
+                const int32_t field = near_field_bits(L);
+                const int32_t per_word = 32 / field;
+                const int32_t record_words = near_record_words(L);
                 std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
                 for(int32_t b = 0; b < N; ++b) {
                     for(int32_t j = 0; j < L; ++j) {
@@ -337,19 +341,21 @@ void DecoderSet::build_device_images() {
                 auto distance = [&](uint32_t low_a, uint32_t high_a, uint32_t low_b, uint32_t high_b) {
                     return __builtin_popcount((low_a ^ low_b) | (high_a ^ high_b));
                 };
-                std::vector<uint16_t> nearest(static_cast<size_t>(1) << 16, 0);
-                const uint32_t position_mask = (1u << L) - 1u;
-                for(uint32_t key = 0; key < (1u << 16); ++key) {
-                    const uint32_t key_low = key & 0xffu & position_mask;
-                    const uint32_t key_high = (key >> 8) & position_mask;
-                    int best = 0, best_distance = 99;
-                    for(int32_t b = 0; b < N; ++b) {
-                        const int dist = distance(key_low, key_high, low[static_cast<size_t>(b)], high[static_cast<size_t>(b)]);
-                        if(dist < best_distance) { best_distance = dist; best = b; }
+                // a read more than one mismatch away from every barcode is not finished by the kernel: only those words
+                std::vector<uint16_t> nearest(static_cast<size_t>(1) << (2 * L), NEAR_NO_BARCODE);
+                for(int32_t b = N - 1; b >= 0; --b) {                     // the lowest ordinal last: it wins a shared word
+                    for(int32_t j = 0; j < L; ++j) {
+                        for(uint32_t other = 0; other < 4; ++other) {
+                            const uint32_t l = (low[static_cast<size_t>(b)] & ~(1u << j)) | ((other & 1u) << j);
+                            const uint32_t h = (high[static_cast<size_t>(b)] & ~(1u << j)) | ((other >> 1) << j);
+                            uint16_t& slot = nearest[l | (h << L)];
+                            const bool is_exact = l == low[static_cast<size_t>(b)] && h == high[static_cast<size_t>(b)];
+                            // an exact word is never taken over by a neighbour of another barcode
+                            if(slot == NEAR_NO_BARCODE || is_exact || !(low[slot] == l && high[slot] == h)) { slot = static_cast<uint16_t>(b); }
+                        }
                     }
-                    nearest[key] = static_cast<uint16_t>(best);
                 }
-                std::vector<uint32_t> record(static_cast<size_t>(N) * NEAR_RECORD_WORDS, 0u);
+                std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
                 int32_t usable = 0;
                 std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
                 for(int32_t b = 0; b < N; ++b) {
@@ -357,22 +363,23 @@ void DecoderSet::build_device_images() {
                         order[static_cast<size_t>(o)] = {o == b ? -1 : distance(low[static_cast<size_t>(b)], high[static_cast<size_t>(b)], low[static_cast<size_t>(o)], high[static_cast<size_t>(o)]), o};
                     }
                     std::sort(order.begin(), order.end());               // b itself first, then by (distance, ordinal)
-                    uint32_t* out = &record[static_cast<size_t>(b) * NEAR_RECORD_WORDS];
-                    for(int32_t k = 0; k < NEAR_LIST; ++k) {
+                    uint32_t* out = &record[static_cast<size_t>(b) * static_cast<size_t>(record_words)];
+                    for(int32_t k = 0; k < list; ++k) {
                         const int32_t o = order[static_cast<size_t>(k)].second;
-                        out[2 * (k / 4)] |= low[static_cast<size_t>(o)] << (8 * (k % 4));
-                        out[2 * (k / 4) + 1] |= high[static_cast<size_t>(o)] << (8 * (k % 4));
+                        out[2 * (k / per_word)] |= low[static_cast<size_t>(o)] << (field * (k % per_word));
+                        out[2 * (k / per_word) + 1] |= high[static_cast<size_t>(o)] << (field * (k % per_word));
                     }
                     // the first barcode not listed sets the radius, at most 5 (the kernel forms its bounds for 4 and 5)
-                    const int radius = std::min(order[static_cast<size_t>(NEAR_LIST)].first, 5);
+                    const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
                     int at_radius = 0;
-                    for(int32_t k = NEAR_LIST; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
+                    for(int32_t k = list; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
                     const float cnt_r = static_cast<float>(at_radius);
-                    const float cnt_rest = static_cast<float>(N - NEAR_LIST - at_radius);
-                    out[8] = static_cast<uint32_t>(radius);
-                    std::memcpy(&out[9], &cnt_r, sizeof(float));
-                    std::memcpy(&out[10], &cnt_rest, sizeof(float));
-                    out[11] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                    const float cnt_rest = static_cast<float>(N - list - at_radius);
+                    uint32_t* meta = out + 2 * (list / per_word);
+                    meta[0] = static_cast<uint32_t>(radius);
+                    std::memcpy(&meta[1], &cnt_r, sizeof(float));
+                    std::memcpy(&meta[2], &cnt_rest, sizeof(float));
+                    meta[3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
                     if(radius >= 4) { ++usable; }
                 }
                 d.near_table = static_cast<const uint16_t*>(upload(nearest.data(), nearest.size() * sizeof(uint16_t)));

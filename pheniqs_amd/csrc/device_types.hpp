@@ -12,9 +12,15 @@ constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
 constexpr int EXACT_SINGLE_UNIQUE = 512;
-constexpr int NEAR_LIST = 16;             // barcodes the neighbour list kernel scores per read (pamld_near.hpp)
-constexpr int NEAR_RECORD_WORDS = 12;
-constexpr int NEAR_MAX_BARCODES = 1024; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
+// neighbour list kernel (pamld_near.hpp), by barcode length: flag bits per barcode in a plane word, barcodes scored per
+// read (c and the nearest to it; a whole number of plane words), words of a barcode's record
+constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }
+constexpr int near_list(int length) { return length <= 8 ? 16 : 15; }
+constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }      // 2 x list words + {radius, cnt_r, cnt_rest, index}, whole quads
+constexpr int NEAR_MIN_LENGTH = 5;
+constexpr int NEAR_MAX_LENGTH = 10;
+constexpr int NEAR_MAX_BARCODES = 1024;
+constexpr uint16_t NEAR_NO_BARCODE = 0xffffu; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
 
 // Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]
 // (TranscodingDecoder::count/pf_count, transcode.h:61-64).  Then per decoder, per barcode bin
@@ -98,12 +104,13 @@ struct DevDecoder {
     // barcodes share a word (even barcode in the low half); padded to whole blocks of 8 barcodes
     const uint32_t* barcode_packed2;
     const float* concentration_single;    // padded with zeros to whole blocks of 8 barcodes
-    // neighbour list kernel only (pamld_near.hpp; ACGT barcodes of 5 to 8 nt, uniform priors): near_table[key] = the
-    // barcode nearest to the word whose 2-bit codes are key (low code bits of positions 0..7 in bits 0..7, high code
-    // bits in bits 8..15; Hamming distance, lowest ordinal on ties), 4^8 entries; near_record[c] = NEAR_RECORD_WORDS
-    // words: the 16 barcodes {c, the 15 nearest to c} as 4 x {low plane word, high plane word} (byte b of a plane
-    // word = barcode 4 g + b, bit j = position j), then the radius (distance from c of the nearest barcode not listed,
-    // at most 5), the number of barcodes not listed at that distance and further away (two floats), and padding
+    // neighbour list kernel only (pamld_near.hpp; ACGT barcodes of 5 to 10 nt, uniform priors): near_table[key] = the
+    // barcode that the word whose 2-bit codes are key (low code bits of positions 0..L-1 in bits 0..L-1, high code
+    // bits in bits L..2L-1) equals or is one mismatch away from (lowest ordinal on ties), NEAR_NO_BARCODE for every
+    // other word; 4^L entries.  near_record[c] = near_record_words(L) words: the near_list(L) barcodes {c, the nearest
+    // to c} as {low plane word, high plane word} pairs (near_field_bits(L) bits per barcode, bit j = position j),
+    // then the radius (distance from c of the nearest barcode not listed, at most 5), the number of barcodes not
+    // listed at that distance and further away (two floats), barcode_index[c], and padding
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
@@ -165,14 +172,14 @@ struct StageArgs {
     // whole classification
     int32_t defer_counters;
     // The neighbour list tier (pamld_near.hpp) hands the reads it defers to the product form kernel WITH their inputs:
-    // beside entry e < carry_stride of workgroup g's worklist segment, plane p (0, 1 the code words, 2, 3 the quality
-    // words, 4 the carried state: flag byte or status word) holds its word at carry[(g * 5 + p) * carry_stride + e],
+    // beside entry e < carry_stride of workgroup g's worklist segment, plane p (0..2 the code words, 3..5 the quality
+    // words, 6 the carried state: flag byte or status word) holds its word at carry[(g * 7 + p) * carry_stride + e],
     // so that the consumer reads whole lines instead of gathering 8 byte rows from HBM.  Entries past carry_stride
     // (a quarter of the segment, a multiple of 512) are gathered as before.
     uint32_t* carry;
     int32_t carry_stride;
 };
-constexpr int CARRY_PLANES = 5;
+constexpr int CARRY_PLANES = 7;
 
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
 enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_PAMLD_NEAR = 6, KERNEL_KINDS = 7 };

@@ -178,8 +178,11 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             i = static_cast<int64_t>(segment[entry]);
             is_carried = (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
             if(is_carried) {
+                constexpr int CARRIED_WORDS = (L + 3) / 4;
 #pragma unroll
-                for(int plane = 0; plane < CARRY_PLANES; ++plane) { carried[plane] = carry[plane * carry_stride + entry]; }
+                for(int plane = 0; plane < CARRY_PLANES; ++plane) {
+                    if(plane < CARRIED_WORDS || (plane >= 3 && plane < 3 + CARRIED_WORDS) || plane == 6) { carried[plane] = carry[plane * carry_stride + entry]; }
+                }
             }
             __syncthreads();                   // every entry of this tile is read before any wave compacts into it
         }
@@ -190,10 +193,10 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             uint32_t code_words[W];
             uint32_t quality_words[W];
             if(CONSUMER && is_carried) {
-                if(args.first_stage) { r.qcfail = (carried[4] & 1u) != 0; r.channel = 0; }
-                else { r.qcfail = (carried[4] >> 31) != 0; r.channel = static_cast<int32_t>(carried[4] & 0x7fffffffu); }
-                code_words[0] = carried[0]; quality_words[0] = carried[2];
-                if(W > 1) { code_words[W > 1 ? 1 : 0] = carried[1]; quality_words[W > 1 ? 1 : 0] = carried[3]; }
+                if(args.first_stage) { r.qcfail = (carried[6] & 1u) != 0; r.channel = 0; }
+                else { r.qcfail = (carried[6] >> 31) != 0; r.channel = static_cast<int32_t>(carried[6] & 0x7fffffffu); }
+#pragma unroll
+                for(int w = 0; w < W && w < 3; ++w) { code_words[w] = carried[w]; quality_words[w] = carried[3 + w]; }
             } else {
                 r = load_read_state(args, i);
                 const uint32_t* code_row = reinterpret_cast<const uint32_t*>(args.base + i * (4 * W));
@@ -520,7 +523,7 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            if constexpr(LO >= 5 && LO <= 8) {
+            if constexpr(LO >= NEAR_MIN_LENGTH && LO <= NEAR_MAX_LENGTH) {
                 // the lengths the neighbour list kernel (pamld_near.hpp) takes, uniform priors: this kernel behind it
                 if(args.worklist_role == 2) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
             }

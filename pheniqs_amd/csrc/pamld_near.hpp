@@ -7,12 +7,13 @@
 // nothing: a read sits on or next to ONE barcode c, and a barcode b' that differs from c in d positions mismatches a
 // read at distance k from c in at least d - k positions, each of which costs it a factor rho = P(mismatch) / P(match)
 // of that position's quality.  So per read this kernel
-//   * names c with one lookup: the read's 2-bit codes are a key into a host built table of the nearest barcode
-//     (Hamming distance, first on ties) of every possible word — 4^L entries of 16 bits, in global memory, the few
-//     hundred words real reads carry stay in L1/L2;
-//   * scores c and the LIST - 1 = 15 barcodes nearest to c with the per read product tables of pamld_lut.hpp (two
-//     16 entry tables of single precision products of 4 factors in LDS); the list of c — the bit sliced words of those
-//     16 barcodes, four barcodes per pair of plane words — is read per lane from LDS (48 bytes: three ds_read_b128);
+//   * names c with one lookup: the read's 2-bit codes are a key into a host built table (4^L entries of 16 bits, in
+//     global memory; the few thousand keys real reads carry stay in L1/L2) that holds, for every word at most ONE
+//     mismatch away from a barcode, that barcode — a read further away is not finished here anyway;
+//   * scores c and the 15 (14 for 9 and 10 nt) barcodes nearest to c with the per read product tables of
+//     pamld_lut.hpp (one 16 entry table of single precision products per group of 4 positions, in LDS); the list of
+//     c — the bit sliced words of those barcodes, four (three) barcodes per pair of plane words — is read per lane
+//     from LDS (three or four ds_read_b128);
 //   * BOUNDS every barcode it did not score: with r = the distance from c of the nearest one not listed (host: 4 or
 //     5 for sets like Illumina's), such a barcode mismatches the read in n >= r - k positions outside the k positions
 //     where the read differs from c, so its probability is at most the largest product the tables hold over n (or
@@ -42,30 +43,43 @@
 namespace phq {
 namespace near {
 
-constexpr int LIST = NEAR_LIST;                // barcodes scored per read: c and the 15 nearest to it
-constexpr int RECORD_WORDS = NEAR_RECORD_WORDS;    // per barcode: 4 x {low plane word, high plane word}, radius, cnt_r, cnt_rest, pad
-static_assert(LIST == 16 && RECORD_WORDS == 12, "the kernel reads a record as three quads");
-constexpr int THREADS = 512;
 constexpr int FACTOR_ROWS = 129;
 constexpr float LISTED_MAX = 5e-4f;            // scored barcodes other than c sum to at most this share of c's probability
 constexpr float X_MAX = 2e-3f;                 // (others + noise) / winner: single precision is enough below this
 constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
 constexpr float SLOP = 1.0f + 1e-5f;           // single precision rounding of the bound itself
 
-struct Layout {
-    static constexpr uint32_t TABLE_AT = 0;                                    // [wave][group][entry][lane] floats: 64 KiB
-    static constexpr uint32_t TABLE_BYTES = (THREADS / 64) * 2 * 16 * 64 * 4;
+// Shapes by barcode length.  5 .. 8 nt: two groups of 4 positions, 8 flag bits per barcode, four barcodes per plane
+// word, 16 listed, 512 lane workgroups (two per CU).  9 and 10 nt: three groups (the last one of 1 or 2 positions),
+// 10 flag bits per barcode, three per word, 15 listed, 256 lane workgroups.
+template <int L> struct Shape {
+    static_assert(L >= 5 && L <= 10, "two or three groups of 4 positions");
+    static constexpr int G = (L + 3) / 4;
+    static constexpr int FIELD = near_field_bits(L);
+    static constexpr int PER_WORD = 32 / FIELD;
+    static constexpr int LIST = near_list(L);
+    static constexpr int LIST_WORDS = LIST / PER_WORD;
+    static constexpr int RECORD_WORDS = near_record_words(L);
+    static constexpr int RECORD_QUADS = RECORD_WORDS / 4;
+    static constexpr int THREADS = G == 2 ? 512 : 256;
+    static constexpr int WAVES = THREADS / 64;
+    static constexpr uint32_t GROUP_BYTES = WAVES * 16u * 64u * 4u;           // one group's tables of the whole workgroup
+    static constexpr uint32_t TABLE_AT = 0;                                    // [group][wave][entry][lane] floats
+    static constexpr uint32_t TABLE_BYTES = G * GROUP_BYTES;
     static constexpr uint32_t FACTOR_AT = TABLE_AT + TABLE_BYTES;              // FACTOR_ROWS x {match, mismatch} floats
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 1040;
     static constexpr uint32_t RECORD_AT = DEFERRED_AT + 16;                    // n_barcode x RECORD_WORDS words
     __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) {
         return RECORD_AT + static_cast<uint32_t>(n_barcode) * RECORD_WORDS * 4u;
     }
+    __host__ __device__ static constexpr int positions(int g) { return L - 4 * g >= 4 ? 4 : L - 4 * g; }
+    static_assert(LIST % PER_WORD == 0 && RECORD_WORDS % 4 == 0 && RECORD_WORDS >= 2 * LIST_WORDS + 4, "record layout");
+    static_assert((G - 1) * GROUP_BYTES <= 65535u, "a group's table is reached through the instruction's offset field");
 };
 
-typedef __attribute__((address_space(3))) const float* LdsFloats;
 typedef uint32_t Quad __attribute__((ext_vector_type(4)));
 typedef float Pair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float* LdsFloats;
 typedef __attribute__((address_space(3))) const Quad* LdsQuads;
 typedef __attribute__((address_space(3))) const Pair* LdsPairs;
 
@@ -78,8 +92,14 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 // 1 the first stage with flag bytes, 2 a later stage (the status word).  A template parameter so that the loads of
 // the prefetch sit in straight line code: behind a branch the compiler can no longer count them and waits for all.
 template <int L, int STATE>
-__global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
-    static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
+__global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs args) {
+    typedef Shape<L> Layout;
+    constexpr int G = Layout::G;
+    constexpr int THREADS = Layout::THREADS;
+    constexpr int FIELD = Layout::FIELD;
+    constexpr int PER_WORD = Layout::PER_WORD;
+    constexpr int LIST_WORDS = Layout::LIST_WORDS;
+    constexpr int RECORD_WORDS = Layout::RECORD_WORDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::FACTOR_AT);
@@ -103,25 +123,28 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     const int64_t n = args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lane_const = ((threadIdx.x & 63u) << 2) | (wave << 13);          // everything of a table address but group and entry
+    const uint32_t lane_const = ((threadIdx.x & 63u) << 2) | (wave << 12);          // everything of a table address but group and entry
     const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
     const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
     const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);       // uniform priors
     const float noise_floor = static_cast<float>(d.random_barcode_probability) * SLOP;
     const double confidence_threshold = d.confidence_threshold;
-    constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);     // the bytes of positions 4 .. L - 1
+    const uint32_t n_barcode = static_cast<uint32_t>(d.n_barcode);
+    // the bytes of the positions a word holds (word w: positions 4 w .. 4 w + 3)
+    auto valid = [](int w) -> uint32_t { return L - 4 * w >= 4 ? 0xffffffffu : ((1u << (8 * (L - 4 * w))) - 1u); };
 
     // A tile's inputs are fetched one tile ahead — behind this tile's table lookup, so that waiting for the lookup does
     // not wait for them (vector memory operations complete in issue order) — through a scalar tile base and a 32-bit
-    // lane offset.  Lanes past the end of the batch recompute its last read and are kept from every store and counter.
-    struct Inputs { uint32_t code0, code1, quality0, quality1, state; };
+    // lane offset.  Lanes past the end of the batch recompute its last read and are kept from every counter.
+    struct Inputs { uint32_t code[G]; uint32_t quality[G]; uint32_t state; };
     auto fetch = [&](int64_t tile, Inputs& in) {
         const int64_t first = tile * THREADS;
         const uint32_t last = static_cast<uint32_t>(min(static_cast<int64_t>(THREADS), n - first)) - 1u;
         const uint32_t at = min(threadIdx.x, last);
-        const uint2 code = *reinterpret_cast<const uint2*>(args.base + first * 8 + at * 8u);
-        const uint2 quality = *reinterpret_cast<const uint2*>(args.quality + first * 8 + at * 8u);
-        in.code0 = code.x; in.code1 = code.y; in.quality0 = quality.x; in.quality1 = quality.y;
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + first * (4 * G) + at * (4u * G));
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + first * (4 * G) + at * (4u * G));
+#pragma unroll
+        for(int w = 0; w < G; ++w) { in.code[w] = code_row[w]; in.quality[w] = quality_row[w]; }
         if(STATE == 1) { in.state = static_cast<uint32_t>(args.input_flag[first + at]); }      // transcode.h:207-211
         else if(STATE == 2) { in.state = args.word[first + at]; }
         else { in.state = 0; }
@@ -131,7 +154,7 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
     __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the loop is entered with nothing in flight, so that its first wait is the one of its back edge
     uint32_t pending_slot = 0xffffffffu;       // this lane's worklist entry of the previous tile, not stored yet
     uint32_t pending_read = 0;
-    uint32_t pending_input[CARRY_PLANES] = {0, 0, 0, 0, 0};
+    uint32_t pending_input[CARRY_PLANES] = {0, 0, 0, 0, 0, 0, 0};
     const uint32_t carry_stride = args.carry ? static_cast<uint32_t>(args.carry_stride) : 0u;
     uint32_t* const carry = args.carry + static_cast<int64_t>(blockIdx.x) * CARRY_PLANES * carry_stride;
     const int hq_threshold = d.high_quality_distance_threshold;
@@ -145,50 +168,63 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
         ReadState r;
         if(STATE != 2) { r.qcfail = (in.state & 1u) != 0; r.channel = 0; }
         else { r.qcfail = (in.state >> 31) != 0; r.channel = static_cast<int32_t>(in.state & 0x7fffffffu); }
-        const uint32_t code0 = in.code0, code1 = in.code1, quality0 = in.quality0, quality1 = in.quality1;
         // BAM codes, four positions per word.  A, C, G or T = exactly one bit of the nibble (iupac.h:51-56); a read
         // with anything else goes to the next tier.
-        const uint32_t x0 = code0 & 0x0f0f0f0fu;
-        const uint32_t x1 = code1 & (0x0f0f0f0fu & VALID1);
-        const uint32_t z0 = x0 & ((x0 | 0x80808080u) - 0x01010101u);
-        const uint32_t z1 = x1 & ((x1 | 0x80808080u) - 0x01010101u);
-        const uint32_t strict0 = (x0 + 0x7f7f7f7fu) & ~(z0 + 0x7f7f7f7fu) & 0x80808080u;
-        const uint32_t strict1 = (x1 + 0x7f7f7f7fu) & ~(z1 + 0x7f7f7f7fu) & 0x80808080u;
-        const bool all_strict = ((strict0 ^ 0x80808080u) | (strict1 ^ (0x80808080u & VALID1))) == 0;
+        uint32_t x[G];
+        uint32_t q7[G];
+        uint32_t not_strict = 0;
+#pragma unroll
+        for(int w = 0; w < G; ++w) {
+            x[w] = in.code[w] & (0x0f0f0f0fu & valid(w));
+            q7[w] = in.quality[w] & (0x7f7f7f7fu & valid(w));                  // the table has 128 rows
+            const uint32_t z = x[w] & ((x[w] | 0x80808080u) - 0x01010101u);
+            const uint32_t strict = (x[w] + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+            not_strict |= strict ^ (0x80808080u & valid(w));
+        }
+        const bool all_strict = not_strict == 0;
         // 2-bit codes A, C, G, T -> 0..3: the low code bit is bit 1 | bit 3 of the nibble, the high one bit 2 | bit 3.
-        // Bits 0 / 4 of the bytes of word 0 / word 1 gathered into one byte: bit j = position j.
+        // Bits 0 / 4 of the bytes of two flag planes gathered into one byte; bit j of low / high = position j.
         auto gather = [](uint32_t planes) {            // bits 8 j and 8 j + 4 -> bits j and 4 + j
             const uint32_t t = planes | (planes >> 7);
             return (t | (t >> 14)) & 0xffu;
         };
-        const uint32_t low8 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x1 << 3) | (x1 << 1)) & 0x10101010u));
-        const uint32_t high8 = gather((((x0 >> 2) | (x0 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
-        const uint32_t key = low8 | (high8 << 8);
+        uint32_t low = gather((((x[0] >> 1) | (x[0] >> 3)) & 0x01010101u) | (((x[1] << 3) | (x[1] << 1)) & 0x10101010u));
+        uint32_t high = gather((((x[0] >> 2) | (x[0] >> 3)) & 0x01010101u) | (((x[1] << 2) | (x[1] << 1)) & 0x10101010u));
+        if(G == 3) {
+            const uint32_t both = gather((((x[G - 1] >> 1) | (x[G - 1] >> 3)) & 0x01010101u) | (((x[G - 1] << 2) | (x[G - 1] << 1)) & 0x10101010u));
+            low |= (both & 0xfu) << 8;
+            high |= (both >> 4) << 8;
+        }
+        const uint32_t key = low | (high << L);
         if(pending_slot != 0xffffffffu) {                                         // the previous tile's deferred reads
             segment[pending_slot] = pending_read;
             if(pending_slot < carry_stride) {
 #pragma unroll
-                for(int plane = 0; plane < CARRY_PLANES; ++plane) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+                for(int plane = 0; plane < CARRY_PLANES; ++plane) {
+                    if(plane < G || (plane >= 3 && plane < 3 + G) || plane == 6) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+                }
             }
         }
-        const uint32_t c = nearest[key];                                          // the barcode nearest to this word
+        const uint32_t looked_up = nearest[key];                                  // the barcode this word is (next to), if any
         fetch(min(tile + gridDim.x, tiles - 1), next);                           // past the last tile: that tile again, unused
-        const uint32_t observed_low = low8 * 0x01010101u;                        // the read against four barcodes at a time
-        const uint32_t observed_high = high8 * 0x01010101u;
-        const uint32_t q0 = quality0 & 0x7f7f7f7fu;                              // the table has 128 rows
-        const uint32_t q1 = quality1 & (0x7f7f7f7fu & VALID1);
+        const bool known = looked_up < n_barcode;
+        const uint32_t c = known ? looked_up : 0u;
+        constexpr uint32_t REPLICATE = PER_WORD == 4 ? 0x01010101u : 0x00100401u;  // the read against PER_WORD barcodes at a time
+        const uint32_t observed_low = low * REPLICATE;
+        const uint32_t observed_high = high * REPLICATE;
         // quality >= high quality threshold (thresholds of 0..128), bit 7 of each byte -> bit j = position j
-        const uint32_t high_quality = gather(((((q0 + high_quality_addend) | quality0) & 0x80808080u) >> 7) |
-                                             ((((q1 + high_quality_addend) | quality1) & (0x80808080u & VALID1)) >> 3));
+        uint32_t high_quality = gather(((((q7[0] + high_quality_addend) | in.quality[0]) & 0x80808080u) >> 7) |
+                                       ((((q7[1] + high_quality_addend) | in.quality[1]) & (0x80808080u & valid(1))) >> 3));
+        if(G == 3) { high_quality |= (gather((((q7[G - 1] + high_quality_addend) | in.quality[G - 1]) & (0x80808080u & valid(G - 1))) >> 7) & 0xfu) << 8; }
 
         // per position {P(match), P(mismatch)} of its quality, single precision
-        float fm[8];
-        float fe[8];
+        float fm[4 * G];
+        float fe[4 * G];
         {
             const uint32_t factor_base = Layout::FACTOR_AT;
 #pragma unroll
             for(int j = 0; j < L; ++j) {
-                const uint32_t q = j < 4 ? q0 : q1;
+                const uint32_t q = q7[j >> 2];
                 const int byte = j & 3;
                 const uint32_t shifted = byte == 0 ? (q << 3) : (q >> (8 * byte - 3));
                 const uint32_t address = and_or(shifted, 0x3f8u, factor_base);
@@ -197,86 +233,122 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
                 fe[j] = pair.y;
             }
 #pragma unroll
-            for(int j = L; j < 8; ++j) { fm[j] = 1.0f; fe[j] = 1.0f; }
+            for(int j = L; j < 4 * G; ++j) { fm[j] = 1.0f; fe[j] = 1.0f; }
         }
         // tables: entry m of group g = product over the group's positions of (bit ? mismatch : match); and per group the
-        // largest entry by number of mismatches, made monotone: ge[a] = the largest entry with a OR MORE mismatches
-        float ge[2][5];
-        float all_match[2];
+        // largest entry by number of mismatches, made monotone: ge[g][a] = the largest entry with a OR MORE mismatches
+        // (none past the group's positions)
+        float ge[G][5];
+        float everything_matches = 1.0f;
 #pragma unroll
-        for(int g = 0; g < 2; ++g) {
-            const int base = 4 * g;
+        for(int g = 0; g < G; ++g) {
+            constexpr int base = 0;
+            const int p0 = 4 * g + base;
             float lo[4];
             float hi[4];
-            lo[0] = fm[base] * fm[base + 1]; lo[1] = fe[base] * fm[base + 1]; lo[2] = fm[base] * fe[base + 1]; lo[3] = fe[base] * fe[base + 1];
-            hi[0] = fm[base + 2] * fm[base + 3]; hi[1] = fe[base + 2] * fm[base + 3]; hi[2] = fm[base + 2] * fe[base + 3]; hi[3] = fe[base + 2] * fe[base + 3];
+            lo[0] = fm[p0] * fm[p0 + 1]; lo[1] = fe[p0] * fm[p0 + 1]; lo[2] = fm[p0] * fe[p0 + 1]; lo[3] = fe[p0] * fe[p0 + 1];
+            hi[0] = fm[p0 + 2] * fm[p0 + 3]; hi[1] = fe[p0 + 2] * fm[p0 + 3]; hi[2] = fm[p0 + 2] * fe[p0 + 3]; hi[3] = fe[p0 + 2] * fe[p0 + 3];
+            const int positions = Layout::positions(g);
+            const int entries = 1 << positions;
             float t[16];
+            float by_count[5] = {0, 0, 0, 0, 0};        // the largest entry with exactly a mismatches
 #pragma unroll
             for(int m = 0; m < 16; ++m) {
-                t[m] = lo[m & 3] * hi[m >> 2];
-                *reinterpret_cast<float*>(lds_raw + (lane_const | (static_cast<uint32_t>(g) << 12) | (static_cast<uint32_t>(m) << 8))) = t[m];
+                if(m < entries) {
+                    t[m] = positions <= 2 ? lo[m & 3] : lo[m & 3] * hi[m >> 2];
+                    *reinterpret_cast<float*>(lds_raw + Layout::TABLE_AT + static_cast<uint32_t>(g) * Layout::GROUP_BYTES + (lane_const | (static_cast<uint32_t>(m) << 8))) = t[m];
+                    const int a = __builtin_popcount(static_cast<unsigned>(m));
+                    by_count[a] = (m == (1 << a) - 1) ? t[m] : fmaxf(by_count[a], t[m]);      // the first entry of a count is 2^a - 1
+                }
             }
-            all_match[g] = t[0];
-            const float g1 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(t[1], t[2]), t[4]), t[8]);
-            const float g2 = fmaxf(fmaxf(fmaxf(t[3], t[5]), fmaxf(t[6], t[9])), fmaxf(t[10], t[12]));
-            const float g3 = fmaxf(fmaxf(t[7], t[11]), fmaxf(t[13], t[14]));
-            ge[g][4] = t[15];
-            ge[g][3] = fmaxf(g3, ge[g][4]);
-            ge[g][2] = fmaxf(g2, ge[g][3]);
-            ge[g][1] = fmaxf(g1, ge[g][2]);
-            ge[g][0] = fmaxf(t[0], ge[g][1]);
+            everything_matches = g == 0 ? t[0] : everything_matches * t[0];
+#pragma unroll
+            for(int a = 4; a >= 0; --a) {
+                ge[g][a] = a > positions ? 0.0f : a == positions ? by_count[a] : fmaxf(by_count[a], ge[g][a + 1 > 4 ? 4 : a + 1]);
+            }
         }
-        // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6
-        const float h3 = fmaxf(fmaxf(ge[0][0] * ge[1][3], ge[0][1] * ge[1][2]), fmaxf(ge[0][2] * ge[1][1], ge[0][3] * ge[1][0]));
-        const float h4 = fmaxf(fmaxf(fmaxf(ge[0][0] * ge[1][4], ge[0][1] * ge[1][3]), fmaxf(ge[0][2] * ge[1][2], ge[0][3] * ge[1][1])), ge[0][4] * ge[1][0]);
-        const float h5 = fmaxf(fmaxf(ge[0][1] * ge[1][4], ge[0][2] * ge[1][3]), fmaxf(ge[0][3] * ge[1][2], ge[0][4] * ge[1][1]));
-        const float h6 = fmaxf(fmaxf(ge[0][2] * ge[1][4], ge[0][3] * ge[1][3]), ge[0][4] * ge[1][2]);
+        // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6.  Two groups at a time.
+        float h[7] = {0, 0, 0, 0, 0, 0, 0};
+        {
+            float front[9];                        // groups 0 and 1 together, by number of mismatches
+#pragma unroll
+            for(int m = 0; m <= 8; ++m) {
+                front[m] = 0.0f;
+                bool any = false;
+#pragma unroll
+                for(int a = 0; a <= 4; ++a) {
+                    const int b = m - a;
+                    if(b >= 0 && b <= 4 && a <= Layout::positions(0) && b <= Layout::positions(1)) {
+                        const float product = ge[0][a] * ge[1][b];
+                        front[m] = any ? fmaxf(front[m], product) : product;
+                        any = true;
+                    }
+                }
+            }
+#pragma unroll
+            for(int count = 3; count <= 6; ++count) {
+                if(G == 2) { h[count] = front[count]; }
+                else {
+                    bool any = false;
+#pragma unroll
+                    for(int third = 0; third <= 4; ++third) {
+                        const int m = count - third;
+                        if(third <= Layout::positions(G - 1) && m >= 0 && m <= 8) {
+                            const float product = front[m] * ge[G - 1][third];
+                            h[count] = any ? fmaxf(h[count], product) : product;
+                            any = true;
+                        }
+                    }
+                }
+            }
+        }
 
-        // the list of c: 16 barcodes as 4 x {low plane word, high plane word}, then {radius, cnt_r, cnt_rest}
+        // the list of c: its barcodes as LIST_WORDS x {low plane word, high plane word}, then {radius, cnt_r, cnt_rest, index}
         const uint32_t record_at = Layout::RECORD_AT + c * (RECORD_WORDS * 4u);
-        const Quad list0 = *(LdsQuads)static_cast<uintptr_t>(record_at);
-        const Quad list1 = *(LdsQuads)static_cast<uintptr_t>(record_at + 16u);
-        const Quad meta = *(LdsQuads)static_cast<uintptr_t>(record_at + 32u);
-        const uint32_t low_words[4] = {list0.x, list0.z, list1.x, list1.z};
-        const uint32_t high_words[4] = {list0.y, list0.w, list1.y, list1.w};
+        Quad record[Layout::RECORD_QUADS];
+#pragma unroll
+        for(int quad = 0; quad < Layout::RECORD_QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(record_at + 16u * quad); }
+        auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
         float winner = 0;                        // P(r|c), single precision
-        float others = 0;                        // the other 15
+        float others = 0;                        // the other listed barcodes
         uint32_t mismatches = 0;                 // of c: bit j = position j
 #pragma unroll
-        for(int g4 = 0; g4 < 4; ++g4) {
-            // byte b of fields = the 8 mismatch flags of barcode 4 g4 + b: the low nibble indexes table 0, the high one table 1
-            const uint32_t fields = (observed_low ^ low_words[g4]) | (observed_high ^ high_words[g4]);
-            if(g4 == 0) { mismatches = fields & 0xffu; }
-            float p[4];
+        for(int w = 0; w < LIST_WORDS; ++w) {
+            // FIELD bits of `fields` per barcode: its mismatch flags, four per group
+            const uint32_t fields = (observed_low ^ record_word(2 * w)) | (observed_high ^ record_word(2 * w + 1));
+            if(w == 0) { mismatches = fields & ((1u << L) - 1u); }
+            float p[PER_WORD];
 #pragma unroll
-            for(int b = 0; b < 4; ++b) {
-                const int low_at = 8 * b;            // bit of the low nibble; the entry index belongs at bits 8..11
-                const uint32_t a0 = and_or(low_at < 8 ? (fields << (8 - low_at)) : (fields >> (low_at - 8)), 0xf00u, lane_const);
-                const int high_at = 8 * b + 4;
-                const uint32_t a1 = and_or(high_at < 8 ? (fields << (8 - high_at)) : (fields >> (high_at - 8)), 0xf00u, lane_const);
-                const float e0 = *(LdsFloats)static_cast<uintptr_t>(a0);
-                const float e1 = ((LdsFloats)static_cast<uintptr_t>(a1))[4096 / 4];
-                p[b] = e0 * e1;
+            for(int b = 0; b < PER_WORD; ++b) {
+#pragma unroll
+                for(int g = 0; g < G; ++g) {
+                    const int at_bit = FIELD * b + 4 * g;     // where the group's flags start; the entry index belongs at bits 8..
+                    const uint32_t mask = ((1u << Layout::positions(g)) - 1u) << 8;
+                    const uint32_t address = and_or(at_bit < 8 ? (fields << (8 - at_bit)) : (fields >> (at_bit - 8)), mask, lane_const);
+                    const float entry = ((LdsFloats)static_cast<uintptr_t>(address))[(Layout::TABLE_AT + g * Layout::GROUP_BYTES) / 4];
+                    p[b] = g == 0 ? entry : p[b] * entry;
+                }
             }
-            if(g4 == 0) {
-                winner = p[0];
-                others = (p[1] + p[2]) + p[3];
-            } else {
-                others += (p[0] + p[1]) + (p[2] + p[3]);
+            float sum = 0;
+#pragma unroll
+            for(int b = 0; b < PER_WORD; ++b) {
+                if(w == 0 && b == 0) { winner = p[0]; }
+                else { sum = (w == 0 && b == 1) ? p[b] : sum + p[b]; }
             }
+            others = w == 0 ? sum : others + sum;
         }
 
         // what was not scored: cnt_r barcodes at distance r from c, cnt_rest further away
-        const uint32_t radius = meta.x;
-        const float cnt_r = __uint_as_float(meta.y);
-        const float cnt_rest = __uint_as_float(meta.z);
+        const uint32_t radius = record_word(2 * LIST_WORDS);
+        const float cnt_r = __uint_as_float(record_word(2 * LIST_WORDS + 1));
+        const float cnt_rest = __uint_as_float(record_word(2 * LIST_WORDS + 2));
+        const uint32_t index = record_word(2 * LIST_WORDS + 3);                  // barcode_index[c]
         const int k = __popc(mismatches);
-        const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5; 4 otherwise (less: not listed here)
-        const float h_r = near5 ? h5 : h4;                                  // H[r]
-        const float h_up = near5 ? h6 : h5;                                 // H[r + 1]
-        const float h_down = near5 ? h4 : h3;                               // H[r - 1]
+        const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5; 4 otherwise (less: not finished here)
+        const float h_r = near5 ? h[5] : h[4];                              // H[r]
+        const float h_up = near5 ? h[6] : h[5];                             // H[r + 1]
+        const float h_down = near5 ? h[4] : h[3];                           // H[r - 1]
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-        const float everything_matches = all_match[0] * all_match[1];
         // k = 1: rho of the read's own mismatch position is winner / everything_matches; without that position
         // top_n <= min(top_n, top_{n+1} / rho), and the position itself costs at most max(rho, 1)
         const float inverse_rho = everything_matches * inverse_winner;
@@ -287,31 +359,30 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
         const float x_listed = others * inverse_winner;
         const float x_rest = rest * inverse_winner;
         const float x_low = x_listed + noise_over_prior * inverse_winner;
-        const float x = x_low + 0.5f * x_rest;
-        const float y = x * __builtin_amdgcn_rcpf(1.0f + x);              // 1 - posterior
-        double confidence = 1.0 - static_cast<double>(y);                  // pamld.cpp:92
+        const float x_mid = x_low + 0.5f * x_rest;
+        const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);            // 1 - posterior
+        const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
-        const bool finished = all_strict && k <= 1 && radius >= 4u && winner > noise_floor &&
+        const bool finished = all_strict && known && k <= 1 && radius >= 4u && winner > noise_floor &&
                               x_listed <= LISTED_MAX && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
                               fabs(confidence_margin) > 2e-9;
         const bool defer = !finished;
 
         // Outcome.  Every lane stores a record and a status word in straight line code — the real ones when the read is
-        // finished, the placeholder the next tier overwrites when it is not; a lane past the end of the batch stores its
-        // (last) read's again — so that the compiler can count these two stores at the wait for the prefetched inputs.
-        const uint32_t index = meta.w;                                              // barcode_index[c]
+        // finished; a deferred read's record is whatever was computed (the next tier writes it again), its status word
+        // the state it came with; a lane past the end of the batch stores its (last) read's again — so that the compiler
+        // can count these two stores at the wait for the prefetched inputs.
         const uint32_t hq_distance = static_cast<uint32_t>(__popc(mismatches & high_quality));
         const bool confident = confidence_margin > 0;                               // pamld.cpp:99
         const bool qcfail = r.qcfail || !confident || (hq_threshold > 0 && static_cast<int>(hq_distance) >= hq_threshold);
         const bool qcfail_out = finished ? qcfail : r.qcfail;
         {
             typedef uint32_t vector4 __attribute__((ext_vector_type(4)));
-            const uint32_t detail = static_cast<uint32_t>(k) | (hq_distance << 8) | ((confident ? STATUS_PASS : STATUS_LOW_CONFIDENCE) << 16);
             vector4 out;
-            out.x = finished ? index : 0u;
-            out.y = (finished ? detail : (static_cast<uint32_t>(STATUS_UNCLASSIFIED) << 16)) | (qcfail_out ? 1u << 24 : 0u);
-            out.z = finished ? static_cast<uint32_t>(__double2loint(confidence)) : 0u;
-            out.w = finished ? static_cast<uint32_t>(__double2hiint(confidence)) : 0u;
+            out.x = index;
+            out.y = static_cast<uint32_t>(k) | (hq_distance << 8) | ((confident ? STATUS_PASS : STATUS_LOW_CONFIDENCE) << 16) | (qcfail_out ? 1u << 24 : 0u);
+            out.z = static_cast<uint32_t>(__double2loint(confidence));
+            out.w = static_cast<uint32_t>(__double2hiint(confidence));
             __builtin_nontemporal_store(out, reinterpret_cast<vector4*>(reinterpret_cast<char*>(args.result) + first * 16 + at * 16u));
             const uint32_t channel = (finished && multiplexing) ? index : static_cast<uint32_t>(r.channel);
             __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
@@ -353,7 +424,9 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
             if(active && defer) {
                 pending_slot = run + __popcll(deferred & ((1ull << lane) - 1ull));
                 pending_read = static_cast<uint32_t>(i);
-                pending_input[0] = code0; pending_input[1] = code1; pending_input[2] = quality0; pending_input[3] = quality1; pending_input[4] = in.state;
+#pragma unroll
+                for(int w = 0; w < G; ++w) { pending_input[w] = in.code[w]; pending_input[3 + w] = in.quality[w]; }
+                pending_input[6] = in.state;
             }
         }
         count_outgoing(args, histogram, active && !defer, r);
@@ -362,7 +435,9 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
         segment[pending_slot] = pending_read;
         if(pending_slot < carry_stride) {
 #pragma unroll
-            for(int plane = 0; plane < CARRY_PLANES; ++plane) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+            for(int plane = 0; plane < CARRY_PLANES; ++plane) {
+                if(plane < G || (plane >= 3 && plane < 3 + G) || plane == 6) { carry[plane * carry_stride + pending_slot] = pending_input[plane]; }
+            }
         }
     }
     __syncthreads();
@@ -372,10 +447,10 @@ __global__ __launch_bounds__(THREADS) void pamld_near_kernel(StageArgs args) {
 
 template <int L, int STATE>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t lds_bytes = Layout::histogram_at(n_barcode) + histogram_bytes;
+    const size_t lds_bytes = Shape<L>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
     if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_near_kernel<L, STATE>), grid, dim3(THREADS), lds_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_near_kernel<L, STATE>), grid, dim3(Shape<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
