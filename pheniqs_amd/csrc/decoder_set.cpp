@@ -386,6 +386,74 @@ void DecoderSet::build_device_images() {
                 d.near_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * usable >= N ? 1 : 0;                  // a denser set leaves the kernel nothing to finish
             }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
+               d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
+               c.barcode_length[0] >= 4 && c.barcode_length[0] <= NEAR_MAX_LENGTH && c.barcode_length[1] >= 4 && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
+                // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most one mismatch from
+                // one of its words — which must be all different in both segments — and per barcode its code bits and
+                // the distance to the nearest other barcode
+                const int32_t L = c.nucleotide_cardinality;
+                const int32_t N = d.n_barcode;
+                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);
+                for(int32_t b = 0; b < N; ++b) {
+                    for(int32_t j = 0; j < L; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
+                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
+                    }
+                }
+                bool distinct = true;
+                std::vector<std::vector<uint16_t>> table(2);
+                for(int32_t s = 0; s < 2 && distinct; ++s) {
+                    const int32_t start = c.segment_offset[static_cast<size_t>(s)];
+                    const int32_t length = c.barcode_length[static_cast<size_t>(s)];
+                    const uint32_t mask = (1u << length) - 1u;
+                    std::vector<uint16_t>& nearest = table[static_cast<size_t>(s)];
+                    nearest.assign(static_cast<size_t>(1) << (2 * length), NEAR_NO_BARCODE);
+                    std::vector<uint32_t> word_low(static_cast<size_t>(N)), word_high(static_cast<size_t>(N));
+                    for(int32_t b = 0; b < N; ++b) {
+                        word_low[static_cast<size_t>(b)] = (low[static_cast<size_t>(b)] >> start) & mask;
+                        word_high[static_cast<size_t>(b)] = (high[static_cast<size_t>(b)] >> start) & mask;
+                        uint16_t& exact = nearest[word_low[static_cast<size_t>(b)] | (word_high[static_cast<size_t>(b)] << length)];
+                        if(exact != NEAR_NO_BARCODE) { distinct = false; break; }                 // two barcodes share this segment word
+                        exact = static_cast<uint16_t>(b);
+                    }
+                    for(int32_t b = N - 1; b >= 0 && distinct; --b) {                             // the lowest ordinal last: it wins a shared neighbour
+                        for(int32_t j = 0; j < length; ++j) {
+                            for(uint32_t other = 0; other < 4; ++other) {
+                                const uint32_t l = (word_low[static_cast<size_t>(b)] & ~(1u << j)) | ((other & 1u) << j);
+                                const uint32_t h = (word_high[static_cast<size_t>(b)] & ~(1u << j)) | ((other >> 1) << j);
+                                uint16_t& slot = nearest[l | (h << length)];
+                                const bool taken_exactly = slot != NEAR_NO_BARCODE && word_low[slot] == l && word_high[slot] == h;
+                                if(!taken_exactly) { slot = static_cast<uint16_t>(b); }
+                            }
+                        }
+                    }
+                }
+                if(distinct) {
+                    std::vector<uint32_t> record(static_cast<size_t>(N) * 4, 0u);
+                    int32_t usable = 0;
+                    for(int32_t b = 0; b < N; ++b) {
+                        int radius = 31;
+                        for(int32_t o = 0; o < N; ++o) {
+                            if(o != b) { radius = std::min(radius, __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]))); }
+                        }
+                        record[static_cast<size_t>(b) * 4] = low[static_cast<size_t>(b)];
+                        record[static_cast<size_t>(b) * 4 + 1] = high[static_cast<size_t>(b)];
+                        record[static_cast<size_t>(b) * 4 + 2] = static_cast<uint32_t>(radius);
+                        record[static_cast<size_t>(b) * 4 + 3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                        if(radius >= 6) { ++usable; }
+                    }
+                    for(int32_t s = 0; s < 2; ++s) {
+                        d.pair_table[s] = static_cast<const uint16_t*>(upload(table[static_cast<size_t>(s)].data(), table[static_cast<size_t>(s)].size() * sizeof(uint16_t)));
+                        d.pair_start[s] = c.segment_offset[static_cast<size_t>(s)];
+                        d.pair_length[s] = c.barcode_length[static_cast<size_t>(s)];
+                    }
+                    d.pair_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                    d.pair_ready = 2 * usable >= N ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
+                }
+            }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {
                 // two words of bit-sliced 2-bit bases per barcode for the long barcode product form (pamld_wide.hpp)
                 const int32_t padded = (d.n_barcode + 7) / 8 * 8;

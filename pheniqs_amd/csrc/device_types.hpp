@@ -114,6 +114,15 @@ struct DevDecoder {
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
+    // paired barcode kernel only (pamld_pair.hpp; two segments of up to 10 nt whose words are all different, uniform
+    // priors): pair_table[s] = the table above for the words of segment s (key over the segment's positions, entry =
+    // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance
+    // to the nearest other barcode (at most 31), barcode_index[c]}
+    const uint16_t* pair_table[2];
+    const uint32_t* pair_record;
+    int32_t pair_start[2];
+    int32_t pair_length[2];
+    int32_t pair_ready;
     // MDD exact match (mdd.cpp:43-46): open addressing hash of the ACGT barcodes; slot = {key low, key high,
     // ordinal + 1 (0 = empty), barcode index}, key = 2 bits per base, position j at bits 2j
     const uint32_t* exact_table;

@@ -176,9 +176,9 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         if(CONSUMER) {
             const int64_t entry = i;
             i = static_cast<int64_t>(segment[entry]);
-            is_carried = (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
+            is_carried = (L + 3) / 4 <= 3 && (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
             if(is_carried) {
-                constexpr int CARRIED_WORDS = (L + 3) / 4;
+                constexpr int CARRIED_WORDS = (L + 3) / 4 <= 3 ? (L + 3) / 4 : 0;        // rows of four words are gathered (no carry planes for them)
 #pragma unroll
                 for(int plane = 0; plane < CARRY_PLANES; ++plane) {
                     if(plane < CARRIED_WORDS || (plane >= 3 && plane < 3 + CARRIED_WORDS) || plane == 6) { carried[plane] = carry[plane * carry_stride + entry]; }
@@ -523,10 +523,8 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            if constexpr(LO >= NEAR_MIN_LENGTH && LO <= NEAR_MAX_LENGTH) {
-                // the lengths the neighbour list kernel (pamld_near.hpp) takes, uniform priors: this kernel behind it
-                if(args.worklist_role == 2) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
-            }
+            // behind the neighbour list kernels (pamld_near.hpp, pamld_pair.hpp; uniform priors): as a consumer of their lists
+            if(args.worklist_role == 2) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
             return host_decoder.uniform_prior ? launch_one<LO, true, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)
                                               : launch_one<LO, false, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
         }

@@ -1,0 +1,26 @@
+// Paired barcode tier of the PAMLD path (pamld_pair.hpp): two segments of up to 10 nt, uniform priors, one barcode scored.
+#include "pamld_pair.hpp"
+
+namespace phq {
+
+bool pamld_pair_supports(const DevDecoder& host_decoder) {
+    const int words = host_decoder.plane_stride / 4;
+    return host_decoder.algorithm == 1 && host_decoder.pair_ready != 0 && host_decoder.uniform_prior != 0 && host_decoder.use_lds_histogram != 0 &&
+           words >= 2 && words <= 8 && host_decoder.nucleotide_cardinality <= 32 &&
+           (pamld_lut_supports(host_decoder) || pamld_wide_supports(host_decoder));
+}
+
+int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.plane_stride / 4) {
+        case 2: return pair::launch_one<2>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 3: return pair::launch_one<3>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 4: return pair::launch_one<4>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 5: return pair::launch_one<5>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 6: return pair::launch_one<6>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 7: return pair::launch_one<7>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 8: return pair::launch_one<8>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+}  // namespace phq

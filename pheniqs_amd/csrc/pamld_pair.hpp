@@ -1,0 +1,277 @@
+// K0p (paired barcodes): PamlDecoder<T>::classify for codecs whose barcodes are PAIRS of words that do not form every
+// combination (unique dual indexes, sci-RNA-seq ligation + RT pairs): two segments of up to 10 nt, up to 32 nt together.
+//
+//   reference pamld.cpp:37-123   posterior over all barcodes, noise / confidence / high quality filters
+//   reference barcode.h:131-164  P(r|b) = pow(base, sum of Phred costs), distance, high quality distance
+//
+// Two barcodes of such a codec differ in most of their ~20 positions (the host finds, per barcode c, the distance r(c)
+// to the nearest other one: 8 or more for sets like these), so a read that sits on or next to c leaves every other
+// barcode at least n = r(c) - k mismatches away, k = the read's own mismatches against c.  The kernel therefore scores
+// ONE barcode per read and bounds all the others:
+//   * c by two table lookups, one per segment (the tables of pamld_near.hpp: the word at most one mismatch from a
+//     segment word, 4^length entries of 16 bits in global memory); both segments must name the same barcode;
+//   * P(r|c) and the all-match product A as single precision products of the per position factors, the factor picked by
+//     putting the position's mismatch flag into the LDS address (no select);
+//   * every other barcode is at most  A * 4^wild * rho20^a * rho30^b * rho36^c  where the n mismatches are charged to
+//     the positions in order of quality — those below Q20 for free, a of those below Q30, b below Q36, the rest c —
+//     `wild` counts the positions below Q4 (a mismatch there is MORE likely than a match, by at most 4), and all the
+//     counts come from byte parallel compares.
+// A read is finished under the certificate of pamld_near.hpp (1e-9 in the posterior); everything else — a third
+// mismatch, a base outside ACGT, many low quality positions, noise — goes to the product form kernel (pamld_wide.hpp
+// for 17 to 32 nt, pamld_lut.hpp up to 16) as a consumer of this workgroup's worklist segment.
+// No per read tables: 12 KiB of LDS per workgroup, eight waves per SIMD.
+#pragma once
+
+#include "kernel_common.hpp"
+
+namespace phq {
+namespace pair {
+
+constexpr int THREADS = 256;
+constexpr int FACTOR_ROWS = 129;
+constexpr float X_MAX = 2e-3f;                 // noise / winner: single precision is enough below this (pamld_near.hpp)
+constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
+constexpr float SLOP = 1.0f + 1e-5f;
+// The bound sorts the positions by quality into four classes; n mismatches are charged to the cheapest classes first:
+// below Q20 for free, then rho(Q20) each for those below Q30, rho(Q30) below Q36, rho(Q36) for the rest
+// (rho = P(mismatch) / P(match) falls with the quality; the logarithms are rounded towards zero).
+constexpr int MARK[3] = {20, 30, 36};
+constexpr float LOG2_RHO[3] = {-6.6293f, -9.9643f, -11.9584f};
+constexpr int WILD_QUALITY = 4;                // below it P(mismatch) > P(match), by at most 4 (Q1: 3.86)
+
+struct Layout {
+    static constexpr uint32_t FACTOR_AT = 0;                                   // FACTOR_ROWS x {match, mismatch} floats
+    static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 1040;
+    static constexpr uint32_t RECORD_AT = DEFERRED_AT + 16;                    // n_barcode x {low, high, radius, index}
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return RECORD_AT + static_cast<uint32_t>(n_barcode) * 16u; }
+};
+
+typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const float* LdsFloats;
+typedef __attribute__((address_space(3))) const Quad* LdsQuads;
+
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, mask, c, 0xEA); }
+
+// G = words of the plane row (4 positions each); STATE as in pamld_near.hpp
+template <int G, int STATE>
+__global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
+    float* const factor = reinterpret_cast<float*>(lds_raw + Layout::FACTOR_AT);           // [row][0 match | 1 mismatch]
+    uint32_t& deferred_total = *reinterpret_cast<uint32_t*>(lds_raw + Layout::DEFERRED_AT);
+    uint32_t* const records = reinterpret_cast<uint32_t*>(lds_raw + Layout::RECORD_AT);
+    DecoderRef d = *constant_cast(args.decoder);
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::histogram_at(d.n_barcode));
+
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+        factor[2 * i] = static_cast<float>(i < 128 ? d.match_probability[i] : d.uniform_probability);
+        factor[2 * i + 1] = static_cast<float>(i < 128 ? d.mismatch_probability[i] : d.uniform_probability);
+    }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    for(int w = threadIdx.x; w < d.n_barcode * 4; w += THREADS) { records[w] = d.pair_record[w]; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const uint16_t* const nearest0 = d.pair_table[0];
+    const uint16_t* const nearest1 = d.pair_table[1];
+    const uint32_t start0 = static_cast<uint32_t>(d.pair_start[0]), start1 = static_cast<uint32_t>(d.pair_start[1]);
+    const uint32_t length0 = static_cast<uint32_t>(d.pair_length[0]), length1 = static_cast<uint32_t>(d.pair_length[1]);
+    const uint32_t mask0 = (1u << length0) - 1u, mask1 = (1u << length1) - 1u;
+    const int L = d.nucleotide_cardinality;
+    const uint32_t full_mask = L >= 32 ? 0xffffffffu : ((1u << L) - 1u);
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + THREADS - 1) / THREADS;
+    const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
+    const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
+    const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);       // uniform priors
+    const float noise_floor = static_cast<float>(d.random_barcode_probability) * SLOP;
+    const double confidence_threshold = d.confidence_threshold;
+    const uint32_t n_barcode = static_cast<uint32_t>(d.n_barcode);
+    const float others_count = static_cast<float>(d.n_barcode - 1);
+    // the bytes of the positions a word holds (word w: positions 4 w .. 4 w + 3)
+    uint32_t valid[G];
+#pragma unroll
+    for(int w = 0; w < G; ++w) { valid[w] = L - 4 * w >= 4 ? 0xffffffffu : (L - 4 * w <= 0 ? 0u : ((1u << (8 * (L - 4 * w))) - 1u)); }
+
+    struct Inputs { uint32_t code[G]; uint32_t quality[G]; uint32_t state; };
+    auto fetch = [&](int64_t tile, Inputs& in) {
+        const int64_t first = tile * THREADS;
+        const uint32_t last = static_cast<uint32_t>(min(static_cast<int64_t>(THREADS), n - first)) - 1u;
+        const uint32_t at = min(threadIdx.x, last);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + first * (4 * G) + at * (4u * G));
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + first * (4 * G) + at * (4u * G));
+#pragma unroll
+        for(int w = 0; w < G; ++w) { in.code[w] = code_row[w]; in.quality[w] = quality_row[w]; }
+        if(STATE == 1) { in.state = static_cast<uint32_t>(args.input_flag[first + at]); }      // transcode.h:207-211
+        else if(STATE == 2) { in.state = args.word[first + at]; }
+        else { in.state = 0; }
+    };
+    Inputs next;
+    fetch(min(static_cast<int64_t>(blockIdx.x), tiles - 1), next);
+    __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0) before the loop (pamld_near.hpp)
+    uint32_t pending_slot = 0xffffffffu;
+    uint32_t pending_read = 0;
+    const int hq_threshold = d.high_quality_distance_threshold;
+    const bool multiplexing = d.multiplexing != 0;
+    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const Inputs in = next;
+        const int64_t first = tile * THREADS;
+        const bool active = first + threadIdx.x < n;
+        const uint32_t at = active ? threadIdx.x : static_cast<uint32_t>(n - 1 - first);
+        const int64_t i = first + at;
+        ReadState r;
+        if(STATE != 2) { r.qcfail = (in.state & 1u) != 0; r.channel = 0; }
+        else { r.qcfail = (in.state >> 31) != 0; r.channel = static_cast<int32_t>(in.state & 0x7fffffffu); }
+
+        auto gather = [](uint32_t planes) {            // bits 8 j and 8 j + 4 -> bits j and 4 + j
+            const uint32_t t = planes | (planes >> 7);
+            return (t | (t >> 14)) & 0xffu;
+        };
+        uint32_t q7[G];
+        uint32_t low = 0, high = 0, high_quality = 0;    // bit j = position j
+        uint32_t not_strict = 0;
+        uint32_t below[3] = {0, 0, 0};         // positions below Q20, Q30, Q36
+        uint32_t wild = 0;
+#pragma unroll
+        for(int w = 0; w < G; ++w) {
+            const uint32_t x = in.code[w] & (0x0f0f0f0fu & valid[w]);
+            q7[w] = in.quality[w] & (0x7f7f7f7fu & valid[w]);
+            // A, C, G or T = exactly one bit of the nibble (iupac.h:51-56)
+            const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
+            const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+            not_strict |= strict ^ (0x80808080u & valid[w]);
+            // 2-bit codes: the low code bit is bit 1 | bit 3 of the nibble, the high one bit 2 | bit 3
+            const uint32_t both = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
+            low |= (both & 0xfu) << (4 * w);
+            high |= (both >> 4) << (4 * w);
+            // quality >= high quality threshold; quality below the bound's two marks
+            const uint32_t is_high = ((q7[w] + high_quality_addend) | in.quality[w]) & (0x80808080u & valid[w]);
+            high_quality |= (gather(is_high >> 7) & 0xfu) << (4 * w);
+#pragma unroll
+            for(int m = 0; m < 3; ++m) { below[m] = __builtin_popcount(~(q7[w] + (128u - MARK[m]) * 0x01010101u) & (0x80808080u & valid[w])) + below[m]; }
+            wild = __builtin_popcount(~(q7[w] + (128u - WILD_QUALITY) * 0x01010101u) & (0x80808080u & valid[w])) + wild;
+        }
+        const bool all_strict = not_strict == 0;
+        const uint32_t key0 = ((low >> start0) & mask0) | (((high >> start0) & mask0) << length0);
+        const uint32_t key1 = ((low >> start1) & mask1) | (((high >> start1) & mask1) << length1);
+        if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }      // the previous tile's deferred reads
+        const uint32_t named0 = nearest0[key0];
+        const uint32_t named1 = nearest1[key1];
+        fetch(min(tile + gridDim.x, tiles - 1), next);
+        const bool known = named0 == named1 && named0 < n_barcode;
+        const uint32_t c = known ? named0 : 0u;
+        const Quad record = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * 16u);
+        const uint32_t mismatches = ((low ^ record.x) | (high ^ record.y)) & full_mask;
+        const int k = __popc(mismatches);
+
+        // P(r|c) and the all match product: the factor row of the position's quality, the mismatch flag in the address
+        float winner = 1.0f;
+        float everything_matches = 1.0f;
+#pragma unroll
+        for(int j = 0; j < 4 * G; ++j) {
+            const uint32_t q = q7[j >> 2];
+            const int byte = j & 3;
+            const uint32_t row = and_or(byte == 0 ? (q << 3) : (q >> (8 * byte - 3)), 0x3f8u, static_cast<uint32_t>(Layout::FACTOR_AT));
+            const uint32_t picked = and_or(j >= 2 ? (mismatches >> (j - 2)) : (mismatches << (2 - j)), 4u, row);
+            const float matching = *(LdsFloats)static_cast<uintptr_t>(row);
+            const float own = *(LdsFloats)static_cast<uintptr_t>(picked);
+            everything_matches = j == 0 ? matching : everything_matches * matching;
+            winner = j == 0 ? own : winner * own;
+        }
+
+        // every other barcode: at least n = r(c) - k mismatches outside the read's own
+        int needed = max(static_cast<int>(record.z) - k - static_cast<int>(below[0]), 0);
+        const int at20 = min(needed, static_cast<int>(below[1] - below[0]));
+        needed -= at20;
+        const int at30 = min(needed, static_cast<int>(below[2] - below[1]));
+        needed -= at30;
+        const float log2_bound = 2.0f * static_cast<float>(wild) + LOG2_RHO[0] * static_cast<float>(at20) + LOG2_RHO[1] * static_cast<float>(at30) + LOG2_RHO[2] * static_cast<float>(needed);
+        const float inverse_winner = __builtin_amdgcn_rcpf(winner);
+        const float x_rest = others_count * __builtin_amdgcn_exp2f(log2_bound) * everything_matches * inverse_winner * SLOP;
+        const float x_low = noise_over_prior * inverse_winner;
+        const float x_mid = x_low + 0.5f * x_rest;
+        const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);       // 1 - posterior
+        const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
+        const double confidence_margin = confidence - confidence_threshold;
+        const bool finished = all_strict && known && k <= 2 && winner > noise_floor && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
+                              fabs(confidence_margin) > 2e-9;
+        const bool defer = !finished;
+
+        // outcome: straight line stores (pamld_near.hpp)
+        const uint32_t index = record.w;                                            // barcode_index[c]
+        const uint32_t hq_distance = static_cast<uint32_t>(__popc(mismatches & high_quality));
+        const bool confident = confidence_margin > 0;                               // pamld.cpp:99
+        const bool qcfail = r.qcfail || !confident || (hq_threshold > 0 && static_cast<int>(hq_distance) >= hq_threshold);
+        const bool qcfail_out = finished ? qcfail : r.qcfail;
+        {
+            typedef uint32_t vector4 __attribute__((ext_vector_type(4)));
+            vector4 out;
+            out.x = index;
+            out.y = static_cast<uint32_t>(k) | (hq_distance << 8) | ((confident ? STATUS_PASS : STATUS_LOW_CONFIDENCE) << 16) | (qcfail_out ? 1u << 24 : 0u);
+            out.z = static_cast<uint32_t>(__double2loint(confidence));
+            out.w = static_cast<uint32_t>(__double2hiint(confidence));
+            __builtin_nontemporal_store(out, reinterpret_cast<vector4*>(reinterpret_cast<char*>(args.result) + first * 16 + at * 16u));
+            const uint32_t channel = (finished && multiplexing) ? index : static_cast<uint32_t>(r.channel);
+            __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
+        }
+        r.qcfail = qcfail_out;
+        if(finished && active) {
+            const uint32_t word = STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + (qcfail ? 0u : static_cast<uint32_t>(STAT_FIELDS));
+            uint32_t* const low_words = reinterpret_cast<uint32_t*>(histogram);      // a workgroup's counts and distances stay below 2^32
+            if(confident) {
+                if(!args.defer_counters) {
+                    atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
+                    if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }
+                    const double shifted = confidence + 1.0;                          // round(confidence * 2^52) in the mantissa (pamld_near.hpp)
+                    const uint32_t fixed_low = static_cast<uint32_t>(__double2loint(shifted));
+                    const uint32_t fixed_high = static_cast<uint32_t>(__double2hiint(shifted)) - 0x3ff00000u;
+                    atomicAdd(&histogram[word + FIELD_CONFIDENCE_LOW], static_cast<unsigned long long>(fixed_low & 0x3ffffffu));
+                    atomicAdd(&histogram[word + FIELD_CONFIDENCE_HIGH], static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
+                }
+            } else {
+                atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u);      // qc-fail half (pamld.cpp:104-106)
+                if(!args.defer_counters) {
+                    atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
+                    if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }
+                }
+            }
+        }
+        const unsigned long long deferred = __ballot(active && defer);
+        pending_slot = 0xffffffffu;
+        if(deferred) {
+            const int lane = threadIdx.x & 63;
+            uint32_t run = 0;
+            if(lane == 0) { run = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
+            run = __shfl(run, 0);
+            if(active && defer) {
+                pending_slot = run + __popcll(deferred & ((1ull << lane) - 1ull));
+                pending_read = static_cast<uint32_t>(i);
+            }
+        }
+        count_outgoing(args, histogram, active && !defer, r);
+    }
+    if(pending_slot != 0xffffffffu) { segment[pending_slot] = pending_read; }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+template <int G, int STATE>
+int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    const size_t lds_bytes = Layout::histogram_at(n_barcode) + histogram_bytes;
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_pair_kernel<G, STATE>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_pair_kernel<G, STATE>), grid, dim3(THREADS), lds_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <int G>
+int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if(!args.first_stage) { return launch_state<G, 2>(args, n_barcode, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<G, 1>(args, n_barcode, grid, histogram_bytes, stream)
+                           : launch_state<G, 0>(args, n_barcode, grid, histogram_bytes, stream);
+}
+
+}  // namespace pair
+}  // namespace phq

@@ -66,7 +66,9 @@ __host__ __device__ inline Layout layout_of(int groups, int threads, int padded_
 }
 
 // G = groups of 4 positions = words of the plane row (plane stride = 4 G bytes, zero filled past the barcode)
-template <int G>
+// CONSUMER: the kernel visits the reads an earlier tier (pamld_pair.hpp) left in this workgroup's worklist segment
+// instead of every read, and compacts what it defers itself back into the segment (pamld_lut.hpp).
+template <int G, bool CONSUMER>
 __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageArgs args) {
     constexpr int THREADS = Geometry<G>::THREADS;
     constexpr uint32_t GROUP_STEP = Geometry<G>::GROUP_STEP;
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
     uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
     const int L = d.nucleotide_cardinality;
     const bool uniform_prior = d.uniform_prior != 0;
-    const int64_t n = args.n_read;
+    const int64_t n = CONSUMER ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const uint32_t lane_low = (threadIdx.x & 63u) << 2;                       // byte 0 of an entry address
     const uint32_t lane_high_bytes = ((threadIdx.x >> 6) & 1u) * 0x01010101u;  // bit 0 of byte 1 of an entry address
@@ -122,9 +124,13 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
 #pragma unroll
     for(int j = 0; j < 4 * G; ++j) { if(j < L) { full_mask[j >> 4] |= 1u << low_bit(j); } }
 
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for(int64_t tile = CONSUMER ? 0 : blockIdx.x; tile < tiles; tile += CONSUMER ? 1 : gridDim.x) {
         const bool active = tile * THREADS + threadIdx.x < n;
-        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        if(CONSUMER) {
+            i = static_cast<int64_t>(segment[i]);
+            __syncthreads();                   // every entry of this tile is read before any wave compacts into it
+        }
         ReadState r = load_read_state(args, i);
         bool defer = false;
         {
@@ -366,14 +372,20 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
     histogram_flush(args, d, histogram);
 }
 
-template <int G>
-int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+template <int G, bool CONSUMER>
+int launch_role(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_wide_kernel<G>, prepared)) { return status; }
+    if(const int status = allow_large_lds(&pamld_wide_kernel<G, CONSUMER>, prepared)) { return status; }
     const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
     const size_t lds_bytes = layout_of(G, Geometry<G>::THREADS, padded).histogram_at + histogram_bytes;
-    hipLaunchKernelGGL((pamld_wide_kernel<G>), grid, dim3(Geometry<G>::THREADS), lds_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_wide_kernel<G, CONSUMER>), grid, dim3(Geometry<G>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
+}
+
+template <int G>
+int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    return args.worklist_role == 2 ? launch_role<G, true>(args, host_decoder, grid, histogram_bytes, stream)
+                                   : launch_role<G, false>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 }  // namespace wide
