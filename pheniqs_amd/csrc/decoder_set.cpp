@@ -162,6 +162,65 @@ void DecoderSet::set_mode(int32_t mode) {
     mode_ = mode;
 }
 
+// The tables of the neighbour list kernels (pamld_near.hpp) for N words of L nucleotides given as code bit planes (bit j =
+// position j): the word -> barcode table over every word at most one mismatch from one of them, and per word the bit
+// planes of the words nearest to it, what bounds the others, and `tag` (what the kernel reports for the word).
+struct NearTables {
+    std::vector<uint16_t> table;
+    std::vector<uint32_t> record;
+    int32_t usable = 0;          // words whose radius is at least 4
+};
+NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector<uint32_t>& high, int32_t L, const std::vector<uint32_t>& tag) {
+    NearTables out;
+    const int32_t N = static_cast<int32_t>(low.size());
+    const int32_t list = near_list(L);
+    const int32_t field = near_field_bits(L);
+    const int32_t per_word = 32 / field;
+    const int32_t record_words = near_record_words(L);
+    auto distance = [&](int32_t a, int32_t b) {
+        return __builtin_popcount((low[static_cast<size_t>(a)] ^ low[static_cast<size_t>(b)]) | (high[static_cast<size_t>(a)] ^ high[static_cast<size_t>(b)]));
+    };
+    // a read more than one mismatch away from every word is not finished by the kernels: only those words
+    out.table.assign(static_cast<size_t>(1) << (2 * L), NEAR_NO_BARCODE);
+    for(int32_t b = N - 1; b >= 0; --b) {                     // the lowest ordinal last: it wins a shared word
+        for(int32_t j = 0; j < L; ++j) {
+            for(uint32_t other = 0; other < 4; ++other) {
+                const uint32_t l = (low[static_cast<size_t>(b)] & ~(1u << j)) | ((other & 1u) << j);
+                const uint32_t h = (high[static_cast<size_t>(b)] & ~(1u << j)) | ((other >> 1) << j);
+                uint16_t& slot = out.table[l | (h << L)];
+                const bool is_exact = l == low[static_cast<size_t>(b)] && h == high[static_cast<size_t>(b)];
+                // an exact word is never taken over by a neighbour of another word
+                if(slot == NEAR_NO_BARCODE || is_exact || !(low[slot] == l && high[slot] == h)) { slot = static_cast<uint16_t>(b); }
+            }
+        }
+    }
+    out.record.assign(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
+    std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
+    for(int32_t b = 0; b < N; ++b) {
+        for(int32_t o = 0; o < N; ++o) { order[static_cast<size_t>(o)] = {o == b ? -1 : distance(b, o), o}; }
+        std::sort(order.begin(), order.end());               // b itself first, then by (distance, ordinal)
+        uint32_t* record = &out.record[static_cast<size_t>(b) * static_cast<size_t>(record_words)];
+        for(int32_t k = 0; k < list; ++k) {
+            const int32_t o = order[static_cast<size_t>(k)].second;
+            record[2 * (k / per_word)] |= low[static_cast<size_t>(o)] << (field * (k % per_word));
+            record[2 * (k / per_word) + 1] |= high[static_cast<size_t>(o)] << (field * (k % per_word));
+        }
+        // the first word not listed sets the radius, at most 5 (the kernels form their bounds for 4 and 5)
+        const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
+        int at_radius = 0;
+        for(int32_t k = list; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
+        const float cnt_r = static_cast<float>(at_radius);
+        const float cnt_rest = static_cast<float>(N - list - at_radius);
+        uint32_t* meta = record + 2 * (list / per_word);
+        meta[0] = static_cast<uint32_t>(radius);
+        std::memcpy(&meta[1], &cnt_r, sizeof(float));
+        std::memcpy(&meta[2], &cnt_rest, sizeof(float));
+        meta[3] = tag[static_cast<size_t>(b)];
+        if(radius >= 4) { ++out.usable; }
+    }
+    return out;
+}
+
 void DecoderSet::build_device_images() {
     int count = 0;
     check(hipGetDeviceCount(&count), "hipGetDeviceCount");
@@ -325,10 +384,6 @@ void DecoderSet::build_device_images() {
                 // per barcode the bit planes of the barcodes nearest to it with what bounds the others
                 const int32_t L = c.nucleotide_cardinality;
                 const int32_t N = d.n_barcode;
-                const int32_t list = near_list(L);
-                const int32_t field = near_field_bits(L);
-                const int32_t per_word = 32 / field;
-                const int32_t record_words = near_record_words(L);
                 std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
                 for(int32_t b = 0; b < N; ++b) {
                     for(int32_t j = 0; j < L; ++j) {
@@ -338,53 +393,12 @@ void DecoderSet::build_device_images() {
                         high[static_cast<size_t>(b)] |= (two >> 1) << j;
                     }
                 }
-                auto distance = [&](uint32_t low_a, uint32_t high_a, uint32_t low_b, uint32_t high_b) {
-                    return __builtin_popcount((low_a ^ low_b) | (high_a ^ high_b));
-                };
-                // a read more than one mismatch away from every barcode is not finished by the kernel: only those words
-                std::vector<uint16_t> nearest(static_cast<size_t>(1) << (2 * L), NEAR_NO_BARCODE);
-                for(int32_t b = N - 1; b >= 0; --b) {                     // the lowest ordinal last: it wins a shared word
-                    for(int32_t j = 0; j < L; ++j) {
-                        for(uint32_t other = 0; other < 4; ++other) {
-                            const uint32_t l = (low[static_cast<size_t>(b)] & ~(1u << j)) | ((other & 1u) << j);
-                            const uint32_t h = (high[static_cast<size_t>(b)] & ~(1u << j)) | ((other >> 1) << j);
-                            uint16_t& slot = nearest[l | (h << L)];
-                            const bool is_exact = l == low[static_cast<size_t>(b)] && h == high[static_cast<size_t>(b)];
-                            // an exact word is never taken over by a neighbour of another barcode
-                            if(slot == NEAR_NO_BARCODE || is_exact || !(low[slot] == l && high[slot] == h)) { slot = static_cast<uint16_t>(b); }
-                        }
-                    }
-                }
-                std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
-                int32_t usable = 0;
-                std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
-                for(int32_t b = 0; b < N; ++b) {
-                    for(int32_t o = 0; o < N; ++o) {
-                        order[static_cast<size_t>(o)] = {o == b ? -1 : distance(low[static_cast<size_t>(b)], high[static_cast<size_t>(b)], low[static_cast<size_t>(o)], high[static_cast<size_t>(o)]), o};
-                    }
-                    std::sort(order.begin(), order.end());               // b itself first, then by (distance, ordinal)
-                    uint32_t* out = &record[static_cast<size_t>(b) * static_cast<size_t>(record_words)];
-                    for(int32_t k = 0; k < list; ++k) {
-                        const int32_t o = order[static_cast<size_t>(k)].second;
-                        out[2 * (k / per_word)] |= low[static_cast<size_t>(o)] << (field * (k % per_word));
-                        out[2 * (k / per_word) + 1] |= high[static_cast<size_t>(o)] << (field * (k % per_word));
-                    }
-                    // the first barcode not listed sets the radius, at most 5 (the kernel forms its bounds for 4 and 5)
-                    const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
-                    int at_radius = 0;
-                    for(int32_t k = list; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
-                    const float cnt_r = static_cast<float>(at_radius);
-                    const float cnt_rest = static_cast<float>(N - list - at_radius);
-                    uint32_t* meta = out + 2 * (list / per_word);
-                    meta[0] = static_cast<uint32_t>(radius);
-                    std::memcpy(&meta[1], &cnt_r, sizeof(float));
-                    std::memcpy(&meta[2], &cnt_rest, sizeof(float));
-                    meta[3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
-                    if(radius >= 4) { ++usable; }
-                }
-                d.near_table = static_cast<const uint16_t*>(upload(nearest.data(), nearest.size() * sizeof(uint16_t)));
-                d.near_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
-                d.near_ready = 2 * usable >= N ? 1 : 0;                  // a denser set leaves the kernel nothing to finish
+                std::vector<uint32_t> tag(static_cast<size_t>(N));
+                for(int32_t b = 0; b < N; ++b) { tag[static_cast<size_t>(b)] = static_cast<uint32_t>(index[static_cast<size_t>(b)]); }
+                const NearTables tables = build_near_tables(low, high, L, tag);
+                d.near_table = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
+                d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
+                d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
@@ -545,6 +559,30 @@ void DecoderSet::build_device_images() {
                         for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
+                        if(d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
+                           c.barcode_length[0] == c.barcode_length[1] && c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
+                           static_cast<int32_t>(distinct[0].size()) > near_list(c.barcode_length[0]) && static_cast<int32_t>(distinct[1].size()) > near_list(c.barcode_length[0])) {
+                            // neighbour list tier of the set (pamld_cross_near.hpp): pamld_near.hpp's tables per segment
+                            const int32_t length = c.barcode_length[0];
+                            int32_t usable = 0;
+                            for(int32_t s2 = 0; s2 < 2; ++s2) {
+                                const auto& set = distinct[static_cast<size_t>(s2)];
+                                std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u), tag(set.size());
+                                for(size_t u = 0; u < set.size(); ++u) {
+                                    for(int32_t j = 0; j < length; ++j) {
+                                        const uint32_t two = (set[u] >> (2 * j)) & 3u;
+                                        low[u] |= (two & 1u) << j;
+                                        high[u] |= (two >> 1) << j;
+                                    }
+                                    tag[u] = static_cast<uint32_t>(u) * static_cast<uint32_t>(stride[s2]);
+                                }
+                                const NearTables tables = build_near_tables(low, high, length, tag);
+                                d.cross_near_table[s2] = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
+                                d.cross_near_record[s2] = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
+                                if(2 * tables.usable >= static_cast<int32_t>(set.size())) { ++usable; }
+                            }
+                            d.cross_near_ready = usable == 2 ? 1 : 0;
+                        }
                         if(!d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD) {
                             // priors that differ between the barcodes: by combination, single precision, for the weighted scans
                             const size_t n0 = distinct[0].size();

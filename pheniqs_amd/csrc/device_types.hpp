@@ -118,6 +118,12 @@ struct DevDecoder {
     // priors): pair_table[s] = the table above for the words of segment s (key over the segment's positions, entry =
     // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance
     // to the nearest other barcode (at most 31), barcode_index[c]}
+    // neighbour list kernel of two segment combinatorial sets (pamld_cross_near.hpp; equal segment lengths, barcodes in
+    // lexicographic order of their words, identity index): near_table / near_record of each segment's distinct words,
+    // a record's last word = the word's share of the barcode ordinal (its ordinal times cross_stride)
+    const uint16_t* cross_near_table[2];
+    const uint32_t* cross_near_record[2];
+    int32_t cross_near_ready;
     const uint16_t* pair_table[2];
     const uint32_t* pair_record;
     int32_t pair_start[2];

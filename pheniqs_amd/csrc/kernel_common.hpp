@@ -287,6 +287,9 @@ int pamld_lut_block(const DevDecoder& host_decoder);       // threads per workgr
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_near_supports(const DevDecoder& host_decoder);   // pamld_near.hip: neighbour list tier in front of the product form kernel
 int launch_pamld_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_cross_near_supports(const DevDecoder& host_decoder);   // pamld_cross_near.hip: neighbour lists per segment of a two segment combinatorial set
+int pamld_cross_near_block(const DevDecoder& host_decoder);
+int launch_pamld_cross_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_pair_supports(const DevDecoder& host_decoder);   // pamld_pair.hip: paired barcodes, one barcode scored, in front of the product form kernels
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_wide_supports(const DevDecoder& host_decoder);

@@ -136,16 +136,23 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         }
     }
 
-    const int64_t n = args.n_read;
+    // behind the neighbour list kernel of combinatorial sets (pamld_cross_near.hpp) the kernel is a CONSUMER: it visits
+    // the reads of this workgroup's worklist segment and compacts what it defers itself back into it (pamld_lut.hpp)
+    const bool consumer = args.worklist_role == 2;
+    const int64_t n = consumer ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const uint32_t lane_offset = threadIdx.x * static_cast<uint32_t>(sizeof(float));
     const int64_t stride = d.plane_stride;
 
-    for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for(int64_t tile = consumer ? 0 : blockIdx.x; tile < tiles; tile += consumer ? 1 : gridDim.x) {
         // every lane stays enabled (cross lane reads of the wave wide tables): lanes past the end of the batch
         // recompute its last read and are kept from every store and counter
         const bool active = tile * THREADS + threadIdx.x < n;
-        const int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        int64_t i = active ? tile * THREADS + threadIdx.x : n - 1;
+        if(consumer) {
+            i = static_cast<int64_t>(segment[i]);
+            __syncthreads();                   // every entry of this tile is read before any wave compacts into it
+        }
         ReadState r = load_read_state(args, i);
         const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
         const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);

@@ -71,10 +71,12 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool paired = !tiny && !listed && args.result != nullptr && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
-                const int64_t threads = (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
+                // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
+                const bool crossed = factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);
+                const int64_t threads = crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 static const int near_share = std::getenv("PHQ_GRID_SHARE_NEAR") ? std::atoi(std::getenv("PHQ_GRID_SHARE_NEAR")) : GRID_SHARE_NEAR;
-                const int64_t product_blocks = paired ? share(near_share) : (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);
+                const int64_t product_blocks = (paired || crossed) ? share(near_share) : (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < product_blocks ? wide_tiles : product_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
                 StageArgs producer = args;
@@ -84,17 +86,19 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
-                if(listed || paired) {
+                if(listed || paired || crossed) {
                     {
                         Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
                         status = listed ? launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s)
-                                        : launch_pamld_pair(producer, host_decoder, wide_grid, histogram_bytes, s);
+                               : paired ? launch_pamld_pair(producer, host_decoder, wide_grid, histogram_bytes, s)
+                                        : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s);
                     }
                     if(status != 0) { return status; }
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
-                    status = long_words ? launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s)
+                    status = crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
+                           : long_words ? launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s)
                                         : launch_pamld_lut(middle, host_decoder, wide_grid, histogram_bytes, s);
                 } else {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
