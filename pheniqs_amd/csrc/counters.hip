@@ -8,16 +8,19 @@
 //   (accumulated confidence of the reads that pass the confidence filter)
 // One workgroup per CU keeps the pass filter half of every bin in LDS — 16 bytes per bin: count | distance in one
 // word, the confidence as 2^-44 fixed point in the other (at most 2^19 reads per workgroup, so neither can
-// overflow) — and flushes it once, bin after bin (contiguous words).  Reads that failed QC (a few %) go to
-// global atomics directly.  Rounding a confidence to 2^-44 moves a sum by < 3e-14 relative; sums stay
-// independent of the order reads are visited in.
+// overflow) — and flushes it once, bin after bin (contiguous words).  Reads that failed QC (a few %) are queued in
+// LDS and leave as dense global atomics whenever the queue is half full: sent directly, almost every wave would
+// issue four global atomic instructions for its one or two failed lanes, and those instructions (one memory side
+// request per lane whatever the lane count, ~50 ns each per CU) were three quarters of the kernel's time.
+// Rounding a confidence to 2^-44 moves a sum by < 3e-14 relative; sums stay independent of the order reads are
+// visited in.
 #include "kernel_common.hpp"
 
 namespace phq {
 namespace {
 
 constexpr int COUNT_THREADS = 1024;
-constexpr int MAX_DEFERRED_BINS = 9984;                  // 16 bytes each: 156 KiB of the 160 KiB of LDS
+constexpr int QUEUE = 768;                               // failed reads waiting for their global atomics: 12 bytes each
 constexpr int64_t READS_PER_WORKGROUP = 1 << 19;
 constexpr int CONFIDENCE_SHIFT = CONFIDENCE_FRACTION_BITS - 44;
 
@@ -26,16 +29,33 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_results_kernel(StageArgs 
     unsigned long long* const bins = reinterpret_cast<unsigned long long*>(lds_raw);       // [bin][count | distance << 32, confidence]
     DecoderRef d = *constant_cast(args.decoder);
     const int n_bin = d.n_barcode + 1;
+    unsigned long long* const queue_fixed = bins + 2 * n_bin;                               // [QUEUE] confidence, 2^-44 units
+    uint32_t* const queue_key = reinterpret_cast<uint32_t*>(queue_fixed + QUEUE);           // [QUEUE] bin | distance << 16
+    uint32_t& queue_count = queue_key[QUEUE];
     for(int w = threadIdx.x; w < 2 * n_bin; w += COUNT_THREADS) { bins[w] = 0; }
+    if(threadIdx.x == 0) { queue_count = 0; }
     __syncthreads();
+    auto send = [&](int bin, uint32_t distance, unsigned long long fixed) {                  // the QC fail half of a bin, in global memory
+        unsigned long long* const words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN;
+        atomicAdd(&words[FIELD_COUNT], 1ull);
+        if(distance) { atomicAdd(&words[FIELD_DISTANCE], static_cast<unsigned long long>(distance)); }
+        if(fixed) {
+            const unsigned long long exact = fixed << CONFIDENCE_SHIFT;
+            atomicAdd(&words[FIELD_CONFIDENCE_LOW], exact & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
+            atomicAdd(&words[FIELD_CONFIDENCE_HIGH], exact >> CONFIDENCE_LIMB_BITS);
+        }
+    };
+    auto drain = [&]() {                                                                     // every lane busy: dense atomics
+        const uint32_t waiting = min(queue_count, static_cast<uint32_t>(QUEUE));
+        for(uint32_t e = threadIdx.x; e < waiting; e += COUNT_THREADS) { send(static_cast<int>(queue_key[e] & 0xffffu), queue_key[e] >> 16, queue_fixed[e]); }
+    };
 
     const int64_t n = args.n_read;
     const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t first = per_block * blockIdx.x;
     const int64_t last = first + per_block < n ? first + per_block : n;
-    for(int64_t i = first + threadIdx.x; i < last; i += COUNT_THREADS) {
-        const DevResult record = args.result[i];
-        if(record.index <= 0) { continue; }              // unclassified: bin 0 was counted by the stage kernel
+    auto count = [&](const DevResult& record) {
+        if(record.index <= 0) { return; }                // unclassified: bin 0 was counted by the stage kernel
         const int bin = record.index;                    // identity numbering (count_results_supports)
         const unsigned long long fixed = record.status == STATUS_PASS
             ? static_cast<unsigned long long>(__double2ll_rn(record.confidence * 17592186044416.0)) : 0ull;      // 2^44
@@ -43,38 +63,78 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_results_kernel(StageArgs 
             atomicAdd(&bins[2 * bin], 1ull | (static_cast<unsigned long long>(record.distance) << 32));
             if(fixed) { atomicAdd(&bins[2 * bin + 1], fixed); }
         } else {
-            unsigned long long* const words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN;
-            atomicAdd(&words[FIELD_COUNT], 1ull);
-            if(record.distance) { atomicAdd(&words[FIELD_DISTANCE], static_cast<unsigned long long>(record.distance)); }
-            if(fixed) {
-                const unsigned long long exact = fixed << CONFIDENCE_SHIFT;
-                atomicAdd(&words[FIELD_CONFIDENCE_LOW], exact & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
-                atomicAdd(&words[FIELD_CONFIDENCE_HIGH], exact >> CONFIDENCE_LIMB_BITS);
-            }
+            const uint32_t slot = atomicAdd(&queue_count, 1u);
+            if(slot < static_cast<uint32_t>(QUEUE)) {
+                queue_key[slot] = static_cast<uint32_t>(bin) | (static_cast<uint32_t>(record.distance) << 16);
+                queue_fixed[slot] = fixed;
+            } else { send(bin, record.distance, fixed); }                                    // a full queue: straight to memory
         }
+    };
+    // after every pass over IN_FLIGHT records per lane: a queue past half of its room is drained by the whole workgroup
+    auto settle = [&]() {
+        __syncthreads();
+        if(queue_count >= static_cast<uint32_t>(QUEUE / 2)) {
+            drain();
+            __syncthreads();
+            if(threadIdx.x == 0) { queue_count = 0; }
+        }
+        __syncthreads();
+    };
+    // The kernel is a stream of 16 byte records into LDS atomics: with one record per lane in flight its 16 waves keep
+    // 16 KiB of loads outstanding per CU and wait on HBM latency most of the time; four records per lane, loaded before
+    // any is counted, quadruple that.
+    constexpr int IN_FLIGHT = 4;
+    int pass = 0;
+    for(int64_t base = first; base < last; base += IN_FLIGHT * COUNT_THREADS, ++pass) {     // the same trips for every lane: settle() has barriers
+        DevResult record[IN_FLIGHT];
+        bool present[IN_FLIGHT];
+#pragma unroll
+        for(int k = 0; k < IN_FLIGHT; ++k) {
+            const int64_t i = base + k * COUNT_THREADS + threadIdx.x;
+            present[k] = i < last;
+            if(present[k]) { record[k] = args.result[i]; }
+        }
+#pragma unroll
+        for(int k = 0; k < IN_FLIGHT; ++k) { if(present[k]) { count(record[k]); } }
+        if((pass & 3) == 3) { settle(); }      // every fourth pass: the waves run ahead of each other in between (a full queue sends directly)
     }
     __syncthreads();
-    for(int bin = 1 + threadIdx.x; bin < n_bin; bin += COUNT_THREADS) {
+    drain();
+    __syncthreads();
+    // The bins leave as DENSE atomics into the staging array: 64 consecutive words per wave instruction.  Added straight
+    // into the counter buffer (96 bytes from bin to bin) every lane's request went to a row of its own — memory side
+    // atomics run 17 times slower that way — and every workgroup sends every bin: that flush was most of the kernel.
+    unsigned long long* const staging = d.count_staging;
+    for(int w = threadIdx.x + 4; w < 4 * n_bin; w += COUNT_THREADS) {                       // bin 0 is not kept here
+        const int bin = w >> 2;
+        const int field = w & 3;
         const unsigned long long packed = bins[2 * bin];
-        if(packed == 0) { continue; }
-        unsigned long long* const words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN + STAT_FIELDS;   // pass filter half
-        atomicAdd(&words[FIELD_COUNT], packed & 0xffffffffull);
-        if(packed >> 32) { atomicAdd(&words[FIELD_DISTANCE], packed >> 32); }
         const unsigned long long confidence = bins[2 * bin + 1];
-        if(confidence) {
-            // 2^-44 units back to the two 26 bit limbs of the 2^-52 fixed point sum (the high limb takes the carry)
-            const unsigned long long low = (confidence & ((1ull << (CONFIDENCE_LIMB_BITS - CONFIDENCE_SHIFT)) - 1)) << CONFIDENCE_SHIFT;
-            atomicAdd(&words[FIELD_CONFIDENCE_LOW], low);
-            atomicAdd(&words[FIELD_CONFIDENCE_HIGH], confidence >> (CONFIDENCE_LIMB_BITS - CONFIDENCE_SHIFT));
-        }
+        // 2^-44 units back to the two 26 bit limbs of the 2^-52 fixed point sum (the high limb takes the carry)
+        const unsigned long long value = field == 0 ? (packed & 0xffffffffull) : field == 1 ? (packed >> 32)
+                                       : field == 2 ? ((confidence & ((1ull << (CONFIDENCE_LIMB_BITS - CONFIDENCE_SHIFT)) - 1)) << CONFIDENCE_SHIFT)
+                                                    : (confidence >> (CONFIDENCE_LIMB_BITS - CONFIDENCE_SHIFT));
+        if(value) { atomicAdd(&staging[w], value); }
     }
+}
+
+// staging -> the pass filter halves of the counter buffer, and the staging array back to zero
+__global__ __launch_bounds__(256) void count_results_finish_kernel(StageArgs args) {
+    DecoderRef d = *constant_cast(args.decoder);
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if(w < 4 || w >= 4 * (d.n_barcode + 1)) { return; }
+    const unsigned long long value = d.count_staging[w];
+    if(value == 0) { return; }
+    d.count_staging[w] = 0;
+    static_assert(FIELD_COUNT == 0 && FIELD_DISTANCE == 1 && FIELD_CONFIDENCE_LOW == 2 && FIELD_CONFIDENCE_HIGH == 3, "staging field order");
+    atomicAdd(&args.stats[d.stats_offset + static_cast<int64_t>(w >> 2) * STAT_WORDS_PER_BIN + STAT_FIELDS + (w & 3)], value);
 }
 
 }  // namespace
 
 // bins that fit the kernel's LDS, numbered the way the compiler numbers them, and no workgroup histogram
 bool count_results_supports(const DevDecoder& host_decoder) {
-    return !host_decoder.use_lds_histogram && host_decoder.identity_index && host_decoder.n_barcode + 1 <= MAX_DEFERRED_BINS;
+    return !host_decoder.use_lds_histogram && host_decoder.identity_index && host_decoder.n_barcode + 1 <= MAX_DEFERRED_BINS && host_decoder.count_staging != nullptr;
 }
 
 int launch_count_results(const StageArgs& args, const DevDecoder& host_decoder, int32_t compute_units, hipStream_t stream) {
@@ -82,8 +142,10 @@ int launch_count_results(const StageArgs& args, const DevDecoder& host_decoder, 
     if(const int status = allow_large_lds(&count_results_kernel, prepared)) { return status; }
     const int64_t by_reads = (args.n_read + READS_PER_WORKGROUP - 1) / READS_PER_WORKGROUP;
     const int64_t blocks = std::max<int64_t>(std::min<int64_t>(compute_units, (args.n_read + COUNT_THREADS - 1) / COUNT_THREADS), by_reads);
-    const size_t lds_bytes = static_cast<size_t>(host_decoder.n_barcode + 1) * 16;
+    const size_t lds_bytes = static_cast<size_t>(host_decoder.n_barcode + 1) * 16 + QUEUE * 12 + 16;
     hipLaunchKernelGGL(count_results_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(blocks, 1))), dim3(COUNT_THREADS), lds_bytes, stream, args);
+    if(const hipError_t status = hipGetLastError()) { return static_cast<int>(status); }
+    hipLaunchKernelGGL(count_results_finish_kernel, dim3(static_cast<unsigned>((4 * (host_decoder.n_barcode + 1) + 255) / 256)), dim3(256), 0, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

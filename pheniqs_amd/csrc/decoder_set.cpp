@@ -325,6 +325,11 @@ void DecoderSet::build_device_images() {
                 // decoder: 4.56 -> 4.41 Greads/s)
                 if(LDS_PER_CU / with_histogram < 2 && LDS_PER_CU / without >= 2) { d.use_lds_histogram = 0; }
             }
+            if(!d.use_lds_histogram && d.identity_index && d.n_barcode + 1 <= MAX_DEFERRED_BINS) {
+                // count_results_kernel's staging array (counters.hip), zero between launches
+                const std::vector<unsigned long long> zeros(static_cast<size_t>(d.n_barcode + 1) * 4, 0ull);
+                d.count_staging = static_cast<unsigned long long*>(upload(zeros.data(), zeros.size() * sizeof(unsigned long long)));
+            }
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));

@@ -17,6 +17,7 @@ constexpr int EXACT_SINGLE_UNIQUE = 512;
 constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }
 constexpr int near_list(int length) { return length <= 8 ? 16 : 15; }
 constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }      // 2 x list words + {radius, cnt_r, cnt_rest, index}, whole quads
+constexpr int MAX_DEFERRED_BINS = 9472;        // count_results_kernel: 16 bytes of LDS each
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
 constexpr int NEAR_MAX_BARCODES = 1024;
@@ -124,6 +125,10 @@ struct DevDecoder {
     const uint16_t* cross_near_table[2];
     const uint32_t* cross_near_record[2];
     int32_t cross_near_ready;
+    // count_results_kernel (counters.hip): [bin][count, distance, confidence low limb, confidence high limb] of the
+    // pass filter halves, where its workgroups add their LDS bins with dense atomics before one small kernel moves the
+    // sums into the counter buffer (zero between launches); null when the decoder's bins fit a workgroup histogram
+    unsigned long long* count_staging;
     const uint16_t* pair_table[2];
     const uint32_t* pair_record;
     int32_t pair_start[2];
