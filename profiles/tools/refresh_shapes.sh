@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 run() {   # name, bench arguments
   name=$1; shift
   rm -rf gpurun_out/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- python3 bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_$name.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$name -- python3 bench.py "$@" --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > gpurun_out/prof_$name.log 2>&1
   stats=$(ls -t gpurun_out/prof_$name/*/*_kernel_stats.csv | head -1)
   (head -1 $stats; grep "phq::" $stats) > gpurun_out/${round}_${name}_kernel_stats.csv
   grep '^{"metric"' gpurun_out/prof_$name.log | tail -1 > gpurun_out/${round}_bench_${name}.json
