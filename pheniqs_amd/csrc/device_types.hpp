@@ -40,6 +40,7 @@ constexpr int STAT_JOB_WORDS = 2;
 //   factorised / wide PAMLD, the rest   8: C3 8.02 (8) -> 7.73 (12) -> 7.49 (16) Greads/s
 constexpr int GRID_BLOCKS_PER_CU = 16;
 constexpr int GRID_SHARE_LUT = 12;
+constexpr int GRID_SHARE_CONSUMER = 12;    // the product form kernel behind a neighbour list tier takes the segments in groups when this is below the producer's share (measured: no gain on C2, 0.47 ms either way)
 constexpr int GRID_SHARE_NEAR = 12;        // the neighbour list tier and the tiers behind it
 constexpr int GRID_SHARE_MDD_FUSED = 16;
 constexpr int GRID_SHARE_DEFAULT = 8;

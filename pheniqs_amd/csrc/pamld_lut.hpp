@@ -136,15 +136,26 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     __syncthreads();
 
     const StatSink sink{histogram, args.stats, args.defer_counters != 0};
-    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    // A consumer takes worklist_group segments one after the other (fewer, longer lived workgroups: the set up above and
+    // the flush below are paid once for all of them); a producer owns the segment of its number.
+    const int group = CONSUMER ? (args.worklist_group < 1 ? 1 : args.worklist_group) : 1;
+    for(int member = 0; member < group; ++member) {
+    const int64_t own = CONSUMER ? static_cast<int64_t>(blockIdx.x) * group + member : static_cast<int64_t>(blockIdx.x);
+    if(CONSUMER && own >= args.worklist_segments) { break; }
+    if(CONSUMER && member > 0) {
+        __syncthreads();
+        if(threadIdx.x == 0) { deferred_total = 0; }
+        __syncthreads();
+    }
+    uint32_t* const segment = args.worklist + own * args.worklist_stride;
     // The packed barcode words sit in LDS: the scan reads a block's words at a wave uniform address (scalar loads
     // would share a counter with the LDS reads of the scan and serialise with them), the winner's block is
     // read back per lane.
     const PHQ_CONSTANT float* prior = constant_cast(d.concentration_single);
     const int n_barcode = d.n_barcode;
-    const int64_t n = CONSUMER ? static_cast<int64_t>(args.worklist_count[blockIdx.x]) : args.n_read;
+    const int64_t n = CONSUMER ? static_cast<int64_t>(args.worklist_count[own]) : args.n_read;
     const uint32_t carry_stride = (CONSUMER && args.carry) ? static_cast<uint32_t>(args.carry_stride) : 0u;
-    const uint32_t* const carry = args.carry + static_cast<int64_t>(blockIdx.x) * CARRY_PLANES * carry_stride;
+    const uint32_t* const carry = args.carry + own * CARRY_PLANES * carry_stride;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     constexpr bool PERMUTED = Layout::PERMUTED;
     constexpr uint32_t GROUP_STEP = Layout::GROUP_STEP;
@@ -502,7 +513,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         count_outgoing(args, histogram, active && !defer, r);
     }
     __syncthreads();
-    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    if(threadIdx.x == 0) { args.worklist_count[own] = deferred_total; }
+    }
     histogram_flush(args, d, histogram);
 }
 

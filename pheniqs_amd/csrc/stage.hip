@@ -96,10 +96,19 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     if(status != 0) { return status; }
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
+                    middle.worklist_segments = static_cast<int32_t>(wide_grid.x);
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
-                    status = crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
-                           : long_words ? launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s)
-                                        : launch_pamld_lut(middle, host_decoder, wide_grid, histogram_bytes, s);
+                    if(!crossed && !long_words) {
+                        // the product form kernel takes the segments in groups: as many workgroups as stay resident
+                        static const int consumer_share = std::getenv("PHQ_GRID_SHARE_CONSUMER") ? std::atoi(std::getenv("PHQ_GRID_SHARE_CONSUMER")) : GRID_SHARE_CONSUMER;
+                        const int64_t wanted = std::max<int64_t>(1, share(consumer_share));
+                        middle.worklist_group = static_cast<int32_t>((wide_grid.x + wanted - 1) / wanted);
+                        const dim3 fewer(static_cast<unsigned>((wide_grid.x + middle.worklist_group - 1) / middle.worklist_group));
+                        status = launch_pamld_lut(middle, host_decoder, fewer, histogram_bytes, s);
+                    } else {
+                        status = crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
+                                         : launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s);
+                    }
                 } else {
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
                     status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)

@@ -72,6 +72,20 @@ unlisted_at_radius = np.array([(bd[b, order[b, LIST:]] == radius[b]).sum() for b
 import os
 if os.environ.get("CLASS_BOUND", "1") == "1":
     U = A * boost * (unlisted_at_radius[c] * top + (N - LIST - unlisted_at_radius[c]) * top2)
+elif os.environ.get("CLASS_BOUND") == "pos":
+    # k = 1: only the unlisted barcodes at the radius whose difference from c covers the read's mismatch position can
+    # come one mismatch closer
+    diff = (words[:, None, :] != words[None, :, :])                   # N x N x L
+    unl = ~inlist                                                       # N x N
+    at_r = unl & (bd == radius[:, None])
+    m_pos = (at_r[:, :, None] & diff).sum(axis=1)                       # N x L: unlisted at the radius differing at position j
+    j0 = Mmask.argmax(axis=1)
+    mj = m_pos[c, j0]
+    k1 = (k == 1)
+    # top (need) for k=1 is r-1; top2 is r
+    U_k1 = A * boost * (mj * top + (unlisted_at_radius[c] - mj) * top2 + (N - LIST - unlisted_at_radius[c]) * top2)
+    U_k0 = A * boost * (unlisted_at_radius[c] * top + (N - LIST - unlisted_at_radius[c]) * top2)
+    U = np.where(k1, U_k1, U_k0)
 elif os.environ.get("CLASS_BOUND") == "3":
     top3 = np.ones(n)
     for i in range(L):
