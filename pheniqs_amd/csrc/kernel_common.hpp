@@ -251,15 +251,15 @@ __device__ __forceinline__ void load_plane_row(const uint8_t* plane, int64_t i, 
     }
 }
 
-// More than 64 KiB of dynamic LDS has to be asked for, once per kernel and device (one process may drive several
+// More than 64 KiB of dynamic LDS has to be asked for (static + dynamic at most 160 KiB), once per kernel and device (one process may drive several
 // devices through several decoder sets, from several threads).
 template <typename Kernel>
-inline int allow_large_lds(Kernel kernel, std::atomic<uint64_t>& done) {
+inline int allow_large_lds(Kernel kernel, std::atomic<uint64_t>& done, int bytes = 160 * 1024) {
     int device = 0;
     if(hipGetDevice(&device) != hipSuccess) { return static_cast<int>(hipErrorInvalidDevice); }
     const uint64_t bit = 1ull << (static_cast<unsigned>(device) & 63u);
     if((done.load(std::memory_order_acquire) & bit) == 0) {
-        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const hipError_t status = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         if(status != hipSuccess) { return static_cast<int>(status); }
         done.fetch_or(bit, std::memory_order_release);
     }

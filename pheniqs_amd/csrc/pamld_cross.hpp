@@ -488,27 +488,54 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 // without information) goes on to the literal kernel.
 // PRIORS (single segment sets only): the barcodes' priors differ, every word's probability carries its prior through
 // the sum, the maximum and the list, as the reference's loop does (pamld.cpp:66-79).
+//
+// Short lists (UNIQUE == CROSS_MAX_UNIQUE, the common case): a word's P is not multiplied up position by position but
+// read from per read fp64 tables, one of 16 entries per group of 4 positions ([group][entry][lane] in the dynamic LDS
+// block behind the histogram, built once per read and segment: 28 multiplications a group) — G table reads and G - 1
+// multiplications a word instead of 4 G of each (the products are associated by group: ~1e-16, far inside the 1e-10
+// window); and the list is a bit mask of UNIQUE bits in registers, the word ordinal being wave uniform.  Measured on
+// C2 (1.4 M reads reach the tier): 0.31 -> see DESIGN.md.
+constexpr int EXACT_TABLE_LANES = 128;        // lanes of a workgroup of the table form: 16 KiB of tables per group of 4 positions
+__host__ __device__ constexpr int exact_lanes(int unique) { return unique == CROSS_MAX_UNIQUE ? EXACT_TABLE_LANES : THREADS; }
+__host__ __device__ constexpr size_t exact_table_bytes(int groups, int unique) {
+    return unique == CROSS_MAX_UNIQUE ? static_cast<size_t>(groups) * 16u * sizeof(double) * EXACT_TABLE_LANES : 0u;
+}
+
 template <int G, int S, int UNIQUE, bool PRIORS>
-__global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs args) {
+__global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(StageArgs args) {
     static_assert(UNIQUE == CROSS_MAX_UNIQUE || S == 1, "long word lists are for single segment sets");
     static_assert(!PRIORS || S == 1, "priors by word are for single segment sets");
-    constexpr int UNIQUE_REGISTERS = UNIQUE / 64;
-    constexpr int LIST = UNIQUE == CROSS_MAX_UNIQUE ? CROSS_MAX_UNIQUE : EXACT_SINGLE_LIST;
+    constexpr bool TABLES = UNIQUE == CROSS_MAX_UNIQUE;
+    constexpr int LANES = exact_lanes(UNIQUE);
+    constexpr int MASK_WORDS = CROSS_MAX_UNIQUE / 32;
+    static_assert(MASK_WORDS == 4, "the scan below names the four chunks of a list mask");
+    constexpr int UNIQUE_REGISTERS = TABLES ? 1 : UNIQUE / 64;
+    constexpr int LIST = EXACT_SINGLE_LIST;
     typedef typename std::conditional<(UNIQUE > 256), uint16_t, uint8_t>::type Ordinal;
-    __shared__ Ordinal near_list[S * LIST * THREADS];                         // [segment][entry][lane] word ordinals
+    __shared__ Ordinal near_list[TABLES ? 1 : S * LIST * LANES];              // [segment][entry][lane] word ordinals (long lists)
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
     __shared__ uint32_t group_start[EXACT_GROUP_MAX + 1];                     // prefix sums of the group's segment counts
     __shared__ uint32_t group_kept[EXACT_GROUP_MAX];                          // reads left in each segment for the literal tier
+    // what the candidate walk indexes per lane, out of LDS instead of chains of dependent global loads: the distinct words,
+    // and for a single segment the barcode of each word
+    __shared__ uint32_t lds_word[S * CROSS_MAX_UNIQUE];
+    __shared__ int32_t lds_ordinal[S == 1 ? UNIQUE : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
 
-    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += LANES) {
         factor_double[i][0] = i < 128 ? d.match_probability[i] : d.uniform_probability;
         factor_double[i][1] = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
         cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
         cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
+    }
+    if(UNIQUE == CROSS_MAX_UNIQUE) {
+        for(int w = threadIdx.x; w < S * CROSS_MAX_UNIQUE; w += LANES) { lds_word[w] = d.cross_words[w]; }
+    }
+    if(S == 1) {
+        for(int w = threadIdx.x; w < UNIQUE; w += LANES) { lds_ordinal[w] = w < d.cross_unique[0] ? d.cross_ordinal[w * d.cross_stride[0]] : 0; }
     }
     // the segments of this workgroup, as one list
     const int group = args.worklist_group < 1 ? 1 : (args.worklist_group > EXACT_GROUP_MAX ? EXACT_GROUP_MAX : args.worklist_group);
@@ -529,7 +556,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
     const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segments = args.worklist + static_cast<int64_t>(first_segment) * args.worklist_stride;
     const int64_t n = static_cast<int64_t>(group_start[EXACT_GROUP_MAX]);
-    const int64_t tiles = (n + THREADS - 1) / THREADS;
+    const int64_t tiles = (n + LANES - 1) / LANES;
 
     uint32_t word_table[S][UNIQUE_REGISTERS];
     int first_word[S];
@@ -559,25 +586,38 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
 #pragma unroll
         for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
             const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
-            word_table[s][v] = w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
+            word_table[s][v] = !TABLES && w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
         }
     }
+    // the table form: this lane's column of the per read tables, behind the histogram in the dynamic block
+    double* const group_table = reinterpret_cast<double*>(lds_raw + ((static_cast<size_t>(histogram_words(d)) * sizeof(unsigned long long) + 15u) & ~static_cast<size_t>(15u))) + threadIdx.x;
+    const PHQ_CONSTANT uint32_t* const word_list = constant_cast(d.cross_words);
     const int64_t stride = d.plane_stride;
     constexpr bool weighted = false;           // priors that differ: pamld_cross_exact_weighted_kernel
     constexpr double near = 1.0 - 1e-10;
+    const double uniform_concentration = d.concentration[0];          // !PRIORS: every barcode's prior is this one
     const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
     const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
 
-    for(int64_t tile = 0; tile < tiles; ++tile) {
-        const int64_t k = tile * THREADS + threadIdx.x;
-        const bool active = k < n;
-        // entry k of the list: in which segment, and where in it
-        const uint32_t at = static_cast<uint32_t>(active ? k : n - 1);
-        int home = 0;
+    // entry k of the list: in which segment, and where in it
+    auto entry_of = [&](int64_t tile, int& home) {
+        const int64_t k = tile * LANES + threadIdx.x;
+        const uint32_t at = static_cast<uint32_t>(k < n ? k : n - 1);
+        home = 0;
 #pragma unroll
         for(int s = 1; s < EXACT_GROUP_MAX; ++s) { home += at >= group_start[s] ? 1 : 0; }       // starts are non decreasing
+        return segments[static_cast<int64_t>(home) * args.worklist_stride + (at - group_start[home])];
+    };
+    int home_ahead = 0;
+    uint32_t entry_ahead = tiles > 0 ? entry_of(0, home_ahead) : 0u;
+    for(int64_t tile = 0; tile < tiles; ++tile) {
+        const bool active = tile * LANES + threadIdx.x < n;
+        const int home = home_ahead;
         uint32_t* const segment = segments + static_cast<int64_t>(home) * args.worklist_stride;
-        const int64_t i = static_cast<int64_t>(segment[at - group_start[home]]);
+        const int64_t i = static_cast<int64_t>(entry_ahead);
+        // the next tile's entries are read a tile ahead (their latency hides behind this tile's work); what this tile
+        // compacts into a segment lands below the entries already read from it
+        entry_ahead = entry_of(tile + 1 < tiles ? tile + 1 : tile, home_ahead);
         __syncthreads();                       // every entry of this tile is read before any wave compacts into it
         ReadState r = load_read_state(args, i);
         const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
@@ -588,6 +628,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
         uint32_t outside[S];
         uint32_t high_quality[S];
         int near_count[S];                     // entries of this lane's column of near_list
+        uint32_t list_mask[S][MASK_WORDS];     // the table form's list: bit u of the segment's mask = word u is listed
         double sum_all = 1.0;                  // product of the per segment sums = sum over every barcode of P(r|b)
         double listed_all = 1.0;               // the same over the listed words only
         bool defer = false;
@@ -619,6 +660,81 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                 if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality[s] |= 1u << low_bit(j); }
                 if(!strict_code(code)) { outside[s] |= 1u << low_bit(j); }
             }
+            double top = 0;
+            double sum = 0;
+            double listed = 0;                     // the sum over the listed words
+            int count = 0;
+            bool overflow = false;
+            if constexpr(TABLES) {
+                // this read's tables of the segment: entry m of group g = product over the group's positions of the
+                // match (bit clear) or mismatch (bit set) factor
+#pragma unroll
+                for(int g = 0; g < G; ++g) {
+                    double entry[16];
+#pragma unroll
+                    for(int jj = 0; jj < 4; ++jj) {
+                        const double* const pair = reinterpret_cast<const double*>(factor_bytes + row_offset[s][4 * g + jj]);
+                        const double match = pair[0];
+                        const double mismatch = pair[1];
+                        if(jj == 0) { entry[0] = match; entry[1] = mismatch; }
+                        else {
+#pragma unroll
+                            for(int m = (1 << jj) - 1; m >= 0; --m) {
+                                entry[m + (1 << jj)] = entry[m] * mismatch;
+                                entry[m] = entry[m] * match;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for(int m = 0; m < 16; ++m) { group_table[(g * 16 + m) * LANES] = entry[m]; }
+                }
+                // flags of group g sit at bits 8 g + 2 .. 8 g + 5: entry * LANES * 8 bytes = (flags moved to bits 10..13) & 0x3c00
+                static_assert(LANES * sizeof(double) == 1024, "an entry of the table form is 1 KiB");
+                const char* const table_bytes = reinterpret_cast<const char*>(group_table);
+                auto probability_of = [&](uint32_t word) {
+                    const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
+                    double p = 1.0;
+#pragma unroll
+                    for(int g = 0; g < G; ++g) {
+                        const uint32_t moved = g == 0 ? flags << 8 : g == 1 ? flags : flags >> (8 * g - 8);
+                        const double t = *reinterpret_cast<const double*>(table_bytes + g * 16 * LANES * sizeof(double) + (moved & 0x3c00u));
+                        p = g == 0 ? t : p * t;
+                    }
+                    return p;
+                };
+                uint32_t chunk_mask[MASK_WORDS] = {0u, 0u, 0u, 0u};
+                const PHQ_CONSTANT uint32_t* const words = word_list + s * CROSS_MAX_UNIQUE;
+                auto scan_chunk = [&](auto which) {
+                    constexpr int c = decltype(which)::value;
+                    if(32 * c >= unique[s]) { return; }                                         // wave uniform
+                    const int here = min(unique[s] - 32 * c, 32);
+                    uint32_t current = 0;
+                    auto visit = [&](int u, uint32_t bit) {
+                        double p = probability_of(words[u]);                                    // scalar load
+                        if(PRIORS) { p *= d.concentration[d.cross_ordinal[u]]; }
+                        sum += p;
+                        const bool clears = p * near > top;
+#pragma unroll
+                        for(int e = 0; e < c; ++e) { chunk_mask[e] = clears ? 0u : chunk_mask[e]; }
+                        current = clears ? 0u : current;
+                        current |= p >= top * near ? bit : 0u;
+                        top = fmax(top, p);
+                    };
+                    int k = 0;
+                    for(; k + 4 <= here; k += 4) {
+#pragma unroll
+                        for(int h = 0; h < 4; ++h) { visit(32 * c + k + h, 1u << (k + h)); }
+                    }
+                    for(; k < here; ++k) { visit(32 * c + k, 1u << k); }
+                    chunk_mask[c] = current;
+                };
+                scan_chunk(std::integral_constant<int, 0>{});
+                scan_chunk(std::integral_constant<int, 1>{});
+                scan_chunk(std::integral_constant<int, 2>{});
+                scan_chunk(std::integral_constant<int, 3>{});
+#pragma unroll
+                for(int e = 0; e < MASK_WORDS; ++e) { list_mask[s][e] = chunk_mask[e]; count += __popc(chunk_mask[e]); }
+            } else {
             auto probability_of = [&](uint32_t word) {
                 const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
                 double p = 1.0;
@@ -631,11 +747,6 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             // one pass: the sum, the maximum, and a list that always holds every word within 1e-10 of the running
             // maximum (it is emptied when a new maximum clears the old one by more than that; words that crept in
             // while the maximum was lower are harmless extras: the literal evaluation below decides)
-            double top = 0;
-            double sum = 0;
-            double listed = 0;                     // the sum over the listed words
-            int count = 0;
-            bool overflow = false;
 #pragma unroll
             for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
                 const int last = min(unique[s], 64 * (v + 1));
@@ -645,8 +756,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                     sum += p;
                     if(p * near > top) { count = 0; listed = 0; overflow = false; }
                     if(p >= top * near) {
-                        if(LIST >= UNIQUE || count < LIST) {
-                            near_list[(s * LIST + count) * THREADS + threadIdx.x] = static_cast<Ordinal>(u);
+                        if(count < LIST) {
+                            near_list[(s * LIST + count) * LANES + threadIdx.x] = static_cast<Ordinal>(u);
                             ++count;
                         } else { overflow = true; }
                         listed += p;
@@ -654,34 +765,53 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
                     top = fmax(top, p);
                 }
             }
+            }
             if(!(top > 0) || overflow) { defer = true; count = 0; }
             near_count[s] = count;
             sum_all *= sum;
             listed_all *= listed;
         }
 
+        // the listed word of segment s at or after ordinal `from` (table form), -1 when there is none
+        auto next_listed = [&](int s, int from) {
+            int found = -1;
+#pragma unroll
+            for(int e = MASK_WORDS - 1; e >= 0; --e) {
+                const int low = from - 32 * e;
+                uint32_t m = list_mask[s][e];
+                m = low >= 32 ? 0u : low > 0 ? m & (~0u << low) : m;
+                found = m ? 32 * e + __ffs(static_cast<int>(m)) - 1 : found;
+            }
+            return found;
+        };
         // walk the combinations of listed words, the last segment fastest
         auto for_each_combination = [&](auto&& body) {
-            int choice[S];
+            int choice[S];                         // long lists: the entry; table form: the word's ordinal
             bool more = true;
 #pragma unroll
-            for(int s = 0; s < S; ++s) { choice[s] = 0; more = more && near_count[s] > 0; }
+            for(int s = 0; s < S; ++s) { choice[s] = TABLES ? next_listed(s, 0) : 0; more = more && near_count[s] > 0; }
             while(more) {
                 int flat = 0;
                 uint32_t flags[S];
 #pragma unroll
                 for(int s = 0; s < S; ++s) {
-                    const int u = near_list[(s * LIST + choice[s]) * THREADS + threadIdx.x];
+                    const int u = TABLES ? choice[s] : static_cast<int>(near_list[(s * LIST + choice[s]) * LANES + threadIdx.x]);
                     flat += u * radix[s];
-                    flags[s] = (mismatch_fields(observed[s] ^ d.cross_words[s * CROSS_MAX_UNIQUE + u]) | outside[s]) & full_mask[s];
+                    const uint32_t word = TABLES ? lds_word[s * CROSS_MAX_UNIQUE + u] : d.cross_words[s * CROSS_MAX_UNIQUE + u];
+                    flags[s] = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
                 }
                 body(flat, flags);
                 bool carry = true;
 #pragma unroll
                 for(int s = S - 1; s >= 0; --s) {
                     if(carry) {
-                        ++choice[s];
-                        if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
+                        if(TABLES) {
+                            const int next = next_listed(s, choice[s] + 1);
+                            if(next < 0) { choice[s] = next_listed(s, 0); } else { choice[s] = next; carry = false; }
+                        } else {
+                            ++choice[s];
+                            if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
+                        }
                     }
                 }
                 more = !carry;
@@ -741,8 +871,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_exact_kernel(StageArgs ar
             if(!(left_out <= 1e-12 * (weighted_sum + d.adjusted_noise_probability)) || !(weighted_top > 0)) { defer = true; }
         }
         for_each_combination([&](int flat, const uint32_t (&flags)[S]) {
-            const int b = d.cross_ordinal[flat];
-            const double prior = d.concentration[b];
+            const int b = S == 1 ? lds_ordinal[S == 1 ? flat / radix[0] : 0] : d.cross_ordinal[flat];
+            const double prior = (weighted || PRIORS) ? d.concentration[b] : uniform_concentration;
             if(weighted && !(product_of(flags) * prior >= weighted_top * (1.0 - 1e-10))) { return; }      // cannot be the argmax
             const double conditional = literal_of(flags);
             const double p = conditional * prior;                                  // pamld.cpp:66
@@ -1125,28 +1255,38 @@ inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_d
 }
 
 // a single segment set: more than CROSS_MAX_UNIQUE words and / or priors that differ
+template <int G, int S, int UNIQUE, bool PRIORS>
+int launch_exact_form(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G, UNIQUE);
+    if(bytes > 64u * 1024u) {
+        static std::atomic<uint64_t> prepared{0};
+        // at most 32 KiB of histogram + 64 KiB of tables; the kernel also has ~5 KiB of static LDS
+        if(const int status = allow_large_lds(&pamld_cross_exact_kernel<G, S, UNIQUE, PRIORS>, prepared, 128 * 1024)) { return status; }
+    }
+    hipLaunchKernelGGL((pamld_cross_exact_kernel<G, S, UNIQUE, PRIORS>), grid, dim3(exact_lanes(UNIQUE)), bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int UNIQUE, bool PRIORS>
 int launch_exact_single(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, 1, UNIQUE, PRIORS>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: return launch_exact_form<1, 1, UNIQUE, PRIORS>(args, grid, histogram_bytes, stream);
+        case 2: return launch_exact_form<2, 1, UNIQUE, PRIORS>(args, grid, histogram_bytes, stream);
+        case 3: return launch_exact_form<3, 1, UNIQUE, PRIORS>(args, grid, histogram_bytes, stream);
+        case 4: return launch_exact_form<4, 1, UNIQUE, PRIORS>(args, grid, histogram_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
-    return static_cast<int>(hipGetLastError());
 }
 
 template <int S>
 int launch_exact_segments(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     switch(host_decoder.cross_groups) {
-        case 1: hipLaunchKernelGGL((pamld_cross_exact_kernel<1, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_cross_exact_kernel<2, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_cross_exact_kernel<3, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_cross_exact_kernel<4, S, CROSS_MAX_UNIQUE, false>), grid, dim3(THREADS), histogram_bytes, stream, args); break;
+        case 1: return launch_exact_form<1, S, CROSS_MAX_UNIQUE, false>(args, grid, histogram_bytes, stream);
+        case 2: return launch_exact_form<2, S, CROSS_MAX_UNIQUE, false>(args, grid, histogram_bytes, stream);
+        case 3: return launch_exact_form<3, S, CROSS_MAX_UNIQUE, false>(args, grid, histogram_bytes, stream);
+        case 4: return launch_exact_form<4, S, CROSS_MAX_UNIQUE, false>(args, grid, histogram_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
-    return static_cast<int>(hipGetLastError());
 }
 
 template <int G, int S, bool WEIGHTED>
