@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -170,13 +171,16 @@ struct NearTables {
     std::vector<uint32_t> record;
     int32_t usable = 0;          // words whose radius is at least 4
 };
-NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector<uint32_t>& high, int32_t L, const std::vector<uint32_t>& tag) {
+// prior: the barcodes' priors when they differ (then `noise` = the prior adjusted noise probability, pamld.cpp:29), else null
+NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector<uint32_t>& high, int32_t L, const std::vector<uint32_t>& tag,
+                             const std::vector<double>* prior = nullptr, double noise = 0) {
     NearTables out;
     const int32_t N = static_cast<int32_t>(low.size());
     const int32_t list = near_list(L);
     const int32_t field = near_field_bits(L);
     const int32_t per_word = 32 / field;
-    const int32_t record_words = near_record_words(L);
+    const int32_t record_words = near_record_words(L, prior != nullptr);
+    const int32_t weight_at = near_record_words(L);
     auto distance = [&](int32_t a, int32_t b) {
         return __builtin_popcount((low[static_cast<size_t>(a)] ^ low[static_cast<size_t>(b)]) | (high[static_cast<size_t>(a)] ^ high[static_cast<size_t>(b)]));
     };
@@ -207,10 +211,24 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
         }
         // the first word not listed sets the radius, at most 5 (the kernels form their bounds for 4 and 5)
         const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
-        int at_radius = 0;
-        for(int32_t k = list; k < N; ++k) { if(order[static_cast<size_t>(k)].first <= radius) { ++at_radius; } }
-        const float cnt_r = static_cast<float>(at_radius);
-        const float cnt_rest = static_cast<float>(N - list - at_radius);
+        // what is not listed, at the radius and beyond it: how many — or, with priors that differ, their priors over b's
+        double at_radius = 0;
+        double beyond = 0;
+        const double own = prior ? (*prior)[static_cast<size_t>(b)] : 1.0;
+        for(int32_t k = list; k < N; ++k) {
+            const double weight = prior ? (*prior)[static_cast<size_t>(order[static_cast<size_t>(k)].second)] / own : 1.0;
+            if(order[static_cast<size_t>(k)].first <= radius) { at_radius += weight; } else { beyond += weight; }
+        }
+        const float up = prior ? 1.0f + 1e-6f : 1.0f;          // the sums bound: rounded up
+        const float cnt_r = static_cast<float>(at_radius) * up;
+        const float cnt_rest = static_cast<float>(beyond) * up;
+        if(prior) {
+            for(int32_t k = 0; k < list; ++k) {
+                const float weight = k == 0 ? static_cast<float>(noise / own)
+                                            : static_cast<float>((*prior)[static_cast<size_t>(order[static_cast<size_t>(k)].second)] / own);
+                std::memcpy(&record[weight_at + k], &weight, sizeof(float));
+            }
+        }
         uint32_t* meta = record + 2 * (list / per_word);
         meta[0] = static_cast<uint32_t>(radius);
         std::memcpy(&meta[1], &cnt_r, sizeof(float));
@@ -383,7 +401,9 @@ void DecoderSet::build_device_images() {
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
             }
-            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
+            bool positive_priors = true;         // ratios of priors are formed below
+            for(double c0 : concentration) { if(!(c0 > 0) || !std::isfinite(c0)) { positive_priors = false; } }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
                d.n_barcode > near_list(c.nucleotide_cardinality) && d.n_barcode <= NEAR_MAX_BARCODES) {
                 // neighbour list tier (pamld_near.hpp): the barcode of every word at most one mismatch away from one, and
                 // per barcode the bit planes of the barcodes nearest to it with what bounds the others
@@ -400,7 +420,7 @@ void DecoderSet::build_device_images() {
                 }
                 std::vector<uint32_t> tag(static_cast<size_t>(N));
                 for(int32_t b = 0; b < N; ++b) { tag[static_cast<size_t>(b)] = static_cast<uint32_t>(index[static_cast<size_t>(b)]); }
-                const NearTables tables = build_near_tables(low, high, L, tag);
+                const NearTables tables = build_near_tables(low, high, L, tag, d.uniform_prior ? nullptr : &concentration, d.adjusted_noise_probability);
                 d.near_table = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
                 d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
@@ -793,13 +813,13 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
 
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"
 size_t DecoderSet::worklist_words(int64_t n_read) const {
-    // whatever the grid (at most max_blocks_ workgroups of at most 512 lanes): grid * ceil(tiles / grid) * threads
+    // whatever the grid (at most max_blocks_ workgroups of at most 1024 lanes): grid * ceil(tiles / grid) * threads
     // is less than n_read + (grid + 1) * threads
     return worklist_entries(n_read) + carry_words(n_read);
 }
 
 size_t DecoderSet::worklist_entries(int64_t n_read) const {
-    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 512;
+    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 1024;
     return static_cast<size_t>(max_blocks_) + worst + static_cast<size_t>(max_blocks_) * 1024 + 512;      // + the 4 tile passes of the MDD exact kernel
 }
 
@@ -809,7 +829,7 @@ size_t DecoderSet::carry_words(int64_t n_read) const {
     bool any = false;
     for(const auto& d : host_decoder_) { if(d.near_ready) { any = true; } }
     if(!any) { return 0; }
-    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 512;
+    const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 1024;
     return CARRY_PLANES * (worst / 4 + static_cast<size_t>(max_blocks_) * 512);
 }
 

@@ -17,6 +17,9 @@ constexpr int EXACT_SINGLE_UNIQUE = 512;
 constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }
 constexpr int near_list(int length) { return length <= 8 ? 16 : 15; }
 constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }      // 2 x list words + {radius, cnt_r, cnt_rest, index}, whole quads
+// ... with priors that differ: behind those, one float per listed barcode — its prior over c's; slot 0 (c itself) holds
+// the noise term over c's prior — again whole quads
+constexpr int near_record_words(int length, bool priors) { return near_record_words(length) + (priors ? (length <= 8 ? 16 : 16) : 0); }
 constexpr int MAX_DEFERRED_BINS = 9472;        // count_results_kernel: 16 bytes of LDS each
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
@@ -112,7 +115,9 @@ struct DevDecoder {
     // other word; 4^L entries.  near_record[c] = near_record_words(L) words: the near_list(L) barcodes {c, the nearest
     // to c} as {low plane word, high plane word} pairs (near_field_bits(L) bits per barcode, bit j = position j),
     // then the radius (distance from c of the nearest barcode not listed, at most 5), the number of barcodes not
-    // listed at that distance and further away (two floats), barcode_index[c], and padding
+    // listed at that distance and further away (two floats; with priors that differ the sums of their priors over c's),
+    // barcode_index[c], and padding; with priors that differ near_record_words(L, true) words, the listed barcodes' prior
+    // ratios behind the rest
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes

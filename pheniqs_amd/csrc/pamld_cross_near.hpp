@@ -26,6 +26,7 @@ using near::LdsQuads;
 using near::LdsPairs;
 using near::and_or;
 constexpr int FACTOR_ROWS = near::FACTOR_ROWS;
+constexpr float X_MAX = 3e-4f;                 // as near::X_MAX, for the up to 20 positions of two segments
 constexpr int SEGMENTS = 2;
 
 // L = nucleotides of EACH segment; the plane row holds 2 L positions in ROW_WORDS words
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
         const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
         // a low confidence read is left to the next tier here: its counter lives in a bin this kernel may not hold
-        const bool finished = all_strict && usable && winner > noise_floor && listed <= near::LISTED_MAX && x_low + x_rest <= near::X_MAX &&
+        const bool finished = all_strict && usable && winner > noise_floor && listed <= near::LISTED_MAX && x_low + x_rest <= X_MAX &&
                               x_rest <= near::REST_MAX && confidence_margin > 2e-9;
         const bool defer = !finished;
 

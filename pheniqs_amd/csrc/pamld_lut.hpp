@@ -535,8 +535,13 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
         return static_cast<int>(hipErrorInvalidValue);
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
-            // behind the neighbour list kernels (pamld_near.hpp, pamld_pair.hpp; uniform priors): as a consumer of their lists
-            if(args.worklist_role == 2) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
+            // behind the neighbour list kernels (pamld_near.hpp, pamld_pair.hpp): as a consumer of their lists; priors that
+            // differ only behind pamld_near.hpp (5 to 10 nt)
+            if(args.worklist_role == 2) {
+                if(host_decoder.uniform_prior) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
+                if constexpr(LO >= NEAR_MIN_LENGTH && LO <= NEAR_MAX_LENGTH) { return launch_one<LO, false, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
+                else { return static_cast<int>(hipErrorInvalidValue); }
+            }
             return host_decoder.uniform_prior ? launch_one<LO, true, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)
                                               : launch_one<LO, false, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
         }

@@ -23,7 +23,7 @@
 //     r (cnt_r of them, host) are charged H[r - k], the others H[r + 1 - k]; the k = 1 case leaves the read's own
 //     mismatch position out through  top_n(without j) <= min(top_n, top_{n+1} / rho_j).
 // A read is FINISHED here when all of this is certain to 1e-9 in the posterior: it passes the noise filter clearly,
-// everything else sums to at most 2e-3 of the winner (so single precision, relative error ~2e-7, moves the
+// everything else sums to at most 5e-4 of the winner (so single precision, relative error below ~1e-6, moves the
 // posterior by less than 5e-10: the posterior is formed as 1 - x / (1 + x), x = (others + noise) / winner, and only
 // that last subtraction is in double precision), the bound on what was not scored moves it by at most 5e-10, and
 // the confidence is further than 2e-9 from its threshold.  About 90 % of the reads of the 96 x 8 nt benchmark.
@@ -45,27 +45,38 @@ namespace near {
 
 constexpr int FACTOR_ROWS = 129;
 constexpr float LISTED_MAX = 5e-4f;            // scored barcodes other than c sum to at most this share of c's probability
-constexpr float X_MAX = 2e-3f;                 // (others + noise) / winner: single precision is enough below this
+// (others + noise) / winner = x: single precision is enough below this.  x carries the roundings of ~2 L + 3 single
+// precision operations (the factors themselves, their products, the reciprocal): at most ~1.4e-6 relative for 10 nt if
+// all of them align, which moves the posterior by x * 1.4e-6 < 7e-10
+constexpr float X_MAX = 5e-4f;
 constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
 constexpr float SLOP = 1.0f + 1e-5f;           // single precision rounding of the bound itself
 
 // Shapes by barcode length.  5 .. 8 nt: two groups of 4 positions, 8 flag bits per barcode, four barcodes per plane
 // word, 16 listed, 512 lane workgroups (two per CU).  9 and 10 nt: three groups (the last one of 1 or 2 positions),
 // 10 flag bits per barcode, three per word, 15 listed, 256 lane workgroups.
-template <int L> struct Shape {
+// PRIORS: the barcodes' priors differ (estimated priors, phq_adjust_prior): a record also holds the prior of each listed
+// barcode over c's, 64 bytes more per barcode.  Beside two 512 lane workgroups' tables (64 KiB each) that no longer fits
+// a CU, so the two group shapes then run ONE workgroup of 1024 lanes per CU (measured with uniform priors: 4 % slower
+// than two of 512), its tables laid out [wave][group] so that a group is still reached through the offset field.
+template <int L, bool PRIORS = false> struct Shape {
     static_assert(L >= 5 && L <= 10, "two or three groups of 4 positions");
     static constexpr int G = (L + 3) / 4;
+    static constexpr bool WIDE = PRIORS && G == 2;
     static constexpr int FIELD = near_field_bits(L);
     static constexpr int PER_WORD = 32 / FIELD;
     static constexpr int LIST = near_list(L);
     static constexpr int LIST_WORDS = LIST / PER_WORD;
-    static constexpr int RECORD_WORDS = near_record_words(L);
+    static constexpr int RECORD_WORDS = near_record_words(L, PRIORS);
     static constexpr int RECORD_QUADS = RECORD_WORDS / 4;
-    static constexpr int THREADS = G == 2 ? 512 : 256;
+    static constexpr int WEIGHT_AT = near_record_words(L);                     // PRIORS: the first of LIST prior ratios (slot 0: the noise term)
+    static constexpr int THREADS = G == 2 ? (WIDE ? 1024 : 512) : 256;
     static constexpr int WAVES = THREADS / 64;
-    static constexpr uint32_t GROUP_BYTES = WAVES * 16u * 64u * 4u;           // one group's tables of the whole workgroup
-    static constexpr uint32_t TABLE_AT = 0;                                    // [group][wave][entry][lane] floats
-    static constexpr uint32_t TABLE_BYTES = G * GROUP_BYTES;
+    static constexpr uint32_t WAVE_TABLE = 16u * 64u * 4u;                     // one group's table of one wave
+    static constexpr uint32_t GROUP_BYTES = WIDE ? WAVE_TABLE : WAVES * WAVE_TABLE;      // from a group's table to the next one's
+    static constexpr uint32_t WAVE_BYTES = WIDE ? G * WAVE_TABLE : WAVE_TABLE;           // from a wave's tables to the next one's
+    static constexpr uint32_t TABLE_AT = 0;                                    // [group][wave][entry][lane] floats; WIDE: [wave][group][entry][lane]
+    static constexpr uint32_t TABLE_BYTES = G * WAVES * WAVE_TABLE;
     static constexpr uint32_t FACTOR_AT = TABLE_AT + TABLE_BYTES;              // FACTOR_ROWS x {match, mismatch} floats
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 1040;
     static constexpr uint32_t RECORD_AT = DEFERRED_AT + 16;                    // n_barcode x RECORD_WORDS words
@@ -91,9 +102,9 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 // STATE: where a read's carried state comes from — 0 the first stage of a job without input flags (nothing to load),
 // 1 the first stage with flag bytes, 2 a later stage (the status word).  A template parameter so that the loads of
 // the prefetch sit in straight line code: behind a branch the compiler can no longer count them and waits for all.
-template <int L, int STATE>
-__global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs args) {
-    typedef Shape<L> Layout;
+template <int L, int STATE, bool PRIORS>
+__global__ __launch_bounds__((Shape<L, PRIORS>::THREADS)) void pamld_near_kernel(StageArgs args) {
+    typedef Shape<L, PRIORS> Layout;
     constexpr int G = Layout::G;
     constexpr int THREADS = Layout::THREADS;
     constexpr int FIELD = Layout::FIELD;
@@ -123,10 +134,10 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs
     const int64_t n = args.n_read;
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lane_const = ((threadIdx.x & 63u) << 2) | (wave << 12);          // everything of a table address but group and entry
+    const uint32_t lane_const = ((threadIdx.x & 63u) << 2) + wave * Layout::WAVE_BYTES;     // everything of a table address but group and entry (bits 8..11 clear)
     const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
     const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
-    const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);       // uniform priors
+    const float uniform_noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);
     const float noise_floor = static_cast<float>(d.random_barcode_probability) * SLOP;
     const double confidence_threshold = d.confidence_threshold;
     const uint32_t n_barcode = static_cast<uint32_t>(d.n_barcode);
@@ -333,6 +344,10 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs
 #pragma unroll
             for(int b = 0; b < PER_WORD; ++b) {
                 if(w == 0 && b == 0) { winner = p[0]; }
+                else if(PRIORS) {
+                    const float weight = __uint_as_float(record_word(Layout::WEIGHT_AT + PER_WORD * w + b));     // prior of this barcode over c's
+                    sum = (w == 0 && b == 1) ? p[b] * weight : __builtin_fmaf(p[b], weight, sum);
+                }
                 else { sum = (w == 0 && b == 1) ? p[b] : sum + p[b]; }
             }
             others = w == 0 ? sum : others + sum;
@@ -343,6 +358,7 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs
         const float cnt_r = __uint_as_float(record_word(2 * LIST_WORDS + 1));
         const float cnt_rest = __uint_as_float(record_word(2 * LIST_WORDS + 2));
         const uint32_t index = record_word(2 * LIST_WORDS + 3);                  // barcode_index[c]
+        const float noise_over_prior = PRIORS ? __uint_as_float(record_word(Layout::WEIGHT_AT)) : uniform_noise_over_prior;
         const int k = __popc(mismatches);
         const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5; 4 otherwise (less: not finished here)
         const float h_r = near5 ? h[5] : h[4];                              // H[r]
@@ -445,20 +461,20 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_near_kernel(StageArgs
     histogram_flush(args, d, histogram);
 }
 
-template <int L, int STATE>
+template <int L, int STATE, bool PRIORS>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t lds_bytes = Shape<L>::histogram_at(n_barcode) + histogram_bytes;
+    const size_t lds_bytes = Shape<L, PRIORS>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_near_kernel<L, STATE>), grid, dim3(Shape<L>::THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE, PRIORS>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_near_kernel<L, STATE, PRIORS>), grid, dim3(Shape<L, PRIORS>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L>
+template <int L, bool PRIORS>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2>(args, n_barcode, grid, histogram_bytes, stream); }
-    return args.input_flag ? launch_state<L, 1>(args, n_barcode, grid, histogram_bytes, stream)
-                           : launch_state<L, 0>(args, n_barcode, grid, histogram_bytes, stream);
+    if(!args.first_stage) { return launch_state<L, 2, PRIORS>(args, n_barcode, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<L, 1, PRIORS>(args, n_barcode, grid, histogram_bytes, stream)
+                           : launch_state<L, 0, PRIORS>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 }  // namespace near

@@ -29,7 +29,7 @@ namespace pair {
 
 constexpr int THREADS = 256;
 constexpr int FACTOR_ROWS = 129;
-constexpr float X_MAX = 2e-3f;                 // noise / winner: single precision is enough below this (pamld_near.hpp)
+constexpr float X_MAX = 3e-4f;                 // noise / winner: single precision is enough below this (pamld_near.hpp; up to 20 positions here)
 constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
 constexpr float SLOP = 1.0f + 1e-5f;
 // The bound sorts the positions by quality into four classes; n mismatches are charged to the cheapest classes first:

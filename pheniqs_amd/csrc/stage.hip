@@ -73,7 +73,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
                 const bool crossed = factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);
-                const int64_t threads = crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
+                const int64_t threads = listed ? pamld_near_block(host_decoder) : crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 static const int near_share = std::getenv("PHQ_GRID_SHARE_NEAR") ? std::atoi(std::getenv("PHQ_GRID_SHARE_NEAR")) : GRID_SHARE_NEAR;
                 const int64_t product_blocks = (paired || crossed) ? share(near_share) : (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);

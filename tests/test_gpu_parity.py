@@ -165,6 +165,22 @@ def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n,
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
 
 
+@pytest.mark.parametrize("length,count,spread", [(8, 96, 1.0), (8, 96, 3.0), (10, 96, 1.0), (6, 40, 1.5), (9, 64, 2.0), (8, 192, 1.0), (5, 20, 0.5)])
+def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread):
+    """Single index sets whose priors differ (what phq_adjust_prior leaves behind): the neighbour list kernel weighs the
+    listed barcodes and its bound by their priors over the nearest barcode's (pamld.cpp:66-79); 192 barcodes with their
+    weights do not fit a CU's LDS and stay with the product form kernel."""
+    rng = np.random.default_rng(700 + 10 * length + count)
+    words = synthetic.barcode_set(rng, count, length, min_distance=3 if length >= 6 else 2)
+    spec = {"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length])}
+    for k, record in enumerate(spec["sample"]["codec"].values()):
+        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+    job = capi.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 16, 77 + length)
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
+    assert int((got[0]["status"] == 0).sum()) > (1 << 15)
+
+
 def test_fast_mode_defers_only_a_small_fraction(oracle, torch_cuda):
     """The product form kernel finishes the clean reads itself; the worklist holds the ambiguous rest."""
     job, recipe = synthetic.config_job("C2")
