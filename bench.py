@@ -208,6 +208,7 @@ def parity_check(job, code, quality, flag, got, reads):
 
 CONFIG_TEXT = {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
                "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10",
+               "C4V": "sci-RNA-seq cellular [96x10, 196x(10+10)] (the vignette's second set) + UMI 8",
                "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
                "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}
 
@@ -395,7 +396,8 @@ def main():
             # the other BASELINE shapes that fit one GPU, kernel only like `value`, fewer steps
             line["shapes"] = {}
             for name, config, algorithm, reads in (("C3_pamld", "C3", "pamld", 100_000_000), ("C5_pamld", "C5", "pamld", 50_000_000),
-                                                   ("C4_pamld", "C4", "pamld", 50_000_000), ("C2_mdd", "C2", "mdd", 100_000_000)):
+                                                   ("C4_pamld", "C4", "pamld", 50_000_000), ("C4V_pamld", "C4V", "pamld", 50_000_000),
+                                                   ("C2_mdd", "C2", "mdd", 100_000_000)):
                 shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool)
                 sm = shape.measure(5, 2, 1, barrier)
                 line["shapes"][name] = {"workload": "%s: %d reads, %s, %s" % (config, reads, CONFIG_TEXT[config], algorithm.upper()),

@@ -68,9 +68,9 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
     return spec
 
 
-# BASELINE.json's C2..C5 plus two shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
+# BASELINE.json's C2..C5 (C4V: C4 with the 196 pairs of the reference's sci-RNA-seq vignette) plus shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
 # 8 + 8 nt in one two segment sample decoder (not every combination: pair i is word i of each list)
-CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10}
+CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10, "C4V": 11}
 
 
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
@@ -93,8 +93,9 @@ def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
         i7, i5 = barcode_set(rng, 96, 10), barcode_set(rng, 96, 10)
         spec = {"input segment cardinality": 3,
                 "sample": decoder_spec(algorithm, [i7, i5], ["1::10", "2::10"])}
-    elif name == "C4":      # sci-RNA-seq: cellular [96 x 10, 96 pairs (10 + 10)] + naive UMI 8
-        a, b, c = barcode_set(rng, 96, 10), barcode_set(rng, 96, 10), barcode_set(rng, 96, 10)
+    elif name in ("C4", "C4V"):      # sci-RNA-seq: cellular [96 x 10, 96 pairs (10 + 10)] + naive UMI 8; C4V: the vignette's 196 pairs
+        pairs = 96 if name == "C4" else 196
+        a, b, c = barcode_set(rng, 96, 10), barcode_set(rng, pairs, 10), barcode_set(rng, pairs, 10)
         spec = {"input segment cardinality": 3,
                 "molecular": [{"algorithm": "naive", "transform": {"token": ["0::8"]}}],
                 "cellular": [decoder_spec(algorithm, [a], ["0:8:18"]),

@@ -156,7 +156,7 @@ MODES = [capi.MODE_LITERAL, capi.MODE_FAST]
 @pytest.mark.parametrize("name,algorithm,n", [
     ("C2", "pamld", 1 << 16), ("C2", "mdd", 1 << 16),
     ("C3", "pamld", 3000), ("C3", "mdd", 1 << 14),
-    ("C4", "pamld", 1 << 14), ("C4", "mdd", 1 << 14),
+    ("C4", "pamld", 1 << 14), ("C4", "mdd", 1 << 14), ("C4V", "pamld", 1 << 14), ("C4V", "mdd", 1 << 14),
     ("C5", "pamld", 1 << 14), ("C5", "mdd", 1 << 14),
 ])
 def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n, mode):
