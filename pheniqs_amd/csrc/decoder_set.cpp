@@ -428,7 +428,7 @@ void DecoderSet::build_device_images() {
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
                c.barcode_length[0] >= 4 && c.barcode_length[0] <= NEAR_MAX_LENGTH && c.barcode_length[1] >= 4 && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
-                // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most one mismatch from
+                // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most two mismatches from
                 // one of its words — which must be all different in both segments — and per barcode its code bits and
                 // the distance to the nearest other barcode
                 const int32_t L = c.nucleotide_cardinality;
@@ -458,14 +458,34 @@ void DecoderSet::build_device_images() {
                         if(exact != NEAR_NO_BARCODE) { distinct = false; break; }                 // two barcodes share this segment word
                         exact = static_cast<uint16_t>(b);
                     }
-                    for(int32_t b = N - 1; b >= 0 && distinct; --b) {                             // the lowest ordinal last: it wins a shared neighbour
-                        for(int32_t j = 0; j < length; ++j) {
-                            for(uint32_t other = 0; other < 4; ++other) {
-                                const uint32_t l = (word_low[static_cast<size_t>(b)] & ~(1u << j)) | ((other & 1u) << j);
-                                const uint32_t h = (word_high[static_cast<size_t>(b)] & ~(1u << j)) | ((other >> 1) << j);
-                                uint16_t& slot = nearest[l | (h << length)];
-                                const bool taken_exactly = slot != NEAR_NO_BARCODE && word_low[slot] == l && word_high[slot] == h;
-                                if(!taken_exactly) { slot = static_cast<uint16_t>(b); }
+                    // every word up to two mismatches from a segment word names the barcode of the NEAREST one, the lowest
+                    // ordinal among equally near ones: distance 1 over distance 2, and within a distance the lowest ordinal last
+                    std::vector<uint8_t> reached(nearest.size(), 3);
+                    for(int32_t b = 0; b < N && distinct; ++b) { reached[word_low[static_cast<size_t>(b)] | (word_high[static_cast<size_t>(b)] << length)] = 0; }
+                    for(int32_t away = 1; away <= 2 && distinct; ++away) {
+                        for(int32_t b = N - 1; b >= 0; --b) {
+                            const uint32_t bl = word_low[static_cast<size_t>(b)], bh = word_high[static_cast<size_t>(b)];
+                            for(int32_t j = 0; j < length; ++j) {
+                                for(uint32_t other = 0; other < 4; ++other) {
+                                    const uint32_t l1 = (bl & ~(1u << j)) | ((other & 1u) << j);
+                                    const uint32_t h1 = (bh & ~(1u << j)) | ((other >> 1) << j);
+                                    if(l1 == bl && h1 == bh) { continue; }
+                                    if(away == 1) {
+                                        const size_t at = l1 | (h1 << length);
+                                        if(reached[at] >= 1) { reached[at] = 1; nearest[at] = static_cast<uint16_t>(b); }
+                                        continue;
+                                    }
+                                    for(int32_t i = j + 1; i < length; ++i) {
+                                        for(uint32_t second = 0; second < 4; ++second) {
+                                            const uint32_t l2 = (l1 & ~(1u << i)) | ((second & 1u) << i);
+                                            const uint32_t h2 = (h1 & ~(1u << i)) | ((second >> 1) << i);
+                                            if(((l2 ^ bl) | (h2 ^ bh)) >> i & 1u) {
+                                                const size_t at = l2 | (h2 << length);
+                                                if(reached[at] >= 2) { reached[at] = 2; nearest[at] = static_cast<uint16_t>(b); }
+                                            }
+                                        }
+                                    }
+                                }
                             }
                         }
                     }

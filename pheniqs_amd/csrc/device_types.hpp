@@ -122,7 +122,7 @@ struct DevDecoder {
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
     // paired barcode kernel only (pamld_pair.hpp; two segments of up to 10 nt whose words are all different, uniform
-    // priors): pair_table[s] = the table above for the words of segment s (key over the segment's positions, entry =
+    // priors): pair_table[s] = the table above — reaching two mismatches — for the words of segment s (key over the segment's positions, entry =
     // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance
     // to the nearest other barcode (at most 31), barcode_index[c]}
     // neighbour list kernel of two segment combinatorial sets (pamld_cross_near.hpp; equal segment lengths, barcodes in

@@ -9,15 +9,16 @@
 // barcode at least n = r(c) - k mismatches away, k = the read's own mismatches against c.  The kernel therefore scores
 // ONE barcode per read and bounds all the others:
 //   * c by two table lookups, one per segment (the tables of pamld_near.hpp: the word at most one mismatch from a
-//     segment word, 4^length entries of 16 bits in global memory); both segments must name the same barcode;
+//     segment word — here up to TWO mismatches: the nearest word's barcode, lowest ordinal among equals —, 4^length entries
+//     of 16 bits in global memory); both segments must name the same barcode;
 //   * P(r|c) and the all-match product A as single precision products of the per position factors, the factor picked by
 //     putting the position's mismatch flag into the LDS address (no select);
-//   * every other barcode is at most  A * 4^wild * rho20^a * rho30^b * rho36^c  where the n mismatches are charged to
-//     the positions in order of quality — those below Q20 for free, a of those below Q30, b below Q36, the rest c —
+//   * every other barcode is at most  A * 4^wild * rho12^a * rho20^b * rho25^c * rho30^d * rho36^e  where the n mismatches are
+//     charged to the positions in order of quality — those below Q12 for free, a of those below Q20, b below Q25, ... —
 //     `wild` counts the positions below Q4 (a mismatch there is MORE likely than a match, by at most 4), and all the
 //     counts come from byte parallel compares.
 // A read is finished under the certificate of pamld_near.hpp (1e-9 in the posterior); everything else — a third
-// mismatch, a base outside ACGT, many low quality positions, noise — goes to the product form kernel (pamld_wide.hpp
+// mismatch in a segment, a base outside ACGT, many low quality positions, noise — goes to the product form kernel (pamld_wide.hpp
 // for 17 to 32 nt, pamld_lut.hpp up to 16) as a consumer of this workgroup's worklist segment.
 // No per read tables: 12 KiB of LDS per workgroup, eight waves per SIMD.
 #pragma once
@@ -32,11 +33,16 @@ constexpr int FACTOR_ROWS = 129;
 constexpr float X_MAX = 3e-4f;                 // noise / winner: single precision is enough below this (pamld_near.hpp; up to 20 positions here)
 constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
 constexpr float SLOP = 1.0f + 1e-5f;
-// The bound sorts the positions by quality into four classes; n mismatches are charged to the cheapest classes first:
-// below Q20 for free, then rho(Q20) each for those below Q30, rho(Q30) below Q36, rho(Q36) for the rest
-// (rho = P(mismatch) / P(match) falls with the quality; the logarithms are rounded towards zero).
-constexpr int MARK[3] = {20, 30, 36};
-constexpr float LOG2_RHO[3] = {-6.6293f, -9.9643f, -11.9584f};
+// The bound sorts the positions by quality into six classes; n mismatches are charged to the cheapest classes first:
+// below Q12 for free, then rho(Q12) each for those below Q20, rho(Q20) below Q25, rho(Q25) below Q30, rho(Q30) below Q36,
+// rho(Q36) for the rest (rho = P(mismatch) / P(match) falls with the quality; the logarithms are rounded towards zero).
+// Measured on the model of the sci-RNA-seq shape (profiles/tools/sim/pair_certificate.py): three marks {20, 30, 36}
+// finish 87.3 % of the reads (82.3 % with 196 pairs), these five 91.0 % (89.1 %), and with tables that name a barcode
+// up to two mismatches per segment away 93.6 % (90.8 %).
+constexpr int MARKS = 5;
+constexpr int MARK[MARKS] = {12, 20, 25, 30, 36};
+constexpr float LOG2_RHO[MARKS] = {-3.8922f, -6.6293f, -8.3002f, -9.9643f, -11.9584f};
+constexpr int MOST_MISMATCHES = 4;            // of a finished read against its barcode: two per segment (the tables' reach)
 constexpr int WILD_QUALITY = 4;                // below it P(mismatch) > P(match), by at most 4 (Q1: 3.86)
 
 struct Layout {
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         uint32_t q7[G];
         uint32_t low = 0, high = 0, high_quality = 0;    // bit j = position j
         uint32_t not_strict = 0;
-        uint32_t below[3] = {0, 0, 0};         // positions below Q20, Q30, Q36
+        uint32_t below[MARKS] = {0, 0, 0, 0, 0};         // positions below each mark
         uint32_t wild = 0;
 #pragma unroll
         for(int w = 0; w < G; ++w) {
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             const uint32_t is_high = ((q7[w] + high_quality_addend) | in.quality[w]) & (0x80808080u & valid[w]);
             high_quality |= (gather(is_high >> 7) & 0xfu) << (4 * w);
 #pragma unroll
-            for(int m = 0; m < 3; ++m) { below[m] = __builtin_popcount(~(q7[w] + (128u - MARK[m]) * 0x01010101u) & (0x80808080u & valid[w])) + below[m]; }
+            for(int m = 0; m < MARKS; ++m) { below[m] = __builtin_popcount(~(q7[w] + (128u - MARK[m]) * 0x01010101u) & (0x80808080u & valid[w])) + below[m]; }
             wild = __builtin_popcount(~(q7[w] + (128u - WILD_QUALITY) * 0x01010101u) & (0x80808080u & valid[w])) + wild;
         }
         const bool all_strict = not_strict == 0;
@@ -182,11 +188,14 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
 
         // every other barcode: at least n = r(c) - k mismatches outside the read's own
         int needed = max(static_cast<int>(record.z) - k - static_cast<int>(below[0]), 0);
-        const int at20 = min(needed, static_cast<int>(below[1] - below[0]));
-        needed -= at20;
-        const int at30 = min(needed, static_cast<int>(below[2] - below[1]));
-        needed -= at30;
-        const float log2_bound = 2.0f * static_cast<float>(wild) + LOG2_RHO[0] * static_cast<float>(at20) + LOG2_RHO[1] * static_cast<float>(at30) + LOG2_RHO[2] * static_cast<float>(needed);
+        float log2_bound = 2.0f * static_cast<float>(wild);
+#pragma unroll
+        for(int m = 0; m + 1 < MARKS; ++m) {
+            const int charged = min(needed, static_cast<int>(below[m + 1] - below[m]));
+            needed -= charged;
+            log2_bound += LOG2_RHO[m] * static_cast<float>(charged);
+        }
+        log2_bound += LOG2_RHO[MARKS - 1] * static_cast<float>(needed);
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
         const float x_rest = others_count * __builtin_amdgcn_exp2f(log2_bound) * everything_matches * inverse_winner * SLOP;
         const float x_low = noise_over_prior * inverse_winner;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);       // 1 - posterior
         const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
-        const bool finished = all_strict && known && k <= 2 && winner > noise_floor && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
+        const bool finished = all_strict && known && k <= MOST_MISMATCHES && winner > noise_floor && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
                               fabs(confidence_margin) > 2e-9;
         const bool defer = !finished;
 
