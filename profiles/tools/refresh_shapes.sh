@@ -16,3 +16,5 @@ run c3 --config C3 --reads 50000000
 run c4 --config C4 --reads 50000000
 run c5 --config C5 --reads 50000000
 run literal --mode literal
+run c4v --config C4V --reads 50000000
+run priors --priors estimated
