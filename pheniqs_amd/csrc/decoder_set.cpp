@@ -425,7 +425,7 @@ void DecoderSet::build_device_images() {
                 d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
             }
-            if(c.all_strict && c.algorithm == Algorithm::PAMLD && d.uniform_prior && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
                c.barcode_length[0] >= 4 && c.barcode_length[0] <= NEAR_MAX_LENGTH && c.barcode_length[1] >= 4 && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
                 // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most two mismatches from
@@ -491,17 +491,26 @@ void DecoderSet::build_device_images() {
                     }
                 }
                 if(distinct) {
-                    std::vector<uint32_t> record(static_cast<size_t>(N) * 4, 0u);
+                    std::vector<uint32_t> record(static_cast<size_t>(N) * PAIR_RECORD_WORDS, 0u);
                     int32_t usable = 0;
+                    double all_priors = 0;
+                    for(double c0 : concentration) { all_priors += c0; }
                     for(int32_t b = 0; b < N; ++b) {
                         int radius = 31;
                         for(int32_t o = 0; o < N; ++o) {
                             if(o != b) { radius = std::min(radius, __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]))); }
                         }
-                        record[static_cast<size_t>(b) * 4] = low[static_cast<size_t>(b)];
-                        record[static_cast<size_t>(b) * 4 + 1] = high[static_cast<size_t>(b)];
-                        record[static_cast<size_t>(b) * 4 + 2] = static_cast<uint32_t>(radius);
-                        record[static_cast<size_t>(b) * 4 + 3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                        uint32_t* const entry = &record[static_cast<size_t>(b) * PAIR_RECORD_WORDS];
+                        entry[0] = low[static_cast<size_t>(b)];
+                        entry[1] = high[static_cast<size_t>(b)];
+                        entry[2] = static_cast<uint32_t>(radius);
+                        entry[3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                        // what scales the bound on every other barcode, and the noise term, in units of this barcode's prior
+                        const double own = concentration[static_cast<size_t>(b)];
+                        const float others = d.uniform_prior ? static_cast<float>(N - 1) : static_cast<float>((all_priors - own) / own) * (1.0f + 1e-6f);
+                        const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / own);
+                        std::memcpy(&entry[4], &others, sizeof(float));
+                        std::memcpy(&entry[5], &noise_over_prior, sizeof(float));
                         if(radius >= 6) { ++usable; }
                     }
                     for(int32_t s = 0; s < 2; ++s) {

@@ -536,10 +536,10 @@ int launch_range(const StageArgs& args, const DevDecoder& host_decoder, dim3 gri
     } else {
         if(host_decoder.nucleotide_cardinality == LO) {
             // behind the neighbour list kernels (pamld_near.hpp, pamld_pair.hpp): as a consumer of their lists; priors that
-            // differ only behind pamld_near.hpp (5 to 10 nt)
+            // differ from 5 nt up (what those two kernels take)
             if(args.worklist_role == 2) {
                 if(host_decoder.uniform_prior) { return launch_one<LO, true, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
-                if constexpr(LO >= NEAR_MIN_LENGTH && LO <= NEAR_MAX_LENGTH) { return launch_one<LO, false, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
+                if constexpr(LO >= NEAR_MIN_LENGTH) { return launch_one<LO, false, true>(args, host_decoder.n_barcode, grid, histogram_bytes, stream); }
                 else { return static_cast<int>(hipErrorInvalidValue); }
             }
             return host_decoder.uniform_prior ? launch_one<LO, true, false>(args, host_decoder.n_barcode, grid, histogram_bytes, stream)

@@ -11,6 +11,8 @@
 //   * c by two table lookups, one per segment (the tables of pamld_near.hpp: the word at most one mismatch from a
 //     segment word — here up to TWO mismatches: the nearest word's barcode, lowest ordinal among equals —, 4^length entries
 //     of 16 bits in global memory); both segments must name the same barcode;
+//   * priors enter through two numbers per barcode (host): the priors of all the others over c's, which scales the bound,
+//     and the noise term over c's prior;
 //   * P(r|c) and the all-match product A as single precision products of the per position factors, the factor picked by
 //     putting the position's mismatch flag into the LDS address (no select);
 //   * every other barcode is at most  A * 4^wild * rho12^a * rho20^b * rho25^c * rho30^d * rho36^e  where the n mismatches are
@@ -48,8 +50,8 @@ constexpr int WILD_QUALITY = 4;                // below it P(mismatch) > P(match
 struct Layout {
     static constexpr uint32_t FACTOR_AT = 0;                                   // FACTOR_ROWS x {match, mismatch} floats
     static constexpr uint32_t DEFERRED_AT = FACTOR_AT + 1040;
-    static constexpr uint32_t RECORD_AT = DEFERRED_AT + 16;                    // n_barcode x {low, high, radius, index}
-    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return RECORD_AT + static_cast<uint32_t>(n_barcode) * 16u; }
+    static constexpr uint32_t RECORD_AT = DEFERRED_AT + 16;                    // n_barcode x {low, high, radius, index, others, noise, -, -}
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return RECORD_AT + static_cast<uint32_t>(n_barcode) * (PAIR_RECORD_WORDS * 4u); }
 };
 
 typedef uint32_t Quad __attribute__((ext_vector_type(4)));
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         factor[2 * i + 1] = static_cast<float>(i < 128 ? d.mismatch_probability[i] : d.uniform_probability);
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
-    for(int w = threadIdx.x; w < d.n_barcode * 4; w += THREADS) { records[w] = d.pair_record[w]; }
+    for(int w = threadIdx.x; w < d.n_barcode * PAIR_RECORD_WORDS; w += THREADS) { records[w] = d.pair_record[w]; }
     histogram_clear(d, histogram);
     __syncthreads();
 
@@ -90,11 +92,9 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
     const int64_t tiles = (n + THREADS - 1) / THREADS;
     const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
     const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
-    const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);       // uniform priors
     const float noise_floor = static_cast<float>(d.random_barcode_probability) * SLOP;
     const double confidence_threshold = d.confidence_threshold;
     const uint32_t n_barcode = static_cast<uint32_t>(d.n_barcode);
-    const float others_count = static_cast<float>(d.n_barcode - 1);
     // the bytes of the positions a word holds (word w: positions 4 w .. 4 w + 3)
     uint32_t valid[G];
 #pragma unroll
@@ -167,7 +167,11 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         fetch(min(tile + gridDim.x, tiles - 1), next);
         const bool known = named0 == named1 && named0 < n_barcode;
         const uint32_t c = known ? named0 : 0u;
-        const Quad record = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * 16u);
+        const Quad record = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u));
+        // the priors of all other barcodes over c's (N - 1 when they are equal) and the noise term over c's prior (pamld.cpp:29,66)
+        const Quad weights = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u) + 16u);
+        const float others_count = __uint_as_float(weights.x);
+        const float noise_over_prior = __uint_as_float(weights.y);
         const uint32_t mismatches = ((low ^ record.x) | (high ^ record.y)) & full_mask;
         const int k = __popc(mismatches);
 

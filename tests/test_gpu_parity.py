@@ -181,6 +181,22 @@ def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread):
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
 
 
+@pytest.mark.parametrize("lengths,count,spread", [((8, 8), 96, 1.0), ((10, 10), 96, 1.0), ((10, 10), 196, 2.0), ((6, 9), 48, 0.5)])
+def test_paired_sets_with_priors(oracle, torch_cuda, lengths, count, spread):
+    """Unique dual index / ligation pairs whose priors differ: the paired kernel scales its bound by the other barcodes'
+    priors over the named one's and takes the noise term over that prior (pamld.cpp:29,66-86)."""
+    rng = np.random.default_rng(900 + lengths[0] + count)
+    first, second = synthetic.barcode_set(rng, count, lengths[0]), synthetic.barcode_set(rng, count, lengths[1])
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("pamld", [first, second], ["0::%d" % lengths[0], "1::%d" % lengths[1]], pairing="zip")}
+    for record in spec["sample"]["codec"].values():
+        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+    job = capi.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 15, 91 + count)
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
+    assert int((got[0]["status"] == 0).sum()) > (1 << 14)
+
+
 def test_fast_mode_defers_only_a_small_fraction(oracle, torch_cuda):
     """The product form kernel finishes the clean reads itself; the worklist holds the ambiguous rest."""
     job, recipe = synthetic.config_job("C2")
