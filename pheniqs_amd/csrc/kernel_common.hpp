@@ -296,6 +296,8 @@ int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim
 bool pamld_wide_supports(const DevDecoder& host_decoder);
 int pamld_wide_block(const DevDecoder& host_decoder);
 int launch_pamld_wide(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_wide_exact_supports(const DevDecoder& host_decoder);      // pamld_wide_exact.hip: fp64 tier behind it
+int launch_pamld_wide_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_cross_supports(const DevDecoder& host_decoder);
 int launch_pamld_cross(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_exact_supports(const DevDecoder& host_decoder);

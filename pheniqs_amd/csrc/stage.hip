@@ -124,6 +124,11 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
                     status = launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
+                } else if(long_words && pamld_wide_exact_supports(host_decoder)) {
+                    // the same for two word barcodes (pamld_wide_exact.hpp)
+                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                    status = launch_pamld_wide_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
+                    if(status != 0) { return status; }
                 }
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
                 return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
