@@ -1,6 +1,9 @@
 // extern "C" surface of libpheniqs_amd.so (declared in include/pheniqs_amd.h).  Exceptions stop here:
 // every entry point converts an Error into its reference ErrorCode (error.h:32-44) and stores the text.
 #include <cstdlib>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -225,8 +228,17 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
         if(batch_capacity <= 0) { throw phq::InternalError("batch capacity must be positive"); }
         std::vector<std::string> input;
         for(int32_t i = 0; i < n_input; ++i) { require(input_path[i], "input_path[i]"); input.emplace_back(input_path[i]); }
-        phq::Transcoder transcoder(set->impl, phq::TranscodePlan::explicit_files(set->impl.job(), input, sam_output_path), batch_capacity);
-        transcoder.run(*incoming_count, *incoming_pf_count);
+        const bool trace = std::getenv("PHQ_TRANSCODE_TRACE") != nullptr;
+        auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
+        double t1 = 0, t2 = 0;
+        {
+            phq::Transcoder transcoder(set->impl, phq::TranscodePlan::explicit_files(set->impl.job(), input, sam_output_path), batch_capacity);
+            t1 = now();
+            transcoder.run(*incoming_count, *incoming_pf_count);
+            t2 = now();
+        }
+        if(trace) { std::fprintf(stderr, "transcode call (s): set up %.3f run %.3f tear down %.3f\n", t1 - t0, t2 - t1, now() - t2); }
     });
 }
 

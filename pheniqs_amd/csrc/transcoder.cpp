@@ -680,6 +680,7 @@ struct Transcoder::Impl {
     std::vector<OutputSink> sink;
     int64_t capacity;
     std::vector<SegmentBatch> batch;              // per input feed
+    std::vector<SegmentBatch> ahead;              // the batch being read while `batch` is in work
     uint8_t* base;
     uint8_t* quality;
     uint8_t* flag;
@@ -690,6 +691,8 @@ struct Transcoder::Impl {
     Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
         for(auto& s : sink) { s.close(); }      // the staging planes belong to the set (DecoderSet::host_stage)
+        // what follows by itself — unmapping the input files and the batches' buffers — is page table work in the kernel:
+        // 26 + 17 ms after 4 M reads (a third of a report only run of that size); threads do not help, unmapping serialises
     }
 };
 
@@ -795,7 +798,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
 
     // f1: one reader thread per input feed (the reference has one producer thread per feed, feed.h:309-314); the
     // next batch is read while this one is staged, classified and written
-    std::vector<SegmentBatch> ahead(m.batch.size());
+    std::vector<SegmentBatch>& ahead = m.ahead;          // torn down with the other buffers (Impl::~Impl)
+    ahead.resize(m.batch.size());
     // decoding threads per feed: the feeds are read concurrently while the previous batch is being formatted; the
     // readers are the critical path (measured, 2 feeds on 16 host threads: 4 threads per feed 16.2 Mreads/s, 8: 19.6)
     int32_t parse_threads = std::max(1, host_threads() / std::max(1, n_feed));

@@ -35,6 +35,8 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as directory:
         out = os.path.join(directory, "out.sam") if target == "file" else target
         best = 1e9
         for _ in range(3):
+            if os.path.isfile(out):
+                os.unlink(out)
             t0 = time.perf_counter()
             s.transcode_fastq_to_sam(paths, out, 1 << 20)
             best = min(best, time.perf_counter() - t0)
