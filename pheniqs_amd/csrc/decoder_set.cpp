@@ -198,6 +198,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
             }
         }
     }
+    if(N <= list) { return out; }                            // the table alone (mdd_near.hpp): no lists of a set this small
     out.record.assign(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
     std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
     for(int32_t b = 0; b < N; ++b) {
@@ -424,6 +425,37 @@ void DecoderSet::build_device_images() {
                 d.near_table = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
                 d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
+            }
+            if(c.all_strict && c.algorithm == Algorithm::MDD && c.segment_cardinality == 1 && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
+               d.n_barcode >= 1 && d.n_barcode <= NEAR_MAX_BARCODES && d.distance_tolerance[0] <= 1 && c.quality_masking_threshold <= 128) {
+                // one lookup MDD (mdd_near.hpp): the same table — the word itself, else the lowest ordinal one mismatch away —
+                // and per barcode its code bits and index
+                const int32_t L = c.nucleotide_cardinality;
+                const int32_t N = d.n_barcode;
+                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
+                std::vector<uint32_t> record(static_cast<size_t>(N) * 4, 0u);
+                for(int32_t b = 0; b < N; ++b) {
+                    for(int32_t j = 0; j < L; ++j) {
+                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
+                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
+                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
+                    }
+                    record[static_cast<size_t>(b) * 4] = low[static_cast<size_t>(b)];
+                    record[static_cast<size_t>(b) * 4 + 1] = high[static_cast<size_t>(b)];
+                    record[static_cast<size_t>(b) * 4 + 2] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                }
+                // two barcodes with the same word: the reference's map keeps one of them for the exact match; not taken here
+                bool distinct = true;
+                for(int32_t b = 0; b < N && distinct; ++b) {
+                    for(int32_t o = b + 1; o < N; ++o) { if(low[static_cast<size_t>(b)] == low[static_cast<size_t>(o)] && high[static_cast<size_t>(b)] == high[static_cast<size_t>(o)]) { distinct = false; break; } }
+                }
+                if(distinct) {
+                    const NearTables tables = build_near_tables(low, high, L, std::vector<uint32_t>(static_cast<size_t>(N), 0u));
+                    d.near_table = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
+                    d.mdd_near_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                    d.mdd_near_ready = 1;
+                }
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&

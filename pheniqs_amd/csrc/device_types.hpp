@@ -122,6 +122,10 @@ struct DevDecoder {
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
+    // one lookup MDD (mdd_near.hpp; one segment of 5 to 10 nt, tolerance 0 or 1): near_table as above and per barcode
+    // {low plane, high plane, barcode index, -}
+    const uint32_t* mdd_near_record;
+    int32_t mdd_near_ready;
     // paired barcode kernel only (pamld_pair.hpp; two segments of up to 10 nt whose words are all different, uniform
     // priors): pair_table[s] = the table above — reaching two mismatches — for the words of segment s (key over the segment's positions, entry =
     // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance

@@ -138,6 +138,26 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
+            if(mode == MODE_FAST && args.result != nullptr && mdd_near_supports(host_decoder) && stage_uses_worklist(host_decoder, mode)) {
+                // one table lookup per read (mdd_near.hpp); the scan kernel on the few reads it cannot finish (same grid)
+                const int64_t near_tiles = (args.n_read + 255) / 256;
+                const int64_t near_blocks = share(GRID_SHARE_NEAR);
+                const dim3 near_grid(static_cast<unsigned>(near_tiles < near_blocks ? near_tiles : near_blocks));
+                StageArgs producer = args;
+                producer.worklist_role = 1;
+                producer.worklist_stride = static_cast<int32_t>((near_tiles + near_grid.x - 1) / near_grid.x * 256);
+                int status;
+                {
+                    Timed timed(timer, KERNEL_MDD_EXACT, stream);
+                    status = launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
+                }
+                if(status != 0) { return status; }
+                StageArgs consumer = producer;
+                consumer.worklist_role = 2;
+                Timed timed(timer, KERNEL_MDD, stream);
+                if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }
+                return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s);
+            }
             if(mode == MODE_FAST && mdd_fused_supports(host_decoder)) {
                 // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
                 Timed timed(timer, KERNEL_MDD, stream);

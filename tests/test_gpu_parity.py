@@ -197,6 +197,31 @@ def test_paired_sets_with_priors(oracle, torch_cuda, lengths, count, spread):
     assert int((got[0]["status"] == 0).sum()) > (1 << 14)
 
 
+@pytest.mark.parametrize("length,count,min_distance,tolerance,masking", [
+    (8, 96, 3, None, 0), (8, 96, 3, [0], 0), (8, 96, 3, None, 20), (6, 30, 2, None, 12), (5, 12, 3, None, 0), (7, 64, 3, None, 30),
+    (9, 96, 3, None, 0), (10, 200, 3, None, 25), (10, 96, 3, [0], 13), (8, 3, 3, None, 0), (8, 700, 1, None, 0)])
+def test_one_lookup_mdd(oracle, torch_cuda, length, count, min_distance, tolerance, masking):
+    """Single segment MDD with a tolerance of 0 or 1 is a function of the observed word (mdd.cpp:43-80): the exact match, else
+    the first barcode one mismatch away; the exact match comes before the quality masking, a masked read that is not a
+    barcode goes through the scan, and so do bases outside ACGT and reads shorter than the barcode."""
+    rng = np.random.default_rng(1300 + 10 * length + count)
+    words = synthetic.barcode_set(rng, count, length, min_distance=min_distance)
+    options = {"quality masking threshold": masking}
+    if tolerance is not None:
+        options["distance tolerance"] = tolerance
+    spec = {"input segment cardinality": 1, "sample": synthetic.decoder_spec("mdd", [words], ["0::%d" % length], **options)}
+    job = capi.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 16, 57 + length)
+    code[100:140, length - 1] = 0                                      # reads one base short
+    quality[100:140, length - 1] = 0
+    code[200:220] = 15                                                 # all N
+    code[300:320, 2] = 3                                               # an ambiguity code
+    quality[400:500] = 2                                               # everything masked, exact matches among them
+    for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
+        s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+    assert int((got[0]["status"] == 0).sum()) > (1 << 15)
+
+
 def test_fast_mode_defers_only_a_small_fraction(oracle, torch_cuda):
     """The product form kernel finishes the clean reads itself; the worklist holds the ambiguous rest."""
     job, recipe = synthetic.config_job("C2")
