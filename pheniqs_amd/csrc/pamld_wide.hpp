@@ -26,8 +26,10 @@ constexpr double DOMINANCE = 5e-4;            // others <= DOMINANCE * winner (p
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
-template <int G> struct Geometry {
-    static constexpr int THREADS = G == 5 ? 192 : 128;
+// NARROW: the 5 group shape on 128 lanes as well — for a consumer whose codec's histogram leaves 192 lane workgroups only
+// one per CU (196 barcodes: 84 KiB; 64 KiB on 128 lanes, two per CU)
+template <int G, bool NARROW = false> struct Geometry {
+    static constexpr int THREADS = (G == 5 && !NARROW) ? 192 : 128;
     static constexpr uint32_t ENTRY_STEP = THREADS * sizeof(float);
     static constexpr uint32_t GROUP_STEP = 16u * ENTRY_STEP;
 };
@@ -68,11 +70,11 @@ __host__ __device__ inline Layout layout_of(int groups, int threads, int padded_
 // G = groups of 4 positions = words of the plane row (plane stride = 4 G bytes, zero filled past the barcode)
 // CONSUMER: the kernel visits the reads an earlier tier (pamld_pair.hpp) left in this workgroup's worklist segment
 // instead of every read, and compacts what it defers itself back into the segment (pamld_lut.hpp).
-template <int G, bool CONSUMER>
-__global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageArgs args) {
-    constexpr int THREADS = Geometry<G>::THREADS;
-    constexpr uint32_t GROUP_STEP = Geometry<G>::GROUP_STEP;
-    constexpr uint32_t ENTRY_STEP = Geometry<G>::ENTRY_STEP;
+template <int G, bool CONSUMER, bool NARROW>
+__global__ __launch_bounds__((Geometry<G, NARROW>::THREADS)) void pamld_wide_kernel(StageArgs args) {
+    constexpr int THREADS = Geometry<G, NARROW>::THREADS;
+    constexpr uint32_t GROUP_STEP = Geometry<G, NARROW>::GROUP_STEP;
+    constexpr uint32_t ENTRY_STEP = Geometry<G, NARROW>::ENTRY_STEP;
     constexpr bool PERMUTED = THREADS == 128;
     constexpr int WORDS = (G + 3) / 4;        // words of 16 positions: 2
     static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
@@ -372,14 +374,26 @@ __global__ __launch_bounds__(Geometry<G>::THREADS) void pamld_wide_kernel(StageA
     histogram_flush(args, d, histogram);
 }
 
+template <int G, bool CONSUMER, bool NARROW>
+int launch_shape(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_wide_kernel<G, CONSUMER, NARROW>, prepared)) { return status; }
+    const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
+    const size_t lds_bytes = layout_of(G, Geometry<G, NARROW>::THREADS, padded).histogram_at + histogram_bytes;
+    hipLaunchKernelGGL((pamld_wide_kernel<G, CONSUMER, NARROW>), grid, dim3(Geometry<G, NARROW>::THREADS), lds_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
 template <int G, bool CONSUMER>
 int launch_role(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_wide_kernel<G, CONSUMER>, prepared)) { return status; }
-    const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
-    const size_t lds_bytes = layout_of(G, Geometry<G>::THREADS, padded).histogram_at + histogram_bytes;
-    hipLaunchKernelGGL((pamld_wide_kernel<G, CONSUMER>), grid, dim3(Geometry<G>::THREADS), lds_bytes, stream, args);
-    return static_cast<int>(hipGetLastError());
+    if constexpr(G == 5 && CONSUMER) {
+        // a consumer's workgroup size is its own business (it walks a worklist segment): narrower if that keeps two per CU
+        const int padded = (host_decoder.n_barcode + FOLD - 1) / FOLD * FOLD;
+        const size_t broad = layout_of(G, Geometry<G, false>::THREADS, padded).histogram_at + histogram_bytes;
+        const size_t narrow = layout_of(G, Geometry<G, true>::THREADS, padded).histogram_at + histogram_bytes;
+        if((160u * 1024u) / broad < 2 && (160u * 1024u) / narrow >= 2) { return launch_shape<G, CONSUMER, true>(args, host_decoder, grid, histogram_bytes, stream); }
+    }
+    return launch_shape<G, CONSUMER, false>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 template <int G>
