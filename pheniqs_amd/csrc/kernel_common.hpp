@@ -7,6 +7,8 @@
 #pragma once
 
 #include <atomic>
+#include <type_traits>
+#include <utility>
 
 #include <hip/hip_runtime.h>
 
@@ -24,6 +26,10 @@ template <typename T> __device__ __forceinline__ const PHQ_CONSTANT T* constant_
 }
 
 constexpr int BLOCK = 256;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the 32 bit chunks of a list mask kept in registers, by
+// their static number (the exact tiers, pamld_cross.hpp and pamld_wide_exact.hpp)
+template <typename F, int... C> __device__ __forceinline__ void for_each_chunk(F&& f, std::integer_sequence<int, C...>) { (f(std::integral_constant<int, C>{}), ...); }
 
 struct ReadState {
     bool qcfail;

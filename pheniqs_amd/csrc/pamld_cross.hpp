@@ -37,7 +37,6 @@ constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a top well inside the n
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
 constexpr int THREADS = 256;
 constexpr int TABLE_REGISTERS = CROSS_MAX_UNIQUE / 64;
-constexpr int EXACT_SINGLE_LIST = 64;            // list entries per lane of the long single segment exact tier
 
 __host__ __device__ constexpr uint32_t low_bit(int position) { return 8u * (position >> 2) + 2u + (position & 3); }
 __host__ __device__ constexpr uint32_t high_bit(int position) { return (low_bit(position) + 4u) & 31u; }
@@ -483,43 +482,33 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 //     over all barcodes is not reproduced bit for bit, so a confidence within 1e-12 of its threshold is left to
 //     the literal kernel — the only reads it still sees).
 // UNIQUE = distinct words a segment may hold: CROSS_MAX_UNIQUE for the combinatorial sets; a single segment set (a
-// codec that is not combinatorial, its barcode taken as one word of up to 16 nt) may hold EXACT_SINGLE_UNIQUE, its
-// lists then stop at EXACT_SINGLE_LIST entries and a read with more words that close to the maximum (ties of a read
-// without information) goes on to the literal kernel.
+// codec that is not combinatorial, its barcode taken as one word of up to 16 nt) may hold EXACT_SINGLE_UNIQUE.
 // PRIORS (single segment sets only): the barcodes' priors differ, every word's probability carries its prior through
 // the sum, the maximum and the list, as the reference's loop does (pamld.cpp:66-79).
 //
-// Short lists (UNIQUE == CROSS_MAX_UNIQUE, the common case): a word's P is not multiplied up position by position but
-// read from per read fp64 tables, one of 16 entries per group of 4 positions ([group][entry][lane] in the dynamic LDS
-// block behind the histogram, built once per read and segment: 28 multiplications a group) — G table reads and G - 1
-// multiplications a word instead of 4 G of each (the products are associated by group: ~1e-16, far inside the 1e-10
-// window); and the list is a bit mask of UNIQUE bits in registers, the word ordinal being wave uniform.  Measured on
-// C2 (1.4 M reads reach the tier): 0.31 -> see DESIGN.md.
-constexpr int EXACT_TABLE_LANES = 128;        // lanes of a workgroup of the table form: 16 KiB of tables per group of 4 positions
-__host__ __device__ constexpr int exact_lanes(int unique) { return unique == CROSS_MAX_UNIQUE ? EXACT_TABLE_LANES : THREADS; }
-__host__ __device__ constexpr size_t exact_table_bytes(int groups, int unique) {
-    return unique == CROSS_MAX_UNIQUE ? static_cast<size_t>(groups) * 16u * sizeof(double) * EXACT_TABLE_LANES : 0u;
-}
+// A word's P is not multiplied up position by position but read from per read fp64 tables, one of 16 entries per group
+// of 4 positions ([group][entry][lane] in the dynamic LDS block behind the histogram, built once per read and segment:
+// 28 multiplications a group) — G table reads and G - 1 multiplications a word instead of 4 G of each (the products are
+// associated by group: ~1e-16, far inside the 1e-10 window); and the list is a bit mask of UNIQUE bits in registers, the
+// word ordinal being wave uniform.  (Round 1 multiplied the factors up and kept per lane lists of ordinals in LDS:
+// 53 instructions per read and word against 27.)
+constexpr int EXACT_TABLE_LANES = 128;        // lanes of a workgroup: 16 KiB of tables per group of 4 positions
+__host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * 16u * sizeof(double) * EXACT_TABLE_LANES; }
 
 template <int G, int S, int UNIQUE, bool PRIORS>
-__global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(StageArgs args) {
+__global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(StageArgs args) {
     static_assert(UNIQUE == CROSS_MAX_UNIQUE || S == 1, "long word lists are for single segment sets");
     static_assert(!PRIORS || S == 1, "priors by word are for single segment sets");
-    constexpr bool TABLES = UNIQUE == CROSS_MAX_UNIQUE;
-    constexpr int LANES = exact_lanes(UNIQUE);
-    constexpr int MASK_WORDS = CROSS_MAX_UNIQUE / 32;
-    static_assert(MASK_WORDS == 4, "the scan below names the four chunks of a list mask");
-    constexpr int UNIQUE_REGISTERS = TABLES ? 1 : UNIQUE / 64;
-    constexpr int LIST = EXACT_SINGLE_LIST;
-    typedef typename std::conditional<(UNIQUE > 256), uint16_t, uint8_t>::type Ordinal;
-    __shared__ Ordinal near_list[TABLES ? 1 : S * LIST * LANES];              // [segment][entry][lane] word ordinals (long lists)
+    static_assert(UNIQUE % 32 == 0, "whole mask words");
+    constexpr int LANES = EXACT_TABLE_LANES;
+    constexpr int MASK_WORDS = UNIQUE / 32;
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
     __shared__ uint32_t group_start[EXACT_GROUP_MAX + 1];                     // prefix sums of the group's segment counts
     __shared__ uint32_t group_kept[EXACT_GROUP_MAX];                          // reads left in each segment for the literal tier
     // what the candidate walk indexes per lane, out of LDS instead of chains of dependent global loads: the distinct words,
     // and for a single segment the barcode of each word
-    __shared__ uint32_t lds_word[S * CROSS_MAX_UNIQUE];
+    __shared__ uint32_t lds_word[S == 1 ? UNIQUE : S * CROSS_MAX_UNIQUE];
     __shared__ int32_t lds_ordinal[S == 1 ? UNIQUE : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
@@ -531,9 +520,7 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
         cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
         cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
     }
-    if(UNIQUE == CROSS_MAX_UNIQUE) {
-        for(int w = threadIdx.x; w < S * CROSS_MAX_UNIQUE; w += LANES) { lds_word[w] = d.cross_words[w]; }
-    }
+    for(int w = threadIdx.x; w < (S == 1 ? UNIQUE : S * CROSS_MAX_UNIQUE); w += LANES) { lds_word[w] = d.cross_words[w]; }
     if(S == 1) {
         for(int w = threadIdx.x; w < UNIQUE; w += LANES) { lds_ordinal[w] = w < d.cross_unique[0] ? d.cross_ordinal[w * d.cross_stride[0]] : 0; }
     }
@@ -558,7 +545,6 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
     const int64_t n = static_cast<int64_t>(group_start[EXACT_GROUP_MAX]);
     const int64_t tiles = (n + LANES - 1) / LANES;
 
-    uint32_t word_table[S][UNIQUE_REGISTERS];
     int first_word[S];
     int length[S];
     uint32_t byte_shift[S];
@@ -583,17 +569,11 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
             const int valid = length[s] - 4 * g;
             byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
         }
-#pragma unroll
-        for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
-            const int w = 64 * v + static_cast<int>(threadIdx.x & 63);
-            word_table[s][v] = !TABLES && w < unique[s] ? d.cross_words[s * CROSS_MAX_UNIQUE + w] : 0u;
-        }
     }
-    // the table form: this lane's column of the per read tables, behind the histogram in the dynamic block
+    // this lane's column of the per read tables, behind the histogram in the dynamic block
     double* const group_table = reinterpret_cast<double*>(lds_raw + ((static_cast<size_t>(histogram_words(d)) * sizeof(unsigned long long) + 15u) & ~static_cast<size_t>(15u))) + threadIdx.x;
     const PHQ_CONSTANT uint32_t* const word_list = constant_cast(d.cross_words);
     const int64_t stride = d.plane_stride;
-    constexpr bool weighted = false;           // priors that differ: pamld_cross_exact_weighted_kernel
     constexpr double near = 1.0 - 1e-10;
     const double uniform_concentration = d.concentration[0];          // !PRIORS: every barcode's prior is this one
     const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
@@ -627,10 +607,9 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
         uint32_t observed[S];
         uint32_t outside[S];
         uint32_t high_quality[S];
-        int near_count[S];                     // entries of this lane's column of near_list
-        uint32_t list_mask[S][MASK_WORDS];     // the table form's list: bit u of the segment's mask = word u is listed
+        int near_count[S];                     // listed words
+        uint32_t list_mask[S][MASK_WORDS];     // the list: bit u of the segment's mask = word u is listed
         double sum_all = 1.0;                  // product of the per segment sums = sum over every barcode of P(r|b)
-        double listed_all = 1.0;               // the same over the listed words only
         bool defer = false;
 
 #pragma unroll
@@ -662,10 +641,8 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
             }
             double top = 0;
             double sum = 0;
-            double listed = 0;                     // the sum over the listed words
             int count = 0;
-            bool overflow = false;
-            if constexpr(TABLES) {
+            {
                 // this read's tables of the segment: entry m of group g = product over the group's positions of the
                 // match (bit clear) or mismatch (bit set) factor
 #pragma unroll
@@ -702,7 +679,9 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
                     }
                     return p;
                 };
-                uint32_t chunk_mask[MASK_WORDS] = {0u, 0u, 0u, 0u};
+                uint32_t chunk_mask[MASK_WORDS];
+#pragma unroll
+                for(int e = 0; e < MASK_WORDS; ++e) { chunk_mask[e] = 0u; }
                 const PHQ_CONSTANT uint32_t* const words = word_list + s * CROSS_MAX_UNIQUE;
                 auto scan_chunk = [&](auto which) {
                     constexpr int c = decltype(which)::value;
@@ -728,48 +707,13 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
                     for(; k < here; ++k) { visit(32 * c + k, 1u << k); }
                     chunk_mask[c] = current;
                 };
-                scan_chunk(std::integral_constant<int, 0>{});
-                scan_chunk(std::integral_constant<int, 1>{});
-                scan_chunk(std::integral_constant<int, 2>{});
-                scan_chunk(std::integral_constant<int, 3>{});
+                for_each_chunk(scan_chunk, std::make_integer_sequence<int, MASK_WORDS>{});
 #pragma unroll
                 for(int e = 0; e < MASK_WORDS; ++e) { list_mask[s][e] = chunk_mask[e]; count += __popc(chunk_mask[e]); }
-            } else {
-            auto probability_of = [&](uint32_t word) {
-                const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
-                double p = 1.0;
-#pragma unroll
-                for(int j = 0; j < 4 * G; ++j) {
-                    p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
-                }
-                return p;
-            };
-            // one pass: the sum, the maximum, and a list that always holds every word within 1e-10 of the running
-            // maximum (it is emptied when a new maximum clears the old one by more than that; words that crept in
-            // while the maximum was lower are harmless extras: the literal evaluation below decides)
-#pragma unroll
-            for(int v = 0; v < UNIQUE_REGISTERS; ++v) {
-                const int last = min(unique[s], 64 * (v + 1));
-                for(int u = 64 * v; u < last; ++u) {
-                    double p = probability_of(__builtin_amdgcn_readlane(word_table[s][v], u - 64 * v));
-                    if(PRIORS) { p *= d.concentration[d.cross_ordinal[u]]; }            // wave uniform: scalar loads
-                    sum += p;
-                    if(p * near > top) { count = 0; listed = 0; overflow = false; }
-                    if(p >= top * near) {
-                        if(count < LIST) {
-                            near_list[(s * LIST + count) * LANES + threadIdx.x] = static_cast<Ordinal>(u);
-                            ++count;
-                        } else { overflow = true; }
-                        listed += p;
-                    }
-                    top = fmax(top, p);
-                }
             }
-            }
-            if(!(top > 0) || overflow) { defer = true; count = 0; }
+            if(!(top > 0)) { defer = true; count = 0; }
             near_count[s] = count;
             sum_all *= sum;
-            listed_all *= listed;
         }
 
         // the listed word of segment s at or after ordinal `from` (table form), -1 when there is none
@@ -789,15 +733,15 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
             int choice[S];                         // long lists: the entry; table form: the word's ordinal
             bool more = true;
 #pragma unroll
-            for(int s = 0; s < S; ++s) { choice[s] = TABLES ? next_listed(s, 0) : 0; more = more && near_count[s] > 0; }
+            for(int s = 0; s < S; ++s) { choice[s] = next_listed(s, 0); more = more && near_count[s] > 0; }
             while(more) {
                 int flat = 0;
                 uint32_t flags[S];
 #pragma unroll
                 for(int s = 0; s < S; ++s) {
-                    const int u = TABLES ? choice[s] : static_cast<int>(near_list[(s * LIST + choice[s]) * LANES + threadIdx.x]);
+                    const int u = choice[s];
                     flat += u * radix[s];
-                    const uint32_t word = TABLES ? lds_word[s * CROSS_MAX_UNIQUE + u] : d.cross_words[s * CROSS_MAX_UNIQUE + u];
+                    const uint32_t word = lds_word[s * CROSS_MAX_UNIQUE + u];
                     flags[s] = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
                 }
                 body(flat, flags);
@@ -805,31 +749,14 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
 #pragma unroll
                 for(int s = S - 1; s >= 0; --s) {
                     if(carry) {
-                        if(TABLES) {
-                            const int next = next_listed(s, choice[s] + 1);
-                            if(next < 0) { choice[s] = next_listed(s, 0); } else { choice[s] = next; carry = false; }
-                        } else {
-                            ++choice[s];
-                            if(choice[s] >= near_count[s]) { choice[s] = 0; } else { carry = false; }
-                        }
+                        const int next = next_listed(s, choice[s] + 1);
+                        if(next < 0) { choice[s] = next_listed(s, 0); } else { choice[s] = next; carry = false; }
                     }
                 }
                 more = !carry;
             }
         };
-        // P(r|b) of a combination as the product of the fp64 factor rows
-        auto product_of = [&](const uint32_t (&flags)[S]) {
-            double p = 1.0;
-#pragma unroll
-            for(int s = 0; s < S; ++s) {
-#pragma unroll
-                for(int j = 0; j < 4 * G; ++j) {
-                    p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags[s] >> low_bit(j)) & 1u) * 8u));
-                }
-            }
-            return p;
-        };
-        // ... and literally: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164)
+        // P(r|b) of a combination literally: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164)
         auto literal_of = [&](const uint32_t (&flags)[S]) {
             double sigma = 0;
             double compensation = 0;
@@ -852,28 +779,15 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
         int best = 0x7fffffff;
         double best_conditional = -1.0;
         double best_p = -1.0;                  // prior * P(r|b) of the winner, literal
-        double weighted_sum = 0;               // sum over the listed combinations of prior * P(r|b)
         uint32_t best_flags[S];
 #pragma unroll
         for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
         bool any_candidate = true;
 #pragma unroll
         for(int s = 0; s < S; ++s) { any_candidate = any_candidate && near_count[s] > 0; }
-        double weighted_top = 0;
-        if(weighted) {
-            for_each_combination([&](int flat, const uint32_t (&flags)[S]) {
-                const double p = product_of(flags) * d.concentration[d.cross_ordinal[flat]];
-                weighted_sum += p;
-                weighted_top = fmax(weighted_top, p);
-            });
-            // what the lists leave out, at most: every unlisted combination at the largest prior
-            const double left_out = d.cross_prior_max * (sum_all - listed_all);
-            if(!(left_out <= 1e-12 * (weighted_sum + d.adjusted_noise_probability)) || !(weighted_top > 0)) { defer = true; }
-        }
         for_each_combination([&](int flat, const uint32_t (&flags)[S]) {
             const int b = S == 1 ? lds_ordinal[S == 1 ? flat / radix[0] : 0] : d.cross_ordinal[flat];
-            const double prior = (weighted || PRIORS) ? d.concentration[b] : uniform_concentration;
-            if(weighted && !(product_of(flags) * prior >= weighted_top * (1.0 - 1e-10))) { return; }      // cannot be the argmax
+            const double prior = PRIORS ? d.concentration[b] : uniform_concentration;
             const double conditional = literal_of(flags);
             const double p = conditional * prior;                                  // pamld.cpp:66
             if(p > best_p || (p == best_p && b < best)) {                          // strict '>' in barcode order
@@ -893,7 +807,7 @@ __global__ __launch_bounds__(exact_lanes(UNIQUE)) void pamld_cross_exact_kernel(
             distance += __popc(best_flags[s]);
             hq_distance += __popc(best_flags[s] & high_quality[s]);
         }
-        const double total = (weighted ? weighted_sum : PRIORS ? sum_all : sum_all * d.concentration[0]) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+        const double total = (PRIORS ? sum_all : sum_all * d.concentration[0]) + d.adjusted_noise_probability;   // pamld.cpp:61-86
         double confidence = best_p / total;                                          // pamld.cpp:92
         const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
         if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
@@ -1257,13 +1171,13 @@ inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_d
 // a single segment set: more than CROSS_MAX_UNIQUE words and / or priors that differ
 template <int G, int S, int UNIQUE, bool PRIORS>
 int launch_exact_form(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G, UNIQUE);
+    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G);
     if(bytes > 64u * 1024u) {
         static std::atomic<uint64_t> prepared{0};
         // at most 32 KiB of histogram + 64 KiB of tables; the kernel also has ~5 KiB of static LDS
         if(const int status = allow_large_lds(&pamld_cross_exact_kernel<G, S, UNIQUE, PRIORS>, prepared, 128 * 1024)) { return status; }
     }
-    hipLaunchKernelGGL((pamld_cross_exact_kernel<G, S, UNIQUE, PRIORS>), grid, dim3(exact_lanes(UNIQUE)), bytes, stream, args);
+    hipLaunchKernelGGL((pamld_cross_exact_kernel<G, S, UNIQUE, PRIORS>), grid, dim3(EXACT_TABLE_LANES), bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

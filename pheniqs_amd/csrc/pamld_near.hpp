@@ -59,10 +59,12 @@ constexpr float SLOP = 1.0f + 1e-5f;           // single precision rounding of t
 // barcode over c's, 64 bytes more per barcode.  Beside two 512 lane workgroups' tables (64 KiB each) that no longer fits
 // a CU, so the two group shapes then run ONE workgroup of 1024 lanes per CU (measured with uniform priors: 4 % slower
 // than two of 512), its tables laid out [wave][group] so that a group is still reached through the offset field.
-template <int L, bool PRIORS = false> struct Shape {
+// BIG: a codec whose records alone push two 512 lane workgroups out of a CU (more than ~120 barcodes of 5 to 8 nt) takes the
+// same 1024 lane shape.
+template <int L, bool PRIORS = false, bool BIG = false> struct Shape {
     static_assert(L >= 5 && L <= 10, "two or three groups of 4 positions");
     static constexpr int G = (L + 3) / 4;
-    static constexpr bool WIDE = PRIORS && G == 2;
+    static constexpr bool WIDE = (PRIORS || BIG) && G == 2;
     static constexpr int FIELD = near_field_bits(L);
     static constexpr int PER_WORD = 32 / FIELD;
     static constexpr int LIST = near_list(L);
@@ -102,9 +104,9 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 // STATE: where a read's carried state comes from — 0 the first stage of a job without input flags (nothing to load),
 // 1 the first stage with flag bytes, 2 a later stage (the status word).  A template parameter so that the loads of
 // the prefetch sit in straight line code: behind a branch the compiler can no longer count them and waits for all.
-template <int L, int STATE, bool PRIORS>
-__global__ __launch_bounds__((Shape<L, PRIORS>::THREADS)) void pamld_near_kernel(StageArgs args) {
-    typedef Shape<L, PRIORS> Layout;
+template <int L, int STATE, bool PRIORS, bool BIG>
+__global__ __launch_bounds__((Shape<L, PRIORS, BIG>::THREADS)) void pamld_near_kernel(StageArgs args) {
+    typedef Shape<L, PRIORS, BIG> Layout;
     constexpr int G = Layout::G;
     constexpr int THREADS = Layout::THREADS;
     constexpr int FIELD = Layout::FIELD;
@@ -170,6 +172,7 @@ __global__ __launch_bounds__((Shape<L, PRIORS>::THREADS)) void pamld_near_kernel
     uint32_t* const carry = args.carry + static_cast<int64_t>(blockIdx.x) * CARRY_PLANES * carry_stride;
     const int hq_threshold = d.high_quality_distance_threshold;
     const bool multiplexing = d.multiplexing != 0;
+    const bool lds_bins = d.use_lds_histogram != 0;          // else the launch defers the classified reads' counters (StageArgs::defer_counters)
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const Inputs in = next;
         const int64_t first = tile * THREADS;
@@ -421,7 +424,9 @@ __global__ __launch_bounds__((Shape<L, PRIORS>::THREADS)) void pamld_near_kernel
                     atomicAdd(&histogram[word + FIELD_CONFIDENCE_HIGH], static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
                 }
             } else {
-                atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u);      // qc-fail half (pamld.cpp:104-106)
+                // qc-fail half (pamld.cpp:104-106); a codec too large for a workgroup histogram counts it in global memory (rare)
+                if(lds_bins) { atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u); }
+                else { atomicAdd(&args.stats[d.stats_offset + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE], 1ull); }
                 if(!args.defer_counters) {
                     atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
                     if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }
@@ -461,20 +466,27 @@ __global__ __launch_bounds__((Shape<L, PRIORS>::THREADS)) void pamld_near_kernel
     histogram_flush(args, d, histogram);
 }
 
-template <int L, int STATE, bool PRIORS>
+template <int L, int STATE, bool PRIORS, bool BIG>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t lds_bytes = Shape<L, PRIORS>::histogram_at(n_barcode) + histogram_bytes;
+    const size_t lds_bytes = Shape<L, PRIORS, BIG>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE, PRIORS>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_near_kernel<L, STATE, PRIORS>), grid, dim3(Shape<L, PRIORS>::THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE, PRIORS, BIG>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_near_kernel<L, STATE, PRIORS, BIG>), grid, dim3(Shape<L, PRIORS, BIG>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L, bool PRIORS>
+template <int L, bool PRIORS, bool BIG>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2, PRIORS>(args, n_barcode, grid, histogram_bytes, stream); }
-    return args.input_flag ? launch_state<L, 1, PRIORS>(args, n_barcode, grid, histogram_bytes, stream)
-                           : launch_state<L, 0, PRIORS>(args, n_barcode, grid, histogram_bytes, stream);
+    if(!args.first_stage) { return launch_state<L, 2, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<L, 1, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream)
+                           : launch_state<L, 0, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream);
+}
+
+// the 1024 lane shape for the two group lengths when two 512 lane workgroups with this codec's records (and histogram)
+// no longer fit a CU
+template <int L>
+inline bool wants_big(int n_barcode, size_t histogram_bytes) {
+    return Shape<L, false, false>::G == 2 && 2 * (Shape<L, false, false>::histogram_at(n_barcode) + histogram_bytes) > 160u * 1024u;
 }
 
 }  // namespace near

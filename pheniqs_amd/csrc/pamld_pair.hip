@@ -5,7 +5,7 @@ namespace phq {
 
 bool pamld_pair_supports(const DevDecoder& host_decoder) {
     const int words = host_decoder.plane_stride / 4;
-    return host_decoder.algorithm == 1 && host_decoder.pair_ready != 0 && host_decoder.use_lds_histogram != 0 &&
+    return host_decoder.algorithm == 1 && host_decoder.pair_ready != 0 && (host_decoder.use_lds_histogram != 0 || count_results_supports(host_decoder)) &&
            words >= 2 && words <= 8 && host_decoder.nucleotide_cardinality <= 32 &&
            (pamld_lut_supports(host_decoder) || pamld_wide_supports(host_decoder));
 }

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
     uint32_t pending_read = 0;
     const int hq_threshold = d.high_quality_distance_threshold;
     const bool multiplexing = d.multiplexing != 0;
+    const bool lds_bins = d.use_lds_histogram != 0;          // else the launch defers the classified reads' counters (StageArgs::defer_counters)
     for(int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const Inputs in = next;
         const int64_t first = tile * THREADS;
@@ -243,7 +244,9 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
                     atomicAdd(&histogram[word + FIELD_CONFIDENCE_HIGH], static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
                 }
             } else {
-                atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u);      // qc-fail half (pamld.cpp:104-106)
+                // qc-fail half (pamld.cpp:104-106); a codec too large for a workgroup histogram counts it in global memory (rare)
+                if(lds_bins) { atomicAdd(&low_words[2 * (STAT_JOB_WORDS + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE)], 1u); }
+                else { atomicAdd(&args.stats[d.stats_offset + (c + 1u) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE], 1ull); }
                 if(!args.defer_counters) {
                     atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
                     if(k) { atomicAdd(&low_words[2 * (word + FIELD_DISTANCE)], static_cast<uint32_t>(k)); }

@@ -1,4 +1,4 @@
-// Exact tier behind the two word product form (pamld_wide_exact.hpp): ACGT barcodes of 17 to 32 nt, up to 256 of them.
+// Exact tier behind the two word product form (pamld_wide_exact.hpp): ACGT barcodes of 17 to 32 nt, up to 512 of them.
 #include "pamld_wide_exact.hpp"
 
 namespace phq {

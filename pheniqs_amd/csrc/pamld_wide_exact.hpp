@@ -26,7 +26,7 @@ namespace phq {
 namespace wide {
 
 constexpr int EXACT_LANES = 64;
-constexpr int EXACT_MAX_BARCODES = 256;       // one list bit each: eight mask registers
+constexpr int EXACT_MAX_BARCODES = 512;       // one list bit each: sixteen mask registers (what the wide product form takes)
 constexpr int EXACT_MASK_WORDS = EXACT_MAX_BARCODES / 32;
 __host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * 8u * sizeof(double) * EXACT_LANES; }      // two pair tables of four entries per group
 
@@ -34,7 +34,6 @@ template <int G>
 __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs args) {
     constexpr int WORDS = 2;
     static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
-    static_assert(EXACT_MASK_WORDS == 8, "the scan below names the eight chunks of the list mask");
     static_assert(EXACT_LANES * sizeof(double) == 512, "an entry of a table is 512 bytes");
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
@@ -152,7 +151,9 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
         // harmless extras: the literal evaluation below decides)
         double top = 0;
         double sum = 0;
-        uint32_t list_mask[EXACT_MASK_WORDS] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        uint32_t list_mask[EXACT_MASK_WORDS];
+#pragma unroll
+        for(int e = 0; e < EXACT_MASK_WORDS; ++e) { list_mask[e] = 0u; }
         auto scan_chunk = [&](auto which) {
             constexpr int c = decltype(which)::value;
             if(32 * c >= n_barcode) { return; }                                         // wave uniform
@@ -176,14 +177,7 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
             for(; k < here; ++k) { visit(32 * c + k, 1u << k); }
             list_mask[c] = current;
         };
-        scan_chunk(std::integral_constant<int, 0>{});
-        scan_chunk(std::integral_constant<int, 1>{});
-        scan_chunk(std::integral_constant<int, 2>{});
-        scan_chunk(std::integral_constant<int, 3>{});
-        scan_chunk(std::integral_constant<int, 4>{});
-        scan_chunk(std::integral_constant<int, 5>{});
-        scan_chunk(std::integral_constant<int, 6>{});
-        scan_chunk(std::integral_constant<int, 7>{});
+        for_each_chunk(scan_chunk, std::make_integer_sequence<int, EXACT_MASK_WORDS>{});
         bool defer = !(top > 0);
 
         // the listed barcode at or after ordinal `from`, -1 when there is none

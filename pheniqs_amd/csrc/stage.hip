@@ -67,8 +67,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // ... and long barcodes that are not combinatorial through the two word product form
                 // ... and a codec of a handful of barcodes through the kernel without tables (pamld_tiny.hip)
                 const bool tiny = pamld_tiny_supports(host_decoder);
-                const bool listed = !tiny && args.result != nullptr && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
-                const bool paired = !tiny && !listed && args.result != nullptr && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
+                const bool listed = !tiny && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
+                const bool paired = !tiny && !listed && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
