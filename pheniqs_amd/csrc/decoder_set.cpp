@@ -457,7 +457,8 @@ void DecoderSet::build_device_images() {
                     d.mdd_near_ready = 1;
                 }
             }
-            if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
+            const bool paired_mdd = c.algorithm == Algorithm::MDD && c.quality_masking_threshold <= 128;
+            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors)) || paired_mdd) && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
                c.barcode_length[0] >= 4 && c.barcode_length[0] <= NEAR_MAX_LENGTH && c.barcode_length[1] >= 4 && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
                 // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most two mismatches from
@@ -551,7 +552,8 @@ void DecoderSet::build_device_images() {
                         d.pair_length[s] = c.barcode_length[static_cast<size_t>(s)];
                     }
                     d.pair_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
-                    d.pair_ready = 2 * usable >= N ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
+                    d.pair_ready = (c.algorithm == Algorithm::PAMLD && 2 * usable >= N) ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
+                    d.mdd_pair_ready = paired_mdd ? 1 : 0;
                 }
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {

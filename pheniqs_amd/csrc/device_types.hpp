@@ -126,6 +126,7 @@ struct DevDecoder {
     // {low plane, high plane, barcode index, -}
     const uint32_t* mdd_near_record;
     int32_t mdd_near_ready;
+    int32_t mdd_pair_ready;               // an MDD codec of two segments with pair_table / pair_record (mdd_near.hpp, mdd_pair_kernel)
     // paired barcode kernel only (pamld_pair.hpp; two segments of up to 10 nt whose words are all different, uniform
     // priors): pair_table[s] = the table above — reaching two mismatches — for the words of segment s (key over the segment's positions, entry =
     // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance

@@ -282,6 +282,8 @@ bool mdd_scan_supports(const DevDecoder& host_decoder);
 int launch_mdd_scan(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_near_supports(const DevDecoder& host_decoder);      // mdd_near.hip: one table lookup per read, the scan on what it leaves
 int launch_mdd_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool mdd_pair_supports(const DevDecoder& host_decoder);      // mdd_near.hip: one lookup per segment of a paired codec
+int launch_mdd_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_fused_supports(const DevDecoder& host_decoder);
 int launch_mdd_fused(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_cross_supports(const DevDecoder& host_decoder);

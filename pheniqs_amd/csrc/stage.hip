@@ -138,8 +138,10 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
-            if(mode == MODE_FAST && args.result != nullptr && mdd_near_supports(host_decoder) && stage_uses_worklist(host_decoder, mode)) {
-                // one table lookup per read (mdd_near.hpp); the scan kernel on the few reads it cannot finish (same grid)
+            const bool paired = mdd_pair_supports(host_decoder);
+            if(mode == MODE_FAST && args.result != nullptr && (paired || mdd_near_supports(host_decoder)) && stage_uses_worklist(host_decoder, mode)) {
+                // one table lookup per read — per segment for a paired codec — (mdd_near.hpp); the scan kernel on the few reads it
+                // cannot finish (same grid)
                 const int64_t near_tiles = (args.n_read + 255) / 256;
                 const int64_t near_blocks = share(GRID_SHARE_NEAR);
                 const dim3 near_grid(static_cast<unsigned>(near_tiles < near_blocks ? near_tiles : near_blocks));
@@ -149,7 +151,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 int status;
                 {
                     Timed timed(timer, KERNEL_MDD_EXACT, stream);
-                    status = launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
+                    status = paired ? launch_mdd_pair(producer, host_decoder, near_grid, histogram_bytes, s)
+                                    : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;

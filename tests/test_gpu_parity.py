@@ -222,6 +222,38 @@ def test_one_lookup_mdd(oracle, torch_cuda, length, count, min_distance, toleran
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
 
 
+@pytest.mark.parametrize("lengths,count,min_distance,tolerance,masking", [
+    ((8, 8), 96, 3, None, 0), ((10, 10), 196, 3, None, 20), ((6, 9), 48, 3, [0, 1], 0), ((10, 10), 24, 5, None, 13), ((5, 7), 30, 2, None, 0)])
+def test_one_lookup_mdd_pairs(oracle, torch_cuda, lengths, count, min_distance, tolerance, masking):
+    """Paired barcodes under MDD: a barcode is within both segments' tolerances only if each segment names it (one table
+    lookup per segment, the nearest word up to two mismatches away), mdd.cpp:43-80; sets at distance 5 take a tolerance of 2."""
+    rng = np.random.default_rng(1700 + lengths[0] + count)
+    first, second = synthetic.barcode_set(rng, count, lengths[0], min_distance), synthetic.barcode_set(rng, count, lengths[1], min_distance)
+    options = {"quality masking threshold": masking}
+    if tolerance is not None:
+        options["distance tolerance"] = tolerance
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("mdd", [first, second], ["0::%d" % lengths[0], "1::%d" % lengths[1]], pairing="zip", **options)}
+    job = capi.compile_job(spec)
+    L = sum(lengths)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 15, 23 + count)
+    # the halves of different barcodes joined: each segment names another barcode
+    words, _ = synthetic._codec_arrays(job["sample"])
+    letters = np.array([1, 2, 4, 8], dtype=np.uint8)
+    for i in range(200):
+        code[1000 + i, :lengths[0]] = letters[words[i % count, :lengths[0]]]
+        code[1000 + i, lengths[0]:L] = letters[words[(i + 1) % count, lengths[0]:L]]
+    code[200:220] = 15
+    code[300:320, 2] = 3
+    quality[400:500] = 2
+    # two mismatches in one segment
+    code[600:700, 0] = letters[(np.searchsorted(letters, code[600:700, 0]) + 1) % 4]
+    code[600:700, 1] = letters[(np.searchsorted(letters, code[600:700, 1]) + 1) % 4]
+    for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
+        s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+    assert int((got[0]["status"] == 0).sum()) > (1 << 13)
+
+
 def test_fast_mode_defers_only_a_small_fraction(oracle, torch_cuda):
     """The product form kernel finishes the clean reads itself; the worklist holds the ambiguous rest."""
     job, recipe = synthetic.config_job("C2")
