@@ -671,6 +671,32 @@ void DecoderSet::build_device_images() {
                             }
                             d.cross_near_ready = usable == 2 ? 1 : 0;
                         }
+                        if(S == 2 && c.algorithm == Algorithm::MDD && d.cross_identity && c.quality_masking_threshold <= 128 &&
+                           d.distance_tolerance[0] <= 1 && d.distance_tolerance[1] <= 1 &&
+                           c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
+                           c.barcode_length[1] >= NEAR_MIN_LENGTH && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
+                            // one lookup per segment (mdd_near.hpp, mdd_cross_kernel2): pamld_near.hpp's table over each segment's
+                            // distinct words, and the words' code bits
+                            std::vector<uint32_t> planes;
+                            for(int32_t s2 = 0; s2 < 2; ++s2) {
+                                const int32_t length = c.barcode_length[static_cast<size_t>(s2)];
+                                const auto& set = distinct[static_cast<size_t>(s2)];
+                                std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u);
+                                for(size_t u = 0; u < set.size(); ++u) {
+                                    for(int32_t j = 0; j < length; ++j) {
+                                        const uint32_t two = (set[u] >> (2 * j)) & 3u;
+                                        low[u] |= (two & 1u) << j;
+                                        high[u] |= (two >> 1) << j;
+                                    }
+                                    planes.push_back(low[u]);
+                                    planes.push_back(high[u]);
+                                }
+                                const NearTables tables = build_near_tables(low, high, length, std::vector<uint32_t>(set.size(), 0u));
+                                d.cross_near_table[s2] = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
+                            }
+                            d.mdd_cross_word = static_cast<const uint32_t*>(upload(planes.data(), planes.size() * sizeof(uint32_t)));
+                            d.mdd_cross_ready = 1;
+                        }
                         if(!d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD) {
                             // priors that differ between the barcodes: by combination, single precision, for the weighted scans
                             const size_t n0 = distinct[0].size();

@@ -127,6 +127,10 @@ struct DevDecoder {
     const uint32_t* mdd_near_record;
     int32_t mdd_near_ready;
     int32_t mdd_pair_ready;               // an MDD codec of two segments with pair_table / pair_record (mdd_near.hpp, mdd_pair_kernel)
+    // a combinatorial MDD codec of two segments (mdd_near.hpp, mdd_cross_kernel2): cross_near_table[s] over the segment's
+    // distinct words and {low plane, high plane} of segment 0's words, then of segment 1's
+    const uint32_t* mdd_cross_word;
+    int32_t mdd_cross_ready;
     // paired barcode kernel only (pamld_pair.hpp; two segments of up to 10 nt whose words are all different, uniform
     // priors): pair_table[s] = the table above — reaching two mismatches — for the words of segment s (key over the segment's positions, entry =
     // the barcode), pair_record[c] = {low code bits, high code bits (bit j = position j of the whole barcode), distance

@@ -284,6 +284,8 @@ bool mdd_near_supports(const DevDecoder& host_decoder);      // mdd_near.hip: on
 int launch_mdd_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_pair_supports(const DevDecoder& host_decoder);      // mdd_near.hip: one lookup per segment of a paired codec
 int launch_mdd_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
+bool mdd_cross2_supports(const DevDecoder& host_decoder);    // mdd_near.hip: one lookup per segment of a two segment combinatorial codec
+int launch_mdd_cross2(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_fused_supports(const DevDecoder& host_decoder);
 int launch_mdd_fused(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool mdd_cross_supports(const DevDecoder& host_decoder);

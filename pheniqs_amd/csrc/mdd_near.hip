@@ -41,4 +41,22 @@ int launch_mdd_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 
     }
 }
 
+// two segment combinatorial codecs numbered in lexicographic order, segments of 5 to 10 nt, tolerances of at most 1
+bool mdd_cross2_supports(const DevDecoder& host_decoder) {
+    const int words = host_decoder.plane_stride / 4;
+    return host_decoder.algorithm == 2 && host_decoder.mdd_cross_ready != 0 && host_decoder.n_segment == 2 && host_decoder.cross_segments == 2 &&
+           host_decoder.cross_identity != 0 && words >= 2 && words <= 8 && host_decoder.nucleotide_cardinality <= 32 &&
+           host_decoder.distance_tolerance[0] <= 1 && host_decoder.distance_tolerance[1] <= 1;
+}
+
+int launch_mdd_cross2(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.plane_stride / 4) {
+        case 2: return mdd_near::launch_cross<2>(args, host_decoder, grid, histogram_bytes, stream);
+        case 3: return mdd_near::launch_cross<3>(args, host_decoder, grid, histogram_bytes, stream);
+        case 4: return mdd_near::launch_cross<4>(args, host_decoder, grid, histogram_bytes, stream);
+        case 5: return mdd_near::launch_cross<5>(args, host_decoder, grid, histogram_bytes, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
 }  // namespace phq

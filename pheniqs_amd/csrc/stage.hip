@@ -139,7 +139,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
             }
         case 2: {
             const bool paired = mdd_pair_supports(host_decoder);
-            if(mode == MODE_FAST && args.result != nullptr && (paired || mdd_near_supports(host_decoder)) && stage_uses_worklist(host_decoder, mode)) {
+            const bool crossed = !paired && mdd_cross2_supports(host_decoder);
+            if(mode == MODE_FAST && args.result != nullptr && (paired || crossed || mdd_near_supports(host_decoder)) && stage_uses_worklist(host_decoder, mode)) {
                 // one table lookup per read — per segment for a paired codec — (mdd_near.hpp); the scan kernel on the few reads it
                 // cannot finish (same grid)
                 const int64_t near_tiles = (args.n_read + 255) / 256;
@@ -152,12 +153,14 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 {
                     Timed timed(timer, KERNEL_MDD_EXACT, stream);
                     status = paired ? launch_mdd_pair(producer, host_decoder, near_grid, histogram_bytes, s)
-                                    : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
+                           : crossed ? launch_mdd_cross2(producer, host_decoder, near_grid, histogram_bytes, s)
+                                     : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 Timed timed(timer, KERNEL_MDD, stream);
+                if(crossed && mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, near_grid, histogram_bytes, s); }
                 if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }
                 return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s);
             }
