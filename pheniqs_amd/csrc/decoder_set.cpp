@@ -443,7 +443,7 @@ void DecoderSet::build_device_images() {
                     }
                     record[static_cast<size_t>(b) * 4] = low[static_cast<size_t>(b)];
                     record[static_cast<size_t>(b) * 4 + 1] = high[static_cast<size_t>(b)];
-                    record[static_cast<size_t>(b) * 4 + 2] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                    record[static_cast<size_t>(b) * 4 + 3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
                 }
                 // two barcodes with the same word: the reference's map keeps one of them for the exact match; not taken here
                 bool distinct = true;
@@ -675,7 +675,7 @@ void DecoderSet::build_device_images() {
                            d.distance_tolerance[0] <= 1 && d.distance_tolerance[1] <= 1 &&
                            c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
                            c.barcode_length[1] >= NEAR_MIN_LENGTH && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
-                            // one lookup per segment (mdd_near.hpp, mdd_cross_kernel2): pamld_near.hpp's table over each segment's
+                            // one lookup per segment (mdd_near.hpp, COMBINATORIAL): pamld_near.hpp's table over each segment's
                             // distinct words, and the words' code bits
                             std::vector<uint32_t> planes;
                             for(int32_t s2 = 0; s2 < 2; ++s2) {

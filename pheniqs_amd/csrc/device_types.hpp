@@ -123,11 +123,11 @@ struct DevDecoder {
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
     // one lookup MDD (mdd_near.hpp; one segment of 5 to 10 nt, tolerance 0 or 1): near_table as above and per barcode
-    // {low plane, high plane, barcode index, -}
+    // {low plane, high plane, -, barcode index}
     const uint32_t* mdd_near_record;
     int32_t mdd_near_ready;
-    int32_t mdd_pair_ready;               // an MDD codec of two segments with pair_table / pair_record (mdd_near.hpp, mdd_pair_kernel)
-    // a combinatorial MDD codec of two segments (mdd_near.hpp, mdd_cross_kernel2): cross_near_table[s] over the segment's
+    int32_t mdd_pair_ready;               // an MDD codec of two segments with pair_table / pair_record (mdd_near.hpp, PAIRED)
+    // a combinatorial MDD codec of two segments (mdd_near.hpp, COMBINATORIAL): cross_near_table[s] over the segment's
     // distinct words and {low plane, high plane} of segment 0's words, then of segment 1's
     const uint32_t* mdd_cross_word;
     int32_t mdd_cross_ready;
