@@ -177,6 +177,40 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
 #pragma unroll
     for(int j = 0; j < L; ++j) { full_mask |= 1u << low_bit(j); }
 
+    // A consumer's loop is laid out so that no load waits behind a scattered store (vector memory operations complete in
+    // issue order, and the 16 + 4 byte stores of a read's record and status word at its own place are slow to complete):
+    //   * a tile's entries and the inputs the producer left beside them are asked for one tile ahead, first thing in a tile;
+    //   * a tile's records and status words are stored at its end by every lane in straight line code (a read deferred
+    //     again stores its placeholder once more, a lane past the end its last read's record again), so that the compiler can
+    //     count them at the next tile's wait for its entries, which were asked for before them;
+    //   * no per lane global load in between: the prior of the winner is the common one when the priors are equal, the barcode
+    //     index is the ordinal + 1 when the codec is numbered that way (else two cached loads, each waiting for the stores);
+    //   * what the tile defers again is written BEHIND the segment's entries when twice their number fits the segment — then
+    //     no wave can overwrite an entry another has not read yet, and there is no barrier in the loop — and moved to the
+    //     front once at the end; else it is compacted in place behind a barrier per tile.
+    constexpr int CARRIED_WORDS = (L + 3) / 4 <= 3 ? (L + 3) / 4 : 0;        // rows of four words are gathered (no carry planes for them)
+    const double common_prior = d.concentration[0];
+    const bool identity_index = d.identity_index != 0;
+    const uint32_t entries_rounded = static_cast<uint32_t>(tiles) * THREADS;
+    const bool apart = CONSUMER && 2u * entries_rounded <= static_cast<uint32_t>(args.worklist_stride);
+    const uint32_t gathered_at = apart ? entries_rounded : 0u;
+    const bool has_carry = CONSUMER && CARRIED_WORDS > 0 && carry_stride > 0;
+    struct Ahead { uint32_t read; uint32_t carried[CARRY_PLANES]; };
+    auto fetch_entries = [&](int64_t tile, Ahead& to) {
+        const int64_t at = tile * THREADS + threadIdx.x;
+        const uint32_t entry = static_cast<uint32_t>(at < n ? at : n - 1);
+        to.read = segment[entry];
+        if(has_carry) {
+            const uint32_t beside = entry < carry_stride ? entry : carry_stride - 1u;      // past the carried entries: unused
+#pragma unroll
+            for(int plane = 0; plane < CARRY_PLANES; ++plane) {
+                if(plane < CARRIED_WORDS || (plane >= 3 && plane < 3 + CARRIED_WORDS) || plane == 6) { to.carried[plane] = carry[plane * carry_stride + beside]; }
+            }
+        }
+    };
+    Ahead ahead;
+    if(CONSUMER && tiles > 0) { fetch_entries(0, ahead); }
+    if(CONSUMER) { __builtin_amdgcn_s_waitcnt(0x0f70); }      // vmcnt(0): the loop is entered with nothing in flight, its first wait is the one of its back edge (pamld_near.hpp)
     for(int64_t tile = CONSUMER ? 0 : blockIdx.x; tile < tiles; tile += CONSUMER ? 1 : gridDim.x) {
         // every lane stays enabled (one code path, whole wave LDS traffic): lanes past the end
         // of the batch recompute its last read and are kept from every store and counter
@@ -185,20 +219,17 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         uint32_t carried[CARRY_PLANES];
         bool is_carried = false;               // the producer left this entry's inputs beside it (StageArgs::carry)
         if(CONSUMER) {
-            const int64_t entry = i;
-            i = static_cast<int64_t>(segment[entry]);
-            is_carried = (L + 3) / 4 <= 3 && (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
-            if(is_carried) {
-                constexpr int CARRIED_WORDS = (L + 3) / 4 <= 3 ? (L + 3) / 4 : 0;        // rows of four words are gathered (no carry planes for them)
+            i = static_cast<int64_t>(ahead.read);
+            is_carried = has_carry && (tile + 1) * THREADS <= static_cast<int64_t>(carry_stride);        // whole tiles, wave uniform
 #pragma unroll
-                for(int plane = 0; plane < CARRY_PLANES; ++plane) {
-                    if(plane < CARRIED_WORDS || (plane >= 3 && plane < 3 + CARRIED_WORDS) || plane == 6) { carried[plane] = carry[plane * carry_stride + entry]; }
-                }
-            }
-            __syncthreads();                   // every entry of this tile is read before any wave compacts into it
+            for(int plane = 0; plane < CARRY_PLANES; ++plane) { carried[plane] = ahead.carried[plane]; }
+            if(!apart) { __syncthreads(); }    // in place: every entry of this tile is read before any wave compacts into it
+            fetch_entries(tile + 1 < tiles ? tile + 1 : tile, ahead);
         }
         ReadState r{false, 0};
         bool defer = false;
+        DevResult finished_out;                // a consumer's record of this tile: the placeholder unless the read is finished
+        finished_out.index = 0; finished_out.distance = 0; finished_out.hq_distance = 0; finished_out.status = STATUS_UNCLASSIFIED; finished_out.qcfail = 0; finished_out.confidence = 0;
         {
             constexpr int W = (L + 3) / 4;
             uint32_t code_words[W];
@@ -214,6 +245,9 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 const uint32_t* quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * (4 * W));
 #pragma unroll
                 for(int w = 0; w < W; ++w) { code_words[w] = code_row[w]; quality_words[w] = quality_row[w]; }
+                // a consumer's gathered tile (past the carried entries: rare) waits here, so that the wait for it does not end up
+                // behind the join, where it would also wait for the carried tiles' next entries
+                if(CONSUMER) { __builtin_amdgcn_s_waitcnt(0x0f70); }
             }
 
             // Per position: factor row, 2-bit base, high quality and "outside ACGT" flags — four positions (one plane
@@ -444,9 +478,10 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                     const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
                     best_conditional *= factor_double[k][(best_flags >> low_bit(j)) & 1u];
                 }
-                const double best_p = best_conditional * d.concentration[best];
+                const double prior_of_best = UNIFORM_PRIOR ? common_prior : d.concentration[best];
+                const double best_p = best_conditional * prior_of_best;
                 // everything but the winner, in units of p: only ever compared against and added to much larger terms
-                const double others = UNIFORM_PRIOR ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma);
+                const double others = UNIFORM_PRIOR ? static_cast<double>(sigma) * prior_of_best : static_cast<double>(sigma);
                 const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
                 double confidence = best_p / total;                                       // pamld.cpp:92
                 const double noise_margin = best_conditional - d.random_barcode_probability;
@@ -459,7 +494,9 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 defer = !noise_clear
                      || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
                                            : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
-                if(!defer && active) {
+                // a consumer's lanes past the end of the list recompute its last read and store its record again (the counters
+                // are kept from them): every lane has a record to store
+                if(!defer && (active || CONSUMER)) {
                     int bin = best + 1;
                     uint8_t status = STATUS_PASS;
                     if(noise_margin > 0) {                                                // pamld.cpp:96
@@ -467,14 +504,14 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                             if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) {
                                 r.qcfail = true;
                             }
-                            stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                            if(active) { stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence); }
                         } else {
-                            stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                            if(active) { stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull); }
                             r.qcfail = true;
                             status = STATUS_LOW_CONFIDENCE;
                         }
                     } else {
-                        stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                        if(active) { stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull); }
                         r.qcfail = true;
                         bin = 0;
                         distance = 0;
@@ -482,22 +519,37 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                         confidence = 0;
                         status = STATUS_NOISE;
                     }
-                    decoder_tail(d, sink, r, bin, distance);
-                    if(args.result) {
-                        DevResult out;
-                        out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
-                        out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
-                        out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
-                        out.status = status;
-                        out.qcfail = r.qcfail ? 1 : 0;
-                        out.confidence = confidence;
-                        stream_result(&args.result[i], out);
+                    const int32_t index_of_bin = bin == 0 ? 0 : identity_index ? bin : d.barcode_index[bin - 1];
+                    if(active && !(sink.defer && bin > 0)) {                              // decoder_tail (kernel_common.hpp)
+                        const int pf = r.qcfail ? 0 : 1;
+                        if(bin > 0 && distance) { stat_add(d, sink, bin, pf, FIELD_DISTANCE, static_cast<unsigned long long>(distance)); }
+                        stat_add(d, sink, bin, pf, FIELD_COUNT, 1ull);
                     }
-                    stream_read_state(args, i, r);
-                } else if(active) {
+                    if(d.multiplexing) { r.channel = index_of_bin; }
+                    DevResult out;
+                    out.index = index_of_bin;
+                    out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                    out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                    out.status = status;
+                    out.qcfail = r.qcfail ? 1 : 0;
+                    out.confidence = confidence;
+                    if(CONSUMER) { finished_out = out; }
+                    else {
+                        if(args.result) { stream_result(&args.result[i], out); }
+                        stream_read_state(args, i, r);
+                    }
+                } else if(active && !CONSUMER) {
                     stream_placeholder(args, i, r);                                   // the next tier overwrites it
                 }
             }
+        }
+        if(CONSUMER) {
+            // every lane stores a record and a status word, in straight line code: the placeholder again for a read deferred
+            // once more, the last read's again for a lane past the end.  The compiler can count these two stores, so the wait
+            // for the next tile's entries (asked for before them) does not wait for them.
+            finished_out.qcfail = defer ? (r.qcfail ? 1 : 0) : finished_out.qcfail;
+            stream_result(&args.result[i], finished_out);
+            __builtin_nontemporal_store((static_cast<uint32_t>(r.channel) & 0x7fffffffu) | (r.qcfail ? 0x80000000u : 0u), &args.word[i]);
         }
         // deferred reads: one LDS add per wave reserves a run of slots in this workgroup's worklist segment
         const unsigned long long deferred = __ballot(active && defer);
@@ -507,12 +559,17 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
             first = __shfl(first, 0);
             if(active && defer) {
-                segment[first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+                segment[gathered_at + first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
             }
         }
         count_outgoing(args, histogram, active && !defer, r);
     }
     __syncthreads();
+    if(apart) {
+        // the list was gathered behind the entries: down to the front (it is no longer than the entries were: no overlap)
+        const uint32_t left = deferred_total;
+        for(uint32_t k = threadIdx.x; k < left; k += THREADS) { segment[k] = segment[gathered_at + k]; }
+    }
     if(threadIdx.x == 0) { args.worklist_count[own] = deferred_total; }
     }
     histogram_flush(args, d, histogram);
