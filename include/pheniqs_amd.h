@@ -44,9 +44,11 @@ extern "C" {
 #define PHQ_STATUS_NOISE            2   /* pamld.cpp:114-121: failed the noise filter, unclassified, QC fail */
 #define PHQ_STATUS_UNCLASSIFIED     3   /* mdd.cpp:82-84: no barcode within tolerance, QC fail */
 
-#define PHQ_MODE_LITERAL            0   /* every barcode scored with the reference's own Kahan recurrence */
-#define PHQ_MODE_FAST               1   /* PAMLD: product form scoring, ambiguous reads re-scored literally;
-                                           MDD: exact match lookup, the rest scanned */
+#define PHQ_MODE_LITERAL            0   /* every barcode scored with the reference's own Kahan recurrence: the posterior within
+                                           1e-12 of the reference's */
+#define PHQ_MODE_FAST               1   /* PAMLD: tiers of kernels, each finishing the reads it can certify (every integer the
+                                           reference's, the posterior within 1e-8 of it; the contract is 1e-6) and handing the
+                                           others on, down to the literal kernel; MDD: table lookups, the rest scanned */
 
 #define PHQ_DEVICE_NONE            (-1) /* host only set: configuration, staging, statistics, report */
 

@@ -19,7 +19,7 @@
 //     charged to the positions in order of quality — those below Q12 for free, a of those below Q20, b below Q25, ... —
 //     `wild` counts the positions below Q4 (a mismatch there is MORE likely than a match, by at most 4), and all the
 //     counts come from byte parallel compares.
-// A read is finished under the certificate of pamld_near.hpp (1e-9 in the posterior); everything else — a third
+// A read is finished under the certificate of pamld_near.hpp (1e-8 in the posterior); everything else — a third
 // mismatch in a segment, a base outside ACGT, many low quality positions, noise — goes to the product form kernel (pamld_wide.hpp
 // for 17 to 32 nt, pamld_lut.hpp up to 16) as a consumer of this workgroup's worklist segment.
 // No per read tables: 12 KiB of LDS per workgroup, eight waves per SIMD.
@@ -33,7 +33,7 @@ namespace pair {
 constexpr int THREADS = 256;
 constexpr int FACTOR_ROWS = 129;
 constexpr float X_MAX = 3e-4f;                 // noise / winner: single precision is enough below this (pamld_near.hpp; up to 20 positions here)
-constexpr float REST_MAX = 1e-9f;              // the bound on what was not scored, as a share of the winner
+constexpr float REST_MAX = 1e-8f;              // the bound on what was not scored, as a share of the winner (pamld_near.hpp)
 constexpr float SLOP = 1.0f + 1e-5f;
 // The bound sorts the positions by quality into six classes; n mismatches are charged to the cheapest classes first:
 // below Q12 for free, then rho(Q12) each for those below Q20, rho(Q20) below Q25, rho(Q25) below Q30, rho(Q30) below Q36,
@@ -204,12 +204,14 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
         const float x_rest = others_count * __builtin_amdgcn_exp2f(log2_bound) * everything_matches * inverse_winner * SLOP;
         const float x_low = noise_over_prior * inverse_winner;
-        const float x_mid = x_low + 0.5f * x_rest;
+        // the posterior is taken WITHOUT what was only bounded: its error is then what those barcodes really weigh — at most
+        // x_rest, typically a tenth of it (profiles/tools/sim/near_certificate.py) — rather than half the bound every time
+        const float x_mid = x_low;
         const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);       // 1 - posterior
         const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
         const bool finished = all_strict && known && k <= MOST_MISMATCHES && winner > noise_floor && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
-                              fabs(confidence_margin) > 2e-9;
+                              fabs(confidence_margin) > 2e-8;
         const bool defer = !finished;
 
         // outcome: straight line stores (pamld_near.hpp)

@@ -19,9 +19,10 @@ pytestmark = pytest.mark.gpu
 
 POSTERIOR_TOLERANCE = 1e-6        # the contract
 # what the kernels are designed to hold: the literal kernel differs from the oracle only through its 2^x
-# (~1e-16); the product form kernel finishes a read only when everything but the winner weighs < 1e-3 of it,
-# and sums that remainder in single precision (relative error ~5e-7): 1e-3 * 5e-7 = 5e-10
-POSTERIOR_DESIGN_TOLERANCE = {capi.MODE_LITERAL: 1e-12, capi.MODE_FAST: 1e-9}
+# (~1e-16); the fast mode's first tier finishes a read only when what it did not score is bounded by 1e-8 of the
+# winner (the posterior is taken at the middle: 5e-9) and everything but the winner weighs < 5e-4 of it, summed in
+# single precision (relative error ~1e-6: 5e-10); the later tiers hold 1e-9 and better
+POSTERIOR_DESIGN_TOLERANCE = {capi.MODE_LITERAL: 1e-12, capi.MODE_FAST: 1e-8}
 INTEGER_FIELDS = ("index", "distance", "hq_distance", "status", "qcfail")
 INTEGER_COUNTERS = ("count", "pf_count", "accumulated_distance", "accumulated_pf_distance",
                     "low_conditional_confidence_count", "low_confidence_count")
@@ -80,7 +81,7 @@ def assert_parity(oracle, torch, job, code, quality, flag, offsets, **kwargs):
         mine, theirs = s.stats_options(words, k), engine.options(k)
         for name in INTEGER_COUNTERS:
             assert np.array_equal(mine[name], theirs[name]), (k, name)
-        tolerance = 1e-12 if kwargs.get("mode", capi.MODE_LITERAL) == capi.MODE_LITERAL else 1e-9
+        tolerance = 1e-12 if kwargs.get("mode", capi.MODE_LITERAL) == capi.MODE_LITERAL else 1e-8
         for name in ("accumulated_confidence", "accumulated_pf_confidence"):
             assert np.allclose(mine[name], theirs[name], rtol=tolerance, atol=tolerance), (k, name)
     return s, engine, got, words

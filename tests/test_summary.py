@@ -95,7 +95,8 @@ def test_summarize_gpu_records_equal_the_oracle(oracle, name, algorithm, noise):
         planes = result.cpu().numpy().view(RESULT_DTYPE).reshape(s.n_result, n)
         got_distance, got_confidence = s.summarize(planes)
         assert np.array_equal(got_distance, distance), (name, algorithm, mode)
-        assert np.abs(got_confidence - confidence).max() < 4e-9, (name, algorithm, mode)
+        # a type's confidence is the product of up to four decoders' posteriors: each within 1e-12 (literal) / 1e-8 (fast)
+        assert np.abs(got_confidence - confidence).max() < (4e-12 if mode == capi.MODE_LITERAL else 4e-8), (name, algorithm, mode)
         assert np.array_equal(got_confidence == 0, confidence == 0) and np.array_equal(got_confidence == 1, confidence == 1)
         s.close()
 
@@ -158,7 +159,7 @@ def test_chain_end_to_end_sam_tags_follow_the_oracle(oracle, tmp_path, algorithm
             c = confidence[i, kind]
             if 0 < c < 1:
                 assert tag in tags, (i, tag, c)
-                # the GPU's confidence is within 1e-9 of the oracle's: the printed float may differ in its last digit
+                # the GPU's confidence is within 1e-8 of the oracle's: the printed float may differ in its last digit
                 assert abs(float(tags[tag]) - float(_format_g(1.0 - c))) <= 1.1e-5 * abs(1.0 - c) + 1e-12, (i, tag, tags[tag], 1.0 - c)      # one unit of %g's sixth digit
                 seen[tag] += 1
             else:
