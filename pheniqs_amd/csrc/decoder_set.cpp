@@ -166,6 +166,23 @@ void DecoderSet::set_mode(int32_t mode) {
 // The tables of the neighbour list kernels (pamld_near.hpp) for N words of L nucleotides given as code bit planes (bit j =
 // position j): the word -> barcode table over every word at most one mismatch from one of them, and per word the bit
 // planes of the words nearest to it, what bounds the others, and `tag` (what the kernel reports for the word).
+// the barcodes of an ACGT codec as two bit planes per barcode: bit j of low / high = the low / high bit of the 2-bit code
+// (A, C, G, T = 0..3) of position j — the key format of the lookup tables of the first tiers
+void code_planes(const DecoderConfig& c, std::vector<uint32_t>& low, std::vector<uint32_t>& high) {
+    const size_t N = c.codec.size();
+    const size_t L = static_cast<size_t>(c.nucleotide_cardinality);
+    low.assign(N, 0u);
+    high.assign(N, 0u);
+    for(size_t b = 0; b < N; ++b) {
+        for(size_t j = 0; j < L; ++j) {
+            const uint32_t code = c.barcode_code[b * L + j];
+            const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
+            low[b] |= (two & 1u) << j;
+            high[b] |= (two >> 1) << j;
+        }
+    }
+}
+
 struct NearTables {
     std::vector<uint16_t> table;
     std::vector<uint32_t> record;
@@ -410,15 +427,8 @@ void DecoderSet::build_device_images() {
                 // per barcode the bit planes of the barcodes nearest to it with what bounds the others
                 const int32_t L = c.nucleotide_cardinality;
                 const int32_t N = d.n_barcode;
-                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
-                for(int32_t b = 0; b < N; ++b) {
-                    for(int32_t j = 0; j < L; ++j) {
-                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
-                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
-                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
-                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
-                    }
-                }
+                std::vector<uint32_t> low, high;
+                code_planes(c, low, high);
                 std::vector<uint32_t> tag(static_cast<size_t>(N));
                 for(int32_t b = 0; b < N; ++b) { tag[static_cast<size_t>(b)] = static_cast<uint32_t>(index[static_cast<size_t>(b)]); }
                 const NearTables tables = build_near_tables(low, high, L, tag, d.uniform_prior ? nullptr : &concentration, d.adjusted_noise_probability);
@@ -432,15 +442,10 @@ void DecoderSet::build_device_images() {
                 // and per barcode its code bits and index
                 const int32_t L = c.nucleotide_cardinality;
                 const int32_t N = d.n_barcode;
-                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);      // bit j = code bit of position j
+                std::vector<uint32_t> low, high;
+                code_planes(c, low, high);
                 std::vector<uint32_t> record(static_cast<size_t>(N) * 4, 0u);
                 for(int32_t b = 0; b < N; ++b) {
-                    for(int32_t j = 0; j < L; ++j) {
-                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
-                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
-                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
-                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
-                    }
                     record[static_cast<size_t>(b) * 4] = low[static_cast<size_t>(b)];
                     record[static_cast<size_t>(b) * 4 + 1] = high[static_cast<size_t>(b)];
                     record[static_cast<size_t>(b) * 4 + 3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
@@ -464,17 +469,9 @@ void DecoderSet::build_device_images() {
                 // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most two mismatches from
                 // one of its words — which must be all different in both segments — and per barcode its code bits and
                 // the distance to the nearest other barcode
-                const int32_t L = c.nucleotide_cardinality;
                 const int32_t N = d.n_barcode;
-                std::vector<uint32_t> low(static_cast<size_t>(N), 0u), high(static_cast<size_t>(N), 0u);
-                for(int32_t b = 0; b < N; ++b) {
-                    for(int32_t j = 0; j < L; ++j) {
-                        const uint32_t code = c.barcode_code[static_cast<size_t>(b) * static_cast<size_t>(L) + static_cast<size_t>(j)];
-                        const uint32_t two = code == 1 ? 0u : code == 2 ? 1u : code == 4 ? 2u : 3u;
-                        low[static_cast<size_t>(b)] |= (two & 1u) << j;
-                        high[static_cast<size_t>(b)] |= (two >> 1) << j;
-                    }
-                }
+                std::vector<uint32_t> low, high;
+                code_planes(c, low, high);
                 bool distinct = true;
                 std::vector<std::vector<uint16_t>> table(2);
                 for(int32_t s = 0; s < 2 && distinct; ++s) {
