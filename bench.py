@@ -256,13 +256,16 @@ class Workload:
         self.stream = torch.cuda.current_stream().cuda_stream
 
     def step(self, events=None):
-        from pheniqs_amd import distributed
-        self.set.stats_reset(self.stream)
+        """One batch of the job: the counters keep accumulating, as a run's do from batch to batch."""
         if events is not None:
             events[0].record()
         self.set.classify_device(self.n, 0, self.n, self.base, self.qual, self.flags, self.result, self.word, self.stream)
         if events is not None:
             events[1].record()
+
+    def merge(self):
+        """The end of run merge of the per barcode statistics (reference transcode.cpp:1816-1818): one SUM all-reduce."""
+        from pheniqs_amd import distributed
         distributed.allreduce_counters(self.counters)
 
     def measure(self, steps, warmup, world, barrier):
@@ -270,12 +273,15 @@ class Workload:
         torch = self.torch
         for _ in range(warmup):
             self.step()
+        self.merge()
+        self.set.stats_reset(self.stream)
         barrier()
         self.set.profile_enable(True)          # HIP events around every kernel launch, on the launch stream
         pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         t0 = time.perf_counter()
         for k in range(steps):
             self.step(pairs[k])
+        self.merge()                           # inside the timed region: the K steps are K batches of one run
         barrier()
         elapsed = time.perf_counter() - t0
         kernels = self.set.profile_collect()
@@ -291,7 +297,7 @@ class Workload:
         kernel_ms = kernels[dominant]["ms"] / steps
         words = self.set.stats_export()
         total = int(words[0] + words[1])
-        assert total == self.n * world, (total, self.n, world)                    # every read counted once
+        assert total == self.n * world * steps, (total, self.n, world, steps)      # every read of every batch counted once
         bytes_per_step = self.bytes_per_read * self.n
         return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
                 "kernels": kernels, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
@@ -373,7 +379,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU, %s, %s, inputs resident in HBM" % (args.config, n, CONFIG_TEXT[args.config], args.algorithm.upper()),
                        "reads_per_gpu": n, "pool": w.pool_n, "kernel_mode": args.mode,
-                       "sharding": "reads x%d, counters merged by one all-reduce per step" % world},
+                       "sharding": "reads x%d, the steps are batches of one run, counters merged by one all-reduce at its end" % world},
             # the dominant kernel kind (all its launches of a step) against the HBM roofline; step_frac: the whole step
             "roofline": {"bound": "hbm", "achieved": m["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": m["achieved_GBs"] / HBM_PEAK_GBS, "traffic": profiled_traffic(m["dominant"], n, args.config, args.algorithm, args.mode),
