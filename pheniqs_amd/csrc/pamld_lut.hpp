@@ -13,12 +13,14 @@
 // costs one quad-cycle on this part whatever its type, so instruction count is the metric.
 //
 // The reference's argmax between NEAR-TIED barcodes is decided by the last bits of its own Kahan sums
-// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to ~1e-9).  So a read is only FINISHED in
-// this kernel when its winner dominates: the summed probability of every other barcode is at most 5e-4 of the
-// winner's (DOMINANCE).  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum can be single
-// precision — their ~5e-7 relative error moves the posterior by at most DOMINANCE * 5e-7 — while the winner's own
-// probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
-// confidence filters are decided in fp64, unless they fall within 1e-9 of their thresholds.  A read that clearly
+// (pamld_literal.hpp), and the posterior must hold 1e-6 (held here to 1e-8, like the tier in front of it).  So a read
+// is only FINISHED in this kernel when its winner dominates: the summed probability of every other barcode is at most
+// dominance(L) of the winner's — 3e-3 to 5e-3.  Then (i) the argmax cannot be a tie, (ii) the tables and the running sum
+// can be single precision — their relative error, at most ~4e-7 per table of a barcode's product plus ~1e-6 for the sum
+// over the barcodes if every rounding aligns, moves the posterior by at most dominance(L) times that: 9e-9 — while the
+// winner's own probability and the posterior are recomputed in fp64 from the fp64 factor tables, and (iii) the noise and
+// confidence filters are decided in fp64, unless they fall within 2e-8 of their thresholds.  (5e-4 and 1e-9 until the end
+// of round 2: the looser bound halves what reaches the exact tier on the 96 x 8 nt benchmark.)  A read that clearly
 // fails the noise filter reports nothing but its argmax (pamld.cpp:113-119): it is finished as soon as the runner
 // up is further than single precision can blur (RUNNER_UP).  Every other read (a second plausible barcode, tied
 // noise reads: ~1.4 % of C2) is appended to a worklist that the exact tier (pamld_cross.hpp) and then the literal
@@ -30,7 +32,8 @@
 namespace phq {
 namespace lut {
 
-constexpr double DOMINANCE = 5e-4;            // others <= DOMINANCE * winner, see the header
+// others <= dominance(L) * winner, see the header: 9e-9 over the worst relative error of the single precision sum
+__host__ __device__ constexpr double dominance(int length) { return 9e-9 / (((length + 3) / 4) * 4.3e-7 + 1e-6); }
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
                 defer = !noise_clear
                      || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
-                                           : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
+                                           : (!(others <= dominance(L) * best_p) || !(fabs(confidence_margin) > 2e-8)));
                 // a consumer's lanes past the end of the list recompute its last read and store its record again (the counters
                 // are kept from them): every lane has a record to store
                 if(!defer && (active || CONSUMER)) {
