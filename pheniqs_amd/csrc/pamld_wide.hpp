@@ -22,7 +22,8 @@
 namespace phq {
 namespace wide {
 
-constexpr double DOMINANCE = 5e-4;            // others <= DOMINANCE * winner (pamld_lut.hpp)
+// others <= dominance(G) * winner (pamld_lut.hpp): 9e-9 over the worst relative error of the single precision sum
+__host__ __device__ constexpr double dominance(int groups) { return 9e-9 / (groups * 4.3e-7 + 1e-6); }
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
@@ -315,7 +316,7 @@ __global__ __launch_bounds__((Geometry<G, NARROW>::THREADS)) void pamld_wide_ker
                 const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
                 defer = !noise_clear
                      || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
-                                           : (!(others <= DOMINANCE * best_p) || !(fabs(confidence_margin) > 1e-9)));
+                                           : (!(others <= dominance(G) * best_p) || !(fabs(confidence_margin) > 2e-8)));
                 if(!defer && active) {
                     int bin = best + 1;
                     uint8_t status = STATUS_PASS;
