@@ -186,6 +186,7 @@ void code_planes(const DecoderConfig& c, std::vector<uint32_t>& low, std::vector
 struct NearTables {
     std::vector<uint16_t> table;
     std::vector<uint32_t> record;
+    std::vector<int32_t> listed; // near_list(L) ordinals per word, in the order of its record (the word itself first)
     int32_t usable = 0;          // words whose radius is at least 4
 };
 // prior: the barcodes' priors when they differ (then `noise` = the prior adjusted noise probability, pamld.cpp:29), else null
@@ -217,6 +218,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
     }
     if(N <= list) { return out; }                            // the table alone (mdd_near.hpp): no lists of a set this small
     out.record.assign(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
+    out.listed.assign(static_cast<size_t>(N) * static_cast<size_t>(list), 0);
     std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
     for(int32_t b = 0; b < N; ++b) {
         for(int32_t o = 0; o < N; ++o) { order[static_cast<size_t>(o)] = {o == b ? -1 : distance(b, o), o}; }
@@ -226,6 +228,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
             const int32_t o = order[static_cast<size_t>(k)].second;
             record[2 * (k / per_word)] |= low[static_cast<size_t>(o)] << (field * (k % per_word));
             record[2 * (k / per_word) + 1] |= high[static_cast<size_t>(o)] << (field * (k % per_word));
+            out.listed[static_cast<size_t>(b) * static_cast<size_t>(list) + static_cast<size_t>(k)] = o;
         }
         // the first word not listed sets the radius, at most 5 (the kernels form their bounds for 4 and 5)
         const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
@@ -644,12 +647,15 @@ void DecoderSet::build_device_images() {
                         for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
-                        if(d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
+                        bool positive_priors = true;
+                        for(int32_t b = 0; b < d.n_barcode; ++b) { positive_priors = positive_priors && concentration[static_cast<size_t>(b)] > 0; }
+                        if((d.uniform_prior || positive_priors) && S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
                            c.barcode_length[0] == c.barcode_length[1] && c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
                            static_cast<int32_t>(distinct[0].size()) > near_list(c.barcode_length[0]) && static_cast<int32_t>(distinct[1].size()) > near_list(c.barcode_length[0])) {
                             // neighbour list tier of the set (pamld_cross_near.hpp): pamld_near.hpp's tables per segment
                             const int32_t length = c.barcode_length[0];
                             int32_t usable = 0;
+                            std::vector<int32_t> listed[2];
                             for(int32_t s2 = 0; s2 < 2; ++s2) {
                                 const auto& set = distinct[static_cast<size_t>(s2)];
                                 std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u), tag(set.size());
@@ -665,8 +671,36 @@ void DecoderSet::build_device_images() {
                                 d.cross_near_table[s2] = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
                                 d.cross_near_record[s2] = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                                 if(2 * tables.usable >= static_cast<int32_t>(set.size())) { ++usable; }
+                                listed[s2] = tables.listed;
                             }
                             d.cross_near_ready = usable == 2 ? 1 : 0;
+                            if(!d.uniform_prior && d.cross_near_ready) {
+                                // priors that differ: the listed words' priors over the combination's, along the row and the
+                                // column of every combination (device_types.hpp, cross_near_weight)
+                                const size_t n0 = distinct[0].size(), n1 = distinct[1].size();
+                                const size_t list = static_cast<size_t>(near_list(length));
+                                auto prior_of = [&](size_t u0, size_t u1) {
+                                    return concentration[static_cast<size_t>(ordinal[u0 * static_cast<size_t>(stride[0]) + u1 * static_cast<size_t>(stride[1])])];
+                                };
+                                double largest = 0;
+                                for(int32_t b = 0; b < d.n_barcode; ++b) { largest = std::max(largest, concentration[static_cast<size_t>(b)]); }
+                                std::vector<float> along_row(n0 * n1 * CROSS_NEAR_WEIGHTS, 0.0f), along_column(n0 * n1 * CROSS_NEAR_WEIGHTS, 0.0f);
+                                for(size_t u0 = 0; u0 < n0; ++u0) {
+                                    for(size_t u1 = 0; u1 < n1; ++u1) {
+                                        const double own = prior_of(u0, u1);
+                                        float* const row = &along_row[(u0 * n1 + u1) * CROSS_NEAR_WEIGHTS];
+                                        float* const column = &along_column[(u0 * n1 + u1) * CROSS_NEAR_WEIGHTS];
+                                        row[0] = static_cast<float>(d.adjusted_noise_probability / own);
+                                        column[0] = static_cast<float>(largest / own * (1.0 + 1e-6));          // a bound: rounded up
+                                        for(size_t k = 1; k < list; ++k) {
+                                            row[k] = static_cast<float>(prior_of(u0, static_cast<size_t>(listed[1][u1 * list + k])) / own);
+                                            column[k] = static_cast<float>(prior_of(static_cast<size_t>(listed[0][u0 * list + k]), u1) / own);
+                                        }
+                                    }
+                                }
+                                d.cross_near_weight[0] = static_cast<const float*>(upload(along_row.data(), along_row.size() * sizeof(float)));
+                                d.cross_near_weight[1] = static_cast<const float*>(upload(along_column.data(), along_column.size() * sizeof(float)));
+                            }
                         }
                         if(S == 2 && c.algorithm == Algorithm::MDD && d.cross_identity && c.quality_masking_threshold <= 128 &&
                            d.distance_tolerance[0] <= 1 && d.distance_tolerance[1] <= 1 &&

@@ -16,6 +16,7 @@ constexpr int EXACT_SINGLE_UNIQUE = 512;
 // read (c and the nearest to it; a whole number of plane words), words of a barcode's record
 constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }
 constexpr int near_list(int length) { return length <= 8 ? 16 : 15; }
+constexpr int CROSS_NEAR_WEIGHTS = 16;          // floats per combination in cross_near_weight (near_list(L), padded)
 constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }      // 2 x list words + {radius, cnt_r, cnt_rest, index}, whole quads
 // ... with priors that differ: behind those, one float per listed barcode — its prior over c's; slot 0 (c itself) holds
 // the noise term over c's prior — again whole quads
@@ -141,6 +142,11 @@ struct DevDecoder {
     const uint16_t* cross_near_table[2];
     const uint32_t* cross_near_record[2];
     int32_t cross_near_ready;
+    // ... with priors that differ: per combination (c0, c1), 16 floats each.  cross_near_weight[0]: the noise term over
+    // the combination's prior, then prior(c0, w) / prior(c0, c1) for the words w listed with c1 in its record;
+    // cross_near_weight[1]: the largest prior over the combination's, then prior(w, c1) / prior(c0, c1) for the words
+    // listed with c0.  Null with uniform priors.
+    const float* cross_near_weight[2];
     // count_results_kernel (counters.hip): [bin][count, distance, confidence low limb, confidence high limb] of the
     // pass filter halves, where its workgroups add their LDS bins with dense atomics before one small kernel moves the
     // sums into the counter buffer (zero between launches); null when the decoder's bins fit a workgroup histogram

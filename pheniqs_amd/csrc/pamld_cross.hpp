@@ -869,7 +869,9 @@ __global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(St
 // evaluated literally and compared in barcode order, as in pamld_cross_exact_kernel.
 constexpr int WEIGHTED_THREADS = 64;
 constexpr int WEIGHTED_LIST = CROSS_MAX_UNIQUE;   // a lane can keep every word of segment 0
-constexpr int WEIGHTED_SHORT = 32;                // ... and this many of segment 1 with their P; more go to the literal kernel
+constexpr int WEIGHTED_SHORT = 32;                // ... and this many of segment 1 with their P
+constexpr int WEIGHTED_PAIRS = 48;                // pairs of listed words a lane walks — one prior from L2 each, one after the other, and the
+                                                  // wave waits for its longest lane; reads with more go to pamld_cross_exact_dense_kernel
 
 template <int G>
 __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_kernel(StageArgs args) {
@@ -877,6 +879,7 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
     __shared__ double listed_value[WEIGHTED_SHORT * WEIGHTED_THREADS];        // [entry][lane] P1 of the listed words of segment 1
     __shared__ uint8_t listed_word[WEIGHTED_SHORT * WEIGHTED_THREADS];        // [entry][lane] their ordinals
     __shared__ uint8_t significant[WEIGHTED_LIST * WEIGHTED_THREADS];         // [entry][lane] words of segment 0 that matter
+    __shared__ uint32_t word_copy[2][CROSS_MAX_UNIQUE];                       // the segments' words: every loop below walks them
     __shared__ double factor_double[FACTOR_ROWS][2];
     __shared__ double cost_double[FACTOR_ROWS][2];
     __shared__ uint32_t deferred_total;
@@ -890,6 +893,7 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
         cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
     }
     if(threadIdx.x == 0) { deferred_total = 0; }
+    for(int i = threadIdx.x; i < 2 * CROSS_MAX_UNIQUE; i += WEIGHTED_THREADS) { word_copy[i / CROSS_MAX_UNIQUE][i % CROSS_MAX_UNIQUE] = d.cross_words[i]; }
     histogram_clear(d, histogram);
     __syncthreads();
 
@@ -925,8 +929,8 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
     const int64_t stride = d.plane_stride;
     const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
     const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
-    const uint32_t* const words0 = d.cross_words;
-    const uint32_t* const words1 = d.cross_words + CROSS_MAX_UNIQUE;
+    const uint32_t* const words0 = word_copy[0];
+    const uint32_t* const words1 = word_copy[1];
     const PHQ_CONSTANT int32_t* const ordinal = constant_cast(d.cross_ordinal);
 
     for(int64_t tile = 0; tile < tiles; ++tile) {
@@ -1036,6 +1040,7 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
             }
         }
         // the bilinear form over the listed words, and the largest prior * P0 * P1
+        if(count0 * count1 > WEIGHTED_PAIRS) { defer = true; count0 = 0; }
         double weighted_sum = 0;
         double weighted_top = 0;
         for(int k0 = 0; k0 < count0; ++k0) {
@@ -1044,6 +1049,7 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
             const double* const prior_row = d.cross_prior_double + u0 * radix[0];
             double row_sum = 0;
             double row_top = 0;
+#pragma unroll 4
             for(int k1 = 0; k1 < count1; ++k1) {
                 const int u1 = listed_word[k1 * WEIGHTED_THREADS + threadIdx.x];
                 const double p = prior_row[u1 * radix[1]] * listed_value[k1 * WEIGHTED_THREADS + threadIdx.x];
@@ -1155,6 +1161,306 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
     __syncthreads();
     if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
     histogram_flush(args, d, histogram);
+}
+
+// What the kernel above leaves — reads with several low quality calls, more than WEIGHTED_SHORT words of segment 1 within
+// 1e-15 of its maximum — takes the WHOLE bilinear form, one wave per read: the lanes share out the words (P of every word
+// of both segments to LDS), then the rows of the prior matrix; nothing is left out, so nothing has to be bounded.  The
+// argmax as above: the combinations within 1e-10 of the largest prior * P0 * P1 literally, in barcode order.  A pass of
+// the literal kernel over a 96 x 96 codec takes a wave ~5 ms however few reads it holds; this takes ~10 us per read.
+constexpr int DENSE_THREADS = 256;
+constexpr int DENSE_WAVES = DENSE_THREADS / 64;   // a segment's reads go round the waves
+
+template <int G>
+__global__ __launch_bounds__(DENSE_THREADS) void pamld_cross_exact_dense_kernel(StageArgs args) {
+    constexpr int S = 2;
+    __shared__ double value_of_wave[DENSE_WAVES][S][CROSS_MAX_UNIQUE];        // P_s of every word, of the read a wave has in hand
+    __shared__ uint32_t word_copy[S][CROSS_MAX_UNIQUE];
+    __shared__ uint32_t deferred_total;
+    __shared__ double factor_double[FACTOR_ROWS][2];
+    __shared__ double cost_double[FACTOR_ROWS][2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
+    DecoderRef d = *constant_cast(args.decoder);
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += DENSE_THREADS) {
+        factor_double[i][0] = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        factor_double[i][1] = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        cost_double[i][0] = i < 128 ? d.true_positive_quality[i] : d.uniform_base_quality;
+        cost_double[i][1] = i < 128 ? static_cast<double>(i) : d.uniform_base_quality;
+    }
+    for(int i = threadIdx.x; i < S * CROSS_MAX_UNIQUE; i += DENSE_THREADS) { word_copy[i / CROSS_MAX_UNIQUE][i % CROSS_MAX_UNIQUE] = d.cross_words[i]; }
+    if(threadIdx.x == 0) { deferred_total = 0; }
+    histogram_clear(d, histogram);
+    __syncthreads();
+
+    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
+    uint32_t* const segment = args.worklist + static_cast<int64_t>(blockIdx.x) * args.worklist_stride;
+    const int64_t n = static_cast<int64_t>(args.worklist_count[blockIdx.x]);
+    int first_word[S];
+    int length[S];
+    uint32_t byte_shift[S];
+    uint32_t byte_mask[S][G];
+    uint32_t full_mask[S];
+    int unique[S];
+    int radix[S];
+    const int row_words = d.plane_stride >> 2;
+#pragma unroll
+    for(int s = 0; s < S; ++s) {
+        const int start = d.cross_start[s];
+        length[s] = d.cross_length[s];
+        first_word[s] = start >> 2;
+        byte_shift[s] = static_cast<uint32_t>(start & 3);
+        unique[s] = d.cross_unique[s];
+        radix[s] = d.cross_stride[s];
+        full_mask[s] = 0;
+#pragma unroll
+        for(int j = 0; j < 4 * G; ++j) { if(j < length[s]) { full_mask[s] |= 1u << low_bit(j); } }
+#pragma unroll
+        for(int g = 0; g < G; ++g) {
+            const int valid = length[s] - 4 * g;
+            byte_mask[s][g] = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : ((1u << (8 * valid)) - 1u);
+        }
+    }
+    const int64_t stride = d.plane_stride;
+    const char* const factor_bytes = reinterpret_cast<const char*>(&factor_double[0][0]);
+    const char* const cost_bytes = reinterpret_cast<const char*>(&cost_double[0][0]);
+    const uint32_t* const words_of[S] = {word_copy[0], word_copy[1]};
+    const PHQ_CONSTANT int32_t* const ordinal = constant_cast(d.cross_ordinal);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double (* const value)[CROSS_MAX_UNIQUE] = value_of_wave[wave];
+
+    for(int64_t round = 0; round * DENSE_WAVES < n; ++round) {
+        const int64_t k = round * DENSE_WAVES + wave;
+        const bool active = k < n;                                             // a wave past the end takes the last read again, silently
+        const int64_t i = static_cast<int64_t>(segment[active ? k : n - 1]);   // one read, the whole wave
+        __syncthreads();                       // every entry of this round is read before any wave compacts into it
+        ReadState r = load_read_state(args, i);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+        uint32_t row_offset[S][4 * G];
+        uint32_t observed[S];
+        uint32_t outside[S];
+        uint32_t high_quality[S];
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            uint32_t c[G + 1];
+            uint32_t q[G + 1];
+#pragma unroll
+            for(int g = 0; g <= G; ++g) {
+                const int w = min(first_word[s] + g, row_words - 1);
+                c[g] = code_row[w];
+                q[g] = quality_row[w];
+            }
+            observed[s] = 0; outside[s] = 0; high_quality[s] = 0;
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                const uint32_t code_word = __builtin_amdgcn_alignbyte(c[(j >> 2) + 1], c[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t quality_word = __builtin_amdgcn_alignbyte(q[(j >> 2) + 1], q[j >> 2], byte_shift[s]) & byte_mask[s][j >> 2];
+                const uint32_t code = (code_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t q8 = (quality_word >> (8 * (j & 3))) & 0xffu;
+                const uint32_t quality = q8 & 0x7fu;
+                const uint32_t row = strict_code(code) ? quality : (quality ? 128u : 0u);
+                row_offset[s][j] = row * 16u;
+                const uint32_t two = (0x30210u >> (2 * (code & 0xfu))) & 3u;
+                observed[s] |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));
+                if(static_cast<int>(q8) >= d.high_quality_threshold) { high_quality[s] |= 1u << low_bit(j); }
+                if(!strict_code(code)) { outside[s] |= 1u << low_bit(j); }
+            }
+        }
+        auto flags_of = [&](int s, uint32_t word) { return (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s]; };
+        auto product_of = [&](int s, uint32_t flags) {
+            double p = 1.0;
+#pragma unroll
+            for(int j = 0; j < 4 * G; ++j) {
+                p *= *reinterpret_cast<const double*>(factor_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
+            }
+            return p;
+        };
+
+        // P of every word of both segments; per segment the maximum (the first word that holds it)
+        double top[S];
+        int first[S];
+#pragma unroll
+        for(int s = 0; s < S; ++s) {
+            double lane_top = 0;
+            int lane_first = 0x7fffffff;
+            for(int u = lane; u < unique[s]; u += 64) {
+                const double p = product_of(s, flags_of(s, words_of[s][u]));
+                value[s][u] = p;
+                if(p > lane_top) { lane_top = p; lane_first = u; }
+            }
+#pragma unroll
+            for(int offset = 32; offset > 0; offset >>= 1) {
+                const double other_top = __shfl_xor(lane_top, offset);
+                const int other_first = __shfl_xor(lane_first, offset);
+                if(other_top > lane_top || (other_top == lane_top && other_first < lane_first)) { lane_top = other_top; lane_first = other_first; }
+            }
+            top[s] = lane_top;
+            first[s] = lane_first;
+        }
+        __syncthreads();
+        bool defer = !(top[0] > 0) || !(top[1] > 0);
+
+        // the bilinear form, a lane per word of segment 1 — a column of the prior matrix, whose rows the lanes then read side by
+        // side — and the largest prior * P0 * P1
+        double weighted_sum = 0;
+        double weighted_top = 0;
+        double top_of_column[CROSS_MAX_UNIQUE / 64];           // P1 * the largest prior * P0 of this lane's columns
+#pragma unroll
+        for(int half = 0; half < CROSS_MAX_UNIQUE / 64; ++half) {
+            const int u1 = lane + 64 * half;
+            top_of_column[half] = 0;
+            if(u1 < unique[1]) {
+                const double* const prior_column = d.cross_prior_double + u1 * radix[1];
+                double column_sum = 0;
+                double column_top = 0;
+#pragma unroll 16
+                for(int u0 = 0; u0 < unique[0]; ++u0) {
+                    const double p = prior_column[u0 * radix[0]] * value[0][u0];
+                    column_sum += p;
+                    column_top = fmax(column_top, p);
+                }
+                weighted_sum += value[1][u1] * column_sum;
+                top_of_column[half] = value[1][u1] * column_top;
+                weighted_top = fmax(weighted_top, top_of_column[half]);
+            }
+        }
+#pragma unroll
+        for(int offset = 32; offset > 0; offset >>= 1) {
+            weighted_sum += __shfl_xor(weighted_sum, offset);
+            weighted_top = fmax(weighted_top, __shfl_xor(weighted_top, offset));
+        }
+        if(!(weighted_top > 0)) { defer = true; }
+
+        // the combinations within 1e-10 of the largest, literally (barcode.h:131-164); the first in barcode order wins
+        int best = 0x7fffffff;
+        double best_conditional = -1.0;
+        double best_p = -1.0;
+        uint32_t best_flags[S] = {0, 0};
+        if(!defer) {
+            const double floor = weighted_top * (1.0 - 1e-10);
+            // only a column whose largest product comes that close holds any: those — one or two — are walked again, the lanes
+            // now sharing out the words of segment 0
+#pragma unroll
+            for(int half = 0; half < CROSS_MAX_UNIQUE / 64; ++half) {
+              unsigned long long columns = __ballot(top_of_column[half] >= floor);
+              while(columns) {
+                const int u1 = 64 * half + __ffsll(static_cast<long long>(columns)) - 1;
+                columns &= columns - 1;
+                const uint32_t flags1 = flags_of(1, words_of[1][u1]);
+                const double p1 = value[1][u1];
+                for(int u0 = lane; u0 < unique[0]; u0 += 64) {
+                    const double prior = d.cross_prior_double[u0 * radix[0] + u1 * radix[1]];
+                    if(!(prior * value[0][u0] * p1 >= floor)) { continue; }
+                    {
+                    const int b = ordinal[u0 * radix[0] + u1 * radix[1]];
+                    const uint32_t flags0 = flags_of(0, words_of[0][u0]);
+                    double sigma = 0;
+                    double compensation = 0;
+#pragma unroll
+                    for(int s = 0; s < S; ++s) {
+                        const uint32_t flags = s == 0 ? flags0 : flags1;
+#pragma unroll
+                        for(int j = 0; j < 4 * G; ++j) {
+                            if(j < length[s]) {
+                                const double x = *reinterpret_cast<const double*>(cost_bytes + (row_offset[s][j] + ((flags >> low_bit(j)) & 1u) * 8u));
+                                const double y = x - compensation;
+                                const double t = sigma + y;
+                                compensation = (t - sigma) - y;
+                                sigma = t;
+                            }
+                        }
+                    }
+                    const double conditional = phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
+                    const double p = conditional * prior;                      // pamld.cpp:66
+                    if(p > best_p || (p == best_p && b < best)) {              // strict '>' in barcode order
+                        best = b; best_p = p; best_conditional = conditional;
+                        best_flags[0] = flags0; best_flags[1] = flags1;
+                    }
+                    }
+                }
+              }
+            }
+            // across the lanes: the largest, the lowest barcode among equals; its lane hands over the rest
+            double wave_p = best_p;
+            int wave_best = best;
+#pragma unroll
+            for(int offset = 32; offset > 0; offset >>= 1) {
+                const double other_p = __shfl_xor(wave_p, offset);
+                const int other_best = __shfl_xor(wave_best, offset);
+                if(other_p > wave_p || (other_p == wave_p && other_best < wave_best)) { wave_p = other_p; wave_best = other_best; }
+            }
+            const unsigned long long holders = __ballot(best == wave_best && wave_best != 0x7fffffff);
+            if(holders) {
+                const int holder = __ffsll(static_cast<long long>(holders)) - 1;
+                best = wave_best;
+                best_p = wave_p;
+                best_conditional = __shfl(best_conditional, holder);
+                best_flags[0] = __shfl(best_flags[0], holder);
+                best_flags[1] = __shfl(best_flags[1], holder);
+            } else {
+                best = 0x7fffffff;
+            }
+        }
+        if(best == 0x7fffffff) { defer = true; best = 0; best_conditional = 0; best_p = 0; }
+        __syncthreads();                       // every lane is done with this read's P before the next one's are written
+
+        int distance = __popc(best_flags[0]) + __popc(best_flags[1]);
+        int hq_distance = __popc(best_flags[0] & high_quality[0]) + __popc(best_flags[1] & high_quality[1]);
+        const double total = weighted_sum + d.adjusted_noise_probability;            // pamld.cpp:61-86
+        double confidence = best_p / total;                                          // pamld.cpp:92
+        const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
+        if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
+        const bool writer = lane == 0 && active;
+        if(!defer && writer) {
+            int bin = best + 1;
+            uint8_t status = STATUS_PASS;
+            if(!is_noise) {
+                if(confidence > d.confidence_threshold) {                            // pamld.cpp:99
+                    if(d.high_quality_distance_threshold > 0 && hq_distance >= d.high_quality_distance_threshold) { r.qcfail = true; }
+                    stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
+                } else {
+                    stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                    r.qcfail = true;
+                    status = STATUS_LOW_CONFIDENCE;
+                }
+            } else {
+                stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                r.qcfail = true;
+                bin = 0; distance = 0; hq_distance = 0; confidence = 0;
+                status = STATUS_NOISE;
+            }
+            decoder_tail(d, sink, r, bin, distance);
+            if(args.result) {
+                DevResult out;
+                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                out.status = status;
+                out.qcfail = r.qcfail ? 1 : 0;
+                out.confidence = confidence;
+                args.result[i] = out;
+            }
+            store_read_state(args, i, r);
+        }
+        if(defer && writer) { segment[atomicAdd(&deferred_total, 1u)] = static_cast<uint32_t>(i); }      // a place behind this round's entries
+        count_outgoing(args, histogram, writer && !defer, r);
+    }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.worklist_count[blockIdx.x] = deferred_total; }
+    histogram_flush(args, d, histogram);
+}
+
+inline int launch_exact_dense(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: hipLaunchKernelGGL((pamld_cross_exact_dense_kernel<1>), grid, dim3(DENSE_THREADS), histogram_bytes, stream, args); break;
+        case 2: hipLaunchKernelGGL((pamld_cross_exact_dense_kernel<2>), grid, dim3(DENSE_THREADS), histogram_bytes, stream, args); break;
+        case 3: hipLaunchKernelGGL((pamld_cross_exact_dense_kernel<3>), grid, dim3(DENSE_THREADS), histogram_bytes, stream, args); break;
+        case 4: hipLaunchKernelGGL((pamld_cross_exact_dense_kernel<4>), grid, dim3(DENSE_THREADS), histogram_bytes, stream, args); break;
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+    return static_cast<int>(hipGetLastError());
 }
 
 inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {

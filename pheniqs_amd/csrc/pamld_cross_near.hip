@@ -4,7 +4,7 @@
 namespace phq {
 
 bool pamld_cross_near_supports(const DevDecoder& host_decoder) {
-    if(!(host_decoder.algorithm == 1 && host_decoder.cross_near_ready != 0 && host_decoder.uniform_prior != 0 && host_decoder.cross_segments == 2 &&
+    if(!(host_decoder.algorithm == 1 && host_decoder.cross_near_ready != 0 && (host_decoder.uniform_prior != 0 || host_decoder.cross_near_weight[0] != nullptr) && host_decoder.cross_segments == 2 &&
          host_decoder.cross_length[0] == host_decoder.cross_length[1] && pamld_cross_supports(host_decoder))) { return false; }
     const int L = host_decoder.cross_length[0];
     if(L < NEAR_MIN_LENGTH || L > NEAR_MAX_LENGTH || host_decoder.plane_stride != 4 * ((2 * L + 3) / 4)) { return false; }

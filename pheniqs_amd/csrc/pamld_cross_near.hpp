@@ -39,7 +39,13 @@ template <int L> struct CrossShape {
     }
 };
 
-template <int L, int STATE>
+// PRIORS: the combinations' priors differ (estimated priors, phq_adjust_prior).  With rho_ij = prior_ij / prior of the named
+// combination (c0, c1),
+//     sum over every other combination / (prior W_0 W_1)  =  sum_j rho_c0j P_1(j)/W_1  +  sum_i rho_ic1 P_0(i)/W_0
+//                                                           +  sum_{i != c0, j != c1} rho_ij P_0(i) P_1(j) / (W_0 W_1) :
+// the first two sums are taken over the listed words with their own rho (DevDecoder::cross_near_weight, 2 x 64 B per read
+// from a table that stays in L2), everything else is bounded with the largest rho.
+template <int L, int STATE, bool PRIORS>
 __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(StageArgs args) {
     typedef Shape<L> Layout;
     constexpr int G = Layout::G;
@@ -160,7 +166,9 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
         fetch(min(tile + gridDim.x, tiles - 1), next);
 
         // per segment: x_s bounds, the winner's probability, mismatches
-        float winner_of[SEGMENTS], x_listed_of[SEGMENTS], x_rest_of[SEGMENTS];
+        float winner_of[SEGMENTS], x_listed_of[SEGMENTS], x_rest_of[SEGMENTS], x_weighted_of[SEGMENTS];
+        typedef float Weights __attribute__((ext_vector_type(4)));
+        Weights along_row[4], along_column[4];                 // PRIORS: cross_near_weight of this read's combination
         uint32_t mismatches_of[SEGMENTS], flat_of[SEGMENTS];
         bool usable = true;
 #pragma unroll
@@ -245,6 +253,21 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
                     }
                 }
             }
+            if(PRIORS && s == 0) {
+                // behind segment 0's tables in program order: the lookups had those to arrive under, these have the sums below
+                uint32_t flat = 0;
+#pragma unroll
+                for(int t = 0; t < SEGMENTS; ++t) {
+                    const uint32_t word = looked_up[t] < words_of[t] ? looked_up[t] : 0u;
+                    flat += *(__attribute__((address_space(3))) const uint32_t*)static_cast<uintptr_t>(record_base[t] + word * (RECORD_WORDS * 4u) + (2 * LIST_WORDS + 3) * 4u);
+                }
+                const Weights* const row = reinterpret_cast<const Weights*>(d.cross_near_weight[0]) + static_cast<size_t>(flat) * (CROSS_NEAR_WEIGHTS / 4);
+                const Weights* const column = reinterpret_cast<const Weights*>(d.cross_near_weight[1]) + static_cast<size_t>(flat) * (CROSS_NEAR_WEIGHTS / 4);
+#pragma unroll
+                for(int quad = 0; quad < 4; ++quad) { along_column[quad] = column[quad]; }
+#pragma unroll
+                for(int quad = 0; quad < 4; ++quad) { along_row[quad] = row[quad]; }
+            }
             const uint32_t record_at = record_base[s] + c * (RECORD_WORDS * 4u);
             Quad record[Layout::RECORD_QUADS];
 #pragma unroll
@@ -252,6 +275,7 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
             auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
             float winner = 0;
             float others = 0;
+            float weighted = 0;               // PRIORS: the listed words by their prior ratios
             uint32_t mismatches = 0;
 #pragma unroll
             for(int w = 0; w < LIST_WORDS; ++w) {
@@ -273,7 +297,14 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
 #pragma unroll
                 for(int b = 0; b < PER_WORD; ++b) {
                     if(w == 0 && b == 0) { winner = p[0]; }
-                    else { sum = (w == 0 && b == 1) ? p[b] : sum + p[b]; }
+                    else {
+                        sum = (w == 0 && b == 1) ? p[b] : sum + p[b];
+                        if(PRIORS) {
+                            const int entry = w * PER_WORD + b;               // the order of the record = the order of the weights
+                            const float ratio = s == 0 ? along_column[entry >> 2][entry & 3] : along_row[entry >> 2][entry & 3];
+                            weighted = fmaf(ratio, p[b], weighted);
+                        }
+                    }
                 }
                 others = w == 0 ? sum : others + sum;
             }
@@ -293,6 +324,7 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
             const float beyond = k == 0 ? h_up : boost * fminf(h_r, h_up * inverse_rho);
             winner_of[s] = winner;
             x_listed_of[s] = others * inverse_winner;
+            x_weighted_of[s] = weighted * inverse_winner;
             x_rest_of[s] = (cnt_r * at_r + cnt_rest * beyond) * near::SLOP * inverse_winner;
             mismatches_of[s] = mismatches;
             usable = usable && known && k <= 1 && radius >= 4u;
@@ -300,11 +332,14 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
 
         // both segments together: others / winner = x_0 + x_1 + x_0 x_1, between its listed part and listed + bound
         const float winner = winner_of[0] * winner_of[1];
-        const float listed = x_listed_of[0] + x_listed_of[1] + x_listed_of[0] * x_listed_of[1];
         const float upper0 = x_listed_of[0] + x_rest_of[0], upper1 = x_listed_of[1] + x_rest_of[1];
-        const float x_rest = (upper0 + upper1 + upper0 * upper1 - listed) * near::SLOP;
+        // PRIORS: the winner's row and column by their own priors; the other combinations and what the lists leave out of the
+        // row and the column by the largest prior over the winner's (along_column[0].x)
+        const float listed = PRIORS ? x_weighted_of[0] + x_weighted_of[1] : x_listed_of[0] + x_listed_of[1] + x_listed_of[0] * x_listed_of[1];
+        const float x_rest = PRIORS ? along_column[0].x * (upper0 * upper1 + x_rest_of[0] + x_rest_of[1]) * near::SLOP
+                                    : (upper0 + upper1 + upper0 * upper1 - listed) * near::SLOP;
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-        const float x_low = listed + noise_over_prior * inverse_winner;
+        const float x_low = listed + (PRIORS ? along_row[0].x : noise_over_prior) * inverse_winner;
         // the posterior is taken WITHOUT what was only bounded: its error is then what those barcodes really weigh — at most
         // x_rest, typically a tenth of it (profiles/tools/sim/near_certificate.py) — rather than half the bound every time
         const float x_mid = x_low;
@@ -365,20 +400,26 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
     histogram_flush(args, d, histogram);
 }
 
-template <int L, int STATE>
+template <int L, int STATE, bool PRIORS>
 int launch_state(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t lds_bytes = CrossShape<L>::histogram_at(host_decoder.cross_unique[0], host_decoder.cross_unique[1]) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_cross_near_kernel<L, STATE>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_cross_near_kernel<L, STATE>), grid, dim3(Shape<L>::THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_cross_near_kernel<L, STATE, PRIORS>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_cross_near_kernel<L, STATE, PRIORS>), grid, dim3(Shape<L>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
+}
+
+template <int L, bool PRIORS>
+int launch_by_state(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if(!args.first_stage) { return launch_state<L, 2, PRIORS>(args, host_decoder, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<L, 1, PRIORS>(args, host_decoder, grid, histogram_bytes, stream)
+                           : launch_state<L, 0, PRIORS>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 template <int L>
 int launch_one(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2>(args, host_decoder, grid, histogram_bytes, stream); }
-    return args.input_flag ? launch_state<L, 1>(args, host_decoder, grid, histogram_bytes, stream)
-                           : launch_state<L, 0>(args, host_decoder, grid, histogram_bytes, stream);
+    return host_decoder.uniform_prior ? launch_by_state<L, false>(args, host_decoder, grid, histogram_bytes, stream)
+                                      : launch_by_state<L, true>(args, host_decoder, grid, histogram_bytes, stream);
 }
 
 }  // namespace cross_near

@@ -1,6 +1,8 @@
 // Stage dispatcher: picks the kernel for one decoder and sizes the launch.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "kernel_common.hpp"
 
@@ -26,6 +28,20 @@ bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
 }
 
 namespace {
+// PHQ_TRACE_WORKLIST=1: after a tier, how many reads it left in the worklist (synchronises the stream: diagnosis only)
+void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, hipStream_t stream) {
+    static const bool wanted = std::getenv("PHQ_TRACE_WORKLIST") != nullptr;
+    if(!wanted || args.worklist_count == nullptr) { return; }
+    std::vector<uint32_t> count(segments);
+    if(hipStreamSynchronize(stream) != hipSuccess) { return; }
+    if(hipMemcpy(count.data(), args.worklist_count, segments * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { return; }
+    uint64_t total = 0;
+    uint32_t largest = 0;
+    for(uint32_t c : count) { total += c; largest = std::max(largest, c); }
+    std::fprintf(stderr, "worklist after %s: %llu of %lld reads in %u segments (largest %u)\n", tier, static_cast<unsigned long long>(total),
+                 static_cast<long long>(args.n_read), segments, largest);
+}
+
 struct Timed {
     LaunchTimer* timer;
     void* stream;
@@ -94,6 +110,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                                         : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s);
                     }
                     if(status != 0) { return status; }
+                    trace_worklist("the neighbour lists", producer, wide_grid.x, s);
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
                     middle.worklist_segments = static_cast<int32_t>(wide_grid.x);
@@ -117,6 +134,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                                         : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
+                trace_worklist("the product form", producer, wide_grid.x, s);
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
@@ -130,6 +148,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     status = launch_pamld_wide_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 }
+                trace_worklist("the exact tier", producer, wide_grid.x, s);
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
                 return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
             }

@@ -409,6 +409,31 @@ def test_combinatorial_sets_with_priors_that_differ(oracle, torch_cuda, lengths,
     assert int((got[0]["status"] == 0).sum()) > n // 2
 
 
+@pytest.mark.parametrize("lengths,counts,spread", [((10, 10), (40, 24), 1.0), ((8, 8), (30, 20), 0.5), ((6, 6), (20, 18), 1.0), ((9, 9), (24, 20), 3.0),
+                                                   ((10, 10), (64, 48), 0.5)])
+def test_combinatorial_neighbour_lists_with_priors(oracle, torch_cuda, lengths, counts, spread):
+    """Two segment combinatorial sets large enough for the neighbour list tier, every prior positive but spread over up to
+    six decades: the tier weighs the winner's row and column by their own priors and bounds every other combination by
+    the largest prior (pamld.cpp:66-86).  The posterior stays within the fast mode's tolerance of the oracle's."""
+    rng = np.random.default_rng(sum(lengths) * 5 + sum(counts))
+    segments = [synthetic.barcode_set(rng, c, l, min_distance=3 if l >= 8 else 2) for l, c in zip(lengths, counts)]
+    tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
+    decoder = synthetic.decoder_spec("pamld", segments, tokens, **{"confidence threshold": 0.95})
+    for record in decoder["codec"].values():
+        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+    job = jobspec.compile_job({"input segment cardinality": len(lengths), "sample": decoder})
+    n = 1 << 15
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 17)
+    L = sum(lengths)
+    noisy = rng.random((n, L)) < 0.01
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random((n, L)) < 0.02] = 0
+    quality[: n // 8] = 30
+    quality[n // 8: n // 4] = 12
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+
+
 @pytest.mark.parametrize("lengths,counts,masking", [((6, 9), (12, 10), 0), ((10, 10), (24, 16), 15), ((4, 7, 5), (5, 6, 4), 0), ((16, 3), (7, 9), 10)])
 def test_combinatorial_sets_factorise_under_mdd(oracle, torch_cuda, lengths, counts, masking):
     """The first barcode, in index order, whose every segment is within tolerance is (first fit of segment 1, ..):
