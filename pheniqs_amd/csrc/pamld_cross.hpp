@@ -32,6 +32,10 @@ namespace phq {
 namespace cross {
 
 constexpr double DOMINANCE = 5e-4;
+// the weighted scans: their single precision sums carry ~2.3e-6 of `others` (pamld_lut.hpp, dominance), so others up to
+// this share of the winner move the posterior by 4e-9; the bounded part adds at most 2e-9 (PHQ_MODE_FAST: 1e-8)
+constexpr double DOMINANCE_WEIGHTED = 1.5e-3;
+constexpr double ELSEWHERE_WEIGHTED = 4e-9;
 constexpr float RUNNER_UP = 0.9999f;          // second <= RUNNER_UP * top: the argmax of a segment is certain
 constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a top well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
         float pass_rest[PASSES];               // the sum of the other words (weighted in the weighted passes)
         float pass_second[PASSES];             // the runner up (weighted in the weighted passes)
         float pass_plain_sum[PASSES];          // the plain sum over every word of the segment
+        float pass_plain_other[PASSES];        // weighted passes: the largest plain P among the words other than the winner
         int pass_best[PASSES];
 
 #pragma unroll
@@ -282,6 +287,8 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             float best_value = 0;
             float second = 0;
             float plain_sum = 0;
+            float plain_top = 0;               // weighted passes: the two largest plain P
+            float plain_second = 0;
             int best_block = -1;
             auto values_of_block = [&](int f, float (&p)[FOLD], float (&plain)[FOLD]) {
                 const uint4 a = blocks[4 * f];                                      // wave uniform address: a broadcast
@@ -307,7 +314,16 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 float p[FOLD];
                 float plain[FOLD];
                 values_of_block(f, p, plain);
-                if(WEIGHTED) { plain_sum += ((plain[0] + plain[1]) + (plain[2] + plain[3])) + ((plain[4] + plain[5]) + (plain[6] + plain[7])); }
+                if(WEIGHTED) {
+                    plain_sum += ((plain[0] + plain[1]) + (plain[2] + plain[3])) + ((plain[4] + plain[5]) + (plain[6] + plain[7]));
+                    if(weigh) {
+#pragma unroll
+                        for(int k = 0; k < FOLD; ++k) {
+                            plain_second = __builtin_amdgcn_fmed3f(plain_top, plain[k], plain_second);      // second <= top: the median
+                            plain_top = fmaxf(plain_top, plain[k]);
+                        }
+                    }
+                }
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                     // strict: the first block keeps a tie
@@ -356,6 +372,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             pass_rest[pass] = rest;
             pass_second[pass] = second;
             pass_plain_sum[pass] = plain_sum;
+            pass_plain_other[pass] = plain_top == top_plain ? plain_second : plain_top;      // two words at the top: the second equals it
             pass_best[pass] = best;
             if(pass < S) {
                 if(!WEIGHTED) { certain = certain && top >= SMALLEST_CERTAIN && (second <= RUNNER_UP * top); }
@@ -380,6 +397,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             const int best = d.cross_ordinal[flat];
             const double prior = WEIGHTED ? d.concentration[best] : d.concentration[0];
             const double best_p = best_conditional * prior;
+            bool elsewhere_clear = true;
             if(WEIGHTED) {
                 // the winner (u0, u1): P0 = pass_top[0], P1 = pass_plain[1]; its row and its column are exact, the
                 // rest is bounded.  `others` becomes the sum of prior_b P(r|b) over every other barcode, in units of p.
@@ -394,10 +412,11 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
                 others = row_rest + column_rest + 0.5 * elsewhere;                             // the midpoint of [0, elsewhere]
                 // the argmax: the column scan must name u0 again, and nothing in the row, the column or elsewhere
                 // may come within single precision of the winner
+                // (elsewhere: at most the largest prior, the runner up of segment 0 and the largest P of segment 1 off the winner's word)
                 const double runner_up = fmax(fmax(p0 * static_cast<double>(pass_second[1]), p1 * static_cast<double>(pass_second[2])),
-                                              d.cross_prior_max * static_cast<double>(pass_second[0]) * plain_rest);
-                if(pass_best[2] != pass_best[0] || !(winner >= 1e-30) || !(pass_top[0] >= SMALLEST_CERTAIN) || !(pass_plain[1] >= SMALLEST_CERTAIN) || !(runner_up <= static_cast<double>(RUNNER_UP) * winner) ||
-                   !(elsewhere <= 4e-10 * winner)) { defer = true; }
+                                              d.cross_prior_max * static_cast<double>(pass_second[0]) * fmin(plain_rest, static_cast<double>(pass_plain_other[1]) * (1.0 + 1e-6)));
+                if(pass_best[2] != pass_best[0] || !(winner >= 1e-30) || !(pass_top[0] >= SMALLEST_CERTAIN) || !(pass_plain[1] >= SMALLEST_CERTAIN) || !(runner_up <= static_cast<double>(RUNNER_UP) * winner)) { defer = true; }
+                elsewhere_clear = elsewhere <= ELSEWHERE_WEIGHTED * winner;          // the posterior: only a read past the noise filter needs it
             }
             const double total = (best_p + (WEIGHTED ? others : others * prior)) + d.adjusted_noise_probability;   // pamld.cpp:61-86
             double confidence = best_p / total;                                       // pamld.cpp:92
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
             if(!noise_clear) { defer = true; }
             if(!is_noise) {
                 // the posterior matters: a dominant winner and no decision within 1e-9 of the threshold
-                if(!(others <= DOMINANCE * (WEIGHTED ? best_p : best_conditional)) || !(fabs(confidence_margin) > 1e-9)) { defer = true; }
+                if(!elsewhere_clear || !(others <= (WEIGHTED ? DOMINANCE_WEIGHTED * best_p : DOMINANCE * best_conditional)) || !(fabs(confidence_margin) > (WEIGHTED ? 1e-8 : 1e-9))) { defer = true; }
             }
             if(!defer && active) {
                 int bin = best + 1;
@@ -868,8 +887,8 @@ __global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(St
 // and walks list against list — per lane lists, so a wave runs as many rounds as its longest lists.  The combinations within 1e-10 of the largest prior * P0 * P1 are
 // evaluated literally and compared in barcode order, as in pamld_cross_exact_kernel.
 constexpr int WEIGHTED_THREADS = 64;
-constexpr int WEIGHTED_LIST = CROSS_MAX_UNIQUE;   // a lane can keep every word of segment 0
-constexpr int WEIGHTED_SHORT = 32;                // ... and this many of segment 1 with their P
+constexpr int WEIGHTED_SHORT = 16;                // words of segment 1 a lane keeps, with their P
+constexpr int WEIGHTED_LIST = 48;                 // words of segment 0 a lane keeps
 constexpr int WEIGHTED_PAIRS = 48;                // pairs of listed words a lane walks — one prior from L2 each, one after the other, and the
                                                   // wave waits for its longest lane; reads with more go to pamld_cross_exact_dense_kernel
 
@@ -1019,9 +1038,13 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
         for(int u0 = 0; u0 < unique[0]; ++u0) {
             const double p = product_of(zero, flags_of(zero, words0[u0]));
             if(p >= top0 * keep && p > 0) {
-                significant[count0 * WEIGHTED_THREADS + threadIdx.x] = static_cast<uint8_t>(u0);
-                ++count0;
-                listed0 += p;
+                if(count0 < WEIGHTED_LIST) {
+                    significant[count0 * WEIGHTED_THREADS + threadIdx.x] = static_cast<uint8_t>(u0);
+                    ++count0;
+                    listed0 += p;
+                } else {
+                    defer = true;
+                }
             }
         }
         double listed1 = 0;
@@ -1171,6 +1194,9 @@ __global__ __launch_bounds__(WEIGHTED_THREADS) void pamld_cross_exact_weighted_k
 constexpr int DENSE_THREADS = 256;
 constexpr int DENSE_WAVES = DENSE_THREADS / 64;   // a segment's reads go round the waves
 
+// The walk reads the whole prior matrix from L2 for every read (72 KiB for 96 x 96: ~5 GB a step of 50 M C3 reads, which is what
+// bounds the kernel).  Tried: the matrix copied to LDS (one workgroup a CU then: 0.99 ms against 0.78 ms), four waves a SIMD by
+// register limit (spills: 1.14 ms).
 template <int G>
 __global__ __launch_bounds__(DENSE_THREADS) void pamld_cross_exact_dense_kernel(StageArgs args) {
     constexpr int S = 2;

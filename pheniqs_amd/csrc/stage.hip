@@ -27,7 +27,6 @@ bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
            (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
 
-namespace {
 // PHQ_TRACE_WORKLIST=1: after a tier, how many reads it left in the worklist (synchronises the stream: diagnosis only)
 void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, hipStream_t stream) {
     static const bool wanted = std::getenv("PHQ_TRACE_WORKLIST") != nullptr;
@@ -42,6 +41,7 @@ void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, 
                  static_cast<long long>(args.n_read), segments, largest);
 }
 
+namespace {
 struct Timed {
     LaunchTimer* timer;
     void* stream;

@@ -18,3 +18,4 @@ run c5 --config C5 --reads 50000000
 run literal --mode literal
 run c4v --config C4V --reads 50000000
 run priors --priors estimated
+run c3priors --config C3 --reads 50000000 --priors estimated
