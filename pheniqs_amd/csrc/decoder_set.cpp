@@ -422,8 +422,10 @@ void DecoderSet::build_device_images() {
                 d.barcode_packed2 = static_cast<const uint32_t*>(upload(packed2.data(), packed2.size() * sizeof(uint32_t)));
                 d.concentration_single = static_cast<const float*>(upload(prior.data(), prior.size() * sizeof(float)));
             }
-            bool positive_priors = true;         // ratios of priors are formed below
-            for(double c0 : concentration) { if(!(c0 > 0) || !std::isfinite(c0)) { positive_priors = false; } }
+            // ratios of priors are formed below; a barcode whose own prior is zero (nothing seen of it by an estimation pass)
+            // gets infinite ones: the kernels' certificates fail on them and a read that names it goes to the next tier
+            bool positive_priors = true;
+            for(double c0 : concentration) { if(!(c0 >= 0) || !std::isfinite(c0)) { positive_priors = false; } }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
                d.n_barcode > near_list(c.nucleotide_cardinality) && d.n_barcode <= NEAR_MAX_BARCODES) {
                 // neighbour list tier (pamld_near.hpp): the barcode of every word at most one mismatch away from one, and
@@ -647,9 +649,7 @@ void DecoderSet::build_device_images() {
                         for(int32_t b = 0; b < d.n_barcode; ++b) { if(ordinal[static_cast<size_t>(b)] != b) { d.cross_identity = 0; } }
                         d.cross_words = static_cast<const uint32_t*>(upload(words.data(), words.size() * sizeof(uint32_t)));
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
-                        bool positive_priors = true;
-                        for(int32_t b = 0; b < d.n_barcode; ++b) { positive_priors = positive_priors && concentration[static_cast<size_t>(b)] > 0; }
-                        if((d.uniform_prior || positive_priors) && S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
+                        if(S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
                            c.barcode_length[0] == c.barcode_length[1] && c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
                            static_cast<int32_t>(distinct[0].size()) > near_list(c.barcode_length[0]) && static_cast<int32_t>(distinct[1].size()) > near_list(c.barcode_length[0])) {
                             // neighbour list tier of the set (pamld_cross_near.hpp): pamld_near.hpp's tables per segment
@@ -676,7 +676,9 @@ void DecoderSet::build_device_images() {
                             d.cross_near_ready = usable == 2 ? 1 : 0;
                             if(!d.uniform_prior && d.cross_near_ready) {
                                 // priors that differ: the listed words' priors over the combination's, along the row and the
-                                // column of every combination (device_types.hpp, cross_near_weight)
+                                // column of every combination (device_types.hpp, cross_near_weight).  A combination whose own
+                                // prior is zero (nothing seen of it by the estimation pass) gets infinities: the kernel's
+                                // certificate fails on them and the read goes to the weighted scans.
                                 const size_t n0 = distinct[0].size(), n1 = distinct[1].size();
                                 const size_t list = static_cast<size_t>(near_list(length));
                                 auto prior_of = [&](size_t u0, size_t u1) {

@@ -166,34 +166,43 @@ def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n,
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
 
 
-@pytest.mark.parametrize("length,count,spread", [(8, 96, 1.0), (8, 96, 3.0), (10, 96, 1.0), (6, 40, 1.5), (9, 64, 2.0), (8, 192, 1.0), (5, 20, 0.5)])
-def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread):
+@pytest.mark.parametrize("length,count,spread,absent", [(8, 96, 1.0, 0), (8, 96, 3.0, 0), (10, 96, 1.0, 0), (6, 40, 1.5, 0), (9, 64, 2.0, 0), (8, 192, 1.0, 0),
+                                                        (5, 20, 0.5, 0), (8, 96, 1.0, 5), (10, 64, 2.0, 2)])
+def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread, absent):
     """Single index sets whose priors differ (what phq_adjust_prior leaves behind): the neighbour list kernel weighs the
     listed barcodes and its bound by their priors over the nearest barcode's (pamld.cpp:66-79); 192 barcodes with their
-    weights do not fit a CU's LDS and stay with the product form kernel."""
+    weights do not fit a CU's LDS and stay with the product form kernel.  `absent`: every absent-th barcode has prior
+    zero; reads still fall on it (sequencing errors of its neighbours, the generator's own draws are replaced)."""
     rng = np.random.default_rng(700 + 10 * length + count)
     words = synthetic.barcode_set(rng, count, length, min_distance=3 if length >= 6 else 2)
     spec = {"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length])}
     for k, record in enumerate(spec["sample"]["codec"].values()):
-        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+        record["concentration"] = 0 if (absent and k % absent == 1) else float(10 ** rng.uniform(-spread, spread))
     job = capi.compile_job(spec)
     code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 16, 77 + length)
+    if absent:          # reads ON the barcodes whose prior is zero
+        picks = rng.integers(0, count, size=1 << 10)
+        code[: 1 << 10] = np.array([[{"A": 1, "C": 2, "G": 4, "T": 8}[c] for c in words[k]] for k in picks], dtype=np.uint8)
     s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
 
 
-@pytest.mark.parametrize("lengths,count,spread", [((8, 8), 96, 1.0), ((10, 10), 96, 1.0), ((10, 10), 196, 2.0), ((6, 9), 48, 0.5)])
-def test_paired_sets_with_priors(oracle, torch_cuda, lengths, count, spread):
+@pytest.mark.parametrize("lengths,count,spread,absent", [((8, 8), 96, 1.0, 0), ((10, 10), 96, 1.0, 0), ((10, 10), 196, 2.0, 0), ((6, 9), 48, 0.5, 0),
+                                                         ((8, 8), 96, 1.0, 4), ((10, 10), 64, 0.5, 2)])
+def test_paired_sets_with_priors(oracle, torch_cuda, lengths, count, spread, absent):
     """Unique dual index / ligation pairs whose priors differ: the paired kernel scales its bound by the other barcodes'
     priors over the named one's and takes the noise term over that prior (pamld.cpp:29,66-86)."""
     rng = np.random.default_rng(900 + lengths[0] + count)
     first, second = synthetic.barcode_set(rng, count, lengths[0]), synthetic.barcode_set(rng, count, lengths[1])
     spec = {"input segment cardinality": 2,
             "sample": synthetic.decoder_spec("pamld", [first, second], ["0::%d" % lengths[0], "1::%d" % lengths[1]], pairing="zip")}
-    for record in spec["sample"]["codec"].values():
-        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+    for k, record in enumerate(spec["sample"]["codec"].values()):
+        record["concentration"] = 0 if (absent and k % absent == 1) else float(10 ** rng.uniform(-spread, spread))
     job = capi.compile_job(spec)
     code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 15, 91 + count)
+    if absent:          # reads ON the pairs whose prior is zero
+        picks = rng.integers(0, count, size=1 << 10)
+        code[: 1 << 10] = np.array([[{"A": 1, "C": 2, "G": 4, "T": 8}[c] for c in first[k] + second[k]] for k in picks], dtype=np.uint8)
     s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
     assert int((got[0]["status"] == 0).sum()) > (1 << 14)
 
@@ -409,18 +418,21 @@ def test_combinatorial_sets_with_priors_that_differ(oracle, torch_cuda, lengths,
     assert int((got[0]["status"] == 0).sum()) > n // 2
 
 
-@pytest.mark.parametrize("lengths,counts,spread", [((10, 10), (40, 24), 1.0), ((8, 8), (30, 20), 0.5), ((6, 6), (20, 18), 1.0), ((9, 9), (24, 20), 3.0),
-                                                   ((10, 10), (64, 48), 0.5)])
-def test_combinatorial_neighbour_lists_with_priors(oracle, torch_cuda, lengths, counts, spread):
-    """Two segment combinatorial sets large enough for the neighbour list tier, every prior positive but spread over up to
-    six decades: the tier weighs the winner's row and column by their own priors and bounds every other combination by
-    the largest prior (pamld.cpp:66-86).  The posterior stays within the fast mode's tolerance of the oracle's."""
+@pytest.mark.parametrize("lengths,counts,spread,absent", [((10, 10), (40, 24), 1.0, 0), ((8, 8), (30, 20), 0.5, 0), ((6, 6), (20, 18), 1.0, 0),
+                                                          ((9, 9), (24, 20), 3.0, 0), ((10, 10), (64, 48), 0.5, 0), ((10, 10), (40, 24), 1.0, 3),
+                                                          ((8, 8), (24, 24), 0.5, 2)])
+def test_combinatorial_neighbour_lists_with_priors(oracle, torch_cuda, lengths, counts, spread, absent):
+    """Two segment combinatorial sets large enough for the neighbour list tier, priors spread over up to six decades: the
+    tier weighs the winner's row and column by their own priors and bounds every other combination by the largest prior
+    (pamld.cpp:66-86).  `absent`: every absent-th combination has prior zero (what a prior estimation pass leaves for a
+    combination it saw nothing of) — a read naming one is left to the next tier.  The posterior stays within the fast
+    mode's tolerance of the oracle's."""
     rng = np.random.default_rng(sum(lengths) * 5 + sum(counts))
     segments = [synthetic.barcode_set(rng, c, l, min_distance=3 if l >= 8 else 2) for l, c in zip(lengths, counts)]
     tokens = ["%d::%d" % (k, l) for k, l in enumerate(lengths)]
     decoder = synthetic.decoder_spec("pamld", segments, tokens, **{"confidence threshold": 0.95})
-    for record in decoder["codec"].values():
-        record["concentration"] = float(10 ** rng.uniform(-spread, spread))
+    for k, record in enumerate(decoder["codec"].values()):
+        record["concentration"] = 0 if (absent and k % absent == 1) else float(10 ** rng.uniform(-spread, spread))
     job = jobspec.compile_job({"input segment cardinality": len(lengths), "sample": decoder})
     n = 1 << 15
     code, quality, flag, offsets = synthetic.generate_rows(job, n, 17)
@@ -430,6 +442,9 @@ def test_combinatorial_neighbour_lists_with_priors(oracle, torch_cuda, lengths, 
     quality[rng.random((n, L)) < 0.02] = 0
     quality[: n // 8] = 30
     quality[n // 8: n // 4] = 12
+    if absent:          # reads ON the combinations whose prior is zero
+        picks = rng.integers(0, counts[0] * counts[1], size=1 << 10)
+        code[: 1 << 10] = np.array([[{"A": 1, "C": 2, "G": 4, "T": 8}[c] for c in segments[0][k // counts[1]] + segments[1][k % counts[1]]] for k in picks], dtype=np.uint8)
     s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
     assert int((got[0]["status"] == 0).sum()) > n // 2
 
