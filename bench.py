@@ -12,7 +12,7 @@ Besides the contract line's fields the JSON line carries, from the same run: `ro
 on the launch stream; `step_frac` = the whole step against the same roofline), `cpu_baseline`, and by default three
 more legs next to the kernel only `value` (kernel only, staged and end to end side by side):
 `staged` (pinned host planes through phq_classify_host, PCIe inclusive), `fastq_to_sam` (FASTQ text to SAM text and
-report only) and `shapes` (C3 at full size, C5, MDD on C2), each with its own whole step roofline fraction.
+report only) and `shapes` (C3 at full size, C4, C5, MDD on C2, C2 and C3 with priors that differ), each with its own whole step roofline fraction.
 """
 import argparse
 import json
@@ -403,12 +403,15 @@ def main():
         if extra_legs:
             # the other BASELINE shapes that fit one GPU, kernel only like `value`, fewer steps
             line["shapes"] = {}
-            for name, config, algorithm, reads in (("C3_pamld", "C3", "pamld", 100_000_000), ("C5_pamld", "C5", "pamld", 50_000_000),
-                                                   ("C4_pamld", "C4", "pamld", 50_000_000), ("C4V_pamld", "C4V", "pamld", 50_000_000),
-                                                   ("C2_mdd", "C2", "mdd", 100_000_000)):
-                shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool)
+            for name, config, algorithm, reads, priors in (("C3_pamld", "C3", "pamld", 100_000_000, "uniform"), ("C5_pamld", "C5", "pamld", 50_000_000, "uniform"),
+                                                           ("C4_pamld", "C4", "pamld", 50_000_000, "uniform"), ("C4V_pamld", "C4V", "pamld", 50_000_000, "uniform"),
+                                                           ("C2_mdd", "C2", "mdd", 100_000_000, "uniform"),
+                                                           ("C2_pamld_estimated_priors", "C2", "pamld", 100_000_000, "estimated"),
+                                                           ("C3_pamld_estimated_priors", "C3", "pamld", 50_000_000, "estimated")):
+                shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool, priors)
                 sm = shape.measure(5, 2, 1, barrier)
-                line["shapes"][name] = {"workload": "%s: %d reads, %s, %s" % (config, reads, CONFIG_TEXT[config], algorithm.upper()),
+                line["shapes"][name] = {"workload": "%s: %d reads, %s, %s%s" % (config, reads, CONFIG_TEXT[config], algorithm.upper(),
+                                                                              ", priors that differ between the barcodes" if priors == "estimated" else ""),
                                         "Mreads/s": sm["Mreads/s"], "ms_per_step": sm["ms_per_step"], "algorithmic_bytes_per_read": shape.bytes_per_read,
                                         "step_frac": sm["step_GBs"] / HBM_PEAK_GBS, "dominant_kernel": sm["dominant"],
                                         "dominant_kernel_frac": sm["achieved_GBs"] / HBM_PEAK_GBS,
