@@ -1335,24 +1335,29 @@ __global__ __launch_bounds__(DENSE_THREADS) void pamld_cross_exact_dense_kernel(
         double weighted_sum = 0;
         double weighted_top = 0;
         double top_of_column[CROSS_MAX_UNIQUE / 64];           // P1 * the largest prior * P0 of this lane's columns
-#pragma unroll
-        for(int half = 0; half < CROSS_MAX_UNIQUE / 64; ++half) {
-            const int u1 = lane + 64 * half;
-            top_of_column[half] = 0;
-            if(u1 < unique[1]) {
-                const double* const prior_column = d.cross_prior_double + u1 * radix[1];
-                double column_sum = 0;
-                double column_top = 0;
+        {
+            // both of a lane's columns in one walk down the rows: twice the loads in flight, half the trips
+            static_assert(CROSS_MAX_UNIQUE == 128, "two columns per lane");
+            const int u1_low = min(lane, unique[1] - 1);                      // a lane past the end walks the last column, unheard
+            const int u1_high = min(lane + 64, unique[1] - 1);
+            const double* const column_low = d.cross_prior_double + u1_low * radix[1];
+            const double* const column_high = d.cross_prior_double + u1_high * radix[1];
+            double sum_low = 0, sum_high = 0, top_low = 0, top_high = 0;
 #pragma unroll 16
-                for(int u0 = 0; u0 < unique[0]; ++u0) {
-                    const double p = prior_column[u0 * radix[0]] * value[0][u0];
-                    column_sum += p;
-                    column_top = fmax(column_top, p);
-                }
-                weighted_sum += value[1][u1] * column_sum;
-                top_of_column[half] = value[1][u1] * column_top;
-                weighted_top = fmax(weighted_top, top_of_column[half]);
+            for(int u0 = 0; u0 < unique[0]; ++u0) {
+                const double p0 = value[0][u0];
+                const double low = column_low[u0 * radix[0]] * p0;
+                const double high = column_high[u0 * radix[0]] * p0;
+                sum_low += low;
+                sum_high += high;
+                top_low = fmax(top_low, low);
+                top_high = fmax(top_high, high);
             }
+            const bool has_low = lane < unique[1], has_high = lane + 64 < unique[1];
+            top_of_column[0] = has_low ? value[1][u1_low] * top_low : 0.0;
+            top_of_column[1] = has_high ? value[1][u1_high] * top_high : 0.0;
+            weighted_sum = (has_low ? value[1][u1_low] * sum_low : 0.0) + (has_high ? value[1][u1_high] * sum_high : 0.0);
+            weighted_top = fmax(top_of_column[0], top_of_column[1]);
         }
 #pragma unroll
         for(int offset = 32; offset > 0; offset >>= 1) {
