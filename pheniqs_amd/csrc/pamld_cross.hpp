@@ -1196,9 +1196,8 @@ constexpr int DENSE_WAVES = DENSE_THREADS / 64;   // a segment's reads go round 
 
 // The walk reads the whole prior matrix from L2 for every read (72 KiB for 96 x 96: ~5 GB a step of 50 M C3 reads).  That is
 // not what bounds the kernel: the matrix through LDS in tiles shared by the workgroup's four reads took the same 0.8 ms (the
-// whole matrix in LDS, one workgroup a CU: 0.99 ms; four waves a SIMD by register limit, spills: 1.14 ms).  The worklist
-// segments are uneven — 17 such reads on average, 80 in the largest — and a round takes ~30 us of dependent steps: the
-// longest segment alone is 0.6 ms.  A flat list across the segments would balance it.
+// whole matrix in LDS, one workgroup a CU: 0.99 ms; four waves a SIMD by register limit, spills: 1.14 ms).  A read takes a
+// wave ~30 us of dependent steps and two waves fit a SIMD: 51 K reads x 30 us over 2 048 waves in flight is the 0.75 ms.
 template <int G>
 __global__ __launch_bounds__(DENSE_THREADS) void pamld_cross_exact_dense_kernel(StageArgs args) {
     constexpr int S = 2;
