@@ -187,7 +187,7 @@ struct NearTables {
     std::vector<uint16_t> table;
     std::vector<uint32_t> record;
     std::vector<int32_t> listed; // near_list(L) ordinals per word, in the order of its record (the word itself first)
-    int32_t usable = 0;          // words whose radius is at least 4
+    int32_t usable = 0;          // words whose radius is at least 3
 };
 // prior: the barcodes' priors when they differ (then `noise` = the prior adjusted noise probability, pamld.cpp:29), else null
 NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector<uint32_t>& high, int32_t L, const std::vector<uint32_t>& tag,
@@ -255,7 +255,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
         std::memcpy(&meta[1], &cnt_r, sizeof(float));
         std::memcpy(&meta[2], &cnt_rest, sizeof(float));
         meta[3] = tag[static_cast<size_t>(b)];
-        if(radius >= 4) { ++out.usable; }
+        if(radius >= 3) { ++out.usable; }                     // at 3 only the reads ON the word are finished by the kernels
     }
     return out;
 }

@@ -314,8 +314,9 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
             flat_of[s] = record_word(2 * LIST_WORDS + 3);                        // this word's share of the barcode ordinal
             const int k = __popc(mismatches);
             const bool near5 = radius >= 5u;
-            const float h_r = near5 ? h[5] : h[4];
-            const float h_up = near5 ? h[6] : h[5];
+            const bool near3 = radius == 3u;                 // pamld_near.hpp: only a read ON the word
+            const float h_r = near5 ? h[5] : near3 ? h[3] : h[4];
+            const float h_up = near5 ? h[6] : near3 ? h[4] : h[5];
             const float h_down = near5 ? h[4] : h[3];
             const float inverse_winner = __builtin_amdgcn_rcpf(winner);
             const float inverse_rho = everything_matches * inverse_winner;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(Shape<L>::THREADS) void pamld_cross_near_kernel(Sta
             x_weighted_of[s] = weighted * inverse_winner;
             x_rest_of[s] = (cnt_r * at_r + cnt_rest * beyond) * near::SLOP * inverse_winner;
             mismatches_of[s] = mismatches;
-            usable = usable && known && k <= 1 && radius >= 4u;
+            usable = usable && known && k <= 1 && (radius >= 4u || (near3 && k == 0));
         }
 
         // both segments together: others / winner = x_0 + x_1 + x_0 x_1, between its listed part and listed + bound

@@ -367,10 +367,11 @@ __global__ __launch_bounds__((Shape<L, PRIORS, BIG>::THREADS)) void pamld_near_k
         const uint32_t index = record_word(2 * LIST_WORDS + 3);                  // barcode_index[c]
         const float noise_over_prior = PRIORS ? __uint_as_float(record_word(Layout::WEIGHT_AT)) : uniform_noise_over_prior;
         const int k = __popc(mismatches);
-        const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5; 4 otherwise (less: not finished here)
-        const float h_r = near5 ? h[5] : h[4];                              // H[r]
-        const float h_up = near5 ? h[6] : h[5];                             // H[r + 1]
-        const float h_down = near5 ? h[4] : h[3];                           // H[r - 1]
+        const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5
+        const bool near3 = radius == 3u;                                    // a crowded set (384 words of 8 nt): only a read ON c is finished here
+        const float h_r = near5 ? h[5] : near3 ? h[3] : h[4];               // H[r]
+        const float h_up = near5 ? h[6] : near3 ? h[4] : h[5];              // H[r + 1]
+        const float h_down = near5 ? h[4] : h[3];                           // H[r - 1] (radius 3: not used)
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
         // k = 1: rho of the read's own mismatch position is winner / everything_matches; without that position
         // top_n <= min(top_n, top_{n+1} / rho), and the position itself costs at most max(rho, 1)
@@ -388,7 +389,7 @@ __global__ __launch_bounds__((Shape<L, PRIORS, BIG>::THREADS)) void pamld_near_k
         const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);            // 1 - posterior
         const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
-        const bool finished = all_strict && known && k <= 1 && radius >= 4u && winner > noise_floor &&
+        const bool finished = all_strict && known && k <= 1 && (radius >= 4u || (near3 && k == 0)) && winner > noise_floor &&
                               x_listed <= LISTED_MAX && x_low + x_rest <= X_MAX && x_rest <= REST_MAX &&
                               fabs(confidence_margin) > 2e-8;
         const bool defer = !finished;
