@@ -528,24 +528,29 @@ void DecoderSet::build_device_images() {
                 if(distinct) {
                     std::vector<uint32_t> record(static_cast<size_t>(N) * PAIR_RECORD_WORDS, 0u);
                     int32_t usable = 0;
-                    double all_priors = 0;
-                    for(double c0 : concentration) { all_priors += c0; }
                     for(int32_t b = 0; b < N; ++b) {
+                        auto away = [&](int32_t o) { return __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)])); };
                         int radius = 31;
-                        for(int32_t o = 0; o < N; ++o) {
-                            if(o != b) { radius = std::min(radius, __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]))); }
-                        }
+                        for(int32_t o = 0; o < N; ++o) { if(o != b) { radius = std::min(radius, away(o)); } }
                         uint32_t* const entry = &record[static_cast<size_t>(b) * PAIR_RECORD_WORDS];
                         entry[0] = low[static_cast<size_t>(b)];
                         entry[1] = high[static_cast<size_t>(b)];
                         entry[2] = static_cast<uint32_t>(radius);
                         entry[3] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
-                        // what scales the bound on every other barcode, and the noise term, in units of this barcode's prior
+                        // what scales the bound on the other barcodes — those at the radius, one further, and all the rest —, and the
+                        // noise term, in units of this barcode's prior
                         const double own = concentration[static_cast<size_t>(b)];
-                        const float others = d.uniform_prior ? static_cast<float>(N - 1) : static_cast<float>((all_priors - own) / own) * (1.0f + 1e-6f);
+                        double weight[3] = {0, 0, 0};
+                        for(int32_t o = 0; o < N; ++o) {
+                            if(o != b) { weight[std::min(std::min(away(o), 31) - radius, 2)] += d.uniform_prior ? 1.0 : concentration[static_cast<size_t>(o)] / own; }
+                        }
+                        const float up = d.uniform_prior ? 1.0f : 1.0f + 1e-6f;          // sums of ratios bound: rounded up
+                        const float others[3] = {static_cast<float>(weight[0]) * up, static_cast<float>(weight[1]) * up, static_cast<float>(weight[2]) * up};
                         const float noise_over_prior = static_cast<float>(d.adjusted_noise_probability / own);
-                        std::memcpy(&entry[4], &others, sizeof(float));
+                        std::memcpy(&entry[4], &others[0], sizeof(float));
                         std::memcpy(&entry[5], &noise_over_prior, sizeof(float));
+                        std::memcpy(&entry[6], &others[1], sizeof(float));
+                        std::memcpy(&entry[7], &others[2], sizeof(float));
                         if(radius >= 6) { ++usable; }
                     }
                     for(int32_t s = 0; s < 2; ++s) {

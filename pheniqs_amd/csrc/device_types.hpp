@@ -22,7 +22,7 @@ constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }   
 // the noise term over c's prior — again whole quads
 constexpr int near_record_words(int length, bool priors) { return near_record_words(length) + (priors ? (length <= 8 ? 16 : 16) : 0); }
 constexpr int MAX_DEFERRED_BINS = 9472;        // count_results_kernel: 16 bytes of LDS each
-constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, high plane, radius, barcode index, others / prior, noise / prior, -, -}
+constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, high plane, radius, barcode index, others at the radius / prior, noise / prior, others one further / prior, the rest / prior}
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
 constexpr int NEAR_MAX_BARCODES = 1024;

@@ -18,7 +18,9 @@
 //   * every other barcode is at most  A * 4^wild * rho12^a * rho20^b * rho25^c * rho30^d * rho36^e  where the n mismatches are
 //     charged to the positions in order of quality — those below Q12 for free, a of those below Q20, b below Q25, ... —
 //     `wild` counts the positions below Q4 (a mismatch there is MORE likely than a match, by at most 4), and all the
-//     counts come from byte parallel compares.
+//     counts come from byte parallel compares.  The others come in three classes (host): at the radius, one further away
+//     (n + 1 mismatches), the rest (n + 2) — of 383 other pairs two or three sit at the radius, and charging all of them
+//     there left the bound 100 times what it is (384 pairs of 8 + 8 nt: 21.8 % of the reads deferred).
 // A read is finished under the certificate of pamld_near.hpp (1e-8 in the posterior); everything else — a third
 // mismatch in a segment, a base outside ACGT, many low quality positions, noise — goes to the product form kernel (pamld_wide.hpp
 // for 17 to 32 nt, pamld_lut.hpp up to 16) as a consumer of this workgroup's worklist segment.
@@ -171,8 +173,10 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         const Quad record = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u));
         // the priors of all other barcodes over c's (N - 1 when they are equal) and the noise term over c's prior (pamld.cpp:29,66)
         const Quad weights = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u) + 16u);
-        const float others_count = __uint_as_float(weights.x);
+        const float others_at_radius = __uint_as_float(weights.x);          // ... at the radius, one further away, all the rest
         const float noise_over_prior = __uint_as_float(weights.y);
+        const float others_next = __uint_as_float(weights.z);
+        const float others_beyond = __uint_as_float(weights.w);
         const uint32_t mismatches = ((low ^ record.x) | (high ^ record.y)) & full_mask;
         const int k = __popc(mismatches);
 
@@ -191,18 +195,22 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             winner = j == 0 ? own : winner * own;
         }
 
-        // every other barcode: at least n = r(c) - k mismatches outside the read's own
-        int needed = max(static_cast<int>(record.z) - k - static_cast<int>(below[0]), 0);
-        float log2_bound = 2.0f * static_cast<float>(wild);
+        // the other barcodes: those at the radius at least n = r(c) - k mismatches outside the read's own, the next n + 1, the rest n + 2
+        auto log2_bound_of = [&](int mismatches_outside) {
+            int needed = max(mismatches_outside - static_cast<int>(below[0]), 0);
+            float log2_bound = 2.0f * static_cast<float>(wild);
 #pragma unroll
-        for(int m = 0; m + 1 < MARKS; ++m) {
-            const int charged = min(needed, static_cast<int>(below[m + 1] - below[m]));
-            needed -= charged;
-            log2_bound += LOG2_RHO[m] * static_cast<float>(charged);
-        }
-        log2_bound += LOG2_RHO[MARKS - 1] * static_cast<float>(needed);
+            for(int m = 0; m + 1 < MARKS; ++m) {
+                const int charged = min(needed, static_cast<int>(below[m + 1] - below[m]));
+                needed -= charged;
+                log2_bound += LOG2_RHO[m] * static_cast<float>(charged);
+            }
+            return log2_bound + LOG2_RHO[MARKS - 1] * static_cast<float>(needed);
+        };
+        const int outside = static_cast<int>(record.z) - k;
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-        const float x_rest = others_count * __builtin_amdgcn_exp2f(log2_bound) * everything_matches * inverse_winner * SLOP;
+        const float x_rest = (others_at_radius * __builtin_amdgcn_exp2f(log2_bound_of(outside)) + others_next * __builtin_amdgcn_exp2f(log2_bound_of(outside + 1)) +
+                              others_beyond * __builtin_amdgcn_exp2f(log2_bound_of(outside + 2))) * everything_matches * inverse_winner * SLOP;
         const float x_low = noise_over_prior * inverse_winner;
         // the posterior is taken WITHOUT what was only bounded: its error is then what those barcodes really weigh — at most
         // x_rest, typically a tenth of it (profiles/tools/sim/near_certificate.py) — rather than half the bound every time
