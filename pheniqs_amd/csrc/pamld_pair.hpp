@@ -42,7 +42,8 @@ constexpr float SLOP = 1.0f + 1e-5f;
 // rho(Q36) for the rest (rho = P(mismatch) / P(match) falls with the quality; the logarithms are rounded towards zero).
 // Measured on the model of the sci-RNA-seq shape (profiles/tools/sim/pair_certificate.py): three marks {20, 30, 36}
 // finish 87.3 % of the reads (82.3 % with 196 pairs), these five 91.0 % (89.1 %), and with tables that name a barcode
-// up to two mismatches per segment away 93.6 % (90.8 %).
+// up to two mismatches per segment away 93.6 % (90.8 %) — at the 1e-9 bound of then; at 1e-8 94.4 %, and 95.4 % with the
+// other barcodes in three distance classes (the kernel: 95.3 %).
 constexpr int MARKS = 5;
 constexpr int MARK[MARKS] = {12, 20, 25, 30, 36};
 constexpr float LOG2_RHO[MARKS] = {-3.8922f, -6.6293f, -8.3002f, -9.9643f, -11.9584f};

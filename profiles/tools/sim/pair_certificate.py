@@ -37,28 +37,40 @@ A = fm.prod(axis=1)
 true_rest = P.sum(axis=1) - Pc
 noise = float(dec["noise"]) * 0.25 ** L / float(prior[0] / prior.sum() * (1 - float(dec["noise"])))
 
-def bound(marks, wild_quality=4):
-    """marks: ascending qualities; positions below marks[0] are free, then rho(marks[i]) for those below marks[i + 1], rho(marks[-1]) for the rest"""
+# the other barcodes of each barcode by distance: at its radius, one further away, all the rest (the kernel's three classes)
+in_class = [(bd == radius[:, None]).sum(axis=1), (bd == radius[:, None] + 1).sum(axis=1), ((bd >= radius[:, None] + 2) & (bd < 99)).sum(axis=1)]
+
+
+def bound(marks, wild_quality=4, classes=1):
+    """marks: ascending qualities; positions below marks[0] are free, then rho(marks[i]) for those below marks[i + 1], rho(marks[-1]) for the rest.
+    classes = 1: every other barcode charged at the radius; 3: those at the radius, one further, the rest two further"""
     rho = [10 ** (-m / 10) / (1 - 10 ** (-m / 10)) for m in marks]
     below = [(q < m).sum(axis=1) for m in marks]
-    needed = np.maximum(radius[c] - k - below[0], 0)
-    value = 4.0 ** (q < wild_quality).sum(axis=1)
-    for i in range(len(marks) - 1):
-        take = np.minimum(needed, below[i + 1] - below[i])
-        value = value * rho[i] ** take
-        needed = needed - take
-    value = value * rho[-1] ** needed
-    return (N - 1) * A * value
+
+    def charged(outside):
+        needed = np.maximum(outside - below[0], 0)
+        value = 4.0 ** (q < wild_quality).sum(axis=1)
+        for i in range(len(marks) - 1):
+            take = np.minimum(needed, below[i + 1] - below[i])
+            value = value * rho[i] ** take
+            needed = needed - take
+        return value * rho[-1] ** needed
+
+    if classes == 1:
+        return (N - 1) * A * charged(radius[c] - k)
+    return A * sum(in_class[j][c] * charged(radius[c] - k + j) for j in range(3))
 
 known2 = (k0 <= 2) & (k1 <= 2)          # tables that name the barcode of a word up to TWO mismatches away
-for marks, reach in (([20, 30, 36], 1), ([12, 20, 30, 36], 1), ([12, 20, 25, 30, 36], 1), ([12, 20, 30, 36], 2), ([12, 20, 25, 30, 36], 2), ([12, 20, 25, 30, 36, 37], 2)):
-    U = bound(marks)
+REST_MAX = 1e-8          # the kernel's (1e-9 when the first four lines below were the choice to make)
+for marks, reach, classes in (([20, 30, 36], 1, 1), ([12, 20, 30, 36], 1, 1), ([12, 20, 25, 30, 36], 1, 1), ([12, 20, 30, 36], 2, 1), ([12, 20, 25, 30, 36], 2, 1),
+                              ([12, 20, 25, 30, 36, 37], 2, 1), ([12, 20, 25, 30, 36], 2, 3)):
+    U = bound(marks, classes=classes)
     named = known if reach == 1 else known2
     most = 2 if reach == 1 else 4
     assert (true_rest <= U * (1 + 1e-9))[named & strict & (k <= most)].all(), "bound violated"
     x_rest = U / Pc; x_low = noise / Pc
-    finished = strict & named & (k <= most) & (Pc > 0.25 ** L) & (x_low + x_rest <= 3e-4) & (x_rest <= 1e-9)
-    print("marks", marks, "reach", reach, "finished %.2f %%" % (100 * finished.mean()), " of k=0: %.2f %%, k=1: %.2f %%, k=2: %.2f %%" % tuple(100 * finished[k == kk].mean() for kk in (0, 1, 2)),
+    finished = strict & named & (k <= most) & (Pc > 0.25 ** L) & (x_low + x_rest <= 3e-4) & (x_rest <= REST_MAX)
+    print("marks", marks, "reach", reach, "classes", classes, "finished %.2f %%" % (100 * finished.mean()), " of k=0: %.2f %%, k=1: %.2f %%, k=2: %.2f %%" % tuple(100 * finished[k == kk].mean() for kk in (0, 1, 2)),
           " shares k=0 %.1f k=1 %.1f k=2 %.1f" % tuple(100 * (k == kk).mean() for kk in (0, 1, 2)))
 U = true_rest
 finished = strict & known & (k <= 2) & (Pc > 0.25 ** L) & ((noise + U) / Pc <= 3e-4)
