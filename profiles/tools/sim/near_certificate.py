@@ -13,7 +13,7 @@ from pheniqs_amd import synthetic
 LIST = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 TOL = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-9
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-job, recipe = synthetic.config_job("C2", "pamld")
+job, recipe = synthetic.config_job(os.environ.get("CONFIG", "C2"), "pamld")        # CONFIG=S384: a crowded set
 dec = job["sample"]
 words, prior = synthetic._codec_arrays(dec)
 N, L = words.shape
