@@ -3,10 +3,16 @@
 
 Workload (BASELINE.json configs[1], "C2"): 100 M synthetic reads, one 8 bp index, 96 barcodes, PAMLD, all
 inputs resident in HBM before the timed region.  One step = one pass of the hot path over the whole batch
-(TranscodingDecoder::classify for every read + the end of run counter merge).  With N GPUs every rank
-decodes its own 100 M reads (weak scaling, no data path collective) and the integer counter buffer is merged
-by one RCCL all-reduce per step.  `python bench.py --gpus N` without a torchrun environment starts the N ranks
-itself (fresh child processes, before this process has touched a GPU).
+(TranscodingDecoder::classify for every read).  With N GPUs every rank decodes its own 100 M reads per step (weak
+scaling, no data path collective); the K timed steps are K batches of ONE run, whose integer counter buffers are
+merged by one RCCL all-reduce at its end, inside the timed region (reference transcode.cpp:1816-1818: the merge
+happens once, when the run ends) — `"merge": "once per run"` in the line.  `python bench.py --gpus N` without a
+torchrun environment starts the N ranks itself (fresh child processes, before this process has touched a GPU);
+`--share-device` puts every rank on cuda:0 with the gloo backend (RCCL wants a device per rank), so that the N > 1
+branch can be exercised on a box with one GPU (tests/test_gpu_bench_ranks.py).
+
+Every read of the batch is its own draw, made on the device (`pheniqs_amd.synthetic.generate_planes_device`); with
+`--pool N` a pool of N reads drawn by numpy is tiled to size instead (what rounds 1 and 2 measured).
 
 Besides the contract line's fields the JSON line carries, from the same run: `roofline` (dominant kernel, HIP events
 on the launch stream; `step_frac` = the whole step against the same roofline), `cpu_baseline`, and by default three
@@ -29,23 +35,29 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def profiled_traffic(mode, reads, config="C2", algorithm="pamld", kernel_mode="fast"):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/rNN_summary.json),
-    scaled to this run's reads per launch.  PMC counters cannot be read from inside the benchmark itself, and the
-    committed summaries are of the headline workload only (C2, PAMLD): null for anything else."""
+def shape_key(config, algorithm, kernel_mode, priors):
+    """The name a workload has in profiles/rNN_traffic.json."""
+    return "%s_%s%s%s" % (config, algorithm, "" if kernel_mode == "fast" else "_" + kernel_mode, "" if priors == "uniform" else "_" + priors + "_priors")
+
+
+def profiled_traffic(reads, config="C2", algorithm="pamld", kernel_mode="fast", priors="uniform"):
+    """HBM bytes of one step from the newest committed PMC summary (profiles/rNN_traffic.json, written by
+    profiles/summarize.py from FETCH_SIZE / WRITE_SIZE passes of this same script), scaled to this run's reads.
+    PMC counters cannot be read from inside the benchmark itself.  Returns {"dominant": bytes of the dominant kernel's
+    launches, "step": bytes of every kernel of the step, "build": the build the passes were taken on, "stale": whether
+    that is another build than the library loaded now} or None when no summary holds this workload."""
     import glob
-    if config != "C2" or algorithm != "pamld":
-        return None
-    pattern = "r*_summary.json" if kernel_mode == "fast" else "r*_summary_%s.json" % kernel_mode
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
-        if kernel_mode == "fast" and not os.path.basename(path).endswith("_summary.json"):
-            continue
+    from pheniqs_amd import capi
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
-            entry = json.load(open(path)).get(mode)
+            summary = json.load(open(path))
         except (OSError, ValueError):
             continue
+        entry = summary.get("shapes", {}).get(shape_key(config, algorithm, kernel_mode, priors))
         if entry:
-            return entry["traffic_bytes_per_read"] * reads
+            return {"dominant": entry["dominant_bytes_per_read"] * reads, "step": entry["step_bytes_per_read"] * reads,
+                    "step_bytes_per_read": entry["step_bytes_per_read"], "file": os.path.basename(path),
+                    "build": summary.get("build"), "stale": summary.get("build") != capi.build_id()}
     return None
 
 
@@ -231,11 +243,23 @@ class Workload:
             self.job = capi.compile_job(spec)
         self.bytes_per_read = synthetic.algorithmic_bytes_per_read(self.job)          # 37 for C2
         self.n = reads
+        s = self.set = DecoderSet(self.job, device=local_rank)
+        s.set_mode(capi.MODE_FAST if mode == "fast" else capi.MODE_LITERAL)
+        self.result = torch.zeros(max(1, s.n_result) * reads * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
+        self.word = torch.zeros(reads, dtype=torch.int32, device=device)
+        self.counters = s.stats_tensor()
+        self.stream = torch.cuda.current_stream().cuda_stream
+        if pool <= 0 or pool >= reads:
+            # every read its own draw, on the device; the first Mi reads come back for the CPU baseline and the parity check
+            self.pool_n = reads
+            self.base, self.qual, self.flags, (self.code, self.quality, self.flag, self.offsets) = synthetic.generate_planes_device(
+                torch, self.job, s.decoders, s.plane_width, reads, recipe["seed"] + 1000 * rank, device)
+            torch.cuda.synchronize(device)
+            torch.cuda.empty_cache()
+            return
         self.pool_n = min(pool, reads)
         tiles = -(-reads // self.pool_n)
         self.code, self.quality, self.flag, self.offsets = synthetic.generate_rows(self.job, self.pool_n, recipe["seed"] + 1000 * rank)
-        s = self.set = DecoderSet(self.job, device=local_rank)
-        s.set_mode(capi.MODE_FAST if mode == "fast" else capi.MODE_LITERAL)
 
         def resident_planes(rows):
             """decoder major planes of the pool, every plane tiled to n reads, concatenated: the layout phq_classify_device takes"""
@@ -250,10 +274,6 @@ class Workload:
         self.base = resident_planes(self.code)
         self.qual = resident_planes(self.quality)
         self.flags = torch.from_numpy(self.flag).to(device).repeat(tiles)[:reads].contiguous()
-        self.result = torch.zeros(max(1, s.n_result) * reads * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=device)
-        self.word = torch.zeros(reads, dtype=torch.int32, device=device)
-        self.counters = s.stats_tensor()
-        self.stream = torch.cuda.current_stream().cuda_stream
 
     def step(self, events=None):
         """One batch of the job: the counters keep accumulating, as a run's do from batch to batch."""
@@ -298,8 +318,9 @@ class Workload:
         words = self.set.stats_export()
         total = int(words[0] + words[1])
         assert total == self.n * world * steps, (total, self.n, world, steps)      # every read of every batch counted once
+        self.counted_reads = total
         bytes_per_step = self.bytes_per_read * self.n
-        return {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
+        return {"elapsed": elapsed, "counted_reads": total, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
                 "kernels": kernels, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
                 "launches_per_step": kernels[dominant]["launches"] / steps,
                 "achieved_GBs": bytes_per_step / (kernel_ms * 1e-3) / 1e9, "step_GBs": bytes_per_step / (classify_ms * 1e-3) / 1e9}
@@ -316,7 +337,10 @@ def main():
     parser.add_argument("--steps", type=int, default=10)
     parser.add_argument("--warmup", type=int, default=3)
     parser.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU per step")
-    parser.add_argument("--pool", type=int, default=1 << 20, help="distinct synthetic reads tiled to --reads")
+    parser.add_argument("--pool", type=int, default=0,
+                        help="0 (default): every read of the batch is its own draw, made on the device; N: a numpy pool of N distinct reads tiled to --reads")
+    parser.add_argument("--share-device", action="store_true",
+                        help="every rank on cuda:0, gloo backend: the N > 1 branch on a box with one GPU (a test switch; RCCL wants one device per rank)")
     parser.add_argument("--algorithm", default="pamld", choices=["pamld", "mdd"])
     parser.add_argument("--config", default="C2", choices=sorted(CONFIG_TEXT),
                         help="BASELINE.json config shape; C2 is the headline workload, the others are for exploration (U96 / U384: unique dual index pairs, not in BASELINE.json)")
@@ -345,11 +369,13 @@ def main():
         raise SystemExit(subprocess.run(command).returncode)
 
     import torch
-    from pheniqs_amd import RESULT_DTYPE, distributed
+    from pheniqs_amd import RESULT_DTYPE, capi, distributed
 
-    rank, local_rank, world = distributed.initialise("nccl")
+    rank, local_rank, world = distributed.initialise("gloo" if args.share_device else "nccl")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     extra_legs = world == 1 and not args.no_extra_legs and args.config == "C2" and args.algorithm == "pamld" and args.priors == "uniform"
@@ -364,6 +390,7 @@ def main():
     n = w.n
 
     if rank == 0:
+        traffic = profiled_traffic(n, args.config, args.algorithm, args.mode, args.priors)
         line = {
             "metric": "Mreads/s decoded (PAMLD, 96-plex 8bp)" if args.algorithm == "pamld" else "Mreads/s decoded (MDD, 96-plex 8bp)",
             "value": m["Mreads/s"],
@@ -375,14 +402,28 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if args.algorithm == "pamld" else "u32",
+            # what the arithmetic really runs in: fast mode finishes most reads in single precision under a certificate
+            # that holds the posterior to 1e-8 of the fp64 reference value and decides every integer exactly; the tiers
+            # behind it and literal mode are fp64
+            "dtype": "u32" if args.algorithm != "pamld" else "f64" if args.mode == "literal" else "f32 certified to 1e-8 + f64 exact tiers",
             "data": "synthetic",
             "config": {"workload": "%s: %d reads per GPU, %s, %s, inputs resident in HBM" % (args.config, n, CONFIG_TEXT[args.config], args.algorithm.upper()),
                        "reads_per_gpu": n, "pool": w.pool_n, "kernel_mode": args.mode,
-                       "sharding": "reads x%d, the steps are batches of one run, counters merged by one all-reduce at its end" % world},
+                       "sharding": "reads x%d, the steps are batches of one run, counters merged by one all-reduce at its end" % world,
+                       "ranks_share_device": bool(args.share_device)},
+            "merge": "once per run",
+            "counted_reads": m["counted_reads"],
             # the dominant kernel kind (all its launches of a step) against the HBM roofline; step_frac: the whole step
             "roofline": {"bound": "hbm", "achieved": m["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": m["achieved_GBs"] / HBM_PEAK_GBS, "traffic": profiled_traffic(m["dominant"], n, args.config, args.algorithm, args.mode),
+                         "frac": m["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic["dominant"] if traffic else None,
+                         # HBM bytes of the WHOLE step (every kernel), the build the counter passes ran on, and whether
+                         # that is another build than the library loaded now (profiles/rNN_traffic.json)
+                         "traffic_step": traffic["step"] if traffic else None,
+                         "traffic_step_bytes_per_read": traffic["step_bytes_per_read"] if traffic else None,
+                         "traffic_file": traffic["file"] if traffic else None,
+                         "traffic_build": traffic["build"] if traffic else None,
+                         "traffic_stale": traffic["stale"] if traffic else None,
+                         "build": capi.build_id(),
                          "kernel": m["dominant"], "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches_per_step"],
                          "algorithmic_bytes_per_read": w.bytes_per_read,
                          "step_achieved": m["step_GBs"], "step_frac": m["step_GBs"] / HBM_PEAK_GBS,
@@ -392,14 +433,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w.job, w.code, w.quality, w.flag)
-            got = w.result[: w.pool_n * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, first pool pass
-            line["parity_checked_reads"] = parity_check(w.job, w.code, w.quality, w.flag, got, min(w.pool_n, 1 << 19))
+            got = w.result[: w.code.shape[0] * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, the reads the host holds a copy of
+            line["parity_checked_reads"] = parity_check(w.job, w.code, w.quality, w.flag, got, min(w.code.shape[0], 1 << 19))
         if world == 1 and args.host_staged and (extra_legs or "--host-staged" in " ".join(sys.argv)):
             line["staged"] = host_staged(torch, w, args.host_staged)
         code, quality, flag = w.code, w.quality, w.flag
         w.close()
         if world == 1 and args.fastq and (extra_legs or "--fastq" in " ".join(sys.argv)):
             line["fastq_to_sam"] = fastq_end_to_end(args, code, quality, flag, args.fastq)
+        if extra_legs and args.mode == "fast":
+            # the same workload with every read through the reference's own sums in fp64 (PHQ_MODE_LITERAL), fewer steps
+            literal = Workload(torch, device, local_rank, rank, args.config, args.algorithm, "literal", args.reads, args.pool, args.priors)
+            lm = literal.measure(2, 1, 1, barrier)
+            line["literal_Mreads/s"] = lm["Mreads/s"]
+            line["literal"] = {"dtype": "f64", "Mreads/s": lm["Mreads/s"], "ms_per_step": lm["ms_per_step"], "step_frac": lm["step_GBs"] / HBM_PEAK_GBS}
+            literal.close()
         if extra_legs:
             # the other BASELINE shapes that fit one GPU, kernel only like `value`, fewer steps
             line["shapes"] = {}
@@ -410,11 +458,14 @@ def main():
                                                            ("C3_pamld_estimated_priors", "C3", "pamld", 50_000_000, "estimated")):
                 shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool, priors)
                 sm = shape.measure(5, 2, 1, barrier)
+                shape_traffic = profiled_traffic(reads, config, algorithm, args.mode, priors)
                 line["shapes"][name] = {"workload": "%s: %d reads, %s, %s%s" % (config, reads, CONFIG_TEXT[config], algorithm.upper(),
                                                                               ", priors that differ between the barcodes" if priors == "estimated" else ""),
                                         "Mreads/s": sm["Mreads/s"], "ms_per_step": sm["ms_per_step"], "algorithmic_bytes_per_read": shape.bytes_per_read,
                                         "step_frac": sm["step_GBs"] / HBM_PEAK_GBS, "dominant_kernel": sm["dominant"],
                                         "dominant_kernel_frac": sm["achieved_GBs"] / HBM_PEAK_GBS,
+                                        "traffic_step_bytes_per_read": shape_traffic["step_bytes_per_read"] if shape_traffic else None,
+                                        "traffic_stale": shape_traffic["stale"] if shape_traffic else None,
                                         "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in sm["kernels"].items()}}
                 shape.close()
         print(json.dumps(line))
@@ -428,7 +479,7 @@ def host_staged(torch, w, m):
     """PCIe inclusive rates of phq_classify_host on m reads of the workload; never the headline value."""
     from pheniqs_amd import RESULT_DTYPE
     s = w.set
-    reps = -(-m // w.pool_n)
+    reps = -(-m // w.code.shape[0])              # the host copy of the first Mi reads, tiled
     host_base = s.planes_from_rows(np.tile(w.code, (reps, 1))[:m], w.offsets)
     host_qual = s.planes_from_rows(np.tile(w.quality, (reps, 1))[:m], w.offsets)
     host_flag = np.tile(w.flag, reps)[:m].copy()

@@ -290,6 +290,11 @@ void phq_free_string(char* text);
  * Release `*adjusted_json` with phq_free_string. */
 int phq_adjust_prior(phq_decoder_set* set, const uint64_t* host_words, const char* job_json, char** adjusted_json);
 
+/* SHA-256 (hex) over the sources this library was built from (the .cpp, .hip and .hpp files of pheniqs_amd/csrc, its Makefile and
+ * this header, sorted by name): ties a measurement or a committed profile summary to a build.  No reference counterpart
+ * (the reference prints its version from version.h through `pheniqs --version`, interface.cpp). */
+const char* phq_build_id(void);
+
 #ifdef __cplusplus
 }
 #endif

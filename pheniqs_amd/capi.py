@@ -27,7 +27,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
            "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
-           "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior")
+           "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id")
 
 
 class PheniqsError(RuntimeError):
@@ -106,8 +106,30 @@ def load_library():
     L.phq_free_string.argtypes = [P]
     L.phq_free_string.restype = None
     L.phq_adjust_prior.argtypes = [P, P, ctypes.c_char_p, ctypes.POINTER(P)]
+    L.phq_build_id.argtypes = []
+    L.phq_build_id.restype = ctypes.c_char_p
     _library = L
     return L
+
+
+def build_id() -> str:
+    """phq_build_id: SHA-256 over the sources the loaded library was built from."""
+    return load_library().phq_build_id().decode()
+
+
+def source_id() -> str:
+    """The same hash computed from the tree (pheniqs_amd/csrc/Makefile, `build_id.inc`): equal to build_id() when the
+    library is the build of the sources beside it."""
+    import glob
+    import hashlib
+    csrc = os.path.join(HERE, "csrc")
+    names = sorted([os.path.basename(p) for pattern in ("*.cpp", "*.hip", "*.hpp") for p in glob.glob(os.path.join(csrc, pattern))] + ["Makefile"])
+    # make's $(sort) orders byte wise over the whole word list, the header's relative path included
+    words = sorted(names + ["../../include/pheniqs_amd.h"])
+    digest = hashlib.sha256()
+    for word in words:
+        digest.update(open(os.path.join(csrc, word), "rb").read())
+    return digest.hexdigest()
 
 
 def compile_job(job: Dict[str, Any]) -> Dict[str, Any]:

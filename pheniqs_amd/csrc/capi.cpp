@@ -363,4 +363,11 @@ int phq_format_double(double value, int32_t precision, char* buffer, int32_t cap
     });
 }
 
+const char* phq_build_id(void) {
+    static const char id[] =
+#include "build/build_id.inc"
+        ;
+    return id;
+}
+
 }  // extern "C"

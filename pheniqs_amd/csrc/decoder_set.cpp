@@ -560,7 +560,23 @@ void DecoderSet::build_device_images() {
                     }
                     d.pair_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                     d.pair_ready = (c.algorithm == Algorithm::PAMLD && 2 * usable >= N) ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
-                    d.mdd_pair_ready = paired_mdd ? 1 : 0;
+                    // one lookup per segment is the reference's first fit (mdd.cpp:50-80) only while at most ONE word of a segment
+                    // can be within its tolerance of an observation: tolerance <= (smallest distance between two of the
+                    // segment's words - 1) / 2, the bound the compiler enforces (metric.h:228) and a hand written compiled
+                    // document may exceed — such a codec takes the scan kernels
+                    bool within_bound = true;
+                    for(int32_t s = 0; s < 2; ++s) {
+                        const uint32_t mask = (c.barcode_length[static_cast<size_t>(s)] >= 32 ? 0xffffffffu : ((1u << c.barcode_length[static_cast<size_t>(s)]) - 1u)) << c.segment_offset[static_cast<size_t>(s)];
+                        int closest = 32;
+                        for(int32_t b = 0; b < N; ++b) {
+                            for(int32_t o = b + 1; o < N; ++o) {
+                                closest = std::min(closest, __builtin_popcount(((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)])) & mask));
+                            }
+                        }
+                        const int32_t tolerance = d.distance_tolerance[s];
+                        if(tolerance < 0 || 2 * tolerance + 1 > closest) { within_bound = false; }
+                    }
+                    d.mdd_pair_ready = (paired_mdd && within_bound) ? 1 : 0;
                 }
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {
@@ -716,6 +732,7 @@ void DecoderSet::build_device_images() {
                             // one lookup per segment (mdd_near.hpp, COMBINATORIAL): pamld_near.hpp's table over each segment's
                             // distinct words, and the words' code bits
                             std::vector<uint32_t> planes;
+                            bool within_bound = true;          // as for the paired kind: at most one word of a segment within its tolerance
                             for(int32_t s2 = 0; s2 < 2; ++s2) {
                                 const int32_t length = c.barcode_length[static_cast<size_t>(s2)];
                                 const auto& set = distinct[static_cast<size_t>(s2)];
@@ -729,11 +746,17 @@ void DecoderSet::build_device_images() {
                                     planes.push_back(low[u]);
                                     planes.push_back(high[u]);
                                 }
+                                int closest = 32;
+                                for(size_t u = 0; u < set.size(); ++u) {
+                                    for(size_t o = u + 1; o < set.size(); ++o) { closest = std::min(closest, __builtin_popcount((low[u] ^ low[o]) | (high[u] ^ high[o]))); }
+                                }
+                                const int32_t tolerance = d.distance_tolerance[s2];
+                                if(tolerance < 0 || 2 * tolerance + 1 > closest) { within_bound = false; }
                                 const NearTables tables = build_near_tables(low, high, length, std::vector<uint32_t>(set.size(), 0u));
                                 d.cross_near_table[s2] = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
                             }
                             d.mdd_cross_word = static_cast<const uint32_t*>(upload(planes.data(), planes.size() * sizeof(uint32_t)));
-                            d.mdd_cross_ready = 1;
+                            d.mdd_cross_ready = within_bound ? 1 : 0;
                         }
                         if(!d.uniform_prior && S == 2 && c.algorithm == Algorithm::PAMLD) {
                             // priors that differ between the barcodes: by combination, single precision, for the weighted scans
@@ -912,6 +935,7 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
         if(worklist_capacity_ < n_read) {
             // grown outside of any stream capture; sized for the worst case (every read deferred)
             check(hipStreamSynchronize(static_cast<hipStream_t>(stream)), "hipStreamSynchronize");
+            if(order_pending_ && order_event_ != nullptr) { check(hipEventSynchronize(static_cast<hipEvent_t>(order_event_)), "hipEventSynchronize"); }      // the previous call may have run on another stream
             (void)hipFree(device_worklist_);
             device_worklist_ = nullptr;
             check(hipMalloc(reinterpret_cast<void**>(&device_worklist_), worklist_words(n_read) * sizeof(uint32_t)), "hipMalloc");
@@ -919,8 +943,9 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
         }
         worklist = device_worklist_;
     }
-    // The worklist, the carry region and the per workgroup counters in front of them belong to the set, not to the
-    // call: two calls on two streams must not run at once.  A call on another stream than the previous one first waits
+    // The worklist, the carry region, the per workgroup counters in front of them and the counter staging words of
+    // count_results_kernel (DevDecoder::count_staging) belong to the set, not to the call: two calls on two streams must
+    // not run at once, with or without a worklist.  A call on another stream than the previous one first waits
     // (on the device) for that one's kernels; calls on one stream are ordered by the stream itself.
     if(order_event_ == nullptr) {
         hipEvent_t event;
@@ -931,11 +956,9 @@ void DecoderSet::classify_device(int64_t batch_capacity, int64_t first_read, int
         check(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(order_event_), 0), "hipStreamWaitEvent");
     }
     run_stages(batch_capacity, first_read, n_read, base_planes, quality_planes, flag, result, word, stream, worklist);
-    if(worklist != nullptr) {
-        check(hipEventRecord(static_cast<hipEvent_t>(order_event_), static_cast<hipStream_t>(stream)), "hipEventRecord");
-        order_pending_ = true;
-        last_stream_ = stream;
-    }
+    check(hipEventRecord(static_cast<hipEvent_t>(order_event_), static_cast<hipStream_t>(stream)), "hipEventRecord");
+    order_pending_ = true;
+    last_stream_ = stream;
 }
 
 // counters + segments: every workgroup owns ceil(tiles / grid) * 256 slots, the worst case "every read deferred"

@@ -1,0 +1,652 @@
+// K0s (streaming): PamlDecoder<T>::classify, the neighbour list tier and the product form scan in ONE persistent kernel.
+//
+//   reference pamld.cpp:37-123   posterior over all barcodes, noise / confidence / high quality filters
+//   reference barcode.h:131-164  P(r|b) = pow(base, sum of Phred costs), distance, high quality distance
+//
+// Rounds 1 and 2 ran a stage as a chain of launches: the neighbour list kernel (pamld_near.hpp) finished ~93 % of the
+// reads and wrote the others to a worklist in HBM, the product form kernel (pamld_lut.hpp) came back for them — their
+// inputs through carry planes, their 16 + 4 byte results as scattered partial line stores, short lists, a memory round
+// trip per tile — and cost a third of the step for 7 % of the reads.  Here every WAVE is its own pipeline:
+//   * pass A, every 64 read tile: name the barcode c the read sits on or next to (one table lookup), score c and the
+//     15 barcodes nearest to c exactly from per read tables in LDS, bound everything else, finish the read under the
+//     certificate of pamld_near.hpp (posterior to 1e-8, every integer exact);
+//   * what pass A cannot certify waits in the wave's own 64 entry ring in LDS — code words, quality words, carried
+//     state, ordinal: 24 bytes — no atomics, no barrier: the wave's ballot and a popcount place the entries;
+//   * pass C, whenever the next tile's deferred reads would overflow the ring (every ~14 tiles on the 96 x 8 nt
+//     benchmark): the wave turns to its ring with all lanes busy — the product form scan over every barcode with the
+//     certificate of pamld_lut.hpp (dominant winner, winner and posterior again in fp64) — and stores those reads'
+//     records and status words.  Only what still cannot be decided (a second plausible barcode, ~0.9 %) goes to the
+//     wave's segment of the HBM worklist for the exact tier (pamld_cross.hpp) and the literal kernel.
+// No workgroup barrier after the set up, no HBM round trip for the deferred reads, one launch instead of two.
+//
+// Arithmetic.  Both passes work in units of the read's all-match product A = prod_j P(match | q_j): the per read tables
+// hold products of rho_j = P(mismatch | q_j) / P(match | q_j) over a group's mismatching positions (entry 0 = 1, written
+// once per kernel), so a barcode's probability over A is T0[m0] * T1[m1], the winner of a read ON its barcode is exactly
+// 1, and a table costs 11 multiplications instead of 24.  A itself only enters the noise term (single precision in
+// pass A; pass C forms it in fp64 next to the winner's probability).  The tables are laid out as pamld_lut.hpp's permuted
+// ones — lane << 2 | group << 8 | wave bit << 9 | entry << 10 | wave bits << 14 — so one v_perm_b32 makes an address from
+// a byte of the mismatch field word in both passes; the neighbour records hold their 16 barcodes as eight pairs in
+// that kernel's plane words.
+#pragma once
+
+#include "kernel_common.hpp"
+#include "pamld_lut.hpp"
+#include "pamld_near.hpp"
+
+namespace phq {
+namespace stream {
+
+constexpr int FACTOR_ROWS = 129;
+constexpr int LIST = 16;                       // barcodes scored in pass A: c and the 15 nearest to it
+constexpr int RECORD_WORDS = STREAM_RECORD_WORDS;   // 8 low plane words, 8 high plane words, {radius, cnt_r, cnt_rest, index}
+constexpr int RING = 64;                       // entries of a wave's ring
+constexpr int RING_PLANES = 6;                 // code word 0, 1, quality word 0, 1, carried state, ordinal
+// the workgroup histogram of this kernel, per bin and [qc fail | pass filter] half: {count | distance << 32,
+// confidence low limb, confidence high limb, low conditional confidence count | low confidence count << 32}; a
+// workgroup sees fewer than 2^31 reads of at most 8 nt per launch, so no half word overflows
+constexpr int BIN_WORDS = 8;
+
+template <int L, int WAVES> struct Shape {
+    static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
+    static_assert(WAVES >= 2 && WAVES <= 16 && WAVES % 2 == 0, "pairs of waves share a 16 KiB block of tables");
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr uint32_t TABLE_BYTES = WAVES * 8192u;        // wave w: block w >> 1 of 16 KiB, bit 9 = w & 1
+    static constexpr uint32_t FACTOR_AT = TABLE_BYTES;            // FACTOR_ROWS x {P(match), rho} floats; a multiple of 1024: rows are reached by OR
+    static constexpr uint32_t DOUBLE_AT = FACTOR_AT + 1040;       // FACTOR_ROWS x {P(match), P(mismatch)} doubles
+    static constexpr uint32_t RING_AT = DOUBLE_AT + FACTOR_ROWS * 16;
+    static constexpr uint32_t RING_BYTES = RING_PLANES * RING * 4;
+    static constexpr uint32_t WORDS_AT = RING_AT + WAVES * RING_BYTES;        // pamld_lut.hpp's plane words of the codec
+    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u; }
+    __host__ __device__ static constexpr uint32_t record_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return record_at(n_barcode) + static_cast<uint32_t>(n_barcode) * RECORD_WORDS * 4u; }
+    __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + static_cast<uint32_t>(n_barcode + 1) * BIN_WORDS); }
+    __host__ __device__ static constexpr int positions(int g) { return L - 4 * g >= 4 ? 4 : L - 4 * g; }
+    static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. L - 1 in the second word
+    static_assert(FACTOR_AT % 1024 == 0 && DOUBLE_AT % 16 == 0 && RING_AT % 16 == 0 && WORDS_AT % 16 == 0, "alignment");
+};
+
+typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+typedef float Pair __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float* LdsFloats;
+typedef __attribute__((address_space(3))) const Quad* LdsQuads;
+typedef __attribute__((address_space(3))) const Pair* LdsPairs;
+using near::and_or;
+using lut::low_bit;
+
+__device__ __forceinline__ void bin_add(unsigned long long* histogram, uint32_t bin, uint32_t pass_filter, uint32_t word, unsigned long long value) {
+    atomicAdd(&histogram[STAT_JOB_WORDS + bin * BIN_WORDS + pass_filter * 4u + word], value);
+}
+
+// STATE: where a read's carried state comes from (pamld_near.hpp): 0 nothing to load, 1 the input flag bytes, 2 the
+// status word of the stage before
+template <int L, int STATE, int WAVES>
+__global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kernel(StageArgs args) {
+    typedef Shape<L, WAVES> Layout;
+    constexpr int THREADS = Layout::THREADS;
+    constexpr uint32_t VALID1 = Layout::VALID1;
+    constexpr uint32_t FIELD_MASK = 0x3c3c3c3cu;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
+    float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::FACTOR_AT);                 // [row] {P(match), rho}
+    double (*const factor_double)[2] = reinterpret_cast<double (*)[2]>(lds_raw + Layout::DOUBLE_AT);      // [row][0 match | 1 mismatch]
+    uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + Layout::WORDS_AT);
+    DecoderRef d = *constant_cast(args.decoder);
+    const int n_barcode = d.n_barcode;
+    uint32_t* const records = reinterpret_cast<uint32_t*>(lds_raw + Layout::record_at(n_barcode));
+    unsigned long long* const histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::histogram_at(n_barcode));
+
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    // this lane's corner of the tables: everything of an entry address but group (bit 8) and entry (bits 10..13)
+    const uint32_t wave_byte = ((wave & 1u) << 1) | (((wave >> 1) & 3u) << 6);        // the wave's share of byte 1 of an address
+    const uint32_t lane_low = (lane << 2) | ((wave >> 3) << 16);                      // bytes 0 and 2 of an address (v_perm_b32 picks them)
+    const uint32_t lane_const = lane_low | (wave_byte << 8);
+    const uint32_t wave_bytes = wave_byte * 0x01010101u;
+
+    for(int i = threadIdx.x; i < FACTOR_ROWS; i += THREADS) {
+        const double m = i < 128 ? d.match_probability[i] : d.uniform_probability;
+        const double e = i < 128 ? d.mismatch_probability[i] : d.uniform_probability;
+        factor_single[i] = make_float2(static_cast<float>(m), static_cast<float>(e / m));
+        factor_double[i][0] = m;
+        factor_double[i][1] = e;
+    }
+    {
+        // per block of 8 barcodes: the low plane words of the block, then its high plane words (pamld_lut.hpp)
+        const int padded = (n_barcode + 7) & ~7;
+        for(int w = threadIdx.x; w < padded >> 1; w += THREADS) {
+            const uint32_t sliced = d.barcode_packed2[w];
+            const int at = 8 * (w / 4) + (w % 4);
+            lds_words[at] = lut::low_plane(sliced);
+            lds_words[at + 4] = lut::high_plane(sliced);
+        }
+    }
+    for(int w = threadIdx.x; w < n_barcode * RECORD_WORDS; w += THREADS) { records[w] = d.stream_record[w]; }
+    for(int i = threadIdx.x; i < STAT_JOB_WORDS + (n_barcode + 1) * BIN_WORDS; i += THREADS) { histogram[i] = 0; }
+    // entry 0 of both tables (no mismatch in the group) is 1 in units of the all-match product: written once
+    *reinterpret_cast<float*>(lds_raw + lane_const) = 1.0f;
+    *reinterpret_cast<float*>(lds_raw + lane_const + 256u) = 1.0f;
+    __syncthreads();
+
+    const int64_t n = args.n_read;
+    const int64_t tiles = (n + 63) / 64;
+    const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
+    const uint16_t* const nearest = d.stream_table;
+    uint32_t* const ring = reinterpret_cast<uint32_t*>(lds_raw + Layout::RING_AT + wave * Layout::RING_BYTES);
+    // this wave's segment of the HBM worklist (what pass C cannot decide either)
+    const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+    uint32_t* const segment = args.worklist + own_segment * args.worklist_stride;
+    uint32_t segment_count = 0;
+    uint32_t ring_count = 0;
+
+    const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
+    const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
+    // pass A tells a high quality mismatch of a read one mismatch from c by its rho: rho falls as the quality rises from
+    // 1 on; quality 0 (rho = 1, a value no other row holds) is below every threshold but 0
+    const float rho_at_threshold = high_quality_threshold <= 0 ? __builtin_inff() : high_quality_threshold >= 128 ? -1.0f : factor_single[high_quality_threshold].y;
+    const bool zero_is_high = high_quality_threshold <= 0;
+    const float uniform_noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);
+    const float noise_floor = static_cast<float>(d.random_barcode_probability) * near::SLOP;
+    const double confidence_threshold = d.confidence_threshold;
+    const double common_prior = d.concentration[0];
+    const int hq_threshold = d.high_quality_distance_threshold;
+    const bool multiplexing = d.multiplexing != 0;
+    const bool identity_index = d.identity_index != 0;
+    const bool last_stage = args.last_stage != 0;
+    constexpr uint32_t FULL_MASK = (L >= 8 ? 0x3c3cu : (0x3cu | (((1u << (L - 4)) - 1u) << 10)));       // the flag bit of each position, one barcode
+
+    struct Inputs { uint32_t code[2]; uint32_t quality[2]; uint32_t state; };
+    auto fetch = [&](int64_t tile, Inputs& in) {
+        const int64_t first = tile * 64;
+        const uint32_t last = static_cast<uint32_t>(min(static_cast<int64_t>(64), n - first)) - 1u;
+        const uint32_t at = min(lane, last);
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + first * 8 + at * 8u);
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + first * 8 + at * 8u);
+        in.code[0] = code_row[0]; in.code[1] = code_row[1];
+        in.quality[0] = quality_row[0]; in.quality[1] = quality_row[1];
+        if(STATE == 1) { in.state = static_cast<uint32_t>(args.input_flag[first + at]); }      // transcode.h:207-211
+        else if(STATE == 2) { in.state = args.word[first + at]; }
+        else { in.state = 0; }
+    };
+    auto gather = [](uint32_t planes) {            // bits 8 j and 8 j + 4 -> bits j and 4 + j
+        const uint32_t t = planes | (planes >> 7);
+        return (t | (t >> 14)) & 0xffu;
+    };
+    // table entry address of (barcode h of a word pair, group g): byte 2 h + g of the fields word to byte 1, the lane's
+    // bytes 0 and 2; the group is the load's immediate offset
+    auto entry = [&](uint32_t fields, int byte, int g) -> float {
+        const uint32_t address = __builtin_amdgcn_perm(fields, lane_low, 0x0c020400u | (static_cast<uint32_t>(byte) << 8));
+        return ((LdsFloats)static_cast<uintptr_t>(address))[g * 64];
+    };
+    // the normalised tables of a read from its rho row
+    auto build_tables = [&](const float (&rho)[8], float (&ge)[2][5]) {
+#pragma unroll
+        for(int g = 0; g < 2; ++g) {
+            const int positions = Layout::positions(g);
+            const int entries = 1 << positions;
+            const float r0 = rho[4 * g], r1 = positions > 1 ? rho[4 * g + 1] : 1.0f, r2 = positions > 2 ? rho[4 * g + 2] : 1.0f, r3 = positions > 3 ? rho[4 * g + 3] : 1.0f;
+            const float lo[4] = {1.0f, r0, r1, r0 * r1};
+            const float hi[4] = {1.0f, r2, r3, r2 * r3};
+            float t[16];
+            float by_count[5] = {1.0f, 0, 0, 0, 0};        // the largest entry with exactly a mismatches
+#pragma unroll
+            for(int m = 1; m < 16; ++m) {
+                if(m < entries) {
+                    t[m] = (m >> 2) == 0 ? lo[m & 3] : (m & 3) == 0 ? hi[m >> 2] : lo[m & 3] * hi[m >> 2];
+                    *reinterpret_cast<float*>(lds_raw + lane_const + static_cast<uint32_t>(g) * 256u + static_cast<uint32_t>(m) * 1024u) = t[m];
+                    const int a = __builtin_popcount(static_cast<unsigned>(m));
+                    by_count[a] = (m == (1 << a) - 1) ? t[m] : fmaxf(by_count[a], t[m]);      // the first entry of a count is 2^a - 1
+                }
+            }
+            // ge[g][a] = the largest entry with a OR MORE mismatches (none past the group's positions): qualities below 4,
+            // where a mismatch is more likely than a match, stay covered
+#pragma unroll
+            for(int a = 4; a >= 0; --a) {
+                ge[g][a] = a > positions ? 0.0f : a == positions ? by_count[a] : fmaxf(by_count[a], ge[g][a + 1 > 4 ? 4 : a + 1]);
+            }
+        }
+    };
+
+    // ---- pass C: the product form scan (pamld_lut.hpp) over the wave's ring --------------------------------------------
+    auto drain = [&](uint32_t count) {
+        // the records and status words pass A stored for these reads (placeholders, by other lanes) must have left
+        // before this pass stores the real ones to the same places: wait for every store of the wave (and its loads)
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
+        const bool live = lane < count;
+        const uint32_t slot = live ? lane : 0u;
+        uint32_t code_words[2] = {ring[slot], ring[RING + slot]};
+        uint32_t quality_words[2] = {ring[2 * RING + slot], ring[3 * RING + slot]};
+        const uint32_t state = ring[4 * RING + slot];
+        const int64_t i = static_cast<int64_t>(ring[5 * RING + slot]);
+        ReadState r;
+        if(STATE != 2) { r.qcfail = (state & 1u) != 0; r.channel = 0; }
+        else { r.qcfail = (state >> 31) != 0; r.channel = static_cast<int32_t>(state & 0x7fffffffu); }
+        bool defer = false;
+
+        uint32_t row[2];                               // factor rows, 8 bits per position
+        uint32_t observed = 0;                         // bit-sliced 2-bit codes; anything outside ACGT arbitrary
+        uint32_t high_quality = 0;                     // flag bits (low_bit of the position)
+        uint32_t outside = 0;                          // flag bits: not A, C, G or T (mismatches every barcode base)
+#pragma unroll
+        for(int w = 0; w < 2; ++w) {
+            const uint32_t valid = w == 0 ? 0xffffffffu : VALID1;
+            const uint32_t x = code_words[w] & (0x0f0f0f0fu & valid);        // BAM codes
+            const uint32_t q8 = quality_words[w] & valid;
+            const uint32_t q7 = q8 & 0x7f7f7f7fu;                             // the table has 128 rows
+            // A, C, G or T = exactly one bit of the nibble: x != 0 and x & (x - 1) == 0   (iupac.h:51-56)
+            const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
+            const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+            const uint32_t strict_bytes = (strict - (strict >> 7)) | strict;                       // 0xff where strict
+            // a base outside ACGT costs the uniform quality against every barcode base (row 128), nothing at
+            // quality 0 (row 0): both factors equal, whatever its 2-bit code compares to (phred.cpp:62-64)
+            const uint32_t nonzero = (q7 + 0x7f7f7f7fu) & 0x80808080u;
+            row[w] = (q7 & strict_bytes) | (nonzero & ~strict_bytes);
+            const uint32_t codes = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
+            observed |= codes << (8 * w + 2);
+            const uint32_t high = ((q7 + high_quality_addend) | q8) & 0x80808080u & valid;
+            const uint32_t flags = gather(((~strict & 0x80808080u & valid) >> 7) | (high >> 3));
+            outside |= (flags & 0xfu) << (8 * w + 2);
+            high_quality |= (flags >> 4) << (8 * w + 2);
+        }
+        float rho[8];
+#pragma unroll
+        for(int j = 0; j < 8; ++j) {
+            if(j < L) { rho[j] = factor_single[(row[j >> 2] >> (8 * (j & 3))) & 0xffu].y; }
+            else { rho[j] = 1.0f; }
+        }
+        observed |= __builtin_amdgcn_alignbit(observed, observed, 16);        // the same read against both halves of a word
+        const uint32_t observed_high = lut::high_plane(observed);
+        const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;   // + the wave's address bits
+        float unused[2][5];
+        build_tables(rho, unused);
+
+        // Single precision scan, eight barcodes at a time (pamld_lut.hpp): per block its maximum and its sum; across
+        // blocks the running maximum, which block holds it, that block's sum set aside, the sum of every other block
+        float others_sum = 0;
+        float held_sum = 0;
+        float best_value = 0;
+        float runner_up = 0;
+        int best_fold = -1;
+        auto block_values = [&](const uint32_t (&w)[8], float (&p)[8]) {
+#pragma unroll
+            for(int k = 0; k < 4; ++k) {
+                const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[4 + k]);
+#pragma unroll
+                for(int h = 0; h < 2; ++h) { p[2 * k + h] = entry(fields, 2 * h, 0) * entry(fields, 2 * h + 1, 1); }
+            }
+        };
+        const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words);
+        const int n_blocks = (n_barcode + 7) >> 3;
+#pragma unroll 2
+        for(int f = 0; f < n_blocks; ++f) {
+            const uint4 first = blocks[2 * f];
+            const uint4 second = blocks[2 * f + 1];
+            const uint32_t w[8] = {first.x, first.y, first.z, first.w, second.x, second.y, second.z, second.w};
+            float p[8];
+            block_values(w, p);
+            if(8 * f + 8 > n_barcode) {                 // the padding of a partial last block
+#pragma unroll
+                for(int k = 1; k < 8; ++k) { if(8 * f + k >= n_barcode) { p[k] = 0.0f; } }
+            }
+            const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+            const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+            const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+            runner_up = __builtin_amdgcn_fmed3f(best_value, block_max, runner_up);
+            others_sum += takes_over ? held_sum : block_sum;
+            held_sum = takes_over ? block_sum : held_sum;
+            best_fold = takes_over ? f : best_fold;
+            best_value = takes_over ? block_max : best_value;
+        }
+        // inside the winning block: the winner (first of equals) and the sum of the other seven, recomputed
+        int best = -1;
+        uint32_t best_flags = 0;
+        float sigma = others_sum;
+        const float winner_single = best_value;
+        {
+            const int block = best_fold < 0 ? 0 : best_fold;
+            uint32_t w[8];
+#pragma unroll
+            for(int k = 0; k < 8; ++k) { w[k] = lds_words[8 * block + k]; }
+            float p[8];
+            block_values(w, p);
+            {
+                const int limit = n_barcode - 8 * block;
+#pragma unroll
+                for(int k = 1; k < 8; ++k) { p[k] = k < limit ? p[k] : 0.0f; }
+            }
+            int within = -1;
+            float q[8];
+#pragma unroll
+            for(int k = 7; k >= 0; --k) {
+                const bool is_top = p[k] == best_value;
+                within = is_top ? k : within;
+                q[k] = is_top ? 0.0f : p[k];
+            }
+            const float rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+            const float second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+            const bool crowded = held_sum - rest >= 1.5f * best_value;         // the block's sum holds the maximum twice
+            runner_up = fmaxf(runner_up, crowded ? best_value : second);
+            sigma += crowded ? best_value : rest;
+            if(best_fold >= 0 && best_value > 0.0f && within >= 0) {
+                best = 8 * block + within;
+                const int at = 8 * block + within / 2;
+                const uint32_t fields = (observed_low ^ lds_words[at]) | (observed_high ^ lds_words[at + 4]);
+                best_flags = ((fields >> (16 * (best & 1))) | outside) & FULL_MASK;
+            }
+        }
+
+        DevResult out;
+        out.index = 0; out.distance = 0; out.hq_distance = 0; out.status = STATUS_UNCLASSIFIED; out.qcfail = 0; out.confidence = 0;
+        if(best < 0) {
+            defer = true;
+        } else {
+            // the winner's distances, its probability and the all-match product in fp64 from the fp64 factor rows
+            int distance = __popc(best_flags);
+            int hq_distance = __popc(best_flags & high_quality);
+            double best_conditional = 1.0;
+            double everything_matches = 1.0;
+#pragma unroll
+            for(int j = 0; j < L; ++j) {
+                const uint32_t k = (row[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                const double match = factor_double[k][0];
+                const double mismatch = factor_double[k][1];
+                best_conditional *= ((best_flags >> low_bit(j)) & 1u) ? mismatch : match;
+                everything_matches *= match;
+            }
+            const double best_p = best_conditional * common_prior;
+            // everything but the winner: a single precision sum in units of the all-match product; only ever compared
+            // against and added to much larger terms
+            const double others = (static_cast<double>(sigma) * everything_matches) * common_prior;
+            const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+            double confidence = best_p / total;                                       // pamld.cpp:92
+            const double noise_margin = best_conditional - d.random_barcode_probability;
+            const double confidence_margin = confidence - confidence_threshold;
+            // the certificate of pamld_lut.hpp: a read that clearly fails the noise filter only needs its argmax; otherwise a
+            // dominant winner and no decision within 2e-8 of its threshold
+            const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
+            defer = !noise_clear
+                 || (noise_margin <= 0 ? !(winner_single >= lut::SMALLEST_CERTAIN && runner_up <= lut::RUNNER_UP * winner_single)
+                                       : (!(others <= lut::dominance(L) * best_p) || !(fabs(confidence_margin) > 2e-8)));
+            if(!defer) {
+                uint32_t bin = static_cast<uint32_t>(best) + 1u;
+                uint8_t status = STATUS_PASS;
+                if(noise_margin > 0) {                                                // pamld.cpp:96
+                    if(confidence_margin > 0) {                                       // pamld.cpp:99
+                        if(hq_threshold > 0 && hq_distance >= hq_threshold) { r.qcfail = true; }
+                        if(live) {
+                            const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));
+                            bin_add(histogram, bin, r.qcfail ? 0u : 1u, 1, fixed & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
+                            bin_add(histogram, bin, r.qcfail ? 0u : 1u, 2, fixed >> CONFIDENCE_LIMB_BITS);
+                        }
+                    } else {
+                        if(live) { bin_add(histogram, bin, 0, 3, 1ull << 32); }           // low confidence count
+                        r.qcfail = true;
+                        status = STATUS_LOW_CONFIDENCE;
+                    }
+                } else {
+                    if(live) { bin_add(histogram, bin, 0, 3, 1ull); }                     // low conditional confidence count
+                    r.qcfail = true;
+                    bin = 0;
+                    distance = 0;
+                    hq_distance = 0;
+                    confidence = 0;
+                    status = STATUS_NOISE;
+                }
+                const int32_t index_of_bin = bin == 0 ? 0 : identity_index ? static_cast<int32_t>(bin) : d.barcode_index[bin - 1];
+                // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86)
+                if(live) { bin_add(histogram, bin, r.qcfail ? 0u : 1u, 0, 1ull | (static_cast<unsigned long long>(bin > 0 ? distance : 0) << 32)); }
+                if(multiplexing) { r.channel = index_of_bin; }
+                out.index = index_of_bin;
+                out.distance = static_cast<uint8_t>(distance);
+                out.hq_distance = static_cast<uint8_t>(hq_distance);
+                out.status = status;
+                out.confidence = confidence;
+            }
+        }
+        out.qcfail = r.qcfail ? 1 : 0;
+        if(live) {
+            // a read handed on keeps its placeholder record and the state it came with (the next tier writes both)
+            if(!defer) {
+                stream_result(&args.result[i], out);
+                __builtin_nontemporal_store((static_cast<uint32_t>(r.channel) & 0x7fffffffu) | (r.qcfail ? 0x80000000u : 0u), &args.word[i]);
+            }
+        }
+        const unsigned long long handed_on = __ballot(live && defer);
+        if(handed_on) {
+            if(live && defer) { segment[segment_count + __popcll(handed_on & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i); }
+            segment_count += static_cast<uint32_t>(__popcll(handed_on));
+        }
+        if(last_stage) {                                  // TranscodingDecoder::count / pf_count (transcode.h:61-64)
+            const unsigned long long pass = __ballot(live && !defer && !r.qcfail);
+            const unsigned long long fail = __ballot(live && !defer && r.qcfail);
+            if(lane == 0) {
+                if(fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(__popcll(fail))); }
+                if(pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(__popcll(pass))); }
+            }
+        }
+    };
+
+    // ---- the wave's loop over its tiles: pass A, then the ring --------------------------------------------------------
+    Inputs next;
+    int64_t tile = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
+    fetch(min(tile, tiles - 1), next);
+    for(bool more = true; more;) {
+        unsigned long long deferred = 0;
+        Inputs in = next;
+        int64_t read_ordinal = 0;
+        if(tile < tiles) {
+            const int64_t first = tile * 64;
+            const bool active = first + lane < n;
+            const uint32_t at = active ? lane : static_cast<uint32_t>(n - 1 - first);
+            read_ordinal = first + at;
+            bool incoming_qcfail;
+            uint32_t incoming_channel;
+            if(STATE != 2) { incoming_qcfail = (in.state & 1u) != 0; incoming_channel = 0; }
+            else { incoming_qcfail = (in.state >> 31) != 0; incoming_channel = in.state & 0x7fffffffu; }
+            // BAM codes, four positions per word.  A, C, G or T = exactly one bit of the nibble (iupac.h:51-56): every valid
+            // byte is not zero and the words hold L bits in all; a read with anything else goes to the ring
+            const uint32_t x0 = in.code[0] & 0x0f0f0f0fu;
+            const uint32_t x1 = in.code[1] & (0x0f0f0f0fu & VALID1);
+            const uint32_t q0 = in.quality[0] & 0x7f7f7f7fu;                  // the table has 128 rows
+            const uint32_t q1 = in.quality[1] & (0x7f7f7f7fu & VALID1);
+            const uint32_t every_byte = (x0 + 0x7f7f7f7fu) & ((x1 + 0x7f7f7f7fu) | ~(0x80808080u & VALID1)) & 0x80808080u;
+            const bool all_strict = (__popc(x0) + __popc(x1)) == L && every_byte == 0x80808080u;
+            // 2-bit codes A, C, G, T -> 0..3, bit-sliced as pamld_lut.hpp has them: position 4 f + k with its low bit at
+            // 8 f + 2 + k and its high bit 4 places up.  Bits 2..17 of that word are the key of the lookup.
+            const uint32_t codes0 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x0 << 2) | (x0 << 1)) & 0x10101010u));
+            const uint32_t codes1 = gather((((x1 >> 1) | (x1 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
+            const uint32_t sliced = (codes0 << 2) | (codes1 << 10);
+            const uint32_t looked_up = nearest[sliced >> 2];                          // the barcode this word is (next to), if any
+            tile += tile_step;
+            fetch(min(tile, tiles - 1), next);                                        // past the last tile: that tile again, unused
+            const bool known = looked_up < static_cast<uint32_t>(n_barcode);
+            const uint32_t c = known ? looked_up : 0u;
+            const uint32_t observed = sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16);      // against both halves of a word
+            const uint32_t observed_high = lut::high_plane(observed);
+            const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
+
+            // per position {P(match), rho} of its quality
+            float rho[8];
+            float everything_matches = 1.0f;
+#pragma unroll
+            for(int j = 0; j < 8; ++j) {
+                if(j < L) {
+                    const uint32_t q = j < 4 ? q0 : q1;
+                    const int byte = j & 3;
+                    const uint32_t shifted = byte == 0 ? (q << 3) : (q >> (8 * byte - 3));
+                    const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x3f8u, Layout::FACTOR_AT));
+                    everything_matches = j == 0 ? pair.x : everything_matches * pair.x;
+                    rho[j] = pair.y;
+                } else { rho[j] = 1.0f; }
+            }
+            float ge[2][5];
+            build_tables(rho, ge);
+            // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6, in units of the all-match product
+            float h[7];
+#pragma unroll
+            for(int m = 3; m <= 6; ++m) {
+                h[m] = 0.0f;
+                bool any = false;
+#pragma unroll
+                for(int a = 0; a <= 4; ++a) {
+                    const int b = m - a;
+                    if(b >= 0 && b <= 4 && a <= Layout::positions(0) && b <= Layout::positions(1)) {
+                        const float product = ge[0][a] * ge[1][b];
+                        h[m] = any ? fmaxf(h[m], product) : product;
+                        any = true;
+                    }
+                }
+            }
+
+            // the list of c: eight pairs of barcodes as plane words, then {radius, cnt_r, cnt_rest, index}
+            const uint32_t record_at = Layout::record_at(0) + static_cast<uint32_t>(Layout::words_bytes(n_barcode)) + c * (RECORD_WORDS * 4u);
+            Quad record[RECORD_WORDS / 4];
+#pragma unroll
+            for(int quad = 0; quad < RECORD_WORDS / 4; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(record_at + 16u * quad); }
+            auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
+            float winner = 0;                        // P(r|c) over the all-match product
+            float others = 0;                        // the other listed barcodes
+            uint32_t mismatches = 0;                 // of c: the flag bits of its mismatching positions
+#pragma unroll
+            for(int w = 0; w < LIST / 2; ++w) {
+                const uint32_t fields = (observed_low ^ record_word(w)) | (observed_high ^ record_word(LIST / 2 + w));
+                const float even = entry(fields, 0, 0) * entry(fields, 1, 1);
+                const float odd = entry(fields, 2, 0) * entry(fields, 3, 1);
+                if(w == 0) { mismatches = fields & FULL_MASK; winner = even; others = odd; }
+                else { others += even + odd; }
+            }
+
+            // what was not scored: cnt_r barcodes at distance r from c, cnt_rest further away (pamld_near.hpp)
+            const uint32_t radius = record_word(LIST);
+            const float cnt_r = __uint_as_float(record_word(LIST + 1));
+            const float cnt_rest = __uint_as_float(record_word(LIST + 2));
+            const uint32_t index = record_word(LIST + 3);                  // barcode_index[c]
+            const int k = __popc(mismatches);
+            const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5
+            const bool near3 = radius == 3u;                                    // a crowded set: only a read ON c is finished here
+            const float h_r = near5 ? h[5] : near3 ? h[3] : h[4];               // H[r]
+            const float h_up = near5 ? h[6] : near3 ? h[4] : h[5];              // H[r + 1]
+            const float h_down = near5 ? h[4] : h[3];                           // H[r - 1] (radius 3: not used)
+            // k = 1: rho of the read's own mismatch position is the winner itself; without that position
+            // top_n <= min(top_n, top_{n+1} / rho), and the position itself costs at most max(rho, 1)
+            const float inverse_winner = __builtin_amdgcn_rcpf(winner);
+            const float boost = fmaxf(winner, 1.0f);
+            const float at_r = k == 0 ? h_r : boost * fminf(h_down, h_r * inverse_winner);
+            const float beyond = k == 0 ? h_up : boost * fminf(h_r, h_up * inverse_winner);
+            const float rest = (cnt_r * at_r + cnt_rest * beyond) * near::SLOP;
+            const float x_listed = others * inverse_winner;
+            const float x_rest = rest * inverse_winner;
+            const float x_low = x_listed + (uniform_noise_over_prior * __builtin_amdgcn_rcpf(everything_matches)) * inverse_winner;
+            // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp)
+            const float y = x_low * __builtin_amdgcn_rcpf(1.0f + x_low);            // 1 - posterior
+            const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
+            const double confidence_margin = confidence - confidence_threshold;
+            const bool finished = all_strict && known && k <= 1 && (radius >= 4u || (near3 && k == 0)) && winner * everything_matches > noise_floor &&
+                                  x_listed <= near::LISTED_MAX && x_low + x_rest <= near::X_MAX && x_rest <= near::REST_MAX &&
+                                  fabs(confidence_margin) > 2e-8;
+
+            // Outcome.  Every lane stores a record and a status word in straight line code — the real ones when the read
+            // is finished; a deferred read's record is whatever was computed (pass C or the tiers behind it write it again),
+            // its status word the state it came with; a lane past the end of the batch stores its (last) read's again
+            const bool high_mismatch = k == 1 && winner <= rho_at_threshold && (zero_is_high || winner != 1.0f);
+            const uint32_t hq_distance = high_mismatch ? 1u : 0u;
+            const bool confident = confidence_margin > 0;                               // pamld.cpp:99
+            const bool qcfail = incoming_qcfail || !confident || (hq_threshold > 0 && static_cast<int>(hq_distance) >= hq_threshold);
+            const bool qcfail_out = finished ? qcfail : incoming_qcfail;
+            {
+                Quad out;
+                out.x = index;
+                out.y = static_cast<uint32_t>(k) | (hq_distance << 8) | ((confident ? STATUS_PASS : STATUS_LOW_CONFIDENCE) << 16) | (qcfail_out ? 1u << 24 : 0u);
+                out.z = static_cast<uint32_t>(__double2loint(confidence));
+                out.w = static_cast<uint32_t>(__double2hiint(confidence));
+                __builtin_nontemporal_store(out, reinterpret_cast<Quad*>(reinterpret_cast<char*>(args.result) + first * 16 + at * 16u));
+                const uint32_t channel = (finished && multiplexing) ? index : incoming_channel;
+                __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
+            }
+            if(finished && active) {
+                // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86), workgroup histogram
+                const uint32_t half = qcfail ? 0u : 1u;
+                bin_add(histogram, c + 1u, half, 0, 1ull | (static_cast<unsigned long long>(k) << 32));
+                if(confident) {
+                    // round(confidence * 2^52) as the mantissa of 1 + confidence (a confidence of exactly 1 carries into the
+                    // exponent, which the subtraction turns into bit 52), split in two 26 bit limbs
+                    const double shifted = confidence + 1.0;
+                    const uint32_t fixed_low = static_cast<uint32_t>(__double2loint(shifted));
+                    const uint32_t fixed_high = static_cast<uint32_t>(__double2hiint(shifted)) - 0x3ff00000u;
+                    bin_add(histogram, c + 1u, half, 1, static_cast<unsigned long long>(fixed_low & 0x3ffffffu));
+                    bin_add(histogram, c + 1u, half, 2, static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
+                } else {
+                    bin_add(histogram, c + 1u, 0, 3, 1ull << 32);                     // low confidence count (pamld.cpp:104-106)
+                }
+            }
+            deferred = __ballot(active && !finished);
+            if(last_stage) {
+                const unsigned long long pass = __ballot(active && finished && !qcfail);
+                const unsigned long long fail = __ballot(active && finished && qcfail);
+                if(lane == 0) {
+                    if(fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(__popcll(fail))); }
+                    if(pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(__popcll(pass))); }
+                }
+            }
+        } else {
+            more = false;
+        }
+        const uint32_t arriving = static_cast<uint32_t>(__popcll(deferred));
+        if(ring_count + arriving > RING || (!more && ring_count > 0)) {
+            drain(ring_count);
+            ring_count = 0;
+        }
+        if(arriving) {
+            if((deferred >> lane) & 1ull) {
+                const uint32_t slot = ring_count + static_cast<uint32_t>(__popcll(deferred & ((1ull << lane) - 1ull)));
+                ring[slot] = in.code[0];
+                ring[RING + slot] = in.code[1];
+                ring[2 * RING + slot] = in.quality[0];
+                ring[3 * RING + slot] = in.quality[1];
+                ring[4 * RING + slot] = in.state;
+                ring[5 * RING + slot] = static_cast<uint32_t>(read_ordinal);
+            }
+            ring_count += arriving;
+        }
+    }
+    if(lane == 0) { args.worklist_count[own_segment] = segment_count; }
+    __syncthreads();
+    // the workgroup's bins into the counter buffer: one global atomic per field that is not zero
+    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += THREADS) {
+        const unsigned long long v = histogram[i];
+        if(v) { atomicAdd(&args.stats[i], v); }
+    }
+    for(int i = threadIdx.x; i < (n_barcode + 1) * BIN_WORDS; i += THREADS) {
+        const unsigned long long v = histogram[STAT_JOB_WORDS + i];
+        if(v == 0) { continue; }
+        const int bin = i / BIN_WORDS;
+        const int pass_filter = (i % BIN_WORDS) / 4;
+        const int word = i % 4;
+        unsigned long long* const to = args.stats + d.stats_offset + bin * STAT_WORDS_PER_BIN + pass_filter * STAT_FIELDS;
+        if(word == 0) {
+            atomicAdd(&to[FIELD_COUNT], v & 0xffffffffull);
+            if(v >> 32) { atomicAdd(&to[FIELD_DISTANCE], v >> 32); }
+        } else if(word == 1) { atomicAdd(&to[FIELD_CONFIDENCE_LOW], v); }
+        else if(word == 2) { atomicAdd(&to[FIELD_CONFIDENCE_HIGH], v); }
+        else {
+            if(v & 0xffffffffull) { atomicAdd(&to[FIELD_LOW_CONDITIONAL_CONFIDENCE], v & 0xffffffffull); }
+            if(v >> 32) { atomicAdd(&to[FIELD_LOW_CONFIDENCE], v >> 32); }
+        }
+    }
+}
+
+template <int L, int STATE, int WAVES>
+int launch_state(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
+    static std::atomic<uint64_t> prepared{0};
+    if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES>), grid, dim3(Shape<L, WAVES>::THREADS), Shape<L, WAVES>::lds_bytes(n_barcode), stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <int L, int WAVES>
+int launch_one(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
+    if(!args.first_stage) { return launch_state<L, 2, WAVES>(args, n_barcode, grid, stream); }
+    return args.input_flag ? launch_state<L, 1, WAVES>(args, n_barcode, grid, stream) : launch_state<L, 0, WAVES>(args, n_barcode, grid, stream);
+}
+
+}  // namespace stream
+}  // namespace phq

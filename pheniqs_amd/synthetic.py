@@ -178,3 +178,67 @@ def algorithmic_bytes_per_read(job: Dict[str, Any]) -> int:
         if decoder["algorithm"] in ("pamld", "mdd"):
             closed += 1
     return 2 * total + 1 + 16 * closed + 4
+
+
+def generate_planes_device(torch, job: Dict[str, Any], decoders: Sequence[Dict[str, int]], plane_width: int, n: int, seed: int, device,
+                           host_rows: int = 1 << 20, chunk: int = 1 << 23):
+    """The recipe of generate_rows drawn ON THE DEVICE, straight into the decoder major planes phq_classify_device takes:
+    every one of the n reads is its own draw (no pool tiled to size), so nothing in a measurement can ride on repeated
+    rows.  Same distributions as generate_rows, another random stream (torch's).  Returns (base, quality, flag) device
+    tensors and the first `host_rows` reads back as generate_rows' row major host arrays (code, quality, flag, offsets)
+    for the CPU baseline and the parity check.  `decoders` = DecoderSet.decoders, `plane_width` = DecoderSet.plane_width."""
+    base = torch.zeros(max(1, n * max(plane_width, 1)), dtype=torch.uint8, device=device)
+    qual = torch.zeros_like(base)
+    flag = torch.empty(n, dtype=torch.uint8, device=device)
+    bam = torch.tensor(BAM, dtype=torch.uint8, device=device)
+    values = torch.tensor(QUALITY_VALUES, dtype=torch.uint8, device=device)
+    error_rate = torch.tensor(np.power(10.0, -QUALITY_VALUES.astype(np.float64) / 10.0), dtype=torch.float32, device=device)
+    edges = torch.tensor(np.cumsum(QUALITY_WEIGHTS)[:-1], dtype=torch.float32, device=device)
+    specs = []
+    offsets: List[int] = []
+    offset = 0
+    for (_, decoder), info in zip(iter_decoders(job), decoders):
+        L = int(decoder["nucleotide cardinality"])
+        offsets.append(offset)
+        offset += L
+        words, prior = _codec_arrays(decoder)
+        specs.append((L, info, torch.from_numpy(words).to(device) if words.shape[0] else None,
+                      torch.tensor(np.cumsum(prior / prior.sum()), dtype=torch.float64, device=device) if words.shape[0] else None,
+                      float(decoder.get("noise", 0.01))))
+    generator = torch.Generator(device=device)
+    for number, first in enumerate(range(0, n, chunk)):
+        m = min(chunk, n - first)
+        generator.manual_seed(seed * 1_000_003 + number)
+        for L, info, words, cumulative, noise in specs:
+            if L == 0 or info["plane_stride"] == 0:
+                continue
+            truth = torch.randint(0, 4, (m, L), generator=generator, device=device, dtype=torch.uint8)
+            if words is not None:
+                pick = torch.searchsorted(cumulative, torch.rand(m, generator=generator, device=device, dtype=torch.float64)).clamp_(max=words.shape[0] - 1)
+                from_codec = torch.rand(m, generator=generator, device=device) >= noise
+                truth = torch.where(from_codec[:, None], words[pick], truth)
+                del pick, from_codec
+            klass = torch.bucketize(torch.rand(m, L, generator=generator, device=device), edges, right=True)
+            error = torch.rand(m, L, generator=generator, device=device) < error_rate[klass]
+            shift = torch.randint(1, 4, (m, L), generator=generator, device=device, dtype=torch.uint8)
+            called = torch.where(error, (truth + shift) & 3, truth)
+            code = bam[called.long()]
+            quality = values[klass]
+            unknown = torch.rand(m, L, generator=generator, device=device) < 0.001
+            code[unknown] = 15
+            quality[unknown] = 2
+            stride, prefix = info["plane_stride"], info["plane_prefix"]
+            base[n * prefix: n * (prefix + stride)].view(n, stride)[first:first + m, :L] = code
+            qual[n * prefix: n * (prefix + stride)].view(n, stride)[first:first + m, :L] = quality
+            del truth, klass, error, shift, called, code, quality, unknown
+        flag[first:first + m] = (torch.rand(m, generator=generator, device=device) < 0.03).to(torch.uint8)
+    rows = min(host_rows, n)
+    code_rows = np.zeros((rows, offset), dtype=np.uint8)
+    quality_rows = np.zeros((rows, offset), dtype=np.uint8)
+    for (L, info, _, _, _), at in zip(specs, offsets):
+        if L == 0 or info["plane_stride"] == 0:
+            continue
+        stride, prefix = info["plane_stride"], info["plane_prefix"]
+        code_rows[:, at:at + L] = base[n * prefix: n * (prefix + stride)].view(n, stride)[:rows, :L].cpu().numpy()
+        quality_rows[:, at:at + L] = qual[n * prefix: n * (prefix + stride)].view(n, stride)[:rows, :L].cpu().numpy()
+    return base, qual, flag, (code_rows, quality_rows, flag[:rows].cpu().numpy(), offsets)

@@ -232,6 +232,42 @@ def test_one_lookup_mdd(oracle, torch_cuda, length, count, min_distance, toleran
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
 
 
+@pytest.mark.parametrize("pairing,lengths,count,tolerance", [("zip", (8, 8), 48, [2, 2]), ("zip", (6, 9), 40, [2, 1]), ("product", (8, 8), 24, [1, 1]), ("product", (6, 7), 12, [1, 1])])
+def test_mdd_tolerance_past_the_shannon_bound_in_a_compiled_job(oracle, torch_cuda, pairing, lengths, count, tolerance):
+    """A compiled document handed in with a `distance tolerance` the compiler would have refused (metric.h:228): several
+    words of a segment can then be within tolerance of one observation and mdd.cpp:50-80 returns the FIRST barcode in
+    index order whose segments all fit, which one table lookup per segment cannot name.  Such a codec must take the scan
+    kernels in both modes: e.g. segment 0 one mismatch from barcode a and two from barcode b, segment 1 on b exactly."""
+    rng = np.random.default_rng(2900 + count + lengths[1])
+    # words two mismatches apart at least (product) or three (pairs): the injected tolerances exceed (distance - 1) / 2
+    first = synthetic.barcode_set(rng, count, lengths[0], 2 if pairing == "product" else 3)
+    second = synthetic.barcode_set(rng, count, lengths[1], 2 if pairing == "product" else 3)
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("mdd", [first, second], ["0::%d" % lengths[0], "1::%d" % lengths[1]], pairing=pairing)}
+    job = capi.compile_job(spec)
+    job["sample"]["distance tolerance"] = list(tolerance)              # past the bound the compiler enforces
+    L = sum(lengths)
+    n = 1 << 15
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 91 + count)
+    words, _ = synthetic._codec_arrays(job["sample"])
+    letters = np.array([1, 2, 4, 8], dtype=np.uint8)
+    # observations built to sit between barcodes: segment 0 of barcode a with one or two positions taken from barcode b,
+    # segment 1 of barcode b
+    N = words.shape[0]
+    for i in range(4000):
+        a, b = int(rng.integers(N)), int(rng.integers(N))
+        row = words[a].copy()
+        differing = np.nonzero(words[a, :lengths[0]] != words[b, :lengths[0]])[0]
+        if differing.size:
+            take = rng.choice(differing, size=min(differing.size, int(rng.integers(1, 4))), replace=False)
+            row[take] = words[b, take]
+        row[lengths[0]:L] = words[b, lengths[0]:L]
+        code[2000 + i] = letters[row]
+    for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
+        s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+    assert int((got[0]["status"] == 0).sum()) > n // 4
+
+
 @pytest.mark.parametrize("lengths,count,min_distance,tolerance,masking", [
     ((8, 8), 96, 3, None, 0), ((10, 10), 196, 3, None, 20), ((6, 9), 48, 3, [0, 1], 0), ((10, 10), 24, 5, None, 13), ((5, 7), 30, 2, None, 0)])
 def test_one_lookup_mdd_pairs(oracle, torch_cuda, lengths, count, min_distance, tolerance, masking):
