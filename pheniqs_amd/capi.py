@@ -49,7 +49,9 @@ class DecoderInfo(ctypes.Structure):
 
 
 def library_path() -> str:
-    return os.path.join(HERE, "libpheniqs_amd.so")
+    """The in-tree library; PHQ_LIBRARY names another build of it (A/B runs of kernel variants on one box,
+    profiles/tools/variant.sh)."""
+    return os.environ.get("PHQ_LIBRARY") or os.path.join(HERE, "libpheniqs_amd.so")
 
 
 _library = None

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <limits>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -440,6 +441,50 @@ void DecoderSet::build_device_images() {
                 d.near_table = static_cast<const uint16_t*>(upload(tables.table.data(), tables.table.size() * sizeof(uint16_t)));
                 d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
+                if(d.uniform_prior && L <= 8 && !tables.record.empty() && N < static_cast<int32_t>(STREAM_UNKNOWN) &&
+                   stream_block_at(STREAM_WAVES, N) + static_cast<uint32_t>(N) * STREAM_RECORD_WORDS * 4u < (1u << 18)) {
+                    // the streaming kernel (pamld_stream.hpp): the same table and lists in pamld_lut.hpp's bit order; the table
+                    // names a barcode by the LDS address of its block and its index
+                    const uint32_t first_block = stream_block_at(STREAM_WAVES, N);
+                    std::vector<uint32_t> table(65536, (STREAM_UNKNOWN << 18) | first_block);
+                    const uint32_t positions = (1u << L) - 1u;
+                    for(uint32_t key = 0; key < (1u << (2 * L)); ++key) {
+                        const uint32_t l = key & positions;
+                        const uint32_t h = key >> L;
+                        const uint16_t named = tables.table[key];
+                        if(named == NEAR_NO_BARCODE) { continue; }
+                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12)] =
+                            (static_cast<uint32_t>(index[named]) << 18) | (first_block + static_cast<uint32_t>(named) * STREAM_RECORD_WORDS * 4u);
+                    }
+                    auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10); };      // bit j = position j -> bit 8 (j / 4) + 2 + j % 4
+                    const int32_t list = near_list(L);
+                    std::vector<uint32_t> record(static_cast<size_t>(N) * STREAM_RECORD_WORDS, 0u);
+                    bool indexable = true;
+                    for(int32_t b = 0; b < N; ++b) {
+                        uint32_t* const to = &record[static_cast<size_t>(b) * STREAM_RECORD_WORDS];
+                        std::vector<bool> is_listed(static_cast<size_t>(N), false);
+                        for(int32_t k = 0; k < list; ++k) {
+                            const size_t o = static_cast<size_t>(tables.listed[static_cast<size_t>(b) * static_cast<size_t>(list) + static_cast<size_t>(k)]);
+                            is_listed[o] = true;
+                            to[k / 2] |= half(low[o]) << (16 * (k & 1));
+                            to[list / 2 + k / 2] |= half(high[o]) << (16 * (k & 1));
+                        }
+                        // the barcodes that are not listed, by their distance from b: 3, 4, 5, 6 or more; one closer than 3 leaves
+                        // the bound nothing to certify
+                        float weight[4] = {0, 0, 0, 0};
+                        for(int32_t o = 0; o < N; ++o) {
+                            if(is_listed[static_cast<size_t>(o)]) { continue; }
+                            const int away = __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]));
+                            if(away < 3) { weight[0] = std::numeric_limits<float>::infinity(); }
+                            else { weight[std::min(away, 6) - 3] += 1.0f; }
+                        }
+                        std::memcpy(&to[list], weight, sizeof(weight));
+                        if(index[static_cast<size_t>(b)] < 0 || index[static_cast<size_t>(b)] >= static_cast<int32_t>(STREAM_UNKNOWN)) { indexable = false; }
+                    }
+                    d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
+                    d.stream_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                    d.stream_ready = indexable ? d.near_ready : 0;
+                }
             }
             if(c.all_strict && c.algorithm == Algorithm::MDD && c.segment_cardinality == 1 && c.nucleotide_cardinality >= NEAR_MIN_LENGTH && c.nucleotide_cardinality <= NEAR_MAX_LENGTH &&
                d.n_barcode >= 1 && d.n_barcode <= NEAR_MAX_BARCODES && d.distance_tolerance[0] <= 1 && c.quality_masking_threshold <= 128) {

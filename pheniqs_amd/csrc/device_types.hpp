@@ -23,6 +23,20 @@ constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }   
 constexpr int near_record_words(int length, bool priors) { return near_record_words(length) + (priors ? (length <= 8 ? 16 : 16) : 0); }
 constexpr int MAX_DEFERRED_BINS = 9472;        // count_results_kernel: 16 bytes of LDS each
 constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, high plane, radius, barcode index, others at the radius / prior, noise / prior, others one further / prior, the rest / prior}
+// pamld_stream.hpp.  A barcode's block in LDS: its 16 listed barcodes as 8 low + 8 high plane words, the four weights of
+// the bound, its counter bin (8 x 64 bits), padding to 11 quads.  STREAM_WAVES waves in its one workgroup per CU, each
+// with 8 KiB of per read tables and a 64 entry ring in LDS.  The LDS map in front of the blocks is fixed by the wave count
+// alone, so the host can put a block's LDS ADDRESS into the lookup table (stream_block_at).
+constexpr int STREAM_RECORD_WORDS = 44;
+#ifndef PHQ_STREAM_WAVES
+#define PHQ_STREAM_WAVES 12
+#endif
+constexpr int STREAM_WAVES = PHQ_STREAM_WAVES;
+constexpr uint32_t stream_words_bytes(int n_barcode) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u; }
+constexpr uint32_t stream_block_at(int waves, int n_barcode) {
+    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 6u * 64u * 4u + stream_words_bytes(n_barcode);
+}
+constexpr uint32_t STREAM_UNKNOWN = 0x3fffu;   // the index field of a lookup that names no barcode
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
 constexpr int NEAR_MAX_BARCODES = 1024;
@@ -123,6 +137,16 @@ struct DevDecoder {
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
+    // streaming kernel (pamld_stream.hpp; 5 to 8 nt, uniform priors): the same two things in pamld_lut.hpp's bit order.
+    // stream_table[key], 65536 entries: key = bits 2..17 of the bit-sliced observation (positions 0..3: low code bits in
+    // key bits 0..3, high code bits in 4..7; positions 4..7 in bits 8..15); an entry = the LDS address of the barcode's
+    // block (18 bits) | barcode_index << 18, index field STREAM_UNKNOWN for a word that names none.  stream_record[c] =
+    // STREAM_RECORD_WORDS words, the image of the block: the listed barcodes two per word (the even one in the low half)
+    // as 8 low plane words then 8 high plane words, then how many barcodes that are not listed sit 3, 4, 5 and 6 or more
+    // mismatches from c (floats; infinite if one sits closer than 3), then zeros (the bin, padding)
+    const uint32_t* stream_table;
+    const uint32_t* stream_record;
+    int32_t stream_ready;
     // one lookup MDD (mdd_near.hpp; one segment of 5 to 10 nt, tolerance 0 or 1): near_table as above and per barcode
     // {low plane, high plane, -, barcode index}
     const uint32_t* mdd_near_record;

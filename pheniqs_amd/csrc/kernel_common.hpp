@@ -300,6 +300,9 @@ int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3
 int pamld_near_block(const DevDecoder& host_decoder);      // threads per workgroup of the neighbour list kernel
 bool pamld_near_supports(const DevDecoder& host_decoder);   // pamld_near.hip: neighbour list tier in front of the product form kernel
 int launch_pamld_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_stream_supports(const DevDecoder& host_decoder);   // pamld_stream.hip: neighbour lists and product form scan in one persistent kernel, a pipeline per wave
+int pamld_stream_waves();                                      // waves (= worklist segments) per workgroup of that kernel
+int launch_pamld_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, hipStream_t stream);   // stage.hip: PHQ_TRACE_WORKLIST
 bool pamld_cross_near_supports(const DevDecoder& host_decoder);   // pamld_cross_near.hip: neighbour lists per segment of a two segment combinatorial set
 int pamld_cross_near_block(const DevDecoder& host_decoder);

@@ -38,13 +38,22 @@ namespace stream {
 
 constexpr int FACTOR_ROWS = 129;
 constexpr int LIST = 16;                       // barcodes scored in pass A: c and the 15 nearest to it
-constexpr int RECORD_WORDS = STREAM_RECORD_WORDS;   // 8 low plane words, 8 high plane words, {radius, cnt_r, cnt_rest, index}
+// a barcode's block in LDS: its list — 8 low plane words, 8 high plane words (two listed barcodes per word) —, the weights
+// of the bound (how many barcodes that are not listed sit at distance 3, 4, 5 and 6 or more from it), then its counter
+// bin, then padding to a stride of 11 quads: an odd number, so the blocks start in all 16 quad places of the banks
+constexpr int BLOCK_WORDS = STREAM_RECORD_WORDS;
+constexpr uint32_t BLOCK_BYTES = BLOCK_WORDS * 4u;
+constexpr uint32_t WEIGHT_AT = 64;             // bytes into the block
+constexpr uint32_t BIN_AT = 80;
 constexpr int RING = 64;                       // entries of a wave's ring
 constexpr int RING_PLANES = 6;                 // code word 0, 1, quality word 0, 1, carried state, ordinal
 // the workgroup histogram of this kernel, per bin and [qc fail | pass filter] half: {count | distance << 32,
 // confidence low limb, confidence high limb, low conditional confidence count | low confidence count << 32}; a
 // workgroup sees fewer than 2^31 reads of at most 8 nt per launch, so no half word overflows
-constexpr int BIN_WORDS = 8;
+constexpr int BIN_WORDS = 8;                   // words 0..3 the qc fail half, 4..7 the pass filter half: {count | distance << 32, confidence low limb, confidence high limb, low conditional confidence count | low confidence count << 32}
+// the posterior of a read pass A finishes is 1 - y with y a float of at most 5e-4: it is counted as the integer
+// 2^38 - round(y 2^38), formed from 32-bit integers and split into the buffer's two limbs
+constexpr int PASS_A_FRACTION_BITS = 38;
 
 template <int L, int WAVES> struct Shape {
     static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
@@ -56,10 +65,12 @@ template <int L, int WAVES> struct Shape {
     static constexpr uint32_t RING_AT = DOUBLE_AT + FACTOR_ROWS * 16;
     static constexpr uint32_t RING_BYTES = RING_PLANES * RING * 4;
     static constexpr uint32_t WORDS_AT = RING_AT + WAVES * RING_BYTES;        // pamld_lut.hpp's plane words of the codec
-    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u; }
-    __host__ __device__ static constexpr uint32_t record_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }
-    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return record_at(n_barcode) + static_cast<uint32_t>(n_barcode) * RECORD_WORDS * 4u; }
-    __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + static_cast<uint32_t>(n_barcode + 1) * BIN_WORDS); }
+    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return stream_words_bytes(n_barcode); }
+    __host__ __device__ static constexpr uint32_t block_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }      // the barcodes' blocks
+    static_assert(WORDS_AT + stream_words_bytes(96) == stream_block_at(WAVES, 96), "the host puts block addresses into the lookup table");
+    // bin 0 (unclassified) and the two job words in front of it, behind the blocks
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * BLOCK_BYTES; }
+    __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + BIN_WORDS); }
     __host__ __device__ static constexpr int positions(int g) { return L - 4 * g >= 4 ? 4 : L - 4 * g; }
     static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. L - 1 in the second word
     static_assert(FACTOR_AT % 1024 == 0 && DOUBLE_AT % 16 == 0 && RING_AT % 16 == 0 && WORDS_AT % 16 == 0, "alignment");
@@ -73,18 +84,24 @@ typedef __attribute__((address_space(3))) const Pair* LdsPairs;
 using near::and_or;
 using lut::low_bit;
 
-__device__ __forceinline__ void bin_add(unsigned long long* histogram, uint32_t bin, uint32_t pass_filter, uint32_t word, unsigned long long value) {
-    atomicAdd(&histogram[STAT_JOB_WORDS + bin * BIN_WORDS + pass_filter * 4u + word], value);
+// a bin's words by their LDS address (bin 0 behind the job words, a barcode's bin inside its block)
+__device__ __forceinline__ void bin_add(unsigned char* lds, uint32_t bin_address, uint32_t pass_filter, uint32_t word, unsigned long long value) {
+#ifdef PHQ_DIAG_NO_ATOMICS
+    return;
+#endif
+    atomicAdd(reinterpret_cast<unsigned long long*>(lds + bin_address + pass_filter * 32u + word * 8u), value);
 }
 
 // STATE: where a read's carried state comes from (pamld_near.hpp): 0 nothing to load, 1 the input flag bytes, 2 the
 // status word of the stage before
 template <int L, int STATE, int WAVES>
-__global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kernel(StageArgs args) {
+// one workgroup per CU: the LDS it takes fixes the occupancy at WAVES / 4 waves per SIMD, and the compiler is told so — left
+// to assume that fewer registers would buy more waves, it serialises the table reads into pairs, each waited for
+__global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
+void pamld_stream_kernel(StageArgs args) {
     typedef Shape<L, WAVES> Layout;
     constexpr int THREADS = Layout::THREADS;
     constexpr uint32_t VALID1 = Layout::VALID1;
-    constexpr uint32_t FIELD_MASK = 0x3c3c3c3cu;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::FACTOR_AT);                 // [row] {P(match), rho}
@@ -92,10 +109,12 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
     uint32_t* const lds_words = reinterpret_cast<uint32_t*>(lds_raw + Layout::WORDS_AT);
     DecoderRef d = *constant_cast(args.decoder);
     const int n_barcode = d.n_barcode;
-    uint32_t* const records = reinterpret_cast<uint32_t*>(lds_raw + Layout::record_at(n_barcode));
-    unsigned long long* const histogram = reinterpret_cast<unsigned long long*>(lds_raw + Layout::histogram_at(n_barcode));
+    uint32_t* const blocks_of_barcodes = reinterpret_cast<uint32_t*>(lds_raw + Layout::block_at(n_barcode));
+    const uint32_t block_base = Layout::block_at(n_barcode);
+    const uint32_t histogram_base = Layout::histogram_at(n_barcode);                    // the two job words, then bin 0
+    unsigned long long* const histogram = reinterpret_cast<unsigned long long*>(lds_raw + histogram_base);
 
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave uniform: tiles, segments and bases stay in scalar registers
     const uint32_t lane = threadIdx.x & 63u;
     // this lane's corner of the tables: everything of an entry address but group (bit 8) and entry (bits 10..13)
     const uint32_t wave_byte = ((wave & 1u) << 1) | (((wave >> 1) & 3u) << 6);        // the wave's share of byte 1 of an address
@@ -120,8 +139,8 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
             lds_words[at + 4] = lut::high_plane(sliced);
         }
     }
-    for(int w = threadIdx.x; w < n_barcode * RECORD_WORDS; w += THREADS) { records[w] = d.stream_record[w]; }
-    for(int i = threadIdx.x; i < STAT_JOB_WORDS + (n_barcode + 1) * BIN_WORDS; i += THREADS) { histogram[i] = 0; }
+    for(int w = threadIdx.x; w < n_barcode * BLOCK_WORDS; w += THREADS) { blocks_of_barcodes[w] = d.stream_record[w]; }      // lists and weights; the bins come as zeros
+    for(int i = threadIdx.x; i < STAT_JOB_WORDS + BIN_WORDS; i += THREADS) { histogram[i] = 0; }
     // entry 0 of both tables (no mismatch in the group) is 1 in units of the all-match product: written once
     *reinterpret_cast<float*>(lds_raw + lane_const) = 1.0f;
     *reinterpret_cast<float*>(lds_raw + lane_const + 256u) = 1.0f;
@@ -130,7 +149,7 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
     const int64_t n = args.n_read;
     const int64_t tiles = (n + 63) / 64;
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
-    const uint16_t* const nearest = d.stream_table;
+    const uint32_t* const nearest = d.stream_table;
     uint32_t* const ring = reinterpret_cast<uint32_t*>(lds_raw + Layout::RING_AT + wave * Layout::RING_BYTES);
     // this wave's segment of the HBM worklist (what pass C cannot decide either)
     const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
@@ -147,7 +166,13 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
     const float uniform_noise_over_prior = static_cast<float>(d.adjusted_noise_probability / d.concentration[0]);
     const float noise_floor = static_cast<float>(d.random_barcode_probability) * near::SLOP;
     const double confidence_threshold = d.confidence_threshold;
+    // pass A decides the confidence filter on y = 1 - posterior, a float: y against 1 - threshold as a float, further apart
+    // than 2e-8 plus what that float is off by — then the fp64 comparison of the posterior it reports says the same
+    const float y_threshold = static_cast<float>(1.0 - confidence_threshold);
+    const float y_guard = static_cast<float>((2e-8 + fabs(static_cast<double>(y_threshold) - (1.0 - confidence_threshold))) * 1.001 + 1e-12);
     const double common_prior = d.concentration[0];
+    uint32_t outgoing_pass = 0;                       // TranscodingDecoder::count / pf_count (transcode.h:61-64): per wave, added once
+    uint32_t outgoing_fail = 0;
     const int hq_threshold = d.high_quality_distance_threshold;
     const bool multiplexing = d.multiplexing != 0;
     const bool identity_index = d.identity_index != 0;
@@ -175,6 +200,9 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
     // bytes 0 and 2; the group is the load's immediate offset
     auto entry = [&](uint32_t fields, int byte, int g) -> float {
         const uint32_t address = __builtin_amdgcn_perm(fields, lane_low, 0x0c020400u | (static_cast<uint32_t>(byte) << 8));
+#ifdef PHQ_DIAG_DOUBLE_READS
+        { const float again = ((volatile __attribute__((address_space(3))) const float*)static_cast<uintptr_t>(address))[g * 64]; asm volatile("" :: "v"(again)); }
+#endif
         return ((LdsFloats)static_cast<uintptr_t>(address))[g * 64];
     };
     // the normalised tables of a read from its rho row
@@ -192,7 +220,9 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
             for(int m = 1; m < 16; ++m) {
                 if(m < entries) {
                     t[m] = (m >> 2) == 0 ? lo[m & 3] : (m & 3) == 0 ? hi[m >> 2] : lo[m & 3] * hi[m >> 2];
+#ifndef PHQ_DIAG_NO_TABLE_WRITES
                     *reinterpret_cast<float*>(lds_raw + lane_const + static_cast<uint32_t>(g) * 256u + static_cast<uint32_t>(m) * 1024u) = t[m];
+#endif
                     const int a = __builtin_popcount(static_cast<unsigned>(m));
                     by_count[a] = (m == (1 << a) - 1) ? t[m] : fmaxf(by_count[a], t[m]);      // the first entry of a count is 2^a - 1
                 }
@@ -368,24 +398,26 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
                                        : (!(others <= lut::dominance(L) * best_p) || !(fabs(confidence_margin) > 2e-8)));
             if(!defer) {
                 uint32_t bin = static_cast<uint32_t>(best) + 1u;
+                uint32_t bin_address = block_base + static_cast<uint32_t>(best) * BLOCK_BYTES + BIN_AT;
                 uint8_t status = STATUS_PASS;
                 if(noise_margin > 0) {                                                // pamld.cpp:96
                     if(confidence_margin > 0) {                                       // pamld.cpp:99
                         if(hq_threshold > 0 && hq_distance >= hq_threshold) { r.qcfail = true; }
                         if(live) {
-                            const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));
-                            bin_add(histogram, bin, r.qcfail ? 0u : 1u, 1, fixed & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
-                            bin_add(histogram, bin, r.qcfail ? 0u : 1u, 2, fixed >> CONFIDENCE_LIMB_BITS);
+                            const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));      // 2^-52 fixed point, two limbs
+                            bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 1, fixed & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
+                            bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 2, fixed >> CONFIDENCE_LIMB_BITS);
                         }
                     } else {
-                        if(live) { bin_add(histogram, bin, 0, 3, 1ull << 32); }           // low confidence count
+                        if(live) { bin_add(lds_raw, bin_address, 0, 3, 1ull << 32); }           // low confidence count
                         r.qcfail = true;
                         status = STATUS_LOW_CONFIDENCE;
                     }
                 } else {
-                    if(live) { bin_add(histogram, bin, 0, 3, 1ull); }                     // low conditional confidence count
+                    if(live) { bin_add(lds_raw, bin_address, 0, 3, 1ull); }                     // low conditional confidence count
                     r.qcfail = true;
                     bin = 0;
+                    bin_address = histogram_base + 8u * STAT_JOB_WORDS;
                     distance = 0;
                     hq_distance = 0;
                     confidence = 0;
@@ -393,7 +425,7 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
                 }
                 const int32_t index_of_bin = bin == 0 ? 0 : identity_index ? static_cast<int32_t>(bin) : d.barcode_index[bin - 1];
                 // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86)
-                if(live) { bin_add(histogram, bin, r.qcfail ? 0u : 1u, 0, 1ull | (static_cast<unsigned long long>(bin > 0 ? distance : 0) << 32)); }
+                if(live) { bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 0, 1ull | (static_cast<unsigned long long>(bin > 0 ? distance : 0) << 32)); }
                 if(multiplexing) { r.channel = index_of_bin; }
                 out.index = index_of_bin;
                 out.distance = static_cast<uint8_t>(distance);
@@ -416,50 +448,95 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
             segment_count += static_cast<uint32_t>(__popcll(handed_on));
         }
         if(last_stage) {                                  // TranscodingDecoder::count / pf_count (transcode.h:61-64)
-            const unsigned long long pass = __ballot(live && !defer && !r.qcfail);
-            const unsigned long long fail = __ballot(live && !defer && r.qcfail);
-            if(lane == 0) {
-                if(fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(__popcll(fail))); }
-                if(pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(__popcll(pass))); }
-            }
+            outgoing_pass += static_cast<uint32_t>(__popcll(__ballot(live && !defer && !r.qcfail)));
+            outgoing_fail += static_cast<uint32_t>(__popcll(__ballot(live && !defer && r.qcfail)));
         }
     };
 
     // ---- the wave's loop over its tiles: pass A, then the ring --------------------------------------------------------
-    Inputs next;
+    // Software pipeline, so that no wait of a tile is for something asked in that tile: a tile's inputs are fetched TWO
+    // tiles ahead, its key is formed and looked up ONE tile ahead (first thing in the tile before — in front of that tile's
+    // stores, so that waiting for the lookup never waits for them: vector memory operations complete in issue order).
+    struct Keyed { Inputs in; uint32_t sliced; uint32_t looked_up; bool all_strict; };
+    auto key_and_look_up = [&](const Inputs& in, Keyed& to) {
+        // BAM codes, four positions per word.  A, C, G or T = exactly one bit of the nibble (iupac.h:51-56): every valid
+        // byte is not zero and the words hold L bits in all; a read with anything else goes to the ring
+        const uint32_t x0 = in.code[0] & 0x0f0f0f0fu;
+        const uint32_t x1 = in.code[1] & (0x0f0f0f0fu & VALID1);
+        const uint32_t every_byte = (x0 + 0x7f7f7f7fu) & ((x1 + 0x7f7f7f7fu) | ~(0x80808080u & VALID1)) & 0x80808080u;
+        // ... and so does one with a quality byte of 128 or more: it counts as high quality whatever row its low bits
+        // name, which the rho test of pass A cannot see
+        const uint32_t beyond_rows = (in.quality[0] | (in.quality[1] & VALID1)) & 0x80808080u;
+        to.all_strict = (__popc(x0) + __popc(x1)) == L && every_byte == 0x80808080u && beyond_rows == 0;
+        // 2-bit codes A, C, G, T -> 0..3, bit-sliced as pamld_lut.hpp has them: position 4 f + k with its low bit at
+        // 8 f + 2 + k and its high bit 4 places up.  Bits 2..17 of that word are the key of the lookup.
+        const uint32_t codes0 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x0 << 2) | (x0 << 1)) & 0x10101010u));
+        const uint32_t codes1 = gather((((x1 >> 1) | (x1 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
+        to.sliced = (codes0 << 2) | (codes1 << 10);
+        to.looked_up = nearest[to.sliced >> 2];                                       // the barcode this word is (next to), if any
+        to.in = in;
+    };
+#ifdef PHQ_DIAG_STAGGER
+    // the waves of a SIMD (w, w + 4, w + 8) and the SIMDs among themselves start out of phase
+    for(uint32_t k = 0; k < ((wave >> 2) * 4u + (wave & 3u)) * PHQ_DIAG_STAGGER; ++k) { __builtin_amdgcn_s_sleep(8); }
+#endif
     int64_t tile = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
-    fetch(min(tile, tiles - 1), next);
+    Keyed current;
+    Inputs next;
+    {
+        Inputs first_inputs;
+        fetch(min(tile, tiles - 1), first_inputs);
+        fetch(min(tile + tile_step, tiles - 1), next);
+        key_and_look_up(first_inputs, current);
+    }
     for(bool more = true; more;) {
         unsigned long long deferred = 0;
-        Inputs in = next;
+        const Inputs in = current.in;
         int64_t read_ordinal = 0;
         if(tile < tiles) {
             const int64_t first = tile * 64;
             const bool active = first + lane < n;
             const uint32_t at = active ? lane : static_cast<uint32_t>(n - 1 - first);
             read_ordinal = first + at;
+            const uint32_t sliced = current.sliced;
+            const uint32_t looked_up = current.looked_up;
+            const bool all_strict = current.all_strict;
+            // the tile after this one: its key and lookup, and the inputs of the one after that (past the last tile: that
+            // tile again, unused)
+            Keyed following;
+            key_and_look_up(next, following);
+            fetch(min(tile + 2 * tile_step, tiles - 1), next);
+            current = following;
+
             bool incoming_qcfail;
             uint32_t incoming_channel;
             if(STATE != 2) { incoming_qcfail = (in.state & 1u) != 0; incoming_channel = 0; }
             else { incoming_qcfail = (in.state >> 31) != 0; incoming_channel = in.state & 0x7fffffffu; }
-            // BAM codes, four positions per word.  A, C, G or T = exactly one bit of the nibble (iupac.h:51-56): every valid
-            // byte is not zero and the words hold L bits in all; a read with anything else goes to the ring
-            const uint32_t x0 = in.code[0] & 0x0f0f0f0fu;
-            const uint32_t x1 = in.code[1] & (0x0f0f0f0fu & VALID1);
             const uint32_t q0 = in.quality[0] & 0x7f7f7f7fu;                  // the table has 128 rows
             const uint32_t q1 = in.quality[1] & (0x7f7f7f7fu & VALID1);
-            const uint32_t every_byte = (x0 + 0x7f7f7f7fu) & ((x1 + 0x7f7f7f7fu) | ~(0x80808080u & VALID1)) & 0x80808080u;
-            const bool all_strict = (__popc(x0) + __popc(x1)) == L && every_byte == 0x80808080u;
-            // 2-bit codes A, C, G, T -> 0..3, bit-sliced as pamld_lut.hpp has them: position 4 f + k with its low bit at
-            // 8 f + 2 + k and its high bit 4 places up.  Bits 2..17 of that word are the key of the lookup.
-            const uint32_t codes0 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x0 << 2) | (x0 << 1)) & 0x10101010u));
-            const uint32_t codes1 = gather((((x1 >> 1) | (x1 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
-            const uint32_t sliced = (codes0 << 2) | (codes1 << 10);
-            const uint32_t looked_up = nearest[sliced >> 2];                          // the barcode this word is (next to), if any
-            tile += tile_step;
-            fetch(min(tile, tiles - 1), next);                                        // past the last tile: that tile again, unused
-            const bool known = looked_up < static_cast<uint32_t>(n_barcode);
-            const uint32_t c = known ? looked_up : 0u;
+#ifdef PHQ_DIAG_EXTRA_VALU
+            { uint32_t sink = lane;
+#pragma unroll
+              for(int k = 0; k < 64; ++k) { asm volatile("v_add_u32 %0, %0, 1" : "+v"(sink)); }
+              asm volatile("" :: "v"(sink)); }
+#endif
+#ifdef PHQ_DIAG_EXTRA_SLOW
+            { uint32_t sink = lane;
+#pragma unroll
+              for(int k = 0; k < 64; ++k) { asm volatile("v_perm_b32 %0, %0, %0, %0" : "+v"(sink)); }
+              asm volatile("" :: "v"(sink)); }
+#endif
+            // the lookup names the barcode by the LDS address of its block (low 18 bits) and its index (above them); a word
+            // more than one mismatch from every barcode comes back with the index field all ones and the first block's address
+            const uint32_t block = looked_up & 0x3ffffu;
+            const uint32_t index = looked_up >> 18;                                  // barcode_index[c]
+            const bool known = index != 0x3fffu;
+            // the list of c — eight pairs of barcodes as plane words, then the weights of the bound — asked for together
+            // with the factor rows: one wait for both
+            Quad record[5];
+#pragma unroll
+            for(int quad = 0; quad < 5; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
+            auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
             const uint32_t observed = sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16);      // against both halves of a word
             const uint32_t observed_high = lut::high_plane(observed);
             const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
@@ -480,76 +557,78 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
             }
             float ge[2][5];
             build_tables(rho, ge);
-            // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6, in units of the all-match product
+
+            // all 32 table reads are asked for before the first is used: the wave has three to a SIMD for company, so a
+            // dependent chain of short read groups would expose the LDS latency eight times over
+            uint32_t fields[LIST / 2];
+#pragma unroll
+            for(int w = 0; w < LIST / 2; ++w) { fields[w] = (observed_low ^ record_word(w)) | (observed_high ^ record_word(LIST / 2 + w)); }
+            float first_group[LIST];
+            float second_group[LIST];
+#pragma unroll
+            for(int o = 0; o < LIST; ++o) {
+                first_group[o] = entry(fields[o >> 1], 2 * (o & 1), 0);
+                second_group[o] = entry(fields[o >> 1], 2 * (o & 1) + 1, 1);
+            }
+            // H[n]: the largest product over n or more mismatching positions, n = 2 .. 6, in units of the all-match product
+            // (while the reads are under way)
             float h[7];
 #pragma unroll
-            for(int m = 3; m <= 6; ++m) {
+            for(int m = 2; m <= 6; ++m) {
                 h[m] = 0.0f;
                 bool any = false;
 #pragma unroll
                 for(int a = 0; a <= 4; ++a) {
-                    const int b = m - a;
-                    if(b >= 0 && b <= 4 && a <= Layout::positions(0) && b <= Layout::positions(1)) {
-                        const float product = ge[0][a] * ge[1][b];
+                    const int o = m - a;
+                    if(o >= 0 && o <= 4 && a <= Layout::positions(0) && o <= Layout::positions(1)) {
+                        const float product = ge[0][a] * ge[1][o];
                         h[m] = any ? fmaxf(h[m], product) : product;
                         any = true;
                     }
                 }
             }
-
-            // the list of c: eight pairs of barcodes as plane words, then {radius, cnt_r, cnt_rest, index}
-            const uint32_t record_at = Layout::record_at(0) + static_cast<uint32_t>(Layout::words_bytes(n_barcode)) + c * (RECORD_WORDS * 4u);
-            Quad record[RECORD_WORDS / 4];
+            const uint32_t mismatches = fields[0] & FULL_MASK;      // of c: the flag bits of its mismatching positions
+            const float winner = first_group[0] * second_group[0];  // P(r|c) over the all-match product: 1 for a read ON c
+            float others;                                           // the other listed barcodes
+            {
+                float p[LIST];
 #pragma unroll
-            for(int quad = 0; quad < RECORD_WORDS / 4; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(record_at + 16u * quad); }
-            auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
-            float winner = 0;                        // P(r|c) over the all-match product
-            float others = 0;                        // the other listed barcodes
-            uint32_t mismatches = 0;                 // of c: the flag bits of its mismatching positions
-#pragma unroll
-            for(int w = 0; w < LIST / 2; ++w) {
-                const uint32_t fields = (observed_low ^ record_word(w)) | (observed_high ^ record_word(LIST / 2 + w));
-                const float even = entry(fields, 0, 0) * entry(fields, 1, 1);
-                const float odd = entry(fields, 2, 0) * entry(fields, 3, 1);
-                if(w == 0) { mismatches = fields & FULL_MASK; winner = even; others = odd; }
-                else { others += even + odd; }
+                for(int o = 1; o < LIST; ++o) { p[o] = first_group[o] * second_group[o]; }
+                others = (((p[1] + p[2]) + (p[3] + p[4])) + ((p[5] + p[6]) + (p[7] + p[8]))) + (((p[9] + p[10]) + (p[11] + p[12])) + ((p[13] + p[14]) + p[15]));
             }
 
-            // what was not scored: cnt_r barcodes at distance r from c, cnt_rest further away (pamld_near.hpp)
-            const uint32_t radius = record_word(LIST);
-            const float cnt_r = __uint_as_float(record_word(LIST + 1));
-            const float cnt_rest = __uint_as_float(record_word(LIST + 2));
-            const uint32_t index = record_word(LIST + 3);                  // barcode_index[c]
-            const int k = __popc(mismatches);
-            const bool near5 = radius >= 5u;                                    // the host clamps the radius to 5
-            const bool near3 = radius == 3u;                                    // a crowded set: only a read ON c is finished here
-            const float h_r = near5 ? h[5] : near3 ? h[3] : h[4];               // H[r]
-            const float h_up = near5 ? h[6] : near3 ? h[4] : h[5];              // H[r + 1]
-            const float h_down = near5 ? h[4] : h[3];                           // H[r - 1] (radius 3: not used)
-            // k = 1: rho of the read's own mismatch position is the winner itself; without that position
-            // top_n <= min(top_n, top_{n+1} / rho), and the position itself costs at most max(rho, 1)
-            const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-            const float boost = fmaxf(winner, 1.0f);
-            const float at_r = k == 0 ? h_r : boost * fminf(h_down, h_r * inverse_winner);
-            const float beyond = k == 0 ? h_up : boost * fminf(h_r, h_up * inverse_winner);
-            const float rest = (cnt_r * at_r + cnt_rest * beyond) * near::SLOP;
+            // What was not scored.  A barcode n mismatches from c mismatches a read one mismatch from c (at position p) in at
+            // least n - 1 positions besides p, and p itself costs it at most max(rho_p, 1); rho_p is the winner itself, and the
+            // largest product over m positions besides p is at most min(H[m], H[m + 1] / rho_p).  For a read ON c the same
+            // expression is H[n]: the winner is exactly 1 and H falls with n.  So, with w_n barcodes n mismatches from c
+            // (w_6: six or more; the host's counts), everything not scored is at most
+            //     max(winner, 1) * sum_n w_n * min(H[n - 1], H[n] / winner)
+            // One reciprocal serves it, the noise term and the posterior.
+            const float inverse_both = __builtin_amdgcn_rcpf(winner * everything_matches);
+            const float inverse_winner = inverse_both * everything_matches;
+            float rest = __uint_as_float(record_word(LIST)) * fminf(h[2], h[3] * inverse_winner);
+            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 1)), fminf(h[3], h[4] * inverse_winner), rest);
+            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 2)), fminf(h[4], h[5] * inverse_winner), rest);
+            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 3)), fminf(h[5], h[6] * inverse_winner), rest);
+            rest *= fmaxf(winner, 1.0f) * near::SLOP;
             const float x_listed = others * inverse_winner;
             const float x_rest = rest * inverse_winner;
-            const float x_low = x_listed + (uniform_noise_over_prior * __builtin_amdgcn_rcpf(everything_matches)) * inverse_winner;
-            // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp)
-            const float y = x_low * __builtin_amdgcn_rcpf(1.0f + x_low);            // 1 - posterior
+            const float x_low = __builtin_fmaf(uniform_noise_over_prior, inverse_both, x_listed);
+            // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp): 1 - y, y = x / (1 + x) = x - x^2 + x^3 up
+            // to x^4 < 7e-14 (x is at most 5e-4 where it counts)
+            const float y = x_low * __builtin_fmaf(-x_low, 1.0f - x_low, 1.0f);
             const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
-            const double confidence_margin = confidence - confidence_threshold;
-            const bool finished = all_strict && known && k <= 1 && (radius >= 4u || (near3 && k == 0)) && winner * everything_matches > noise_floor &&
+            const int k = __popc(mismatches);
+            const bool finished = all_strict && known && k <= 1 && winner * everything_matches > noise_floor &&
                                   x_listed <= near::LISTED_MAX && x_low + x_rest <= near::X_MAX && x_rest <= near::REST_MAX &&
-                                  fabs(confidence_margin) > 2e-8;
+                                  fabsf(y - y_threshold) > y_guard;
 
             // Outcome.  Every lane stores a record and a status word in straight line code — the real ones when the read
             // is finished; a deferred read's record is whatever was computed (pass C or the tiers behind it write it again),
             // its status word the state it came with; a lane past the end of the batch stores its (last) read's again
             const bool high_mismatch = k == 1 && winner <= rho_at_threshold && (zero_is_high || winner != 1.0f);
             const uint32_t hq_distance = high_mismatch ? 1u : 0u;
-            const bool confident = confidence_margin > 0;                               // pamld.cpp:99
+            const bool confident = y < y_threshold;                                     // pamld.cpp:99
             const bool qcfail = incoming_qcfail || !confident || (hq_threshold > 0 && static_cast<int>(hq_distance) >= hq_threshold);
             const bool qcfail_out = finished ? qcfail : incoming_qcfail;
             {
@@ -563,36 +642,35 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
                 __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
             }
             if(finished && active) {
-                // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86), workgroup histogram
+                // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86): the barcode's bin, in its block
                 const uint32_t half = qcfail ? 0u : 1u;
-                bin_add(histogram, c + 1u, half, 0, 1ull | (static_cast<unsigned long long>(k) << 32));
+                bin_add(lds_raw, block + BIN_AT, half, 0, 1ull | (static_cast<unsigned long long>(k) << 32));
                 if(confident) {
-                    // round(confidence * 2^52) as the mantissa of 1 + confidence (a confidence of exactly 1 carries into the
-                    // exponent, which the subtraction turns into bit 52), split in two 26 bit limbs
-                    const double shifted = confidence + 1.0;
-                    const uint32_t fixed_low = static_cast<uint32_t>(__double2loint(shifted));
-                    const uint32_t fixed_high = static_cast<uint32_t>(__double2hiint(shifted)) - 0x3ff00000u;
-                    bin_add(histogram, c + 1u, half, 1, static_cast<unsigned long long>(fixed_low & 0x3ffffffu));
-                    bin_add(histogram, c + 1u, half, 2, static_cast<unsigned long long>((fixed_high << 6) | (fixed_low >> 26)));
+                    // the posterior as the integer 2^38 - round(y 2^38) (y is at most 5e-4 here: its multiple fits 32 bits), as
+                    // the buffer's two limbs of 2^-52: every read adds the same two numbers however the reads are batched
+                    const uint32_t t = __float2uint_rn(y * static_cast<float>(1ull << PASS_A_FRACTION_BITS));
+                    constexpr int SHIFT = CONFIDENCE_FRACTION_BITS - PASS_A_FRACTION_BITS;                 // 14
+                    constexpr uint32_t BELOW = (1u << (CONFIDENCE_LIMB_BITS - SHIFT)) - 1u;                 // the 12 bits under the high limb
+                    bin_add(lds_raw, block + BIN_AT, half, 1, static_cast<unsigned long long>(((0u - t) & BELOW) << SHIFT));
+                    bin_add(lds_raw, block + BIN_AT, half, 2, static_cast<unsigned long long>((1u << CONFIDENCE_LIMB_BITS) - ((t + BELOW) >> (CONFIDENCE_LIMB_BITS - SHIFT))));
                 } else {
-                    bin_add(histogram, c + 1u, 0, 3, 1ull << 32);                     // low confidence count (pamld.cpp:104-106)
+                    bin_add(lds_raw, block + BIN_AT, 0, 3, 1ull << 32);                            // low confidence count (pamld.cpp:104-106)
                 }
             }
             deferred = __ballot(active && !finished);
             if(last_stage) {
-                const unsigned long long pass = __ballot(active && finished && !qcfail);
-                const unsigned long long fail = __ballot(active && finished && qcfail);
-                if(lane == 0) {
-                    if(fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(__popcll(fail))); }
-                    if(pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(__popcll(pass))); }
-                }
+                outgoing_pass += static_cast<uint32_t>(__popcll(__ballot(active && finished && !qcfail)));
+                outgoing_fail += static_cast<uint32_t>(__popcll(__ballot(active && finished && qcfail)));
             }
+            tile += tile_step;
         } else {
             more = false;
         }
         const uint32_t arriving = static_cast<uint32_t>(__popcll(deferred));
         if(ring_count + arriving > RING || (!more && ring_count > 0)) {
+#ifndef PHQ_DIAG_NO_DRAIN
             drain(ring_count);
+#endif
             ring_count = 0;
         }
         if(arriving) {
@@ -608,7 +686,11 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
             ring_count += arriving;
         }
     }
-    if(lane == 0) { args.worklist_count[own_segment] = segment_count; }
+    if(lane == 0) {
+        args.worklist_count[own_segment] = segment_count;
+        if(outgoing_fail) { atomicAdd(&histogram[0], static_cast<unsigned long long>(outgoing_fail)); }
+        if(outgoing_pass) { atomicAdd(&histogram[1], static_cast<unsigned long long>(outgoing_pass)); }
+    }
     __syncthreads();
     // the workgroup's bins into the counter buffer: one global atomic per field that is not zero
     for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += THREADS) {
@@ -616,18 +698,19 @@ __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) void pamld_stream_kerne
         if(v) { atomicAdd(&args.stats[i], v); }
     }
     for(int i = threadIdx.x; i < (n_barcode + 1) * BIN_WORDS; i += THREADS) {
-        const unsigned long long v = histogram[STAT_JOB_WORDS + i];
-        if(v == 0) { continue; }
         const int bin = i / BIN_WORDS;
         const int pass_filter = (i % BIN_WORDS) / 4;
         const int word = i % 4;
+        const unsigned long long v = bin == 0 ? histogram[STAT_JOB_WORDS + i]
+                                              : *reinterpret_cast<const unsigned long long*>(lds_raw + block_base + static_cast<uint32_t>(bin - 1) * BLOCK_BYTES + BIN_AT + 8u * (i % BIN_WORDS));
+        if(v == 0) { continue; }
         unsigned long long* const to = args.stats + d.stats_offset + bin * STAT_WORDS_PER_BIN + pass_filter * STAT_FIELDS;
         if(word == 0) {
             atomicAdd(&to[FIELD_COUNT], v & 0xffffffffull);
             if(v >> 32) { atomicAdd(&to[FIELD_DISTANCE], v >> 32); }
         } else if(word == 1) { atomicAdd(&to[FIELD_CONFIDENCE_LOW], v); }
         else if(word == 2) { atomicAdd(&to[FIELD_CONFIDENCE_HIGH], v); }
-        else {
+        else if(word == 3) {
             if(v & 0xffffffffull) { atomicAdd(&to[FIELD_LOW_CONDITIONAL_CONFIDENCE], v & 0xffffffffull); }
             if(v >> 32) { atomicAdd(&to[FIELD_LOW_CONFIDENCE], v >> 32); }
         }
@@ -638,7 +721,8 @@ template <int L, int STATE, int WAVES>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
     if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES>), grid, dim3(Shape<L, WAVES>::THREADS), Shape<L, WAVES>::lds_bytes(n_barcode), stream, args);
+    typedef Shape<L, WAVES> Layout;
+    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES>), grid, dim3(Layout::THREADS), Layout::lds_bytes(n_barcode), stream, args);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -85,6 +85,10 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool tiny = pamld_tiny_supports(host_decoder);
                 const bool listed = !tiny && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
                 const bool paired = !tiny && !listed && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
+                // ... and where the streaming kernel takes the codec (5 to 8 nt, uniform priors), lists and scan are ONE launch, every
+                // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)
+                static const bool no_stream = std::getenv("PHQ_NO_STREAM") != nullptr;
+                const bool streamed = listed && !no_stream && host_decoder.use_lds_histogram && !args.defer_counters && pamld_stream_supports(host_decoder);
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
@@ -102,6 +106,34 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
+                if(streamed) {
+                    // one workgroup per CU, a worklist segment per WAVE: what the scan cannot decide either goes there
+                    const int waves = pamld_stream_waves();
+                    const int64_t wave_tiles = (args.n_read + 63) / 64;
+                    const int64_t wanted = std::max<int64_t>(1, std::min<int64_t>(cus, (wave_tiles + waves - 1) / waves));
+                    const dim3 stream_grid(static_cast<unsigned>(wanted));
+                    const int64_t segments = wanted * waves;
+                    producer.worklist_stride = static_cast<int32_t>((wave_tiles + segments - 1) / segments * 64);
+                    producer.carry = nullptr;
+                    producer.carry_stride = 0;
+                    {
+                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
+                        status = launch_pamld_stream(producer, host_decoder, stream_grid, s);
+                    }
+                    if(status != 0) { return status; }
+                    const dim3 segment_grid(static_cast<unsigned>(segments));
+                    trace_worklist("the streaming kernel", producer, segment_grid.x, s);
+                    StageArgs consumer = producer;
+                    consumer.worklist_role = 2;
+                    if(pamld_exact_supports(host_decoder)) {
+                        Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                        status = launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                        if(status != 0) { return status; }
+                        trace_worklist("the exact tier", producer, segment_grid.x, s);
+                    }
+                    Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
+                    return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
+                }
                 if(listed || paired || crossed) {
                     {
                         Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
