@@ -1,76 +1,92 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 output into the per kernel summary bench.py quotes (profiles/rNN_summary.json).
+"""Fold the rocprofv3 passes of profiles/tools/refresh.sh into profiles/rNN_traffic.json, the file bench.py quotes
+`roofline.traffic` from.
 
-usage: summarize.py <kernel-trace dir> <FETCH_SIZE pmc dir> <WRITE_SIZE pmc dir> <reads per launch> <out.json> [note]
+usage: summarize.py <gpurun_out/prof_rNN> <out.json> shape [shape ...]
 
-  kernel-trace dir : rocprofv3 --kernel-trace --stats --output-format csv   (*_kernel_stats.csv)
-  pmc dirs         : rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE           (*_counter_collection.csv), own passes
-
-HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KiB and is
-doubled on gfx950 (128 byte requests are tallied as 64), WRITE_SIZE is in KiB and taken as is.
+Per shape directory: trace/ (rocprofv3 --kernel-trace --stats --output-format csv), fetch/ and write/ (rocprofv3 --pmc
+FETCH_SIZE / --pmc WRITE_SIZE, passes of their own) and bench.json (the bench line of the trace pass).  HBM bytes follow
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KiB and doubled on gfx950 (128 byte requests are
+tallied as 64), WRITE_SIZE is in KiB and taken as is.  A shape's `step_bytes_per_read` sums EVERY kernel of the library a
+step launches; `wasted` = that over the algorithmic bytes.  The file names the build the passes ran on
+(phq_build_id, the SHA-256 over the library's sources) and the commit: bench.py flags a summary of another build as stale.
 """
 import collections
 import csv
 import glob
 import json
 import os
+import subprocess
 import sys
 
-KINDS = (("pamld_near", ("pamld_near_kernel",)),
-         ("pamld_product", ("pamld_lut_kernel", "pamld_cross_kernel", "pamld_wide_kernel")),
-         ("pamld_exact", ("pamld_cross_exact_kernel",)),
-         ("pamld_literal", ("pamld_literal_kernel",)),
-         ("mdd_exact", ("mdd_exact_kernel",)),
-         ("mdd", ("mdd_scan_kernel", "mdd_kernel")),
-         ("count", ("count_kernel",)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def kind_of(name):
-    for kind, needles in KINDS:
-        if any(n in name for n in needles):
-            return kind
-    return None
-
-
-def first(directory, pattern):
-    """The newest match: a directory may hold the output of earlier runs too."""
+def newest(directory, pattern):
     found = sorted(glob.glob(os.path.join(directory, "**", pattern), recursive=True), key=os.path.getmtime)
     if not found:
         raise SystemExit("no %s under %s" % (pattern, directory))
     return found[-1]
 
 
-def counter_average(directory, counter):
+def counter_by_kernel(directory, counter):
+    """{kernel: (summed value over its dispatches, dispatches)}"""
     total = collections.defaultdict(float)
     calls = collections.defaultdict(int)
-    for row in csv.DictReader(open(first(directory, "*_counter_collection.csv"))):
-        if row["Counter_Name"] == counter:
+    for row in csv.DictReader(open(newest(directory, "*_counter_collection.csv"))):
+        if row["Counter_Name"] == counter and "phq::" in row["Kernel_Name"]:
             total[row["Kernel_Name"]] += float(row["Counter_Value"])
             calls[row["Kernel_Name"]] += 1
-    return {name: total[name] / calls[name] for name in total}
+    return {name: (total[name], calls[name]) for name in total}
+
+
+def short(name):
+    return name.replace("void phq::", "").replace("(phq::StageArgs)", "")
 
 
 def main():
-    trace, fetch_dir, write_dir, reads, out = sys.argv[1:6]
-    note = sys.argv[6] if len(sys.argv) > 6 else ""
-    reads = int(reads)
-    fetch = counter_average(fetch_dir, "FETCH_SIZE")
-    write = counter_average(write_dir, "WRITE_SIZE")
-    summary = {}
-    for row in csv.DictReader(open(first(trace, "*_kernel_stats.csv"))):
-        name = row["Name"]
-        kind = kind_of(name)
-        if kind is None or kind in summary:
-            continue
-        entry = {"kernel": name, "calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "reads_per_launch": reads}
-        if name in fetch and name in write:
-            traffic = (2.0 * fetch[name] + write[name]) * 1024.0
-            entry.update({"fetch_size_kib": fetch[name], "write_size_kib": write[name], "traffic_bytes_per_launch": traffic,
-                          "traffic_bytes_per_read": traffic / reads,
-                          "note": ("FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section (gfx950 counts 128 B requests as 64 B). " + note).strip()})
-        summary[kind] = entry
-    json.dump(summary, open(out, "w"), indent=2)
-    print(json.dumps(summary, indent=2))
+    directory, out = sys.argv[1:3]
+    from pheniqs_amd import capi
+    try:
+        commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        commit = None                                   # the GPU box holds no .git: the caller may add it
+    summary = {"build": capi.build_id(), "source": capi.source_id(), "commit": commit, "shapes": {},
+               "note": "traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 tallies 128 B requests as 64 B); "
+                       "per launch averages over every dispatch of a pass; counter passes ran 3 steps, the trace 7"}
+    for shape in sys.argv[3:]:
+        where = os.path.join(directory, shape)
+        line = json.load(open(os.path.join(where, "bench.json")))
+        reads = line["config"]["reads_per_gpu"]
+        algorithmic = line["roofline"]["algorithmic_bytes_per_read"]
+        fetch = counter_by_kernel(os.path.join(where, "fetch"), "FETCH_SIZE")
+        write = counter_by_kernel(os.path.join(where, "write"), "WRITE_SIZE")
+        counter_steps = 3                               # refresh.sh: --steps 2 --warmup 1
+        kernels = {}
+        for row in csv.DictReader(open(newest(os.path.join(where, "trace"), "*_kernel_stats.csv"))):
+            name = row["Name"]
+            if "phq::" not in name:
+                continue
+            entry = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "launches_per_step": int(row["Calls"]) / 7.0}
+            if name in fetch and name in write:
+                entry["fetch_kib_per_launch"] = fetch[name][0] / fetch[name][1]
+                entry["write_kib_per_launch"] = write[name][0] / write[name][1]
+                entry["bytes_per_step"] = (2.0 * fetch[name][0] + write[name][0]) * 1024.0 / counter_steps
+                entry["bytes_per_read"] = entry["bytes_per_step"] / reads
+            kernels[short(name)] = entry
+        step = sum(k.get("bytes_per_step", 0.0) for k in kernels.values())
+        dominant = max(kernels, key=lambda k: kernels[k]["average_ns"] * kernels[k]["launches_per_step"])
+        # bench.py's dominant kernel is a KIND (all launches of it in a step): every kernel of that family together
+        family = dominant.split("<")[0]
+        dominant_bytes = sum(k.get("bytes_per_step", 0.0) for n, k in kernels.items() if n.split("<")[0] == family)
+        summary["shapes"][shape] = {"reads_per_step": reads, "algorithmic_bytes_per_read": algorithmic, "ms_per_step": line["ms_per_step"],
+                                    "dominant_kernel": family, "dominant_bytes_per_read": dominant_bytes / reads,
+                                    "step_bytes_per_read": step / reads, "wasted": step / reads / algorithmic, "kernels": kernels}
+    json.dump(summary, open(out, "w"), indent=1)
+    for shape, entry in summary["shapes"].items():
+        print("%-28s %6.3f ms  step %.2f B/read over %d algorithmic = %.2fx  (dominant %s %.2f B/read)" % (
+            shape, entry["ms_per_step"], entry["step_bytes_per_read"], entry["algorithmic_bytes_per_read"], entry["wasted"], entry["dominant_kernel"], entry["dominant_bytes_per_read"]))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,33 @@
+#!/bin/bash
+# The profile set of a round, taken on ONE build: bash profiles/tools/refresh.sh r03 [shape ...]   (GPU box, repo root).
+# Per workload: a kernel trace (--kernel-trace --stats) and two counter passes of their own (--pmc FETCH_SIZE, --pmc
+# WRITE_SIZE: MI355X_MICROARCH.md's HBM recipe), each of the same bench.py command; then profiles/summarize.py folds
+# them into profiles/rNN_traffic.json, stamped with the build (phq_build_id) and the commit.
+round=${1:-r03}; shift
+export TMPDIR=/tmp
+declare -A ARGS=(
+  [C2_pamld]=""
+  [C2_pamld_literal]="--mode literal"
+  [C2_mdd]="--algorithm mdd"
+  [C2_pamld_estimated_priors]="--priors estimated"
+  [C3_pamld]="--config C3"
+  [C3_pamld_estimated_priors]="--config C3 --reads 50000000 --priors estimated"
+  [C4_pamld]="--config C4 --reads 50000000"
+  [C4V_pamld]="--config C4V --reads 50000000"
+  [C5_pamld]="--config C5 --reads 50000000"
+)
+shapes=("$@"); [ ${#shapes[@]} -eq 0 ] && shapes=(C2_pamld C2_pamld_literal C2_mdd C2_pamld_estimated_priors C3_pamld C3_pamld_estimated_priors C4_pamld C4V_pamld C5_pamld)
+out=gpurun_out/prof_$round
+for shape in "${shapes[@]}"; do
+  a="${ARGS[$shape]}"
+  d=$out/$shape; rm -rf $d; mkdir -p $d
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 bench.py $a --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $d/trace.log 2>&1
+  grep '^{"metric"' $d/trace.log | tail -1 > $d/bench.json
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $d/fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $d/write.log 2>&1
+  stats=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
+  (head -1 $stats; grep "phq::" $stats) > gpurun_out/${round}_${shape}_kernel_stats.csv
+  cp $d/bench.json gpurun_out/${round}_bench_${shape}.json
+  echo "$shape: $(grep -o '"ms_per_step": [0-9.]*' $d/bench.json)"
+done
+python3 profiles/summarize.py $out gpurun_out/${round}_traffic.json "${shapes[@]}"
