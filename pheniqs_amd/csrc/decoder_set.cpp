@@ -1252,19 +1252,29 @@ void summarize_read(const JobConfig& job, const DevResult* result, int64_t batch
 const DecoderSet::HostStage& DecoderSet::host_stage(int64_t capacity) {
     if(host_stage_.capacity < capacity) {
         release_host_stage();
+        // pinned for a set with a device; a host only set (configuration, staging, the sanitizer build) takes plain memory
+        const bool pinned = device_ >= 0;
+        auto take = [&](size_t bytes) -> void* {
+            if(pinned) { return host_alloc(bytes); }
+            void* pointer = std::malloc(bytes > 0 ? bytes : 16);
+            if(pointer == nullptr) { throw OutOfMemoryError("host staging planes"); }
+            return pointer;
+        };
         const size_t planes = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
-        host_stage_.base = static_cast<uint8_t*>(host_alloc(planes));
-        host_stage_.quality = static_cast<uint8_t*>(host_alloc(planes));
-        host_stage_.flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(capacity)));
-        host_stage_.result = static_cast<DevResult*>(host_alloc(static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult)));
-        host_stage_.word = static_cast<uint32_t*>(host_alloc(static_cast<size_t>(capacity) * sizeof(uint32_t)));
+        host_stage_.pinned = pinned;
+        host_stage_.base = static_cast<uint8_t*>(take(planes));
+        host_stage_.quality = static_cast<uint8_t*>(take(planes));
+        host_stage_.flag = static_cast<uint8_t*>(take(static_cast<size_t>(capacity)));
+        host_stage_.result = static_cast<DevResult*>(take(static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult)));
+        host_stage_.word = static_cast<uint32_t*>(take(static_cast<size_t>(capacity) * sizeof(uint32_t)));
         host_stage_.capacity = capacity;
     }
     return host_stage_;
 }
 
 void DecoderSet::release_host_stage() {
-    host_free(host_stage_.base); host_free(host_stage_.quality); host_free(host_stage_.flag); host_free(host_stage_.result); host_free(host_stage_.word);
+    void* const all[] = {host_stage_.base, host_stage_.quality, host_stage_.flag, host_stage_.result, host_stage_.word};
+    for(void* pointer : all) { if(host_stage_.pinned) { host_free(pointer); } else { std::free(pointer); } }
     host_stage_ = HostStage();
 }
 

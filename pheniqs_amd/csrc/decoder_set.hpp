@@ -48,7 +48,7 @@ public:
     void summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const;
     // pinned host planes for the transcoder's batches, kept by the set from one run to the next (pinning tens of
     // megabytes costs more than classifying a batch)
-    struct HostStage { int64_t capacity = 0; uint8_t* base = nullptr; uint8_t* quality = nullptr; uint8_t* flag = nullptr; DevResult* result = nullptr; uint32_t* word = nullptr; };
+    struct HostStage { int64_t capacity = 0; bool pinned = true; uint8_t* base = nullptr; uint8_t* quality = nullptr; uint8_t* flag = nullptr; DevResult* result = nullptr; uint32_t* word = nullptr; };
     const HostStage& host_stage(int64_t capacity);
     void release_host_stage();
     const std::string& report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count);

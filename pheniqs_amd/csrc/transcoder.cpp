@@ -687,6 +687,7 @@ struct Transcoder::Impl {
     DevResult* result;
     uint32_t* word;
     std::vector<int64_t> kept;
+    Transcoder::Classifier classifier;           // empty: DecoderSet::classify_host
 
     Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
@@ -732,6 +733,8 @@ Transcoder::Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch
 }
 
 Transcoder::~Transcoder() { delete impl_; }
+
+void Transcoder::set_classifier(Classifier classifier) { impl_->classifier = std::move(classifier); }
 
 void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     Impl& m = *impl_;
@@ -927,7 +930,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                           view[static_cast<size_t>(leader)].qcfails(), m.capacity, m.base, m.quality, m.flag, m.kept.data(), &n_kept,
                           &incoming_count, &incoming_pf_count);
         lap(1);
-        m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word);
+        if(m.classifier) { m.classifier(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word); }
+        else { m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word); }
         lap(2);
 
         // f2: records, a contiguous range of the batch per thread, written in order

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <utility>
@@ -46,6 +47,12 @@ public:
     Transcoder& operator=(const Transcoder&) = delete;
     // runs to the end of the input; adds every read pulled to the incoming counters (transcode.cpp:304-309)
     void run(uint64_t& incoming_count, uint64_t& incoming_pf_count);
+    // A seam for the sanitizer build (check/transcoder_check.cpp): what fills the result planes and status words of a
+    // staged batch.  The product never sets it — a batch is classified by DecoderSet::classify_host on the GPU, and a set
+    // without a device fails there; the check injects planes of its own so that the reader and the record writers run
+    // under AddressSanitizer, where no GPU code can.
+    typedef std::function<void(int64_t capacity, int64_t n_read, const uint8_t* base, const uint8_t* quality, const uint8_t* flag, DevResult* result, uint32_t* word)> Classifier;
+    void set_classifier(Classifier classifier);
 
 private:
     struct Impl;

@@ -308,3 +308,60 @@ def test_host_side_under_sanitizers(tmp_path):
     ran = subprocess.run([os.path.join(csrc, "build", "host_check_asan")] + paths, capture_output=True, text=True)
     assert ran.returncode == 0, ran.stdout + ran.stderr
     assert "host check ok" in ran.stdout
+
+
+def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
+    """csrc/transcoder.cpp — mapped input, 32 byte line scans, raw pointer record writers — under ASan + UBSan, driven with
+    damaged FASTQ files (fastq.h:427-440: truncated records, broken separators, names out of sync) and with result planes
+    the check injects (auxiliary.cpp:327-354 is the writers' side): an error code or a result every time, nothing for the
+    sanitizers to report.  The test's own exact match planes stand where the GPU's would be; the product path is not touched."""
+    import json
+    import subprocess
+
+    import numpy as np
+
+    import bench
+    from pheniqs_amd import synthetic
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "pheniqs_amd", "csrc")
+    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    if built.returncode != 0:
+        pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
+    check = os.path.join(csrc, "build", "transcoder_check_asan")
+    # the reference's own three segment test files, 250 records each: 260 damaged runs
+    work = tmp_path / "bdggg"
+    work.mkdir()
+    job = work / "job.json"
+    job.write_text(json.dumps(bdggg.user_job()))
+    inputs = [os.path.join(here, "golden", "BDGGG", "BDGGG_s0%d.fastq" % k) for k in (1, 2, 3)]
+    ran = subprocess.run([check, str(job), "260", str(work)] + inputs, capture_output=True, text=True)
+    assert ran.returncode == 0, ran.stdout + ran.stderr
+    assert "261 runs" in ran.stdout
+    # a two segment job over 3 000 synthetic records (batches of 37 records: many batches, the read ahead of the readers),
+    # every barcode a channel with FASTQ outputs of its own for the rounds that take the job's directives: 140 runs
+    work = tmp_path / "c2"
+    work.mkdir()
+    spec = synthetic.config_spec("C2", "mdd")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    spec["base output url"] = str(work)
+    for number, record in enumerate(spec["sample"]["codec"].values()):
+        if number < 5:
+            record["output"] = ["channel_%d_s1.fastq" % number, "channel_%d_s2.fastq.gz" % number]
+    spec["sample"]["output"] = ["rest.sam"]
+    compiled = capi.compile_job(spec)
+    code, quality, flag, _ = synthetic.generate_rows(compiled, 3000, 11)
+    letters = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
+    rng = np.random.default_rng(5)
+    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(3000, 30), dtype=np.uint8)]
+    paths = []
+    for k, (text, qual) in enumerate(((template, np.full((3000, 30), ord("F"), dtype=np.uint8)), (letters[code], (np.minimum(quality, 93) + 33).astype(np.uint8)))):
+        path = str(work / ("segment_in_%d.fastq" % k))
+        bench.write_fastq(path, k + 1, text, qual, flag)
+        paths.append(path)
+    job = work / "job.json"
+    job.write_text(json.dumps(spec))
+    ran = subprocess.run([check, str(job), "140", str(work)] + paths, capture_output=True, text=True)
+    assert ran.returncode == 0, ran.stdout + ran.stderr
+    results = int(ran.stdout.split(" runs, ")[1].split(" results")[0])
+    assert "141 runs" in ran.stdout and results >= 20, ran.stdout
