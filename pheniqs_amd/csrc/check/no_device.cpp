@@ -1,8 +1,13 @@
 // The sanitizer build holds no kernel translation unit: a decoder set created with PHQ_DEVICE_NONE never launches, and
-// these two entry points of the stage dispatcher (stage.hip) only have to link.
+// these entry points of the kernel translation units (stage.hip, fastq_device.hip) only have to link.
 #include "../device_types.hpp"
+#include "../fastq_device.hpp"
 
 namespace phq {
 int launch_stage(const StageArgs&, const DevDecoder&, int32_t, int32_t, void*, LaunchTimer*) { return 100; }      // hipErrorNoDevice
 bool stage_uses_worklist(const DevDecoder&, int32_t) { return false; }
+// ... and the device FASTQ path (fastq_device.hip) is never taken by a set without a device
+int fastq_index(const FastqFeedChunk&, void*) { return 100; }
+int fastq_plan_round(const FastqFeedChunk*, int32_t, uint32_t, FastqRound*, void*) { return 100; }
+int fastq_decode(const FastqPlan&, const FastqFeedChunk*, uint32_t, int64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*, unsigned long long*, void*) { return 100; }
 }

@@ -7,6 +7,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,7 @@ public:
     void profile_collect(double* milliseconds, int64_t* launches);
 
     std::string last_error;
+    std::shared_ptr<void> device_fastq_cache;      // transcoder.cpp: the buffers of the device FASTQ path, kept from run to run
 
 private:
     void require_device() const;

@@ -1,0 +1,261 @@
+// FASTQ text -> decoder planes on the device: see fastq_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include "fastq_device.hpp"
+#include "job.hpp"
+
+namespace phq {
+
+namespace {
+
+constexpr int TILE_THREADS = 256;             // 16 bytes per thread: a workgroup indexes 4 KiB of text
+
+// bit 7 of every byte of x that is '\n' (exact per byte: no borrow runs from one byte into the next)
+__device__ __forceinline__ uint32_t newline_bytes(uint32_t x) {
+    const uint32_t y = x ^ 0x0a0a0a0au;
+    return ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;
+}
+
+__device__ __forceinline__ uint4 unit_of(const uint8_t* raw, uint32_t bytes, uint32_t unit) {
+    // the buffer is zero padded to whole units of 16 bytes: a zero is no newline
+    return static_cast<uint64_t>(unit) * 16u < bytes ? reinterpret_cast<const uint4*>(raw)[unit] : make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void fastq_count_kernel(const uint8_t* raw, uint32_t bytes, uint32_t* block_count) {
+    __shared__ uint32_t sum;
+    if(threadIdx.x == 0) { sum = 0; }
+    __syncthreads();
+    const uint4 v = unit_of(raw, bytes, blockIdx.x * TILE_THREADS + threadIdx.x);
+    uint32_t mine = __popc(newline_bytes(v.x)) + __popc(newline_bytes(v.y)) + __popc(newline_bytes(v.z)) + __popc(newline_bytes(v.w));
+    for(int step = 32; step > 0; step >>= 1) { mine += __shfl_down(mine, step); }
+    if((threadIdx.x & 63) == 0 && mine) { atomicAdd(&sum, mine); }
+    __syncthreads();
+    if(threadIdx.x == 0) { block_count[blockIdx.x] = sum; }
+}
+
+// exclusive prefix sums of the workgroups' counts, in place; block_count[n_block] = *total = the number of newlines
+__global__ __launch_bounds__(1024) void fastq_scan_kernel(uint32_t* block_count, uint32_t n_block, uint32_t* total) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carried;
+    if(threadIdx.x == 0) { carried = 0; }
+    __syncthreads();
+    for(uint32_t first = 0; first < n_block; first += 1024) {
+        const uint32_t at = first + threadIdx.x;
+        const uint32_t own = at < n_block ? block_count[at] : 0u;
+        uint32_t inclusive = own;
+        for(int step = 1; step < 64; step <<= 1) {
+            const uint32_t below = __shfl_up(inclusive, step);
+            if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+        }
+        if((threadIdx.x & 63) == 63) { wave_sum[threadIdx.x >> 6] = inclusive; }
+        __syncthreads();
+        uint32_t before = carried;
+        for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { before += wave_sum[w]; }
+        if(at < n_block) { block_count[at] = before + inclusive - own; }
+        __syncthreads();
+        if(threadIdx.x == 1023) { carried = before + inclusive; }
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) { block_count[n_block] = carried; *total = carried; }
+}
+
+__global__ __launch_bounds__(TILE_THREADS) void fastq_scatter_kernel(const uint8_t* raw, uint32_t bytes, const uint32_t* block_offset, uint32_t* newline, uint32_t capacity) {
+    __shared__ uint32_t wave_sum[TILE_THREADS / 64];
+    const uint32_t unit = blockIdx.x * TILE_THREADS + threadIdx.x;
+    const uint4 v = unit_of(raw, bytes, unit);
+    const uint32_t word[4] = {newline_bytes(v.x), newline_bytes(v.y), newline_bytes(v.z), newline_bytes(v.w)};
+    const uint32_t own = __popc(word[0]) + __popc(word[1]) + __popc(word[2]) + __popc(word[3]);
+    uint32_t inclusive = own;
+    for(int step = 1; step < 64; step <<= 1) {
+        const uint32_t below = __shfl_up(inclusive, step);
+        if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+    }
+    if((threadIdx.x & 63) == 63) { wave_sum[threadIdx.x >> 6] = inclusive; }
+    __syncthreads();
+    uint32_t at = block_offset[blockIdx.x] + inclusive - own;
+    for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { at += wave_sum[w]; }
+    if(own == 0) { return; }
+#pragma unroll
+    for(int k = 0; k < 4; ++k) {
+        uint32_t bits = word[k];
+        while(bits) {
+            const uint32_t bit = static_cast<uint32_t>(__ffs(static_cast<int>(bits))) - 1u;      // 7, 15, 23 or 31
+            bits &= bits - 1u;
+            if(at < capacity) { newline[at] = unit * 16u + static_cast<uint32_t>(k) * 4u + (bit >> 3); }
+            ++at;
+        }
+    }
+}
+
+struct PlanArgs {
+    FastqFeedChunk chunk[FASTQ_MAX_FEED];
+    int32_t n_feed;
+    uint32_t capacity;
+    FastqRound* round;
+};
+
+__global__ void fastq_plan_kernel(PlanArgs args) {
+    if(threadIdx.x != 0 || blockIdx.x != 0) { return; }
+    uint32_t records = args.capacity;
+    uint32_t irregular = 0;
+    for(int f = 0; f < args.n_feed; ++f) {
+        const uint32_t lines = *args.chunk[f].total;
+        args.round->lines[f] = lines;
+        if(lines > args.chunk[f].newline_capacity) { irregular = 1; }
+        records = min(records, lines / 4u);
+    }
+    if(irregular) { records = 0; }
+    for(int f = 0; f < args.n_feed; ++f) { args.round->consumed[f] = records > 0 ? args.chunk[f].newline[4u * records - 1u] + 1u : 0u; }
+    args.round->records = records;
+    args.round->irregular = irregular;
+}
+
+struct DecodeArgs {
+    FastqPlan plan;
+    FastqFeedChunk chunk[FASTQ_MAX_FEED];
+    uint32_t n;
+    int64_t capacity;
+    uint8_t* base_planes;
+    uint8_t* quality_planes;
+    uint8_t* flag;
+    uint32_t* irregular;
+    unsigned long long* flagged;
+    uint8_t bam_of_ascii[256];
+    uint8_t complement_of_bam[16];
+};
+
+__global__ __launch_bounds__(256) void fastq_decode_kernel(DecodeArgs args) {
+    const FastqPlan& plan = args.plan;
+    for(uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < args.n; r += gridDim.x * blockDim.x) {
+        uint32_t sequence_at[FASTQ_MAX_FEED];
+        uint32_t quality_at[FASTQ_MAX_FEED];
+        uint32_t length[FASTQ_MAX_FEED];
+        bool odd = false;
+        bool filtered = false;
+        uint32_t first_name_at = 0;
+        uint32_t first_name_size = 0;
+        for(int f = 0; f < plan.n_feed; ++f) {
+            const uint8_t* const raw = args.chunk[f].raw;
+            const uint32_t* const newline = args.chunk[f].newline + 4u * r;
+            const uint32_t header_at = r == 0 ? 0u : newline[-1] + 1u;
+            const uint32_t header_end = newline[0];
+            const uint32_t sequence_end = newline[1];
+            const uint32_t separator_end = newline[2];
+            const uint32_t quality_end = newline[3];
+            sequence_at[f] = header_end + 1u;
+            quality_at[f] = separator_end + 1u;
+            length[f] = sequence_end - sequence_at[f];
+            // the framing of a record (fastq.h:427-440), nothing the host reader would have to tolerate or report
+            odd = odd || header_end == header_at || raw[header_at] != '@' || separator_end == sequence_end + 1u || raw[sequence_end + 1u] != '+' ||
+                  quality_end - quality_at[f] != length[f] || raw[header_end - 1u] == '\r' || (length[f] > 0 && raw[sequence_end - 1u] == '\r') ||
+                  raw[separator_end - 1u] == '\r' || (length[f] > 0 && raw[quality_end - 1u] == '\r');
+            // the name up to the first blank (kseq), the same in every file (read.h:253-264)
+            uint32_t name_end = header_at + 1u;
+            while(name_end < header_end && raw[name_end] != ' ' && raw[name_end] != '\t') { ++name_end; }
+            if(f == 0) { first_name_at = header_at + 1u; first_name_size = name_end - header_at - 1u; }
+            else {
+                bool same = name_end - header_at - 1u == first_name_size;
+                const uint8_t* const first_raw = args.chunk[0].raw;
+                for(uint32_t k = 0; same && k < first_name_size; ++k) { same = raw[header_at + 1u + k] == first_raw[first_name_at + k]; }
+                odd = odd || !same;
+            }
+            // the Illumina comment `segment:filtered:control:barcode` of the leading segment (fastq.h:253-285)
+            if(f == plan.leader_feed && plan.illumina_comment) {
+                uint32_t p = name_end < header_end ? name_end + 1u : header_end;
+                while(p < header_end && raw[p] != ':') { ++p; }
+                if(p + 1u < header_end) { filtered = raw[p + 1u] == 'Y'; }
+            }
+        }
+        if(odd) { atomicOr(args.irregular, 1u); }
+        // Rule::apply of every decoder into its plane (transform.h:142-169), zero filled past what the tokens bring
+        for(int k = 0; k < plan.n_decoder; ++k) {
+            const FastqDecoderPlan& d = plan.decoder[k];
+            if(d.plane_stride == 0) { continue; }
+            uint8_t* const row_code = args.base_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(r) * d.plane_stride;
+            uint8_t* const row_quality = args.quality_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(r) * d.plane_stride;
+            for(int w = 0; w < d.plane_stride / 4; ++w) {
+                reinterpret_cast<uint32_t*>(row_code)[w] = 0u;
+                reinterpret_cast<uint32_t*>(row_quality)[w] = 0u;
+            }
+            int32_t filled[DEV_MAX_SEGMENT] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for(int t = d.first_token; t < d.first_token + d.n_token; ++t) {
+                const FastqToken& token = plan.token[t];
+                const int32_t from_length = static_cast<int32_t>(length[token.feed]);
+                int32_t start = token.start;                                   // Token::absolute_start, transform.h:73-80
+                if(start < 0) { start = from_length + start; start = start < 0 ? 0 : start; }
+                else if(start > from_length) { start = 0; }
+                int32_t end = from_length;                                     // Token::absolute_end, transform.h:65-72
+                if(token.end_terminated) {
+                    if(token.end < 0) { end = from_length + token.end; end = end < 0 ? 0 : end; }
+                    else { end = token.end > from_length ? from_length : token.end; }
+                }
+                const int32_t size = end - start;
+                if(size <= 0 || odd) { continue; }
+                int32_t& done = filled[token.output_segment];
+                const int32_t room = token.output_room - done;
+                const int32_t take = size < room ? size : room;
+                const uint8_t* const raw = args.chunk[token.feed].raw;
+                for(int32_t j = 0; j < take; ++j) {
+                    const int32_t from = token.reverse_complement ? end - j - 1 : start + j;
+                    uint8_t code = args.bam_of_ascii[raw[sequence_at[token.feed] + static_cast<uint32_t>(from)]];
+                    if(token.reverse_complement) { code = args.complement_of_bam[code & 15u]; }
+                    row_code[token.output_offset + done + j] = code;
+                    row_quality[token.output_offset + done + j] = static_cast<uint8_t>(raw[quality_at[token.feed] + static_cast<uint32_t>(from)] - plan.phred_offset);
+                }
+                done += take > 0 ? take : 0;
+            }
+        }
+        args.flag[r] = filtered ? 1 : 0;
+        const unsigned long long marked = __ballot(filtered);
+        if(marked && (threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(marked)) - 1)) { atomicAdd(args.flagged, static_cast<unsigned long long>(__popcll(marked))); }
+    }
+}
+
+}  // namespace
+
+int fastq_index(const FastqFeedChunk& chunk, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t units = (chunk.bytes + 15u) / 16u;
+    const uint32_t blocks = (units + TILE_THREADS - 1) / TILE_THREADS;
+    if(blocks > 0) { hipLaunchKernelGGL(fastq_count_kernel, dim3(blocks), dim3(TILE_THREADS), 0, s, chunk.raw, chunk.bytes, chunk.block_count); }
+    hipLaunchKernelGGL(fastq_scan_kernel, dim3(1), dim3(1024), 0, s, chunk.block_count, blocks, chunk.total);
+    if(blocks > 0) { hipLaunchKernelGGL(fastq_scatter_kernel, dim3(blocks), dim3(TILE_THREADS), 0, s, chunk.raw, chunk.bytes, chunk.block_count, chunk.newline, chunk.newline_capacity); }
+    return static_cast<int>(hipGetLastError());
+}
+
+int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capacity, FastqRound* round_on_device, void* stream) {
+    PlanArgs args;
+    for(int f = 0; f < n_feed && f < FASTQ_MAX_FEED; ++f) { args.chunk[f] = chunk[f]; }
+    args.n_feed = n_feed;
+    args.capacity = capacity;
+    args.round = round_on_device;
+    hipLaunchKernelGGL(fastq_plan_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), args);
+    return static_cast<int>(hipGetLastError());
+}
+
+int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, void* stream) {
+    if(n == 0) { return 0; }
+    static DecodeArgs args;                  // filled per call; the tables once
+    static bool tables = false;
+    if(!tables) {
+        for(int c = 0; c < 256; ++c) { args.bam_of_ascii[c] = ascii_to_bam(static_cast<uint8_t>(c)); }
+        for(int c = 0; c < 16; ++c) { args.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c)); }
+        tables = true;
+    }
+    DecodeArgs call = args;
+    call.plan = plan;
+    for(int f = 0; f < plan.n_feed; ++f) { call.chunk[f] = chunk[f]; }
+    call.n = n;
+    call.capacity = capacity;
+    call.base_planes = base_planes;
+    call.quality_planes = quality_planes;
+    call.flag = flag;
+    call.irregular = irregular;
+    call.flagged = flagged;
+    const uint32_t blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(fastq_decode_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, static_cast<hipStream_t>(stream), call);
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace phq

@@ -1,0 +1,77 @@
+// FASTQ text -> decoder planes ON THE DEVICE, for runs that write nothing (report only: every
+// output /dev/null, reference feed.h:105 NullFeed — the workload of docs/illumina_api_vignette.md's prior estimation).
+//
+//   reference fastq.h:55-78      FastqRecord::decode: ASCII -> BAM code, quality - phred offset
+//   reference fastq.h:253-285    the Illumina comment's filter flag
+//   reference read.h:253-264     Read::validate: every segment of a read carries the same identifier
+//   reference transform.h:142-169, 65-80   Rule::apply, Token::absolute_start / absolute_end
+//
+// The host threads only move raw file bytes into a pinned buffer; kernels find the line ends, check the framing of every
+// record, compare the names across the input files, read the filter flag and cut the decoders' tokens straight into the
+// observation planes phq_classify_device takes.  Anything out of the ordinary — a record that is not framed by '@' and
+// '+', a carriage return, a blank line, names out of sync, sequence and quality of different lengths — raises a flag and
+// the caller runs the input through the host reader instead, which tolerates or reports it exactly as the reference does.
+#pragma once
+
+#include <cstdint>
+
+namespace phq {
+
+constexpr int FASTQ_MAX_FEED = 8;
+constexpr int FASTQ_MAX_TOKEN = 64;
+constexpr int FASTQ_MAX_DECODER = 16;
+
+struct FastqToken {                 // one token of a decoder's transform (TransformConfig), resolved against the plan
+    int32_t feed;                   // input file
+    int32_t start;
+    int32_t end;
+    int32_t end_terminated;
+    int32_t reverse_complement;
+    int32_t output_offset;          // segment_offset of the token's output segment inside the decoder's observation
+    int32_t output_room;            // barcode_length of that output segment
+    int32_t output_segment;
+};
+
+struct FastqDecoderPlan {
+    int32_t plane_prefix;
+    int32_t plane_stride;
+    int32_t first_token;
+    int32_t n_token;
+};
+
+struct FastqPlan {
+    int32_t n_feed;
+    int32_t n_decoder;
+    int32_t leader_feed;            // whose comment carries the filter flag
+    int32_t phred_offset;
+    int32_t illumina_comment;
+    FastqDecoderPlan decoder[FASTQ_MAX_DECODER];
+    FastqToken token[FASTQ_MAX_TOKEN];
+};
+
+// what the planning kernel leaves for the host after a round's chunks are indexed
+struct FastqRound {
+    uint32_t lines[FASTQ_MAX_FEED];          // complete lines found in the feed's chunk
+    uint32_t consumed[FASTQ_MAX_FEED];       // bytes of the chunk the round's records take
+    uint32_t records;                        // records every feed holds, at most the batch capacity
+    uint32_t irregular;                      // a feed's newline index overflowed (lines shorter than any FASTQ has)
+};
+
+struct FastqFeedChunk {
+    const uint8_t* raw;             // device: the chunk's bytes, zero padded to a multiple of 16
+    uint32_t bytes;
+    uint32_t* newline;              // device: offsets of the chunk's newlines, in order
+    uint32_t newline_capacity;
+    uint32_t* block_count;          // device: scratch, one word per 4 KiB of the chunk (+ 1)
+    uint32_t* total;                // device: number of newlines found
+};
+
+// every function returns a hipError_t value; all work goes to `stream`
+int fastq_index(const FastqFeedChunk& chunk, void* stream);
+int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capacity, FastqRound* round_on_device, void* stream);
+// records [0, n) of the round -> planes laid out for `capacity` reads; *irregular |= 1 on anything out of the ordinary;
+// *flagged += reads whose filter flag is set
+int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, void* stream);
+
+}  // namespace phq

@@ -16,8 +16,10 @@
 //
 // Out of scope here: BAM/CRAM (htslib), bz2 / xz, QC histograms.
 #include "transcoder.hpp"
+#include "fastq_device.hpp"
 
 #include <fcntl.h>
+#include <hip/hip_runtime_api.h>
 #include <immintrin.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -25,6 +27,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cstdio>
 #include <chrono>
@@ -111,7 +114,14 @@ public:
     }
     ~FastqStream() {
         if(file_) { gzclose(file_); }
-        if(map_) { ::munmap(const_cast<char*>(map_), map_size_); }
+        // unmapping hundreds of megabytes is page table work in the kernel (26 ms after 4 M reads: a fifth of a report only
+        // run of that size): it is left to a thread of its own, the call does not wait for it
+        if(map_) {
+            char* const address = const_cast<char*>(map_);
+            const size_t size = map_size_;
+            try { std::thread([address, size]() { ::munmap(address, size); }).detach(); }
+            catch(...) { ::munmap(address, size); }
+        }
     }
     bool mapped() const { return map_ != nullptr; }
     FastqStream(const FastqStream&) = delete;
@@ -692,8 +702,11 @@ struct Transcoder::Impl {
     Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
         for(auto& s : sink) { s.close(); }      // the staging planes belong to the set (DecoderSet::host_stage)
-        // what follows by itself — unmapping the input files and the batches' buffers — is page table work in the kernel:
-        // 26 + 17 ms after 4 M reads (a third of a report only run of that size); threads do not help, unmapping serialises
+        // giving the batches' buffers back (and, in ~FastqStream, unmapping the input files) is page table work in the kernel:
+        // 17 + 26 ms after 4 M reads, a third of a report only run of that size.  Both go to threads of their own.
+        auto* const doomed = new std::pair<std::vector<SegmentBatch>, std::vector<SegmentBatch>>(std::move(batch), std::move(ahead));
+        try { std::thread([doomed]() { delete doomed; }).detach(); }
+        catch(...) { delete doomed; }
     }
 };
 
@@ -735,6 +748,237 @@ Transcoder::Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch
 Transcoder::~Transcoder() { delete impl_; }
 
 void Transcoder::set_classifier(Classifier classifier) { impl_->classifier = std::move(classifier); }
+
+
+// ---- report only runs: FASTQ text decoded on the device (fastq_device.hpp) ---------------------------------------------
+namespace {
+
+// what a set keeps from one report only run to the next: pinning and allocating these costs more than a small run
+struct DeviceFastqCache {
+    size_t raw_bytes[FASTQ_MAX_FEED] = {0};
+    uint8_t* pinned[FASTQ_MAX_FEED] = {nullptr};
+    uint8_t* raw[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
+    uint32_t* newline[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
+    uint32_t* block_count[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
+    uint32_t* total = nullptr;                     // [2][FASTQ_MAX_FEED] device words
+    FastqRound* round_device = nullptr;
+    FastqRound* round_host = nullptr;              // pinned
+    uint32_t* irregular = nullptr;                 // device
+    unsigned long long* flagged = nullptr;         // device
+    uint64_t* counters_before = nullptr;           // device: the counter buffer when the run began
+    int64_t capacity = 0;
+    uint8_t* base = nullptr;
+    uint8_t* quality = nullptr;
+    uint8_t* flag = nullptr;
+    DevResult* result = nullptr;
+    uint32_t* word = nullptr;
+    hipStream_t stream = nullptr;
+    ~DeviceFastqCache() {
+        for(int f = 0; f < FASTQ_MAX_FEED; ++f) {
+            if(pinned[f]) { (void)hipHostFree(pinned[f]); }
+            for(int s = 0; s < 2; ++s) { (void)hipFree(raw[s][f]); (void)hipFree(newline[s][f]); (void)hipFree(block_count[s][f]); }
+        }
+        (void)hipFree(total); (void)hipFree(round_device); (void)hipFree(irregular); (void)hipFree(flagged); (void)hipFree(counters_before);
+        if(round_host) { (void)hipHostFree(round_host); }
+        (void)hipFree(base); (void)hipFree(quality); (void)hipFree(flag); (void)hipFree(result); (void)hipFree(word);
+        if(stream) { (void)hipStreamDestroy(stream); }
+    }
+};
+
+void device_check(hipError_t status, const char* what) {
+    if(status != hipSuccess) { throw InternalError(std::string(what) + ": " + hipGetErrorString(status)); }
+}
+
+struct PlainFile {
+    int descriptor = -1;
+    size_t size = 0;
+    size_t position = 0;
+    double bytes_per_record = 0;
+    ~PlainFile() { if(descriptor >= 0) { ::close(descriptor); } }
+};
+
+}  // namespace
+
+// true: the whole input went through the device path; false: the run has to go through the host reader (nothing counted)
+bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
+    Impl& m = *impl_;
+    const JobConfig& job = m.set.job();
+    const TranscodePlan& plan = m.plan;
+    const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
+    if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return false; }
+    if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return false; }
+    // what the device path does not do: interleaved files, the pre-filters of Transcode::pull (transcode.h:193-205)
+    if(job.filter_incoming_qc_fail) { return false; }
+    for(size_t s = 1; s < job.min_input_length.size(); ++s) { if(job.min_input_length[s] > 0) { return false; } }
+    for(const auto& feed : plan.input_feed) { if(feed.resolution != 1) { return false; } }
+    FastqPlan device_plan;
+    std::memset(&device_plan, 0, sizeof(device_plan));
+    device_plan.n_feed = n_feed;
+    device_plan.n_decoder = static_cast<int32_t>(job.decoder.size());
+    device_plan.leader_feed = plan.input_segment[static_cast<size_t>(job.leading_segment_index)].first;
+    device_plan.phred_offset = job.input_phred_offset;
+    device_plan.illumina_comment = (job.platform == "ILLUMINA" || job.platform == "ELEMENT") ? 1 : 0;
+    int32_t n_token = 0;
+    for(size_t k = 0; k < job.decoder.size(); ++k) {
+        const DecoderConfig& d = job.decoder[k];
+        FastqDecoderPlan& to = device_plan.decoder[k];
+        to.plane_prefix = d.plane_prefix;
+        to.plane_stride = d.plane_stride;
+        to.first_token = n_token;
+        for(const auto& t : d.transform) {
+            if(n_token >= FASTQ_MAX_TOKEN || t.input_segment_index < 0 || t.input_segment_index >= static_cast<int32_t>(plan.input_segment.size()) ||
+               t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return false; }
+            FastqToken& token = device_plan.token[n_token++];
+            token.feed = plan.input_segment[static_cast<size_t>(t.input_segment_index)].first;
+            token.start = t.start;
+            token.end = t.end;
+            token.end_terminated = t.end_terminated ? 1 : 0;
+            token.reverse_complement = t.reverse_complement ? 1 : 0;
+            token.output_offset = d.segment_offset[static_cast<size_t>(t.output_segment_index)];
+            token.output_room = d.barcode_length[static_cast<size_t>(t.output_segment_index)];
+            token.output_segment = t.output_segment_index;
+        }
+        to.n_token = n_token - to.first_token;
+    }
+    // plain regular files only (gzip members go through the host reader)
+    std::vector<PlainFile> file(static_cast<size_t>(n_feed));
+    for(int32_t f = 0; f < n_feed; ++f) {
+        PlainFile& p = file[static_cast<size_t>(f)];
+        p.descriptor = ::open(plan.input_feed[static_cast<size_t>(f)].path.c_str(), O_RDONLY);
+        if(p.descriptor < 0) { return false; }
+        struct stat status;
+        if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return false; }
+        p.size = static_cast<size_t>(status.st_size);
+        char head[1 << 16];
+        const ssize_t got = ::pread(p.descriptor, head, sizeof(head), 0);
+        if(got < 4 || (static_cast<unsigned char>(head[0]) == 0x1f && static_cast<unsigned char>(head[1]) == 0x8b) || head[0] != '@') { return false; }
+        size_t lines = 0;
+        for(ssize_t k = 0; k < got; ++k) { lines += head[k] == '\n' ? 1 : 0; }
+        if(lines < 4) { return false; }
+        p.bytes_per_record = 4.0 * static_cast<double>(got) / static_cast<double>(lines);
+    }
+
+    device_check(hipSetDevice(m.set.device()), "hipSetDevice");
+    if(!m.set.device_fastq_cache) { m.set.device_fastq_cache = std::make_shared<DeviceFastqCache>(); }
+    DeviceFastqCache& c = *static_cast<DeviceFastqCache*>(m.set.device_fastq_cache.get());
+    if(c.stream == nullptr) { device_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate"); }
+    // records per round: the batch capacity, in chunks of at most 192 MiB of text per file
+    const int64_t capacity = std::max<int64_t>(1 << 12, std::min<int64_t>(m.capacity, int64_t(1) << 22));
+    if(c.capacity < capacity) {
+        (void)hipFree(c.base); (void)hipFree(c.quality); (void)hipFree(c.flag); (void)hipFree(c.result); (void)hipFree(c.word);
+        c.base = c.quality = c.flag = nullptr; c.result = nullptr; c.word = nullptr; c.capacity = 0;
+        const size_t planes = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.plane_width, 4));
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.base), planes), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.quality), planes), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.flag), static_cast<size_t>(capacity)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.result), static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.word), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
+        c.capacity = capacity;
+    }
+    if(c.total == nullptr) {
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.total), 2 * FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.round_device), sizeof(FastqRound)), "hipMalloc");
+        device_check(hipHostMalloc(reinterpret_cast<void**>(&c.round_host), sizeof(FastqRound), hipHostMallocDefault), "hipHostMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.irregular), sizeof(uint32_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.flagged), sizeof(unsigned long long)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.counters_before), static_cast<size_t>(job.stats_words) * sizeof(uint64_t)), "hipMalloc");
+    }
+    size_t chunk_bytes[FASTQ_MAX_FEED];
+    for(int32_t f = 0; f < n_feed; ++f) {
+        const double wanted = static_cast<double>(capacity) * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;
+        chunk_bytes[f] = static_cast<size_t>(std::min(wanted, 192.0 * 1048576.0));
+        chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1);
+        chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
+        if(c.raw_bytes[f] < chunk_bytes[f]) {
+            if(c.pinned[f]) { (void)hipHostFree(c.pinned[f]); c.pinned[f] = nullptr; }
+            for(int s = 0; s < 2; ++s) { (void)hipFree(c.raw[s][f]); (void)hipFree(c.newline[s][f]); (void)hipFree(c.block_count[s][f]); c.raw[s][f] = nullptr; c.newline[s][f] = nullptr; c.block_count[s][f] = nullptr; }
+            c.raw_bytes[f] = 0;
+            device_check(hipHostMalloc(reinterpret_cast<void**>(&c.pinned[f]), chunk_bytes[f] + 16, hipHostMallocDefault), "hipHostMalloc");
+            for(int s = 0; s < 2; ++s) {
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.raw[s][f]), chunk_bytes[f] + 16), "hipMalloc");
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.newline[s][f]), (chunk_bytes[f] / 8 + 1024) * sizeof(uint32_t)), "hipMalloc");
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.block_count[s][f]), (chunk_bytes[f] / 4096 + 2) * sizeof(uint32_t)), "hipMalloc");
+            }
+            c.raw_bytes[f] = chunk_bytes[f];
+        }
+    }
+    hipStream_t stream = c.stream;
+    // the counter buffer as it is now: a run that turns out to need the host reader starts over from it
+    device_check(hipMemcpyAsync(c.counters_before, m.set.stats_device_pointer(), static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
+    device_check(hipMemsetAsync(c.irregular, 0, sizeof(uint32_t), stream), "hipMemsetAsync");
+    device_check(hipMemsetAsync(c.flagged, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
+    auto give_up = [&]() {
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(m.set.stats_device_pointer(), c.counters_before, static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+        return false;
+    };
+    uint64_t reads = 0;
+    int slot = 0;
+    const int threads = host_threads();
+    while(true) {
+        bool any_left = false;
+        FastqFeedChunk chunk[FASTQ_MAX_FEED];
+        for(int32_t f = 0; f < n_feed; ++f) {
+            PlainFile& p = file[static_cast<size_t>(f)];
+            const size_t left = p.size - p.position;
+            size_t bytes = std::min(left, chunk_bytes[f] - 1);
+            any_left = any_left || left > 0;
+            // the file's bytes into the pinned buffer, on every host thread
+            uint8_t* const to = c.pinned[f];
+            std::atomic<bool> failed{false};
+            parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
+                const size_t from = static_cast<size_t>(first) << 20;
+                const size_t until = std::min(bytes, static_cast<size_t>(last) << 20);
+                size_t done = from;
+                while(done < until) {
+                    const ssize_t got = ::pread(p.descriptor, to + done, until - done, static_cast<off_t>(p.position + done));
+                    if(got <= 0) { failed = true; return; }
+                    done += static_cast<size_t>(got);
+                }
+            });
+            if(failed) { return give_up(); }
+            if(bytes == left && bytes > 0 && to[bytes - 1] != '\n') { to[bytes++] = '\n'; }      // the last line of a file may lack its newline
+            std::memset(to + bytes, 0, 16);
+            device_check(hipMemcpyAsync(c.raw[slot][f], to, bytes + 16, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            chunk[f].raw = c.raw[slot][f];
+            chunk[f].bytes = static_cast<uint32_t>(bytes);
+            chunk[f].newline = c.newline[slot][f];
+            chunk[f].newline_capacity = static_cast<uint32_t>(chunk_bytes[f] / 8 + 1024);
+            chunk[f].block_count = c.block_count[slot][f];
+            chunk[f].total = c.total + slot * FASTQ_MAX_FEED + f;
+            device_check(static_cast<hipError_t>(fastq_index(chunk[f], stream)), "fastq_index");
+        }
+        if(!any_left) { break; }
+        device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
+        device_check(hipMemcpyAsync(c.round_host, c.round_device, sizeof(FastqRound), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // the pinned buffers are free again, the round is known
+        const FastqRound round = *c.round_host;
+        if(round.irregular) { return give_up(); }
+        if(round.records == 0) {
+            // not one whole record in a chunk: a record longer than a chunk, a truncated file, files of different lengths —
+            // the host reader says which
+            return give_up();
+        }
+        for(int32_t f = 0; f < n_feed; ++f) {
+            PlainFile& p = file[static_cast<size_t>(f)];
+            p.position += round.consumed[f];
+            if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
+        }
+        device_check(static_cast<hipError_t>(fastq_decode(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged, stream)), "fastq_decode");
+        m.set.classify_device(c.capacity, 0, round.records, c.base, c.quality, c.flag, c.result, c.word, stream);
+        reads += round.records;
+        slot ^= 1;
+    }
+    uint32_t irregular = 0;
+    unsigned long long flagged = 0;
+    device_check(hipMemcpyAsync(&irregular, c.irregular, sizeof(irregular), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    device_check(hipMemcpyAsync(&flagged, c.flagged, sizeof(flagged), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if(irregular) { return give_up(); }
+    incoming_count += reads;                                                      // transcode.cpp:304-309
+    incoming_pf_count += reads - flagged;
+    return true;
+}
 
 void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     Impl& m = *impl_;
@@ -796,6 +1040,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         channel_silent[c] = silent ? 1 : 0;
         all_silent = all_silent && silent;
     }
+    // nothing is written: the FASTQ text is decoded on the device when it can be (plain files, no pre-filters); a file that
+    // holds anything out of the ordinary sends the whole run through the host reader below
+    if(all_silent && run_on_device(incoming_count, incoming_pf_count)) { return; }
     const DecoderConfig* const multiplexer = job.multiplexing_decoder >= 0 ? &job.decoder[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
     const std::vector<int>* const multiplexer_ordinal = multiplexer ? &ordinal_by_index[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
 
@@ -819,16 +1066,21 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         if(all_silent) { break; }                 // nothing is written: no feed needs its printable text
         if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].text = true; }
     }
-    auto start_readers = [&](std::vector<SegmentBatch>& into) {
+    // the first batches are short ones, doubling up to the capacity: nothing else can start before the first batch is read
+    // (a full first batch of a million records cost a third of a 4 M read report only run), and the staging planes are laid
+    // out for the capacity whatever a batch holds
+    int64_t requested = std::min<int64_t>(m.capacity, int64_t(1) << 16);     // records asked of the batch in work
+    int64_t requested_ahead = requested;                                      // ... and of the one being read
+    auto start_readers = [&](std::vector<SegmentBatch>& into, int64_t records) {
         std::vector<std::thread> readers;
         for(int32_t f = 0; f < n_feed; ++f) {
-            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(f)]), m.capacity * plan.input_feed[static_cast<size_t>(f)].resolution,
+            readers.emplace_back(read_segment_batch, std::ref(*m.stream[static_cast<size_t>(f)]), records * plan.input_feed[static_cast<size_t>(f)].resolution,
                                  job.input_phred_offset, parse_threads, needs[static_cast<size_t>(f)], std::ref(into[static_cast<size_t>(f)]));
         }
         return readers;
     };
     {
-        auto readers = start_readers(m.batch);
+        auto readers = start_readers(m.batch, requested);
         for(auto& t : readers) { t.join(); }
     }
     const double first_read_end = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -886,10 +1138,13 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             if(v.size() != n_read) { throw SequenceError("input files hold different numbers of records"); }
         }
         if(n_read == 0) { break; }
-        const bool last_batch = n_read < m.capacity;
+        const bool last_batch = n_read < requested;
         std::vector<std::thread> readers;
         struct Joiner { std::vector<std::thread>& threads; ~Joiner() { for(auto& t : threads) { if(t.joinable()) { t.join(); } } } } joiner{readers};
-        if(!last_batch) { readers = start_readers(ahead); }
+        if(!last_batch) {
+            requested_ahead = std::min<int64_t>(m.capacity, requested * 4);
+            readers = start_readers(ahead, requested_ahead);
+        }
         // Read::validate (read.h:253-264): every segment of a read carries the same identifier
         if(n_segment > 1) {
             try {
@@ -1159,6 +1414,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& t : readers) { t.join(); }
         lap(5);
         m.batch.swap(ahead);
+        requested = requested_ahead;
     }
     for(auto& sink : m.sink) { sink.close(); }
     if(trace) {

@@ -57,6 +57,7 @@ public:
 private:
     struct Impl;
     Impl* impl_;
+    bool run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count);      // report only runs: fastq_device.hpp
 };
 
 }  // namespace phq
