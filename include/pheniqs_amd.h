@@ -290,6 +290,19 @@ void phq_free_string(char* text);
  * Release `*adjusted_json` with phq_free_string. */
 int phq_adjust_prior(phq_decoder_set* set, const uint64_t* host_words, const char* job_json, char** adjusted_json);
 
+/* Quality control accumulators of the output reads (reference multiplex.h:28-181): when the job sets `enable quality
+ * control`, phq_transcode_fastq_to_sam / phq_transcode_job count every output segment of every read by channel, cycle,
+ * nucleotide and quality — one private copy per record thread, merged at the end of the run as Multiplexer::collect does
+ * (multiplex.cpp:405-411) — and phq_report_json adds the report's "multiplex" array (multiplex.cpp:419-431).
+ * phq_stats_reset clears them with the counters.  To merge several sets or processes (the reference's per thread merge,
+ * transcode.cpp:319): phq_qc_export writes a flat image — {channels, segments}, then per channel and segment {cycles,
+ * shortest, nucleotide counts[16], mean quality count, sum (2^-24 fixed point), max (a double's bits), distribution[42],
+ * cycles x 16 x 42 counts} — and returns its size in words in *n_words (call with words == NULL to ask for the size);
+ * phq_qc_merge adds such an image to the set's (counts add, shortest / max take the min / max).  A plain SUM all-reduce
+ * does NOT merge an image (two of its fields are a min and a max): gather the images and merge them on one rank. */
+int phq_qc_export(phq_decoder_set* set, uint64_t* words, int64_t capacity_words, int64_t* n_words);
+int phq_qc_merge(phq_decoder_set* set, const uint64_t* words, int64_t n_words);
+
 /* SHA-256 (hex) over the sources this library was built from (the .cpp, .hip and .hpp files of pheniqs_amd/csrc, its Makefile and
  * this header, sorted by name): ties a measurement or a committed profile summary to a build.  No reference counterpart
  * (the reference prints its version from version.h through `pheniqs --version`, interface.cpp). */

@@ -27,7 +27,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
            "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
-           "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id")
+           "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
 class PheniqsError(RuntimeError):
@@ -108,6 +108,8 @@ def load_library():
     L.phq_free_string.argtypes = [P]
     L.phq_free_string.restype = None
     L.phq_adjust_prior.argtypes = [P, P, ctypes.c_char_p, ctypes.POINTER(P)]
+    L.phq_qc_export.argtypes = [P, P, I64, ctypes.POINTER(I64)]
+    L.phq_qc_merge.argtypes = [P, P, I64]
     L.phq_build_id.argtypes = []
     L.phq_build_id.restype = ctypes.c_char_p
     _library = L
@@ -369,6 +371,18 @@ class DecoderSet:
         confidence = np.zeros((n, 3), dtype=np.float64)
         self._check(self.lib.phq_summarize(self.handle, capacity, n, result.ctypes.data, distance.ctypes.data, confidence.ctypes.data))
         return distance, confidence
+
+    def qc_export(self) -> np.ndarray:
+        """phq_qc_export: the flat image of the quality control accumulators (empty shape when the job has them off)."""
+        n = ctypes.c_int64(0)
+        self._check(self.lib.phq_qc_export(self.handle, None, 0, ctypes.byref(n)))
+        words = np.zeros(max(1, n.value), dtype=np.uint64)
+        self._check(self.lib.phq_qc_export(self.handle, words.ctypes.data, n.value, ctypes.byref(n)))
+        return words[:n.value]
+
+    def qc_merge(self, words: np.ndarray):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        self._check(self.lib.phq_qc_merge(self.handle, words.ctypes.data, words.size))
 
     def stats_allreduce(self, rccl_comm: int, stream: int = 0):
         self._check(self.lib.phq_stats_allreduce(self.handle, rccl_comm, stream or None))

@@ -363,6 +363,25 @@ int phq_format_double(double value, int32_t precision, char* buffer, int32_t cap
     });
 }
 
+int phq_qc_export(phq_decoder_set* set, uint64_t* words, int64_t capacity_words, int64_t* n_words) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(n_words, "n_words");
+        const std::vector<uint64_t> image = set->impl.quality_control().to_words();
+        *n_words = static_cast<int64_t>(image.size());
+        if(words == nullptr) { return; }
+        if(capacity_words < *n_words) { throw phq::OverflowError("buffer too small for the quality control image"); }
+        std::memcpy(words, image.data(), image.size() * sizeof(uint64_t));
+    });
+}
+
+int phq_qc_merge(phq_decoder_set* set, const uint64_t* words, int64_t n_words) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(words, "words");
+        if(n_words < 2) { throw phq::InternalError("quality control image too short"); }
+        set->impl.quality_control_merge(phq::QcState::from_words(words, static_cast<size_t>(n_words)));
+    });
+}
+
 const char* phq_build_id(void) {
     static const char id[] =
 #include "build/build_id.inc"

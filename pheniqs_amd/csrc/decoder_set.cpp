@@ -1187,6 +1187,7 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
 // ---- statistics ----------------------------------------------------------------------------------------
 
 void DecoderSet::stats_reset(void* stream) {
+    qc_ = QcState();                       // the quality control accumulators go with the counters
     require_device();
     check(hipMemsetAsync(device_stats_, 0, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t), static_cast<hipStream_t>(stream)), "hipMemsetAsync");
 }
@@ -1293,8 +1294,16 @@ void DecoderSet::summarize(int64_t batch_capacity, int64_t n_read, const DevResu
 }
 
 const std::string& DecoderSet::report_json(const uint64_t* host_words, uint64_t incoming_count, uint64_t incoming_pf_count) {
-    report_ = encode_report(job_, host_words, incoming_count, incoming_pf_count).dump(job_.float_precision);
+    Json report = encode_report(job_, host_words, incoming_count, incoming_pf_count);
+    if(job_.enable_quality_control) {                                          // transcode.cpp:1830-1833, multiplex.cpp:419-431
+        if(qc_.empty()) { qc_.shape(job_.multiplexing_decoder >= 0 ? static_cast<int32_t>(job_.decoder[static_cast<size_t>(job_.multiplexing_decoder)].codec.size()) + 1 : 1, job_.output_segment_cardinality); }
+        report.set("multiplex", qc_.encode());
+        report.sort_keys();
+    }
+    report_ = report.dump(job_.float_precision);
     return report_;
 }
+
+void DecoderSet::quality_control_merge(const QcState& other) { qc_.merge(other); }
 
 }  // namespace phq

@@ -13,6 +13,7 @@
 
 #include "device_types.hpp"
 #include "job.hpp"
+#include "qc.hpp"
 #include "json.hpp"
 
 namespace phq {
@@ -58,10 +59,15 @@ public:
     void profile_enable(bool enable);
     void profile_collect(double* milliseconds, int64_t* launches);
 
+    // quality control accumulators of the output reads (qc.hpp), filled by the transcoder's record threads when the job
+    // enables them; cleared with the counters (stats_reset), merged across sets or processes through their flat image
+    QcState& quality_control() { return qc_; }
+    void quality_control_merge(const QcState& other);
     std::string last_error;
     std::shared_ptr<void> device_fastq_cache;      // transcoder.cpp: the buffers of the device FASTQ path, kept from run to run
 
 private:
+    QcState qc_;
     void require_device() const;
     void run_stages(int64_t batch_capacity, int64_t first_read, int64_t n_read,
                     const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,

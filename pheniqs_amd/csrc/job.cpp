@@ -235,6 +235,7 @@ DecoderConfig parse_decoder(const Json& node, Kind kind) {
     d.algorithm = parse_algorithm(node, kind);
     d.index = get_int(node, "index");
     d.multiplexing_classifier = get_bool(node, "multiplexing classifier", false);
+    d.enable_quality_control = get_bool(node, "enable quality control", false);
     d.corrected_quality = get_int(node, "corrected quality", 30);
 
     const Json* undetermined = node.find("undetermined");
@@ -370,6 +371,7 @@ JobConfig JobConfig::from_json(const Json& document) {
     job.platform = "ILLUMINA";
     if(const Json* platform = document.find("platform")) { if(platform->is_string()) { job.platform = platform->as_string(); } }
     job.multiplexing_decoder = -1;
+    job.enable_quality_control = get_bool(document, "enable quality control", false);
 
     int32_t multiplexing = 0;
     int32_t column = 0;
@@ -377,7 +379,11 @@ JobConfig JobConfig::from_json(const Json& document) {
     int32_t slot = 0;
     int64_t word = STAT_JOB_WORDS;
     for(auto& d : job.decoder) {
-        if(d.multiplexing_classifier) { ++multiplexing; job.multiplexing_decoder = static_cast<int32_t>(&d - job.decoder.data()); }
+        if(d.multiplexing_classifier) {
+            ++multiplexing;
+            job.multiplexing_decoder = static_cast<int32_t>(&d - job.decoder.data());
+            job.enable_quality_control = d.enable_quality_control;
+        }
         d.plane_stride = (d.nucleotide_cardinality + 3) / 4 * 4;
         d.plane_prefix = column;
         column += d.plane_stride;

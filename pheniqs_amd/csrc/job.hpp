@@ -58,6 +58,7 @@ struct DecoderConfig {
     Algorithm algorithm;
     int32_t index;                        // position inside its topic
     bool multiplexing_classifier;
+    bool enable_quality_control;          // multiplex.cpp:303,393: of the multiplexing decoder (inherited from the root by the compiler)
     int32_t corrected_quality;
     int32_t segment_cardinality;
     int32_t nucleotide_cardinality;
@@ -103,6 +104,7 @@ struct JobConfig {
     std::vector<std::string> output;       // root level fallback for a job without a multiplexing decoder
     std::string platform;                  // "ILLUMINA" by default (configuration.json:375): decides the FASTQ comment (fastq.h:176-194)
     int32_t multiplexing_decoder;          // position in `decoder`, -1 when none is marked
+    bool enable_quality_control;           // the multiplexer's (multiplex.cpp:393), the root's without one
 
     static JobConfig from_json(const Json& document);
 };

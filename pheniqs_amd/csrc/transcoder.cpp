@@ -808,7 +808,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return false; }
     if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return false; }
     // what the device path does not do: interleaved files, the pre-filters of Transcode::pull (transcode.h:193-205)
-    if(job.filter_incoming_qc_fail) { return false; }
+    if(job.filter_incoming_qc_fail || job.enable_quality_control) { return false; }      // (the accumulators count the output read's text: host side)
     for(size_t s = 1; s < job.min_input_length.size(); ++s) { if(job.min_input_length[s] > 0) { return false; } }
     for(const auto& feed : plan.input_feed) { if(feed.resolution != 1) { return false; } }
     FastqPlan device_plan;
@@ -1063,7 +1063,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         }
     }
     for(const auto& t : job.template_transform) {
-        if(all_silent) { break; }                 // nothing is written: no feed needs its printable text
+        if(all_silent && !job.enable_quality_control) { break; }                 // nothing is written or counted: no feed needs its printable text
         if(t.input_segment_index >= 0 && t.input_segment_index < n_segment) { needs[static_cast<size_t>(plan.input_segment[static_cast<size_t>(t.input_segment_index)].first)].text = true; }
     }
     // the first batches are short ones, doubling up to the capacity: nothing else can start before the first batch is read
@@ -1092,6 +1092,10 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         canonical_text[c] = bam_to_ascii(ascii_to_bam(static_cast<uint8_t>(c)));
     }
     const int workers = host_threads();
+    // quality control accumulators (qc.hpp): one private copy per record thread, merged into the set's at the end of the run
+    const bool quality_control = job.enable_quality_control;
+    std::vector<QcState> quality_by_part(quality_control ? static_cast<size_t>(workers) : 0);
+    for(auto& q : quality_by_part) { q.shape(static_cast<int32_t>(plan.channel.size()), job.output_segment_cardinality); }
     std::vector<ByteBuffer> part_text(static_cast<size_t>(workers) * static_cast<size_t>(n_sink));
     std::vector<ByteBuffer> part_packed(part_text.size());
     // the tokens of every output segment, the widest tag block, the flag column per (output segment, QC fail)
@@ -1192,7 +1196,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         // f2: records, a contiguous range of the batch per thread, written in order
         for(auto& text : part_text) { text.clear(); }
         for(auto& text : part_packed) { text.clear(); }
-        parallel_ranges(all_silent ? 0 : n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
+        parallel_ranges((all_silent && !quality_control) ? 0 : n_kept, 1 << 13, workers, [&](int64_t first_kept, int64_t last_kept, int part) {
+        QcState* const counted = quality_control ? &quality_by_part[static_cast<size_t>(part)] : nullptr;
+        std::vector<uint8_t> counted_code, counted_quality;
         ByteBuffer* const text_of_sink = &part_text[static_cast<size_t>(part) * static_cast<size_t>(n_sink)];
         Text raw[3], corrected[3];
         for(auto& t : raw) { t.allocate(barcode_capacity); }
@@ -1209,8 +1215,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 size_t early = 0;
                 if(res.index > 0 && static_cast<size_t>(res.index) < multiplexer_ordinal->size()) { early = static_cast<size_t>((*multiplexer_ordinal)[static_cast<size_t>(res.index)] + 1); }
                 if(early >= plan.channel.size()) { early = 0; }
-                if(channel_silent[early] || plan.channel[early].feed_by_segment.empty()) { continue; }
-            } else if(channel_silent[0]) { continue; }
+                if(!quality_control && (channel_silent[early] || plan.channel[early].feed_by_segment.empty())) { continue; }
+            } else if(!quality_control && channel_silent[0]) { continue; }
             uint32_t distance[3] = {0, 0, 0};
             double confidence[3] = {1, 1, 1};                               // read.h:176-183
             for(auto& t : raw) { t.clear(); }
@@ -1259,7 +1265,8 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             const bool qcfail = (m.word[k] >> 31) != 0;
             if(channel_index >= plan.channel.size()) { channel_index = 0; }
             const TranscodePlan::Channel& channel = plan.channel[channel_index];
-            if(channel.feed_by_segment.empty() || (channel.filter_outgoing_qc_fail && qcfail)) { continue; }
+            const bool written = !(channel.feed_by_segment.empty() || (channel.filter_outgoing_qc_fail && qcfail)) && !channel_silent[channel_index];
+            if(!written && !quality_control) { continue; }
 
             // TemplateRule::apply (transform.h:190-226): where every token's bases are
             for(size_t t = 0; t < job.template_transform.size(); ++t) {
@@ -1283,6 +1290,30 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 piece[t] = Piece{fc ? fc + start : nullptr, fq ? fq + start : nullptr, ft ? ft + start : nullptr, fqt ? fqt + start : nullptr,
                                  end - start > 0 ? end - start : 0, token.reverse_complement, lent, quality_shift};
             }
+            // Channel::push counts the read whether or not it is written (multiplex.h:219-221): BAM codes and Phred values of
+            // every output segment, as the reference's Segment holds them
+            if(counted != nullptr) {
+                for(int32_t o = 0; o < n_out; ++o) {
+                    counted_code.clear();
+                    counted_quality.clear();
+                    for(const int32_t t : token_of_output[static_cast<size_t>(o)]) {
+                        const Piece& p = piece[static_cast<size_t>(t)];
+                        for(int32_t i = 0; i < p.size; ++i) {
+                            const int32_t from = p.reverse_complement ? p.size - i - 1 : i;
+                            uint8_t code;
+                            uint8_t quality;
+                            if(p.text != nullptr) {
+                                code = ascii_to_bam(static_cast<uint8_t>(p.text[from]));
+                                quality = static_cast<uint8_t>(p.quality_text[from] - (p.lent ? job.input_phred_offset : job.output_phred_offset));
+                            } else { code = p.code[from]; quality = p.quality[from]; }
+                            counted_code.push_back(p.reverse_complement ? reverse_complement_bam(code) : code);
+                            counted_quality.push_back(quality);
+                        }
+                    }
+                    counted->at(static_cast<int32_t>(channel_index), o).increment(counted_code.data(), counted_quality.data(), static_cast<int32_t>(counted_code.size()));
+                }
+            }
+            if(!written) { continue; }
 
             // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
             char* tag_end = tags.data();
@@ -1417,6 +1448,11 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         requested = requested_ahead;
     }
     for(auto& sink : m.sink) { sink.close(); }
+    if(quality_control) {                                                      // Multiplexer::collect, multiplex.cpp:405-411
+        QcState total;
+        for(const auto& q : quality_by_part) { total.merge(q); }
+        m.set.quality_control_merge(total);
+    }
     if(trace) {
         std::fprintf(stderr, "transcode phases (s): first batch read %.3f | validate %.3f stage %.3f classify %.3f format %.3f write %.3f wait for readers %.3f | run %.3f\n",
                      first_read_end - run_begin, phase[0], phase[1], phase[2], phase[3], phase[4], phase[5], now() - run_begin);

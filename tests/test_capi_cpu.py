@@ -344,6 +344,7 @@ def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
     work.mkdir()
     spec = synthetic.config_spec("C2", "mdd")
     spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    spec["enable quality control"] = True                # the accumulators' hook in the record threads (qc.cpp) runs under the sanitizers too
     spec["base output url"] = str(work)
     for number, record in enumerate(spec["sample"]["codec"].values()):
         if number < 5:
