@@ -27,14 +27,16 @@ constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, hi
 // the bound, its counter bin (8 x 64 bits), padding to 11 quads.  STREAM_WAVES waves in its one workgroup per CU, each
 // with 8 KiB of per read tables and a 64 entry ring in LDS.  The LDS map in front of the blocks is fixed by the wave count
 // alone, so the host can put a block's LDS ADDRESS into the lookup table (stream_block_at).
-constexpr int STREAM_RECORD_WORDS = 44;
+// with priors that differ a block also holds the prior of each listed barcode over c's (16 floats; slot 0: the noise term
+// over c's prior) between the weights and the bin: 15 quads; and the codec's single precision priors sit behind its words
+constexpr int stream_record_words(bool priors) { return priors ? 60 : 44; }
 #ifndef PHQ_STREAM_WAVES
 #define PHQ_STREAM_WAVES 12
 #endif
 constexpr int STREAM_WAVES = PHQ_STREAM_WAVES;
-constexpr uint32_t stream_words_bytes(int n_barcode) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u; }
-constexpr uint32_t stream_block_at(int waves, int n_barcode) {
-    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 6u * 64u * 4u + stream_words_bytes(n_barcode);
+constexpr uint32_t stream_words_bytes(int n_barcode, bool priors) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u + (priors ? static_cast<uint32_t>((n_barcode + 7) & ~7) * 4u : 0u); }
+constexpr uint32_t stream_block_at(int waves, int n_barcode, bool priors) {
+    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 6u * 64u * 4u + stream_words_bytes(n_barcode, priors);
 }
 constexpr uint32_t STREAM_UNKNOWN = 0x3fffu;   // the index field of a lookup that names no barcode
 constexpr int NEAR_MIN_LENGTH = 5;
@@ -141,9 +143,10 @@ struct DevDecoder {
     // stream_table[key], 65536 entries: key = bits 2..17 of the bit-sliced observation (positions 0..3: low code bits in
     // key bits 0..3, high code bits in 4..7; positions 4..7 in bits 8..15); an entry = the LDS address of the barcode's
     // block (18 bits) | barcode_index << 18, index field STREAM_UNKNOWN for a word that names none.  stream_record[c] =
-    // STREAM_RECORD_WORDS words, the image of the block: the listed barcodes two per word (the even one in the low half)
+    // stream_record_words(priors differ) words, the image of the block: the listed barcodes two per word (the even one in the low half)
     // as 8 low plane words then 8 high plane words, then how many barcodes that are not listed sit 3, 4, 5 and 6 or more
-    // mismatches from c (floats; infinite if one sits closer than 3), then zeros (the bin, padding)
+    // mismatches from c (floats; with priors that differ the sums of their priors over c's; infinite if one sits closer than 3),
+    // with priors that differ the 16 prior ratios of the listed barcodes (slot 0: the noise term over c's prior), then zeros (the bin, padding)
     const uint32_t* stream_table;
     const uint32_t* stream_record;
     int32_t stream_ready;

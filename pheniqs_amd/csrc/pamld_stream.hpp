@@ -41,10 +41,14 @@ constexpr int LIST = 16;                       // barcodes scored in pass A: c a
 // a barcode's block in LDS: its list — 8 low plane words, 8 high plane words (two listed barcodes per word) —, the weights
 // of the bound (how many barcodes that are not listed sit at distance 3, 4, 5 and 6 or more from it), then its counter
 // bin, then padding to a stride of 11 quads: an odd number, so the blocks start in all 16 quad places of the banks
-constexpr int BLOCK_WORDS = STREAM_RECORD_WORDS;
-constexpr uint32_t BLOCK_BYTES = BLOCK_WORDS * 4u;
-constexpr uint32_t WEIGHT_AT = 64;             // bytes into the block
-constexpr uint32_t BIN_AT = 80;
+template <bool PRIORS> struct Block {
+    static constexpr int WORDS = stream_record_words(PRIORS);
+    static constexpr uint32_t BYTES = WORDS * 4u;
+    static constexpr uint32_t WEIGHT_AT = 64;      // bytes into the block: the four weights of the bound
+    static constexpr uint32_t RATIO_AT = 80;       // PRIORS: the noise term over c's prior, then the prior of each listed barcode over c's
+    static constexpr uint32_t BIN_AT = PRIORS ? 144 : 80;
+    static constexpr int QUADS = PRIORS ? 9 : 5;   // what pass A reads of it
+};
 constexpr int RING = 64;                       // entries of a wave's ring
 constexpr int RING_PLANES = 6;                 // code word 0, 1, quality word 0, 1, carried state, ordinal
 // the workgroup histogram of this kernel, per bin and [qc fail | pass filter] half: {count | distance << 32,
@@ -55,7 +59,7 @@ constexpr int BIN_WORDS = 8;                   // words 0..3 the qc fail half, 4
 // 2^38 - round(y 2^38), formed from 32-bit integers and split into the buffer's two limbs
 constexpr int PASS_A_FRACTION_BITS = 38;
 
-template <int L, int WAVES> struct Shape {
+template <int L, int WAVES, bool PRIORS = false> struct Shape {
     static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
     static_assert(WAVES >= 2 && WAVES <= 16 && WAVES % 2 == 0, "pairs of waves share a 16 KiB block of tables");
     static constexpr int THREADS = 64 * WAVES;
@@ -65,11 +69,12 @@ template <int L, int WAVES> struct Shape {
     static constexpr uint32_t RING_AT = DOUBLE_AT + FACTOR_ROWS * 16;
     static constexpr uint32_t RING_BYTES = RING_PLANES * RING * 4;
     static constexpr uint32_t WORDS_AT = RING_AT + WAVES * RING_BYTES;        // pamld_lut.hpp's plane words of the codec
-    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return stream_words_bytes(n_barcode); }
+    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return stream_words_bytes(n_barcode, PRIORS); }
+    __host__ __device__ static constexpr uint32_t prior_at(int n_barcode) { return WORDS_AT + stream_words_bytes(n_barcode, false); }        // PRIORS: the codec's priors, single precision, padded to blocks of 8
     __host__ __device__ static constexpr uint32_t block_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }      // the barcodes' blocks
-    static_assert(WORDS_AT + stream_words_bytes(96) == stream_block_at(WAVES, 96), "the host puts block addresses into the lookup table");
+    static_assert(WORDS_AT + stream_words_bytes(96, PRIORS) == stream_block_at(WAVES, 96, PRIORS), "the host puts block addresses into the lookup table");
     // bin 0 (unclassified) and the two job words in front of it, behind the blocks
-    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * BLOCK_BYTES; }
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * Block<PRIORS>::BYTES; }
     __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + BIN_WORDS); }
     __host__ __device__ static constexpr int positions(int g) { return L - 4 * g >= 4 ? 4 : L - 4 * g; }
     static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. L - 1 in the second word
@@ -94,12 +99,15 @@ __device__ __forceinline__ void bin_add(unsigned char* lds, uint32_t bin_address
 
 // STATE: where a read's carried state comes from (pamld_near.hpp): 0 nothing to load, 1 the input flag bytes, 2 the
 // status word of the stage before
-template <int L, int STATE, int WAVES>
+template <int L, int STATE, int WAVES, bool PRIORS>
 // one workgroup per CU: the LDS it takes fixes the occupancy at WAVES / 4 waves per SIMD, and the compiler is told so — left
 // to assume that fewer registers would buy more waves, it serialises the table reads into pairs, each waited for
-__global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
+__global__ __launch_bounds__((Shape<L, WAVES, PRIORS>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
 void pamld_stream_kernel(StageArgs args) {
-    typedef Shape<L, WAVES> Layout;
+    typedef Shape<L, WAVES, PRIORS> Layout;
+    constexpr int BLOCK_WORDS = Block<PRIORS>::WORDS;
+    constexpr uint32_t BLOCK_BYTES = Block<PRIORS>::BYTES;
+    constexpr uint32_t BIN_AT = Block<PRIORS>::BIN_AT;
     constexpr int THREADS = Layout::THREADS;
     constexpr uint32_t VALID1 = Layout::VALID1;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -139,6 +147,8 @@ void pamld_stream_kernel(StageArgs args) {
             lds_words[at + 4] = lut::high_plane(sliced);
         }
     }
+    float* const lds_prior = reinterpret_cast<float*>(lds_raw + Layout::prior_at(n_barcode));
+    if(PRIORS) { for(int b = threadIdx.x; b < ((n_barcode + 7) & ~7); b += THREADS) { lds_prior[b] = d.concentration_single[b]; } }      // padded with zeros by the host
     for(int w = threadIdx.x; w < n_barcode * BLOCK_WORDS; w += THREADS) { blocks_of_barcodes[w] = d.stream_record[w]; }      // lists and weights; the bins come as zeros
     for(int i = threadIdx.x; i < STAT_JOB_WORDS + BIN_WORDS; i += THREADS) { histogram[i] = 0; }
     // entry 0 of both tables (no mismatch in the group) is 1 in units of the all-match product: written once
@@ -313,6 +323,11 @@ void pamld_stream_kernel(StageArgs args) {
             const uint32_t w[8] = {first.x, first.y, first.z, first.w, second.x, second.y, second.z, second.w};
             float p[8];
             block_values(w, p);
+            if(PRIORS) {
+                const float4 lower = reinterpret_cast<const float4*>(lds_prior)[2 * f];
+                const float4 upper = reinterpret_cast<const float4*>(lds_prior)[2 * f + 1];
+                p[0] *= lower.x; p[1] *= lower.y; p[2] *= lower.z; p[3] *= lower.w; p[4] *= upper.x; p[5] *= upper.y; p[6] *= upper.z; p[7] *= upper.w;
+            }
             if(8 * f + 8 > n_barcode) {                 // the padding of a partial last block
 #pragma unroll
                 for(int k = 1; k < 8; ++k) { if(8 * f + k >= n_barcode) { p[k] = 0.0f; } }
@@ -338,6 +353,10 @@ void pamld_stream_kernel(StageArgs args) {
             for(int k = 0; k < 8; ++k) { w[k] = lds_words[8 * block + k]; }
             float p[8];
             block_values(w, p);
+            if(PRIORS) {
+#pragma unroll
+                for(int k = 0; k < 8; ++k) { p[k] *= lds_prior[8 * block + k]; }
+            }
             {
                 const int limit = n_barcode - 8 * block;
 #pragma unroll
@@ -382,10 +401,11 @@ void pamld_stream_kernel(StageArgs args) {
                 best_conditional *= ((best_flags >> low_bit(j)) & 1u) ? mismatch : match;
                 everything_matches *= match;
             }
-            const double best_p = best_conditional * common_prior;
+            const double prior_of_best = PRIORS ? d.concentration[best] : common_prior;
+            const double best_p = best_conditional * prior_of_best;
             // everything but the winner: a single precision sum in units of the all-match product; only ever compared
             // against and added to much larger terms
-            const double others = (static_cast<double>(sigma) * everything_matches) * common_prior;
+            const double others = PRIORS ? static_cast<double>(sigma) * everything_matches : (static_cast<double>(sigma) * everything_matches) * common_prior;
             const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
             double confidence = best_p / total;                                       // pamld.cpp:92
             const double noise_margin = best_conditional - d.random_barcode_probability;
@@ -533,9 +553,9 @@ void pamld_stream_kernel(StageArgs args) {
             const bool known = index != 0x3fffu;
             // the list of c — eight pairs of barcodes as plane words, then the weights of the bound — asked for together
             // with the factor rows: one wait for both
-            Quad record[5];
+            Quad record[Block<PRIORS>::QUADS];
 #pragma unroll
-            for(int quad = 0; quad < 5; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
+            for(int quad = 0; quad < Block<PRIORS>::QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
             auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
             const uint32_t observed = sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16);      // against both halves of a word
             const uint32_t observed_high = lut::high_plane(observed);
@@ -593,7 +613,10 @@ void pamld_stream_kernel(StageArgs args) {
             {
                 float p[LIST];
 #pragma unroll
-                for(int o = 1; o < LIST; ++o) { p[o] = first_group[o] * second_group[o]; }
+                for(int o = 1; o < LIST; ++o) {
+                    p[o] = first_group[o] * second_group[o];
+                    if(PRIORS) { p[o] *= __uint_as_float(record_word(LIST + 4 + o)); }            // the barcode's prior over c's
+                }
                 others = (((p[1] + p[2]) + (p[3] + p[4])) + ((p[5] + p[6]) + (p[7] + p[8]))) + (((p[9] + p[10]) + (p[11] + p[12])) + ((p[13] + p[14]) + p[15]));
             }
 
@@ -613,7 +636,8 @@ void pamld_stream_kernel(StageArgs args) {
             rest *= fmaxf(winner, 1.0f) * near::SLOP;
             const float x_listed = others * inverse_winner;
             const float x_rest = rest * inverse_winner;
-            const float x_low = __builtin_fmaf(uniform_noise_over_prior, inverse_both, x_listed);
+            const float noise_over_prior = PRIORS ? __uint_as_float(record_word(LIST + 4)) : uniform_noise_over_prior;
+            const float x_low = __builtin_fmaf(noise_over_prior, inverse_both, x_listed);
             // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp): 1 - y, y = x / (1 + x) = x - x^2 + x^3 up
             // to x^4 < 7e-14 (x is at most 5e-4 where it counts)
             const float y = x_low * __builtin_fmaf(-x_low, 1.0f - x_low, 1.0f);
@@ -717,19 +741,19 @@ void pamld_stream_kernel(StageArgs args) {
     }
 }
 
-template <int L, int STATE, int WAVES>
+template <int L, int STATE, int WAVES, bool PRIORS>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES>, prepared)) { return status; }
-    typedef Shape<L, WAVES> Layout;
-    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES>), grid, dim3(Layout::THREADS), Layout::lds_bytes(n_barcode), stream, args);
+    if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES, PRIORS>, prepared)) { return status; }
+    typedef Shape<L, WAVES, PRIORS> Layout;
+    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES, PRIORS>), grid, dim3(Layout::THREADS), Layout::lds_bytes(n_barcode), stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L, int WAVES>
+template <int L, int WAVES, bool PRIORS>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2, WAVES>(args, n_barcode, grid, stream); }
-    return args.input_flag ? launch_state<L, 1, WAVES>(args, n_barcode, grid, stream) : launch_state<L, 0, WAVES>(args, n_barcode, grid, stream);
+    if(!args.first_stage) { return launch_state<L, 2, WAVES, PRIORS>(args, n_barcode, grid, stream); }
+    return args.input_flag ? launch_state<L, 1, WAVES, PRIORS>(args, n_barcode, grid, stream) : launch_state<L, 0, WAVES, PRIORS>(args, n_barcode, grid, stream);
 }
 
 }  // namespace stream
