@@ -210,9 +210,6 @@ void pamld_stream_kernel(StageArgs args) {
     // bytes 0 and 2; the group is the load's immediate offset
     auto entry = [&](uint32_t fields, int byte, int g) -> float {
         const uint32_t address = __builtin_amdgcn_perm(fields, lane_low, 0x0c020400u | (static_cast<uint32_t>(byte) << 8));
-#ifdef PHQ_DIAG_DOUBLE_READS
-        { const float again = ((volatile __attribute__((address_space(3))) const float*)static_cast<uintptr_t>(address))[g * 64]; asm volatile("" :: "v"(again)); }
-#endif
         return ((LdsFloats)static_cast<uintptr_t>(address))[g * 64];
     };
     // the normalised tables of a read from its rho row
@@ -230,9 +227,7 @@ void pamld_stream_kernel(StageArgs args) {
             for(int m = 1; m < 16; ++m) {
                 if(m < entries) {
                     t[m] = (m >> 2) == 0 ? lo[m & 3] : (m & 3) == 0 ? hi[m >> 2] : lo[m & 3] * hi[m >> 2];
-#ifndef PHQ_DIAG_NO_TABLE_WRITES
                     *reinterpret_cast<float*>(lds_raw + lane_const + static_cast<uint32_t>(g) * 256u + static_cast<uint32_t>(m) * 1024u) = t[m];
-#endif
                     const int a = __builtin_popcount(static_cast<unsigned>(m));
                     by_count[a] = (m == (1 << a) - 1) ? t[m] : fmaxf(by_count[a], t[m]);      // the first entry of a count is 2^a - 1
                 }
@@ -692,9 +687,7 @@ void pamld_stream_kernel(StageArgs args) {
         }
         const uint32_t arriving = static_cast<uint32_t>(__popcll(deferred));
         if(ring_count + arriving > RING || (!more && ring_count > 0)) {
-#ifndef PHQ_DIAG_NO_DRAIN
             drain(ring_count);
-#endif
             ring_count = 0;
         }
         if(arriving) {
