@@ -18,9 +18,12 @@ namespace {
 
 constexpr int TINY_MAX_BARCODES = 8;
 
-template <int ROW_WORDS>
+// L: the codec's nucleotide cardinality, a template parameter since round 3 — the loops over the positions used to run to
+// the row's capacity (8 for a 6 nt codec) under run time guards: a quarter of C5's fourth round for nothing
+template <int L>
 __global__ __launch_bounds__(BLOCK) void pamld_tiny_kernel(StageArgs args) {
-    constexpr int LMAX = 4 * ROW_WORDS;
+    constexpr int ROW_WORDS = (L + 3) / 4;
+    constexpr int LMAX = L;
     __shared__ double factor[129][2];                 // [row][0 match | 1 mismatch]; row 128 = a base outside ACGT
     __shared__ uint32_t deferred_total;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -40,7 +43,6 @@ __global__ __launch_bounds__(BLOCK) void pamld_tiny_kernel(StageArgs args) {
     const PHQ_CONSTANT double* concentration = constant_cast(d.concentration);
     const int n_barcode = d.n_barcode;
     const int n_word = d.n_word;
-    const int L = d.nucleotide_cardinality;
     const int64_t n = args.n_read;
     const int64_t tiles = (n + BLOCK - 1) / BLOCK;
 
@@ -179,15 +181,23 @@ bool pamld_tiny_supports(const DevDecoder& host_decoder) {
            host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 && host_decoder.barcode_packed != nullptr;
 }
 
-int launch_pamld_tiny(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    switch(host_decoder.plane_stride / 4) {
-        case 1: hipLaunchKernelGGL((pamld_tiny_kernel<1>), grid, dim3(BLOCK), histogram_bytes, stream, args); break;
-        case 2: hipLaunchKernelGGL((pamld_tiny_kernel<2>), grid, dim3(BLOCK), histogram_bytes, stream, args); break;
-        case 3: hipLaunchKernelGGL((pamld_tiny_kernel<3>), grid, dim3(BLOCK), histogram_bytes, stream, args); break;
-        case 4: hipLaunchKernelGGL((pamld_tiny_kernel<4>), grid, dim3(BLOCK), histogram_bytes, stream, args); break;
-        default: return static_cast<int>(hipErrorInvalidValue);
+namespace {
+template <int LO, int HI>
+int launch_tiny_range(const StageArgs& args, int length, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if constexpr(LO > HI) { (void)args; (void)length; (void)grid; (void)histogram_bytes; (void)stream; return static_cast<int>(hipErrorInvalidValue); }
+    else {
+        if(length == LO) {
+            hipLaunchKernelGGL((pamld_tiny_kernel<LO>), grid, dim3(BLOCK), histogram_bytes, stream, args);
+            return static_cast<int>(hipGetLastError());
+        }
+        return launch_tiny_range<LO + 1, HI>(args, length, grid, histogram_bytes, stream);
     }
-    return static_cast<int>(hipGetLastError());
+}
+}  // namespace
+
+int launch_pamld_tiny(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    if(host_decoder.plane_stride != 4 * ((host_decoder.nucleotide_cardinality + 3) / 4)) { return static_cast<int>(hipErrorInvalidValue); }
+    return launch_tiny_range<1, 16>(args, host_decoder.nucleotide_cardinality, grid, histogram_bytes, stream);
 }
 
 }  // namespace phq
