@@ -294,6 +294,9 @@ bool mdd_exact_supports(const DevDecoder& host_decoder);
 int launch_mdd_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream);
 bool pamld_tiny_supports(const DevDecoder& host_decoder);   // pamld_tiny.hip: at most 8 barcodes, fp64 products, no tables
 int launch_pamld_tiny(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_few_supports(const DevDecoder& host_decoder);    // pamld_few.hip: the same codecs up to 8 nt in one persistent kernel, a pipeline per wave
+int pamld_few_waves();                                      // waves (= worklist segments) per workgroup of that kernel
+int launch_pamld_few(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 bool pamld_lut_supports(const DevDecoder& host_decoder);
 int pamld_lut_block(const DevDecoder& host_decoder);       // threads per workgroup of the product form kernel
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);

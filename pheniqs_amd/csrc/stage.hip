@@ -89,6 +89,10 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)
                 static const bool no_stream = std::getenv("PHQ_NO_STREAM") != nullptr;
                 const bool streamed = listed && !no_stream && host_decoder.use_lds_histogram && !args.defer_counters && pamld_stream_supports(host_decoder);
+                // ... and a codec of a few barcodes of up to 8 nt has its own streaming kernel: every barcode scored in single
+                // precision, the fp64 products of the tiny kernel on the wave's ring (pamld_few.hip)
+                static const bool no_few = std::getenv("PHQ_NO_FEW") != nullptr;
+                const bool few = tiny && !no_few && args.result != nullptr && !args.defer_counters && pamld_few_supports(host_decoder);
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
@@ -106,23 +110,24 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
-                if(streamed) {
-                    // one workgroup per CU, a worklist segment per WAVE: what the scan cannot decide either goes there
-                    const int waves = pamld_stream_waves();
+                if(streamed || few) {
+                    // one workgroup per CU (two of the smaller ones of the few barcode kernel), a worklist segment per WAVE: what
+                    // the second pass cannot decide either goes there
+                    const int waves = few ? pamld_few_waves() : pamld_stream_waves();
                     const int64_t wave_tiles = (args.n_read + 63) / 64;
-                    const int64_t wanted = std::max<int64_t>(1, std::min<int64_t>(cus, (wave_tiles + waves - 1) / waves));
+                    const int64_t wanted = std::max<int64_t>(1, std::min<int64_t>(few ? std::min<int64_t>(2 * cus, max_blocks / waves) : cus, (wave_tiles + waves - 1) / waves));
                     const dim3 stream_grid(static_cast<unsigned>(wanted));
                     const int64_t segments = wanted * waves;
                     producer.worklist_stride = static_cast<int32_t>((wave_tiles + segments - 1) / segments * 64);
                     producer.carry = nullptr;
                     producer.carry_stride = 0;
                     {
-                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
-                        status = launch_pamld_stream(producer, host_decoder, stream_grid, s);
+                        Timed timed(timer, few ? KERNEL_PAMLD_PRODUCT : KERNEL_PAMLD_NEAR, stream);
+                        status = few ? launch_pamld_few(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s);
                     }
                     if(status != 0) { return status; }
                     const dim3 segment_grid(static_cast<unsigned>(segments));
-                    trace_worklist("the streaming kernel", producer, segment_grid.x, s);
+                    trace_worklist(few ? "the few barcode kernel" : "the streaming kernel", producer, segment_grid.x, s);
                     StageArgs consumer = producer;
                     consumer.worklist_role = 2;
                     if(pamld_exact_supports(host_decoder)) {

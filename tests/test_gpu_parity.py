@@ -187,6 +187,39 @@ def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread, 
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
 
 
+@pytest.mark.parametrize("priors", [False, True])
+@pytest.mark.parametrize("length,count", [(1, 2), (2, 4), (3, 8), (4, 5), (5, 1), (6, 4), (7, 8), (8, 3), (8, 8)])
+def test_codecs_of_a_few_barcodes(oracle, torch_cuda, length, count, priors):
+    """At most 8 barcodes of up to 8 nt (a SPLiT-seq round, a multiplex of a handful of samples) take the kernel of
+    pamld_few.hip in fast mode: every barcode scored in fp64 by masks, the posterior by a refined reciprocal, bins in
+    16 copies.  As first decoder (with and without an input flag plane) and behind another one (the state word), with
+    bases outside ACGT, qualities of 0 and of 128 and more, priors that differ and a prior of zero; the literal mode
+    beside it.  Held to 1e-12 like pamld_tiny.hip, whose arithmetic it is."""
+    rng = np.random.default_rng(9000 + 10 * length + count + (100 if priors else 0))
+    words = synthetic.barcode_set(rng, count, length, min_distance=1 if length < 6 else 2)
+    front = synthetic.barcode_set(rng, 5, 8, min_distance=3)
+    spec = {"input segment cardinality": 2,
+            "cellular": [synthetic.decoder_spec("pamld", [front], ["1::8"]), synthetic.decoder_spec("pamld", [words], ["0::%d" % length])],
+            "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length])}
+    if priors:
+        for decoder in (spec["sample"], spec["cellular"][1]):
+            for k, record in enumerate(decoder["codec"].values()):
+                record["concentration"] = 0 if (count > 2 and k == 1) else float(10 ** rng.uniform(-1.0, 1.0))
+    job = capi.compile_job(spec)
+    n = 1 << 14
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 31 + length)
+    code[rng.random(code.shape) < 0.01] = 15
+    quality[rng.random(quality.shape) < 0.01] = 0
+    quality[rng.random(quality.shape) < 0.002] = 200
+    flag[:] = rng.random(n) < 0.1
+    for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
+        s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+        expected, _ = oracle.OracleJob(job).classify(code, quality, flag)
+        for slot in range(s.n_result):         # all three are codecs of a few barcodes: first in the chain and behind another decoder
+            assert float(np.abs(got[slot]["confidence"] - expected[:, slot]["confidence"]).max()) <= 1e-12
+    assert_parity(oracle, torch_cuda, job, code, quality, None, offsets, mode=capi.MODE_FAST)
+
+
 @pytest.mark.parametrize("lengths,count,spread,absent", [((8, 8), 96, 1.0, 0), ((10, 10), 96, 1.0, 0), ((10, 10), 196, 2.0, 0), ((6, 9), 48, 0.5, 0),
                                                          ((8, 8), 96, 1.0, 4), ((10, 10), 64, 0.5, 2)])
 def test_paired_sets_with_priors(oracle, torch_cuda, lengths, count, spread, absent):
