@@ -443,14 +443,16 @@ void DecoderSet::build_device_images() {
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
                 const bool stream_priors = !d.uniform_prior;
                 const uint32_t stream_stride = static_cast<uint32_t>(stream_record_words(stream_priors)) * 4u;
-                if(L <= 8 && !tables.record.empty() && N < static_cast<int32_t>(STREAM_UNKNOWN) &&
-                   stream_block_at(STREAM_WAVES, N, stream_priors) + static_cast<uint32_t>(N) * stream_stride < (1u << 18)) {
+                if(!tables.record.empty() && N < static_cast<int32_t>(STREAM_UNKNOWN) &&
+                   stream_block_at(STREAM_WAVES, N, stream_priors, L) + static_cast<uint32_t>(N) * stream_stride < (1u << 18)) {
                     // the streaming kernel (pamld_stream.hpp): the same table and lists in pamld_lut.hpp's bit order; the table
                     // names a barcode by the LDS address of its block and its index
-                    const uint32_t first_block = stream_block_at(STREAM_WAVES, N, stream_priors);
-                    const int32_t list = near_list(L);
+                    const uint32_t first_block = stream_block_at(STREAM_WAVES, N, stream_priors, L);
+                    const int32_t near_listed = near_list(L);                 // tables.listed holds that many per barcode, nearest first
+                    const int32_t list = stream_list(L);                      // 16 up to 8 nt, two to a plane word; 8 beyond, one to a word
+                    const bool one_per_word = L > 8;
                     const int32_t record_words = stream_record_words(stream_priors);
-                    auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10); };      // bit j = position j -> bit 8 (j / 4) + 2 + j % 4
+                    auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10) | (((bits >> 8) & 0x3u) << 18); };      // bit j = position j -> bit 8 (j / 4) + 2 + j % 4
                     std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
                     std::vector<char> usable(static_cast<size_t>(N), 1);
                     bool indexable = true;
@@ -461,14 +463,19 @@ void DecoderSet::build_device_images() {
                         if(stream_priors && !(own > 0)) { usable[static_cast<size_t>(b)] = 0; }
                         std::vector<bool> is_listed(static_cast<size_t>(N), false);
                         for(int32_t k = 0; k < list; ++k) {
-                            const size_t o = static_cast<size_t>(tables.listed[static_cast<size_t>(b) * static_cast<size_t>(list) + static_cast<size_t>(k)]);
+                            const size_t o = static_cast<size_t>(tables.listed[static_cast<size_t>(b) * static_cast<size_t>(near_listed) + static_cast<size_t>(k)]);
                             is_listed[o] = true;
-                            to[k / 2] |= half(low[o]) << (16 * (k & 1));
-                            to[list / 2 + k / 2] |= half(high[o]) << (16 * (k & 1));
+                            if(one_per_word) {
+                                to[k] = half(low[o]);
+                                to[STREAM_PLANE_WORDS / 2 + k] = half(high[o]);
+                            } else {
+                                to[k / 2] |= half(low[o]) << (16 * (k & 1));
+                                to[STREAM_PLANE_WORDS / 2 + k / 2] |= half(high[o]) << (16 * (k & 1));
+                            }
                             if(stream_priors) {
                                 // slot 0: the noise term over this barcode's prior; then each listed barcode's prior over it
                                 const float ratio = k == 0 ? static_cast<float>(d.adjusted_noise_probability / own) : static_cast<float>(concentration[o] / own);
-                                std::memcpy(&to[list + 4 + k], &ratio, sizeof(float));
+                                std::memcpy(&to[STREAM_PLANE_WORDS + 4 + k], &ratio, sizeof(float));
                             }
                         }
                         // the barcodes that are not listed, by their distance from b: 3, 4, 5, 6 or more — how many, or with
@@ -484,18 +491,20 @@ void DecoderSet::build_device_images() {
                         }
                         for(int k = 0; k < 4; ++k) {
                             const float rounded = crowded ? std::numeric_limits<float>::infinity() : static_cast<float>(weight[k]) * (stream_priors ? 1.0f + 1e-6f : 1.0f);
-                            std::memcpy(&to[list + k], &rounded, sizeof(float));
+                            std::memcpy(&to[STREAM_PLANE_WORDS + k], &rounded, sizeof(float));
                         }
                         if(index[static_cast<size_t>(b)] < 0 || index[static_cast<size_t>(b)] >= static_cast<int32_t>(STREAM_UNKNOWN)) { indexable = false; }
                     }
-                    std::vector<uint32_t> table(65536, (STREAM_UNKNOWN << 18) | first_block);
+                    // up to 8 nt the key is 16 bits whatever the length; beyond, the bits of positions 8 and 9 follow them
+                    const int32_t tail = L > 8 ? L - 8 : 0;
+                    std::vector<uint32_t> table(L > 8 ? (static_cast<size_t>(1) << (2 * L)) : 65536, (STREAM_UNKNOWN << 18) | first_block);
                     const uint32_t positions = (1u << L) - 1u;
                     for(uint32_t key = 0; key < (1u << (2 * L)); ++key) {
                         const uint32_t l = key & positions;
                         const uint32_t h = key >> L;
                         const uint16_t named = tables.table[key];
                         if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
-                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12)] =
+                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] =
                             (static_cast<uint32_t>(index[named]) << 18) | (first_block + static_cast<uint32_t>(named) * stream_stride);
                     }
                     d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));

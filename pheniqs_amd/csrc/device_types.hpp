@@ -34,9 +34,17 @@ constexpr int stream_record_words(bool priors) { return priors ? 60 : 44; }
 #define PHQ_STREAM_WAVES 12
 #endif
 constexpr int STREAM_WAVES = PHQ_STREAM_WAVES;
-constexpr uint32_t stream_words_bytes(int n_barcode, bool priors) { return static_cast<uint32_t>(((n_barcode + 7) & ~7) / 2) * 2u * 4u + (priors ? static_cast<uint32_t>((n_barcode + 7) & ~7) * 4u : 0u); }
-constexpr uint32_t stream_block_at(int waves, int n_barcode, bool priors) {
-    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 6u * 64u * 4u + stream_words_bytes(n_barcode, priors);
+// 9 and 10 nt: two tabled groups of four positions and one or two positions picked by masks, 8 listed barcodes one per plane
+// word (the 16 plane words of a block either way), three words per input row, the codec's words one barcode per word
+constexpr int stream_list(int length) { return length > 8 ? 8 : 16; }
+constexpr int STREAM_PLANE_WORDS = 16;
+constexpr int stream_row_words(int length) { return length > 8 ? 3 : 2; }
+constexpr uint32_t stream_ring_bytes(int length) { return static_cast<uint32_t>(2 * stream_row_words(length) + 2) * 64u * 4u; }      // code words, quality words, carried state, ordinal
+constexpr uint32_t stream_words_bytes(int n_barcode, bool priors, int length = 8) {
+    return static_cast<uint32_t>((n_barcode + 7) & ~7) * (length > 8 ? 2u : 1u) * 4u + (priors ? static_cast<uint32_t>((n_barcode + 7) & ~7) * 4u : 0u);
+}
+constexpr uint32_t stream_block_at(int waves, int n_barcode, bool priors, int length = 8) {
+    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * stream_ring_bytes(length) + stream_words_bytes(n_barcode, priors, length);
 }
 constexpr uint32_t STREAM_UNKNOWN = 0x3fffu;   // the index field of a lookup that names no barcode
 constexpr int NEAR_MIN_LENGTH = 5;

@@ -37,7 +37,11 @@ namespace phq {
 namespace stream {
 
 constexpr int FACTOR_ROWS = 129;
-constexpr int LIST = 16;                       // barcodes scored in pass A: c and the 15 nearest to it
+constexpr int LIST = 16;                       // barcodes scored in pass A: c and the 15 nearest to it (5 to 8 nt)
+// 9 and 10 nt: words that long sit further apart — 8 listed barcodes defer 6.2 % where 16 defer 5.4 %
+// (profiles/tools/sim/list_size.py) — and their positions 8 and 9 have no table: the factor of each is picked by a mask
+__host__ __device__ constexpr int list_of(int length) { return stream_list(length); }
+constexpr int PLANE_WORDS = STREAM_PLANE_WORDS; // a block's list: 8 low + 8 high plane words — 16 barcodes two per word, or 8 one per word
 // a barcode's block in LDS: its list — 8 low plane words, 8 high plane words (two listed barcodes per word) —, the weights
 // of the bound (how many barcodes that are not listed sit at distance 3, 4, 5 and 6 or more from it), then its counter
 // bin, then padding to a stride of 11 quads: an odd number, so the blocks start in all 16 quad places of the banks
@@ -50,7 +54,7 @@ template <bool PRIORS> struct Block {
     static constexpr int QUADS = PRIORS ? 9 : 5;   // what pass A reads of it
 };
 constexpr int RING = 64;                       // entries of a wave's ring
-constexpr int RING_PLANES = 6;                 // code word 0, 1, quality word 0, 1, carried state, ordinal
+// a ring entry: the code words, the quality words, the carried state, the ordinal — 6 planes up to 8 nt, 8 beyond
 // the workgroup histogram of this kernel, per bin and [qc fail | pass filter] half: {count | distance << 32,
 // confidence low limb, confidence high limb, low conditional confidence count | low confidence count << 32}; a
 // workgroup sees fewer than 2^31 reads of at most 8 nt per launch, so no half word overflows
@@ -60,24 +64,32 @@ constexpr int BIN_WORDS = 8;                   // words 0..3 the qc fail half, 4
 constexpr int PASS_A_FRACTION_BITS = 38;
 
 template <int L, int WAVES, bool PRIORS = false> struct Shape {
-    static_assert(L >= 5 && L <= 8, "two groups of 4 positions");
+    static_assert(L >= 5 && L <= 10, "two groups of 4 positions, and up to two positions picked by masks");
     static_assert(WAVES >= 2 && WAVES <= 16 && WAVES % 2 == 0, "pairs of waves share a 16 KiB block of tables");
     static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TABLED = L > 8 ? 8 : L;                  // positions that go through the tables
+    static constexpr int TAIL = L - TABLED;                       // positions 8 .. L - 1: a mask picks rho or 1
+    static constexpr int ROW_WORDS = stream_row_words(L);
+    static constexpr int LISTED = list_of(L);
+    static constexpr int RING_PLANES = 2 * ROW_WORDS + 2;
     static constexpr uint32_t TABLE_BYTES = WAVES * 8192u;        // wave w: block w >> 1 of 16 KiB, bit 9 = w & 1
     static constexpr uint32_t FACTOR_AT = TABLE_BYTES;            // FACTOR_ROWS x {P(match), rho} floats; a multiple of 1024: rows are reached by OR
     static constexpr uint32_t DOUBLE_AT = FACTOR_AT + 1040;       // FACTOR_ROWS x {P(match), P(mismatch)} doubles
     static constexpr uint32_t RING_AT = DOUBLE_AT + FACTOR_ROWS * 16;
-    static constexpr uint32_t RING_BYTES = RING_PLANES * RING * 4;
+    static constexpr uint32_t RING_BYTES = stream_ring_bytes(L);
+    static_assert(RING_BYTES == RING_PLANES * RING * 4, "the host's map of the block");
     static constexpr uint32_t WORDS_AT = RING_AT + WAVES * RING_BYTES;        // pamld_lut.hpp's plane words of the codec
-    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return stream_words_bytes(n_barcode, PRIORS); }
-    __host__ __device__ static constexpr uint32_t prior_at(int n_barcode) { return WORDS_AT + stream_words_bytes(n_barcode, false); }        // PRIORS: the codec's priors, single precision, padded to blocks of 8
+    __host__ __device__ static constexpr uint32_t words_bytes(int n_barcode) { return stream_words_bytes(n_barcode, PRIORS, L); }
+    __host__ __device__ static constexpr uint32_t prior_at(int n_barcode) { return WORDS_AT + stream_words_bytes(n_barcode, false, L); }        // PRIORS: the codec's priors, single precision, padded to blocks of 8
     __host__ __device__ static constexpr uint32_t block_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }      // the barcodes' blocks
-    static_assert(WORDS_AT + stream_words_bytes(96, PRIORS) == stream_block_at(WAVES, 96, PRIORS), "the host puts block addresses into the lookup table");
+    static_assert(WORDS_AT + stream_words_bytes(96, PRIORS, L) == stream_block_at(WAVES, 96, PRIORS, L), "the host puts block addresses into the lookup table");
     // bin 0 (unclassified) and the two job words in front of it, behind the blocks
     __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * Block<PRIORS>::BYTES; }
     __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + BIN_WORDS); }
-    __host__ __device__ static constexpr int positions(int g) { return L - 4 * g >= 4 ? 4 : L - 4 * g; }
-    static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. L - 1 in the second word
+    __host__ __device__ static constexpr int positions(int g) { return TABLED - 4 * g >= 4 ? 4 : TABLED - 4 * g; }
+    static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. 7 in the second word
+    static constexpr uint32_t VALID2 = TAIL == 0 ? 0u : ((1u << (8 * TAIL)) - 1u);               // ... of positions 8 .. L - 1 in the third
+    __host__ __device__ static constexpr uint32_t valid(int w) { return w == 0 ? 0xffffffffu : w == 1 ? VALID1 : VALID2; }
     static_assert(FACTOR_AT % 1024 == 0 && DOUBLE_AT % 16 == 0 && RING_AT % 16 == 0 && WORDS_AT % 16 == 0, "alignment");
 };
 
@@ -110,6 +122,11 @@ void pamld_stream_kernel(StageArgs args) {
     constexpr uint32_t BIN_AT = Block<PRIORS>::BIN_AT;
     constexpr int THREADS = Layout::THREADS;
     constexpr uint32_t VALID1 = Layout::VALID1;
+    constexpr uint32_t VALID2 = Layout::VALID2;
+    constexpr int TAIL = Layout::TAIL;
+    constexpr int ROW_WORDS = Layout::ROW_WORDS;
+    constexpr int LISTED = Layout::LISTED;                   // barcodes scored in pass A
+    constexpr int RHO = TAIL ? 10 : 8;                       // slots of a read's rho row
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     float2* const factor_single = reinterpret_cast<float2*>(lds_raw + Layout::FACTOR_AT);                 // [row] {P(match), rho}
@@ -140,11 +157,21 @@ void pamld_stream_kernel(StageArgs args) {
     {
         // per block of 8 barcodes: the low plane words of the block, then its high plane words (pamld_lut.hpp)
         const int padded = (n_barcode + 7) & ~7;
-        for(int w = threadIdx.x; w < padded >> 1; w += THREADS) {
-            const uint32_t sliced = d.barcode_packed2[w];
-            const int at = 8 * (w / 4) + (w % 4);
-            lds_words[at] = lut::low_plane(sliced);
-            lds_words[at + 4] = lut::high_plane(sliced);
+        if(TAIL == 0) {
+            for(int w = threadIdx.x; w < padded >> 1; w += THREADS) {
+                const uint32_t sliced = d.barcode_packed2[w];
+                const int at = 8 * (w / 4) + (w % 4);
+                lds_words[at] = lut::low_plane(sliced);
+                lds_words[at + 4] = lut::high_plane(sliced);
+            }
+        } else {
+            // past 8 nt a word holds one barcode: per block of 8 barcodes eight low plane words, then eight high plane words
+            for(int w = threadIdx.x; w < padded; w += THREADS) {
+                const uint32_t sliced = d.barcode_packed2[w];
+                const int at = 16 * (w / 8) + (w % 8);
+                lds_words[at] = lut::low_plane(sliced);
+                lds_words[at + 8] = lut::high_plane(sliced);
+            }
         }
     }
     float* const lds_prior = reinterpret_cast<float*>(lds_raw + Layout::prior_at(n_barcode));
@@ -187,17 +214,17 @@ void pamld_stream_kernel(StageArgs args) {
     const bool multiplexing = d.multiplexing != 0;
     const bool identity_index = d.identity_index != 0;
     const bool last_stage = args.last_stage != 0;
-    constexpr uint32_t FULL_MASK = (L >= 8 ? 0x3c3cu : (0x3cu | (((1u << (L - 4)) - 1u) << 10)));       // the flag bit of each position, one barcode
+    constexpr uint32_t FULL_MASK = (L >= 8 ? 0x3c3cu : (0x3cu | (((1u << (L - 4)) - 1u) << 10))) | (TAIL ? (((1u << TAIL) - 1u) << 18) : 0u);       // the flag bit of each position, one barcode
 
-    struct Inputs { uint32_t code[2]; uint32_t quality[2]; uint32_t state; };
+    struct Inputs { uint32_t code[ROW_WORDS]; uint32_t quality[ROW_WORDS]; uint32_t state; };
     auto fetch = [&](int64_t tile, Inputs& in) {
         const int64_t first = tile * 64;
         const uint32_t last = static_cast<uint32_t>(min(static_cast<int64_t>(64), n - first)) - 1u;
         const uint32_t at = min(lane, last);
-        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + first * 8 + at * 8u);
-        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + first * 8 + at * 8u);
-        in.code[0] = code_row[0]; in.code[1] = code_row[1];
-        in.quality[0] = quality_row[0]; in.quality[1] = quality_row[1];
+        const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + first * (4 * ROW_WORDS) + at * (4u * ROW_WORDS));
+        const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + first * (4 * ROW_WORDS) + at * (4u * ROW_WORDS));
+#pragma unroll
+        for(int w = 0; w < ROW_WORDS; ++w) { in.code[w] = code_row[w]; in.quality[w] = quality_row[w]; }
         if(STATE == 1) { in.state = static_cast<uint32_t>(args.input_flag[first + at]); }      // transcode.h:207-211
         else if(STATE == 2) { in.state = args.word[first + at]; }
         else { in.state = 0; }
@@ -213,7 +240,7 @@ void pamld_stream_kernel(StageArgs args) {
         return ((LdsFloats)static_cast<uintptr_t>(address))[g * 64];
     };
     // the normalised tables of a read from its rho row
-    auto build_tables = [&](const float (&rho)[8], float (&ge)[2][5]) {
+    auto build_tables = [&](const float (&rho)[RHO], float (&ge)[3][5]) {
 #pragma unroll
         for(int g = 0; g < 2; ++g) {
             const int positions = Layout::positions(g);
@@ -239,6 +266,15 @@ void pamld_stream_kernel(StageArgs args) {
                 ge[g][a] = a > positions ? 0.0f : a == positions ? by_count[a] : fmaxf(by_count[a], ge[g][a + 1 > 4 ? 4 : a + 1]);
             }
         }
+        // the positions past the tables, for the bound: the largest product over a or more of them
+        ge[2][4] = 0.0f; ge[2][3] = 0.0f;
+        if(TAIL == 0) { ge[2][0] = 1.0f; ge[2][1] = 0.0f; ge[2][2] = 0.0f; }
+        else if(TAIL == 1) { ge[2][2] = 0.0f; ge[2][1] = rho[8]; ge[2][0] = fmaxf(1.0f, rho[8]); }
+        else {
+            ge[2][2] = rho[8] * rho[9];
+            ge[2][1] = fmaxf(fmaxf(rho[8], rho[9]), ge[2][2]);
+            ge[2][0] = fmaxf(1.0f, ge[2][1]);
+        }
     };
 
     // ---- pass C: the product form scan (pamld_lut.hpp) over the wave's ring --------------------------------------------
@@ -248,22 +284,24 @@ void pamld_stream_kernel(StageArgs args) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0)
         const bool live = lane < count;
         const uint32_t slot = live ? lane : 0u;
-        uint32_t code_words[2] = {ring[slot], ring[RING + slot]};
-        uint32_t quality_words[2] = {ring[2 * RING + slot], ring[3 * RING + slot]};
-        const uint32_t state = ring[4 * RING + slot];
-        const int64_t i = static_cast<int64_t>(ring[5 * RING + slot]);
+        uint32_t code_words[ROW_WORDS];
+        uint32_t quality_words[ROW_WORDS];
+#pragma unroll
+        for(int w = 0; w < ROW_WORDS; ++w) { code_words[w] = ring[w * RING + slot]; quality_words[w] = ring[(ROW_WORDS + w) * RING + slot]; }
+        const uint32_t state = ring[2 * ROW_WORDS * RING + slot];
+        const int64_t i = static_cast<int64_t>(ring[(2 * ROW_WORDS + 1) * RING + slot]);
         ReadState r;
         if(STATE != 2) { r.qcfail = (state & 1u) != 0; r.channel = 0; }
         else { r.qcfail = (state >> 31) != 0; r.channel = static_cast<int32_t>(state & 0x7fffffffu); }
         bool defer = false;
 
-        uint32_t row[2];                               // factor rows, 8 bits per position
+        uint32_t row[ROW_WORDS];                       // factor rows, 8 bits per position
         uint32_t observed = 0;                         // bit-sliced 2-bit codes; anything outside ACGT arbitrary
         uint32_t high_quality = 0;                     // flag bits (low_bit of the position)
         uint32_t outside = 0;                          // flag bits: not A, C, G or T (mismatches every barcode base)
 #pragma unroll
-        for(int w = 0; w < 2; ++w) {
-            const uint32_t valid = w == 0 ? 0xffffffffu : VALID1;
+        for(int w = 0; w < ROW_WORDS; ++w) {
+            const uint32_t valid = Layout::valid(w);
             const uint32_t x = code_words[w] & (0x0f0f0f0fu & valid);        // BAM codes
             const uint32_t q8 = quality_words[w] & valid;
             const uint32_t q7 = q8 & 0x7f7f7f7fu;                             // the table has 128 rows
@@ -282,17 +320,28 @@ void pamld_stream_kernel(StageArgs args) {
             outside |= (flags & 0xfu) << (8 * w + 2);
             high_quality |= (flags >> 4) << (8 * w + 2);
         }
-        float rho[8];
+        float rho[RHO];
 #pragma unroll
-        for(int j = 0; j < 8; ++j) {
+        for(int j = 0; j < RHO; ++j) {
             if(j < L) { rho[j] = factor_single[(row[j >> 2] >> (8 * (j & 3))) & 0xffu].y; }
             else { rho[j] = 1.0f; }
         }
-        observed |= __builtin_amdgcn_alignbit(observed, observed, 16);        // the same read against both halves of a word
+        if(TAIL == 0) { observed |= __builtin_amdgcn_alignbit(observed, observed, 16); }        // the same read against both halves of a word
         const uint32_t observed_high = lut::high_plane(observed);
         const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;   // + the wave's address bits
-        float unused[2][5];
+        float unused[3][5];
         build_tables(rho, unused);
+        // the factor of a position past the tables: rho where the flag bit is set, else 1 (one v_bfe_i32, one v_bitop3_b32)
+        auto tail_factor = [&](uint32_t fields) {
+            float factor = 1.0f;
+#pragma unroll
+            for(int t = 0; t < TAIL; ++t) {
+                const uint32_t mask = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(fields), 18 + t, 1));
+                const float picked = __uint_as_float(__builtin_amdgcn_bitop3_b32(mask, __float_as_uint(rho[8 + t]), 0x3f800000u, 0xCA));
+                factor = t == 0 ? picked : factor * picked;
+            }
+            return factor;
+        };
 
         // Single precision scan, eight barcodes at a time (pamld_lut.hpp): per block its maximum and its sum; across
         // blocks the running maximum, which block holds it, that block's sum set aside, the sum of every other block
@@ -301,21 +350,33 @@ void pamld_stream_kernel(StageArgs args) {
         float best_value = 0;
         float runner_up = 0;
         int best_fold = -1;
-        auto block_values = [&](const uint32_t (&w)[8], float (&p)[8]) {
+        constexpr int BLOCK_PLANE_WORDS = TAIL ? 16 : 8;           // plane words of a block of 8 barcodes
+        auto block_values = [&](const uint32_t (&w)[BLOCK_PLANE_WORDS], float (&p)[8]) {
+            if(TAIL == 0) {
 #pragma unroll
-            for(int k = 0; k < 4; ++k) {
-                const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[4 + k]);
+                for(int k = 0; k < 4; ++k) {
+                    const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[4 + k]);
 #pragma unroll
-                for(int h = 0; h < 2; ++h) { p[2 * k + h] = entry(fields, 2 * h, 0) * entry(fields, 2 * h + 1, 1); }
+                    for(int h = 0; h < 2; ++h) { p[2 * k + h] = entry(fields, 2 * h, 0) * entry(fields, 2 * h + 1, 1); }
+                }
+            } else {
+#pragma unroll
+                for(int k = 0; k < 8; ++k) {
+                    const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[(BLOCK_PLANE_WORDS / 2) + k]);
+                    p[k] = (entry(fields, 0, 0) * entry(fields, 1, 1)) * tail_factor(fields);
+                }
             }
         };
         const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words);
         const int n_blocks = (n_barcode + 7) >> 3;
 #pragma unroll 2
         for(int f = 0; f < n_blocks; ++f) {
-            const uint4 first = blocks[2 * f];
-            const uint4 second = blocks[2 * f + 1];
-            const uint32_t w[8] = {first.x, first.y, first.z, first.w, second.x, second.y, second.z, second.w};
+            uint32_t w[BLOCK_PLANE_WORDS];
+#pragma unroll
+            for(int quad = 0; quad < BLOCK_PLANE_WORDS / 4; ++quad) {
+                const uint4 four = blocks[(BLOCK_PLANE_WORDS / 4) * f + quad];
+                w[4 * quad] = four.x; w[4 * quad + 1] = four.y; w[4 * quad + 2] = four.z; w[4 * quad + 3] = four.w;
+            }
             float p[8];
             block_values(w, p);
             if(PRIORS) {
@@ -343,9 +404,9 @@ void pamld_stream_kernel(StageArgs args) {
         const float winner_single = best_value;
         {
             const int block = best_fold < 0 ? 0 : best_fold;
-            uint32_t w[8];
+            uint32_t w[BLOCK_PLANE_WORDS];
 #pragma unroll
-            for(int k = 0; k < 8; ++k) { w[k] = lds_words[8 * block + k]; }
+            for(int k = 0; k < BLOCK_PLANE_WORDS; ++k) { w[k] = lds_words[BLOCK_PLANE_WORDS * block + k]; }
             float p[8];
             block_values(w, p);
             if(PRIORS) {
@@ -372,9 +433,15 @@ void pamld_stream_kernel(StageArgs args) {
             sigma += crowded ? best_value : rest;
             if(best_fold >= 0 && best_value > 0.0f && within >= 0) {
                 best = 8 * block + within;
-                const int at = 8 * block + within / 2;
-                const uint32_t fields = (observed_low ^ lds_words[at]) | (observed_high ^ lds_words[at + 4]);
-                best_flags = ((fields >> (16 * (best & 1))) | outside) & FULL_MASK;
+                if(TAIL == 0) {
+                    const int at = 8 * block + within / 2;
+                    const uint32_t fields = (observed_low ^ lds_words[at]) | (observed_high ^ lds_words[at + 4]);
+                    best_flags = ((fields >> (16 * (best & 1))) | outside) & FULL_MASK;
+                } else {
+                    const int at = 16 * block + within;
+                    const uint32_t fields = (observed_low ^ lds_words[at]) | (observed_high ^ lds_words[at + 8]);
+                    best_flags = (fields | outside) & FULL_MASK;
+                }
             }
         }
 
@@ -478,17 +545,24 @@ void pamld_stream_kernel(StageArgs args) {
         // byte is not zero and the words hold L bits in all; a read with anything else goes to the ring
         const uint32_t x0 = in.code[0] & 0x0f0f0f0fu;
         const uint32_t x1 = in.code[1] & (0x0f0f0f0fu & VALID1);
-        const uint32_t every_byte = (x0 + 0x7f7f7f7fu) & ((x1 + 0x7f7f7f7fu) | ~(0x80808080u & VALID1)) & 0x80808080u;
+        const uint32_t x2 = TAIL ? in.code[ROW_WORDS - 1] & (0x0f0f0f0fu & VALID2) : 0u;
+        const uint32_t every_byte = (x0 + 0x7f7f7f7fu) & ((x1 + 0x7f7f7f7fu) | ~(0x80808080u & VALID1)) & ((x2 + 0x7f7f7f7fu) | ~(0x80808080u & VALID2)) & 0x80808080u;
         // ... and so does one with a quality byte of 128 or more: it counts as high quality whatever row its low bits
         // name, which the rho test of pass A cannot see
-        const uint32_t beyond_rows = (in.quality[0] | (in.quality[1] & VALID1)) & 0x80808080u;
-        to.all_strict = (__popc(x0) + __popc(x1)) == L && every_byte == 0x80808080u && beyond_rows == 0;
+        const uint32_t beyond_rows = (in.quality[0] | (in.quality[1] & VALID1) | (TAIL ? in.quality[ROW_WORDS - 1] & VALID2 : 0u)) & 0x80808080u;
+        to.all_strict = (__popc(x0) + __popc(x1) + __popc(x2)) == L && every_byte == 0x80808080u && beyond_rows == 0;
         // 2-bit codes A, C, G, T -> 0..3, bit-sliced as pamld_lut.hpp has them: position 4 f + k with its low bit at
-        // 8 f + 2 + k and its high bit 4 places up.  Bits 2..17 of that word are the key of the lookup.
+        // 8 f + 2 + k and its high bit 4 places up.  Bits 2..17 of that word (and the bits of positions 8 and 9) are the key of the lookup.
         const uint32_t codes0 = gather((((x0 >> 1) | (x0 >> 3)) & 0x01010101u) | (((x0 << 2) | (x0 << 1)) & 0x10101010u));
         const uint32_t codes1 = gather((((x1 >> 1) | (x1 >> 3)) & 0x01010101u) | (((x1 << 2) | (x1 << 1)) & 0x10101010u));
         to.sliced = (codes0 << 2) | (codes1 << 10);
-        to.looked_up = nearest[to.sliced >> 2];                                       // the barcode this word is (next to), if any
+        uint32_t key = to.sliced >> 2;
+        if(TAIL) {
+            const uint32_t codes2 = gather((((x2 >> 1) | (x2 >> 3)) & 0x01010101u) | (((x2 << 2) | (x2 << 1)) & 0x10101010u));
+            to.sliced |= codes2 << 18;
+            key |= ((codes2 & ((1u << TAIL) - 1u)) << 16) | (((codes2 >> 4) & ((1u << TAIL) - 1u)) << (16 + TAIL));
+        }
+        to.looked_up = nearest[key];                                                  // the barcode this word is (next to), if any
         to.in = in;
     };
 #ifdef PHQ_DIAG_STAGGER
@@ -529,6 +603,7 @@ void pamld_stream_kernel(StageArgs args) {
             else { incoming_qcfail = (in.state >> 31) != 0; incoming_channel = in.state & 0x7fffffffu; }
             const uint32_t q0 = in.quality[0] & 0x7f7f7f7fu;                  // the table has 128 rows
             const uint32_t q1 = in.quality[1] & (0x7f7f7f7fu & VALID1);
+            const uint32_t q2 = TAIL ? in.quality[ROW_WORDS - 1] & (0x7f7f7f7fu & VALID2) : 0u;
 #ifdef PHQ_DIAG_EXTRA_VALU
             { uint32_t sink = lane;
 #pragma unroll
@@ -552,17 +627,17 @@ void pamld_stream_kernel(StageArgs args) {
 #pragma unroll
             for(int quad = 0; quad < Block<PRIORS>::QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
             auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
-            const uint32_t observed = sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16);      // against both halves of a word
+            const uint32_t observed = TAIL ? sliced : (sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16));      // up to 8 nt: against both halves of a word
             const uint32_t observed_high = lut::high_plane(observed);
             const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
 
             // per position {P(match), rho} of its quality
-            float rho[8];
+            float rho[RHO];
             float everything_matches = 1.0f;
 #pragma unroll
-            for(int j = 0; j < 8; ++j) {
+            for(int j = 0; j < RHO; ++j) {
                 if(j < L) {
-                    const uint32_t q = j < 4 ? q0 : q1;
+                    const uint32_t q = j < 4 ? q0 : j < 8 ? q1 : q2;
                     const int byte = j & 3;
                     const uint32_t shifted = byte == 0 ? (q << 3) : (q >> (8 * byte - 3));
                     const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x3f8u, Layout::FACTOR_AT));
@@ -570,68 +645,94 @@ void pamld_stream_kernel(StageArgs args) {
                     rho[j] = pair.y;
                 } else { rho[j] = 1.0f; }
             }
-            float ge[2][5];
+            float ge[3][5];
             build_tables(rho, ge);
 
-            // all 32 table reads are asked for before the first is used: the wave has three to a SIMD for company, so a
+            // all the table reads are asked for before the first is used: the wave has three to a SIMD for company, so a
             // dependent chain of short read groups would expose the LDS latency eight times over
-            uint32_t fields[LIST / 2];
+            constexpr int FIELD_WORDS = TAIL ? LISTED : LISTED / 2;        // up to 8 nt a word holds the flags of two listed barcodes
+            uint32_t fields[FIELD_WORDS];
 #pragma unroll
-            for(int w = 0; w < LIST / 2; ++w) { fields[w] = (observed_low ^ record_word(w)) | (observed_high ^ record_word(LIST / 2 + w)); }
-            float first_group[LIST];
-            float second_group[LIST];
+            for(int w = 0; w < FIELD_WORDS; ++w) { fields[w] = (observed_low ^ record_word(w)) | (observed_high ^ record_word(PLANE_WORDS / 2 + w)); }
+            float first_group[LISTED];
+            float second_group[LISTED];
 #pragma unroll
-            for(int o = 0; o < LIST; ++o) {
-                first_group[o] = entry(fields[o >> 1], 2 * (o & 1), 0);
-                second_group[o] = entry(fields[o >> 1], 2 * (o & 1) + 1, 1);
+            for(int o = 0; o < LISTED; ++o) {
+                first_group[o] = TAIL ? entry(fields[o], 0, 0) : entry(fields[o >> 1], 2 * (o & 1), 0);
+                second_group[o] = TAIL ? entry(fields[o], 1, 1) : entry(fields[o >> 1], 2 * (o & 1) + 1, 1);
             }
-            // H[n]: the largest product over n or more mismatching positions, n = 2 .. 6, in units of the all-match product
-            // (while the reads are under way)
+            // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6, in units of the all-match product
+            // (while the reads are under way): over the two tabled groups, then with the positions past them
             float h[7];
+            {
+                float tabled[7];
 #pragma unroll
-            for(int m = 2; m <= 6; ++m) {
-                h[m] = 0.0f;
-                bool any = false;
+                for(int m = 1; m <= 6; ++m) {
+                    tabled[m] = 0.0f;
+                    bool any = false;
 #pragma unroll
-                for(int a = 0; a <= 4; ++a) {
-                    const int o = m - a;
-                    if(o >= 0 && o <= 4 && a <= Layout::positions(0) && o <= Layout::positions(1)) {
-                        const float product = ge[0][a] * ge[1][o];
-                        h[m] = any ? fmaxf(h[m], product) : product;
-                        any = true;
+                    for(int a = 0; a <= 4; ++a) {
+                        const int o = m - a;
+                        if(o >= 0 && o <= 4 && a <= Layout::positions(0) && o <= Layout::positions(1) && (m >= 3 || TAIL)) {
+                            const float product = ge[0][a] * ge[1][o];
+                            tabled[m] = any ? fmaxf(tabled[m], product) : product;
+                            any = true;
+                        }
                     }
                 }
+#pragma unroll
+                for(int m = 3; m <= 6; ++m) {
+                    h[m] = tabled[m];
+#pragma unroll
+                    for(int t = 1; t <= TAIL; ++t) { h[m] = fmaxf(h[m], tabled[m - t] * ge[2][t]); }
+                }
             }
+            // a position past the tables: rho where its flag bit is set, else 1 (one v_bfe_i32, one v_bitop3_b32)
+            auto tail_factor = [&](uint32_t word) {
+                float factor = 1.0f;
+#pragma unroll
+                for(int t = 0; t < TAIL; ++t) {
+                    const uint32_t mask = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(word), 18 + t, 1));
+                    const float picked = __uint_as_float(__builtin_amdgcn_bitop3_b32(mask, __float_as_uint(rho[8 + t]), 0x3f800000u, 0xCA));
+                    factor = t == 0 ? picked : factor * picked;
+                }
+                return factor;
+            };
             const uint32_t mismatches = fields[0] & FULL_MASK;      // of c: the flag bits of its mismatching positions
-            const float winner = first_group[0] * second_group[0];  // P(r|c) over the all-match product: 1 for a read ON c
+            const float winner = TAIL ? (first_group[0] * second_group[0]) * tail_factor(fields[0]) : first_group[0] * second_group[0];  // P(r|c) over the all-match product: 1 for a read ON c
             float others;                                           // the other listed barcodes
             {
                 float p[LIST];
 #pragma unroll
                 for(int o = 1; o < LIST; ++o) {
-                    p[o] = first_group[o] * second_group[o];
-                    if(PRIORS) { p[o] *= __uint_as_float(record_word(LIST + 4 + o)); }            // the barcode's prior over c's
+                    if(o < LISTED) {
+                        p[o] = first_group[o] * second_group[o];
+                        if(TAIL) { p[o] *= tail_factor(fields[o]); }
+                        if(PRIORS) { p[o] *= __uint_as_float(record_word(PLANE_WORDS + 4 + o)); }            // the barcode's prior over c's
+                    } else { p[o] = 0.0f; }
                 }
-                others = (((p[1] + p[2]) + (p[3] + p[4])) + ((p[5] + p[6]) + (p[7] + p[8]))) + (((p[9] + p[10]) + (p[11] + p[12])) + ((p[13] + p[14]) + p[15]));
+                others = LISTED == LIST ? (((p[1] + p[2]) + (p[3] + p[4])) + ((p[5] + p[6]) + (p[7] + p[8]))) + (((p[9] + p[10]) + (p[11] + p[12])) + ((p[13] + p[14]) + p[15]))
+                                        : ((p[1] + p[2]) + (p[3] + p[4])) + ((p[5] + p[6]) + p[7]);
             }
 
             // What was not scored.  A barcode n mismatches from c mismatches a read one mismatch from c (at position p) in at
-            // least n - 1 positions besides p, and p itself costs it at most max(rho_p, 1); rho_p is the winner itself, and the
-            // largest product over m positions besides p is at most min(H[m], H[m + 1] / rho_p).  For a read ON c the same
-            // expression is H[n]: the winner is exactly 1 and H falls with n.  So, with w_n barcodes n mismatches from c
+            // least n - 1 positions besides p, and p itself costs it at most max(rho_p, 1); rho_p is the winner itself, and a
+            // product over n - 1 or more positions besides p is at most H[n] / rho_p (with p it is one over n or more).  For
+            // a read ON c the same expression is H[n]: the winner is exactly 1.  So, with w_n barcodes n mismatches from c
             // (w_6: six or more; the host's counts), everything not scored is at most
-            //     max(winner, 1) * sum_n w_n * min(H[n - 1], H[n] / winner)
-            // One reciprocal serves it, the noise term and the posterior.
+            //     max(winner, 1) * sum_n w_n * H[n] / winner
+            // (rounds 2 and 3 also took the smaller of that and H[n - 1]: no read of the model is finished by it,
+            // profiles/tools/sim/list_size.py).  One reciprocal serves it, the noise term and the posterior.
             const float inverse_both = __builtin_amdgcn_rcpf(winner * everything_matches);
             const float inverse_winner = inverse_both * everything_matches;
-            float rest = __uint_as_float(record_word(LIST)) * fminf(h[2], h[3] * inverse_winner);
-            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 1)), fminf(h[3], h[4] * inverse_winner), rest);
-            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 2)), fminf(h[4], h[5] * inverse_winner), rest);
-            rest = __builtin_fmaf(__uint_as_float(record_word(LIST + 3)), fminf(h[5], h[6] * inverse_winner), rest);
-            rest *= fmaxf(winner, 1.0f) * near::SLOP;
+            float rest = __uint_as_float(record_word(PLANE_WORDS)) * h[3];
+            rest = __builtin_fmaf(__uint_as_float(record_word(PLANE_WORDS + 1)), h[4], rest);
+            rest = __builtin_fmaf(__uint_as_float(record_word(PLANE_WORDS + 2)), h[5], rest);
+            rest = __builtin_fmaf(__uint_as_float(record_word(PLANE_WORDS + 3)), h[6], rest);
+            rest *= (fmaxf(winner, 1.0f) * near::SLOP) * inverse_winner;
             const float x_listed = others * inverse_winner;
             const float x_rest = rest * inverse_winner;
-            const float noise_over_prior = PRIORS ? __uint_as_float(record_word(LIST + 4)) : uniform_noise_over_prior;
+            const float noise_over_prior = PRIORS ? __uint_as_float(record_word(PLANE_WORDS + 4)) : uniform_noise_over_prior;
             const float x_low = __builtin_fmaf(noise_over_prior, inverse_both, x_listed);
             // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp): 1 - y, y = x / (1 + x) = x - x^2 + x^3 up
             // to x^4 < 7e-14 (x is at most 5e-4 where it counts)
@@ -693,12 +794,10 @@ void pamld_stream_kernel(StageArgs args) {
         if(arriving) {
             if((deferred >> lane) & 1ull) {
                 const uint32_t slot = ring_count + static_cast<uint32_t>(__popcll(deferred & ((1ull << lane) - 1ull)));
-                ring[slot] = in.code[0];
-                ring[RING + slot] = in.code[1];
-                ring[2 * RING + slot] = in.quality[0];
-                ring[3 * RING + slot] = in.quality[1];
-                ring[4 * RING + slot] = in.state;
-                ring[5 * RING + slot] = static_cast<uint32_t>(read_ordinal);
+#pragma unroll
+                for(int w = 0; w < ROW_WORDS; ++w) { ring[w * RING + slot] = in.code[w]; ring[(ROW_WORDS + w) * RING + slot] = in.quality[w]; }
+                ring[2 * ROW_WORDS * RING + slot] = in.state;
+                ring[(2 * ROW_WORDS + 1) * RING + slot] = static_cast<uint32_t>(read_ordinal);
             }
             ring_count += arriving;
         }
