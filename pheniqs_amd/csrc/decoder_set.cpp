@@ -748,6 +748,7 @@ void DecoderSet::build_device_images() {
                             const int32_t length = c.barcode_length[0];
                             int32_t usable = 0;
                             std::vector<int32_t> listed[2];
+                            std::vector<uint16_t> near_table_of[2];
                             for(int32_t s2 = 0; s2 < 2; ++s2) {
                                 const auto& set = distinct[static_cast<size_t>(s2)];
                                 std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u), tag(set.size());
@@ -764,8 +765,72 @@ void DecoderSet::build_device_images() {
                                 d.cross_near_record[s2] = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                                 if(2 * tables.usable >= static_cast<int32_t>(set.size())) { ++usable; }
                                 listed[s2] = tables.listed;
+                                near_table_of[s2] = tables.table;
                             }
                             d.cross_near_ready = usable == 2 ? 1 : 0;
+                            if(d.uniform_prior && d.cross_near_ready && length >= 8) {
+                                // the streaming kernel (pamld_cross_stream.hpp): per segment the lookup table and the blocks of
+                                // pamld_stream.hpp over the segment's words, one listed word per plane word
+                                const int32_t near_listed = near_list(length);
+                                const int32_t list = stream_list(length);
+                                const int32_t block_words = cross_stream_block_words(length);
+                                const int32_t unique0 = static_cast<int32_t>(distinct[0].size()), unique1 = static_cast<int32_t>(distinct[1].size());
+                                const int32_t tail = length > 8 ? length - 8 : 0;
+                                auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10) | (((bits >> 8) & 0x3u) << 18); };
+                                bool fits = cross_stream_block_at(STREAM_WAVES, length, unique0, unique1, 1) + static_cast<uint32_t>(unique1) * static_cast<uint32_t>(block_words) * 4u < (1u << 18);
+                                for(int32_t s2 = 0; s2 < 2 && fits; ++s2) {
+                                    const auto& set = distinct[static_cast<size_t>(s2)];
+                                    const int32_t N = static_cast<int32_t>(set.size());
+                                    if(N >= static_cast<int32_t>(STREAM_UNKNOWN)) { fits = false; break; }
+                                    std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u);
+                                    for(size_t u = 0; u < set.size(); ++u) {
+                                        for(int32_t j = 0; j < length; ++j) {
+                                            const uint32_t two = (set[u] >> (2 * j)) & 3u;
+                                            low[u] |= (two & 1u) << j;
+                                            high[u] |= (two >> 1) << j;
+                                        }
+                                    }
+                                    const uint32_t first_block = cross_stream_block_at(STREAM_WAVES, length, unique0, unique1, s2);
+                                    std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(block_words), 0u);
+                                    for(int32_t b = 0; b < N; ++b) {
+                                        uint32_t* const to = &record[static_cast<size_t>(b) * static_cast<size_t>(block_words)];
+                                        std::vector<bool> is_listed(static_cast<size_t>(N), false);
+                                        for(int32_t k = 0; k < list; ++k) {
+                                            const size_t o = static_cast<size_t>(listed[s2][static_cast<size_t>(b) * static_cast<size_t>(near_listed) + static_cast<size_t>(k)]);
+                                            is_listed[o] = true;
+                                            to[k] = half(low[o]);
+                                            to[list + k] = half(high[o]);
+                                        }
+                                        // the words that are not listed, by their distance from b: 3, 4, 5, 6 or more; one closer than 3
+                                        // leaves the bound nothing to certify
+                                        double weight[4] = {0, 0, 0, 0};
+                                        bool crowded = false;
+                                        for(int32_t o = 0; o < N; ++o) {
+                                            if(is_listed[static_cast<size_t>(o)]) { continue; }
+                                            const int away = __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]));
+                                            if(away < 3) { crowded = true; } else { weight[std::min(away, 6) - 3] += 1.0; }
+                                        }
+                                        for(int k = 0; k < 4; ++k) {
+                                            const float rounded = crowded ? std::numeric_limits<float>::infinity() : static_cast<float>(weight[k]);
+                                            std::memcpy(&to[2 * list + k], &rounded, sizeof(float));
+                                        }
+                                    }
+                                    std::vector<uint32_t> table(length > 8 ? (static_cast<size_t>(1) << (2 * length)) : 65536, (STREAM_UNKNOWN << 18) | first_block);
+                                    const uint32_t positions = (1u << length) - 1u;
+                                    const std::vector<uint16_t>& named_by = near_table_of[s2];
+                                    for(uint32_t key = 0; key < (1u << (2 * length)); ++key) {
+                                        const uint32_t l = key & positions;
+                                        const uint32_t h = key >> length;
+                                        const uint16_t named = named_by[key];
+                                        if(named == NEAR_NO_BARCODE) { continue; }
+                                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] =
+                                            (static_cast<uint32_t>(named) << 18) | (first_block + static_cast<uint32_t>(named) * static_cast<uint32_t>(block_words) * 4u);
+                                    }
+                                    d.cross_stream_table[s2] = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
+                                    d.cross_stream_record[s2] = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                                }
+                                d.cross_stream_ready = fits ? 1 : 0;
+                            }
                             if(!d.uniform_prior && d.cross_near_ready) {
                                 // priors that differ: the listed words' priors over the combination's, along the row and the
                                 // column of every combination (device_types.hpp, cross_near_weight).  A combination whose own

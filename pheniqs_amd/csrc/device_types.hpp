@@ -46,6 +46,15 @@ constexpr uint32_t stream_words_bytes(int n_barcode, bool priors, int length = 8
 constexpr uint32_t stream_block_at(int waves, int n_barcode, bool priors, int length = 8) {
     return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * stream_ring_bytes(length) + stream_words_bytes(n_barcode, priors, length);
 }
+// pamld_cross_stream.hpp (two segment combinatorial sets, L nt each): a word's block is its list — stream_list(L) low plane
+// words then as many high plane words, one listed word per plane word — and the four weights of the bound; the LDS map in
+// front of the blocks: tables, factor rows, rings (state and ordinal), the two segments' words
+constexpr int cross_stream_block_words(int length) { return 2 * stream_list(length) + 4; }
+constexpr uint32_t cross_stream_block_at(int waves, int length, int unique0, int unique1, int segment) {
+    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 2u * 64u * 4u +
+           static_cast<uint32_t>((unique0 + 7) & ~7) * 8u + static_cast<uint32_t>((unique1 + 7) & ~7) * 8u +
+           (segment ? static_cast<uint32_t>(unique0) * static_cast<uint32_t>(cross_stream_block_words(length)) * 4u : 0u);
+}
 constexpr uint32_t STREAM_UNKNOWN = 0x3fffu;   // the index field of a lookup that names no barcode
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
@@ -177,6 +186,13 @@ struct DevDecoder {
     const uint16_t* cross_near_table[2];
     const uint32_t* cross_near_record[2];
     int32_t cross_near_ready;
+    // the streaming kernel of such sets (pamld_cross_stream.hpp; uniform priors, 8 to 10 nt words): per segment the lookup
+    // table of pamld_stream.hpp over the segment's distinct words — an entry = the LDS address of the word's block (18 bits)
+    // | the word's ordinal in its segment << 18, ordinal field STREAM_UNKNOWN for a word that names none — and the image
+    // of the blocks, cross_stream_block_words(L) words each
+    const uint32_t* cross_stream_table[2];
+    const uint32_t* cross_stream_record[2];
+    int32_t cross_stream_ready;
     // ... with priors that differ: per combination (c0, c1), 16 floats each.  cross_near_weight[0]: the noise term over
     // the combination's prior, then prior(c0, w) / prior(c0, c1) for the words w listed with c1 in its record;
     // cross_near_weight[1]: the largest prior over the combination's, then prior(w, c1) / prior(c0, c1) for the words

@@ -310,6 +310,8 @@ void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, 
 bool pamld_cross_near_supports(const DevDecoder& host_decoder);   // pamld_cross_near.hip: neighbour lists per segment of a two segment combinatorial set
 int pamld_cross_near_block(const DevDecoder& host_decoder);
 int launch_pamld_cross_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_cross_stream_supports(const DevDecoder& host_decoder);   // pamld_cross_stream.hip: the same sets (uniform priors, 8 to 10 nt), lists and factorised scan in one persistent kernel
+int launch_pamld_cross_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 bool pamld_pair_supports(const DevDecoder& host_decoder);   // pamld_pair.hip: paired barcodes, one barcode scored, in front of the product form kernels
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_wide_supports(const DevDecoder& host_decoder);

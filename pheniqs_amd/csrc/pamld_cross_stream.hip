@@ -1,0 +1,34 @@
+// Streaming kernel of two segment combinatorial barcode sets (pamld_cross_stream.hpp): equal segment lengths of 8 to 10 nt,
+// uniform priors, counters rebuilt from the records.
+#include "pamld_cross_stream.hpp"
+
+namespace phq {
+
+namespace {
+uint32_t bytes_needed(const DevDecoder& host_decoder) {
+    const int u0 = host_decoder.cross_unique[0], u1 = host_decoder.cross_unique[1];
+    switch(host_decoder.cross_length[0]) {
+        case 8: return cross_stream::Shape<8, STREAM_WAVES>::lds_bytes(u0, u1);
+        case 9: return cross_stream::Shape<9, STREAM_WAVES>::lds_bytes(u0, u1);
+        default: return cross_stream::Shape<10, STREAM_WAVES>::lds_bytes(u0, u1);
+    }
+}
+}
+
+bool pamld_cross_stream_supports(const DevDecoder& host_decoder) {
+    if(!pamld_cross_near_supports(host_decoder)) { return false; }
+    const int L = host_decoder.cross_length[0];
+    return host_decoder.cross_stream_ready != 0 && host_decoder.uniform_prior != 0 && L >= 8 && L <= 10 && host_decoder.use_lds_histogram == 0 &&
+           host_decoder.cross_identity != 0 && host_decoder.identity_index != 0 && bytes_needed(host_decoder) <= 160u * 1024u;
+}
+
+int launch_pamld_cross_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream) {
+    switch(host_decoder.cross_length[0]) {
+        case 8: return cross_stream::launch_one<8, STREAM_WAVES>(args, host_decoder, grid, stream);
+        case 9: return cross_stream::launch_one<9, STREAM_WAVES>(args, host_decoder, grid, stream);
+        case 10: return cross_stream::launch_one<10, STREAM_WAVES>(args, host_decoder, grid, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
+}  // namespace phq

@@ -97,6 +97,9 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
                 const bool crossed = factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);
+                // ... and where the streaming kernel of such sets takes the codec, lists and factorised scan are one launch too
+                static const bool no_cross_stream = std::getenv("PHQ_NO_CROSS_STREAM") != nullptr;
+                const bool cross_streamed = crossed && !no_stream && !no_cross_stream && args.defer_counters && pamld_cross_stream_supports(host_decoder);
                 const int64_t threads = listed ? pamld_near_block(host_decoder) : crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 static const int near_share = std::getenv("PHQ_GRID_SHARE_NEAR") ? std::atoi(std::getenv("PHQ_GRID_SHARE_NEAR")) : GRID_SHARE_NEAR;
@@ -110,7 +113,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
-                if(streamed || few) {
+                if(streamed || few || cross_streamed) {
                     // one workgroup per CU (two of the smaller ones of the few barcode kernel), a worklist segment per WAVE: what
                     // the second pass cannot decide either goes there
                     const int waves = few ? pamld_few_waves() : pamld_stream_waves();
@@ -123,11 +126,12 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     producer.carry_stride = 0;
                     {
                         Timed timed(timer, few ? KERNEL_PAMLD_PRODUCT : KERNEL_PAMLD_NEAR, stream);
-                        status = few ? launch_pamld_few(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s);
+                        status = few ? launch_pamld_few(producer, host_decoder, stream_grid, s)
+                               : cross_streamed ? launch_pamld_cross_stream(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s);
                     }
                     if(status != 0) { return status; }
                     const dim3 segment_grid(static_cast<unsigned>(segments));
-                    trace_worklist(few ? "the few barcode kernel" : "the streaming kernel", producer, segment_grid.x, s);
+                    trace_worklist(few ? "the few barcode kernel" : cross_streamed ? "the streaming kernel of the set" : "the streaming kernel", producer, segment_grid.x, s);
                     StageArgs consumer = producer;
                     consumer.worklist_role = 2;
                     if(pamld_exact_supports(host_decoder)) {
