@@ -48,10 +48,10 @@ constexpr uint32_t stream_block_at(int waves, int n_barcode, bool priors, int le
 }
 // pamld_cross_stream.hpp (two segment combinatorial sets, L nt each): a word's block is its list — stream_list(L) low plane
 // words then as many high plane words, one listed word per plane word — and the four weights of the bound; the LDS map in
-// front of the blocks: tables, factor rows, rings (state and ordinal), the two segments' words
+// front of the blocks: tables, factor rows, three rings a wave (state and ordinal), the two segments' words
 constexpr int cross_stream_block_words(int length) { return 2 * stream_list(length) + 4; }
 constexpr uint32_t cross_stream_block_at(int waves, int length, int unique0, int unique1, int segment) {
-    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 2u * 64u * 4u +
+    return static_cast<uint32_t>(waves) * 8192u + 1040u + 129u * 16u + static_cast<uint32_t>(waves) * 3u * 2u * 64u * 4u +
            static_cast<uint32_t>((unique0 + 7) & ~7) * 8u + static_cast<uint32_t>((unique1 + 7) & ~7) * 8u +
            (segment ? static_cast<uint32_t>(unique0) * static_cast<uint32_t>(cross_stream_block_words(length)) * 4u : 0u);
 }

@@ -52,11 +52,12 @@ template <int L, int WAVES> struct Shape {
     static constexpr uint32_t BLOCK_BYTES = BLOCK_WORDS * 4u;
     static constexpr int BLOCK_QUADS = (2 * LISTED + 4) / 4;       // what pass A reads of a block
     static constexpr int RING_PLANES = 2;                          // carried state, ordinal: pass C reads the input row again (it is in L2)
+    static constexpr int RINGS = 3;                                // per wave: segment 0 to scan, segment 1 to scan, both
     static constexpr uint32_t TABLE_BYTES = WAVES * 8192u;
     static constexpr uint32_t FACTOR_AT = TABLE_BYTES;
     static constexpr uint32_t DOUBLE_AT = FACTOR_AT + 1040;
     static constexpr uint32_t RING_AT = DOUBLE_AT + FACTOR_ROWS * 16;
-    static constexpr uint32_t RING_BYTES = RING_PLANES * RING * 4;
+    static constexpr uint32_t RING_BYTES = RINGS * RING_PLANES * RING * 4;
     static constexpr uint32_t WORDS_AT = RING_AT + WAVES * RING_BYTES;
     __host__ __device__ static constexpr uint32_t words_bytes(int unique) { return static_cast<uint32_t>((unique + 7) & ~7) * 8u; }
     __host__ __device__ static constexpr uint32_t words_at(int unique0, int s) { return WORDS_AT + (s ? words_bytes(unique0) : 0u); }
@@ -75,6 +76,7 @@ template <int L, int WAVES> struct Shape {
 typedef uint32_t Quad __attribute__((ext_vector_type(4)));
 typedef float Pair __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const float* LdsFloats;
+typedef __attribute__((address_space(3))) const uint32_t* LdsWords;
 typedef __attribute__((address_space(3))) const Quad* LdsQuads;
 typedef __attribute__((address_space(3))) const Pair* LdsPairs;
 using near::and_or;
@@ -137,16 +139,16 @@ void pamld_cross_stream_kernel(StageArgs args) {
     *reinterpret_cast<float*>(lds_raw + lane_const + 256u) = 1.0f;
     __syncthreads();
 
-    const StatSink sink{histogram, args.stats, args.defer_counters != 0};
+    const uint32_t histogram_at = Layout::histogram_at(unique[0], unique[1]);
     const int64_t n = args.n_read;
     const int64_t tiles = (n + 63) / 64;
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
     const uint32_t* const nearest[SEGMENTS] = {d.cross_stream_table[0], d.cross_stream_table[1]};
-    uint32_t* const ring = reinterpret_cast<uint32_t*>(lds_raw + Layout::RING_AT + wave * Layout::RING_BYTES);
+    const uint32_t rings_at = Layout::RING_AT + wave * Layout::RING_BYTES;      // this wave's three rings: by what pass C has to scan
     const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
     uint32_t* const segment = args.worklist + own_segment * args.worklist_stride;
     uint32_t segment_count = 0;
-    uint32_t ring_count = 0;
+    uint32_t ring_count[Layout::RINGS] = {0, 0, 0};
 
     const int high_quality_threshold = min(max(d.high_quality_threshold, 0), 128);
     const uint32_t high_quality_addend = static_cast<uint32_t>(128 - high_quality_threshold) * 0x01010101u;
@@ -242,13 +244,115 @@ void pamld_cross_stream_kernel(StageArgs args) {
         return factor;
     };
 
+    // pass A of ONE segment (pamld_stream.hpp): the word named by the lookup and the words listed with it scored through the
+    // per read tables, every other word bounded by four distance classes — x_s = (listed + rest) / winner, in units of the
+    // segment's all-match product
+    struct Score { float winner, matches, x_listed, x_rest; uint32_t k, high_mismatch, ordinal, mismatches; bool known; };
+    auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, Score& out) {
+        const uint32_t block = looked_up & 0x3ffffu;
+        const uint32_t ordinal = looked_up >> 18;                              // the word's ordinal in its segment
+        const bool known = ordinal != STREAM_UNKNOWN;
+        Quad record[Layout::BLOCK_QUADS];
+#pragma unroll
+        for(int quad = 0; quad < Layout::BLOCK_QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
+        auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
+        const uint32_t observed = sliced;
+        const uint32_t observed_high = lut::high_plane(observed);
+        const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
+        float rho[RHO];
+        float everything_matches = 1.0f;
+#pragma unroll
+        for(int j = 0; j < RHO; ++j) {
+            if(j < L) {
+                const uint32_t word = q[j >> 2] & 0x7f7f7f7fu;
+                const int byte = j & 3;
+                const uint32_t shifted = byte == 0 ? (word << 3) : (word >> (8 * byte - 3));
+                const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x3f8u, Layout::FACTOR_AT));
+                everything_matches = j == 0 ? pair.x : everything_matches * pair.x;
+                rho[j] = pair.y;
+            } else { rho[j] = 1.0f; }
+        }
+        float ge[3][5];
+        build_tables(rho, ge);
+        uint32_t fields[LISTED];
+#pragma unroll
+        for(int o = 0; o < LISTED; ++o) { fields[o] = (observed_low ^ record_word(o)) | (observed_high ^ record_word(LISTED + o)); }
+        float first_group[LISTED];
+        float second_group[LISTED];
+#pragma unroll
+        for(int o = 0; o < LISTED; ++o) {
+            first_group[o] = entry(fields[o], 0, 0);
+            second_group[o] = entry(fields[o], 1, 1);
+        }
+        // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6 (pamld_stream.hpp)
+        float h[7];
+        {
+            float tabled[7];
+#pragma unroll
+            for(int m = 1; m <= 6; ++m) {
+                tabled[m] = 0.0f;
+                bool any = false;
+#pragma unroll
+                for(int a = 0; a <= 4; ++a) {
+                    const int o = m - a;
+                    if(o >= 0 && o <= 4 && a <= Layout::positions(0) && o <= Layout::positions(1) && (m >= 3 || TAIL)) {
+                        const float product = ge[0][a] * ge[1][o];
+                        tabled[m] = any ? fmaxf(tabled[m], product) : product;
+                        any = true;
+                    }
+                }
+            }
+#pragma unroll
+            for(int m = 3; m <= 6; ++m) {
+                h[m] = tabled[m];
+#pragma unroll
+                for(int t = 1; t <= TAIL; ++t) { h[m] = fmaxf(h[m], tabled[m - t] * ge[2][t]); }
+            }
+        }
+        const uint32_t mismatches = fields[0] & FULL_MASK;
+        float winner = first_group[0] * second_group[0];
+        if(TAIL) { winner *= tail_factor(fields[0], rho); }
+        float others = 0.0f;
+#pragma unroll
+        for(int o = 1; o < LISTED; ++o) {
+            float p = first_group[o] * second_group[o];
+            if(TAIL) { p *= tail_factor(fields[o], rho); }
+            others = o == 1 ? p : others + p;
+        }
+        const float inverse_winner = __builtin_amdgcn_rcpf(winner);
+        float rest = __uint_as_float(record_word(2 * LISTED)) * h[3];
+        rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 1)), h[4], rest);
+        rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 2)), h[5], rest);
+        rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 3)), h[6], rest);
+        rest *= (fmaxf(winner, 1.0f) * near::SLOP) * inverse_winner;
+        const uint32_t k = static_cast<uint32_t>(__popc(mismatches));
+        const bool high_mismatch = k == 1 && winner <= rho_at_threshold && (zero_is_high || winner != 1.0f);
+        out.winner = winner;
+        out.matches = everything_matches;
+        out.x_listed = others * inverse_winner;
+        out.x_rest = rest * inverse_winner;
+        out.k = k;
+        out.high_mismatch = high_mismatch ? 1u : 0u;
+        out.ordinal = known ? ordinal : 0u;
+        out.mismatches = mismatches;
+        out.known = known;
+    };
+    // a segment pass A leaves alone: the word is known, at most one mismatch away, and x_s is small and tightly bounded (half of
+    // pass A's allowance for the bounded part: the other half is the scanned segment's)
+    auto segment_good = [&](const Score& score, bool strict) {
+        return strict && score.known && score.k <= 1 && score.x_listed <= near::LISTED_MAX && score.x_rest <= 0.5f * near::REST_MAX;
+    };
+
     // ---- pass C: the factorised scan (pamld_cross.hpp) over the wave's ring ------------------------------------------------
-    auto drain = [&](uint32_t count) {
+    // mode (wave uniform): 0 / 1 = only that segment is scanned, the other one is scored again as pass A scored it (it was
+    // good: a lookup, the listed words and the bound instead of a scan over every word); 2 = both are scanned
+    auto drain = [&](int mode, uint32_t count) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): pass A's placeholder stores of these reads have left
         const bool live = lane < count;
         const uint32_t slot = live ? lane : 0u;
-        const uint32_t state = ring[slot];
-        const int64_t i = static_cast<int64_t>(ring[RING + slot]);
+        const uint32_t ring_at = rings_at + static_cast<uint32_t>(mode) * (Layout::RING_PLANES * RING * 4u) + slot * 4u;      // an LDS address: no generic pointer
+        const uint32_t state = *(LdsWords)static_cast<uintptr_t>(ring_at);
+        const int64_t i = static_cast<int64_t>(*(LdsWords)static_cast<uintptr_t>(ring_at + RING * 4u));
         uint32_t code_row[ROW_WORDS];
         uint32_t quality_row[ROW_WORDS];
         {
@@ -297,90 +401,116 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 outside |= (flags & 0xfu) << (8 * w + 2);
                 high_quality |= (flags >> 4) << (8 * w + 2);
             }
-            float rho[RHO];
-#pragma unroll
-            for(int j = 0; j < RHO; ++j) {
-                if(j < L) { rho[j] = factor_single[(row[j >> 2] >> (8 * (j & 3))) & 0xffu].y; }
-                else { rho[j] = 1.0f; }
-            }
-            const uint32_t observed_high = lut::high_plane(observed);
-            const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
-            float unused[3][5];
-            build_tables(rho, unused);
-
-            // the segment's words eight at a time (pamld_lut.hpp): per block its maximum and its sum; across blocks the running
-            // maximum, which block holds it, that block's sum set aside, the sum of every other block
-            float others_sum = 0;
-            float held_sum = 0;
-            float best_value = 0;
+            float top = 0;
+            float rest = 0;
             float second = 0;
-            int best_block = -1;
-            auto block_values = [&](const uint32_t (&w)[16], float (&p)[8]) {
-#pragma unroll
-                for(int k = 0; k < 8; ++k) {
-                    const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[8 + k]);
-                    p[k] = entry(fields, 0, 0) * entry(fields, 1, 1);
-                    if(TAIL) { p[k] *= tail_factor(fields, rho); }
-                }
-            };
-            const uint4* const blocks = reinterpret_cast<const uint4*>(lds_words[s]);
-            const int n_blocks = (unique[s] + 7) >> 3;
-#pragma unroll 2
-            for(int f = 0; f < n_blocks; ++f) {
-                uint32_t w[16];
-#pragma unroll
-                for(int quad = 0; quad < 4; ++quad) {
-                    const uint4 four = blocks[4 * f + quad];
-                    w[4 * quad] = four.x; w[4 * quad + 1] = four.y; w[4 * quad + 2] = four.z; w[4 * quad + 3] = four.w;
-                }
-                float p[8];
-                block_values(w, p);
-                if(8 * f + 8 > unique[s]) {
-#pragma unroll
-                    for(int k = 1; k < 8; ++k) { if(8 * f + k >= unique[s]) { p[k] = 0.0f; } }
-                }
-                const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
-                const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-                const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
-                second = __builtin_amdgcn_fmed3f(best_value, block_max, second);
-                others_sum += takes_over ? held_sum : block_sum;
-                held_sum = takes_over ? block_sum : held_sum;
-                best_block = takes_over ? f : best_block;
-                best_value = takes_over ? block_max : best_value;
-            }
-            // inside the winning block: the winner (first of equals) and the sum of the other seven, recomputed
-            const float top = best_value;
-            float rest = others_sum;
             int best = -1;
             uint32_t flags_of_best = 0;
-            {
-                const int block = best_block < 0 ? 0 : best_block;
-                uint32_t w[16];
-#pragma unroll
-                for(int k = 0; k < 16; ++k) { w[k] = lds_words[s][16 * block + k]; }
-                float p[8];
-                block_values(w, p);
+            if(mode == 2 || mode == s) {
+                float rho[RHO];
+    #pragma unroll
+                for(int j = 0; j < RHO; ++j) {
+                    if(j < L) { rho[j] = factor_single[(row[j >> 2] >> (8 * (j & 3))) & 0xffu].y; }
+                    else { rho[j] = 1.0f; }
+                }
+                const uint32_t observed_high = lut::high_plane(observed);
+                const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
+                float unused[3][5];
+                build_tables(rho, unused);
+
+                // the segment's words eight at a time (pamld_lut.hpp): per block its maximum and its sum; across blocks the running
+                // maximum, which block holds it, that block's sum set aside, the sum of every other block
+                float others_sum = 0;
+                float held_sum = 0;
+                float best_value = 0;
+                int best_block = -1;
+                auto block_values = [&](const uint32_t (&w)[16], float (&p)[8]) {
+    #pragma unroll
+                    for(int k = 0; k < 8; ++k) {
+                        const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[8 + k]);
+                        p[k] = entry(fields, 0, 0) * entry(fields, 1, 1);
+                        if(TAIL) { p[k] *= tail_factor(fields, rho); }
+                    }
+                };
+                const uint32_t words_at = s == 0 ? Layout::WORDS_AT : Layout::WORDS_AT + Layout::words_bytes(unique[0]);      // LDS addresses: no generic pointers
+                const LdsQuads blocks = (LdsQuads)static_cast<uintptr_t>(words_at);
+                const LdsWords words = (LdsWords)static_cast<uintptr_t>(words_at);
+                const int n_blocks = (unique[s] + 7) >> 3;
+    #pragma unroll 2
+                for(int f = 0; f < n_blocks; ++f) {
+                    uint32_t w[16];
+    #pragma unroll
+                    for(int quad = 0; quad < 4; ++quad) {
+                        const Quad four = blocks[4 * f + quad];
+                        w[4 * quad] = four.x; w[4 * quad + 1] = four.y; w[4 * quad + 2] = four.z; w[4 * quad + 3] = four.w;
+                    }
+                    float p[8];
+                    block_values(w, p);
+                    if(8 * f + 8 > unique[s]) {
+    #pragma unroll
+                        for(int k = 1; k < 8; ++k) { if(8 * f + k >= unique[s]) { p[k] = 0.0f; } }
+                    }
+                    const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+                    const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                    const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+                    second = __builtin_amdgcn_fmed3f(best_value, block_max, second);
+                    others_sum += takes_over ? held_sum : block_sum;
+                    held_sum = takes_over ? block_sum : held_sum;
+                    best_block = takes_over ? f : best_block;
+                    best_value = takes_over ? block_max : best_value;
+                }
+                // inside the winning block: the winner (first of equals) and the sum of the other seven, recomputed
+                top = best_value;
+                rest = others_sum;
                 {
-                    const int limit = unique[s] - 8 * block;
-#pragma unroll
-                    for(int k = 1; k < 8; ++k) { p[k] = k < limit ? p[k] : 0.0f; }
+                    const int block = best_block < 0 ? 0 : best_block;
+                    uint32_t w[16];
+    #pragma unroll
+                    for(int k = 0; k < 16; ++k) { w[k] = words[16 * block + k]; }
+                    float p[8];
+                    block_values(w, p);
+                    {
+                        const int limit = unique[s] - 8 * block;
+    #pragma unroll
+                        for(int k = 1; k < 8; ++k) { p[k] = k < limit ? p[k] : 0.0f; }
+                    }
+                    int within = -1;
+                    float q[8];
+    #pragma unroll
+                    for(int k = 7; k >= 0; --k) {
+                        const bool is_top = p[k] == best_value;
+                        within = is_top ? k : within;
+                        q[k] = is_top ? 0.0f : p[k];
+                    }
+                    const float inner_rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                    const float inner_second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+                    const bool crowded = held_sum - inner_rest >= 1.5f * best_value;         // the block's sum holds the maximum twice
+                    second = fmaxf(second, crowded ? best_value : inner_second);
+                    rest += crowded ? best_value : inner_rest;
+                    if(best_block >= 0 && best_value > 0.0f && within >= 0) { best = 8 * block + within; }
+                    const int at = 16 * (best < 0 ? 0 : best / 8) + (best < 0 ? 0 : best % 8);
+                    flags_of_best = (observed_low ^ words[at]) | (observed_high ^ words[at + 8]);
                 }
-                int within = -1;
-                float q[8];
+            } else {
+                // the segment pass A found good: the same lookup, listed words and bound again
+                uint32_t key = 0;
+                bool strict = true;
 #pragma unroll
-                for(int k = 7; k >= 0; --k) {
-                    const bool is_top = p[k] == best_value;
-                    within = is_top ? k : within;
-                    q[k] = is_top ? 0.0f : p[k];
+                for(int w = 0; w < G; ++w) {
+                    const uint32_t codes = (observed >> (8 * w + 2)) & 0xffu;
+                    if(w < 2) { key |= codes << (8 * w); }
+                    else { key |= ((codes & ((1u << TAIL) - 1u)) << 16) | (((codes >> 4) & ((1u << TAIL) - 1u)) << (16 + TAIL)); }
+                    strict = strict && (quality_words[w] & 0x80808080u) == 0;
                 }
-                const float inner_rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-                const float inner_second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
-                const bool crowded = held_sum - inner_rest >= 1.5f * best_value;         // the block's sum holds the maximum twice
-                second = fmaxf(second, crowded ? best_value : inner_second);
-                rest += crowded ? best_value : inner_rest;
-                if(best_block >= 0 && best_value > 0.0f && within >= 0) { best = 8 * block + within; }
-                const int at = 16 * (best < 0 ? 0 : best / 8) + (best < 0 ? 0 : best % 8);
-                flags_of_best = (observed_low ^ lds_words[s][at]) | (observed_high ^ lds_words[s][at + 8]);
+                strict = strict && outside == 0;
+                Score score;
+                score_segment(quality_words, observed, nearest[s][key], score);
+                top = score.winner;
+                rest = score.x_listed * score.winner;
+                second = rest;
+                best = static_cast<int>(score.ordinal);
+                flags_of_best = score.mismatches;
+                if(!segment_good(score, strict)) { certain = false; }
             }
             if(best < 0) { certain = false; best = 0; }       // underflow: everything rounded to zero
             certain = certain && top >= cross::SMALLEST_CERTAIN && (second <= cross::RUNNER_UP * top);
@@ -419,27 +549,31 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 if(!(others * everything_matches <= cross::DOMINANCE * best_conditional) || !(fabs(confidence_margin) > 1e-9)) { defer = true; }
             }
             if(!defer && live) {
+                // the counters of a codec this size: count, distance and confidence of a classified read are rebuilt from its
+                // record (counters.hip); the two rare counts go straight to the counter buffer, bin 0 to the workgroup's copy
                 int bin = best + 1;
                 uint8_t status = STATUS_PASS;
+                unsigned long long* const bin_words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN;
                 if(!is_noise) {                                                       // pamld.cpp:96
                     if(confidence_margin > 0) {                                       // pamld.cpp:99
                         if(hq_threshold > 0 && hq_distance >= hq_threshold) { r.qcfail = true; }
-                        stat_add_confidence(d, sink, bin, r.qcfail ? 0 : 1, confidence);
                     } else {
-                        stat_add(d, sink, bin, 0, FIELD_LOW_CONFIDENCE, 1ull);
+                        atomicAdd(&bin_words[FIELD_LOW_CONFIDENCE], 1ull);
                         r.qcfail = true;
                         status = STATUS_LOW_CONFIDENCE;
                     }
                 } else {
-                    stat_add(d, sink, bin, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                    atomicAdd(&bin_words[FIELD_LOW_CONDITIONAL_CONFIDENCE], 1ull);
                     r.qcfail = true;
                     bin = 0;
                     distance = 0;
                     hq_distance = 0;
                     confidence = 0;
                     status = STATUS_NOISE;
+                    // Decoder<T>::classify then Classifier<T>::classify of the unclassified bin (decoder.h:68-76, classifier.h:78-86)
+                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long*)static_cast<uintptr_t>(histogram_at + 8u * (STAT_JOB_WORDS + FIELD_COUNT)), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                decoder_tail(d, sink, r, bin, distance);
+                if(multiplexing) { r.channel = bin > 0 ? d.barcode_index[bin - 1] : 0; }
                 DevResult out;
                 out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
                 out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
@@ -463,9 +597,8 @@ void pamld_cross_stream_kernel(StageArgs args) {
     };
 
     // ---- the wave's loop over its tiles: pass A, then the ring (software pipeline of pamld_stream.hpp) ------------------
-    struct Keyed { uint32_t quality[ROW_WORDS]; uint32_t state; uint32_t sliced[SEGMENTS]; uint32_t looked_up[SEGMENTS]; bool all_strict; };
+    struct Keyed { uint32_t quality[ROW_WORDS]; uint32_t state; uint32_t sliced[SEGMENTS]; uint32_t looked_up[SEGMENTS]; bool strict[SEGMENTS]; };
     auto key_and_look_up = [&](const Inputs& in, Keyed& to) {
-        bool strict = true;
 #pragma unroll
         for(int s = 0; s < SEGMENTS; ++s) {
             uint32_t x[G];
@@ -489,11 +622,10 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 if(w < 2) { key |= codes << (8 * w); }
                 else { key |= ((codes & ((1u << TAIL) - 1u)) << 16) | (((codes >> 4) & ((1u << TAIL) - 1u)) << (16 + TAIL)); }
             }
-            strict = strict && bits == L && every_byte == 0x80808080u && beyond_rows == 0;
+            to.strict[s] = bits == L && every_byte == 0x80808080u && beyond_rows == 0;
             to.sliced[s] = sliced;
             to.looked_up[s] = nearest[s][key];
         }
-        to.all_strict = strict;
 #pragma unroll
         for(int w = 0; w < ROW_WORDS; ++w) { to.quality[w] = in.quality[w]; }
         to.state = in.state;
@@ -508,7 +640,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
         key_and_look_up(first_inputs, current);
     }
     for(bool more = true; more;) {
-        unsigned long long deferred = 0;
+        unsigned long long deferred_to[Layout::RINGS] = {0, 0, 0};
         const uint32_t state_in = current.state;
         int64_t read_ordinal = 0;
         if(tile < tiles) {
@@ -518,7 +650,8 @@ void pamld_cross_stream_kernel(StageArgs args) {
             read_ordinal = first + at;
             const uint32_t sliced_of[SEGMENTS] = {current.sliced[0], current.sliced[1]};
             const uint32_t looked_up_of[SEGMENTS] = {current.looked_up[0], current.looked_up[1]};
-            const bool all_strict = current.all_strict;
+            const bool strict_of[SEGMENTS] = {current.strict[0], current.strict[1]};
+            const bool all_strict = strict_of[0] && strict_of[1];
             uint32_t quality_in[ROW_WORDS];
 #pragma unroll
             for(int w = 0; w < ROW_WORDS; ++w) { quality_in[w] = current.quality[w]; }
@@ -535,97 +668,23 @@ void pamld_cross_stream_kernel(StageArgs args) {
             // per segment: the winner over the segment's all-match product, the listed and the bounded part of x_s
             float winner_of[SEGMENTS], x_listed_of[SEGMENTS], x_rest_of[SEGMENTS], matches_of[SEGMENTS];
             uint32_t k_of[SEGMENTS], hq_of[SEGMENTS], ordinal_of[SEGMENTS];
+            bool good_of[SEGMENTS];
             bool usable = true;
 #pragma unroll
             for(int s = 0; s < SEGMENTS; ++s) {
                 uint32_t q[G];
                 segment_words(quality_in, s, q);
-                const uint32_t block = looked_up_of[s] & 0x3ffffu;
-                const uint32_t ordinal = looked_up_of[s] >> 18;                              // the word's ordinal in its segment
-                const bool known = ordinal != STREAM_UNKNOWN;
-                Quad record[Layout::BLOCK_QUADS];
-#pragma unroll
-                for(int quad = 0; quad < Layout::BLOCK_QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
-                auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
-                const uint32_t observed = sliced_of[s];
-                const uint32_t observed_high = lut::high_plane(observed);
-                const uint32_t observed_low = lut::low_plane(observed) | wave_bytes;
-                float rho[RHO];
-                float everything_matches = 1.0f;
-#pragma unroll
-                for(int j = 0; j < RHO; ++j) {
-                    if(j < L) {
-                        const uint32_t word = q[j >> 2] & 0x7f7f7f7fu;
-                        const int byte = j & 3;
-                        const uint32_t shifted = byte == 0 ? (word << 3) : (word >> (8 * byte - 3));
-                        const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x3f8u, Layout::FACTOR_AT));
-                        everything_matches = j == 0 ? pair.x : everything_matches * pair.x;
-                        rho[j] = pair.y;
-                    } else { rho[j] = 1.0f; }
-                }
-                float ge[3][5];
-                build_tables(rho, ge);
-                uint32_t fields[LISTED];
-#pragma unroll
-                for(int o = 0; o < LISTED; ++o) { fields[o] = (observed_low ^ record_word(o)) | (observed_high ^ record_word(LISTED + o)); }
-                float first_group[LISTED];
-                float second_group[LISTED];
-#pragma unroll
-                for(int o = 0; o < LISTED; ++o) {
-                    first_group[o] = entry(fields[o], 0, 0);
-                    second_group[o] = entry(fields[o], 1, 1);
-                }
-                // H[n]: the largest product over n or more mismatching positions, n = 3 .. 6 (pamld_stream.hpp)
-                float h[7];
-                {
-                    float tabled[7];
-#pragma unroll
-                    for(int m = 1; m <= 6; ++m) {
-                        tabled[m] = 0.0f;
-                        bool any = false;
-#pragma unroll
-                        for(int a = 0; a <= 4; ++a) {
-                            const int o = m - a;
-                            if(o >= 0 && o <= 4 && a <= Layout::positions(0) && o <= Layout::positions(1) && (m >= 3 || TAIL)) {
-                                const float product = ge[0][a] * ge[1][o];
-                                tabled[m] = any ? fmaxf(tabled[m], product) : product;
-                                any = true;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for(int m = 3; m <= 6; ++m) {
-                        h[m] = tabled[m];
-#pragma unroll
-                        for(int t = 1; t <= TAIL; ++t) { h[m] = fmaxf(h[m], tabled[m - t] * ge[2][t]); }
-                    }
-                }
-                const uint32_t mismatches = fields[0] & FULL_MASK;
-                float winner = first_group[0] * second_group[0];
-                if(TAIL) { winner *= tail_factor(fields[0], rho); }
-                float others = 0.0f;
-#pragma unroll
-                for(int o = 1; o < LISTED; ++o) {
-                    float p = first_group[o] * second_group[o];
-                    if(TAIL) { p *= tail_factor(fields[o], rho); }
-                    others = o == 1 ? p : others + p;
-                }
-                const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-                float rest = __uint_as_float(record_word(2 * LISTED)) * h[3];
-                rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 1)), h[4], rest);
-                rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 2)), h[5], rest);
-                rest = __builtin_fmaf(__uint_as_float(record_word(2 * LISTED + 3)), h[6], rest);
-                rest *= (fmaxf(winner, 1.0f) * near::SLOP) * inverse_winner;
-                const uint32_t k = static_cast<uint32_t>(__popc(mismatches));
-                const bool high_mismatch = k == 1 && winner <= rho_at_threshold && (zero_is_high || winner != 1.0f);
-                winner_of[s] = winner;
-                matches_of[s] = everything_matches;
-                x_listed_of[s] = others * inverse_winner;
-                x_rest_of[s] = rest * inverse_winner;
-                k_of[s] = k;
-                hq_of[s] = high_mismatch ? 1u : 0u;
-                ordinal_of[s] = known ? ordinal : 0u;
-                usable = usable && known && k <= 1;
+                Score score;
+                score_segment(q, sliced_of[s], looked_up_of[s], score);
+                winner_of[s] = score.winner;
+                matches_of[s] = score.matches;
+                x_listed_of[s] = score.x_listed;
+                x_rest_of[s] = score.x_rest;
+                k_of[s] = score.k;
+                hq_of[s] = score.high_mismatch;
+                ordinal_of[s] = score.ordinal;
+                good_of[s] = segment_good(score, strict_of[s]);
+                usable = usable && score.known && score.k <= 1;
             }
 
             // both segments together: others / winner = x_0 + x_1 + x_0 x_1, between its listed part and listed + bound
@@ -658,7 +717,14 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 const uint32_t channel = (finished && multiplexing) ? index : incoming_channel;
                 __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
             }
-            deferred = __ballot(active && !finished);
+            {
+                // which ring: a segment pass A found good is not scanned again
+                const bool left = active && !finished;
+                const bool bad0 = !good_of[0], bad1 = !good_of[1];
+                deferred_to[2] = __ballot(left && bad0 && bad1);
+                deferred_to[1] = __ballot(left && !bad0 && bad1);
+                deferred_to[0] = __ballot(left && !bad1);
+            }
             if(last_stage) {
                 outgoing_pass += static_cast<uint32_t>(__popcll(__ballot(active && finished && !qcfail)));
                 outgoing_fail += static_cast<uint32_t>(__popcll(__ballot(active && finished && qcfail)));
@@ -667,18 +733,34 @@ void pamld_cross_stream_kernel(StageArgs args) {
         } else {
             more = false;
         }
-        const uint32_t arriving = static_cast<uint32_t>(__popcll(deferred));
-        if(ring_count + arriving > RING || (!more && ring_count > 0)) {
-            drain(ring_count);
-            ring_count = 0;
+        // a ring its arrivals would overflow (or, behind the last tile, one that holds anything) is scanned first — one call
+        // site, the ring's number a scalar
+        uint32_t arriving[Layout::RINGS];
+#pragma unroll
+        for(int m = 0; m < Layout::RINGS; ++m) { arriving[m] = static_cast<uint32_t>(__popcll(deferred_to[m])); }
+        for(;;) {
+            const bool due0 = ring_count[0] + arriving[0] > RING || (!more && ring_count[0] > 0);
+            const bool due1 = ring_count[1] + arriving[1] > RING || (!more && ring_count[1] > 0);
+            const bool due2 = ring_count[2] + arriving[2] > RING || (!more && ring_count[2] > 0);
+            if(__builtin_expect(!(due0 || due1 || due2), 1)) { break; }      // the scan is the cold path: what it spills, it spills there
+            const int m = due0 ? 0 : due1 ? 1 : 2;
+            drain(m, m == 0 ? ring_count[0] : m == 1 ? ring_count[1] : ring_count[2]);
+            ring_count[0] = m == 0 ? 0u : ring_count[0];
+            ring_count[1] = m == 1 ? 0u : ring_count[1];
+            ring_count[2] = m == 2 ? 0u : ring_count[2];
         }
-        if(arriving) {
-            if((deferred >> lane) & 1ull) {
-                const uint32_t slot = ring_count + static_cast<uint32_t>(__popcll(deferred & ((1ull << lane) - 1ull)));
-                ring[slot] = state_in;
-                ring[RING + slot] = static_cast<uint32_t>(read_ordinal);
+#pragma unroll
+        for(int m = 0; m < Layout::RINGS; ++m) {
+            const unsigned long long deferred = deferred_to[m];
+            if(arriving[m]) {
+                if((deferred >> lane) & 1ull) {
+                    const uint32_t slot = ring_count[m] + static_cast<uint32_t>(__popcll(deferred & ((1ull << lane) - 1ull)));
+                    const uint32_t ring_at = rings_at + static_cast<uint32_t>(m) * (Layout::RING_PLANES * RING * 4u) + slot * 4u;
+                    *(__attribute__((address_space(3))) uint32_t*)static_cast<uintptr_t>(ring_at) = state_in;
+                    *(__attribute__((address_space(3))) uint32_t*)static_cast<uintptr_t>(ring_at + RING * 4u) = static_cast<uint32_t>(read_ordinal);
+                }
+                ring_count[m] += arriving[m];
             }
-            ring_count += arriving;
         }
     }
     if(lane == 0) {
