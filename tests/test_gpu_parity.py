@@ -1048,6 +1048,37 @@ def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=2)
 
 
+@pytest.mark.parametrize("length,counts", [(8, (24, 20)), (9, (20, 24)), (10, (24, 20)), (8, (96, 96)), (10, (128, 17))])
+def test_combinatorial_sets_in_the_streaming_kernel(oracle, torch_cuda, length, counts):
+    """Dual index sets of 8 to 10 nt words holding every combination, past the workgroup histogram (340 bins): lists and
+    factorised scan in one persistent kernel (pamld_cross_stream.hpp) — per segment the lookup, the listed words, the
+    bound; three rings by what the second pass has to scan.  N calls, qualities of 0 and of 128 and more, uniform
+    qualities (exact ties), short observations; first in the chain with and without a flag plane and behind another
+    decoder (the state word); a batch in two pieces; both modes."""
+    rng = np.random.default_rng(4242 + 100 * length + counts[0])
+    segments = [synthetic.barcode_set(rng, c, length, min_distance=3) for c in counts]
+    front = synthetic.barcode_set(rng, 5, 8, min_distance=3)
+    spec = {"input segment cardinality": 3,
+            "cellular": [synthetic.decoder_spec("pamld", [front], ["2::8"]),
+                         synthetic.decoder_spec("pamld", segments, ["0::%d" % length, "1::%d" % length], **{"confidence threshold": 0.9})],
+            "sample": synthetic.decoder_spec("pamld", segments, ["0::%d" % length, "1::%d" % length])}
+    job = capi.compile_job(spec)
+    n = 1 << 13
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 70 + length)
+    noisy = rng.random(code.shape) < 0.01
+    code[noisy] = np.array([15, 0, 3], dtype=np.uint8)[rng.integers(0, 3, size=int(noisy.sum()))]
+    quality[rng.random(quality.shape) < 0.01] = 0
+    quality[rng.random(quality.shape) < 0.002] = 200
+    quality[: n // 8] = 30                                   # uniform qualities: exact ties between equidistant words
+    for i in range(2 * length):                              # short observations: zero filled tail (SURVEY S1)
+        code[n // 2 + i, i:2 * length] = 0
+        quality[n // 2 + i, i:2 * length] = 0
+    flag[:] = rng.random(n) < 0.1
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    assert int((got[0]["status"] == 0).sum()) > n // 2       # most reads decode
+    assert_parity(oracle, torch_cuda, job, code, quality, None, offsets, mode=capi.MODE_FAST, pieces=2)
+
+
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("counts", [(128, 3), (129, 3), (2, 128)])
 def test_combinatorial_size_extremes(oracle, torch_cuda, algorithm, counts):
