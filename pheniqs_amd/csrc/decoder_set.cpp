@@ -495,19 +495,33 @@ void DecoderSet::build_device_images() {
                         }
                         if(index[static_cast<size_t>(b)] < 0 || index[static_cast<size_t>(b)] >= static_cast<int32_t>(STREAM_UNKNOWN)) { indexable = false; }
                     }
-                    // up to 8 nt the key is 16 bits whatever the length; beyond, the bits of positions 8 and 9 follow them
+                    // up to 8 nt the key is 16 bits whatever the length and an entry names the barcode by its block's LDS address and
+                    // its index; beyond, the bits of positions 8 and 9 follow them and an entry is the barcode's ordinal in 16 bits
                     const int32_t tail = L > 8 ? L - 8 : 0;
-                    std::vector<uint32_t> table(L > 8 ? (static_cast<size_t>(1) << (2 * L)) : 65536, (STREAM_UNKNOWN << 18) | first_block);
                     const uint32_t positions = (1u << L) - 1u;
-                    for(uint32_t key = 0; key < (1u << (2 * L)); ++key) {
+                    auto slot_of = [&](uint32_t key) {
                         const uint32_t l = key & positions;
                         const uint32_t h = key >> L;
-                        const uint16_t named = tables.table[key];
-                        if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
-                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] =
-                            (static_cast<uint32_t>(index[named]) << 18) | (first_block + static_cast<uint32_t>(named) * stream_stride);
+                        return (l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail));
+                    };
+                    if(L > 8) {
+                        std::vector<uint16_t> table(static_cast<size_t>(1) << (2 * L), static_cast<uint16_t>(0xffffu));
+                        for(uint32_t key = 0; key < (1u << (2 * L)); ++key) {
+                            const uint16_t named = tables.table[key];
+                            if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
+                            table[slot_of(key)] = named;
+                        }
+                        d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint16_t)));
+                        if(!d.identity_index) { indexable = false; }
+                    } else {
+                        std::vector<uint32_t> table(65536, (STREAM_UNKNOWN << 18) | first_block);
+                        for(uint32_t key = 0; key < (1u << (2 * L)); ++key) {
+                            const uint16_t named = tables.table[key];
+                            if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
+                            table[slot_of(key)] = (static_cast<uint32_t>(index[named]) << 18) | (first_block + static_cast<uint32_t>(named) * stream_stride);
+                        }
+                        d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
                     }
-                    d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
                     d.stream_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                     d.stream_ready = indexable ? d.near_ready : 0;
                 }
@@ -790,7 +804,6 @@ void DecoderSet::build_device_images() {
                                             high[u] |= (two >> 1) << j;
                                         }
                                     }
-                                    const uint32_t first_block = cross_stream_block_at(STREAM_WAVES, length, unique0, unique1, s2);
                                     std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(block_words), 0u);
                                     for(int32_t b = 0; b < N; ++b) {
                                         uint32_t* const to = &record[static_cast<size_t>(b) * static_cast<size_t>(block_words)];
@@ -815,7 +828,7 @@ void DecoderSet::build_device_images() {
                                             std::memcpy(&to[2 * list + k], &rounded, sizeof(float));
                                         }
                                     }
-                                    std::vector<uint32_t> table(length > 8 ? (static_cast<size_t>(1) << (2 * length)) : 65536, (STREAM_UNKNOWN << 18) | first_block);
+                                    std::vector<uint8_t> table(length > 8 ? (static_cast<size_t>(1) << (2 * length)) : 65536, static_cast<uint8_t>(0xffu));      // a word's ordinal
                                     const uint32_t positions = (1u << length) - 1u;
                                     const std::vector<uint16_t>& named_by = near_table_of[s2];
                                     for(uint32_t key = 0; key < (1u << (2 * length)); ++key) {
@@ -823,10 +836,9 @@ void DecoderSet::build_device_images() {
                                         const uint32_t h = key >> length;
                                         const uint16_t named = named_by[key];
                                         if(named == NEAR_NO_BARCODE) { continue; }
-                                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] =
-                                            (static_cast<uint32_t>(named) << 18) | (first_block + static_cast<uint32_t>(named) * static_cast<uint32_t>(block_words) * 4u);
+                                        table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] = static_cast<uint8_t>(named);
                                     }
-                                    d.cross_stream_table[s2] = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
+                                    d.cross_stream_table[s2] = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint8_t)));
                                     d.cross_stream_record[s2] = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                                 }
                                 d.cross_stream_ready = fits ? 1 : 0;

@@ -143,7 +143,9 @@ void pamld_cross_stream_kernel(StageArgs args) {
     const int64_t n = args.n_read;
     const int64_t tiles = (n + 63) / 64;
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
-    const uint32_t* const nearest[SEGMENTS] = {d.cross_stream_table[0], d.cross_stream_table[1]};
+    // the lookup tables hold a word's ORDINAL in its segment, one byte an entry (1 MB a segment of 10 nt: both stay in L2)
+    const uint8_t* const nearest[SEGMENTS] = {reinterpret_cast<const uint8_t*>(d.cross_stream_table[0]), reinterpret_cast<const uint8_t*>(d.cross_stream_table[1])};
+    const uint32_t blocks_at[SEGMENTS] = {Layout::block_at(unique[0], unique[1], 0), Layout::block_at(unique[0], unique[1], 1)};
     const uint32_t rings_at = Layout::RING_AT + wave * Layout::RING_BYTES;      // this wave's three rings: by what pass C has to scan
     const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
     uint32_t* const segment = args.worklist + own_segment * args.worklist_stride;
@@ -248,10 +250,10 @@ void pamld_cross_stream_kernel(StageArgs args) {
     // per read tables, every other word bounded by four distance classes — x_s = (listed + rest) / winner, in units of the
     // segment's all-match product
     struct Score { float winner, matches, x_listed, x_rest; uint32_t k, high_mismatch, ordinal, mismatches; bool known; };
-    auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, Score& out) {
-        const uint32_t block = looked_up & 0x3ffffu;
-        const uint32_t ordinal = looked_up >> 18;                              // the word's ordinal in its segment
-        const bool known = ordinal != STREAM_UNKNOWN;
+    auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, uint32_t first_block, Score& out) {
+        const uint32_t ordinal = looked_up;                                    // the word's ordinal in its segment
+        const bool known = ordinal != 0xffu;
+        const uint32_t block = first_block + (known ? ordinal : 0u) * Layout::BLOCK_BYTES;
         Quad record[Layout::BLOCK_QUADS];
 #pragma unroll
         for(int quad = 0; quad < Layout::BLOCK_QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
@@ -504,7 +506,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 }
                 strict = strict && outside == 0;
                 Score score;
-                score_segment(quality_words, observed, nearest[s][key], score);
+                score_segment(quality_words, observed, static_cast<uint32_t>(nearest[s][key]), blocks_at[s], score);
                 top = score.winner;
                 rest = score.x_listed * score.winner;
                 second = rest;
@@ -624,7 +626,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
             }
             to.strict[s] = bits == L && every_byte == 0x80808080u && beyond_rows == 0;
             to.sliced[s] = sliced;
-            to.looked_up[s] = nearest[s][key];
+            to.looked_up[s] = static_cast<uint32_t>(nearest[s][key]);
         }
 #pragma unroll
         for(int w = 0; w < ROW_WORDS; ++w) { to.quality[w] = in.quality[w]; }
@@ -675,7 +677,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 uint32_t q[G];
                 segment_words(quality_in, s, q);
                 Score score;
-                score_segment(q, sliced_of[s], looked_up_of[s], score);
+                score_segment(q, sliced_of[s], looked_up_of[s], blocks_at[s], score);
                 winner_of[s] = score.winner;
                 matches_of[s] = score.matches;
                 x_listed_of[s] = score.x_listed;

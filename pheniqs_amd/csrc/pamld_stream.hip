@@ -31,6 +31,7 @@ bool pamld_stream_supports(const DevDecoder& host_decoder) {
     const int L = host_decoder.nucleotide_cardinality;
     return pamld_lut_supports(host_decoder) && host_decoder.stream_ready != 0 && host_decoder.stream_table != nullptr &&
            L >= NEAR_MIN_LENGTH && L <= 10 && host_decoder.plane_stride == 4 * stream_row_words(L) && host_decoder.n_barcode > stream::LIST &&
+           (L <= 8 || host_decoder.identity_index != 0) &&          // past 8 nt the lookup table holds ordinals
            (host_decoder.uniform_prior != 0 || host_decoder.concentration_single != nullptr) &&
            host_decoder.use_lds_histogram != 0 && bytes_needed(host_decoder) <= 160u * 1024u;
 }

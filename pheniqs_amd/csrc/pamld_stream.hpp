@@ -562,7 +562,9 @@ void pamld_stream_kernel(StageArgs args) {
             to.sliced |= codes2 << 18;
             key |= ((codes2 & ((1u << TAIL) - 1u)) << 16) | (((codes2 >> 4) & ((1u << TAIL) - 1u)) << (16 + TAIL));
         }
-        to.looked_up = nearest[key];                                                  // the barcode this word is (next to), if any
+        // the barcode this word is (next to), if any.  Past 8 nt the table has 4^L entries and holds the barcode's ORDINAL in 16
+        // bits (2 MB for 10 nt, where 32 bit entries were 4 MB and missed in L2 for a third of the reads)
+        to.looked_up = TAIL ? static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(nearest)[key]) : nearest[key];
         to.in = in;
     };
 #ifdef PHQ_DIAG_STAGGER
@@ -618,9 +620,9 @@ void pamld_stream_kernel(StageArgs args) {
 #endif
             // the lookup names the barcode by the LDS address of its block (low 18 bits) and its index (above them); a word
             // more than one mismatch from every barcode comes back with the index field all ones and the first block's address
-            const uint32_t block = looked_up & 0x3ffffu;
-            const uint32_t index = looked_up >> 18;                                  // barcode_index[c]
-            const bool known = index != 0x3fffu;
+            const bool known = TAIL ? looked_up != 0xffffu : (looked_up >> 18) != 0x3fffu;
+            const uint32_t block = TAIL ? block_base + (known ? looked_up : 0u) * BLOCK_BYTES : looked_up & 0x3ffffu;
+            const uint32_t index = TAIL ? looked_up + 1u : looked_up >> 18;          // barcode_index[c] (past 8 nt: the identity, host checked)
             // the list of c — eight pairs of barcodes as plane words, then the weights of the bound — asked for together
             // with the factor rows: one wait for both
             Quad record[Block<PRIORS>::QUADS];
