@@ -791,7 +791,7 @@ void DecoderSet::build_device_images() {
                                 const int32_t unique0 = static_cast<int32_t>(distinct[0].size()), unique1 = static_cast<int32_t>(distinct[1].size());
                                 const int32_t tail = length > 8 ? length - 8 : 0;
                                 auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10) | (((bits >> 8) & 0x3u) << 18); };
-                                bool fits = cross_stream_block_at(STREAM_WAVES, length, unique0, unique1, 1) + static_cast<uint32_t>(unique1) * static_cast<uint32_t>(block_words) * 4u < (1u << 18);
+                                bool fits = cross_stream_block_at(CROSS_STREAM_WAVES, length, unique0, unique1, 1) + static_cast<uint32_t>(unique1) * static_cast<uint32_t>(block_words) * 4u < (1u << 18);
                                 for(int32_t s2 = 0; s2 < 2 && fits; ++s2) {
                                     const auto& set = distinct[static_cast<size_t>(s2)];
                                     const int32_t N = static_cast<int32_t>(set.size());

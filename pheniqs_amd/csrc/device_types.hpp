@@ -34,6 +34,10 @@ constexpr int stream_record_words(bool priors) { return priors ? 60 : 44; }
 #define PHQ_STREAM_WAVES 12
 #endif
 constexpr int STREAM_WAVES = PHQ_STREAM_WAVES;
+#ifndef PHQ_CROSS_STREAM_WAVES
+#define PHQ_CROSS_STREAM_WAVES 12
+#endif
+constexpr int CROSS_STREAM_WAVES = PHQ_CROSS_STREAM_WAVES;      // pamld_cross_stream.hpp (its lookup tables hold ordinals: the host's tables do not depend on it)
 // 9 and 10 nt: two tabled groups of four positions and one or two positions picked by masks, 8 listed barcodes one per plane
 // word (the 16 plane words of a block either way), three words per input row, the codec's words one barcode per word
 constexpr int stream_list(int length) { return length > 8 ? 8 : 16; }

@@ -311,6 +311,7 @@ bool pamld_cross_near_supports(const DevDecoder& host_decoder);   // pamld_cross
 int pamld_cross_near_block(const DevDecoder& host_decoder);
 int launch_pamld_cross_near(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_cross_stream_supports(const DevDecoder& host_decoder);   // pamld_cross_stream.hip: the same sets (uniform priors, 8 to 10 nt), lists and factorised scan in one persistent kernel
+int pamld_cross_stream_waves();
 int launch_pamld_cross_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 bool pamld_pair_supports(const DevDecoder& host_decoder);   // pamld_pair.hip: paired barcodes, one barcode scored, in front of the product form kernels
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);

@@ -8,12 +8,14 @@ namespace {
 uint32_t bytes_needed(const DevDecoder& host_decoder) {
     const int u0 = host_decoder.cross_unique[0], u1 = host_decoder.cross_unique[1];
     switch(host_decoder.cross_length[0]) {
-        case 8: return cross_stream::Shape<8, STREAM_WAVES>::lds_bytes(u0, u1);
-        case 9: return cross_stream::Shape<9, STREAM_WAVES>::lds_bytes(u0, u1);
-        default: return cross_stream::Shape<10, STREAM_WAVES>::lds_bytes(u0, u1);
+        case 8: return cross_stream::Shape<8, CROSS_STREAM_WAVES>::lds_bytes(u0, u1);
+        case 9: return cross_stream::Shape<9, CROSS_STREAM_WAVES>::lds_bytes(u0, u1);
+        default: return cross_stream::Shape<10, CROSS_STREAM_WAVES>::lds_bytes(u0, u1);
     }
 }
 }
+
+int pamld_cross_stream_waves() { return CROSS_STREAM_WAVES; }
 
 bool pamld_cross_stream_supports(const DevDecoder& host_decoder) {
     if(!pamld_cross_near_supports(host_decoder)) { return false; }
@@ -24,9 +26,9 @@ bool pamld_cross_stream_supports(const DevDecoder& host_decoder) {
 
 int launch_pamld_cross_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream) {
     switch(host_decoder.cross_length[0]) {
-        case 8: return cross_stream::launch_one<8, STREAM_WAVES>(args, host_decoder, grid, stream);
-        case 9: return cross_stream::launch_one<9, STREAM_WAVES>(args, host_decoder, grid, stream);
-        case 10: return cross_stream::launch_one<10, STREAM_WAVES>(args, host_decoder, grid, stream);
+        case 8: return cross_stream::launch_one<8, CROSS_STREAM_WAVES>(args, host_decoder, grid, stream);
+        case 9: return cross_stream::launch_one<9, CROSS_STREAM_WAVES>(args, host_decoder, grid, stream);
+        case 10: return cross_stream::launch_one<10, CROSS_STREAM_WAVES>(args, host_decoder, grid, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }

@@ -116,7 +116,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(streamed || few || cross_streamed) {
                     // one workgroup per CU (two of the smaller ones of the few barcode kernel), a worklist segment per WAVE: what
                     // the second pass cannot decide either goes there
-                    const int waves = few ? pamld_few_waves() : pamld_stream_waves();
+                    const int waves = few ? pamld_few_waves() : cross_streamed ? pamld_cross_stream_waves() : pamld_stream_waves();
                     const int64_t wave_tiles = (args.n_read + 63) / 64;
                     const int64_t wanted = std::max<int64_t>(1, std::min<int64_t>(few ? std::min<int64_t>(2 * cus, max_blocks / waves) : cus, (wave_tiles + waves - 1) / waves));
                     const dim3 stream_grid(static_cast<unsigned>(wanted));
