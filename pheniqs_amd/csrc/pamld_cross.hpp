@@ -24,6 +24,7 @@
 // Every other read goes to this workgroup's worklist segment for the literal kernel.
 #pragma once
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernel_common.hpp"
@@ -512,7 +513,13 @@ __global__ __launch_bounds__(THREADS) void pamld_cross_kernel(StageArgs args) {
 // word ordinal being wave uniform.  (Round 1 multiplied the factors up and kept per lane lists of ordinals in LDS:
 // 53 instructions per read and word against 27.)
 constexpr int EXACT_TABLE_LANES = 128;        // lanes of a workgroup: 16 KiB of tables per group of 4 positions
-__host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * 16u * sizeof(double) * EXACT_TABLE_LANES; }
+// Round 3, three and four groups (9 to 16 nt words): the tables are by PAIR of positions — 4 entries a pair, 8 KiB a group of
+// four positions for the workgroup instead of 16 KiB — as in pamld_wide_exact.hpp: twice the table reads and multiplications
+// per word, and five workgroups on a CU where the 16 entry tables left two (48 KiB of them for 10 nt words).  The tier is
+// latency bound: padded down from three workgroups a CU to two (PHQ_EXACT_PAD_LDS) the 8 nt shape takes 1.6 times as long.
+// C3: 0.94 -> 0.63 ms per 100 M reads.  Up to 8 nt the 16 entry tables stay: with pairs C2's tier took 0.20 instead of 0.19 ms.
+__host__ __device__ constexpr bool exact_pair_tables(int groups) { return groups >= 3; }
+__host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * (exact_pair_tables(groups) ? 8u : 16u) * sizeof(double) * EXACT_TABLE_LANES; }
 
 template <int G, int S, int UNIQUE, bool PRIORS>
 __global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(StageArgs args) {
@@ -664,6 +671,18 @@ __global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(St
             {
                 // this read's tables of the segment: entry m of group g = product over the group's positions of the
                 // match (bit clear) or mismatch (bit set) factor
+                if(exact_pair_tables(G)) {
+#pragma unroll
+                    for(int pr = 0; pr < 2 * G; ++pr) {
+                        const double* const first = reinterpret_cast<const double*>(factor_bytes + row_offset[s][2 * pr]);
+                        const double* const second = reinterpret_cast<const double*>(factor_bytes + row_offset[s][2 * pr + 1]);
+                        const double m0 = first[0], e0 = first[1], m1 = second[0], e1 = second[1];
+                        group_table[(pr * 4 + 0) * LANES] = m0 * m1;
+                        group_table[(pr * 4 + 1) * LANES] = e0 * m1;
+                        group_table[(pr * 4 + 2) * LANES] = m0 * e1;
+                        group_table[(pr * 4 + 3) * LANES] = e0 * e1;
+                    }
+                } else {
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
                     double entry[16];
@@ -684,12 +703,24 @@ __global__ __launch_bounds__(EXACT_TABLE_LANES) void pamld_cross_exact_kernel(St
 #pragma unroll
                     for(int m = 0; m < 16; ++m) { group_table[(g * 16 + m) * LANES] = entry[m]; }
                 }
+                }
                 // flags of group g sit at bits 8 g + 2 .. 8 g + 5: entry * LANES * 8 bytes = (flags moved to bits 10..13) & 0x3c00
                 static_assert(LANES * sizeof(double) == 1024, "an entry of the table form is 1 KiB");
                 const char* const table_bytes = reinterpret_cast<const char*>(group_table);
                 auto probability_of = [&](uint32_t word) {
                     const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
                     double p = 1.0;
+                    if(exact_pair_tables(G)) {
+                        // the pair's two flags sit at bits 8 (pr / 2) + 2 + 2 (pr % 2) and the next: moved to bits 10 and 11 = entry * 1 KiB
+#pragma unroll
+                        for(int pr = 0; pr < 2 * G; ++pr) {
+                            const int at_bit = 8 * (pr >> 1) + 2 + 2 * (pr & 1);
+                            const uint32_t moved = at_bit < 10 ? flags << (10 - at_bit) : flags >> (at_bit - 10);
+                            const double t = *reinterpret_cast<const double*>(table_bytes + pr * 4 * LANES * sizeof(double) + (moved & 0xc00u));
+                            p = pr == 0 ? t : p * t;
+                        }
+                        return p;
+                    }
 #pragma unroll
                     for(int g = 0; g < G; ++g) {
                         const uint32_t moved = g == 0 ? flags << 8 : g == 1 ? flags : flags >> (8 * g - 8);
@@ -1509,7 +1540,8 @@ inline int launch_exact_weighted(const StageArgs& args, const DevDecoder& host_d
 // a single segment set: more than CROSS_MAX_UNIQUE words and / or priors that differ
 template <int G, int S, int UNIQUE, bool PRIORS>
 int launch_exact_form(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G);
+    static const size_t pad = std::getenv("PHQ_EXACT_PAD_LDS") ? static_cast<size_t>(std::atoi(std::getenv("PHQ_EXACT_PAD_LDS"))) : 0;      // occupancy experiments
+    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G) + pad;
     if(bytes > 64u * 1024u) {
         static std::atomic<uint64_t> prepared{0};
         // at most 32 KiB of histogram + 64 KiB of tables; the kernel also has ~5 KiB of static LDS
