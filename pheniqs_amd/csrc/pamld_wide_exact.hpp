@@ -37,13 +37,16 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
     static_assert(EXACT_LANES * sizeof(double) == 512, "an entry of a table is 512 bytes");
     __shared__ double factor_double[FACTOR_ROWS][2];                          // probabilities [row][0 match | 1 mismatch]
     __shared__ double cost_double[FACTOR_ROWS][2];                            // Phred costs, same layout (phred.cpp:44-68)
-    __shared__ uint32_t lds_word[WORDS * EXACT_MAX_BARCODES];                 // the barcodes' two words, for the candidate walk
-    __shared__ double lds_prior[EXACT_MAX_BARCODES];
     __shared__ uint32_t kept;                                                 // reads left in the segment for the literal tier
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
     const int n_barcode = d.n_barcode;
+    // the barcodes' two words (for the candidate walk) and their priors behind the tables, sized by the codec: as static
+    // arrays for 512 barcodes they took 8 KiB, and with them three of these one wave workgroups fit a CU, not four — the
+    // tier is latency bound (pamld_cross.hpp, PHQ_EXACT_PAD_LDS)
+    double* const lds_prior = reinterpret_cast<double*>(lds_raw + ((static_cast<size_t>(histogram_words(d)) * sizeof(unsigned long long) + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G));
+    uint32_t* const lds_word = reinterpret_cast<uint32_t*>(lds_prior + n_barcode);
 
     for(int i = threadIdx.x; i < FACTOR_ROWS; i += EXACT_LANES) {
         factor_double[i][0] = i < 128 ? d.match_probability[i] : d.uniform_probability;
@@ -281,11 +284,11 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
 }
 
 template <int G>
-int launch_exact_groups(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G);
+int launch_exact_groups(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G) + static_cast<size_t>(n_barcode) * (sizeof(double) + 2 * sizeof(uint32_t));
     if(bytes > 64u * 1024u) {
         static std::atomic<uint64_t> prepared{0};
-        // at most 32 KiB of histogram + 32 KiB of tables; the kernel also has ~9 KiB of static LDS
+        // at most 32 KiB of histogram + 32 KiB of tables + 8 KiB of words and priors; the kernel also has ~4 KiB of static LDS
         if(const int status = allow_large_lds(&pamld_wide_exact_kernel<G>, prepared, 128 * 1024)) { return status; }
     }
     hipLaunchKernelGGL((pamld_wide_exact_kernel<G>), grid, dim3(EXACT_LANES), bytes, stream, args);
