@@ -364,6 +364,16 @@ def test_empty_and_ragged_batches(oracle, torch_cuda, n, mode):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
 
 
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+@pytest.mark.parametrize("n", [1, 63, 65, 257, 1000])
+def test_ragged_batches_of_the_streaming_kernels(oracle, torch_cuda, name, n):
+    """The persistent kernels of round 3 (10 nt single index, two segment combinatorial sets, codecs of a few barcodes) on
+    batches that end inside a 64 read tile, smaller than one tile, and of a single read."""
+    job, recipe = synthetic.config_job(name)
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 123 + n)
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_split_ranges_equal_one_call(oracle, torch_cuda, mode):
     job, recipe = synthetic.config_job("C5")
