@@ -53,7 +53,9 @@ constexpr float X_MAX = 5e-4f;
 // two orders inside the 1e-6 the posterior has to hold.  (1e-9 until the
 // end of round 2: the model — profiles/tools/sim/near_certificate.py — and the GPU agree that ten times the room finishes
 // 94.8 % of the 96 x 8 nt reads here instead of 91.4 %, and every deferred read costs two scattered line writes.)
-constexpr float REST_MAX = 1e-8f;
+// Round 3: 9e-9, not 1e-8 — the bound can be tight (a crowded 76 x 6 nt set, a Q7 call beside five Q37: what was left out weighed
+// 1.0001 of its bound's 1e-8) and x's own 7e-10 comes on top: seed 12982 of the random jobs, 1.0008e-8 from the oracle
+constexpr float REST_MAX = 9e-9f;
 constexpr float SLOP = 1.0f + 1e-5f;           // single precision rounding of the bound itself
 
 // Shapes by barcode length.  5 .. 8 nt: two groups of 4 positions, 8 flag bits per barcode, four barcodes per plane

@@ -35,7 +35,7 @@ namespace pair {
 constexpr int THREADS = 256;
 constexpr int FACTOR_ROWS = 129;
 constexpr float X_MAX = 3e-4f;                 // noise / winner: single precision is enough below this (pamld_near.hpp; up to 20 positions here)
-constexpr float REST_MAX = 1e-8f;              // the bound on what was not scored, as a share of the winner (pamld_near.hpp)
+constexpr float REST_MAX = 9e-9f;              // the bound on what was not scored, as a share of the winner (pamld_near.hpp: a tenth under the 1e-8 of the tests)
 constexpr float SLOP = 1.0f + 1e-5f;
 // The bound sorts the positions by quality into six classes; n mismatches are charged to the cheapest classes first:
 // below Q12 for free, then rho(Q12) each for those below Q20, rho(Q20) below Q25, rho(Q25) below Q30, rho(Q30) below Q36,
