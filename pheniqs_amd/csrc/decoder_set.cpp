@@ -1141,8 +1141,16 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
                             const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                             DevResult* result, uint32_t* word, void* stream, uint32_t* worklist) {
     const size_t n_decoder = job_.decoder.size();
+    static const bool no_fold = std::getenv("PHQ_NO_FOLD") != nullptr;
     for(size_t k = 0; k < n_decoder; ++k) {
         const DecoderConfig& c = job_.decoder[k];
+        // the decoders behind this one that only count (passthrough, naive): their reads are this stage's outgoing reads, so
+        // their two counts are added by this stage's kernels and their launches dropped (StageArgs::echo_offset)
+        size_t folded = 0;
+        if(!no_fold && (c.algorithm == Algorithm::PAMLD || c.algorithm == Algorithm::MDD)) {
+            while(folded < 4 && k + folded + 1 < n_decoder &&
+                  (job_.decoder[k + folded + 1].algorithm == Algorithm::PASSTHROUGH || job_.decoder[k + folded + 1].algorithm == Algorithm::NAIVE)) { ++folded; }
+        }
         StageArgs args;
         std::memset(&args, 0, sizeof(args));
         args.worklist_count = worklist;                                   // one counter per workgroup ...
@@ -1157,8 +1165,12 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         args.word = word + first_read;
         args.stats = device_stats_;
         args.first_stage = k == 0 ? 1 : 0;
-        args.last_stage = k + 1 == n_decoder ? 1 : 0;
+        args.job_outgoing = k + folded + 1 == n_decoder ? 1 : 0;
+        args.last_stage = (args.job_outgoing || folded > 0) ? 1 : 0;      // the stage counts its outgoing reads
+        args.echo_count = static_cast<int32_t>(folded);
+        for(size_t e = 0; e < folded; ++e) { args.echo_offset[e] = host_decoder_[k + 1 + e].stats_offset; }
         check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream, timer_)), "kernel launch");
+        k += folded;
     }
 }
 

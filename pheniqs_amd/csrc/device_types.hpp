@@ -250,6 +250,13 @@ struct StageArgs {
     unsigned long long* stats;            // counter buffer
     int32_t first_stage;                  // initialise word from input_flag
     int32_t last_stage;                   // count outgoing reads (transcode.h:61-64)
+    // ... into the job words when job_outgoing is set (the stage is the job's last), and into bin 0 of the passthrough
+    // decoders folded into this stage (round 3): a decoder that only counts (the naive UMI decoder behind C4's and C5's
+    // classifiers) sees exactly this stage's outgoing reads, so its launch — a pass over the state words of every read — is
+    // dropped and its two counts are added here.  echo_offset[e] = stats_offset of the e-th such decoder.
+    int32_t job_outgoing;
+    int32_t echo_count;
+    int64_t echo_offset[4];
     // Two tier PAMLD (PHQ_MODE_FAST): workgroup g of the product form kernel appends the reads it cannot
     // certify to its own segment worklist[g * worklist_stride ...] and leaves their number in
     // worklist_count[g]; workgroup g of the literal kernel (same grid) then visits exactly those.

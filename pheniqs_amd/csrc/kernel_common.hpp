@@ -136,11 +136,19 @@ __device__ __forceinline__ void count_outgoing(const StageArgs& args, unsigned l
 }
 
 // one global atomic per non zero histogram word per workgroup
-__device__ __forceinline__ void histogram_flush(const StageArgs& args, DecoderRef d, const unsigned long long* histogram) {
+// the workgroup's outgoing reads [qc fail | pass filter]: to the job words when the stage is the job's last, and to bin 0
+// of every passthrough decoder folded into the stage (StageArgs::echo_offset)
+__device__ __forceinline__ void outgoing_flush(const StageArgs& args, const unsigned long long* outgoing) {
     for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += blockDim.x) {
-        const unsigned long long v = histogram[i];
-        if(v) { atomicAdd(&args.stats[i], v); }
+        const unsigned long long v = outgoing[i];
+        if(v == 0) { continue; }
+        if(args.job_outgoing) { atomicAdd(&args.stats[i], v); }
+        for(int e = 0; e < args.echo_count; ++e) { atomicAdd(&args.stats[args.echo_offset[e] + (i == 0 ? 0 : STAT_FIELDS) + FIELD_COUNT], v); }
     }
+}
+
+__device__ __forceinline__ void histogram_flush(const StageArgs& args, DecoderRef d, const unsigned long long* histogram) {
+    outgoing_flush(args, histogram);
     {
         const int words = d.use_lds_histogram ? (d.n_barcode + 1) * STAT_WORDS_PER_BIN : STAT_WORDS_PER_BIN;
         for(int i = threadIdx.x; i < words; i += blockDim.x) {

@@ -296,10 +296,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_fused_kernel(StageArgs args) {
     }
     __syncthreads();
     // one global atomic per non zero word per workgroup, back in the counter buffer's layout
-    for(int w = threadIdx.x; w < STAT_JOB_WORDS; w += BLOCK) {
-        const unsigned long long v = histogram[w];
-        if(v) { atomicAdd(&args.stats[w], v); }
-    }
+    outgoing_flush(args, histogram);
     for(int w = threadIdx.x; w < 4 * compact_bins; w += BLOCK) {
         const unsigned long long v = histogram[STAT_JOB_WORDS + w];
         const int bin = w >> 2;

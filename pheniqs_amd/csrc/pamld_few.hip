@@ -303,10 +303,7 @@ __global__ __launch_bounds__(THREADS) void pamld_few_kernel(StageArgs args) {
     }
     __syncthreads();
     // the workgroup's bins into the counter buffer: the copies of a word summed, one global atomic per field that is not zero
-    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += THREADS) {
-        const unsigned long long v = job[i];
-        if(v) { atomicAdd(&args.stats[i], v); }
-    }
+    outgoing_flush(args, job);
     for(int i = threadIdx.x; i < (n_barcode + 1) * BIN_WORDS; i += THREADS) {
         const int bin = i / BIN_WORDS;
         const int pass_filter = (i % BIN_WORDS) / 4;

@@ -811,10 +811,7 @@ void pamld_stream_kernel(StageArgs args) {
     }
     __syncthreads();
     // the workgroup's bins into the counter buffer: one global atomic per field that is not zero
-    for(int i = threadIdx.x; i < STAT_JOB_WORDS; i += THREADS) {
-        const unsigned long long v = histogram[i];
-        if(v) { atomicAdd(&args.stats[i], v); }
-    }
+    outgoing_flush(args, histogram);
     for(int i = threadIdx.x; i < (n_barcode + 1) * BIN_WORDS; i += THREADS) {
         const int bin = i / BIN_WORDS;
         const int pass_filter = (i % BIN_WORDS) / 4;

@@ -49,3 +49,10 @@ for mode in (capi.MODE_LITERAL, capi.MODE_FAST):
         bad = np.nonzero(delta > 1e-8)[0]
         for i in bad[:5]:
             print("   read", i, "code", code[i], "quality", quality[i], "got", got[slot][i], "expected", expected[i, slot])
+    count, pf_count = engine.outgoing()
+    print("mode", mode, "outgoing mine", int(words[0] + words[1]), int(words[1]), "oracle", count, pf_count, "pieces", pieces)
+    for k in range(s.n_decoder):
+        mine, theirs = s.stats_options(words, k), engine.options(k)
+        for name in ("count", "pf_count"):
+            if not np.array_equal(mine[name], theirs[name]):
+                print("   decoder", k, name, "mine", mine[name][:6], "oracle", theirs[name][:6])
