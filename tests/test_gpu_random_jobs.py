@@ -85,3 +85,62 @@ def test_random_job(oracle, torch_cuda, seed):
         code[n // 2 + i, i:] = 0
         quality[n // 2 + i, i:] = 0
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=int(rng.integers(1, 4)))
+
+
+def _streaming_seeds():
+    text = os.environ.get("PHQ_STREAMING_SEEDS", "0:60")
+    first, last = (int(x) for x in text.split(":"))
+    return list(range(first, last))
+
+
+@pytest.mark.parametrize("seed", _streaming_seeds())
+def test_random_job_of_the_streaming_shapes(oracle, torch_cuda, seed):
+    """The same, drawn from the shapes round 3's persistent kernels take (the general generator above seldom draws them):
+    single index sets of 9 and 10 nt, two segment combinatorial sets of 8 to 10 nt words past the workgroup histogram,
+    codecs of at most 8 barcodes of up to 8 nt — chained behind or in front of each other and of a naive decoder, with
+    priors that differ half of the time.  PHQ_STREAMING_SEEDS=first:last widens it."""
+    rng = np.random.default_rng(77000 + seed)
+
+    def decoder(shape):
+        options = {"confidence threshold": float(rng.choice([0.5, 0.9, 0.95, 0.99])),
+                   "noise": float(rng.choice([0.0, 0.01, 0.05])),
+                   "high quality threshold": int(rng.choice([0, 20, 30, 41])),
+                   "high quality distance threshold": int(rng.choice([0, 0, 1, 2]))}
+        if shape == "long":
+            length = int(rng.choice([9, 10]))
+            words = [synthetic.barcode_set(rng, int(rng.integers(17, 200)), length, min_distance=int(rng.choice([1, 2, 3])))]
+            pairing = "zip"
+        elif shape == "combinatorial":
+            length = int(rng.choice([8, 9, 10]))
+            counts = [int(rng.integers(17, 30)), int(rng.integers(21, 30))]
+            words = [synthetic.barcode_set(rng, c, length, min_distance=int(rng.choice([1, 2, 3]))) for c in counts]
+            pairing = "product"
+        else:
+            length = int(rng.integers(1, 9))
+            words = [synthetic.barcode_set(rng, int(min(rng.integers(1, 9), 4 ** length)), length, min_distance=1)]
+            pairing = "zip"
+        lengths = [len(w[0]) for w in words]
+        spec = synthetic.decoder_spec("pamld", words, ["%d::%d" % (k, l) for k, l in enumerate(lengths)], pairing=pairing, **options)
+        if rng.random() < 0.5 and shape != "combinatorial":
+            for record in spec["codec"].values():
+                record["concentration"] = float(10 ** rng.uniform(-1, 1))
+        return spec, len(lengths)
+
+    shapes = [str(rng.choice(["long", "combinatorial", "few"])) for _ in range(int(rng.integers(1, 4)))]
+    decoders = [decoder(shape) for shape in shapes]
+    spec = {"input segment cardinality": max(n for _, n in decoders), "sample": decoders[0][0]}
+    if len(decoders) > 1:
+        spec["cellular"] = [d for d, _ in decoders[1:]]
+    if rng.random() < 0.4:
+        spec["molecular"] = [{"algorithm": "naive", "transform": {"token": ["0::4"]}}]
+    job = jobspec.compile_job(spec)
+    n = 3000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, seed)
+    width = code.shape[1]
+    noisy = rng.random((n, width)) < 0.02
+    code[noisy] = np.array([15, 0, 3, 5], dtype=np.uint8)[rng.integers(0, 4, size=int(noisy.sum()))]
+    quality[rng.random((n, width)) < 0.02] = 0
+    wild = rng.random((n, width)) < 0.01
+    quality[wild] = rng.integers(0, 256, size=int(wild.sum())).astype(np.uint8)
+    quality[: n // 10] = int(rng.choice([2, 12, 30, 40]))            # uniform qualities: exact ties
+    assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=int(rng.integers(1, 4)))
