@@ -160,7 +160,8 @@ struct DevDecoder {
     const uint16_t* near_table;
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
-    // streaming kernel (pamld_stream.hpp; 5 to 8 nt, uniform priors): the same two things in pamld_lut.hpp's bit order.
+    // streaming kernel (pamld_stream.hpp; 5 to 10 nt): the same two things in pamld_lut.hpp's bit order (9 and 10 nt: the
+    // table has 4^L entries of 16 bits, a barcode's ordinal, and a block lists 8 barcodes one per plane word — stream_list).
     // stream_table[key], 65536 entries: key = bits 2..17 of the bit-sliced observation (positions 0..3: low code bits in
     // key bits 0..3, high code bits in 4..7; positions 4..7 in bits 8..15); an entry = the LDS address of the barcode's
     // block (18 bits) | barcode_index << 18, index field STREAM_UNKNOWN for a word that names none.  stream_record[c] =

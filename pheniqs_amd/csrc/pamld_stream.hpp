@@ -27,6 +27,11 @@
 // ones — lane << 2 | group << 8 | wave bit << 9 | entry << 10 | wave bits << 14 — so one v_perm_b32 makes an address from
 // a byte of the mismatch field word in both passes; the neighbour records hold their 16 barcodes as eight pairs in
 // that kernel's plane words.
+//
+// 9 and 10 nt.  The tables stay two groups of four positions (8 KiB a wave); positions 8 and 9 are picked by masks — the flag
+// bit spread to a word (v_bfe_i32), rho or 1.0 taken by it (v_bitop3_b32) — and, words that long sitting further apart, 8
+// barcodes are listed instead of 16, one per plane word (6.2 % of the reads deferred instead of 5.4 %:
+// profiles/tools/sim/list_size.py).  The lookup table has 4^L entries of 16 bits, the barcode's ordinal.
 #pragma once
 
 #include "kernel_common.hpp"

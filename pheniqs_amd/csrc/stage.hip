@@ -85,7 +85,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool tiny = pamld_tiny_supports(host_decoder);
                 const bool listed = !tiny && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
                 const bool paired = !tiny && !listed && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
-                // ... and where the streaming kernel takes the codec (5 to 8 nt, uniform priors), lists and scan are ONE launch, every
+                // ... and where the streaming kernel takes the codec (5 to 10 nt), lists and scan are ONE launch, every
                 // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)
                 static const bool no_stream = std::getenv("PHQ_NO_STREAM") != nullptr;
                 const bool streamed = listed && !no_stream && host_decoder.use_lds_histogram && !args.defer_counters && pamld_stream_supports(host_decoder);
