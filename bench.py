@@ -204,20 +204,37 @@ def cpu_baseline(job, code, quality, flag, target_seconds=12.0):
                       "1 thread alone: %.3f Mreads/s" % (total, cores, elapsed, single / 1e6)}
 
 
-def parity_check(job, code, quality, flag, got, reads):
-    """The first `reads` reads of the batch through the oracle: the GPU records must be the same."""
+POSTERIOR_TOLERANCE = {"fast": 1e-8, "literal": 1e-12}       # what the kernels are designed to hold (tests/test_gpu_parity.py); the contract is 1e-6
+
+
+def parity_check(torch, w, mode, reads):
+    """`reads` reads spread evenly over the WHOLE batch (first and last included) through the oracle: every result plane and
+    the status word of the GPU run must be the oracle's — integers the same, posteriors within the design tolerance of
+    the mode (1e-8 fast, 1e-12 literal; the contract is 1e-6)."""
     from oracle import pyoracle
+    from pheniqs_amd import RESULT_DTYPE, synthetic
+    n = w.n
+    ordinals = np.unique(np.linspace(0, n - 1, min(reads, n)).astype(np.int64))
+    code, quality, flag = synthetic.rows_from_planes(torch, w.job, w.set.decoders, n, w.base, w.qual, w.flags, ordinals)
     cores = min(usable_cores(), 64)
-    bounds = np.linspace(0, reads, cores + 1).astype(np.int64)
-    engines = [pyoracle.OracleJob(job) for _ in range(cores)]
+    bounds = np.linspace(0, ordinals.size, cores + 1).astype(np.int64)
+    engines = [pyoracle.OracleJob(w.job) for _ in range(cores)]
     with ThreadPoolExecutor(cores) as pool:
-        results = list(pool.map(lambda k: engines[k].classify(code[bounds[k]:bounds[k + 1]], quality[bounds[k]:bounds[k + 1]],
-                                                             flag[bounds[k]:bounds[k + 1]])[0], range(cores)))
-    expected = np.concatenate(results)[:, 0]
-    for name in ("index", "distance", "hq_distance", "status", "qcfail"):
-        assert np.array_equal(got[:reads][name], expected[name]), name
-    assert np.abs(got[:reads]["confidence"] - expected["confidence"]).max() < 1e-6
-    return reads
+        parts = list(pool.map(lambda k: engines[k].classify(code[bounds[k]:bounds[k + 1]], quality[bounds[k]:bounds[k + 1]], flag[bounds[k]:bounds[k + 1]]), range(cores)))
+    expected = np.concatenate([p[0] for p in parts])
+    expected_word = np.concatenate([p[1] for p in parts])
+    index = torch.from_numpy(ordinals).to(w.result.device)
+    worst = 0.0
+    for slot in range(w.set.n_result):
+        plane = w.result[slot * n * RESULT_DTYPE.itemsize:(slot + 1) * n * RESULT_DTYPE.itemsize].view(n, RESULT_DTYPE.itemsize)
+        got = plane[index].cpu().numpy().view(RESULT_DTYPE).reshape(-1)
+        for name in ("index", "distance", "hq_distance", "status", "qcfail"):
+            assert np.array_equal(got[name], expected[:, slot][name]), (slot, name)
+        worst = max(worst, float(np.abs(got["confidence"] - expected[:, slot]["confidence"]).max()))
+    assert worst < POSTERIOR_TOLERANCE[mode], worst
+    assert np.array_equal(w.word[index].cpu().numpy().view(np.uint32), expected_word)
+    return {"reads": int(ordinals.size), "spread": "evenly over all %d reads of the batch" % n, "result_planes": int(w.set.n_result),
+            "posterior_tolerance": POSTERIOR_TOLERANCE[mode], "posterior_worst": worst}
 
 
 CONFIG_TEXT = {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
@@ -351,6 +368,7 @@ def main():
     parser.add_argument("--mode", default="fast", choices=["literal", "fast"],
                         help="fast: neighbour list / product form kernels + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-parity", action="store_true", help="skip the oracle check of a sample of the timed batch")
     parser.add_argument("--host-staged", type=int, default=16_000_000, metavar="READS",
                         help="reads of the phq_classify_host leg (host planes -> pinned -> device -> back); 0 = skip")
     parser.add_argument("--no-extra-legs", action="store_true", help="only the contract line: no staged / fastq_to_sam / shapes blocks")
@@ -433,8 +451,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w.job, w.code, w.quality, w.flag)
-            got = w.result[: w.code.shape[0] * RESULT_DTYPE.itemsize].cpu().numpy().view(RESULT_DTYPE)      # first result plane, the reads the host holds a copy of
-            line["parity_checked_reads"] = parity_check(w.job, w.code, w.quality, w.flag, got, min(w.code.shape[0], 1 << 19))
+        if world == 1 and not args.no_parity:
+            line["parity"] = parity_check(torch, w, args.mode, 1 << 19)
+            line["parity_checked_reads"] = line["parity"]["reads"]
         if world == 1 and args.host_staged and (extra_legs or "--host-staged" in " ".join(sys.argv)):
             line["staged"] = host_staged(torch, w, args.host_staged)
         code, quality, flag = w.code, w.quality, w.flag
@@ -445,8 +464,10 @@ def main():
             # the same workload with every read through the reference's own sums in fp64 (PHQ_MODE_LITERAL), fewer steps
             literal = Workload(torch, device, local_rank, rank, args.config, args.algorithm, "literal", args.reads, args.pool, args.priors)
             lm = literal.measure(2, 1, 1, barrier)
+            literal_parity = None if args.no_parity else parity_check(torch, literal, "literal", 1 << 16)
             line["literal_Mreads/s"] = lm["Mreads/s"]
-            line["literal"] = {"dtype": "f64", "Mreads/s": lm["Mreads/s"], "ms_per_step": lm["ms_per_step"], "step_frac": lm["step_GBs"] / HBM_PEAK_GBS}
+            line["literal"] = {"dtype": "f64", "Mreads/s": lm["Mreads/s"], "ms_per_step": lm["ms_per_step"], "step_frac": lm["step_GBs"] / HBM_PEAK_GBS,
+                               "parity_checked_reads": literal_parity["reads"] if literal_parity else 0, "parity": literal_parity}
             literal.close()
         if extra_legs:
             # the other BASELINE shapes that fit one GPU, kernel only like `value`, fewer steps
@@ -458,6 +479,7 @@ def main():
                                                            ("C3_pamld_estimated_priors", "C3", "pamld", 50_000_000, "estimated")):
                 shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool, priors)
                 sm = shape.measure(5, 2, 1, barrier)
+                shape_parity = None if args.no_parity else parity_check(torch, shape, args.mode, 1 << 16)
                 shape_traffic = profiled_traffic(reads, config, algorithm, args.mode, priors)
                 line["shapes"][name] = {"workload": "%s: %d reads, %s, %s%s" % (config, reads, CONFIG_TEXT[config], algorithm.upper(),
                                                                               ", priors that differ between the barcodes" if priors == "estimated" else ""),
@@ -466,6 +488,7 @@ def main():
                                         "dominant_kernel_frac": sm["achieved_GBs"] / HBM_PEAK_GBS,
                                         "traffic_step_bytes_per_read": shape_traffic["step_bytes_per_read"] if shape_traffic else None,
                                         "traffic_stale": shape_traffic["stale"] if shape_traffic else None,
+                                        "parity_checked_reads": shape_parity["reads"] if shape_parity else 0, "parity": shape_parity,
                                         "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in sm["kernels"].items()}}
                 shape.close()
         print(json.dumps(line))

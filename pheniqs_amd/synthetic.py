@@ -242,3 +242,22 @@ def generate_planes_device(torch, job: Dict[str, Any], decoders: Sequence[Dict[s
         code_rows[:, at:at + L] = base[n * prefix: n * (prefix + stride)].view(n, stride)[:rows, :L].cpu().numpy()
         quality_rows[:, at:at + L] = qual[n * prefix: n * (prefix + stride)].view(n, stride)[:rows, :L].cpu().numpy()
     return base, qual, flag, (code_rows, quality_rows, flag[:rows].cpu().numpy(), offsets)
+
+
+def rows_from_planes(torch, job: Dict[str, Any], decoders: Sequence[Dict[str, int]], n: int, base, qual, flag, ordinals: np.ndarray):
+    """The reads `ordinals` of a batch resident in decoder major planes (n reads a plane) back as generate_rows' row major host
+    arrays (code, quality, flag): what a parity check hands the oracle when the sample is spread over the whole batch."""
+    index = torch.from_numpy(np.ascontiguousarray(ordinals, dtype=np.int64)).to(base.device)
+    width = sum(int(decoder["nucleotide cardinality"]) for _, decoder in iter_decoders(job))
+    code_rows = np.zeros((index.numel(), width), dtype=np.uint8)
+    quality_rows = np.zeros((index.numel(), width), dtype=np.uint8)
+    at = 0
+    for (_, decoder), info in zip(iter_decoders(job), decoders):
+        L = int(decoder["nucleotide cardinality"])
+        stride, prefix = info["plane_stride"], info["plane_prefix"]
+        if L and stride:
+            code_rows[:, at:at + L] = base[n * prefix: n * (prefix + stride)].view(n, stride)[index][:, :L].cpu().numpy()
+            quality_rows[:, at:at + L] = qual[n * prefix: n * (prefix + stride)].view(n, stride)[index][:, :L].cpu().numpy()
+        at += L
+    flags = flag[index].cpu().numpy() if flag is not None else np.zeros(index.numel(), dtype=np.uint8)
+    return code_rows, quality_rows, flags

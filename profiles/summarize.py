@@ -54,7 +54,7 @@ def main():
         commit = None                                   # the GPU box holds no .git: the caller may add it
     summary = {"build": capi.build_id(), "source": capi.source_id(), "commit": commit, "shapes": {},
                "note": "traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md (gfx950 tallies 128 B requests as 64 B); "
-                       "per launch averages over every dispatch of a pass; counter passes ran 3 steps, the trace 7"}
+                       "per launch averages over every dispatch of a pass; the steps of a pass (timed + warmup) are read from the bench line it printed"}
     for shape in sys.argv[3:]:
         where = os.path.join(directory, shape)
         line = json.load(open(os.path.join(where, "bench.json")))
@@ -62,17 +62,25 @@ def main():
         algorithmic = line["roofline"]["algorithmic_bytes_per_read"]
         fetch = counter_by_kernel(os.path.join(where, "fetch"), "FETCH_SIZE")
         write = counter_by_kernel(os.path.join(where, "write"), "WRITE_SIZE")
-        counter_steps = 3                               # refresh.sh: --steps 2 --warmup 1
+        def steps_of(name):
+            """timed + warmup steps of a pass, from the bench line that pass printed (refresh.sh keeps all three)"""
+            path = os.path.join(where, name)
+            try:
+                pass_line = json.load(open(path))
+                return int(pass_line["steps"]) + int(pass_line["warmup"])
+            except (OSError, ValueError, KeyError):
+                raise SystemExit("%s: no bench line with steps and warmup; the traffic of %s cannot be scaled" % (path, shape))
+        trace_steps, fetch_steps, write_steps = steps_of("bench.json"), steps_of("fetch.json"), steps_of("write.json")
         kernels = {}
         for row in csv.DictReader(open(newest(os.path.join(where, "trace"), "*_kernel_stats.csv"))):
             name = row["Name"]
             if "phq::" not in name:
                 continue
-            entry = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "launches_per_step": int(row["Calls"]) / 7.0}
+            entry = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "launches_per_step": int(row["Calls"]) / float(trace_steps)}
             if name in fetch and name in write:
                 entry["fetch_kib_per_launch"] = fetch[name][0] / fetch[name][1]
                 entry["write_kib_per_launch"] = write[name][0] / write[name][1]
-                entry["bytes_per_step"] = (2.0 * fetch[name][0] + write[name][0]) * 1024.0 / counter_steps
+                entry["bytes_per_step"] = (2.0 * fetch[name][0] / fetch_steps + write[name][0] / write_steps) * 1024.0
                 entry["bytes_per_read"] = entry["bytes_per_step"] / reads
             kernels[short(name)] = entry
         step = sum(k.get("bytes_per_step", 0.0) for k in kernels.values())

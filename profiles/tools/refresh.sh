@@ -21,10 +21,12 @@ out=gpurun_out/prof_$round
 for shape in "${shapes[@]}"; do
   a="${ARGS[$shape]}"
   d=$out/$shape; rm -rf $d; mkdir -p $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 bench.py $a --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $d/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 bench.py $a --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra-legs > $d/trace.log 2>&1
   grep '^{"metric"' $d/trace.log | tail -1 > $d/bench.json
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $d/fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs > $d/write.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > $d/fetch.log 2>&1
+  grep '^{"metric"' $d/fetch.log | tail -1 > $d/fetch.json
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > $d/write.log 2>&1
+  grep '^{"metric"' $d/write.log | tail -1 > $d/write.json
   stats=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
   (head -1 $stats; grep "phq::" $stats) > gpurun_out/${round}_${shape}_kernel_stats.csv
   cp $d/bench.json gpurun_out/${round}_bench_${shape}.json
