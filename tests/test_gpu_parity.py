@@ -648,39 +648,73 @@ def test_decoder_chain_sticky_qcfail_and_passthrough(oracle, torch_cuda):
 # ---- properties at BASELINE.json's full size -----------------------------------------------------------------
 
 
+def oracle_classify_threads(oracle, job, code, quality, flag, threads=16):
+    """The oracle on `threads` host threads (a private engine each, merged by its own collect): (records, status words,
+    the engine that holds the merged counters)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = code.shape[0]
+    bounds = np.linspace(0, n, threads + 1).astype(np.int64)
+    engines = [oracle.OracleJob(job) for _ in range(threads)]
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(lambda k: engines[k].classify(code[bounds[k]:bounds[k + 1]], quality[bounds[k]:bounds[k + 1]], flag[bounds[k]:bounds[k + 1]]), range(threads)))
+    for other in engines[1:]:
+        engines[0].collect(other)
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), engines[0]
+
+
+# BASELINE.json's sizes per GPU: C2 and C3 100 M reads on one, C4 500 M over four, C5 1 B over eight (125 M each)
+FULL_SIZE = [("C2", 1 << 18, 382), ("C3", 1 << 16, 1526), ("C4", 1 << 17, 954), ("C5", 1 << 17, 954)]
+
+
+@pytest.mark.parametrize("config,pool_n,tiles", FULL_SIZE)
 @pytest.mark.parametrize("mode", MODES)
-def test_full_size_c2_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda, mode):
-    """100 M reads (config C2) built by tiling a pool the oracle can decode in seconds: every counter must be
-    exactly `tiles` times the pool's, and every result record equal to the pool's record."""
+def test_full_size_is_a_tiling_of_the_oracle_checked_pool(oracle, torch_cuda, mode, config, pool_n, tiles):
+    """BASELINE.json's full size per GPU (100 M reads of C2 and C3, 125 M of C4 and C5) built by tiling a pool the oracle can
+    decode in seconds: every counter of every decoder must be exactly `tiles` times the pool's, and every result record
+    of every decoder equal to the pool's record.  Literal mode walks every barcode of every read in fp64: it takes the
+    single index shape only (C3's 9 216 barcodes at 100 M reads are minutes of GPU time)."""
+    if mode == capi.MODE_LITERAL and config != "C2":
+        pytest.skip("literal mode at full size: C2 only")
     torch = torch_cuda
-    job, recipe = synthetic.config_job("C2")
-    pool_n, tiles = 1 << 18, 382                                       # 100 139 008 reads
+    job, recipe = synthetic.config_job(config)
     code, quality, flag, offsets = synthetic.generate_rows(job, pool_n, recipe["seed"])
-    engine = oracle.OracleJob(job)
-    expected, expected_word = engine.classify(code, quality, flag)
+    expected, expected_word, engine = oracle_classify_threads(oracle, job, code, quality, flag)
     s = DecoderSet(job, device=0)
     s.set_mode(mode)
     n = pool_n * tiles
-    base = torch.from_numpy(s.planes_from_rows(code, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
-    qual = torch.from_numpy(s.planes_from_rows(quality, offsets)).cuda().view(pool_n, 8).repeat(tiles, 1).contiguous().view(-1)
+
+    def resident(rows):
+        pool_planes = torch.from_numpy(s.planes_from_rows(rows, offsets)).cuda()
+        parts = [pool_planes[pool_n * d["plane_prefix"]: pool_n * (d["plane_prefix"] + d["plane_stride"])].view(pool_n, d["plane_stride"]).repeat(tiles, 1).view(-1)
+                 for d in s.decoders if d["plane_stride"]]
+        return torch.cat(parts) if len(parts) > 1 else parts[0]
+
+    base, qual = resident(code), resident(quality)
     flags = torch.from_numpy(flag).cuda().repeat(tiles)
-    result = torch.zeros(n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    result = torch.zeros(s.n_result * n * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     word = torch.zeros(n, dtype=torch.int32, device="cuda")
     s.classify_device(n, 0, n, base, qual, flags, result, word, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    del base, qual
     words = s.stats_export()
     assert int(words[0] + words[1]) == n
-    mine, theirs = s.stats_options(words, 0), engine.options(0)
-    for name in INTEGER_COUNTERS:
-        assert np.array_equal(mine[name], theirs[name] * tiles), name
+    count, pf_count = engine.outgoing()
+    assert (int(words[0] + words[1]), int(words[1])) == (count * tiles, pf_count * tiles)
+    for k in range(s.n_decoder):
+        mine, theirs = s.stats_options(words, k), engine.options(k)
+        for name in INTEGER_COUNTERS:
+            assert np.array_equal(mine[name], theirs[name] * tiles), (k, name)
     # idempotence across tiles: every tile's records equal the first tile's, and the first equals the oracle's
-    records = result.view(tiles, pool_n * RESULT_DTYPE.itemsize)
-    assert bool((records == records[0]).all())
-    first = records[0].cpu().numpy().view(RESULT_DTYPE)
-    for name in INTEGER_FIELDS:
-        assert np.array_equal(first[name], expected[:, 0][name]), name
-    assert np.abs(first["confidence"] - expected[:, 0]["confidence"]).max() < POSTERIOR_DESIGN_TOLERANCE[mode]
+    for slot in range(s.n_result):
+        records = result[slot * n * RESULT_DTYPE.itemsize:(slot + 1) * n * RESULT_DTYPE.itemsize].view(tiles, pool_n * RESULT_DTYPE.itemsize)
+        assert bool((records == records[0]).all()), slot
+        first = records[0].cpu().numpy().view(RESULT_DTYPE)
+        for name in INTEGER_FIELDS:
+            assert np.array_equal(first[name], expected[:, slot][name]), (slot, name)
+        assert np.abs(first["confidence"] - expected[:, slot]["confidence"]).max() < POSTERIOR_DESIGN_TOLERANCE[mode]
     assert bool((word.view(tiles, pool_n) == word.view(tiles, pool_n)[0]).all())
+    assert np.array_equal(word[:pool_n].cpu().numpy().view(np.uint32), expected_word)
+    s.close()
 
 
 @pytest.mark.parametrize("mode", MODES)
