@@ -135,8 +135,10 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     StageArgs consumer = producer;
                     consumer.worklist_role = 2;
                     if(pamld_exact_supports(host_decoder)) {
+                        // several lanes per read where the set is one the lane parallel tier takes (pamld_exact_lanes.hip)
                         Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
-                        status = launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                        status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
+                                                                                          : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
                         if(status != 0) { return status; }
                         trace_worklist("the exact tier", producer, segment_grid.x, s);
                     }
@@ -181,7 +183,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
-                    status = launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
+                    status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, wide_grid, histogram_bytes, s)
+                                                                                      : launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 } else if(long_words && pamld_wide_exact_supports(host_decoder)) {
                     // the same for two word barcodes (pamld_wide_exact.hpp)
