@@ -14,4 +14,9 @@ int launch_pamld_cross_exact_weighted_s2(const StageArgs& args, const DevDecoder
     return cross::launch_exact_dense(args, host_decoder, grid, histogram_bytes, stream);
 }
 
+// the whole bilinear form alone: behind the lane parallel list kernel (pamld_exact_lanes.hip)
+int launch_pamld_cross_exact_dense(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    return cross::launch_exact_dense(args, host_decoder, grid, histogram_bytes, stream);
+}
+
 }  // namespace phq

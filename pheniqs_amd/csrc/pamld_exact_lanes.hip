@@ -21,12 +21,15 @@
 //     of its threshold, more listed words than the list holds — to the front of the read's own segment for the literal
 //     kernel: no barrier after the set up, nothing shared between waves but the counter histogram.
 // Serves single segment sets (up to EXACT_SINGLE_UNIQUE words of up to 16 nt, priors that differ or not) and two segment
-// combinatorial sets with uniform priors; three segment sets and weighted combinatorial sets keep pamld_cross.hpp's kernels.
+// combinatorial sets, with uniform priors or (WEIGHTED, below) priors that differ; three segment sets keep pamld_cross.hpp's kernel.
 #include <algorithm>
 #include <cstdlib>
 
 #include "kernel_common.hpp"
 
+#ifndef PHQ_WEIGHTED_PAIRS
+#define PHQ_WEIGHTED_PAIRS 256
+#endif
 #ifndef PHQ_LANES_TRIP
 #define PHQ_LANES_TRIP 4
 #endif
@@ -36,6 +39,7 @@ namespace lanes {
 
 constexpr int WAVES = 4;
 constexpr int THREADS = 64 * WAVES;
+constexpr int WEIGHTED_CAP = 48;           // listed words of a segment in the weighted form
 constexpr int CAP = 32;                    // listed words of a segment a read may bring to the literal walk
 constexpr int GROUP_MAX = EXACT_GROUP_MAX;
 
@@ -52,8 +56,16 @@ __device__ __forceinline__ double shuffle_xor(double v, int mask) {
 
 // WORDS = distinct words a segment may hold (CROSS_MAX_UNIQUE; a single segment set may hold EXACT_SINGLE_UNIQUE), R = lanes of
 // a read: 4 where a lane's share of the words fits one mask word, 8 for the long lists
-template <int G, int S, bool PRIORS, int WORDS, int R>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4))) void pamld_exact_lanes_kernel(StageArgs args) {
+// WEIGHTED: a two segment combinatorial set whose priors differ between the barcodes (what pamld_cross_exact_weighted_kernel
+// and, behind it, pamld_cross_exact_dense_kernel decided): sum_b prior_b P(r|b) is the bilinear form
+// sum_u0 P0[u0] (sum_u1 prior[u0][u1] P1[u1]) over the words that matter — a first scan of both segments for their sums and
+// maxima, a second one that lists (word, P) of every word within 1e-15 of its segment's maximum (or, for a read no barcode of
+// which can pass the noise filter, the words that can still hold the argmax), the pairs of listed words dealt to the read's
+// lanes with their priors from L2, what the lists leave out bounded at the largest prior, the pairs within 1e-10 of the
+// largest prior P0 P1 literally.  A read with more listed words than WEIGHTED_CAP stays in the worklist for the dense kernel.
+template <int G, int S, bool PRIORS, int WORDS, int R, bool WEIGHTED = false>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WEIGHTED ? 2 : 3, 4))) void pamld_exact_lanes_kernel(StageArgs args) {
+    static_assert(!WEIGHTED || (S == 2 && !PRIORS), "the weighted form is the two segment one; PRIORS is priors by word of a single segment set");
     static_assert(S == 1 || S == 2, "single segment sets and two segment combinatorial sets");
     static_assert(!PRIORS || S == 1, "priors by word are for single segment sets");
     static_assert(WORDS == CROSS_MAX_UNIQUE || S == 1, "long word lists are for single segment sets");
@@ -77,6 +89,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
     // walk, and what the iteration decided until the next one stores it
     __shared__ uint32_t kept[WAVES][READS][S][G + 3];
     __shared__ uint32_t decided[WAVES][READS][11];
+    __shared__ double weighted_value[WEIGHTED ? WAVES : 1][WEIGHTED ? READS : 1][2][WEIGHTED ? WEIGHTED_CAP : 1];      // P of the listed words
+    __shared__ uint16_t weighted_word[WEIGHTED ? WAVES : 1][WEIGHTED ? READS : 1][2][WEIGHTED ? WEIGHTED_CAP : 1];     // their ordinals
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* const histogram = reinterpret_cast<unsigned long long*>(lds_raw);
     DecoderRef d = *constant_cast(args.decoder);
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
             uint32_t observed[S];
             uint32_t outside[S];
             uint32_t high_quality[S];
-            double sum_all = 1.0;                  // product of the per segment sums = sum over every barcode of P(r|b)
+            double sum_all = 1.0;                  // sum over every barcode of (prior) P(r|b): uniform priors, the product of the per segment sums
             bool defer = false;
             if(sub < S) { listed_count[wave][slot][sub < S ? sub : 0] = 0; }
             __builtin_amdgcn_wave_barrier();       // the lanes of a read talk through LDS: a wave's LDS operations complete in order
@@ -357,12 +371,23 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                     outside[s] |= (flags & 0xfu) << (8 * g + 2);
                     high_quality[s] |= (flags >> 4) << (8 * g + 2);
                 }
-                // this read's tables of the segment, 16 / R entries a lane: entry m of group g = product over the group's positions of
-                // the match (bit clear) or mismatch (bit set) factor, associated as the tier before did ((p0 p1) p2) p3
+                // what the literal walk reads again: nothing of the scans stays in registers for it
+                if(sub == 0) {
+#pragma unroll
+                    for(int g = 0; g < G; ++g) { kept[wave][slot][s][g] = row[s][g]; }
+                    kept[wave][slot][s][G] = observed[s];
+                    kept[wave][slot][s][G + 1] = outside[s];
+                    kept[wave][slot][s][G + 2] = high_quality[s];
+                }
+            }
+            // this read's tables of segment s, 16 / R entries a lane: entry m of group g = product over the group's positions of the
+            // match (bit clear) or mismatch (bit set) factor.  A lane's entries m = sub + R half share their two low positions:
+            // one product for those, one for the two high positions of each entry ((p0 p1) (p2 p3): associated by pair)
+            auto build_tables = [&](auto which) {
+                constexpr int s = decltype(which)::value;
+                __builtin_amdgcn_wave_barrier();   // the tables in place are read no more
 #pragma unroll
                 for(int g = 0; g < G; ++g) {
-                    // a lane's entries m = sub + R half share their two low positions: one product for those, one for the two
-                    // high positions of each entry ((p0 p1) (p2 p3): associated by pair)
                     auto factor = [&](int jj, uint32_t bit) {
                         return *reinterpret_cast<const double*>(factor_bytes + (((row[s][g] >> (8 * jj)) & 0xffu) * 16u + bit * 8u));
                     };
@@ -375,25 +400,25 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                // flags of group g sit at bits 8 g + 2 .. 8 g + 5: entry * 8 bytes = (flags moved to bits 3..6) & 0x78
-                auto probability_of = [&](uint32_t word) {
-                    const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
-                    double p = 1.0;
+            };
+            // flags of group g sit at bits 8 g + 2 .. 8 g + 5: entry * 8 bytes = (flags moved to bits 3..6) & 0x78
+            auto probability_of = [&](auto which, uint32_t word) {
+                constexpr int s = decltype(which)::value;
+                const uint32_t flags = (mismatch_fields(observed[s] ^ word) | outside[s]) & full_mask[s];
+                double p = 1.0;
 #pragma unroll
-                    for(int g = 0; g < G; ++g) {
-                        // (the reads of a wave keep their tables 128 G bytes apart — the same banks: entry m sits at (m + slot) % 16)
-                        const uint32_t moved = (g == 0 ? flags << 1 : flags >> (8 * g - 1)) + rotation;
-                        const double t = *(LdsDouble)static_cast<uintptr_t>(__builtin_amdgcn_bitop3_b32(moved, 0x78u, table_at, 0xEA) + static_cast<uint32_t>(g) * 128u);      // (moved & 0x78) | table_at
-                        p = g == 0 ? t : p * t;
-                    }
-                    return p;
-                };
-                double top = 0;
-                double sum = 0;
-                uint32_t mask[MASKS];
-#pragma unroll
-                for(int e = 0; e < MASKS; ++e) { mask[e] = 0u; }
-                // several words a trip: their table reads are in flight together (the loop is a chain of LDS round trips otherwise)
+                for(int g = 0; g < G; ++g) {
+                    // (the reads of a wave keep their tables 128 G bytes apart — the same banks: entry m sits at (m + slot) % 16)
+                    const uint32_t moved = (g == 0 ? flags << 1 : flags >> (8 * g - 1)) + rotation;
+                    const double t = *(LdsDouble)static_cast<uintptr_t>(__builtin_amdgcn_bitop3_b32(moved, 0x78u, table_at, 0xEA) + static_cast<uint32_t>(g) * 128u);      // (moved & 0x78) | table_at
+                    p = g == 0 ? t : p * t;
+                }
+                return p;
+            };
+            // the words of segment s dealt to the read's lanes, several a trip — their table reads are in flight together (the
+            // loop is a chain of LDS round trips otherwise): visit(word ordinal, ordinal / R, P) in ascending order of the lane's words
+            auto for_each_word = [&](auto which, auto&& visit) {
+                constexpr int s = decltype(which)::value;
                 for(int first = 0, t = 0; first < unique[s]; first += TRIP * R, t += TRIP) {
                     uint32_t word[TRIP];
                     bool valid[TRIP];
@@ -406,96 +431,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                     }
 #pragma unroll
                     for(int h = 0; h < TRIP; ++h) {
-                        p[h] = probability_of(word[h]);
+                        p[h] = probability_of(which, word[h]);
                         if(PRIORS) { p[h] *= d.concentration[lds_ordinal[S == 1 && valid[h] ? first + h * R + sub : 0]]; }
                         p[h] = valid[h] ? p[h] : 0.0;
                     }
 #pragma unroll
-                    for(int h = 0; h < TRIP; ++h) {
-                        sum += p[h];
-                        const bool clears = p[h] * near > top;
-                        const bool lists = valid[h] && p[h] >= top * near;
-#pragma unroll
-                        for(int e = 0; e < MASKS; ++e) {
-                            mask[e] = clears ? 0u : mask[e];
-                            if(((t + h) >> 5) == e) { mask[e] |= lists ? 1u << ((t + h) & 31) : 0u; }
-                        }
-                        top = fmax(top, p[h]);
-                    }
+                    for(int h = 0; h < TRIP; ++h) { visit(first + h * R + sub, t + h, p[h], valid[h]); }
                 }
-                // over the read's lanes: the sum, the maximum; a lane whose own maximum is outside the window of the read's lists nothing
-                double read_top = top;
-#pragma unroll
-                for(int step = 1; step < R; step <<= 1) {
-                    sum += shuffle_xor(sum, step);
-                    read_top = fmax(read_top, shuffle_xor(read_top, step));
-                }
-                if(!(read_top > 0)) { defer = true; }
-                const bool mine = top >= read_top * near && read_top > 0;
-#pragma unroll
-                for(int e = 0; e < MASKS; ++e) {
-                    uint32_t m = mine ? mask[e] : 0u;
-                    while(m) {
-                        const int t = 32 * e + __ffs(static_cast<int>(m)) - 1;
-                        m &= m - 1u;
-                        const uint32_t at = atomicAdd(&listed_count[wave][slot][s], 1u);
-                        if(at < static_cast<uint32_t>(CAP)) { listed[wave][slot][s][at] = static_cast<uint16_t>(sub + R * t); }
-                    }
-                }
-                sum_all *= sum;
-                if(sub == 0) {
-#pragma unroll
-                    for(int g = 0; g < G; ++g) { kept[wave][slot][s][g] = row[s][g]; }
-                    kept[wave][slot][s][G] = observed[s];
-                    kept[wave][slot][s][G + 1] = outside[s];
-                    kept[wave][slot][s][G + 2] = high_quality[s];
-                }
-                __builtin_amdgcn_wave_barrier();   // the next segment's tables overwrite this one's
-            }
-            asm volatile("" ::: "memory");         // ... and read back: nothing of the scan stays in registers
-#pragma unroll
-            for(int s = 0; s < S; ++s) {
-#pragma unroll
-                for(int g = 0; g < G; ++g) { row[s][g] = kept[wave][slot][s][g]; }
-                observed[s] = kept[wave][slot][s][G];
-                outside[s] = kept[wave][slot][s][G + 1];
-                high_quality[s] = kept[wave][slot][s][G + 2];
-            }
-
-            // the combinations of listed words, dealt to the read's lanes; each LITERALLY: Kahan sum of the costs over the
-            // barcode's positions, then pow (barcode.h:131-164)
-            uint32_t count[S];
-            uint32_t combinations = 1;
-#pragma unroll
-            for(int s = 0; s < S; ++s) {
-                count[s] = listed_count[wave][slot][s];
-                if(count[s] == 0 || count[s] > static_cast<uint32_t>(CAP)) { defer = true; count[s] = 0; }
-                combinations *= count[s];
-            }
-            int best = 0x7fffffff;
-            double best_conditional = -1.0;
-            double best_p = -1.0;                  // prior * P(r|b) of the winner, literal
-            uint32_t best_flags[S];
-#pragma unroll
-            for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
-            for(uint32_t c = static_cast<uint32_t>(sub); c < combinations; c += R) {
-                uint32_t flags[S];
-                int flat = 0;
-                {
-                    uint32_t rest = c;
-#pragma unroll
-                    for(int s = S - 1; s >= 0; --s) {
-                        const uint32_t pick = S == 1 ? rest : rest % count[s];
-                        rest = S == 1 ? 0u : rest / count[s];
-                        const int u = listed[wave][slot][s][pick];
-                        flat += u * radix[s];
-                        flags[s] = (mismatch_fields(observed[s] ^ lds_word[s * WORDS + u]) | outside[s]) & full_mask[s];
-                    }
-                }
+            };
+            // P(r|b) of a combination LITERALLY: Kahan sum of the costs over the barcode's positions, then pow (barcode.h:131-164).
+            // Position by position, a loop and not unrolled: unrolled, the scheduler hoists every position's cost read in front of
+            // the recurrence and holds 2 x 4 G S registers for them; the factor rows come back from LDS byte by byte
+            auto literal_of = [&](const uint32_t (&flags)[S]) {
                 double sigma = 0;
                 double compensation = 0;
-                // position by position, a loop and not unrolled: unrolled, the scheduler hoists every position's cost read in
-                // front of the recurrence and holds 2 x 4 G S registers for them; the factor rows come back from LDS byte by byte
 #pragma unroll
                 for(int s = 0; s < S; ++s) {
                     const uint8_t* const row_bytes = reinterpret_cast<const uint8_t*>(&kept[wave][slot][s][0]);
@@ -509,9 +458,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                         sigma = t;
                     }
                 }
-                const double conditional = phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
-                const int b = S == 1 ? lds_ordinal[S == 1 ? flat / radix[0] : 0] : (d.cross_identity ? flat : d.cross_ordinal[flat]);
-                const double prior = PRIORS ? d.concentration[b] : uniform_concentration;
+                return phred_probability(sigma, d.log2_base_hi, d.log2_base_lo);
+            };
+            int best = 0x7fffffff;
+            double best_conditional = -1.0;
+            double best_p = -1.0;                  // prior * P(r|b) of the winner, literal
+            uint32_t best_flags[S];
+#pragma unroll
+            for(int s = 0; s < S; ++s) { best_flags[s] = 0; }
+            auto candidate = [&](int b, double prior, const uint32_t (&flags)[S]) {
+                const double conditional = literal_of(flags);
                 const double p = conditional * prior;                                  // pamld.cpp:66
                 if(p > best_p || (p == best_p && b < best)) {                          // strict '>' in barcode order
                     best = b;
@@ -519,6 +475,207 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                     best_conditional = conditional;
 #pragma unroll
                     for(int s = 0; s < S; ++s) { best_flags[s] = flags[s]; }
+                }
+            };
+            const std::integral_constant<int, 0> zero;
+            const std::integral_constant<int, S - 1> last;
+
+            if constexpr(!WEIGHTED) {
+                auto scan = [&](auto which) {
+                    constexpr int s = decltype(which)::value;
+                    build_tables(which);
+                    double top = 0;
+                    double sum = 0;
+                    uint32_t mask[MASKS];
+#pragma unroll
+                    for(int e = 0; e < MASKS; ++e) { mask[e] = 0u; }
+                    for_each_word(which, [&](int, int t, double p, bool valid) {
+                        sum += p;
+                        const bool clears = p * near > top;
+                        const bool lists = valid && p >= top * near;
+#pragma unroll
+                        for(int e = 0; e < MASKS; ++e) {
+                            mask[e] = clears ? 0u : mask[e];
+                            if((t >> 5) == e) { mask[e] |= lists ? 1u << (t & 31) : 0u; }
+                        }
+                        top = fmax(top, p);
+                    });
+                    // over the read's lanes: the sum, the maximum; a lane whose own maximum is outside the window of the read's lists nothing
+                    double read_top = top;
+#pragma unroll
+                    for(int step = 1; step < R; step <<= 1) {
+                        sum += shuffle_xor(sum, step);
+                        read_top = fmax(read_top, shuffle_xor(read_top, step));
+                    }
+                    if(!(read_top > 0)) { defer = true; }
+                    const bool mine = top >= read_top * near && read_top > 0;
+#pragma unroll
+                    for(int e = 0; e < MASKS; ++e) {
+                        uint32_t m = mine ? mask[e] : 0u;
+                        while(m) {
+                            const int t = 32 * e + __ffs(static_cast<int>(m)) - 1;
+                            m &= m - 1u;
+                            const uint32_t at = atomicAdd(&listed_count[wave][slot][s], 1u);
+                            if(at < static_cast<uint32_t>(CAP)) { listed[wave][slot][s][at] = static_cast<uint16_t>(sub + R * t); }
+                        }
+                    }
+                    sum_all *= sum;
+                };
+                scan(zero);
+                if constexpr(S > 1) { scan(last); }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                // the combinations of listed words, dealt to the read's lanes
+                uint32_t count[S];
+                uint32_t combinations = 1;
+#pragma unroll
+                for(int s = 0; s < S; ++s) {
+                    count[s] = listed_count[wave][slot][s];
+                    if(count[s] == 0 || count[s] > static_cast<uint32_t>(CAP)) { defer = true; count[s] = 0; }
+                    combinations *= count[s];
+                }
+                for(uint32_t c = static_cast<uint32_t>(sub); c < combinations; c += R) {
+                    uint32_t flags[S];
+                    int flat = 0;
+                    uint32_t rest = c;
+#pragma unroll
+                    for(int s = S - 1; s >= 0; --s) {
+                        const uint32_t pick = S == 1 ? rest : rest % count[s];
+                        rest = S == 1 ? 0u : rest / count[s];
+                        const int u = listed[wave][slot][s][pick];
+                        flat += u * radix[s];
+                        flags[s] = (mismatch_fields(observed[s] ^ lds_word[s * WORDS + u]) | outside[s]) & full_mask[s];
+                    }
+                    const int b = S == 1 ? lds_ordinal[S == 1 ? flat / radix[0] : 0] : (d.cross_identity ? flat : d.cross_ordinal[flat]);
+                    candidate(b, PRIORS ? d.concentration[b] : uniform_concentration, flags);
+                }
+            } else {
+                // both segments: sum, maximum and where it is (the first word of the largest P)
+                double top_of[2], sum_of[2];
+                int first_of[2];
+                auto survey = [&](auto which) {
+                    constexpr int s = decltype(which)::value;
+                    build_tables(which);
+                    double top = 0;
+                    double sum = 0;
+                    int first = 0;
+                    for_each_word(which, [&](int u, int, double p, bool) {
+                        sum += p;
+                        const bool larger = p > top;                     // a lane's words come in ascending order: the first of equals stays
+                        first = larger ? u : first;
+                        top = larger ? p : top;
+                    });
+#pragma unroll
+                    for(int step = 1; step < R; step <<= 1) {
+                        sum += shuffle_xor(sum, step);
+                        const double other_top = shuffle_xor(top, step);
+                        const int other_first = __shfl_xor(first, step, 64);
+                        const bool takes = other_top > top || (other_top == top && other_first < first);
+                        top = takes ? other_top : top;
+                        first = takes ? other_first : first;
+                    }
+                    top_of[s] = top; sum_of[s] = sum; first_of[s] = first;
+                };
+                survey(zero);
+                survey(last);
+                if(!(top_of[0] > 0) || !(top_of[1] > 0)) { defer = true; }
+                // A read no barcode of which can pass the noise filter (every P(r|b) <= top0 * top1 < the random barcode probability,
+                // the literal values being within 1e-13 of these products) reports nothing but its argmax: then only words that can
+                // still beat the pair of the two maxima are listed — prior P0 P1 >= prior_tt top0 top1 needs P0 >= top0 * prior_tt /
+                // largest prior, and the same for P1 — and no sum is taken.  Otherwise: every word within 1e-15 of its segment's
+                // maximum, the only ones that can move the sum by 1e-12 or be the argmax (pamld_cross_exact_weighted_kernel).
+                const double prior_of_tops = d.cross_prior_double[first_of[0] * radix[0] + first_of[1] * radix[1]];
+                const bool only_argmax = top_of[0] * top_of[1] < d.random_barcode_probability * (1.0 - 1e-9) && prior_of_tops > 0;
+                const double keep = only_argmax ? (prior_of_tops / d.cross_prior_max) * (1.0 - 1e-9) : 1e-15;
+                double listed_sum[2];
+                auto list = [&](auto which) {
+                    constexpr int s = decltype(which)::value;
+                    build_tables(which);
+                    double total = 0;
+                    const double floor = top_of[s] * keep;
+                    for_each_word(which, [&](int u, int, double p, bool valid) {
+                        if(valid && p >= floor && p > 0) {
+                            const uint32_t at = atomicAdd(&listed_count[wave][slot][s], 1u);
+                            if(at < static_cast<uint32_t>(WEIGHTED_CAP)) {
+                                weighted_value[wave][slot][s][at] = p;
+                                weighted_word[wave][slot][s][at] = static_cast<uint16_t>(u);
+                                total += p;
+                            }
+                        }
+                    });
+#pragma unroll
+                    for(int step = 1; step < R; step <<= 1) { total += shuffle_xor(total, step); }
+                    listed_sum[s] = total;
+                };
+                list(zero);
+                list(last);
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("" ::: "memory");
+                uint32_t count[2];
+#pragma unroll
+                for(int s = 0; s < 2; ++s) {
+                    count[s] = listed_count[wave][slot][s];
+                    if(count[s] == 0 || count[s] > static_cast<uint32_t>(WEIGHTED_CAP)) { defer = true; count[s] = 0; }
+                }
+                // (a read with more pairs than this goes to the dense kernel as well: a wave would walk them for tens of microseconds
+                // with one read's lanes busy)
+                if(count[0] * count[1] > static_cast<uint32_t>(PHQ_WEIGHTED_PAIRS)) { defer = true; count[0] = 0; }
+                const uint32_t pairs = count[0] * count[1];
+                // the bilinear form over the listed words, and the largest prior * P0 * P1: the pairs dealt to the lanes
+                double weighted_sum = 0;
+                double weighted_top = 0;
+                // four pairs a trip: their priors come from L2, one round trip a trip instead of one a pair
+                for(uint32_t c = static_cast<uint32_t>(sub); c < pairs; c += 4 * R) {
+                    double prior[4], value[4];
+#pragma unroll
+                    for(int h = 0; h < 4; ++h) {
+                        const uint32_t at = c + static_cast<uint32_t>(h * R);
+                        const bool valid = at < pairs;
+                        const uint32_t k0 = valid ? at / count[1] : 0u, k1 = valid ? at % count[1] : 0u;
+                        const int u0 = weighted_word[wave][slot][0][k0], u1 = weighted_word[wave][slot][1][k1];
+                        prior[h] = d.cross_prior_double[u0 * radix[0] + u1 * radix[1]];
+                        value[h] = valid ? weighted_value[wave][slot][1][k1] * weighted_value[wave][slot][0][k0] : 0.0;
+                    }
+#pragma unroll
+                    for(int h = 0; h < 4; ++h) {
+                        const double p = prior[h] * value[h];
+                        weighted_sum += p;
+                        weighted_top = fmax(weighted_top, p);
+                    }
+                }
+#pragma unroll
+                for(int step = 1; step < R; step <<= 1) {
+                    weighted_sum += shuffle_xor(weighted_sum, step);
+                    weighted_top = fmax(weighted_top, shuffle_xor(weighted_top, step));
+                }
+                // what the lists leave out, at most: the unlisted mass at the largest prior
+                const double left_out = d.cross_prior_max * (fmax(sum_of[0] * sum_of[1] - listed_sum[0] * listed_sum[1], 0.0) + 1e-15 * sum_of[0] * sum_of[1]);
+                if(!(weighted_top > 0)) { defer = true; }
+                if(!only_argmax && !(left_out <= 1e-12 * (weighted_sum + d.adjusted_noise_probability))) { defer = true; }
+                sum_all = weighted_sum;
+                // the pairs within 1e-10 of the largest, literally, in barcode order
+                const double floor = weighted_top * (1.0 - 1e-10);
+                for(uint32_t c = static_cast<uint32_t>(sub); c < (defer ? 0u : pairs); c += 4 * R) {
+                    double prior[4], value[4];
+                    int word0[4], word1[4];
+#pragma unroll
+                    for(int h = 0; h < 4; ++h) {
+                        const uint32_t at = c + static_cast<uint32_t>(h * R);
+                        const bool valid = at < pairs;
+                        const uint32_t k0 = valid ? at / count[1] : 0u, k1 = valid ? at % count[1] : 0u;
+                        word0[h] = weighted_word[wave][slot][0][k0]; word1[h] = weighted_word[wave][slot][1][k1];
+                        prior[h] = d.cross_prior_double[word0[h] * radix[0] + word1[h] * radix[1]];
+                        value[h] = valid ? weighted_value[wave][slot][1][k1] * weighted_value[wave][slot][0][k0] : -1.0;
+                    }
+#pragma unroll
+                    for(int h = 0; h < 4; ++h) {
+                        if(!(value[h] >= 0 && prior[h] * value[h] >= floor)) { continue; }
+                        const int flat = word0[h] * radix[0] + word1[h] * radix[1];
+                        uint32_t flags[S];
+                        flags[0] = (mismatch_fields(observed[0] ^ lds_word[word0[h]]) | outside[0]) & full_mask[0];
+                        flags[S - 1] = (mismatch_fields(observed[S - 1] ^ lds_word[(S - 1) * WORDS + word1[h]]) | outside[S - 1]) & full_mask[S - 1];
+                        candidate(d.cross_identity ? flat : d.cross_ordinal[flat], prior[h], flags);
+                    }
                 }
             }
             // ... folded over the read's lanes the same way
@@ -547,7 +704,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 4)))
                 distance += __popc(best_flags[s]);
                 hq_distance += __popc(best_flags[s] & high_quality[s]);
             }
-            const double total = (PRIORS ? sum_all : sum_all * uniform_concentration) + d.adjusted_noise_probability;   // pamld.cpp:61-86
+            const double total = ((PRIORS || WEIGHTED) ? sum_all : sum_all * uniform_concentration) + d.adjusted_noise_probability;   // pamld.cpp:61-86
             const double confidence = best_p / total;                                    // pamld.cpp:92
             const bool is_noise = !(best_conditional > d.random_barcode_probability);    // pamld.cpp:96, on the literal value
             if(!is_noise && !(fabs(confidence - d.confidence_threshold) > 1e-12)) { defer = true; }
@@ -583,6 +740,21 @@ int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 gr
     }
 }
 
+template <int G>
+int launch_weighted_form(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    hipLaunchKernelGGL((pamld_exact_lanes_kernel<G, 2, false, CROSS_MAX_UNIQUE, 8, true>), grid, dim3(THREADS), histogram_bytes, stream, args);
+    return static_cast<int>(hipGetLastError());
+}
+inline int launch_weighted(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    switch(host_decoder.cross_groups) {
+        case 1: return launch_weighted_form<1>(args, grid, histogram_bytes, stream);
+        case 2: return launch_weighted_form<2>(args, grid, histogram_bytes, stream);
+        case 3: return launch_weighted_form<3>(args, grid, histogram_bytes, stream);
+        case 4: return launch_weighted_form<4>(args, grid, histogram_bytes, stream);
+        default: return static_cast<int>(hipErrorInvalidValue);
+    }
+}
+
 constexpr int SHORT_LANES = 4;             // lanes of a read of a set of at most CROSS_MAX_UNIQUE words a segment
 constexpr int LONG_LANES = 8;              // ... of a single segment set of up to EXACT_SINGLE_UNIQUE words
 
@@ -592,8 +764,10 @@ constexpr int LONG_LANES = 8;              // ... of a single segment set of up 
 // quality compare wants a threshold of at most 128 and the histogram must leave the kernel's static LDS its room
 bool pamld_exact_lanes_supports(const DevDecoder& host_decoder, size_t histogram_bytes) {
     static const bool off = std::getenv("PHQ_NO_EXACT_LANES") != nullptr;
+    static const bool no_weighted = std::getenv("PHQ_NO_EXACT_LANES_WEIGHTED") != nullptr;
     if(off || !pamld_exact_supports(host_decoder)) { return false; }
-    if(host_decoder.cross_segments > 2 || (host_decoder.cross_segments == 2 && !host_decoder.uniform_prior)) { return false; }
+    if(host_decoder.cross_segments > 2) { return false; }
+    if(host_decoder.cross_segments == 2 && !host_decoder.uniform_prior && (host_decoder.cross_prior_double == nullptr || no_weighted)) { return false; }
     return host_decoder.high_quality_threshold <= 128 && histogram_bytes <= 24u * 1024u;
 }
 
@@ -603,7 +777,8 @@ int launch_pamld_exact_lanes(const StageArgs& args, const DevDecoder& host_decod
     grouped.worklist_segments = static_cast<int32_t>(grid.x);
     // about 1 % of the reads reach this tier: segments are grouped until a wave can expect a few iterations' worth of them
     const bool many = host_decoder.cross_segments == 1 && host_decoder.cross_unique[0] > CROSS_MAX_UNIQUE;
-    const int reads = 64 / (many ? lanes::LONG_LANES : lanes::SHORT_LANES);
+    const bool weighted = host_decoder.cross_segments == 2 && !host_decoder.uniform_prior;
+    const int reads = 64 / ((many || weighted) ? lanes::LONG_LANES : lanes::SHORT_LANES);
     const double expected_per_segment = 0.01 * static_cast<double>(args.n_read) / static_cast<double>(std::max(1u, grid.x));
     const int group = expected_per_segment >= 4.0 * reads ? 1 : static_cast<int>(4.0 * reads / std::max(expected_per_segment, 0.25)) + 1;
     grouped.worklist_group = std::min(lanes::GROUP_MAX, std::max(1, group));
@@ -611,6 +786,12 @@ int launch_pamld_exact_lanes(const StageArgs& args, const DevDecoder& host_decod
     if(forced > 0) { grouped.worklist_group = std::min(lanes::GROUP_MAX, forced); }
     const unsigned per_workgroup = static_cast<unsigned>(lanes::WAVES * grouped.worklist_group);
     const dim3 fewer((grid.x + per_workgroup - 1) / per_workgroup);
+    if(weighted) {
+        // the listed form with eight lanes a read, then the whole form — a wave per read — on what its lists could not hold
+        if(const int status = lanes::launch_weighted(grouped, host_decoder, fewer, histogram_bytes, stream)) { return status; }
+        trace_worklist("the exact tier's lists", args, grid.x, stream);
+        return launch_pamld_cross_exact_dense(args, host_decoder, grid, histogram_bytes, stream);
+    }
     if(host_decoder.cross_segments == 1) {
         if(many) {
             return host_decoder.uniform_prior ? lanes::launch_groups<1, false, EXACT_SINGLE_UNIQUE, lanes::LONG_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream)
