@@ -240,6 +240,8 @@ def parity_check(torch, w, mode, reads):
 CONFIG_TEXT = {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x96 barcodes",
                "C4": "sci-RNA-seq cellular [96x10, 96x(10+10)] + UMI 8", "C5": "SPLiT-seq cellular [96x8 x3, 4x6 rc] + UMI 10",
                "C4V": "sci-RNA-seq cellular [96x10, 196x(10+10)] (the vignette's second set) + UMI 8",
+               "H94": "unique dual index, the 94 pairs of 8+8 bp of flowcell H7LT2DSXX lane 1, noise 0.05 (the reference's prior estimation run, docs/illumina_api_vignette.md:222)",
+               "H94A": "the same 94 pairs with the priors and the noise that run estimated (example/H7LT2DSXX/H7LT2DSXX_l01_adjusted.json)",
                "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
                "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}
 
@@ -321,8 +323,21 @@ class Workload:
         self.merge()                           # inside the timed region: the K steps are K batches of one run
         barrier()
         elapsed = time.perf_counter() - t0
-        kernels = self.set.profile_collect()
+        # every timed launch under the name of the kernel the dispatcher took: summed per kind (what the line has always
+        # carried) and per (decoder, kernel) — the chain that really ran, with its time per step
+        spans = self.set.profile_chain()
         self.set.profile_enable(False)
+        kernels, chain, order = {}, {}, []
+        for span in spans:
+            kind = self.set.KERNEL_KINDS[span["kind"]]
+            entry = kernels.setdefault(kind, {"ms": 0.0, "launches": 0})
+            entry["ms"] += span["ms"]; entry["launches"] += 1
+            key = (span["decoder"], span["kernel"])
+            if key not in chain:
+                chain[key] = 0.0
+                order.append(key)
+            chain[key] += span["ms"]
+        self.chain = [{"decoder": decoder, "kernel": kernel, "ms_per_step": chain[(decoder, kernel)] / steps} for decoder, kernel in order]
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -338,7 +353,7 @@ class Workload:
         self.counted_reads = total
         bytes_per_step = self.bytes_per_read * self.n
         return {"elapsed": elapsed, "counted_reads": total, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
-                "kernels": kernels, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
+                "kernels": kernels, "chain": self.chain, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
                 "launches_per_step": kernels[dominant]["launches"] / steps,
                 "achieved_GBs": bytes_per_step / (kernel_ms * 1e-3) / 1e9, "step_GBs": bytes_per_step / (classify_ms * 1e-3) / 1e9}
 
@@ -447,6 +462,7 @@ def main():
                          "step_achieved": m["step_GBs"], "step_frac": m["step_GBs"] / HBM_PEAK_GBS,
                          "measured_copy_GBs": measured_copy_bandwidth(torch, device) if world == 1 else None,
                          "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in m["kernels"].items()},
+                         "chain": m["chain"],
                          "classify_ms_per_step": m["classify_ms"]},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -476,7 +492,11 @@ def main():
                                                            ("C4_pamld", "C4", "pamld", 50_000_000, "uniform"), ("C4V_pamld", "C4V", "pamld", 50_000_000, "uniform"),
                                                            ("C2_mdd", "C2", "mdd", 100_000_000, "uniform"),
                                                            ("C2_pamld_estimated_priors", "C2", "pamld", 100_000_000, "estimated"),
-                                                           ("C3_pamld_estimated_priors", "C3", "pamld", 50_000_000, "estimated")):
+                                                           ("C3_pamld_estimated_priors", "C3", "pamld", 50_000_000, "estimated"),
+                                                           # the one workload the reference publishes a wall clock for, and the cliffs
+                                                           # outside BASELINE.json's shapes (384 indexes, 384 pairs)
+                                                           ("H94_pamld", "H94", "pamld", 100_000_000, "uniform"), ("H94A_pamld", "H94A", "pamld", 100_000_000, "uniform"),
+                                                           ("S384_pamld", "S384", "pamld", 100_000_000, "uniform"), ("U384_pamld", "U384", "pamld", 100_000_000, "uniform")):
                 shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool, priors)
                 sm = shape.measure(5, 2, 1, barrier)
                 shape_parity = None if args.no_parity else parity_check(torch, shape, args.mode, 1 << 16)
@@ -489,7 +509,10 @@ def main():
                                         "traffic_step_bytes_per_read": shape_traffic["step_bytes_per_read"] if shape_traffic else None,
                                         "traffic_stale": shape_traffic["stale"] if shape_traffic else None,
                                         "parity_checked_reads": shape_parity["reads"] if shape_parity else 0, "parity": shape_parity,
-                                        "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in sm["kernels"].items()}}
+                                        "kernels_ms_per_step": {k: v["ms"] / 5 for k, v in sm["kernels"].items()}, "chain": sm["chain"]}
+                if config in ("H94", "H94A"):
+                    line["shapes"][name]["published"] = {"whole process Mreads/s": 0.459, "where": "docs/illumina_api_vignette.md:222: about 1:45 hours per lane of 2 894 717 093 reads, "
+                                                         "gzip FASTQ in, /dev/null out, dual socket Xeon E5-2620 (12 cores); IO inclusive, not a kernel figure"}
                 shape.close()
         print(json.dumps(line))
     else:

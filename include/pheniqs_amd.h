@@ -228,6 +228,11 @@ int phq_transcode_plan(phq_decoder_set* set, char** plan_json);
 #define PHQ_KERNEL_KINDS            7
 int phq_profile_enable(phq_decoder_set* set, int32_t enable);
 int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNEL_KINDS] */, int64_t* launches /* [PHQ_KERNEL_KINDS] */);
+/* The same spans one by one, in launch order, under the name of the kernel (or tier) the stage dispatcher took for the
+ * decoder — the names are given where its predicates choose, so this is the chain that really ran, not a description of
+ * it: *chain_json = [{"decoder": k, "kernel": "pamld_stream_kernel", "kind": PHQ_KERNEL_*, "ms": t}, ...] (release with
+ * phq_free_string).  Forgets the spans like phq_profile_collect; call one or the other after a batch. */
+int phq_profile_chain(phq_decoder_set* set, char** chain_json);
 
 /* Pinned host memory for batches handed to phq_classify_host (hipHostMalloc / hipHostFree). */
 int phq_host_alloc(uint64_t bytes, void** pointer);

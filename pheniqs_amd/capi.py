@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -103,6 +103,7 @@ def load_library():
     L.phq_transcode_plan.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
+    L.phq_profile_chain.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_load_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
@@ -334,6 +335,15 @@ class DecoderSet:
         return {name: {"ms": ms[k], "launches": launches[k]} for k, name in enumerate(self.KERNEL_KINDS) if launches[k]}
 
     # ---- statistics -----------------------------------------------------------------------------------
+
+    def profile_chain(self) -> List[Dict[str, Any]]:
+        """phq_profile_chain: every timed launch since the last collect, in launch order, under the kernel's name."""
+        out = ctypes.c_void_p()
+        self._check(self.lib.phq_profile_chain(self.handle, ctypes.byref(out)))
+        try:
+            return json.loads(ctypes.string_at(out.value).decode())
+        finally:
+            self.lib.phq_free_string(out)
 
     def stats_reset(self, stream: int = 0):
         self._check(self.lib.phq_stats_reset(self.handle, stream or None))

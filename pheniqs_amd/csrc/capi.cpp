@@ -220,6 +220,18 @@ int phq_profile_collect(phq_decoder_set* set, double* milliseconds, int64_t* lau
     });
 }
 
+int phq_profile_chain(phq_decoder_set* set, char** chain_json) {
+    if(chain_json != nullptr) { *chain_json = nullptr; }
+    return guarded(set, [&]() {
+        require(set, "set"); require(chain_json, "chain_json");
+        const std::string text = set->impl.profile_chain();
+        char* const out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *chain_json = out;
+    });
+}
+
 int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char* const* input_path, const char* sam_output_path,
                                int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count) {
     return guarded(set, [&]() {

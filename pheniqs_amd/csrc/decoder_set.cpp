@@ -39,10 +39,10 @@ void check(hipError_t status, const char* what) {
 
 // hipEventRecord right before and right after each kernel launch, on the launch stream
 struct DecoderSet::EventTimer : LaunchTimer {
-    struct Span { int32_t kind; hipEvent_t start; hipEvent_t stop; };
+    struct Span { int32_t kind; hipEvent_t start; hipEvent_t stop; int32_t decoder; const char* name; };
     std::vector<Span> spans;
-    void begin(int32_t kind, void* stream) override {
-        Span span{kind, nullptr, nullptr};
+    void begin(int32_t kind, void* stream, const char* name) override {
+        Span span{kind, nullptr, nullptr, decoder, name};
         check(hipEventCreate(&span.start), "hipEventCreate");
         check(hipEventCreate(&span.stop), "hipEventCreate");
         check(hipEventRecord(span.start, static_cast<hipStream_t>(stream)), "hipEventRecord");
@@ -63,6 +63,23 @@ struct DecoderSet::EventTimer : LaunchTimer {
             (void)hipEventDestroy(span.stop);
         }
         spans.clear();
+    }
+    // every span since the last collect, in launch order: [{"decoder", "kernel", "kind", "ms"}]; forgets them
+    std::string chain() {
+        std::string out = "[";
+        char number[64];
+        for(size_t k = 0; k < spans.size(); ++k) {
+            auto& span = spans[k];
+            check(hipEventSynchronize(span.stop), "hipEventSynchronize");
+            float ms = 0;
+            check(hipEventElapsedTime(&ms, span.start, span.stop), "hipEventElapsedTime");
+            std::snprintf(number, sizeof(number), "%.6f", static_cast<double>(ms));
+            out += std::string(k ? ", " : "") + "{\"decoder\": " + std::to_string(span.decoder) + ", \"kernel\": \"" + span.name + "\", \"kind\": " + std::to_string(span.kind) + ", \"ms\": " + number + "}";
+            (void)hipEventDestroy(span.start);
+            (void)hipEventDestroy(span.stop);
+        }
+        spans.clear();
+        return out + "]";
     }
     ~EventTimer() override {
         for(auto& span : spans) { (void)hipEventDestroy(span.start); (void)hipEventDestroy(span.stop); }
@@ -123,6 +140,12 @@ void DecoderSet::profile_enable(bool enable) {
     require_device();
     if(enable && timer_ == nullptr) { timer_ = new EventTimer(); }
     if(!enable) { delete timer_; timer_ = nullptr; }
+}
+
+std::string DecoderSet::profile_chain() {
+    require_device();
+    if(timer_ == nullptr) { throw InternalError("profiling is not enabled"); }
+    return timer_->chain();
 }
 
 void DecoderSet::profile_collect(double* milliseconds, int64_t* launches) {
@@ -511,7 +534,7 @@ void DecoderSet::build_device_images() {
                             if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
                             table[slot_of(key)] = named;
                         }
-                        d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint16_t)));
+                        d.stream_table = upload(table.data(), table.size() * sizeof(uint16_t));
                         if(!d.identity_index) { indexable = false; }
                     } else {
                         std::vector<uint32_t> table(65536, (STREAM_UNKNOWN << 18) | first_block);
@@ -520,7 +543,7 @@ void DecoderSet::build_device_images() {
                             if(named == NEAR_NO_BARCODE || !usable[named]) { continue; }
                             table[slot_of(key)] = (static_cast<uint32_t>(index[named]) << 18) | (first_block + static_cast<uint32_t>(named) * stream_stride);
                         }
-                        d.stream_table = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint32_t)));
+                        d.stream_table = upload(table.data(), table.size() * sizeof(uint32_t));
                     }
                     d.stream_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                     d.stream_ready = indexable ? d.near_ready : 0;
@@ -795,7 +818,7 @@ void DecoderSet::build_device_images() {
                                 for(int32_t s2 = 0; s2 < 2 && fits; ++s2) {
                                     const auto& set = distinct[static_cast<size_t>(s2)];
                                     const int32_t N = static_cast<int32_t>(set.size());
-                                    if(N >= static_cast<int32_t>(STREAM_UNKNOWN)) { fits = false; break; }
+                                    if(N >= static_cast<int32_t>(CROSS_STREAM_UNKNOWN)) { fits = false; break; }      // an ordinal is a byte of the table
                                     std::vector<uint32_t> low(set.size(), 0u), high(set.size(), 0u);
                                     for(size_t u = 0; u < set.size(); ++u) {
                                         for(int32_t j = 0; j < length; ++j) {
@@ -828,7 +851,7 @@ void DecoderSet::build_device_images() {
                                             std::memcpy(&to[2 * list + k], &rounded, sizeof(float));
                                         }
                                     }
-                                    std::vector<uint8_t> table(length > 8 ? (static_cast<size_t>(1) << (2 * length)) : 65536, static_cast<uint8_t>(0xffu));      // a word's ordinal
+                                    std::vector<uint8_t> table(length > 8 ? (static_cast<size_t>(1) << (2 * length)) : 65536, CROSS_STREAM_UNKNOWN);      // a word's ordinal
                                     const uint32_t positions = (1u << length) - 1u;
                                     const std::vector<uint16_t>& named_by = near_table_of[s2];
                                     for(uint32_t key = 0; key < (1u << (2 * length)); ++key) {
@@ -838,7 +861,7 @@ void DecoderSet::build_device_images() {
                                         if(named == NEAR_NO_BARCODE) { continue; }
                                         table[(l & 0xfu) | ((h & 0xfu) << 4) | (((l >> 4) & 0xfu) << 8) | (((h >> 4) & 0xfu) << 12) | ((l >> 8) << 16) | ((h >> 8) << (16 + tail))] = static_cast<uint8_t>(named);
                                     }
-                                    d.cross_stream_table[s2] = static_cast<const uint32_t*>(upload(table.data(), table.size() * sizeof(uint8_t)));
+                                    d.cross_stream_table[s2] = upload(table.data(), table.size() * sizeof(uint8_t));
                                     d.cross_stream_record[s2] = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                                 }
                                 d.cross_stream_ready = fits ? 1 : 0;
@@ -1169,6 +1192,7 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         args.last_stage = (args.job_outgoing || folded > 0) ? 1 : 0;      // the stage counts its outgoing reads
         args.echo_count = static_cast<int32_t>(folded);
         for(size_t e = 0; e < folded; ++e) { args.echo_offset[e] = host_decoder_[k + 1 + e].stats_offset; }
+        if(timer_) { timer_->decoder = static_cast<int32_t>(k); }
         check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream, timer_)), "kernel launch");
         k += folded;
     }

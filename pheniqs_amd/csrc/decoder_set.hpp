@@ -58,6 +58,7 @@ public:
     // HIP event timing of every kernel launch (bench.py roofline): enable, run, then collect sums per kernel kind
     void profile_enable(bool enable);
     void profile_collect(double* milliseconds, int64_t* launches);
+    std::string profile_chain();
 
     // quality control accumulators of the output reads (qc.hpp), filled by the transcoder's record threads when the job
     // enables them; cleared with the counters (stats_reset), merged across sets or processes through their flat image

@@ -60,6 +60,8 @@ constexpr uint32_t cross_stream_block_at(int waves, int length, int unique0, int
            (segment ? static_cast<uint32_t>(unique0) * static_cast<uint32_t>(cross_stream_block_words(length)) * 4u : 0u);
 }
 constexpr uint32_t STREAM_UNKNOWN = 0x3fffu;   // the index field of a lookup that names no barcode
+constexpr uint8_t CROSS_STREAM_UNKNOWN = 0xffu; // pamld_cross_stream.hpp's byte tables: a key that names no word
+static_assert(CROSS_MAX_UNIQUE < CROSS_STREAM_UNKNOWN, "a word's ordinal and the unknown mark share a byte");
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
 constexpr int NEAR_MAX_BARCODES = 1024;
@@ -161,7 +163,8 @@ struct DevDecoder {
     const uint32_t* near_record;
     int32_t near_ready;                   // both present and the radius is at least 4 for most barcodes
     // streaming kernel (pamld_stream.hpp; 5 to 10 nt): the same two things in pamld_lut.hpp's bit order (9 and 10 nt: the
-    // table has 4^L entries of 16 bits, a barcode's ordinal, and a block lists 8 barcodes one per plane word — stream_list).
+    // table has 4^L entries of 16 BITS, a barcode's ordinal — hence `const void*`: 32 bit entries up to 8 nt, 16 bit ones past
+    // it — and a block lists 8 barcodes one per plane word — stream_list).
     // stream_table[key], 65536 entries: key = bits 2..17 of the bit-sliced observation (positions 0..3: low code bits in
     // key bits 0..3, high code bits in 4..7; positions 4..7 in bits 8..15); an entry = the LDS address of the barcode's
     // block (18 bits) | barcode_index << 18, index field STREAM_UNKNOWN for a word that names none.  stream_record[c] =
@@ -169,7 +172,7 @@ struct DevDecoder {
     // as 8 low plane words then 8 high plane words, then how many barcodes that are not listed sit 3, 4, 5 and 6 or more
     // mismatches from c (floats; with priors that differ the sums of their priors over c's; infinite if one sits closer than 3),
     // with priors that differ the 16 prior ratios of the listed barcodes (slot 0: the noise term over c's prior), then zeros (the bin, padding)
-    const uint32_t* stream_table;
+    const void* stream_table;
     const uint32_t* stream_record;
     int32_t stream_ready;
     // one lookup MDD (mdd_near.hpp; one segment of 5 to 10 nt, tolerance 0 or 1): near_table as above and per barcode
@@ -191,11 +194,11 @@ struct DevDecoder {
     const uint16_t* cross_near_table[2];
     const uint32_t* cross_near_record[2];
     int32_t cross_near_ready;
-    // the streaming kernel of such sets (pamld_cross_stream.hpp; uniform priors, 8 to 10 nt words): per segment the lookup
-    // table of pamld_stream.hpp over the segment's distinct words — an entry = the LDS address of the word's block (18 bits)
-    // | the word's ordinal in its segment << 18, ordinal field STREAM_UNKNOWN for a word that names none — and the image
-    // of the blocks, cross_stream_block_words(L) words each
-    const uint32_t* cross_stream_table[2];
+    // the streaming kernel of such sets (pamld_cross_stream.hpp; uniform priors, 8 to 10 nt words): per segment a lookup
+    // table over the segment's distinct words — ONE BYTE an entry (4^L of them; 65 536 up to 8 nt): the ordinal in its segment
+    // of the word the key names, CROSS_STREAM_UNKNOWN (0xff) for a key that names none, so a segment holds at most 254 words
+    // (CROSS_MAX_UNIQUE is 128: checked below) — and the image of the blocks, cross_stream_block_words(L) words each
+    const void* cross_stream_table[2];
     const uint32_t* cross_stream_record[2];
     int32_t cross_stream_ready;
     // ... with priors that differ: per combination (c0, c1), 16 floats each.  cross_near_weight[0]: the noise term over
@@ -289,8 +292,9 @@ constexpr int CARRY_PLANES = 7;
 // Optional per launch timing: HIP events recorded on the launch stream right around each kernel.
 enum KernelKind : int32_t { KERNEL_PAMLD_PRODUCT = 0, KERNEL_PAMLD_LITERAL = 1, KERNEL_MDD = 2, KERNEL_COUNT = 3, KERNEL_MDD_EXACT = 4, KERNEL_PAMLD_EXACT = 5, KERNEL_PAMLD_NEAR = 6, KERNEL_KINDS = 7 };
 struct LaunchTimer {
+    int32_t decoder = 0;                  // the decoder whose stage is being launched (set by the caller of launch_stage)
     virtual ~LaunchTimer() {}
-    virtual void begin(int32_t kind, void* stream) = 0;
+    virtual void begin(int32_t kind, void* stream, const char* name) = 0;      // name: a literal, the kernel the dispatcher took
     virtual void end(void* stream) = 0;
 };
 

@@ -236,14 +236,15 @@ int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capac
 int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
                  uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, void* stream) {
     if(n == 0) { return 0; }
-    static DecodeArgs args;                  // filled per call; the tables once
-    static bool tables = false;
-    if(!tables) {
-        for(int c = 0; c < 256; ++c) { args.bam_of_ascii[c] = ascii_to_bam(static_cast<uint8_t>(c)); }
-        for(int c = 0; c < 16; ++c) { args.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c)); }
-        tables = true;
-    }
-    DecodeArgs call = args;
+    // the two tables once per process: a function local static initialised by a lambda (thread safe: two host threads
+    // transcoding with two decoder sets may come here together); every call copies them into its own arguments
+    static const DecodeArgs with_tables = []() {
+        DecodeArgs filled{};
+        for(int c = 0; c < 256; ++c) { filled.bam_of_ascii[c] = ascii_to_bam(static_cast<uint8_t>(c)); }
+        for(int c = 0; c < 16; ++c) { filled.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c)); }
+        return filled;
+    }();
+    DecodeArgs call = with_tables;
     call.plan = plan;
     for(int f = 0; f < plan.n_feed; ++f) { call.chunk[f] = chunk[f]; }
     call.n = n;

@@ -144,7 +144,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
     const int64_t tiles = (n + 63) / 64;
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
     // the lookup tables hold a word's ORDINAL in its segment, one byte an entry (1 MB a segment of 10 nt: both stay in L2)
-    const uint8_t* const nearest[SEGMENTS] = {reinterpret_cast<const uint8_t*>(d.cross_stream_table[0]), reinterpret_cast<const uint8_t*>(d.cross_stream_table[1])};
+    const uint8_t* const nearest[SEGMENTS] = {static_cast<const uint8_t*>(d.cross_stream_table[0]), static_cast<const uint8_t*>(d.cross_stream_table[1])};
     const uint32_t blocks_at[SEGMENTS] = {Layout::block_at(unique[0], unique[1], 0), Layout::block_at(unique[0], unique[1], 1)};
     const uint32_t rings_at = Layout::RING_AT + wave * Layout::RING_BYTES;      // this wave's three rings: by what pass C has to scan
     const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
@@ -252,7 +252,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
     struct Score { float winner, matches, x_listed, x_rest; uint32_t k, high_mismatch, ordinal, mismatches; bool known; };
     auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, uint32_t first_block, Score& out) {
         const uint32_t ordinal = looked_up;                                    // the word's ordinal in its segment
-        const bool known = ordinal != 0xffu;
+        const bool known = ordinal != CROSS_STREAM_UNKNOWN;
         const uint32_t block = first_block + (known ? ordinal : 0u) * Layout::BLOCK_BYTES;
         Quad record[Layout::BLOCK_QUADS];
 #pragma unroll

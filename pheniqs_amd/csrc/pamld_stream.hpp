@@ -191,7 +191,7 @@ void pamld_stream_kernel(StageArgs args) {
     const int64_t n = args.n_read;
     const int64_t tiles = (n + 63) / 64;
     const int64_t tile_step = static_cast<int64_t>(gridDim.x) * WAVES;
-    const uint32_t* const nearest = d.stream_table;
+    const void* const nearest = d.stream_table;      // 32 bit entries (block address | index) up to 8 nt, 16 bit ordinals past it
     uint32_t* const ring = reinterpret_cast<uint32_t*>(lds_raw + Layout::RING_AT + wave * Layout::RING_BYTES);
     // this wave's segment of the HBM worklist (what pass C cannot decide either)
     const int64_t own_segment = static_cast<int64_t>(blockIdx.x) * WAVES + wave;
@@ -569,7 +569,7 @@ void pamld_stream_kernel(StageArgs args) {
         }
         // the barcode this word is (next to), if any.  Past 8 nt the table has 4^L entries and holds the barcode's ORDINAL in 16
         // bits (2 MB for 10 nt, where 32 bit entries were 4 MB and missed in L2 for a third of the reads)
-        to.looked_up = TAIL ? static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(nearest)[key]) : nearest[key];
+        to.looked_up = TAIL ? static_cast<uint32_t>(static_cast<const uint16_t*>(nearest)[key]) : static_cast<const uint32_t*>(nearest)[key];
         to.in = in;
     };
 #ifdef PHQ_DIAG_STAGGER

@@ -1,6 +1,8 @@
 // Quality control accumulators: see qc.hpp.
 #include "qc.hpp"
 
+#include <cmath>
+
 #include <algorithm>
 #include <cstring>
 
@@ -190,6 +192,9 @@ std::vector<uint64_t> QcState::to_words() const {
     return words;
 }
 
+// An image gathered from another rank or process may be cut short or damaged: nothing is allocated on the word of its
+// header alone — every cell's room is checked against what the image still holds before it is resized — and an average that
+// is not a finite number is refused (it would poison the maximum of a merge).
 QcState QcState::from_words(const uint64_t* words, size_t n) {
     QcState state;
     if(n < 2) { throw InternalError("quality control image too short"); }
@@ -197,10 +202,15 @@ QcState QcState::from_words(const uint64_t* words, size_t n) {
     auto take = [&]() { if(at >= n) { throw InternalError("quality control image too short"); } return words[at++]; };
     const uint64_t channels = take(), segments = take();
     if(channels > (1u << 20) || segments > 64) { throw InternalError("quality control image out of range"); }
+    constexpr size_t CELL_FIXED = 2 + QC_CODES + 3 + QC_PHRED_RANGE;               // what a cell holds besides its cycles
+    const uint64_t cells = channels * segments;
+    if(cells > (n - at) / CELL_FIXED) { throw InternalError("quality control image too short for its " + std::to_string(cells) + " cells"); }
     state.shape(static_cast<int32_t>(channels), static_cast<int32_t>(segments));
     for(auto& cell_of : state.cell) {
         const uint64_t capacity = take();
         if(capacity > (1u << 20)) { throw InternalError("quality control image out of range"); }
+        const size_t cycle_words = static_cast<size_t>(capacity) * QC_CODES * QC_PHRED_RANGE;
+        if(CELL_FIXED - 1 + cycle_words > n - at) { throw InternalError("quality control image too short"); }      // before anything is resized
         cell_of.capacity = static_cast<int32_t>(capacity);
         cell_of.shortest = static_cast<int32_t>(static_cast<uint32_t>(take()));
         for(int c = 0; c < QC_CODES; ++c) { cell_of.nucleic[c] = take(); }
@@ -208,8 +218,9 @@ QcState QcState::from_words(const uint64_t* words, size_t n) {
         cell_of.average_sum_fixed = take();
         const uint64_t bits = take();
         std::memcpy(&cell_of.average_max, &bits, sizeof(bits));
+        if(!std::isfinite(cell_of.average_max)) { throw InternalError("quality control image: an average that is not a number"); }
         for(int q = 0; q < QC_PHRED_RANGE; ++q) { cell_of.average_distribution[q] = take(); }
-        cell_of.cycle.resize(static_cast<size_t>(capacity) * QC_CODES * QC_PHRED_RANGE);
+        cell_of.cycle.resize(cycle_words);
         for(auto& w : cell_of.cycle) { w = take(); }
     }
     return state;

@@ -42,12 +42,20 @@ void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, 
 }
 
 namespace {
+// a launch (or the launches of one tier) between two events of the timer, under the name of the kernel taken: the names
+// are given where the dispatcher's predicates have just chosen, so phq_profile_chain reports the chain that really ran
 struct Timed {
     LaunchTimer* timer;
     void* stream;
-    Timed(LaunchTimer* timer, int32_t kind, void* stream) : timer(timer), stream(stream) { if(timer) { timer->begin(kind, stream); } }
+    Timed(LaunchTimer* timer, int32_t kind, void* stream, const char* name) : timer(timer), stream(stream) { if(timer) { timer->begin(kind, stream, name); } }
     ~Timed() { if(timer) { timer->end(stream); } }
 };
+const char* exact_name(const DevDecoder& host_decoder, size_t histogram_bytes) {
+    if(pamld_exact_lanes_supports(host_decoder, histogram_bytes)) {
+        return (host_decoder.cross_segments == 2 && !host_decoder.uniform_prior) ? "pamld_exact_lanes_kernel (weighted) + pamld_cross_exact_dense_kernel" : "pamld_exact_lanes_kernel";
+    }
+    return (host_decoder.cross_segments == 2 && !host_decoder.uniform_prior) ? "pamld_cross_exact_weighted_kernel + pamld_cross_exact_dense_kernel" : "pamld_cross_exact_kernel";
+}
 }  // namespace
 
 int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer);
@@ -60,7 +68,7 @@ int launch_stage(const StageArgs& caller_args, const DevDecoder& host_decoder, i
                           count_results_supports(host_decoder) ? 1 : 0;
     const int status = launch_classifier(args, host_decoder, mode, max_blocks, stream, timer);
     if(status != 0 || !args.defer_counters) { return status; }
-    Timed timed(timer, KERNEL_COUNT, stream);
+    Timed timed(timer, KERNEL_COUNT, stream, "count_results_kernel");
     return launch_count_results(args, host_decoder, max_blocks / GRID_BLOCKS_PER_CU, static_cast<hipStream_t>(stream));      // one workgroup per CU
 }
 
@@ -125,7 +133,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     producer.carry = nullptr;
                     producer.carry_stride = 0;
                     {
-                        Timed timed(timer, few ? KERNEL_PAMLD_PRODUCT : KERNEL_PAMLD_NEAR, stream);
+                        Timed timed(timer, few ? KERNEL_PAMLD_PRODUCT : KERNEL_PAMLD_NEAR, stream, few ? "pamld_few_kernel" : cross_streamed ? "pamld_cross_stream_kernel" : "pamld_stream_kernel");
                         status = few ? launch_pamld_few(producer, host_decoder, stream_grid, s)
                                : cross_streamed ? launch_pamld_cross_stream(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s);
                     }
@@ -136,18 +144,18 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     consumer.worklist_role = 2;
                     if(pamld_exact_supports(host_decoder)) {
                         // several lanes per read where the set is one the lane parallel tier takes (pamld_exact_lanes.hip)
-                        Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                        Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
                         status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
                                                                                           : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
                         if(status != 0) { return status; }
                         trace_worklist("the exact tier", producer, segment_grid.x, s);
                     }
-                    Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
+                    Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
                     return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
                 }
                 if(listed || paired || crossed) {
                     {
-                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream);
+                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream, listed ? "pamld_near_kernel" : paired ? "pamld_pair_kernel" : "pamld_cross_near_kernel");
                         status = listed ? launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s)
                                : paired ? launch_pamld_pair(producer, host_decoder, wide_grid, histogram_bytes, s)
                                         : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s);
@@ -157,7 +165,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
                     middle.worklist_segments = static_cast<int32_t>(wide_grid.x);
-                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
+                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, (!crossed && !long_words) ? "pamld_lut_kernel (consumer)" : crossed ? (host_decoder.uniform_prior ? "pamld_cross_kernel (consumer)" : "pamld_cross_kernel (weighted, consumer)") : "pamld_wide_kernel (consumer)");
                     if(!crossed && !long_words) {
                         // the product form kernel takes the segments in groups: as many workgroups as stay resident
                         static const int consumer_share = std::getenv("PHQ_GRID_SHARE_CONSUMER") ? std::atoi(std::getenv("PHQ_GRID_SHARE_CONSUMER")) : GRID_SHARE_CONSUMER;
@@ -170,7 +178,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                                          : launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s);
                     }
                 } else {
-                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream);
+                    Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, tiny ? "pamld_tiny_kernel" : factorised ? (host_decoder.uniform_prior ? "pamld_cross_kernel" : "pamld_cross_kernel (weighted)") : long_words ? "pamld_wide_kernel" : "pamld_lut_kernel");
                     status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : long_words ? launch_pamld_wide(producer, host_decoder, wide_grid, histogram_bytes, s)
@@ -182,22 +190,22 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 consumer.worklist_role = 2;
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
-                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
                     status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, wide_grid, histogram_bytes, s)
                                                                                       : launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 } else if(long_words && pamld_wide_exact_supports(host_decoder)) {
                     // the same for two word barcodes (pamld_wide_exact.hpp)
-                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream);
+                    Timed timed(timer, KERNEL_PAMLD_EXACT, stream, "pamld_wide_exact_kernel");
                     status = launch_pamld_wide_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 }
                 trace_worklist("the exact tier", producer, wide_grid.x, s);
-                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
+                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
                 return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
             }
             {
-                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream);
+                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel (every read)");
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
@@ -214,7 +222,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.worklist_stride = static_cast<int32_t>((near_tiles + near_grid.x - 1) / near_grid.x * 256);
                 int status;
                 {
-                    Timed timed(timer, KERNEL_MDD_EXACT, stream);
+                    Timed timed(timer, KERNEL_MDD_EXACT, stream, paired ? "mdd_lookup_kernel (paired)" : crossed ? "mdd_lookup_kernel (combinatorial)" : "mdd_lookup_kernel");
                     status = paired ? launch_mdd_pair(producer, host_decoder, near_grid, histogram_bytes, s)
                            : crossed ? launch_mdd_cross2(producer, host_decoder, near_grid, histogram_bytes, s)
                                      : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
@@ -222,14 +230,14 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
-                Timed timed(timer, KERNEL_MDD, stream);
+                Timed timed(timer, KERNEL_MDD, stream, (crossed && mdd_cross_supports(host_decoder)) ? "mdd_cross_kernel" : mdd_scan_supports(host_decoder) ? "mdd_scan_kernel" : "mdd_kernel");
                 if(crossed && mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, near_grid, histogram_bytes, s); }
                 if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }
                 return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s);
             }
             if(mode == MODE_FAST && mdd_fused_supports(host_decoder)) {
                 // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
-                Timed timed(timer, KERNEL_MDD, stream);
+                Timed timed(timer, KERNEL_MDD, stream, "mdd_fused_kernel");
                 const int64_t fused_blocks = share(GRID_SHARE_MDD_FUSED);
                 const dim3 fused_grid(static_cast<unsigned>(tiles < fused_blocks ? tiles : fused_blocks));
                 return launch_mdd_fused(args, host_decoder, fused_grid, histogram_bytes, s);
@@ -243,22 +251,22 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.worklist_stride = static_cast<int32_t>(tiles_per_block * BLOCK);
                 int status;
                 {
-                    Timed timed(timer, KERNEL_MDD_EXACT, stream);
+                    Timed timed(timer, KERNEL_MDD_EXACT, stream, "mdd_exact_kernel");
                     status = launch_mdd_exact(producer, host_decoder, grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
-                Timed timed(timer, KERNEL_MDD, stream);
+                Timed timed(timer, KERNEL_MDD, stream, mdd_scan_supports(host_decoder) ? "mdd_scan_kernel" : mdd_cross_supports(host_decoder) ? "mdd_cross_kernel" : "mdd_kernel");
                 if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, grid, histogram_bytes, s); }
                 if(mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, grid, histogram_bytes, s); }
                 return launch_mdd(consumer, host_decoder, grid, histogram_bytes, s);
             }
-            Timed timed(timer, KERNEL_MDD, stream);
+            Timed timed(timer, KERNEL_MDD, stream, "mdd_kernel (every read)");
             return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
         }
         default: {
-            Timed timed(timer, KERNEL_COUNT, stream);
+            Timed timed(timer, KERNEL_COUNT, stream, "count_kernel");
             return launch_count(args, host_decoder, grid, histogram_bytes, s);
         }
     }

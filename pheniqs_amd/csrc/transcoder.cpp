@@ -33,7 +33,11 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 
@@ -44,6 +48,51 @@
 namespace phq {
 
 namespace {
+
+// Work a call does not wait for (unmapping input files, giving batch buffers back: page table work in the kernel) runs on ONE
+// helper thread owned by this object, which its destructor drains and joins — at process exit or when the library is
+// unloaded nothing of it is left running library code (detached threads could be, and made leak checks flaky).
+class Afterwards {
+public:
+    static Afterwards& instance() { static Afterwards one; return one; }
+    void run(std::function<void()> task) {
+        try {
+            std::unique_lock<std::mutex> lock(mutex_);
+            if(!worker_.joinable()) { worker_ = std::thread([this]() { loop(); }); }
+            queue_.push_back(std::move(task));
+            lock.unlock();
+            wake_.notify_one();
+        } catch(...) {
+            task();                              // no thread to be had: done here and now
+        }
+    }
+    ~Afterwards() {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            stop_ = true;
+        }
+        wake_.notify_one();
+        if(worker_.joinable()) { worker_.join(); }
+    }
+private:
+    void loop() {
+        std::unique_lock<std::mutex> lock(mutex_);
+        for(;;) {
+            wake_.wait(lock, [this]() { return stop_ || !queue_.empty(); });
+            if(queue_.empty()) { return; }       // stopping, and drained
+            std::function<void()> task = std::move(queue_.front());
+            queue_.pop_front();
+            lock.unlock();
+            task();
+            lock.lock();
+        }
+    }
+    std::mutex mutex_;
+    std::condition_variable wake_;
+    std::deque<std::function<void()>> queue_;
+    std::thread worker_;
+    bool stop_ = false;
+};
 
 // std::vector whose resize() leaves trivially constructible elements uninitialised: the batch arrays below are
 // written in full by the parallel passes right after they are sized, and a value initialising resize would first
@@ -115,12 +164,11 @@ public:
     ~FastqStream() {
         if(file_) { gzclose(file_); }
         // unmapping hundreds of megabytes is page table work in the kernel (26 ms after 4 M reads: a fifth of a report only
-        // run of that size): it is left to a thread of its own, the call does not wait for it
+        // run of that size): it is left to the helper thread, the call does not wait for it
         if(map_) {
             char* const address = const_cast<char*>(map_);
             const size_t size = map_size_;
-            try { std::thread([address, size]() { ::munmap(address, size); }).detach(); }
-            catch(...) { ::munmap(address, size); }
+            Afterwards::instance().run([address, size]() { ::munmap(address, size); });
         }
     }
     bool mapped() const { return map_ != nullptr; }
@@ -703,10 +751,9 @@ struct Transcoder::Impl {
     ~Impl() {
         for(auto& s : sink) { s.close(); }      // the staging planes belong to the set (DecoderSet::host_stage)
         // giving the batches' buffers back (and, in ~FastqStream, unmapping the input files) is page table work in the kernel:
-        // 17 + 26 ms after 4 M reads, a third of a report only run of that size.  Both go to threads of their own.
+        // 17 + 26 ms after 4 M reads, a third of a report only run of that size.  Both go to the helper thread (Afterwards).
         auto* const doomed = new std::pair<std::vector<SegmentBatch>, std::vector<SegmentBatch>>(std::move(batch), std::move(ahead));
-        try { std::thread([doomed]() { delete doomed; }).detach(); }
-        catch(...) { delete doomed; }
+        Afterwards::instance().run([doomed]() { delete doomed; });
     }
 };
 

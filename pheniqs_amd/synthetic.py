@@ -10,6 +10,9 @@ from __future__ import annotations
 
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
+import json
+import os
+
 import numpy as np
 
 from . import capi
@@ -70,7 +73,12 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
 
 # BASELINE.json's C2..C5 (C4V: C4 with the 196 pairs of the reference's sci-RNA-seq vignette) plus shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
 # 8 + 8 nt in one two segment sample decoder (not every combination: pair i is word i of each list)
-CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10, "C4V": 11}
+CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10, "C4V": 11, "H94": 12, "H94A": 13}
+# H94 / H94A: the one workload the reference publishes a wall clock for (docs/illumina_api_vignette.md:222, lane 1 of flowcell
+# H7LT2DSXX): 94 unique dual index pairs of 8 + 8 nt, PAMLD — H94 as its prior estimation run has them (uniform priors, noise
+# 0.05), H94A with the priors and the noise that run left (example/H7LT2DSXX/H7LT2DSXX_l01_adjusted.json).  The barcodes and
+# priors are the reference's own data, kept as a fixture (tests/tools/make_h7lt2dsxx_fixture.py writes it).
+H7LT2DSXX_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "H7LT2DSXX", "l01_sample_decoder.json")
 
 
 def config_job(name: str, algorithm: str = "pamld") -> Tuple[Dict[str, Any], Dict[str, Any]]:
@@ -109,6 +117,14 @@ def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
         i7, i5 = barcode_set(rng, 384, 10), barcode_set(rng, 384, 10)
         spec = {"input segment cardinality": 3,
                 "sample": decoder_spec(algorithm, [i7, i5], ["1::10", "2::10"], pairing="zip")}
+    elif name in ("H94", "H94A"):
+        fixture = json.load(open(H7LT2DSXX_FIXTURE))
+        which = fixture["estimate" if name == "H94" else "adjusted"]
+        codec = {key: {"barcode": list(record["barcode"]), "concentration": 1 if name == "H94" else record["concentration"]}
+                 for key, record in fixture["codec"].items()}
+        spec = {"input segment cardinality": 3,
+                "sample": {"algorithm": algorithm, "noise": which["noise"], "confidence threshold": which["confidence threshold"],
+                           "transform": {"token": ["1::8", "2::8"]}, "codec": codec}}
     elif name in ("S384", "S192"):     # 384 / 192 single 8 nt indexes
         spec = {"input segment cardinality": 2,
                 "sample": decoder_spec(algorithm, [barcode_set(rng, 384 if name == "S384" else 192, 8)], ["1::8"])}

@@ -366,3 +366,16 @@ def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
     assert ran.returncode == 0, ran.stdout + ran.stderr
     results = int(ran.stdout.split(" runs, ")[1].split(" results")[0])
     assert "141 runs" in ran.stdout and results >= 20, ran.stdout
+
+
+def test_a_damaged_quality_control_image_is_refused_before_anything_is_allocated():
+    """phq_qc_merge on an image gathered from another rank: a header that promises more cells or cycles than the image
+    holds, or an average that is not a number, is an error — never an allocation sized by the header alone."""
+    s = DecoderSet(jobspec.compile_job(bdggg.user_job()), device=capi.DEVICE_NONE)
+    cell_fixed = 2 + 16 + 3 + 42                                     # capacity, shortest, 16 nucleic counts, 3 average fields, 42 distribution words (qc.hpp)
+    promised = np.array([1 << 20, 64] + [0] * 100, dtype=np.uint64)              # 67 M cells in a hundred words
+    huge_cell = np.array([1, 1, 1 << 20, 0] + [0] * (cell_fixed + 10), dtype=np.uint64)      # one cell of 2^20 cycles
+    for image in (promised, huge_cell, np.array([3], dtype=np.uint64)):
+        with pytest.raises(PheniqsError):
+            s.qc_merge(image)
+    s.close()
