@@ -205,6 +205,16 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
  * Records keep the input order inside every file. */
 int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
 
+/* The same run with n_copy further copies of the decoder set behind the one pull loop — what the reference does with one
+ * TranscodingDecoder per thread (transcode.cpp:1769-1775,2287-2300), here one copy per GPU of a node driven by one process:
+ * copy[k] is a set created from the same job on another device (phq_create(job, device k + 1, ...)); batch b is classified
+ * by the set (b mod (n_copy + 1) == 0) or by copy (b mod (n_copy + 1)) - 1, records leave in input order, and when the input
+ * ends every copy's counters are added into the set's and zeroed (transcode.cpp:1816-1818 -> selector.cpp:68-77), so
+ * phq_stats_export / phq_report_json on `set` then speak for the whole run.  With processes per GPU instead, the same merge
+ * is phq_stats_allreduce.  A report only run that decodes its FASTQ text on the device stays on the set's own device. */
+int phq_transcode_job_copies(phq_decoder_set* set, int32_t n_copy, phq_decoder_set* const* copy, int64_t batch_capacity,
+                             uint64_t* incoming_count, uint64_t* incoming_pf_count);
+
 /* What phq_transcode_job would open, without opening it: the counterpart of the `feed` section the reference's compile
  * step leaves in the job (transcode.cpp:683-733 "input feed" / "input feed by segment", 1373-1413 "output feed") and of
  * the channels' output routing (multiplex.h:198-240).  *plan_json (release with phq_free_string):

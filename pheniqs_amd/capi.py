@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -100,6 +100,7 @@ def load_library():
     L.phq_format_double.argtypes = [ctypes.c_double, I32, ctypes.c_char_p, I32]
     L.phq_transcode_fastq_to_sam.argtypes = [P, I32, P, ctypes.c_char_p, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
     L.phq_transcode_job.argtypes = [P, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
+    L.phq_transcode_job_copies.argtypes = [P, I32, P, I64, ctypes.POINTER(U64), ctypes.POINTER(U64)]
     L.phq_transcode_plan.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
@@ -301,6 +302,14 @@ class DecoderSet:
         incoming = ctypes.c_uint64(0)
         incoming_pf = ctypes.c_uint64(0)
         self._check(self.lib.phq_transcode_job(self.handle, batch_capacity, ctypes.byref(incoming), ctypes.byref(incoming_pf)))
+        return incoming.value, incoming_pf.value
+
+    def transcode_job_copies(self, copies: Sequence["DecoderSet"], batch_capacity: int = 1 << 20):
+        """phq_transcode_job_copies: the job's own run with further copies of this set (one per device) behind the pull loop."""
+        incoming = ctypes.c_uint64(0)
+        incoming_pf = ctypes.c_uint64(0)
+        handles = (ctypes.c_void_p * max(1, len(copies)))(*[c.handle for c in copies])
+        self._check(self.lib.phq_transcode_job_copies(self.handle, len(copies), handles, batch_capacity, ctypes.byref(incoming), ctypes.byref(incoming_pf)))
         return incoming.value, incoming_pf.value
 
     def transcode_plan(self) -> Dict[str, Any]:

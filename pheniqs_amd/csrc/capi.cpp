@@ -263,6 +263,17 @@ int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* in
     });
 }
 
+int phq_transcode_job_copies(phq_decoder_set* set, int32_t n_copy, phq_decoder_set* const* copy, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count) {
+    return guarded(set, [&]() {
+        require(set, "set"); require(incoming_count, "incoming_count"); require(incoming_pf_count, "incoming_pf_count");
+        if(batch_capacity <= 0) { throw phq::InternalError("batch capacity must be positive"); }
+        if(n_copy < 0 || (n_copy > 0 && copy == nullptr)) { throw phq::InternalError("copies missing"); }
+        phq::Transcoder transcoder(set->impl, phq::TranscodePlan::from_job(set->impl.job()), batch_capacity);
+        for(int32_t k = 0; k < n_copy; ++k) { require(copy[k], "copy"); transcoder.add_copy(copy[k]->impl); }
+        transcoder.run(*incoming_count, *incoming_pf_count);
+    });
+}
+
 int phq_host_alloc(uint64_t bytes, void** pointer) {
     return guarded(nullptr, [&]() { require(pointer, "pointer"); *pointer = phq::host_alloc(static_cast<size_t>(bytes)); });
 }

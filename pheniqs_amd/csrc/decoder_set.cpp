@@ -1348,6 +1348,17 @@ void DecoderSet::stats_import(const uint64_t* host_words) {
     check(hipMemcpy(device_stats_, host_words, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t), hipMemcpyHostToDevice), "hipMemcpy");
 }
 
+void DecoderSet::stats_take(DecoderSet& other) {
+    if(other.job_.stats_words != job_.stats_words) { throw ConfigurationError("cannot merge statistics of different jobs"); }
+    std::vector<uint64_t> mine(static_cast<size_t>(job_.stats_words)), theirs(mine.size());
+    other.stats_export(theirs.data());
+    stats_export(mine.data());
+    for(size_t i = 0; i < mine.size(); ++i) { mine[i] += theirs[i]; }
+    stats_import(mine.data());
+    std::fill(theirs.begin(), theirs.end(), 0);
+    other.stats_import(theirs.data());
+}
+
 // RCCL is resolved at first use so that single GPU users never load it.
 void DecoderSet::stats_allreduce(void* rccl_comm, void* stream) {
     require_device();

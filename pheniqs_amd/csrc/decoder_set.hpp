@@ -45,6 +45,7 @@ public:
     void stats_reset(void* stream);
     uint64_t* stats_device_pointer();
     void stats_export(uint64_t* host_words);
+    void stats_take(DecoderSet& other);           // this += other, other = 0 (selector.cpp:68-77: operator+= of every accumulator)
     void stats_import(const uint64_t* host_words);
     void stats_allreduce(void* rccl_comm, void* stream);
     void summarize(int64_t batch_capacity, int64_t n_read, const DevResult* result, uint32_t* distance, double* confidence) const;

@@ -746,6 +746,7 @@ struct Transcoder::Impl {
     uint32_t* word;
     std::vector<int64_t> kept;
     Transcoder::Classifier classifier;           // empty: DecoderSet::classify_host
+    std::vector<DecoderSet*> copy;               // further copies of the set, on devices of their own (Transcoder::add_copy)
 
     Impl(DecoderSet& set, const TranscodePlan& plan) : set(set), plan(plan), capacity(0), base(nullptr), quality(nullptr), flag(nullptr), result(nullptr), word(nullptr) {}
     ~Impl() {
@@ -795,6 +796,13 @@ Transcoder::Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch
 Transcoder::~Transcoder() { delete impl_; }
 
 void Transcoder::set_classifier(Classifier classifier) { impl_->classifier = std::move(classifier); }
+
+void Transcoder::add_copy(DecoderSet& copy) {
+    if(copy.job().stats_words != impl_->set.job().stats_words || copy.job().decoder.size() != impl_->set.job().decoder.size()) {
+        throw ConfigurationError("a copy of the decoder set must be built from the same job");
+    }
+    impl_->copy.push_back(&copy);
+}
 
 
 // ---- report only runs: FASTQ text decoded on the device (fastq_device.hpp) ---------------------------------------------
@@ -1173,6 +1181,13 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double mark = now();
     auto lap = [&](int k) { const double t = now(); phase[k] += t - mark; mark = t; };
+    // N copies of the decoders behind one pull loop (reference transcode.cpp:1769-1775: one TranscodingDecoder per thread, the
+    // reads dealt to whichever pulls next): batch b goes to copy b mod N — each copy on a device of its own —, records leave in
+    // input order because batches are written in the order they were read, and the copies' counters are added into this
+    // set's when the input ends (transcode.cpp:1816-1818 -> selector.cpp:68-77)
+    std::vector<DecoderSet*> taker{&m.set};
+    taker.insert(taker.end(), m.copy.begin(), m.copy.end());
+    size_t batch_number = 0;
     while(true) {
         for(const auto& b : m.batch) { if(!b.error.empty()) { throw_error(b.error_code, b.error); } }
         for(int32_t f = 0; f < n_feed; ++f) {
@@ -1237,7 +1252,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                           &incoming_count, &incoming_pf_count);
         lap(1);
         if(m.classifier) { m.classifier(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word); }
-        else { m.set.classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word); }
+        else { taker[batch_number++ % taker.size()]->classify_host(m.capacity, n_kept, m.base, m.quality, m.flag, m.result, m.word); }
         lap(2);
 
         // f2: records, a contiguous range of the batch per thread, written in order
@@ -1495,6 +1510,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         requested = requested_ahead;
     }
     for(auto& sink : m.sink) { sink.close(); }
+    for(DecoderSet* const copy : m.copy) { m.set.stats_take(*copy); }         // the end of run merge: integer sums, word for word
     if(quality_control) {                                                      // Multiplexer::collect, multiplex.cpp:405-411
         QcState total;
         for(const auto& q : quality_by_part) { total.merge(q); }

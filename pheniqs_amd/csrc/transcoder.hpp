@@ -53,6 +53,10 @@ public:
     // under AddressSanitizer, where no GPU code can.
     typedef std::function<void(int64_t capacity, int64_t n_read, const uint8_t* base, const uint8_t* quality, const uint8_t* flag, DevResult* result, uint32_t* word)> Classifier;
     void set_classifier(Classifier classifier);
+    // a further copy of the decoder set (same job), typically on another device: batches are dealt round robin to the set
+    // and its copies, whose counters are added into the set's (and zeroed) when the run ends.  The report only path that
+    // decodes FASTQ text on the device (run_on_device) stays on the set's own device.
+    void add_copy(DecoderSet& copy);
 
 private:
     struct Impl;

@@ -873,6 +873,32 @@ def test_job_directives_user_level_config_to_the_golden_file(torch_cuda, tmp_pat
     assert mine == golden
 
 
+def test_copies_of_the_set_behind_one_pull_loop(torch_cuda, tmp_path):
+    """phq_transcode_job_copies (reference transcode.cpp:1769-1775: N decoder copies behind one pull loop; 1816-1818: their
+    counters merged at the end): the BDGGG job in batches of 16 reads dealt to the set and two copies of it — on this one
+    GPU pool all three on device 0, on a node one per device — writes valid/annotated.out byte for byte, and after the run the
+    set's counters are the whole run's (word for word a single set's), the copies' zero."""
+    job = _bdggg_job_with_io(tmp_path, output=["out.sam"])
+    devices = list(range(min(3, torch_cuda.cuda.device_count()))) or [0]
+    s = DecoderSet(json.dumps(job), device=0)
+    copies = [DecoderSet(json.dumps(job), device=devices[(k + 1) % len(devices)]) for k in range(2)]
+    for each in [s] + copies:
+        each.stats_reset()
+    assert s.transcode_job_copies(copies, 16) == (250, 243)
+    golden = open(os.path.join(bdggg.HERE, "annotated.out.sam")).readlines()
+    mine = [line for line in open(os.path.join(tmp_path, "out.sam")) if not line.startswith("@PG")]
+    assert mine == golden
+    merged = s.stats_export()
+    for copy in copies:
+        assert int(copy.stats_export().sum()) == 0
+    alone = DecoderSet(json.dumps(job), device=0)
+    alone.stats_reset()
+    assert alone.transcode_job(16) == (250, 243)
+    assert np.array_equal(merged, alone.stats_export())
+    for each in [alone, s] + copies:
+        each.close()
+
+
 def test_job_directives_interleaved_input_feed(torch_cuda, tmp_path):
     """A path stated three times in `input` is ONE feed whose consecutive records are the three segments of a read
     (transcode.cpp:693-701): the same output as from the three separate files; a feed that ends inside a read and

@@ -111,3 +111,56 @@ def test_stats_allreduce_on_a_one_rank_rccl_communicator():
         s.close()
     finally:
         rccl.ncclCommDestroy(communicator)
+
+
+def test_stats_allreduce_on_a_two_rank_rccl_communicator():
+    """phq_stats_allreduce with more than one rank, without torch.distributed: two decoder sets on two devices of this
+    process, each with half of the reads, one RCCL communicator per device (ncclCommInitAll), the two calls inside one
+    ncclGroupStart / ncclGroupEnd.  Both buffers must then hold, word for word, what one set counts over all the reads.
+    Needs two GPUs: skipped on a one GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    rccl = _rccl()
+    rccl.ncclCommInitAll.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    communicators = (ctypes.c_void_p * 2)()
+    devices = (ctypes.c_int * 2)(0, 1)
+    assert rccl.ncclCommInitAll(communicators, 2, devices) == 0
+    try:
+        job, recipe = synthetic.config_job("C5")
+        n = 60000
+        code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
+
+        def count(device, first, last):
+            s = DecoderSet(job, device=device)
+            s.stats_reset()
+            torch.cuda.set_device(device)
+            where = "cuda:%d" % device
+            m = last - first
+            base = torch.from_numpy(s.planes_from_rows(code[first:last], offsets)).to(where)
+            qual = torch.from_numpy(s.planes_from_rows(quality[first:last], offsets)).to(where)
+            flags = torch.from_numpy(flag[first:last].copy()).to(where)
+            result = torch.zeros(max(1, s.n_result) * m * RESULT_DTYPE.itemsize, dtype=torch.uint8, device=where)
+            word = torch.zeros(m, dtype=torch.int32, device=where)
+            s.classify_device(m, 0, m, base, qual, flags, result, word, torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.synchronize(device)
+            return s
+
+        whole = count(0, 0, n)
+        expected = whole.stats_export()
+        halves = [count(0, 0, n // 2), count(1, n // 2, n)]
+        assert rccl.ncclGroupStart() == 0
+        for rank, s in enumerate(halves):
+            torch.cuda.set_device(rank)
+            s.stats_allreduce(communicators[rank], torch.cuda.current_stream(rank).cuda_stream)
+        assert rccl.ncclGroupEnd() == 0
+        for rank, s in enumerate(halves):
+            torch.cuda.synchronize(rank)
+            assert np.array_equal(s.stats_export(), expected), rank
+        for s in halves + [whole]:
+            s.close()
+    finally:
+        for communicator in communicators:
+            rccl.ncclCommDestroy(communicator)
+        torch.cuda.set_device(0)
