@@ -89,6 +89,7 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_scatter_kernel(const uint8
 
 struct PlanArgs {
     FastqFeedChunk chunk[FASTQ_MAX_FEED];
+    int32_t resolution[FASTQ_MAX_FEED];
     int32_t n_feed;
     uint32_t capacity;
     FastqRound* round;
@@ -102,10 +103,12 @@ __global__ void fastq_plan_kernel(PlanArgs args) {
         const uint32_t lines = *args.chunk[f].total;
         args.round->lines[f] = lines;
         if(lines > args.chunk[f].newline_capacity) { irregular = 1; }
-        records = min(records, lines / 4u);
+        records = min(records, lines / (4u * static_cast<uint32_t>(args.resolution[f])));      // whole reads: every segment of an interleaved feed
     }
     if(irregular) { records = 0; }
-    for(int f = 0; f < args.n_feed; ++f) { args.round->consumed[f] = records > 0 ? args.chunk[f].newline[4u * records - 1u] + 1u : 0u; }
+    for(int f = 0; f < args.n_feed; ++f) {
+        args.round->consumed[f] = records > 0 ? args.chunk[f].newline[4u * records * static_cast<uint32_t>(args.resolution[f]) - 1u] + 1u : 0u;
+    }
     args.round->records = records;
     args.round->irregular = irregular;
 }
@@ -120,59 +123,124 @@ struct DecodeArgs {
     uint8_t* flag;
     uint32_t* irregular;
     unsigned long long* flagged;
+    uint8_t* keep;                  // a plan that filters: 1 = the read is decoded
+    uint32_t* keep_block;           // ... kept reads per workgroup of 256 reads, then their exclusive prefix sums
     uint8_t bam_of_ascii[256];
     uint8_t complement_of_bam[16];
 };
 
-__global__ __launch_bounds__(256) void fastq_decode_kernel(DecodeArgs args) {
+// where read r's segments sit in their files' chunks, and what the pull loop would make of it
+struct Located {
+    uint32_t sequence_at[FASTQ_MAX_FEED];
+    uint32_t quality_at[FASTQ_MAX_FEED];
+    uint32_t length[FASTQ_MAX_FEED];
+    bool odd;                       // framing or name sync out of the ordinary: the host reader takes the run
+    bool filtered;                  // the Illumina filter flag of the leading segment
+    bool dropped;                   // the pre-filters of the pull loop drop the read (transcode.h:193-205)
+};
+
+__device__ __forceinline__ void locate(const DecodeArgs& args, uint32_t r, Located& to) {
     const FastqPlan& plan = args.plan;
-    for(uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < args.n; r += gridDim.x * blockDim.x) {
-        uint32_t sequence_at[FASTQ_MAX_FEED];
-        uint32_t quality_at[FASTQ_MAX_FEED];
-        uint32_t length[FASTQ_MAX_FEED];
-        bool odd = false;
-        bool filtered = false;
-        uint32_t first_name_at = 0;
-        uint32_t first_name_size = 0;
-        for(int f = 0; f < plan.n_feed; ++f) {
-            const uint8_t* const raw = args.chunk[f].raw;
-            const uint32_t* const newline = args.chunk[f].newline + 4u * r;
-            const uint32_t header_at = r == 0 ? 0u : newline[-1] + 1u;
-            const uint32_t header_end = newline[0];
-            const uint32_t sequence_end = newline[1];
-            const uint32_t separator_end = newline[2];
-            const uint32_t quality_end = newline[3];
-            sequence_at[f] = header_end + 1u;
-            quality_at[f] = separator_end + 1u;
-            length[f] = sequence_end - sequence_at[f];
-            // the framing of a record (fastq.h:427-440), nothing the host reader would have to tolerate or report
-            odd = odd || header_end == header_at || raw[header_at] != '@' || separator_end == sequence_end + 1u || raw[sequence_end + 1u] != '+' ||
-                  quality_end - quality_at[f] != length[f] || raw[header_end - 1u] == '\r' || (length[f] > 0 && raw[sequence_end - 1u] == '\r') ||
-                  raw[separator_end - 1u] == '\r' || (length[f] > 0 && raw[quality_end - 1u] == '\r');
-            // the name up to the first blank (kseq), the same in every file (read.h:253-264)
-            uint32_t name_end = header_at + 1u;
-            while(name_end < header_end && raw[name_end] != ' ' && raw[name_end] != '\t') { ++name_end; }
-            if(f == 0) { first_name_at = header_at + 1u; first_name_size = name_end - header_at - 1u; }
-            else {
-                bool same = name_end - header_at - 1u == first_name_size;
-                const uint8_t* const first_raw = args.chunk[0].raw;
-                for(uint32_t k = 0; same && k < first_name_size; ++k) { same = raw[header_at + 1u + k] == first_raw[first_name_at + k]; }
-                odd = odd || !same;
-            }
-            // the Illumina comment `segment:filtered:control:barcode` of the leading segment (fastq.h:253-285)
-            if(f == plan.leader_feed && plan.illumina_comment) {
-                uint32_t p = name_end < header_end ? name_end + 1u : header_end;
-                while(p < header_end && raw[p] != ':') { ++p; }
-                if(p + 1u < header_end) { filtered = raw[p + 1u] == 'Y'; }
-            }
+    to.odd = false;
+    to.filtered = false;
+    to.dropped = false;
+    uint32_t first_name_at = 0;
+    uint32_t first_name_size = 0;
+    const uint8_t* first_raw = nullptr;
+    for(int s = 0; s < plan.n_segment; ++s) {
+        const int f = plan.segment_feed[s];
+        const uint32_t record = r * static_cast<uint32_t>(plan.feed_resolution[f]) + static_cast<uint32_t>(plan.segment_slot[s]);
+        const uint8_t* const raw = args.chunk[f].raw;
+        const uint32_t* const newline = args.chunk[f].newline + 4u * record;
+        const uint32_t header_at = record == 0 ? 0u : newline[-1] + 1u;
+        const uint32_t header_end = newline[0];
+        const uint32_t sequence_end = newline[1];
+        const uint32_t separator_end = newline[2];
+        const uint32_t quality_end = newline[3];
+        to.sequence_at[s] = header_end + 1u;
+        to.quality_at[s] = separator_end + 1u;
+        to.length[s] = sequence_end - to.sequence_at[s];
+        // the framing of a record (fastq.h:427-440), nothing the host reader would have to tolerate or report
+        to.odd = to.odd || header_end == header_at || raw[header_at] != '@' || separator_end == sequence_end + 1u || raw[sequence_end + 1u] != '+' ||
+                 quality_end - to.quality_at[s] != to.length[s] || raw[header_end - 1u] == '\r' || (to.length[s] > 0 && raw[sequence_end - 1u] == '\r') ||
+                 raw[separator_end - 1u] == '\r' || (to.length[s] > 0 && raw[quality_end - 1u] == '\r');
+        // the name up to the first blank (kseq), the same in every segment (read.h:253-264)
+        uint32_t name_end = header_at + 1u;
+        while(name_end < header_end && raw[name_end] != ' ' && raw[name_end] != '\t') { ++name_end; }
+        if(s == 0) { first_name_at = header_at + 1u; first_name_size = name_end - header_at - 1u; first_raw = raw; }
+        else {
+            bool same = name_end - header_at - 1u == first_name_size;
+            for(uint32_t k = 0; same && k < first_name_size; ++k) { same = raw[header_at + 1u + k] == first_raw[first_name_at + k]; }
+            to.odd = to.odd || !same;
         }
-        if(odd) { atomicOr(args.irregular, 1u); }
+        // the Illumina comment `segment:filtered:control:barcode` of the leading segment (fastq.h:253-285)
+        if(s == plan.leader_segment && plan.illumina_comment) {
+            uint32_t p = name_end < header_end ? name_end + 1u : header_end;
+            while(p < header_end && raw[p] != ':') { ++p; }
+            if(p + 1u < header_end) { to.filtered = raw[p + 1u] == 'Y'; }
+        }
+        if(s >= 1 && static_cast<int32_t>(to.length[s]) < plan.min_length[s]) { to.dropped = true; }      // filter_input, transcode.h:193-200
+    }
+    if(plan.filter_incoming_qc_fail && to.filtered) { to.dropped = true; }                                  // transcode.h:205
+}
+
+__device__ __forceinline__ void count_flagged(const DecodeArgs& args, bool filtered) {
+    const unsigned long long marked = __ballot(filtered);
+    if(marked && (threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(marked)) - 1)) { atomicAdd(args.flagged, static_cast<unsigned long long>(__popcll(marked))); }
+}
+
+// a plan that filters, first pass: which reads are kept, how many per workgroup; framing and the flag count as the decode does
+__global__ __launch_bounds__(TILE_THREADS) void fastq_keep_kernel(DecodeArgs args) {
+    __shared__ uint32_t kept_here;
+    if(threadIdx.x == 0) { kept_here = 0; }
+    __syncthreads();
+    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    bool keep = false;
+    bool filtered = false;
+    if(r < args.n) {
+        Located at;
+        locate(args, r, at);
+        if(at.odd) { atomicOr(args.irregular, 1u); }
+        keep = !at.dropped;
+        filtered = at.filtered;
+        args.keep[r] = keep ? 1 : 0;
+    }
+    count_flagged(args, filtered);
+    const unsigned long long kept = __ballot(keep);
+    if((threadIdx.x & 63) == 0 && kept) { atomicAdd(&kept_here, static_cast<uint32_t>(__popcll(kept))); }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.keep_block[blockIdx.x] = kept_here; }
+}
+
+// FILTER: rows by rank among the kept reads (keep_block holds the exclusive prefix sums by now); else row r for read r
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs args) {
+    const FastqPlan& plan = args.plan;
+    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
+    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    const bool present = r < args.n;
+    uint32_t row = r;
+    bool wanted = present;
+    if(FILTER) {
+        wanted = present && args.keep[r] != 0;
+        const unsigned long long kept = __ballot(wanted);
+        if((threadIdx.x & 63) == 0) { wave_kept[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(kept)); }
+        __syncthreads();
+        row = args.keep_block[blockIdx.x] + static_cast<uint32_t>(__popcll(kept & ((1ull << (threadIdx.x & 63)) - 1ull)));
+        for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { row += wave_kept[w]; }
+    }
+    bool filtered = false;
+    if(wanted) {
+        Located at;
+        locate(args, r, at);
+        filtered = at.filtered;
+        if(!FILTER && at.odd) { atomicOr(args.irregular, 1u); }
         // Rule::apply of every decoder into its plane (transform.h:142-169), zero filled past what the tokens bring
         for(int k = 0; k < plan.n_decoder; ++k) {
             const FastqDecoderPlan& d = plan.decoder[k];
             if(d.plane_stride == 0) { continue; }
-            uint8_t* const row_code = args.base_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(r) * d.plane_stride;
-            uint8_t* const row_quality = args.quality_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(r) * d.plane_stride;
+            uint8_t* const row_code = args.base_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride;
+            uint8_t* const row_quality = args.quality_planes + args.capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride;
             for(int w = 0; w < d.plane_stride / 4; ++w) {
                 reinterpret_cast<uint32_t*>(row_code)[w] = 0u;
                 reinterpret_cast<uint32_t*>(row_quality)[w] = 0u;
@@ -180,7 +248,7 @@ __global__ __launch_bounds__(256) void fastq_decode_kernel(DecodeArgs args) {
             int32_t filled[DEV_MAX_SEGMENT] = {0, 0, 0, 0, 0, 0, 0, 0};
             for(int t = d.first_token; t < d.first_token + d.n_token; ++t) {
                 const FastqToken& token = plan.token[t];
-                const int32_t from_length = static_cast<int32_t>(length[token.feed]);
+                const int32_t from_length = static_cast<int32_t>(at.length[token.segment]);
                 int32_t start = token.start;                                   // Token::absolute_start, transform.h:73-80
                 if(start < 0) { start = from_length + start; start = start < 0 ? 0 : start; }
                 else if(start > from_length) { start = 0; }
@@ -190,25 +258,24 @@ __global__ __launch_bounds__(256) void fastq_decode_kernel(DecodeArgs args) {
                     else { end = token.end > from_length ? from_length : token.end; }
                 }
                 const int32_t size = end - start;
-                if(size <= 0 || odd) { continue; }
+                if(size <= 0 || at.odd) { continue; }
                 int32_t& done = filled[token.output_segment];
                 const int32_t room = token.output_room - done;
                 const int32_t take = size < room ? size : room;
-                const uint8_t* const raw = args.chunk[token.feed].raw;
+                const uint8_t* const raw = args.chunk[plan.segment_feed[token.segment]].raw;
                 for(int32_t j = 0; j < take; ++j) {
                     const int32_t from = token.reverse_complement ? end - j - 1 : start + j;
-                    uint8_t code = args.bam_of_ascii[raw[sequence_at[token.feed] + static_cast<uint32_t>(from)]];
+                    uint8_t code = args.bam_of_ascii[raw[at.sequence_at[token.segment] + static_cast<uint32_t>(from)]];
                     if(token.reverse_complement) { code = args.complement_of_bam[code & 15u]; }
                     row_code[token.output_offset + done + j] = code;
-                    row_quality[token.output_offset + done + j] = static_cast<uint8_t>(raw[quality_at[token.feed] + static_cast<uint32_t>(from)] - plan.phred_offset);
+                    row_quality[token.output_offset + done + j] = static_cast<uint8_t>(raw[at.quality_at[token.segment] + static_cast<uint32_t>(from)] - plan.phred_offset);
                 }
                 done += take > 0 ? take : 0;
             }
         }
-        args.flag[r] = filtered ? 1 : 0;
-        const unsigned long long marked = __ballot(filtered);
-        if(marked && (threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(marked)) - 1)) { atomicAdd(args.flagged, static_cast<unsigned long long>(__popcll(marked))); }
+        args.flag[row] = filtered ? 1 : 0;
     }
+    if(!FILTER) { count_flagged(args, filtered); }
 }
 
 }  // namespace
@@ -223,9 +290,9 @@ int fastq_index(const FastqFeedChunk& chunk, void* stream) {
     return static_cast<int>(hipGetLastError());
 }
 
-int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capacity, FastqRound* round_on_device, void* stream) {
+int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, const int32_t* resolution, uint32_t capacity, FastqRound* round_on_device, void* stream) {
     PlanArgs args;
-    for(int f = 0; f < n_feed && f < FASTQ_MAX_FEED; ++f) { args.chunk[f] = chunk[f]; }
+    for(int f = 0; f < n_feed && f < FASTQ_MAX_FEED; ++f) { args.chunk[f] = chunk[f]; args.resolution[f] = resolution[f] > 0 ? resolution[f] : 1; }
     args.n_feed = n_feed;
     args.capacity = capacity;
     args.round = round_on_device;
@@ -234,7 +301,7 @@ int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capac
 }
 
 int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
-                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, void* stream) {
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream) {
     if(n == 0) { return 0; }
     // the two tables once per process: a function local static initialised by a lambda (thread safe: two host threads
     // transcoding with two decoder sets may come here together); every call copies them into its own arguments
@@ -254,8 +321,18 @@ int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n,
     call.flag = flag;
     call.irregular = irregular;
     call.flagged = flagged;
-    const uint32_t blocks = (n + 255u) / 256u;
-    hipLaunchKernelGGL(fastq_decode_kernel, dim3(blocks < 4096u ? blocks : 4096u), dim3(256), 0, static_cast<hipStream_t>(stream), call);
+    call.keep = keep;
+    call.keep_block = keep_block;
+    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if(plan.filtering) {
+        if(keep == nullptr || keep_block == nullptr || kept == nullptr) { return static_cast<int>(hipErrorInvalidValue); }
+        hipLaunchKernelGGL(fastq_keep_kernel, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+        hipLaunchKernelGGL(fastq_scan_kernel, dim3(1), dim3(1024), 0, s, keep_block, blocks, kept);
+        hipLaunchKernelGGL(fastq_decode_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+    } else {
+        hipLaunchKernelGGL(fastq_decode_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+    }
     return static_cast<int>(hipGetLastError());
 }
 

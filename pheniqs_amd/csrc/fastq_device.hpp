@@ -22,7 +22,7 @@ constexpr int FASTQ_MAX_TOKEN = 64;
 constexpr int FASTQ_MAX_DECODER = 16;
 
 struct FastqToken {                 // one token of a decoder's transform (TransformConfig), resolved against the plan
-    int32_t feed;                   // input file
+    int32_t segment;                // input segment
     int32_t start;
     int32_t end;
     int32_t end_terminated;
@@ -42,9 +42,19 @@ struct FastqDecoderPlan {
 struct FastqPlan {
     int32_t n_feed;
     int32_t n_decoder;
-    int32_t leader_feed;            // whose comment carries the filter flag
+    int32_t n_segment;              // input segments: segment s is record (r * resolution + slot) of its feed (transcode.cpp:693-701)
+    int32_t segment_feed[FASTQ_MAX_FEED];
+    int32_t segment_slot[FASTQ_MAX_FEED];
+    int32_t feed_resolution[FASTQ_MAX_FEED];      // consecutive records of the file that make one read (an interleaved feed)
+    int32_t leader_segment;         // whose comment carries the filter flag
     int32_t phred_offset;
     int32_t illumina_comment;
+    // the pre-filters of the pull loop (transcode.h:193-205): a read is dropped — pulled, counted as incoming, never decoded —
+    // when its filter flag is set and the job filters incoming QC fail, or when a segment past the first is shorter than the
+    // job's minimum for it.  With either in force the kept reads are compacted: read r goes to the row of its rank among them.
+    int32_t filter_incoming_qc_fail;
+    int32_t min_length[FASTQ_MAX_FEED];
+    int32_t filtering;              // either of the two
     FastqDecoderPlan decoder[FASTQ_MAX_DECODER];
     FastqToken token[FASTQ_MAX_TOKEN];
 };
@@ -53,7 +63,7 @@ struct FastqPlan {
 struct FastqRound {
     uint32_t lines[FASTQ_MAX_FEED];          // complete lines found in the feed's chunk
     uint32_t consumed[FASTQ_MAX_FEED];       // bytes of the chunk the round's records take
-    uint32_t records;                        // records every feed holds, at most the batch capacity
+    uint32_t records;                        // READS every feed holds whole (a read is `resolution` records of an interleaved feed), at most the batch capacity
     uint32_t irregular;                      // a feed's newline index overflowed (lines shorter than any FASTQ has)
 };
 
@@ -68,10 +78,12 @@ struct FastqFeedChunk {
 
 // every function returns a hipError_t value; all work goes to `stream`
 int fastq_index(const FastqFeedChunk& chunk, void* stream);
-int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, uint32_t capacity, FastqRound* round_on_device, void* stream);
-// records [0, n) of the round -> planes laid out for `capacity` reads; *irregular |= 1 on anything out of the ordinary;
-// *flagged += reads whose filter flag is set
+int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, const int32_t* resolution, uint32_t capacity, FastqRound* round_on_device, void* stream);
+// reads [0, n) of the round -> planes laid out for `capacity` reads; *irregular |= 1 on anything out of the ordinary;
+// *flagged += reads whose filter flag is set.  A plan that filters needs the scratch `keep` (n bytes) and `keep_block`
+// (n / 256 + 2 words) and leaves the number of rows it wrote — the reads it kept, in input order — in *kept (device);
+// a plan that does not writes row r for read r and leaves *kept alone.
 int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
-                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, void* stream);
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream);
 
 }  // namespace phq

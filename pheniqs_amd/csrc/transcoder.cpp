@@ -827,8 +827,14 @@ struct DeviceFastqCache {
     uint8_t* flag = nullptr;
     DevResult* result = nullptr;
     uint32_t* word = nullptr;
+    uint8_t* keep = nullptr;                       // device: a job with pre-filters: which reads of the round are decoded
+    uint32_t* keep_block = nullptr;                // device: kept reads per 256, then their prefix sums
+    uint32_t* kept_device = nullptr;
+    uint32_t* kept_host = nullptr;                 // pinned
     hipStream_t stream = nullptr;
     ~DeviceFastqCache() {
+        (void)hipFree(keep); (void)hipFree(keep_block); (void)hipFree(kept_device);
+        if(kept_host) { (void)hipHostFree(kept_host); }
         for(int f = 0; f < FASTQ_MAX_FEED; ++f) {
             if(pinned[f]) { (void)hipHostFree(pinned[f]); }
             for(int s = 0; s < 2; ++s) { (void)hipFree(raw[s][f]); (void)hipFree(newline[s][f]); (void)hipFree(block_count[s][f]); }
@@ -862,15 +868,29 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
     if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return false; }
     if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return false; }
-    // what the device path does not do: interleaved files, the pre-filters of Transcode::pull (transcode.h:193-205)
-    if(job.filter_incoming_qc_fail || job.enable_quality_control) { return false; }      // (the accumulators count the output read's text: host side)
-    for(size_t s = 1; s < job.min_input_length.size(); ++s) { if(job.min_input_length[s] > 0) { return false; } }
-    for(const auto& feed : plan.input_feed) { if(feed.resolution != 1) { return false; } }
+    // what the device path does not do: the quality control accumulators (they count the output read's text: host side)
+    if(job.enable_quality_control) { return false; }
+    const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
+    if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return false; }
     FastqPlan device_plan;
     std::memset(&device_plan, 0, sizeof(device_plan));
     device_plan.n_feed = n_feed;
     device_plan.n_decoder = static_cast<int32_t>(job.decoder.size());
-    device_plan.leader_feed = plan.input_segment[static_cast<size_t>(job.leading_segment_index)].first;
+    // interleaved feeds (a path stated k times in `input`: transcode.cpp:693-701): segment s is record r k + slot of its file
+    device_plan.n_segment = n_segment;
+    for(int32_t f = 0; f < n_feed; ++f) { device_plan.feed_resolution[f] = std::max(1, plan.input_feed[static_cast<size_t>(f)].resolution); }
+    for(int32_t s = 0; s < n_segment; ++s) {
+        device_plan.segment_feed[s] = plan.input_segment[static_cast<size_t>(s)].first;
+        device_plan.segment_slot[s] = plan.input_segment[static_cast<size_t>(s)].second;
+        if(device_plan.segment_feed[s] < 0 || device_plan.segment_feed[s] >= n_feed || device_plan.segment_slot[s] < 0 ||
+           device_plan.segment_slot[s] >= device_plan.feed_resolution[device_plan.segment_feed[s]]) { return false; }
+    }
+    // the pre-filters of the pull loop (transcode.h:193-205), on the device too: kept reads are compacted into the planes
+    device_plan.filter_incoming_qc_fail = job.filter_incoming_qc_fail ? 1 : 0;
+    for(int32_t s = 1; s < n_segment && s < static_cast<int32_t>(job.min_input_length.size()); ++s) { device_plan.min_length[s] = job.min_input_length[static_cast<size_t>(s)]; }
+    device_plan.filtering = device_plan.filter_incoming_qc_fail;
+    for(int32_t s = 1; s < n_segment; ++s) { if(device_plan.min_length[s] > 0) { device_plan.filtering = 1; } }
+    device_plan.leader_segment = job.leading_segment_index;
     device_plan.phred_offset = job.input_phred_offset;
     device_plan.illumina_comment = (job.platform == "ILLUMINA" || job.platform == "ELEMENT") ? 1 : 0;
     int32_t n_token = 0;
@@ -884,7 +904,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
             if(n_token >= FASTQ_MAX_TOKEN || t.input_segment_index < 0 || t.input_segment_index >= static_cast<int32_t>(plan.input_segment.size()) ||
                t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return false; }
             FastqToken& token = device_plan.token[n_token++];
-            token.feed = plan.input_segment[static_cast<size_t>(t.input_segment_index)].first;
+            token.segment = t.input_segment_index;
             token.start = t.start;
             token.end = t.end;
             token.end_terminated = t.end_terminated ? 1 : 0;
@@ -928,6 +948,9 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         device_check(hipMalloc(reinterpret_cast<void**>(&c.flag), static_cast<size_t>(capacity)), "hipMalloc");
         device_check(hipMalloc(reinterpret_cast<void**>(&c.result), static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)), "hipMalloc");
         device_check(hipMalloc(reinterpret_cast<void**>(&c.word), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
+        (void)hipFree(c.keep); (void)hipFree(c.keep_block); c.keep = nullptr; c.keep_block = nullptr;
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep), static_cast<size_t>(capacity)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep_block), (static_cast<size_t>(capacity) / 256 + 2) * sizeof(uint32_t)), "hipMalloc");
         c.capacity = capacity;
     }
     if(c.total == nullptr) {
@@ -937,10 +960,12 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         device_check(hipMalloc(reinterpret_cast<void**>(&c.irregular), sizeof(uint32_t)), "hipMalloc");
         device_check(hipMalloc(reinterpret_cast<void**>(&c.flagged), sizeof(unsigned long long)), "hipMalloc");
         device_check(hipMalloc(reinterpret_cast<void**>(&c.counters_before), static_cast<size_t>(job.stats_words) * sizeof(uint64_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.kept_device), sizeof(uint32_t)), "hipMalloc");
+        device_check(hipHostMalloc(reinterpret_cast<void**>(&c.kept_host), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
     }
     size_t chunk_bytes[FASTQ_MAX_FEED];
     for(int32_t f = 0; f < n_feed; ++f) {
-        const double wanted = static_cast<double>(capacity) * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;
+        const double wanted = static_cast<double>(capacity) * device_plan.feed_resolution[f] * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;      // a read is `resolution` records of an interleaved file
         chunk_bytes[f] = static_cast<size_t>(std::min(wanted, 192.0 * 1048576.0));
         chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1);
         chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
@@ -1004,7 +1029,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
             device_check(static_cast<hipError_t>(fastq_index(chunk[f], stream)), "fastq_index");
         }
         if(!any_left) { break; }
-        device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
+        device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, device_plan.feed_resolution, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
         device_check(hipMemcpyAsync(c.round_host, c.round_device, sizeof(FastqRound), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
         device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // the pinned buffers are free again, the round is known
         const FastqRound round = *c.round_host;
@@ -1019,8 +1044,16 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
-        device_check(static_cast<hipError_t>(fastq_decode(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged, stream)), "fastq_decode");
-        m.set.classify_device(c.capacity, 0, round.records, c.base, c.quality, c.flag, c.result, c.word, stream);
+        device_check(static_cast<hipError_t>(fastq_decode(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
+                                                          c.keep, c.keep_block, c.kept_device, stream)), "fastq_decode");
+        uint32_t decoded = round.records;
+        if(device_plan.filtering) {
+            // how many reads the pre-filters kept: the rows the planes hold
+            device_check(hipMemcpyAsync(c.kept_host, c.kept_device, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            decoded = *c.kept_host;
+        }
+        if(decoded > 0) { m.set.classify_device(c.capacity, 0, decoded, c.base, c.quality, c.flag, c.result, c.word, stream); }
         reads += round.records;
         slot ^= 1;
     }

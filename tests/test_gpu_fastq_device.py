@@ -4,11 +4,13 @@ counters such a run leaves are held against the CPU ORACLE's for the same file c
 text, `~` tokens included), and word for word against the host reader's (PHQ_HOST_FASTQ=1); anything out of the ordinary
 in a file sends the run through the host reader, which tolerates or reports it as the reference does.
 """
+import json
 import os
 
 import numpy as np
 import pytest
 
+import bdggg
 import bench
 from pheniqs_amd import DecoderSet, PheniqsError, capi, synthetic
 
@@ -187,3 +189,97 @@ def test_oddities_go_through_the_host_reader(tmp_path):
             finally:
                 os.environ.pop("PHQ_HOST_FASTQ", None)
         assert codes[0] == codes[1], name
+
+
+def _device_path_taken(job_json, run):
+    """Runs `run(set)` twice — device FASTQ decode, then the host reader — and returns both (incoming, counter words, report)."""
+    out = []
+    for host in (False, True):
+        if host:
+            os.environ["PHQ_HOST_FASTQ"] = "1"
+        try:
+            s = DecoderSet(job_json, device=0)
+            s.stats_reset()
+            incoming = run(s)
+            words = s.stats_export()
+            out.append((incoming, words, json.loads(s.report(words, incoming))))
+            s.close()
+        finally:
+            os.environ.pop("PHQ_HOST_FASTQ", None)
+    return out
+
+
+def _assert_report_is_the_golden_one(report):
+    theirs = bdggg.golden_report()
+    assert report["incoming"] == theirs["incoming"]
+    assert report["outgoing"]["count"] == theirs["outgoing"]["count"] and report["outgoing"]["pf count"] == theirs["outgoing"]["pf count"]
+    for mine_block, their_block in ((report["sample"], theirs["sample"]), (report["cellular"][0], theirs["cellular"][0]), (report["molecular"][0], theirs["molecular"][0])):
+        for key in ("count", "pf count", "classified count", "pf classified count"):
+            assert mine_block[key] == their_block[key]
+        for m, t in zip(mine_block.get("classified", []), their_block.get("classified", [])):
+            assert (m["count"], m["pf count"], m.get("low confidence count"), m.get("low conditional confidence count")) == \
+                   (t["count"], t["pf count"], t.get("low confidence count"), t.get("low conditional confidence count"))
+            assert abs(m["average confidence"] - t["average confidence"]) < 1e-12
+
+
+def test_the_reference_job_report_only_on_the_device(tmp_path):
+    """test/BDGGG's own job (BDGGG_annotated.json: `min input length` [0, 0, 22], three decoders) with every output /dev/null
+    runs its FASTQ text through the device decode — the pre-filter of the pull loop (transcode.h:193-205) included — and its
+    report is valid/annotated.err's; the same files as ONE interleaved feed (transcode.cpp:693-701) likewise."""
+    job = bdggg.raw_job()
+    job["base input url"] = bdggg.HERE
+    job["output"] = ["/dev/null"]
+    device, host = _device_path_taken(json.dumps(job), lambda s: s.transcode_job(100))
+    assert device[0] == host[0] == (250, 243)
+    assert np.array_equal(device[1], host[1])
+    _assert_report_is_the_golden_one(device[2])
+    # interleaved: record 3 i + k of the one file is segment k of read i
+    sources = [open(os.path.join(bdggg.HERE, "BDGGG_s0%d.fastq" % k)).read().split("\n") for k in (1, 2, 3)]
+    n = min(len(lines) // 4 for lines in sources)
+    path = os.path.join(str(tmp_path), "interleaved.fastq")
+    with open(path, "w") as out:
+        for i in range(n):
+            for lines in sources:
+                out.write("\n".join(lines[4 * i:4 * i + 4]) + "\n")
+    job["input"] = [path, path, path]
+    device, host = _device_path_taken(json.dumps(job), lambda s: s.transcode_job(64))
+    assert device[0] == host[0] == (250, 243)
+    assert np.array_equal(device[1], host[1])
+    _assert_report_is_the_golden_one(device[2])
+
+
+def test_pre_filters_compact_the_reads_on_the_device(oracle, tmp_path):
+    """`filter incoming qc fail` and `min input length` on the device (transcode.h:193-205): reads the pull loop drops are
+    counted as incoming and nothing else; what is left must count exactly as the oracle counts the kept reads, in several
+    rounds (a capacity far under the file's reads) — the device, the host reader and the oracle agree word for word."""
+    rng = np.random.default_rng(9)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::"]}}
+    spec["filter incoming qc fail"] = True
+    spec["min input length"] = [0, 6]
+    job = capi.compile_job(spec)
+    n = 90001
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 31)
+    template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 30))]
+    short = (np.arange(n) % 89) == 0                          # an index read of 5 nt: under the minimum of 6
+    paths = [os.path.join(str(tmp_path), "s%d.fastq" % k) for k in (0, 1)]
+    with open(paths[0], "wb") as a, open(paths[1], "wb") as b:
+        for i in range(n):
+            filtered = b"Y" if flag[i] else b"N"
+            keep = 5 if short[i] else 8
+            a.write(b"@r%d 1:%s:0:1\n%s\n+\n%s\n" % (i, filtered, template[i].tobytes(), b"F" * 30))
+            b.write(b"@r%d 2:%s:0:1\n%s\n+\n%s\n" % (i, filtered, LETTERS[code[i, :keep]].tobytes(), (np.minimum(quality[i, :keep], 93) + 33).astype(np.uint8).tobytes()))
+    (device_words, device_incoming), (host_words, host_incoming) = _both(spec, paths, 1 << 13)
+    assert device_incoming == host_incoming == (n, n - int(flag.sum()))
+    assert np.array_equal(device_words, host_words)
+    kept = (flag == 0) & ~short
+    engine = oracle.OracleJob(job)
+    engine.classify(code[kept], np.minimum(quality[kept], 93), np.zeros(int(kept.sum()), dtype=np.uint8))
+    count, pf_count = engine.outgoing()
+    assert (int(device_words[0] + device_words[1]), int(device_words[1])) == (count, pf_count)
+    assert count == int(kept.sum())
+    s = DecoderSet(spec, device=0)
+    mine, theirs = s.stats_options(device_words, 0), engine.options(0)
+    for name in INTEGER_COUNTERS:
+        assert np.array_equal(mine[name], theirs[name]), name
+    s.close()
