@@ -687,6 +687,121 @@ void DecoderSet::build_device_images() {
                     d.mdd_pair_ready = (paired_mdd && within_bound) ? 1 : 0;
                 }
             }
+            if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.segment_cardinality == 2 && d.n_barcode > 1 && d.n_barcode <= 256 &&
+               c.barcode_length[0] >= 4 && c.barcode_length[0] <= 8 && c.barcode_length[1] >= 4 && c.barcode_length[1] <= 8) {
+                // plates (pamld_plate.hip): few words a segment, every combination of them or a part
+                constexpr int32_t SLOTS = 16;
+                const int32_t N = d.n_barcode;
+                std::vector<uint32_t> low, high;
+                code_planes(c, low, high);
+                std::vector<std::pair<uint32_t, uint32_t>> words[2];           // (low plane, high plane) of the segment's distinct words, first appearance order
+                std::vector<int32_t> word_of[2];
+                bool fits = true;
+                for(int32_t s = 0; s < 2 && fits; ++s) {
+                    const int32_t start = c.segment_offset[static_cast<size_t>(s)];
+                    const uint32_t mask = (1u << c.barcode_length[static_cast<size_t>(s)]) - 1u;
+                    word_of[s].resize(static_cast<size_t>(N));
+                    for(int32_t b = 0; b < N && fits; ++b) {
+                        const std::pair<uint32_t, uint32_t> word((low[static_cast<size_t>(b)] >> start) & mask, (high[static_cast<size_t>(b)] >> start) & mask);
+                        auto found = std::find(words[s].begin(), words[s].end(), word);
+                        if(found == words[s].end()) {
+                            if(static_cast<int32_t>(words[s].size()) >= SLOTS) { fits = false; break; }
+                            words[s].push_back(word);
+                            found = words[s].end() - 1;
+                        }
+                        word_of[s][static_cast<size_t>(b)] = static_cast<int32_t>(found - words[s].begin());
+                    }
+                }
+                const int32_t n0 = static_cast<int32_t>(words[0].size()), n1 = static_cast<int32_t>(words[1].size());
+                std::vector<int32_t> barcode_of(static_cast<size_t>(n0) * static_cast<size_t>(std::max(n1, 1)), -1);
+                for(int32_t b = 0; b < N && fits; ++b) {
+                    int32_t& at = barcode_of[static_cast<size_t>(word_of[0][static_cast<size_t>(b)]) * static_cast<size_t>(n1) + static_cast<size_t>(word_of[1][static_cast<size_t>(b)])];
+                    if(at >= 0) { fits = false; }                 // the same barcode twice
+                    at = b;
+                }
+                // a plate, not a list of pairs: words are shared between barcodes (a set of all different words is the paired tier's)
+                if(fits && n0 >= 2 && n1 >= 2 && N > std::max(n0, n1)) {
+                    std::vector<uint32_t> block(static_cast<size_t>(n0 + n1) * 3 * SLOTS, 0u);
+                    std::vector<std::vector<int32_t>> slot_word[2];          // per word: the word each slot of its block holds (-1: none)
+                    for(int32_t s = 0; s < 2; ++s) {
+                        const int32_t length = c.barcode_length[static_cast<size_t>(s)];
+                        const int32_t ns = static_cast<int32_t>(words[s].size());
+                        slot_word[s].assign(static_cast<size_t>(ns), std::vector<int32_t>(SLOTS, -1));
+                        for(int32_t u = 0; u < ns; ++u) {
+                            uint32_t* const to = &block[(static_cast<size_t>(s == 0 ? 0 : n0) + static_cast<size_t>(u)) * 3 * SLOTS];
+                            int32_t slot = 0;
+                            auto put = [&](int32_t w) {
+                                to[slot] = words[s][static_cast<size_t>(w)].first;
+                                to[SLOTS + slot] = words[s][static_cast<size_t>(w)].second;
+                                const float one = 1.0f;
+                                std::memcpy(&to[2 * SLOTS + slot], &one, sizeof(float));
+                                slot_word[s][static_cast<size_t>(u)][static_cast<size_t>(slot)] = w;
+                                ++slot;
+                            };
+                            put(u);
+                            for(int32_t w = 0; w < ns; ++w) { if(w != u) { put(w); } }
+                        }
+                        // the lookup: the word itself and every word one mismatch from it; a key two words claim names none
+                        std::vector<uint8_t> table(static_cast<size_t>(1) << (2 * length), static_cast<uint8_t>(0xffu));
+                        std::vector<uint8_t> reached(table.size(), 2);
+                        for(int32_t u = 0; u < ns; ++u) {
+                            const size_t at = words[s][static_cast<size_t>(u)].first | (words[s][static_cast<size_t>(u)].second << length);
+                            table[at] = static_cast<uint8_t>(u);
+                            reached[at] = 0;
+                        }
+                        for(int32_t u = 0; u < ns; ++u) {
+                            const uint32_t wl = words[s][static_cast<size_t>(u)].first, wh = words[s][static_cast<size_t>(u)].second;
+                            for(int32_t j = 0; j < length; ++j) {
+                                for(uint32_t other = 0; other < 4; ++other) {
+                                    const uint32_t l1 = (wl & ~(1u << j)) | ((other & 1u) << j);
+                                    const uint32_t h1 = (wh & ~(1u << j)) | ((other >> 1) << j);
+                                    if(l1 == wl && h1 == wh) { continue; }
+                                    const size_t at = l1 | (h1 << length);
+                                    if(reached[at] == 0) { continue; }                           // a word of the set
+                                    if(reached[at] == 1 && table[at] != static_cast<uint8_t>(u)) { table[at] = static_cast<uint8_t>(0xffu); reached[at] = 3; continue; }
+                                    if(reached[at] == 2) { table[at] = static_cast<uint8_t>(u); reached[at] = 1; }
+                                }
+                            }
+                        }
+                        d.plate_table[s] = static_cast<const uint8_t*>(upload(table.data(), table.size()));
+                        d.plate_unique[s] = ns;
+                        d.plate_start[s] = c.segment_offset[static_cast<size_t>(s)];
+                        d.plate_length[s] = length;
+                    }
+                    double largest = 0;
+                    for(int32_t b = 0; b < N; ++b) { largest = std::max(largest, concentration[static_cast<size_t>(b)]); }
+                    std::vector<float> ratio(static_cast<size_t>(n0) * static_cast<size_t>(n1) * 2 * SLOTS, 0.0f);
+                    std::vector<uint32_t> info(static_cast<size_t>(n0) * static_cast<size_t>(n1) * 2, 0u);
+                    auto prior_of = [&](int32_t u0, int32_t u1) {
+                        const int32_t b = (u0 < 0 || u1 < 0) ? -1 : barcode_of[static_cast<size_t>(u0) * static_cast<size_t>(n1) + static_cast<size_t>(u1)];
+                        return b < 0 ? 0.0 : concentration[static_cast<size_t>(b)];
+                    };
+                    for(int32_t u0 = 0; u0 < n0; ++u0) {
+                        for(int32_t u1 = 0; u1 < n1; ++u1) {
+                            const size_t combination = static_cast<size_t>(u0) * static_cast<size_t>(n1) + static_cast<size_t>(u1);
+                            float* const to = &ratio[combination * 2 * SLOTS];
+                            const int32_t b = barcode_of[combination];
+                            const double own = prior_of(u0, u1);
+                            if(b < 0 || !(own > 0)) {
+                                for(int32_t k = 0; k < 2 * SLOTS; ++k) { to[k] = std::numeric_limits<float>::infinity(); }      // not in the set: nothing is finished on it
+                                continue;
+                            }
+                            to[0] = static_cast<float>(d.adjusted_noise_probability / own);
+                            to[SLOTS] = static_cast<float>(largest / own * (1.0 + 1e-6));                      // a bound: rounded up
+                            for(int32_t k = 1; k < SLOTS; ++k) {
+                                to[k] = static_cast<float>(prior_of(u0, slot_word[1][static_cast<size_t>(u1)][static_cast<size_t>(k)]) / own);
+                                to[SLOTS + k] = static_cast<float>(prior_of(slot_word[0][static_cast<size_t>(u0)][static_cast<size_t>(k)], u1) / own);
+                            }
+                            info[combination * 2] = static_cast<uint32_t>(b + 1);
+                            info[combination * 2 + 1] = static_cast<uint32_t>(index[static_cast<size_t>(b)]);
+                        }
+                    }
+                    d.plate_block = static_cast<const uint32_t*>(upload(block.data(), block.size() * sizeof(uint32_t)));
+                    d.plate_ratio = static_cast<const uint32_t*>(upload(ratio.data(), ratio.size() * sizeof(float)));
+                    d.plate_info = static_cast<const uint32_t*>(upload(info.data(), info.size() * sizeof(uint32_t)));
+                    d.plate_ready = 1;
+                }
+            }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality > 16 && c.nucleotide_cardinality <= 32 && d.n_barcode > 0) {
                 // two words of bit-sliced 2-bit bases per barcode for the long barcode product form (pamld_wide.hpp)
                 const int32_t padded = (d.n_barcode + 7) / 8 * 8;

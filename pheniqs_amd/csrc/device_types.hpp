@@ -210,6 +210,22 @@ struct DevDecoder {
     // pass filter halves, where its workgroups add their LDS bins with dense atomics before one small kernel moves the
     // sums into the counter buffer (zero between launches); null when the decoder's bins fit a workgroup histogram
     unsigned long long* count_staging;
+    // plates (pamld_plate.hip): two segments of 4 to 8 nt with at most 16 distinct words each, every combination or a part of
+    // them.  plate_table[s]: 4^length entries of one byte, the ordinal of the segment's word at most one mismatch from the key
+    // (key = low code bits | high code bits << length), 0xff for none; plate_block: per word of segment 0 then of segment 1,
+    // 48 words — 16 low code planes (bit j = position j of the segment), 16 high code planes, 16 floats 1 / 0: slot 0 the word
+    // itself, then the segment's other words in order, zero past them; plate_ratio: per combination u0 * unique[1] + u1, 32
+    // floats — [0] the noise term over the combination's prior, [k] prior(u0, slot k of u1's block) / its own, [16] the largest
+    // prior over its own (rounded up), [16 + k] prior(slot k of u0's block, u1) / its own; infinities for a combination that
+    // is not in the set; plate_info: per combination {counter bin = barcode ordinal + 1 (0: not in the set), barcode index}
+    const uint8_t* plate_table[2];
+    const uint32_t* plate_block;
+    const uint32_t* plate_ratio;
+    const uint32_t* plate_info;
+    int32_t plate_unique[2];
+    int32_t plate_start[2];
+    int32_t plate_length[2];
+    int32_t plate_ready;
     const uint16_t* pair_table[2];
     const uint32_t* pair_record;
     int32_t pair_start[2];

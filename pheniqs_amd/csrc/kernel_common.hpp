@@ -323,6 +323,10 @@ int pamld_cross_stream_waves();
 int launch_pamld_cross_stream(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 bool pamld_pair_supports(const DevDecoder& host_decoder);   // pamld_pair.hip: paired barcodes, one barcode scored, in front of the product form kernels
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
+bool pamld_plate_supports(const DevDecoder& host_decoder);   // pamld_plate.hip: dual index plates, few words a segment, every word of both segments scored
+int pamld_plate_block();                                     // threads of its one workgroup a CU
+int pamld_plate_waves();                                     // ... and its waves: a worklist segment each
+int launch_pamld_plate(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_wide_supports(const DevDecoder& host_decoder);
 int pamld_wide_block(const DevDecoder& host_decoder);
 int launch_pamld_wide(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);

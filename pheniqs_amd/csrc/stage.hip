@@ -92,7 +92,9 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // ... and a codec of a handful of barcodes through the kernel without tables (pamld_tiny.hip)
                 const bool tiny = pamld_tiny_supports(host_decoder);
                 const bool listed = !tiny && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
-                const bool paired = !tiny && !listed && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
+                // tier 0 of plates: dual index sets of few words a segment, every word of both segments scored (pamld_plate.hip)
+                const bool plated = !tiny && !listed && args.result != nullptr && host_decoder.use_lds_histogram && !args.defer_counters && pamld_plate_supports(host_decoder);
+                const bool paired = !tiny && !listed && !plated && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
                 // ... and where the streaming kernel takes the codec (5 to 10 nt), lists and scan are ONE launch, every
                 // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)
                 static const bool no_stream = std::getenv("PHQ_NO_STREAM") != nullptr;
@@ -104,19 +106,22 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool factorised = !tiny && !pamld_lut_supports(host_decoder) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
-                const bool crossed = factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);
+                const bool crossed = !plated && factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);
                 // ... and where the streaming kernel of such sets takes the codec, lists and factorised scan are one launch too
                 static const bool no_cross_stream = std::getenv("PHQ_NO_CROSS_STREAM") != nullptr;
                 const bool cross_streamed = crossed && !no_stream && !no_cross_stream && args.defer_counters && pamld_cross_stream_supports(host_decoder);
-                const int64_t threads = listed ? pamld_near_block(host_decoder) : crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
+                const int64_t threads = listed ? pamld_near_block(host_decoder) : plated ? pamld_plate_block() : crossed ? pamld_cross_near_block(host_decoder) : (tiny || factorised || paired) ? BLOCK : long_words ? pamld_wide_block(host_decoder) : pamld_lut_block(host_decoder);
                 const int64_t wide_tiles = (args.n_read + threads - 1) / threads;
                 static const int near_share = std::getenv("PHQ_GRID_SHARE_NEAR") ? std::atoi(std::getenv("PHQ_GRID_SHARE_NEAR")) : GRID_SHARE_NEAR;
-                const int64_t product_blocks = (paired || crossed) ? share(near_share) : (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);
+                const int64_t product_blocks = plated ? cus : (paired || crossed) ? share(near_share) : (factorised || long_words) ? default_blocks : listed ? share(near_share) : share(GRID_SHARE_LUT);
                 const dim3 wide_grid(static_cast<unsigned>(wide_tiles < product_blocks ? wide_tiles : product_blocks));
                 const int64_t tiles_per_block = (wide_tiles + wide_grid.x - 1) / wide_grid.x;
                 StageArgs producer = args;
                 producer.worklist_role = 1;
                 producer.worklist_stride = static_cast<int32_t>(tiles_per_block * threads);
+                // the plate kernel keeps a segment per WAVE: 12 per CU for the tiers behind it
+                const dim3 segment_grid(plated ? wide_grid.x * static_cast<unsigned>(pamld_plate_waves()) : wide_grid.x);
+                if(plated) { producer.worklist_stride = static_cast<int32_t>(tiles_per_block * 64); }
                 // the deferred reads' inputs travel beside the first quarter of a segment (device_types.hpp, StageArgs::carry)
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
@@ -153,25 +158,26 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
                     return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
                 }
-                if(listed || paired || crossed) {
+                if(listed || paired || crossed || plated) {
                     {
-                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream, listed ? "pamld_near_kernel" : paired ? "pamld_pair_kernel" : "pamld_cross_near_kernel");
+                        Timed timed(timer, KERNEL_PAMLD_NEAR, stream, listed ? "pamld_near_kernel" : plated ? "pamld_plate_kernel" : paired ? "pamld_pair_kernel" : "pamld_cross_near_kernel");
                         status = listed ? launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s)
+                               : plated ? launch_pamld_plate(producer, host_decoder, wide_grid, histogram_bytes, s)
                                : paired ? launch_pamld_pair(producer, host_decoder, wide_grid, histogram_bytes, s)
                                         : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s);
                     }
                     if(status != 0) { return status; }
-                    trace_worklist("the neighbour lists", producer, wide_grid.x, s);
+                    trace_worklist("the neighbour lists", producer, segment_grid.x, s);
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
-                    middle.worklist_segments = static_cast<int32_t>(wide_grid.x);
+                    middle.worklist_segments = static_cast<int32_t>(segment_grid.x);
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, (!crossed && !long_words) ? "pamld_lut_kernel (consumer)" : crossed ? (host_decoder.uniform_prior ? "pamld_cross_kernel (consumer)" : "pamld_cross_kernel (weighted, consumer)") : "pamld_wide_kernel (consumer)");
                     if(!crossed && !long_words) {
                         // the product form kernel takes the segments in groups: as many workgroups as stay resident
                         static const int consumer_share = std::getenv("PHQ_GRID_SHARE_CONSUMER") ? std::atoi(std::getenv("PHQ_GRID_SHARE_CONSUMER")) : GRID_SHARE_CONSUMER;
                         const int64_t wanted = std::max<int64_t>(1, share(consumer_share));
-                        middle.worklist_group = static_cast<int32_t>((wide_grid.x + wanted - 1) / wanted);
-                        const dim3 fewer(static_cast<unsigned>((wide_grid.x + middle.worklist_group - 1) / middle.worklist_group));
+                        middle.worklist_group = static_cast<int32_t>((segment_grid.x + wanted - 1) / wanted);
+                        const dim3 fewer(static_cast<unsigned>((segment_grid.x + middle.worklist_group - 1) / middle.worklist_group));
                         status = launch_pamld_lut(middle, host_decoder, fewer, histogram_bytes, s);
                     } else {
                         status = crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
@@ -185,24 +191,24 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                                         : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
                 }
                 if(status != 0) { return status; }
-                trace_worklist("the product form", producer, wide_grid.x, s);
+                trace_worklist("the product form", producer, segment_grid.x, s);
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
-                    status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, wide_grid, histogram_bytes, s)
-                                                                                      : launch_pamld_cross_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
+                    status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
+                                                                                      : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 } else if(long_words && pamld_wide_exact_supports(host_decoder)) {
                     // the same for two word barcodes (pamld_wide_exact.hpp)
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, "pamld_wide_exact_kernel");
-                    status = launch_pamld_wide_exact(consumer, host_decoder, wide_grid, histogram_bytes, s);
+                    status = launch_pamld_wide_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
                     if(status != 0) { return status; }
                 }
-                trace_worklist("the exact tier", producer, wide_grid.x, s);
+                trace_worklist("the exact tier", producer, segment_grid.x, s);
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
-                return launch_pamld_literal(consumer, host_decoder, wide_grid, 128 * sizeof(double) + histogram_bytes, s);
+                return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
             }
             {
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel (every read)");

@@ -159,11 +159,49 @@ MODES = [capi.MODE_LITERAL, capi.MODE_FAST]
     ("C3", "pamld", 3000), ("C3", "mdd", 1 << 14),
     ("C4", "pamld", 1 << 14), ("C4", "mdd", 1 << 14), ("C4V", "pamld", 1 << 14), ("C4V", "mdd", 1 << 14),
     ("C5", "pamld", 1 << 14), ("C5", "mdd", 1 << 14),
+    # the reference's own published workload (docs/illumina_api_vignette.md:222): 94 wells of a 12 x 8 dual index plate
+    ("H94", "pamld", 1 << 16), ("H94A", "pamld", 1 << 16), ("H94", "mdd", 1 << 14),
 ])
 def test_baseline_configs_against_oracle(oracle, torch_cuda, name, algorithm, n, mode):
     job, recipe = synthetic.config_job(name, algorithm)
     code, quality, flag, offsets = synthetic.generate_rows(job, n, recipe["seed"])
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=mode)
+
+
+@pytest.mark.parametrize("rows,columns,lengths,wells_missing,spread,noise", [
+    (12, 8, (8, 8), 2, 0.0, 0.05), (12, 8, (8, 8), 0, 0.0, 0.01), (16, 16, (8, 8), 40, 0.0, 0.01), (12, 8, (8, 8), 2, 1.0, 0.02),
+    (5, 9, (6, 7), 11, 0.5, 0.01), (3, 16, (8, 5), 0, 2.0, 0.01), (2, 2, (4, 4), 1, 0.3, 0.1), (16, 12, (7, 8), 100, 1.0, 0.01)])
+def test_plates_every_word_of_both_segments_scored(oracle, torch_cuda, rows, columns, lengths, wells_missing, spread, noise):
+    """Dual index plates (pamld_plate.hip): few words a segment, every combination or a part of them, uniform priors or
+    priors that differ; the wells that are missing still get reads (sequencing errors, and draws put ON them here).  The
+    kernel must take the set, finish most reads, and everything must be the oracle's in both modes."""
+    rng = np.random.default_rng(1000 * rows + 10 * columns + wells_missing)
+    first = synthetic.barcode_set(rng, rows, lengths[0], min_distance=3 if lengths[0] >= 6 else 2)
+    second = synthetic.barcode_set(rng, columns, lengths[1], min_distance=3 if lengths[1] >= 6 else 2)
+    spec = {"input segment cardinality": 2,
+            "sample": synthetic.decoder_spec("pamld", [first, second], ["0::%d" % lengths[0], "1::%d" % lengths[1]], noise=noise)}
+    keys = list(spec["sample"]["codec"])
+    missing = set(rng.choice(len(keys), size=wells_missing, replace=False).tolist()) if wells_missing else set()
+    wells = [(key, spec["sample"]["codec"][key]) for k, key in enumerate(keys) if k not in missing]
+    spec["sample"]["codec"] = {key: dict(record, concentration=float(10 ** rng.uniform(-spread, spread)) if spread else 1) for key, record in wells}
+    job = capi.compile_job(spec)
+    n = 1 << 16
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 17 + rows)
+    if missing:          # reads ON wells that are not in the set
+        letters = {"A": 1, "C": 2, "G": 4, "T": 8}
+        picks = rng.choice(sorted(missing), size=1 << 9)
+        code[: 1 << 9] = np.array([[letters[c] for c in first[k // columns] + second[k % columns]] for k in picks], dtype=np.uint8)
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    # (a set of some two hundred barcodes may lose its workgroup histogram to the product form kernel's occupancy, and with it
+    # this tier: the chain is asserted where the histogram is sure to stay)
+    if max(rows, columns, 8) < rows * columns - wells_missing <= 128:          # (up to 8 barcodes are the few barcode kernel's)
+        s.set_mode(capi.MODE_FAST)
+        s.profile_enable(True)
+        run_gpu(torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST, device_set=s)
+        chain = [span["kernel"] for span in s.profile_chain()]
+        assert chain[0] == "pamld_plate_kernel", chain
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+    s.close()
 
 
 @pytest.mark.parametrize("length,count,spread,absent", [(8, 96, 1.0, 0), (8, 96, 3.0, 0), (10, 96, 1.0, 0), (6, 40, 1.5, 0), (9, 64, 2.0, 0), (8, 192, 1.0, 0),
