@@ -384,7 +384,7 @@ def main():
                         help="fast: neighbour list / product form kernels + literal kernel on the ambiguous reads; literal: literal kernel on every read")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     parser.add_argument("--no-parity", action="store_true", help="skip the oracle check of a sample of the timed batch")
-    parser.add_argument("--host-staged", type=int, default=16_000_000, metavar="READS",
+    parser.add_argument("--host-staged", type=int, default=64_000_000, metavar="READS",
                         help="reads of the phq_classify_host leg (host planes -> pinned -> device -> back); 0 = skip")
     parser.add_argument("--no-extra-legs", action="store_true", help="only the contract line: no staged / fastq_to_sam / shapes blocks")
     args = parser.parse_args()
@@ -535,7 +535,7 @@ def host_staged(torch, w, m):
     s.classify_host(m, host_base, host_qual, host_flag)
     dt = time.perf_counter() - t0
     out["pageable"] = {"Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * w.bytes_per_read / dt / 1e9,
-                       "note": "pageable host planes, memcpy to pinned slots, 2 streams, results copied back"}
+                       "note": "pageable host planes, memcpy to pinned slots, uploads on one stream and three slots of 2 Mi reads behind it, results copied back"}
     # the same batch in pinned memory end to end (phq_host_alloc): no bounce copy on either side
     pinned = {}
     for name, array in (("base", host_base), ("qual", host_qual), ("flag", host_flag)):
@@ -550,7 +550,9 @@ def host_staged(torch, w, m):
     dt = time.perf_counter() - t0
     out["pinned"] = {"Mreads/s": m / dt / 1e6, "GB/s_over_pcie": m * w.bytes_per_read / dt / 1e9,
                      "step_frac_of_pcie_63GBs": m * w.bytes_per_read / dt / 1e9 / 63.0,
-                     "note": "caller's planes and result buffers pinned: async copies straight from / to them"}
+                     "step_frac_of_duplex_96GBs": m * w.bytes_per_read / dt / 1e9 / 96.0,
+                     "note": "caller's planes and result buffers pinned: async copies straight from / to them, both directions of the link at once "
+                             "(profiles/tools/micro/pcie_duplex.py on this pool: 57 GB/s either way alone, 96 GB/s for both together)"}
     return out
 
 

@@ -163,9 +163,12 @@ void DecoderSet::release() {
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
         if(slot.done) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.done)); }
+        if(slot.uploaded) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.uploaded)); }
+        if(slot.consumed) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.consumed)); }
         if(slot.stream) { (void)hipStreamDestroy(static_cast<hipStream_t>(slot.stream)); }
         slot = Slot();
     }
+    if(upload_stream_) { (void)hipStreamDestroy(static_cast<hipStream_t>(upload_stream_)); upload_stream_ = nullptr; }
     release_host_stage();
     if(order_event_) { (void)hipEventDestroy(static_cast<hipEvent_t>(order_event_)); order_event_ = nullptr; order_pending_ = false; }
     for(void* p : device_allocation_) { (void)hipFree(p); }
@@ -1322,7 +1325,7 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
         // nothing of the old buffers is left in the slot should an allocation below throw (release() frees what it finds)
-        { Slot fresh; fresh.stream = slot.stream; fresh.done = slot.done; slot = fresh; }
+        { Slot fresh; fresh.stream = slot.stream; fresh.done = slot.done; fresh.uploaded = slot.uploaded; fresh.consumed = slot.consumed; slot = fresh; }
         chunk_capacity_ = 0;
         const size_t planes = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
         const size_t results = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult);
@@ -1344,22 +1347,36 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
             hipEvent_t event;
             check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
             slot.done = event;
+            check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
+            slot.uploaded = event;
+            check(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreate");
+            slot.consumed = event;
         }
         slot.busy = false;
+    }
+    if(upload_stream_ == nullptr) {
+        hipStream_t stream;
+        check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+        upload_stream_ = stream;
     }
     chunk_capacity_ = chunk_capacity;
 }
 
-// Host batch -> pinned slot -> device -> pinned slot -> host batch, two slots on two streams so that the
-// copies of one chunk run behind the kernels of the other (the reference's per-read Transcode::pull /
+// Host batch -> pinned slot -> device -> pinned slot -> host batch (the reference's per-read Transcode::pull /
 // Multiplexer::push hand-offs, transcode.cpp:287-316 and multiplex.h:198-222, become two async copies per chunk).
+// The link moves bytes BOTH ways at once (profiles/tools/micro/pcie_duplex.py: 57 GB/s either way alone, 96 GB/s together),
+// so the pipeline is laid out for that: every chunk's uploads go through ONE stream, one after the other at the link's full
+// rate, and a chunk's kernels and downloads through its slot's stream behind an event — while chunk k comes down, chunk
+// k + 1 goes up.  (Round 3 had each slot upload, compute and download on its own stream: two chunks then ran in step, both
+// up and then both down, and the two directions took turns: 55 GB/s for both together.)  Three slots of 2 Mi reads.
 void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                                DevResult* result, uint32_t* word) {
     require_device();
     if(n_read <= 0) { return; }
     if(n_read > batch_capacity) { throw OverflowError("read count exceeds the batch capacity"); }
-    const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 22);
+    const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 21);
     ensure_pipeline(chunk);
+    hipStream_t upload = static_cast<hipStream_t>(upload_stream_);
     // batches that already live in pinned memory (phq_host_alloc) are copied straight from / to the caller's
     // buffers; pageable ones bounce through the slot's pinned buffers
     auto pinned = [](const void* pointer) {
@@ -1387,36 +1404,43 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
     };
 
     int which = 0;
-    for(int64_t first = 0; first < n_read; first += chunk, which ^= 1) {
+    for(int64_t first = 0; first < n_read; first += chunk, which = (which + 1) % SLOTS) {
         Slot& slot = slot_[which];
         drain(slot);
         const int64_t count = std::min(chunk, n_read - first);
         hipStream_t stream = static_cast<hipStream_t>(slot.stream);
+        // the slot's device planes are free once its previous chunk's kernels are through (the host has waited for that
+        // chunk's downloads just above; the event orders the two streams on the device as well)
+        if(slot.used) { check(hipStreamWaitEvent(upload, static_cast<hipEvent_t>(slot.consumed), 0), "hipStreamWaitEvent"); }
         for(const auto& c : job_.decoder) {
             if(c.plane_stride == 0) { continue; }
             const size_t bytes = static_cast<size_t>(count) * static_cast<size_t>(c.plane_stride);
             const int64_t source = batch_capacity * c.plane_prefix + first * c.plane_stride;
             const int64_t target = chunk_capacity_ * c.plane_prefix;
             if(direct_in) {
-                check(hipMemcpyAsync(slot.device_base + target, base_planes + source, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
-                check(hipMemcpyAsync(slot.device_quality + target, quality_planes + source, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_base + target, base_planes + source, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_quality + target, quality_planes + source, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             } else {
                 host_copy(slot.pinned_base + target, base_planes + source, bytes);
                 host_copy(slot.pinned_quality + target, quality_planes + source, bytes);
-                check(hipMemcpyAsync(slot.device_base + target, slot.pinned_base + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
-                check(hipMemcpyAsync(slot.device_quality + target, slot.pinned_quality + target, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_base + target, slot.pinned_base + target, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_quality + target, slot.pinned_quality + target, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             }
         }
         if(flag != nullptr) {
             if(direct_in) {
-                check(hipMemcpyAsync(slot.device_flag, flag + first, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_flag, flag + first, static_cast<size_t>(count), hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             } else {
                 host_copy(slot.pinned_flag, flag + first, static_cast<size_t>(count));
-                check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+                check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             }
         }
+        check(hipEventRecord(static_cast<hipEvent_t>(slot.uploaded), upload), "hipEventRecord");
+        check(hipStreamWaitEvent(stream, static_cast<hipEvent_t>(slot.uploaded), 0), "hipStreamWaitEvent");
         run_stages(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
                    slot.device_result, slot.device_word, stream, slot.device_worklist);
+        check(hipEventRecord(static_cast<hipEvent_t>(slot.consumed), stream), "hipEventRecord");
+        slot.used = true;
         for(const auto& c : job_.decoder) {
             if(c.result_slot >= 0 && result != nullptr) {
                 const int64_t plane = static_cast<int64_t>(c.result_slot) * chunk_capacity_;
@@ -1434,8 +1458,7 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
         slot.first = first;
         slot.count = count;
     }
-    drain(slot_[0]);
-    drain(slot_[1]);
+    for(auto& slot : slot_) { drain(slot); }
 }
 
 // ---- statistics ----------------------------------------------------------------------------------------

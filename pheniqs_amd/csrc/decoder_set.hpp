@@ -115,11 +115,16 @@ private:
         uint32_t* device_worklist = nullptr;
         void* stream = nullptr;
         void* done = nullptr;                   // hipEvent_t recorded after the slot's last D2H
+        void* uploaded = nullptr;               // ... after its chunk's last H2D, on the upload stream
+        void* consumed = nullptr;               // ... after its chunk's kernels: the device planes may take the next chunk
         bool busy = false;
+        bool used = false;                      // a chunk has gone through the slot: `consumed` has been recorded
         int64_t first = 0;
         int64_t count = 0;
     };
-    Slot slot_[2];
+    static constexpr int SLOTS = 3;
+    Slot slot_[SLOTS];
+    void* upload_stream_ = nullptr;             // every chunk's host to device copies, one after the other
     int64_t chunk_capacity_;
 };
 
