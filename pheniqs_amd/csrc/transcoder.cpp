@@ -811,7 +811,7 @@ namespace {
 // what a set keeps from one report only run to the next: pinning and allocating these costs more than a small run
 struct DeviceFastqCache {
     size_t raw_bytes[FASTQ_MAX_FEED] = {0};
-    uint8_t* pinned[FASTQ_MAX_FEED] = {nullptr};
+    uint8_t* pinned[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};      // a round's bytes, and the next round's read ahead of its start being known
     uint8_t* raw[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
     uint32_t* newline[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
     uint32_t* block_count[2][FASTQ_MAX_FEED] = {{nullptr}, {nullptr}};
@@ -836,7 +836,7 @@ struct DeviceFastqCache {
         (void)hipFree(keep); (void)hipFree(keep_block); (void)hipFree(kept_device);
         if(kept_host) { (void)hipHostFree(kept_host); }
         for(int f = 0; f < FASTQ_MAX_FEED; ++f) {
-            if(pinned[f]) { (void)hipHostFree(pinned[f]); }
+            for(int b = 0; b < 2; ++b) { if(pinned[b][f]) { (void)hipHostFree(pinned[b][f]); } }
             for(int s = 0; s < 2; ++s) { (void)hipFree(raw[s][f]); (void)hipFree(newline[s][f]); (void)hipFree(block_count[s][f]); }
         }
         (void)hipFree(total); (void)hipFree(round_device); (void)hipFree(irregular); (void)hipFree(flagged); (void)hipFree(counters_before);
@@ -970,10 +970,10 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1);
         chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
         if(c.raw_bytes[f] < chunk_bytes[f]) {
-            if(c.pinned[f]) { (void)hipHostFree(c.pinned[f]); c.pinned[f] = nullptr; }
+            for(int b = 0; b < 2; ++b) { if(c.pinned[b][f]) { (void)hipHostFree(c.pinned[b][f]); c.pinned[b][f] = nullptr; } }
             for(int s = 0; s < 2; ++s) { (void)hipFree(c.raw[s][f]); (void)hipFree(c.newline[s][f]); (void)hipFree(c.block_count[s][f]); c.raw[s][f] = nullptr; c.newline[s][f] = nullptr; c.block_count[s][f] = nullptr; }
             c.raw_bytes[f] = 0;
-            device_check(hipHostMalloc(reinterpret_cast<void**>(&c.pinned[f]), chunk_bytes[f] + 16, hipHostMallocDefault), "hipHostMalloc");
+            for(int b = 0; b < 2; ++b) { device_check(hipHostMalloc(reinterpret_cast<void**>(&c.pinned[b][f]), chunk_bytes[f] + chunk_bytes[f] / 8 + 8192 + 16, hipHostMallocDefault), "hipHostMalloc"); }
             for(int s = 0; s < 2; ++s) {
                 device_check(hipMalloc(reinterpret_cast<void**>(&c.raw[s][f]), chunk_bytes[f] + 16), "hipMalloc");
                 device_check(hipMalloc(reinterpret_cast<void**>(&c.newline[s][f]), (chunk_bytes[f] / 8 + 1024) * sizeof(uint32_t)), "hipMalloc");
@@ -994,6 +994,10 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     };
     uint64_t reads = 0;
     int slot = 0;
+    int buffer = 0;                                  // which pinned buffer of a feed this round's bytes are in
+    bool ahead_valid[FASTQ_MAX_FEED] = {false};
+    size_t ahead_start[FASTQ_MAX_FEED] = {0}, ahead_bytes[FASTQ_MAX_FEED] = {0};
+    size_t source_bytes[FASTQ_MAX_FEED] = {0};
     const int threads = host_threads();
     while(true) {
         bool any_left = false;
@@ -1003,23 +1007,32 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
             const size_t left = p.size - p.position;
             size_t bytes = std::min(left, chunk_bytes[f] - 1);
             any_left = any_left || left > 0;
-            // the file's bytes into the pinned buffer, on every host thread
-            uint8_t* const to = c.pinned[f];
+            // the file's bytes into a pinned buffer, on every host thread — unless the read ahead of the round before already
+            // holds them: that one started a little before where this round could begin at the earliest
+            uint8_t* to = c.pinned[buffer][f];
             std::atomic<bool> failed{false};
-            parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
-                const size_t from = static_cast<size_t>(first) << 20;
-                const size_t until = std::min(bytes, static_cast<size_t>(last) << 20);
-                size_t done = from;
-                while(done < until) {
-                    const ssize_t got = ::pread(p.descriptor, to + done, until - done, static_cast<off_t>(p.position + done));
-                    if(got <= 0) { failed = true; return; }
-                    done += static_cast<size_t>(got);
-                }
-            });
-            if(failed) { return give_up(); }
+            auto read_into = [&](uint8_t* target, size_t from_position, size_t count) {
+                parallel_ranges(static_cast<int64_t>((count + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
+                    const size_t from = static_cast<size_t>(first) << 20;
+                    const size_t until = std::min(count, static_cast<size_t>(last) << 20);
+                    size_t done = from;
+                    while(done < until) {
+                        const ssize_t got = ::pread(p.descriptor, target + done, until - done, static_cast<off_t>(from_position + done));
+                        if(got <= 0) { failed = true; return; }
+                        done += static_cast<size_t>(got);
+                    }
+                });
+            };
+            if(ahead_valid[f] && p.position >= ahead_start[f] && p.position + bytes <= ahead_start[f] + ahead_bytes[f]) {
+                to = c.pinned[buffer][f] + (p.position - ahead_start[f]);
+            } else {
+                read_into(to, p.position, bytes);
+                if(failed) { return give_up(); }
+            }
+            source_bytes[f] = bytes;
             if(bytes == left && bytes > 0 && to[bytes - 1] != '\n') { to[bytes++] = '\n'; }      // the last line of a file may lack its newline
-            std::memset(to + bytes, 0, 16);
-            device_check(hipMemcpyAsync(c.raw[slot][f], to, bytes + 16, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            device_check(hipMemcpyAsync(c.raw[slot][f], to, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            device_check(hipMemsetAsync(c.raw[slot][f] + bytes, 0, 16, stream), "hipMemsetAsync");      // zero padded to whole units of 16 bytes
             chunk[f].raw = c.raw[slot][f];
             chunk[f].bytes = static_cast<uint32_t>(bytes);
             chunk[f].newline = c.newline[slot][f];
@@ -1031,7 +1044,35 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         if(!any_left) { break; }
         device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, device_plan.feed_resolution, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
         device_check(hipMemcpyAsync(c.round_host, c.round_device, sizeof(FastqRound), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
-        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // the pinned buffers are free again, the round is known
+        // While the round's bytes cross the link and are indexed, the host reads AHEAD: where the next round starts is only
+        // known once this one is planned (it takes whole records), but never before 7/8 of this round's bytes — a round's
+        // bytes are sized for the capacity plus 3 % — so the next round's bytes are read from there on into the other
+        // pinned buffer, and the round finds them at whatever offset its start turns out to have.
+        const int other = buffer ^ 1;
+        for(int32_t f = 0; f < n_feed; ++f) {
+            PlainFile& p = file[static_cast<size_t>(f)];
+            ahead_valid[f] = false;
+            const size_t start = p.position + (source_bytes[f] - source_bytes[f] / 8);
+            if(source_bytes[f] < (size_t(1) << 20) || start >= p.size) { continue; }                 // a small file, or its end: nothing to gain
+            const size_t count = std::min(p.size - start, chunk_bytes[f] - 1 + source_bytes[f] / 8 + 4096);
+            std::atomic<bool> failed{false};
+            parallel_ranges(static_cast<int64_t>((count + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
+                const size_t from = static_cast<size_t>(first) << 20;
+                const size_t until = std::min(count, static_cast<size_t>(last) << 20);
+                size_t done = from;
+                while(done < until) {
+                    const ssize_t got = ::pread(p.descriptor, c.pinned[other][f] + done, until - done, static_cast<off_t>(start + done));
+                    if(got <= 0) { failed = true; return; }
+                    done += static_cast<size_t>(got);
+                }
+            });
+            if(failed) { continue; }
+            ahead_valid[f] = true;
+            ahead_start[f] = start;
+            ahead_bytes[f] = count;
+        }
+        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // this round's pinned buffers are free again, the round is known
+        buffer = other;
         const FastqRound round = *c.round_host;
         if(round.irregular) { return give_up(); }
         if(round.records == 0) {
