@@ -1,9 +1,9 @@
 #!/bin/bash
-# The profile set of a round, taken on ONE build: bash profiles/tools/refresh.sh r03 [shape ...]   (GPU box, repo root).
+# The profile set of a round, taken on ONE build: bash profiles/tools/refresh.sh r04 [shape ...]   (GPU box, repo root).
 # Per workload: a kernel trace (--kernel-trace --stats) and two counter passes of their own (--pmc FETCH_SIZE, --pmc
 # WRITE_SIZE: MI355X_MICROARCH.md's HBM recipe), each of the same bench.py command; then profiles/summarize.py folds
 # them into profiles/rNN_traffic.json, stamped with the build (phq_build_id) and the commit.
-round=${1:-r03}; shift
+round=${1:-r04}; shift
 export TMPDIR=/tmp
 declare -A ARGS=(
   [C2_pamld]=""
@@ -15,8 +15,12 @@ declare -A ARGS=(
   [C4_pamld]="--config C4 --reads 50000000"
   [C4V_pamld]="--config C4V --reads 50000000"
   [C5_pamld]="--config C5 --reads 50000000"
+  [H94_pamld]="--config H94"
+  [H94A_pamld]="--config H94A"
+  [S384_pamld]="--config S384"
+  [U384_pamld]="--config U384"
 )
-shapes=("$@"); [ ${#shapes[@]} -eq 0 ] && shapes=(C2_pamld C2_pamld_literal C2_mdd C2_pamld_estimated_priors C3_pamld C3_pamld_estimated_priors C4_pamld C4V_pamld C5_pamld)
+shapes=("$@"); [ ${#shapes[@]} -eq 0 ] && shapes=(C2_pamld C2_pamld_literal C2_mdd C2_pamld_estimated_priors C3_pamld C3_pamld_estimated_priors C4_pamld C4V_pamld C5_pamld H94_pamld H94A_pamld S384_pamld U384_pamld)
 out=gpurun_out/prof_$round
 for shape in "${shapes[@]}"; do
   a="${ARGS[$shape]}"
