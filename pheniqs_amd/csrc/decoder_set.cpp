@@ -468,7 +468,10 @@ void DecoderSet::build_device_images() {
                 d.near_record = static_cast<const uint32_t*>(upload(tables.record.data(), tables.record.size() * sizeof(uint32_t)));
                 d.near_ready = 2 * tables.usable >= N ? 1 : 0;          // a denser set leaves the kernel nothing to finish
                 const bool stream_priors = !d.uniform_prior;
-                const uint32_t stream_stride = static_cast<uint32_t>(stream_record_words(stream_priors)) * 4u;
+                // a decoder without a workgroup histogram streams with blocks that hold no bin (its counters come from the records)
+                const bool stream_bins = d.use_lds_histogram != 0;
+                d.stream_binless = stream_bins ? 0 : 1;
+                const uint32_t stream_stride = static_cast<uint32_t>(stream_record_words(stream_priors, stream_bins)) * 4u;
                 if(!tables.record.empty() && N < static_cast<int32_t>(STREAM_UNKNOWN) &&
                    stream_block_at(STREAM_WAVES, N, stream_priors, L) + static_cast<uint32_t>(N) * stream_stride < (1u << 18)) {
                     // the streaming kernel (pamld_stream.hpp): the same table and lists in pamld_lut.hpp's bit order; the table
@@ -477,7 +480,7 @@ void DecoderSet::build_device_images() {
                     const int32_t near_listed = near_list(L);                 // tables.listed holds that many per barcode, nearest first
                     const int32_t list = stream_list(L);                      // 16 up to 8 nt, two to a plane word; 8 beyond, one to a word
                     const bool one_per_word = L > 8;
-                    const int32_t record_words = stream_record_words(stream_priors);
+                    const int32_t record_words = stream_record_words(stream_priors, stream_bins);
                     auto half = [](uint32_t bits) { return ((bits & 0xfu) << 2) | (((bits >> 4) & 0xfu) << 10) | (((bits >> 8) & 0x3u) << 18); };      // bit j = position j -> bit 8 (j / 4) + 2 + j % 4
                     std::vector<uint32_t> record(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
                     std::vector<char> usable(static_cast<size_t>(N), 1);

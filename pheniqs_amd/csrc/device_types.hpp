@@ -29,7 +29,8 @@ constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, hi
 // alone, so the host can put a block's LDS ADDRESS into the lookup table (stream_block_at).
 // with priors that differ a block also holds the prior of each listed barcode over c's (16 floats; slot 0: the noise term
 // over c's prior) between the weights and the bin: 15 quads; and the codec's single precision priors sit behind its words
-constexpr int stream_record_words(bool priors) { return priors ? 60 : 44; }
+// (round 4) without the bin — a codec whose counters are rebuilt from the records — 5 quads, 9 with prior ratios
+constexpr int stream_record_words(bool priors, bool bins = true) { return bins ? (priors ? 60 : 44) : (priors ? 36 : 20); }
 #ifndef PHQ_STREAM_WAVES
 #define PHQ_STREAM_WAVES 12
 #endif
@@ -175,6 +176,7 @@ struct DevDecoder {
     const void* stream_table;
     const uint32_t* stream_record;
     int32_t stream_ready;
+    int32_t stream_binless;               // the blocks hold no counter bin (the decoder has no workgroup histogram): stream_record_words(priors, false)
     // one lookup MDD (mdd_near.hpp; one segment of 5 to 10 nt, tolerance 0 or 1): near_table as above and per barcode
     // {low plane, high plane, -, barcode index}
     const uint32_t* mdd_near_record;

@@ -50,8 +50,12 @@ constexpr int PLANE_WORDS = STREAM_PLANE_WORDS; // a block's list: 8 low + 8 hig
 // a barcode's block in LDS: its list — 8 low plane words, 8 high plane words (two listed barcodes per word) —, the weights
 // of the bound (how many barcodes that are not listed sit at distance 3, 4, 5 and 6 or more from it), then its counter
 // bin, then padding to a stride of 11 quads: an odd number, so the blocks start in all 16 quad places of the banks
-template <bool PRIORS> struct Block {
-    static constexpr int WORDS = stream_record_words(PRIORS);
+// BINS = false (round 4): a codec whose counters do not fit the workgroup — 171 to ~500 barcodes — keeps no bin in its
+// blocks (80 bytes a barcode, 144 with prior ratios: 5 and 9 quads, odd strides again); the classified reads' count, distance
+// and confidence are then rebuilt from the records (counters.hip), the two rare counts go straight to the counter buffer,
+// bin 0 stays in the workgroup's histogram — as pamld_cross_stream.hpp does for its sets
+template <bool PRIORS, bool BINS = true> struct Block {
+    static constexpr int WORDS = stream_record_words(PRIORS, BINS);
     static constexpr uint32_t BYTES = WORDS * 4u;
     static constexpr uint32_t WEIGHT_AT = 64;      // bytes into the block: the four weights of the bound
     static constexpr uint32_t RATIO_AT = 80;       // PRIORS: the noise term over c's prior, then the prior of each listed barcode over c's
@@ -68,7 +72,7 @@ constexpr int BIN_WORDS = 8;                   // words 0..3 the qc fail half, 4
 // 2^38 - round(y 2^38), formed from 32-bit integers and split into the buffer's two limbs
 constexpr int PASS_A_FRACTION_BITS = 38;
 
-template <int L, int WAVES, bool PRIORS = false> struct Shape {
+template <int L, int WAVES, bool PRIORS = false, bool BINS = true> struct Shape {
     static_assert(L >= 5 && L <= 10, "two groups of 4 positions, and up to two positions picked by masks");
     static_assert(WAVES >= 2 && WAVES <= 16 && WAVES % 2 == 0, "pairs of waves share a 16 KiB block of tables");
     static constexpr int THREADS = 64 * WAVES;
@@ -89,7 +93,7 @@ template <int L, int WAVES, bool PRIORS = false> struct Shape {
     __host__ __device__ static constexpr uint32_t block_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }      // the barcodes' blocks
     static_assert(WORDS_AT + stream_words_bytes(96, PRIORS, L) == stream_block_at(WAVES, 96, PRIORS, L), "the host puts block addresses into the lookup table");
     // bin 0 (unclassified) and the two job words in front of it, behind the blocks
-    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * Block<PRIORS>::BYTES; }
+    __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return block_at(n_barcode) + static_cast<uint32_t>(n_barcode) * Block<PRIORS, BINS>::BYTES; }
     __host__ __device__ static constexpr uint32_t lds_bytes(int n_barcode) { return histogram_at(n_barcode) + 8u * (STAT_JOB_WORDS + BIN_WORDS); }
     __host__ __device__ static constexpr int positions(int g) { return TABLED - 4 * g >= 4 ? 4 : TABLED - 4 * g; }
     static constexpr uint32_t VALID1 = L >= 8 ? 0xffffffffu : ((1u << (8 * (L - 4))) - 1u);      // the bytes of positions 4 .. 7 in the second word
@@ -116,15 +120,15 @@ __device__ __forceinline__ void bin_add(unsigned char* lds, uint32_t bin_address
 
 // STATE: where a read's carried state comes from (pamld_near.hpp): 0 nothing to load, 1 the input flag bytes, 2 the
 // status word of the stage before
-template <int L, int STATE, int WAVES, bool PRIORS>
+template <int L, int STATE, int WAVES, bool PRIORS, bool BINS = true>
 // one workgroup per CU: the LDS it takes fixes the occupancy at WAVES / 4 waves per SIMD, and the compiler is told so — left
 // to assume that fewer registers would buy more waves, it serialises the table reads into pairs, each waited for
-__global__ __launch_bounds__((Shape<L, WAVES, PRIORS>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
+__global__ __launch_bounds__((Shape<L, WAVES, PRIORS, BINS>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
 void pamld_stream_kernel(StageArgs args) {
-    typedef Shape<L, WAVES, PRIORS> Layout;
-    constexpr int BLOCK_WORDS = Block<PRIORS>::WORDS;
-    constexpr uint32_t BLOCK_BYTES = Block<PRIORS>::BYTES;
-    constexpr uint32_t BIN_AT = Block<PRIORS>::BIN_AT;
+    typedef Shape<L, WAVES, PRIORS, BINS> Layout;
+    constexpr int BLOCK_WORDS = Block<PRIORS, BINS>::WORDS;
+    constexpr uint32_t BLOCK_BYTES = Block<PRIORS, BINS>::BYTES;
+    constexpr uint32_t BIN_AT = Block<PRIORS, BINS>::BIN_AT;
     constexpr int THREADS = Layout::THREADS;
     constexpr uint32_t VALID1 = Layout::VALID1;
     constexpr uint32_t VALID2 = Layout::VALID2;
@@ -490,18 +494,24 @@ void pamld_stream_kernel(StageArgs args) {
                 if(noise_margin > 0) {                                                // pamld.cpp:96
                     if(confidence_margin > 0) {                                       // pamld.cpp:99
                         if(hq_threshold > 0 && hq_distance >= hq_threshold) { r.qcfail = true; }
-                        if(live) {
+                        if(live && BINS) {
                             const unsigned long long fixed = static_cast<unsigned long long>(__double2ll_rn(confidence * 4503599627370496.0));      // 2^-52 fixed point, two limbs
                             bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 1, fixed & ((1ull << CONFIDENCE_LIMB_BITS) - 1));
                             bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 2, fixed >> CONFIDENCE_LIMB_BITS);
                         }
                     } else {
-                        if(live) { bin_add(lds_raw, bin_address, 0, 3, 1ull << 32); }           // low confidence count
+                        if(live) {                                                                // low confidence count
+                            if(BINS) { bin_add(lds_raw, bin_address, 0, 3, 1ull << 32); }
+                            else { atomicAdd(&args.stats[d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE], 1ull); }
+                        }
                         r.qcfail = true;
                         status = STATUS_LOW_CONFIDENCE;
                     }
                 } else {
-                    if(live) { bin_add(lds_raw, bin_address, 0, 3, 1ull); }                     // low conditional confidence count
+                    if(live) {                                                                    // low conditional confidence count
+                        if(BINS) { bin_add(lds_raw, bin_address, 0, 3, 1ull); }
+                        else { atomicAdd(&args.stats[d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN + FIELD_LOW_CONDITIONAL_CONFIDENCE], 1ull); }
+                    }
                     r.qcfail = true;
                     bin = 0;
                     bin_address = histogram_base + 8u * STAT_JOB_WORDS;
@@ -512,7 +522,8 @@ void pamld_stream_kernel(StageArgs args) {
                 }
                 const int32_t index_of_bin = bin == 0 ? 0 : identity_index ? static_cast<int32_t>(bin) : d.barcode_index[bin - 1];
                 // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86)
-                if(live) { bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 0, 1ull | (static_cast<unsigned long long>(bin > 0 ? distance : 0) << 32)); }
+                // (BINS = false: a classified read's count and distance are rebuilt from its record; bin 0 is counted here)
+                if(live && (BINS || bin == 0)) { bin_add(lds_raw, bin_address, r.qcfail ? 0u : 1u, 0, 1ull | (static_cast<unsigned long long>(bin > 0 ? distance : 0) << 32)); }
                 if(multiplexing) { r.channel = index_of_bin; }
                 out.index = index_of_bin;
                 out.distance = static_cast<uint8_t>(distance);
@@ -630,9 +641,9 @@ void pamld_stream_kernel(StageArgs args) {
             const uint32_t index = TAIL ? looked_up + 1u : looked_up >> 18;          // barcode_index[c] (past 8 nt: the identity, host checked)
             // the list of c — eight pairs of barcodes as plane words, then the weights of the bound — asked for together
             // with the factor rows: one wait for both
-            Quad record[Block<PRIORS>::QUADS];
+            Quad record[Block<PRIORS, BINS>::QUADS];
 #pragma unroll
-            for(int quad = 0; quad < Block<PRIORS>::QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
+            for(int quad = 0; quad < Block<PRIORS, BINS>::QUADS; ++quad) { record[quad] = *(LdsQuads)static_cast<uintptr_t>(block + 16u * quad); }
             auto record_word = [&](int w) { return record[w >> 2][w & 3]; };
             const uint32_t observed = TAIL ? sliced : (sliced | __builtin_amdgcn_alignbit(sliced, sliced, 16));      // up to 8 nt: against both halves of a word
             const uint32_t observed_high = lut::high_plane(observed);
@@ -768,7 +779,10 @@ void pamld_stream_kernel(StageArgs args) {
                 const uint32_t channel = (finished && multiplexing) ? index : incoming_channel;
                 __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
             }
-            if(finished && active) {
+            if(!BINS) {
+                // the counters of a codec this size are rebuilt from the records; only the rare count leaves from here
+                if(finished && active && !confident) { atomicAdd(&args.stats[d.stats_offset + static_cast<int64_t>(index) * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE], 1ull); }      // identity numbering: the index is the bin (count_results_supports)
+            } else if(finished && active) {
                 // Decoder<T>::classify then Classifier<T>::classify (decoder.h:68-76, classifier.h:78-86): the barcode's bin, in its block
                 const uint32_t half = qcfail ? 0u : 1u;
                 bin_add(lds_raw, block + BIN_AT, half, 0, 1ull | (static_cast<unsigned long long>(k) << 32));
@@ -817,7 +831,7 @@ void pamld_stream_kernel(StageArgs args) {
     __syncthreads();
     // the workgroup's bins into the counter buffer: one global atomic per field that is not zero
     outgoing_flush(args, histogram);
-    for(int i = threadIdx.x; i < (n_barcode + 1) * BIN_WORDS; i += THREADS) {
+    for(int i = threadIdx.x; i < (BINS ? n_barcode + 1 : 1) * BIN_WORDS; i += THREADS) {
         const int bin = i / BIN_WORDS;
         const int pass_filter = (i % BIN_WORDS) / 4;
         const int word = i % 4;
@@ -837,19 +851,19 @@ void pamld_stream_kernel(StageArgs args) {
     }
 }
 
-template <int L, int STATE, int WAVES, bool PRIORS>
+template <int L, int STATE, int WAVES, bool PRIORS, bool BINS = true>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES, PRIORS>, prepared)) { return status; }
-    typedef Shape<L, WAVES, PRIORS> Layout;
-    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES, PRIORS>), grid, dim3(Layout::THREADS), Layout::lds_bytes(n_barcode), stream, args);
+    if(const int status = allow_large_lds(&pamld_stream_kernel<L, STATE, WAVES, PRIORS, BINS>, prepared)) { return status; }
+    typedef Shape<L, WAVES, PRIORS, BINS> Layout;
+    hipLaunchKernelGGL((pamld_stream_kernel<L, STATE, WAVES, PRIORS, BINS>), grid, dim3(Layout::THREADS), Layout::lds_bytes(n_barcode), stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L, int WAVES, bool PRIORS>
+template <int L, int WAVES, bool PRIORS, bool BINS = true>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2, WAVES, PRIORS>(args, n_barcode, grid, stream); }
-    return args.input_flag ? launch_state<L, 1, WAVES, PRIORS>(args, n_barcode, grid, stream) : launch_state<L, 0, WAVES, PRIORS>(args, n_barcode, grid, stream);
+    if(!args.first_stage) { return launch_state<L, 2, WAVES, PRIORS, BINS>(args, n_barcode, grid, stream); }
+    return args.input_flag ? launch_state<L, 1, WAVES, PRIORS, BINS>(args, n_barcode, grid, stream) : launch_state<L, 0, WAVES, PRIORS, BINS>(args, n_barcode, grid, stream);
 }
 
 }  // namespace stream

@@ -98,7 +98,9 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // ... and where the streaming kernel takes the codec (5 to 10 nt), lists and scan are ONE launch, every
                 // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)
                 static const bool no_stream = std::getenv("PHQ_NO_STREAM") != nullptr;
-                const bool streamed = listed && !no_stream && host_decoder.use_lds_histogram && !args.defer_counters && pamld_stream_supports(host_decoder);
+                // (round 4: also a codec past the workgroup histogram — blocks without bins, counters from the records)
+                const bool streamed = listed && !no_stream && pamld_stream_supports(host_decoder) &&
+                                      (host_decoder.stream_binless ? args.defer_counters != 0 : (host_decoder.use_lds_histogram && !args.defer_counters));
                 // ... and a codec of a few barcodes of up to 8 nt has its own streaming kernel: every barcode scored in single
                 // precision, the fp64 products of the tiny kernel on the wave's ring (pamld_few.hip)
                 static const bool no_few = std::getenv("PHQ_NO_FEW") != nullptr;
