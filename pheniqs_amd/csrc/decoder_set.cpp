@@ -926,7 +926,7 @@ void DecoderSet::build_device_images() {
                                 near_table_of[s2] = tables.table;
                             }
                             d.cross_near_ready = usable == 2 ? 1 : 0;
-                            if(d.uniform_prior && d.cross_near_ready && length >= 8) {
+                            if(d.cross_near_ready && length >= 8) {          // (priors that differ: pass A of the same kernel, with the weights below)
                                 // the streaming kernel (pamld_cross_stream.hpp): per segment the lookup table and the blocks of
                                 // pamld_stream.hpp over the segment's words, one listed word per plane word
                                 const int32_t near_listed = near_list(length);

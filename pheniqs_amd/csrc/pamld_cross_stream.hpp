@@ -84,7 +84,13 @@ using lut::low_bit;
 
 // STATE: where a read's carried state comes from: 0 nothing to load, 1 the input flag bytes, 2 the status word of the
 // stage before
-template <int L, int STATE, int WAVES>
+// PRIORS (round 4): the combinations' priors differ (estimated priors, phq_adjust_prior).  Pass A then weighs the winner's row
+// and column by their own priors — the listed words' prior ratios per combination, 2 x 64 bytes a read from L2
+// (DevDecoder::cross_near_weight, as pamld_cross_near.hpp) —, bounds every other combination and what the lists leave out at
+// the largest prior over the winner's; pass C (drain_weighted below) takes the reads ONE of whose segments pass A found good,
+// scanning the other segment along a row of the prior matrix; a read with no good segment goes to the wave's worklist
+// segment for the weighted scan kernel (pamld_cross.hpp, WEIGHTED, as consumer).
+template <int L, int STATE, int WAVES, bool PRIORS = false>
 __global__ __launch_bounds__((Shape<L, WAVES>::THREADS)) __attribute__((amdgpu_waves_per_eu(WAVES / 4, (WAVES + 3) / 4)))
 void pamld_cross_stream_kernel(StageArgs args) {
     typedef Shape<L, WAVES> Layout;
@@ -249,8 +255,9 @@ void pamld_cross_stream_kernel(StageArgs args) {
     // pass A of ONE segment (pamld_stream.hpp): the word named by the lookup and the words listed with it scored through the
     // per read tables, every other word bounded by four distance classes — x_s = (listed + rest) / winner, in units of the
     // segment's all-match product
-    struct Score { float winner, matches, x_listed, x_rest; uint32_t k, high_mismatch, ordinal, mismatches; bool known; };
-    auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, uint32_t first_block, Score& out) {
+    typedef float Weights __attribute__((ext_vector_type(4)));
+    struct Score { float winner, matches, x_listed, x_rest, x_weighted; uint32_t k, high_mismatch, ordinal, mismatches; bool known; };
+    auto score_segment = [&](const uint32_t (&q)[G], uint32_t sliced, uint32_t looked_up, uint32_t first_block, Score& out, const Weights* ratio = nullptr) {
         const uint32_t ordinal = looked_up;                                    // the word's ordinal in its segment
         const bool known = ordinal != CROSS_STREAM_UNKNOWN;
         const uint32_t block = first_block + (known ? ordinal : 0u) * Layout::BLOCK_BYTES;
@@ -315,11 +322,13 @@ void pamld_cross_stream_kernel(StageArgs args) {
         float winner = first_group[0] * second_group[0];
         if(TAIL) { winner *= tail_factor(fields[0], rho); }
         float others = 0.0f;
+        float weighted = 0.0f;                 // PRIORS: the listed words by their prior over the combination's
 #pragma unroll
         for(int o = 1; o < LISTED; ++o) {
             float p = first_group[o] * second_group[o];
             if(TAIL) { p *= tail_factor(fields[o], rho); }
             others = o == 1 ? p : others + p;
+            if(PRIORS && ratio != nullptr) { weighted = __builtin_fmaf(ratio[o >> 2][o & 3], p, weighted); }
         }
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
         float rest = __uint_as_float(record_word(2 * LISTED)) * h[3];
@@ -333,6 +342,7 @@ void pamld_cross_stream_kernel(StageArgs args) {
         out.matches = everything_matches;
         out.x_listed = others * inverse_winner;
         out.x_rest = rest * inverse_winner;
+        out.x_weighted = weighted * inverse_winner;
         out.k = k;
         out.high_mismatch = high_mismatch ? 1u : 0u;
         out.ordinal = known ? ordinal : 0u;
@@ -598,6 +608,257 @@ void pamld_cross_stream_kernel(StageArgs args) {
         }
     };
 
+    // ---- pass C with priors that differ: a read ONE of whose segments pass A found good ------------------------------------
+    // mode = the segment that is scanned (0 or 1); the other one, g, named its word c_g by the lookup.  Every combination through
+    // c_g is exact: the scan weighs the words of the scanned segment by prior(c_g, .), a row of the prior matrix (or of its
+    // transpose) from L2.  Through the scan's winner w the listed words of segment g come by their prior ratios for the
+    // combination (c_g, w); what the lists leave out and every combination through neither is bounded at the largest prior over
+    // the winner's — pamld_cross.hpp's weighted certificate: that bound at most 4e-9 of the winner and taken at its midpoint,
+    // everything else at most 1.5e-3 of it, the argmax certain, no decision within 1e-8 of its threshold.  A read neither of
+    // whose segments is good never comes here: the tile loop hands it to the worklist for the three scan kernel.
+    auto drain_weighted = [&](int mode, uint32_t count) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): pass A's placeholder stores of these reads have left
+        const bool live = lane < count;
+        const uint32_t slot = live ? lane : 0u;
+        const uint32_t ring_at = rings_at + static_cast<uint32_t>(mode) * (Layout::RING_PLANES * RING * 4u) + slot * 4u;
+        const uint32_t state = *(LdsWords)static_cast<uintptr_t>(ring_at);
+        const int64_t i = static_cast<int64_t>(*(LdsWords)static_cast<uintptr_t>(ring_at + RING * 4u));
+        uint32_t code_row[ROW_WORDS];
+        uint32_t quality_row[ROW_WORDS];
+        {
+            const uint32_t* const code_at = reinterpret_cast<const uint32_t*>(args.base + i * (4 * ROW_WORDS));
+            const uint32_t* const quality_at = reinterpret_cast<const uint32_t*>(args.quality + i * (4 * ROW_WORDS));
+#pragma unroll
+            for(int w = 0; w < ROW_WORDS; ++w) { code_row[w] = code_at[w]; quality_row[w] = quality_at[w]; }
+        }
+        ReadState r;
+        if(STATE != 2) { r.qcfail = (state & 1u) != 0; r.channel = 0; }
+        else { r.qcfail = (state >> 31) != 0; r.channel = static_cast<int32_t>(state & 0x7fffffffu); }
+
+        // both segments: factor rows, bit planes, flags (as the uniform pass C)
+        uint32_t row_of[SEGMENTS][G], observed_of[SEGMENTS], outside_of[SEGMENTS], high_quality_of[SEGMENTS], quality_words_of[SEGMENTS][G];
+        bool strict_of[SEGMENTS];
+#pragma unroll
+        for(int s = 0; s < SEGMENTS; ++s) {
+            uint32_t code_words[G];
+            segment_words(code_row, s, code_words);
+            segment_words(quality_row, s, quality_words_of[s]);
+            observed_of[s] = 0; outside_of[s] = 0; high_quality_of[s] = 0;
+            bool strict = true;
+#pragma unroll
+            for(int w = 0; w < G; ++w) {
+                const uint32_t valid = Layout::valid(w);
+                const uint32_t x = code_words[w] & 0x0f0f0f0fu;
+                const uint32_t q8 = quality_words_of[s][w];
+                const uint32_t q7 = q8 & 0x7f7f7f7fu;
+                const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
+                const uint32_t strict_bits = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
+                const uint32_t strict_bytes = (strict_bits - (strict_bits >> 7)) | strict_bits;
+                const uint32_t nonzero = (q7 + 0x7f7f7f7fu) & 0x80808080u;
+                row_of[s][w] = (q7 & strict_bytes) | (nonzero & ~strict_bytes);
+                const uint32_t codes = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
+                observed_of[s] |= codes << (8 * w + 2);
+                const uint32_t high = ((q7 + high_quality_addend) | q8) & 0x80808080u & valid;
+                const uint32_t flags = gather(((~strict_bits & 0x80808080u & valid) >> 7) | (high >> 3));
+                outside_of[s] |= (flags & 0xfu) << (8 * w + 2);
+                high_quality_of[s] |= (flags >> 4) << (8 * w + 2);
+                strict = strict && (q8 & 0x80808080u) == 0;
+            }
+            strict_of[s] = strict && outside_of[s] == 0;
+        }
+        auto key_of = [&](int s) {
+            uint32_t key = 0;
+#pragma unroll
+            for(int w = 0; w < G; ++w) {
+                const uint32_t codes = (observed_of[s] >> (8 * w + 2)) & 0xffu;
+                if(w < 2) { key |= codes << (8 * w); }
+                else { key |= ((codes & ((1u << TAIL) - 1u)) << 16) | (((codes >> 4) & ((1u << TAIL) - 1u)) << (16 + TAIL)); }
+            }
+            return key;
+        };
+        // the good segment's word, by its lookup alone: the row of the prior matrix the scan runs along
+        const int scanned = mode, good = 1 - mode;
+        const uint32_t looked_up_good = static_cast<uint32_t>(nearest[good][key_of(good)]);
+        const uint32_t word_good = looked_up_good != CROSS_STREAM_UNKNOWN ? looked_up_good : 0u;
+        const float* const weights = (good == 0 ? d.cross_prior : d.cross_prior_transposed) + static_cast<size_t>(word_good) * CROSS_MAX_UNIQUE;
+        // the scan of the other segment, weighted: the block's maximum and sum, across blocks the running maximum and so on
+        // (pamld_cross.hpp), and the plain sum and the plain value of the weighted winner for the bound
+        float top = 0, rest = 0, second = 0, plain_sum = 0, top_plain = 0;
+        int best = -1;
+        uint32_t flags_of_best = 0;
+        {
+            float rho[RHO];
+#pragma unroll
+            for(int j = 0; j < RHO; ++j) {
+                if(j < L) { rho[j] = factor_single[(row_of[scanned][j >> 2] >> (8 * (j & 3))) & 0xffu].y; }
+                else { rho[j] = 1.0f; }
+            }
+            const uint32_t observed_high = lut::high_plane(observed_of[scanned]);
+            const uint32_t observed_low = lut::low_plane(observed_of[scanned]) | wave_bytes;
+            float unused[3][5];
+            build_tables(rho, unused);
+            const uint32_t words_at = scanned == 0 ? Layout::WORDS_AT : Layout::WORDS_AT + Layout::words_bytes(unique[0]);
+            const LdsQuads blocks = (LdsQuads)static_cast<uintptr_t>(words_at);
+            const LdsWords words = (LdsWords)static_cast<uintptr_t>(words_at);
+            const int limit = scanned == 0 ? unique[0] : unique[1];
+            const int n_blocks = (limit + 7) >> 3;
+            auto block_values = [&](int f, float (&p)[8], float (&plain)[8]) {
+                uint32_t w[16];
+#pragma unroll
+                for(int quad = 0; quad < 4; ++quad) {
+                    const Quad four = blocks[4 * f + quad];
+                    w[4 * quad] = four.x; w[4 * quad + 1] = four.y; w[4 * quad + 2] = four.z; w[4 * quad + 3] = four.w;
+                }
+                const Weights low_weights = *reinterpret_cast<const Weights*>(weights + 8 * f);
+                const Weights high_weights = *reinterpret_cast<const Weights*>(weights + 8 * f + 4);
+#pragma unroll
+                for(int k = 0; k < 8; ++k) {
+                    const uint32_t fields = (observed_low ^ w[k]) | (observed_high ^ w[8 + k]);
+                    plain[k] = entry(fields, 0, 0) * entry(fields, 1, 1);
+                    if(TAIL) { plain[k] *= tail_factor(fields, rho); }
+                    if(8 * f + k >= limit) { plain[k] = 0.0f; }
+                    p[k] = plain[k] * (k < 4 ? low_weights[k] : high_weights[k - 4]);       // the prior matrix is zero padded past the segment's words
+                }
+            };
+            float others_sum = 0, held_sum = 0, best_value = 0;
+            int best_block = -1;
+#pragma unroll 1
+            for(int f = 0; f < n_blocks; ++f) {
+                float p[8], plain[8];
+                block_values(f, p, plain);
+                plain_sum += ((plain[0] + plain[1]) + (plain[2] + plain[3])) + ((plain[4] + plain[5]) + (plain[6] + plain[7]));
+                const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
+                const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+                const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+                second = __builtin_amdgcn_fmed3f(best_value, block_max, second);
+                others_sum += takes_over ? held_sum : block_sum;
+                held_sum = takes_over ? block_sum : held_sum;
+                best_block = takes_over ? f : best_block;
+                best_value = takes_over ? block_max : best_value;
+            }
+            top = best_value;
+            rest = others_sum;
+            {
+                const int block = best_block < 0 ? 0 : best_block;
+                float p[8], plain[8];
+                block_values(block, p, plain);
+                int within = -1;
+                float q[8];
+#pragma unroll
+                for(int k = 7; k >= 0; --k) {
+                    const bool is_top = p[k] == best_value;
+                    within = is_top ? k : within;
+                    top_plain = is_top ? plain[k] : top_plain;
+                    q[k] = is_top ? 0.0f : p[k];
+                }
+                const float inner_rest = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                const float inner_second = fmaxf(fmaxf(fmaxf(q[0], q[1]), fmaxf(q[2], q[3])), fmaxf(fmaxf(q[4], q[5]), fmaxf(q[6], q[7])));
+                const bool crowded = held_sum - inner_rest >= 1.5f * best_value;         // the block's sum holds the maximum twice
+                second = fmaxf(second, crowded ? best_value : inner_second);
+                rest += crowded ? best_value : inner_rest;
+                if(best_block >= 0 && best_value > 0.0f && within >= 0) { best = 8 * block + within; }
+                const int at = 16 * (best < 0 ? 0 : best / 8) + (best < 0 ? 0 : best % 8);
+                flags_of_best = (observed_low ^ words[at]) | (observed_high ^ words[at + 8]);
+            }
+        }
+        bool certain = best >= 0 && top >= cross::SMALLEST_CERTAIN && second <= cross::RUNNER_UP * top && top_plain >= cross::SMALLEST_CERTAIN;
+        const uint32_t word_scanned = best < 0 ? 0u : static_cast<uint32_t>(best);
+        // the good segment again, its listed words by the prior ratios of the combination the scan has named
+        const uint32_t ordinal_of[SEGMENTS] = {good == 0 ? word_good : word_scanned, good == 0 ? word_scanned : word_good};
+        const size_t combination = static_cast<size_t>(ordinal_of[0]) * static_cast<size_t>(radix[0]) + static_cast<size_t>(ordinal_of[1]) * static_cast<size_t>(radix[1]);
+        Weights ratio[LISTED / 4];
+        {
+            const Weights* const from = reinterpret_cast<const Weights*>(d.cross_near_weight[good == 0 ? 1 : 0]) + combination * (CROSS_NEAR_WEIGHTS / 4);
+#pragma unroll
+            for(int quad = 0; quad < LISTED / 4; ++quad) { ratio[quad] = from[quad]; }
+        }
+        const float largest_over_own = reinterpret_cast<const float*>(d.cross_near_weight[1])[combination * CROSS_NEAR_WEIGHTS];      // its slot 0: the largest prior over the combination's
+        Score score;
+        score_segment(quality_words_of[good], observed_of[good], looked_up_good, blocks_at[good], score, ratio);
+        if(!segment_good(score, strict_of[good]) || !(score.x_weighted <= near::LISTED_MAX)) { certain = false; }
+        // everything in units of the winner prior(c) P_good(c_good) P_scanned(w)
+        const float inverse_top = __builtin_amdgcn_rcpf(top);
+        const float through_good = rest * inverse_top;                                            // exact: the weighted scan
+        const float through_scanned = score.x_weighted;                                           // the listed words of the good segment
+        const float plain_others = fmaxf(plain_sum - top_plain, 0.0f) * __builtin_amdgcn_rcpf(top_plain) * (1.0f + 1e-5f) + 2e-6f * plain_sum * __builtin_amdgcn_rcpf(top_plain);
+        const float bounded = largest_over_own * (score.x_rest + (score.x_listed + score.x_rest) * plain_others) * near::SLOP;
+        const float others_single = through_good + through_scanned + 0.5f * bounded;             // the bounded part at its midpoint
+
+        // the winner again in fp64 over both segments, its prior in fp64
+        double best_conditional = 1.0;
+        int distance = 0;
+        int hq_distance = 0;
+#pragma unroll
+        for(int s = 0; s < SEGMENTS; ++s) {
+            const uint32_t flags = ((s == scanned ? flags_of_best : score.mismatches) | outside_of[s]) & FULL_MASK;
+            distance += __popc(flags);
+            hq_distance += __popc(flags & high_quality_of[s]);
+#pragma unroll
+            for(int j = 0; j < L; ++j) {
+                const uint32_t k = (row_of[s][j >> 2] >> (8 * (j & 3))) & 0xffu;
+                best_conditional *= ((flags >> low_bit(j)) & 1u) ? factor_double[k][1] : factor_double[k][0];
+            }
+        }
+        bool defer = !certain;
+        {
+            const double prior = d.cross_prior_double[combination];
+            const double best_p = best_conditional * prior;
+            const double others_p = static_cast<double>(others_single) * best_p;
+            const double total = (best_p + others_p) + d.adjusted_noise_probability;                // pamld.cpp:61-86
+            double confidence = best_p / total;                                                     // pamld.cpp:92
+            const double noise_margin = best_conditional - d.random_barcode_probability;
+            const double confidence_margin = confidence - confidence_threshold;
+            const bool noise_clear = fabs(noise_margin) > 1e-9 * d.random_barcode_probability;
+            const bool is_noise = noise_margin <= 0;
+            if(!noise_clear || !(prior > 0)) { defer = true; }
+            if(!is_noise) {
+                if(!(bounded <= static_cast<float>(cross::ELSEWHERE_WEIGHTED)) || !(others_single <= static_cast<float>(cross::DOMINANCE_WEIGHTED)) || !(fabs(confidence_margin) > 1e-8)) { defer = true; }
+            } else if(!(others_single < 0.5f)) { defer = true; }                                   // the argmax: nothing else comes near the winner
+            if(!defer && live) {
+                int bin = static_cast<int>(combination) + 1;                                       // cross_ordinal and the index are the identity (host checked)
+                uint8_t status = STATUS_PASS;
+                unsigned long long* const bin_words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN;
+                if(!is_noise) {                                                       // pamld.cpp:96
+                    if(confidence_margin > 0) {                                       // pamld.cpp:99
+                        if(hq_threshold > 0 && hq_distance >= hq_threshold) { r.qcfail = true; }
+                    } else {
+                        atomicAdd(&bin_words[FIELD_LOW_CONFIDENCE], 1ull);
+                        r.qcfail = true;
+                        status = STATUS_LOW_CONFIDENCE;
+                    }
+                } else {
+                    atomicAdd(&bin_words[FIELD_LOW_CONDITIONAL_CONFIDENCE], 1ull);
+                    r.qcfail = true;
+                    bin = 0;
+                    distance = 0;
+                    hq_distance = 0;
+                    confidence = 0;
+                    status = STATUS_NOISE;
+                    __hip_atomic_fetch_add((__attribute__((address_space(3))) unsigned long long*)static_cast<uintptr_t>(histogram_at + 8u * (STAT_JOB_WORDS + FIELD_COUNT)), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if(multiplexing) { r.channel = bin > 0 ? d.barcode_index[bin - 1] : 0; }
+                DevResult out;
+                out.index = bin > 0 ? d.barcode_index[bin - 1] : 0;
+                out.distance = static_cast<uint8_t>(distance > 255 ? 255 : distance);
+                out.hq_distance = static_cast<uint8_t>(hq_distance > 255 ? 255 : hq_distance);
+                out.status = status;
+                out.qcfail = r.qcfail ? 1 : 0;
+                out.confidence = confidence;
+                stream_result(&args.result[i], out);
+                stream_read_state(args, i, r);
+            }
+        }
+        const unsigned long long handed_on = __ballot(live && defer);
+        if(handed_on) {
+            if(live && defer) { segment[segment_count + __popcll(handed_on & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i); }
+            segment_count += static_cast<uint32_t>(__popcll(handed_on));
+        }
+        if(last_stage) {
+            outgoing_pass += static_cast<uint32_t>(__popcll(__ballot(live && !defer && !r.qcfail)));
+            outgoing_fail += static_cast<uint32_t>(__popcll(__ballot(live && !defer && r.qcfail)));
+        }
+    };
+
     // ---- the wave's loop over its tiles: pass A, then the ring (software pipeline of pamld_stream.hpp) ------------------
     struct Keyed { uint32_t quality[ROW_WORDS]; uint32_t state; uint32_t sliced[SEGMENTS]; uint32_t looked_up[SEGMENTS]; bool strict[SEGMENTS]; };
     auto key_and_look_up = [&](const Inputs& in, Keyed& to) {
@@ -668,16 +929,27 @@ void pamld_cross_stream_kernel(StageArgs args) {
             else { incoming_qcfail = (state_in >> 31) != 0; incoming_channel = state_in & 0x7fffffffu; }
 
             // per segment: the winner over the segment's all-match product, the listed and the bounded part of x_s
-            float winner_of[SEGMENTS], x_listed_of[SEGMENTS], x_rest_of[SEGMENTS], matches_of[SEGMENTS];
+            float winner_of[SEGMENTS], x_listed_of[SEGMENTS], x_rest_of[SEGMENTS], matches_of[SEGMENTS], x_weighted_of[SEGMENTS];
             uint32_t k_of[SEGMENTS], hq_of[SEGMENTS], ordinal_of[SEGMENTS];
             bool good_of[SEGMENTS];
             bool usable = true;
+            // PRIORS: the prior ratios of this read's combination, along its row (segment 1's listed words) and its column
+            Weights along_row[LISTED / 4], along_column[LISTED / 4];
+            if(PRIORS) {
+                const uint32_t named0 = looked_up_of[0] != CROSS_STREAM_UNKNOWN ? looked_up_of[0] : 0u, named1 = looked_up_of[1] != CROSS_STREAM_UNKNOWN ? looked_up_of[1] : 0u;
+                const size_t combination = static_cast<size_t>(named0) * static_cast<size_t>(radix[0]) + static_cast<size_t>(named1) * static_cast<size_t>(radix[1]);
+                const Weights* const row = reinterpret_cast<const Weights*>(d.cross_near_weight[0]) + combination * (CROSS_NEAR_WEIGHTS / 4);
+                const Weights* const column = reinterpret_cast<const Weights*>(d.cross_near_weight[1]) + combination * (CROSS_NEAR_WEIGHTS / 4);
+#pragma unroll
+                for(int quad = 0; quad < LISTED / 4; ++quad) { along_column[quad] = column[quad]; along_row[quad] = row[quad]; }
+            }
 #pragma unroll
             for(int s = 0; s < SEGMENTS; ++s) {
                 uint32_t q[G];
                 segment_words(quality_in, s, q);
                 Score score;
-                score_segment(q, sliced_of[s], looked_up_of[s], blocks_at[s], score);
+                score_segment(q, sliced_of[s], looked_up_of[s], blocks_at[s], score, PRIORS ? (s == 0 ? along_column : along_row) : nullptr);
+                x_weighted_of[s] = score.x_weighted;
                 winner_of[s] = score.winner;
                 matches_of[s] = score.matches;
                 x_listed_of[s] = score.x_listed;
@@ -692,9 +964,12 @@ void pamld_cross_stream_kernel(StageArgs args) {
             // both segments together: others / winner = x_0 + x_1 + x_0 x_1, between its listed part and listed + bound
             const float winner_probability = (winner_of[0] * matches_of[0]) * (winner_of[1] * matches_of[1]);      // P(r|c)
             const float upper0 = x_listed_of[0] + x_rest_of[0], upper1 = x_listed_of[1] + x_rest_of[1];
-            const float listed = x_listed_of[0] + x_listed_of[1] + x_listed_of[0] * x_listed_of[1];
-            const float x_rest = (upper0 + upper1 + upper0 * upper1 - listed) * near::SLOP;
-            const float x_low = __builtin_fmaf(noise_over_prior, __builtin_amdgcn_rcpf(winner_probability), listed);
+            // PRIORS: the winner's row and column by their own priors; the other combinations and what the lists leave out of the row
+            // and the column by the largest prior over the winner's (along_column[0].x), as pamld_cross_near.hpp
+            const float listed = PRIORS ? x_weighted_of[0] + x_weighted_of[1] : x_listed_of[0] + x_listed_of[1] + x_listed_of[0] * x_listed_of[1];
+            const float x_rest = PRIORS ? along_column[0].x * (upper0 * upper1 + x_rest_of[0] + x_rest_of[1]) * near::SLOP
+                                        : (upper0 + upper1 + upper0 * upper1 - listed) * near::SLOP;
+            const float x_low = __builtin_fmaf(PRIORS ? along_row[0].x : noise_over_prior, __builtin_amdgcn_rcpf(winner_probability), listed);
             // the posterior is taken WITHOUT what was only bounded: 1 - y, y = x / (1 + x) = x - x^2 + x^3 (x at most 3e-4)
             const float y = x_low * __builtin_fmaf(-x_low, 1.0f - x_low, 1.0f);
             const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
@@ -723,9 +998,17 @@ void pamld_cross_stream_kernel(StageArgs args) {
                 // which ring: a segment pass A found good is not scanned again
                 const bool left = active && !finished;
                 const bool bad0 = !good_of[0], bad1 = !good_of[1];
-                deferred_to[2] = __ballot(left && bad0 && bad1);
+                const unsigned long long both = __ballot(left && bad0 && bad1);
                 deferred_to[1] = __ballot(left && !bad0 && bad1);
                 deferred_to[0] = __ballot(left && !bad1);
+                if(PRIORS) {
+                    // priors that differ: pass C takes a read one of whose segments is good (and, of a read both of whose are,
+                    // scans segment 0); one with neither goes to the worklist for the three scan kernel
+                    if(both) {
+                        if((both >> lane) & 1ull) { segment[segment_count + static_cast<uint32_t>(__popcll(both & ((1ull << lane) - 1ull)))] = static_cast<uint32_t>(read_ordinal); }
+                        segment_count += static_cast<uint32_t>(__popcll(both));
+                    }
+                } else { deferred_to[2] = both; }
             }
             if(last_stage) {
                 outgoing_pass += static_cast<uint32_t>(__popcll(__ballot(active && finished && !qcfail)));
@@ -746,7 +1029,8 @@ void pamld_cross_stream_kernel(StageArgs args) {
             const bool due2 = ring_count[2] + arriving[2] > RING || (!more && ring_count[2] > 0);
             if(__builtin_expect(!(due0 || due1 || due2), 1)) { break; }      // the scan is the cold path: what it spills, it spills there
             const int m = due0 ? 0 : due1 ? 1 : 2;
-            drain(m, m == 0 ? ring_count[0] : m == 1 ? ring_count[1] : ring_count[2]);
+            if(PRIORS) { drain_weighted(m, m == 0 ? ring_count[0] : ring_count[1]); }
+            else { drain(m, m == 0 ? ring_count[0] : m == 1 ? ring_count[1] : ring_count[2]); }
             ring_count[0] = m == 0 ? 0u : ring_count[0];
             ring_count[1] = m == 1 ? 0u : ring_count[1];
             ring_count[2] = m == 2 ? 0u : ring_count[2];
@@ -774,19 +1058,19 @@ void pamld_cross_stream_kernel(StageArgs args) {
     histogram_flush(args, d, histogram);
 }
 
-template <int L, int STATE, int WAVES>
+template <int L, int STATE, int WAVES, bool PRIORS = false>
 int launch_state(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream) {
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_cross_stream_kernel<L, STATE, WAVES>, prepared)) { return status; }
+    if(const int status = allow_large_lds(&pamld_cross_stream_kernel<L, STATE, WAVES, PRIORS>, prepared)) { return status; }
     typedef Shape<L, WAVES> Layout;
-    hipLaunchKernelGGL((pamld_cross_stream_kernel<L, STATE, WAVES>), grid, dim3(Layout::THREADS), Layout::lds_bytes(host_decoder.cross_unique[0], host_decoder.cross_unique[1]), stream, args);
+    hipLaunchKernelGGL((pamld_cross_stream_kernel<L, STATE, WAVES, PRIORS>), grid, dim3(Layout::THREADS), Layout::lds_bytes(host_decoder.cross_unique[0], host_decoder.cross_unique[1]), stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L, int WAVES>
+template <int L, int WAVES, bool PRIORS = false>
 int launch_one(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2, WAVES>(args, host_decoder, grid, stream); }
-    return args.input_flag ? launch_state<L, 1, WAVES>(args, host_decoder, grid, stream) : launch_state<L, 0, WAVES>(args, host_decoder, grid, stream);
+    if(!args.first_stage) { return launch_state<L, 2, WAVES, PRIORS>(args, host_decoder, grid, stream); }
+    return args.input_flag ? launch_state<L, 1, WAVES, PRIORS>(args, host_decoder, grid, stream) : launch_state<L, 0, WAVES, PRIORS>(args, host_decoder, grid, stream);
 }
 
 }  // namespace cross_stream

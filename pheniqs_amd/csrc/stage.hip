@@ -149,6 +149,15 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     trace_worklist(few ? "the few barcode kernel" : cross_streamed ? "the streaming kernel of the set" : "the streaming kernel", producer, segment_grid.x, s);
                     StageArgs consumer = producer;
                     consumer.worklist_role = 2;
+                    if(cross_streamed && !host_decoder.uniform_prior) {
+                        // priors that differ: the streaming kernel ran pass A alone; the weighted scans take the wave's segments
+                        StageArgs middle = consumer;
+                        middle.worklist_segments = static_cast<int32_t>(segment_grid.x);
+                        Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, "pamld_cross_kernel (weighted, consumer)");
+                        status = launch_pamld_cross(middle, host_decoder, segment_grid, histogram_bytes, s);
+                        if(status != 0) { return status; }
+                        trace_worklist("the product form", producer, segment_grid.x, s);
+                    }
                     if(pamld_exact_supports(host_decoder)) {
                         // several lanes per read where the set is one the lane parallel tier takes (pamld_exact_lanes.hip)
                         Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
