@@ -460,7 +460,9 @@ def main():
                          "kernel": m["dominant"], "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches_per_step"],
                          "algorithmic_bytes_per_read": w.bytes_per_read,
                          "step_achieved": m["step_GBs"], "step_frac": m["step_GBs"] / HBM_PEAK_GBS,
-                         "measured_copy_GBs": measured_copy_bandwidth(torch, device) if world == 1 else None,
+                         # the node's practical ceiling: the library's own 16 bytes a lane streaming copy (the guide: 6.3 TB/s), and torch's copy kernel
+                         "measured_copy_GBs": capi.copy_bandwidth(local_rank) if world == 1 else None,
+                         "measured_copy_GBs_torch": measured_copy_bandwidth(torch, device) if world == 1 else None,
                          "all_kernels_ms_per_step": {name: v["ms"] / args.steps for name, v in m["kernels"].items()},
                          "chain": m["chain"],
                          "classify_ms_per_step": m["classify_ms"]},

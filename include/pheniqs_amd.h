@@ -243,6 +243,9 @@ int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNE
  * it: *chain_json = [{"decoder": k, "kernel": "pamld_stream_kernel", "kind": PHQ_KERNEL_*, "ms": t}, ...] (release with
  * phq_free_string).  Forgets the spans like phq_profile_collect; call one or the other after a batch. */
 int phq_profile_chain(phq_decoder_set* set, char** chain_json);
+/* The node's practical HBM ceiling next to the 8 TB/s rooflines are priced against: a plain streaming copy of `bytes` (a
+ * multiple of 16), 16 bytes a lane, `repeats` times; *gigabytes_per_second counts bytes read + bytes written. */
+int phq_copy_bandwidth(int32_t device, uint64_t bytes, int32_t repeats, double* gigabytes_per_second);
 
 /* Pinned host memory for batches handed to phq_classify_host (hipHostMalloc / hipHostFree). */
 int phq_host_alloc(uint64_t bytes, void** pointer);

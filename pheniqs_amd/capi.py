@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -105,6 +105,7 @@ def load_library():
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
     L.phq_profile_chain.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
+    L.phq_copy_bandwidth.argtypes = [I32, U64, I32, ctypes.POINTER(ctypes.c_double)]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_load_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
@@ -136,6 +137,15 @@ def source_id() -> str:
     for word in words:
         digest.update(open(os.path.join(csrc, word), "rb").read())
     return digest.hexdigest()
+
+
+def copy_bandwidth(device: int = 0, gigabytes: float = 1.0, repeats: int = 10) -> float:
+    """phq_copy_bandwidth: GB/s (read + written) of a plain 16 bytes a lane streaming copy on the device."""
+    out = ctypes.c_double(0)
+    status = load_library().phq_copy_bandwidth(device, int(gigabytes * (1 << 30)) // 16 * 16, repeats, ctypes.byref(out))
+    if status != 0:
+        raise PheniqsError(status, "phq_copy_bandwidth")
+    return out.value
 
 
 def compile_job(job: Dict[str, Any]) -> Dict[str, Any]:

@@ -220,6 +220,16 @@ int phq_profile_collect(phq_decoder_set* set, double* milliseconds, int64_t* lau
     });
 }
 
+int phq_copy_bandwidth(int32_t device, uint64_t bytes, int32_t repeats, double* gigabytes_per_second) {
+    return guarded(nullptr, [&]() {
+        require(gigabytes_per_second, "gigabytes_per_second");
+        *gigabytes_per_second = 0;
+        if(bytes < 16 || bytes % 16 != 0 || repeats < 1) { throw phq::InternalError("copy probe: a multiple of 16 bytes, at least one repeat"); }
+        const int status = phq::copy_bandwidth(device, static_cast<size_t>(bytes), repeats, gigabytes_per_second);
+        if(status != 0) { throw phq::InternalError("copy probe: HIP error " + std::to_string(status)); }
+    });
+}
+
 int phq_profile_chain(phq_decoder_set* set, char** chain_json) {
     if(chain_json != nullptr) { *chain_json = nullptr; }
     return guarded(set, [&]() {

@@ -129,6 +129,7 @@ private:
 };
 
 void* host_alloc(size_t bytes);   // pinned host memory
+int copy_bandwidth(int device, size_t bytes, int repeats, double* gigabytes_per_second);      // copy_probe.hip: a hipError_t value
 void host_free(void* pointer);
 
 // the per type accumulators of one read (read.h:152-165) from its result records; shared with the transcoder

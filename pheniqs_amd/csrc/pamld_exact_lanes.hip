@@ -27,6 +27,12 @@
 
 #include "kernel_common.hpp"
 
+#ifndef PHQ_WEIGHTED_LANES
+#define PHQ_WEIGHTED_LANES 8
+#endif
+#ifndef PHQ_WEIGHTED_CAP
+#define PHQ_WEIGHTED_CAP 48
+#endif
 #ifndef PHQ_WEIGHTED_PAIRS
 #define PHQ_WEIGHTED_PAIRS 256
 #endif
@@ -39,7 +45,7 @@ namespace lanes {
 
 constexpr int WAVES = 4;
 constexpr int THREADS = 64 * WAVES;
-constexpr int WEIGHTED_CAP = 48;           // listed words of a segment in the weighted form
+constexpr int WEIGHTED_CAP = PHQ_WEIGHTED_CAP;           // listed words of a segment in the weighted form
 constexpr int CAP = 32;                    // listed words of a segment a read may bring to the literal walk
 constexpr int GROUP_MAX = EXACT_GROUP_MAX;
 
@@ -742,7 +748,7 @@ int launch_groups(const StageArgs& args, const DevDecoder& host_decoder, dim3 gr
 
 template <int G>
 int launch_weighted_form(const StageArgs& args, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    hipLaunchKernelGGL((pamld_exact_lanes_kernel<G, 2, false, CROSS_MAX_UNIQUE, 8, true>), grid, dim3(THREADS), histogram_bytes, stream, args);
+    hipLaunchKernelGGL((pamld_exact_lanes_kernel<G, 2, false, CROSS_MAX_UNIQUE, PHQ_WEIGHTED_LANES, true>), grid, dim3(THREADS), histogram_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 inline int launch_weighted(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
@@ -778,7 +784,7 @@ int launch_pamld_exact_lanes(const StageArgs& args, const DevDecoder& host_decod
     // about 1 % of the reads reach this tier: segments are grouped until a wave can expect a few iterations' worth of them
     const bool many = host_decoder.cross_segments == 1 && host_decoder.cross_unique[0] > CROSS_MAX_UNIQUE;
     const bool weighted = host_decoder.cross_segments == 2 && !host_decoder.uniform_prior;
-    const int reads = 64 / ((many || weighted) ? lanes::LONG_LANES : lanes::SHORT_LANES);
+    const int reads = 64 / (many ? lanes::LONG_LANES : weighted ? PHQ_WEIGHTED_LANES : lanes::SHORT_LANES);
     const double expected_per_segment = 0.01 * static_cast<double>(args.n_read) / static_cast<double>(std::max(1u, grid.x));
     const int group = expected_per_segment >= 4.0 * reads ? 1 : static_cast<int>(4.0 * reads / std::max(expected_per_segment, 0.25)) + 1;
     grouped.worklist_group = std::min(lanes::GROUP_MAX, std::max(1, group));
