@@ -246,6 +246,10 @@ int phq_profile_chain(phq_decoder_set* set, char** chain_json);
 /* The node's practical HBM ceiling next to the 8 TB/s rooflines are priced against: a plain streaming copy of `bytes` (a
  * multiple of 16), 16 bytes a lane, `repeats` times; *gigabytes_per_second counts bytes read + bytes written. */
 int phq_copy_bandwidth(int32_t device, uint64_t bytes, int32_t repeats, double* gigabytes_per_second);
+/* Which way the transcoding calls of this process went, summed since it started: counters[0] = rounds whose FASTQ text was
+ * decoded on the device, counters[1] = the reads of those rounds, counters[2] = bytes of output records assembled on the
+ * device, counters[3] = runs the device path handed to the host reader part way (an input out of the ordinary). */
+int phq_device_path_counters(uint64_t counters[4]);
 
 /* Pinned host memory for batches handed to phq_classify_host (hipHostMalloc / hipHostFree). */
 int phq_host_alloc(uint64_t bytes, void** pointer);

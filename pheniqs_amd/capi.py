@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_device_path_counters", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -106,6 +106,7 @@ def load_library():
     L.phq_profile_collect.argtypes = [P, P, P]
     L.phq_profile_chain.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_copy_bandwidth.argtypes = [I32, U64, I32, ctypes.POINTER(ctypes.c_double)]
+    L.phq_device_path_counters.argtypes = [ctypes.POINTER(U64)]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_load_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
@@ -146,6 +147,15 @@ def copy_bandwidth(device: int = 0, gigabytes: float = 1.0, repeats: int = 10) -
     if status != 0:
         raise PheniqsError(status, "phq_copy_bandwidth")
     return out.value
+
+
+def device_path_counters() -> Dict[str, int]:
+    """phq_device_path_counters: what the transcoding calls of this process did on the device so far."""
+    out = (ctypes.c_uint64 * 4)()
+    status = load_library().phq_device_path_counters(out)
+    if status != 0:
+        raise PheniqsError(status, "phq_device_path_counters")
+    return {"rounds": int(out[0]), "reads": int(out[1]), "record_bytes": int(out[2]), "resumed": int(out[3])}
 
 
 def compile_job(job: Dict[str, Any]) -> Dict[str, Any]:

@@ -230,6 +230,13 @@ int phq_copy_bandwidth(int32_t device, uint64_t bytes, int32_t repeats, double* 
     });
 }
 
+int phq_device_path_counters(uint64_t counters[4]) {
+    return guarded(nullptr, [&]() {
+        require(counters, "counters");
+        phq::device_path_counters(counters);
+    });
+}
+
 int phq_profile_chain(phq_decoder_set* set, char** chain_json) {
     if(chain_json != nullptr) { *chain_json = nullptr; }
     return guarded(set, [&]() {

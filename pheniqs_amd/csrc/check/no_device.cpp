@@ -2,6 +2,7 @@
 // these entry points of the kernel translation units (stage.hip, fastq_device.hip) only have to link.
 #include "../device_types.hpp"
 #include "../fastq_device.hpp"
+#include "../record_device.hpp"
 
 namespace phq {
 int launch_stage(const StageArgs&, const DevDecoder&, int32_t, int32_t, void*, LaunchTimer*) { return 100; }      // hipErrorNoDevice
@@ -10,4 +11,6 @@ bool stage_uses_worklist(const DevDecoder&, int32_t) { return false; }
 int fastq_index(const FastqFeedChunk&, void*) { return 100; }
 int fastq_plan_round(const FastqFeedChunk*, int32_t, const int32_t*, uint32_t, FastqRound*, void*) { return 100; }
 int fastq_decode(const FastqPlan&, const FastqFeedChunk*, uint32_t, int64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*, unsigned long long*, uint8_t*, uint32_t*, uint32_t*, void*) { return 100; }
+int record_sizes(const FastqPlan&, const FastqFeedChunk*, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, void*) { return 100; }
+int record_write(const FastqPlan&, const FastqFeedChunk*, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, void*) { return 100; }
 }

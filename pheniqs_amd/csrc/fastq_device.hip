@@ -1,14 +1,11 @@
 // FASTQ text -> decoder planes on the device: see fastq_device.hpp.
 #include <hip/hip_runtime.h>
 
-#include "fastq_device.hpp"
-#include "job.hpp"
+#include "fastq_device_inner.hpp"
 
 namespace phq {
 
 namespace {
-
-constexpr int TILE_THREADS = 256;             // 16 bytes per thread: a workgroup indexes 4 KiB of text
 
 // bit 7 of every byte of x that is '\n' (exact per byte: no borrow runs from one byte into the next)
 __device__ __forceinline__ uint32_t newline_bytes(uint32_t x) {
@@ -113,77 +110,6 @@ __global__ void fastq_plan_kernel(PlanArgs args) {
     args.round->irregular = irregular;
 }
 
-struct DecodeArgs {
-    FastqPlan plan;
-    FastqFeedChunk chunk[FASTQ_MAX_FEED];
-    uint32_t n;
-    int64_t capacity;
-    uint8_t* base_planes;
-    uint8_t* quality_planes;
-    uint8_t* flag;
-    uint32_t* irregular;
-    unsigned long long* flagged;
-    uint8_t* keep;                  // a plan that filters: 1 = the read is decoded
-    uint32_t* keep_block;           // ... kept reads per workgroup of 256 reads, then their exclusive prefix sums
-    uint8_t bam_of_ascii[256];
-    uint8_t complement_of_bam[16];
-};
-
-// where read r's segments sit in their files' chunks, and what the pull loop would make of it
-struct Located {
-    uint32_t sequence_at[FASTQ_MAX_FEED];
-    uint32_t quality_at[FASTQ_MAX_FEED];
-    uint32_t length[FASTQ_MAX_FEED];
-    bool odd;                       // framing or name sync out of the ordinary: the host reader takes the run
-    bool filtered;                  // the Illumina filter flag of the leading segment
-    bool dropped;                   // the pre-filters of the pull loop drop the read (transcode.h:193-205)
-};
-
-__device__ __forceinline__ void locate(const DecodeArgs& args, uint32_t r, Located& to) {
-    const FastqPlan& plan = args.plan;
-    to.odd = false;
-    to.filtered = false;
-    to.dropped = false;
-    uint32_t first_name_at = 0;
-    uint32_t first_name_size = 0;
-    const uint8_t* first_raw = nullptr;
-    for(int s = 0; s < plan.n_segment; ++s) {
-        const int f = plan.segment_feed[s];
-        const uint32_t record = r * static_cast<uint32_t>(plan.feed_resolution[f]) + static_cast<uint32_t>(plan.segment_slot[s]);
-        const uint8_t* const raw = args.chunk[f].raw;
-        const uint32_t* const newline = args.chunk[f].newline + 4u * record;
-        const uint32_t header_at = record == 0 ? 0u : newline[-1] + 1u;
-        const uint32_t header_end = newline[0];
-        const uint32_t sequence_end = newline[1];
-        const uint32_t separator_end = newline[2];
-        const uint32_t quality_end = newline[3];
-        to.sequence_at[s] = header_end + 1u;
-        to.quality_at[s] = separator_end + 1u;
-        to.length[s] = sequence_end - to.sequence_at[s];
-        // the framing of a record (fastq.h:427-440), nothing the host reader would have to tolerate or report
-        to.odd = to.odd || header_end == header_at || raw[header_at] != '@' || separator_end == sequence_end + 1u || raw[sequence_end + 1u] != '+' ||
-                 quality_end - to.quality_at[s] != to.length[s] || raw[header_end - 1u] == '\r' || (to.length[s] > 0 && raw[sequence_end - 1u] == '\r') ||
-                 raw[separator_end - 1u] == '\r' || (to.length[s] > 0 && raw[quality_end - 1u] == '\r');
-        // the name up to the first blank (kseq), the same in every segment (read.h:253-264)
-        uint32_t name_end = header_at + 1u;
-        while(name_end < header_end && raw[name_end] != ' ' && raw[name_end] != '\t') { ++name_end; }
-        if(s == 0) { first_name_at = header_at + 1u; first_name_size = name_end - header_at - 1u; first_raw = raw; }
-        else {
-            bool same = name_end - header_at - 1u == first_name_size;
-            for(uint32_t k = 0; same && k < first_name_size; ++k) { same = raw[header_at + 1u + k] == first_raw[first_name_at + k]; }
-            to.odd = to.odd || !same;
-        }
-        // the Illumina comment `segment:filtered:control:barcode` of the leading segment (fastq.h:253-285)
-        if(s == plan.leader_segment && plan.illumina_comment) {
-            uint32_t p = name_end < header_end ? name_end + 1u : header_end;
-            while(p < header_end && raw[p] != ':') { ++p; }
-            if(p + 1u < header_end) { to.filtered = raw[p + 1u] == 'Y'; }
-        }
-        if(s >= 1 && static_cast<int32_t>(to.length[s]) < plan.min_length[s]) { to.dropped = true; }      // filter_input, transcode.h:193-200
-    }
-    if(plan.filter_incoming_qc_fail && to.filtered) { to.dropped = true; }                                  // transcode.h:205
-}
-
 __device__ __forceinline__ void count_flagged(const DecodeArgs& args, bool filtered) {
     const unsigned long long marked = __ballot(filtered);
     if(marked && (threadIdx.x & 63) == static_cast<unsigned>(__ffsll(static_cast<long long>(marked)) - 1)) { atomicAdd(args.flagged, static_cast<unsigned long long>(__popcll(marked))); }
@@ -199,7 +125,7 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_keep_kernel(DecodeArgs arg
     bool filtered = false;
     if(r < args.n) {
         Located at;
-        locate(args, r, at);
+        locate(args.plan, args.chunk, r, at);
         if(at.odd) { atomicOr(args.irregular, 1u); }
         keep = !at.dropped;
         filtered = at.filtered;
@@ -218,21 +144,12 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
     const FastqPlan& plan = args.plan;
     __shared__ uint32_t wave_kept[TILE_THREADS / 64];
     const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
-    const bool present = r < args.n;
-    uint32_t row = r;
-    bool wanted = present;
-    if(FILTER) {
-        wanted = present && args.keep[r] != 0;
-        const unsigned long long kept = __ballot(wanted);
-        if((threadIdx.x & 63) == 0) { wave_kept[threadIdx.x >> 6] = static_cast<uint32_t>(__popcll(kept)); }
-        __syncthreads();
-        row = args.keep_block[blockIdx.x] + static_cast<uint32_t>(__popcll(kept & ((1ull << (threadIdx.x & 63)) - 1ull)));
-        for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { row += wave_kept[w]; }
-    }
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
     bool filtered = false;
     if(wanted) {
         Located at;
-        locate(args, r, at);
+        locate(args.plan, args.chunk, r, at);
         filtered = at.filtered;
         if(!FILTER && at.odd) { atomicOr(args.irregular, 1u); }
         // Rule::apply of every decoder into its plane (transform.h:142-169), zero filled past what the tokens bring
@@ -249,14 +166,8 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
             for(int t = d.first_token; t < d.first_token + d.n_token; ++t) {
                 const FastqToken& token = plan.token[t];
                 const int32_t from_length = static_cast<int32_t>(at.length[token.segment]);
-                int32_t start = token.start;                                   // Token::absolute_start, transform.h:73-80
-                if(start < 0) { start = from_length + start; start = start < 0 ? 0 : start; }
-                else if(start > from_length) { start = 0; }
-                int32_t end = from_length;                                     // Token::absolute_end, transform.h:65-72
-                if(token.end_terminated) {
-                    if(token.end < 0) { end = from_length + token.end; end = end < 0 ? 0 : end; }
-                    else { end = token.end > from_length ? from_length : token.end; }
-                }
+                int32_t start, end;
+                token_range(token.start, token.end, token.end_terminated, from_length, start, end);
                 const int32_t size = end - start;
                 if(size <= 0 || at.odd) { continue; }
                 int32_t& done = filled[token.output_segment];

@@ -1,0 +1,437 @@
+// Output records assembled on the device: see record_device.hpp.
+#include <hip/hip_runtime.h>
+
+#include "fastq_device_inner.hpp"
+#include "record_device.hpp"
+
+namespace phq {
+
+namespace {
+
+struct RecordArgs {
+    FastqPlan plan;
+    FastqFeedChunk chunk[FASTQ_MAX_FEED];
+    uint32_t n;
+    int64_t capacity;
+    const uint8_t* base_planes;
+    const uint8_t* quality_planes;
+    const uint8_t* keep;
+    const uint32_t* keep_block;
+    RecordRound round;
+};
+static_assert(sizeof(RecordArgs) <= 4096, "kernel arguments");
+
+// the bytes of a record: counted (pass 1) or stored (pass 2)
+template <bool WRITE>
+struct Out {
+    char* at;
+    uint32_t count;
+    __device__ __forceinline__ void put(char c) { if(WRITE) { *at++ = c; } else { ++count; } }
+    __device__ __forceinline__ void room(uint32_t bytes) { count += bytes; }      // pass 1: bytes whose values do not matter
+    __device__ __forceinline__ void literal(const char* text) { for(; *text; ++text) { put(*text); } }
+    __device__ __forceinline__ void bytes(const char* from, uint32_t size) {
+        if(WRITE) { for(uint32_t i = 0; i < size; ++i) { *at++ = from[i]; } } else { count += size; }
+    }
+    __device__ __forceinline__ void number(uint32_t value) {
+        char digits[10];
+        int n = 0;
+        do { digits[n++] = static_cast<char>('0' + value % 10u); value /= 10u; } while(value);
+        while(n > 0) { put(digits[--n]); }
+    }
+};
+
+// printf("%g") of a float in (0, 1]: six significant digits, round half to even on the exact binary value, trailing zeros
+// dropped, d.ddddde-XX below 1e-4 (text_format.hpp put_float_g is the host's; the values here are 1 - confidence: at least
+// 2^-53, at most 1)
+template <bool WRITE>
+__device__ void put_float_g(Out<WRITE>& out, float value) {
+    if(!(value < 1.0f)) { out.put('1'); return; }
+    const uint32_t bits = __float_as_uint(value);
+    const int binary_exponent = static_cast<int>((bits >> 23) & 0xffu) - 126;       // value = fraction * 2^e, fraction in [0.5, 1)
+    const unsigned long long mantissa = (bits & 0x7fffffu) | 0x800000u;             // fraction * 2^24
+    const int shift = 24 - binary_exponent;                                         // value = mantissa / 2^shift, shift in [24, 77]
+    int exponent = ((binary_exponent - 1) * 78913) >> 18;                           // floor(log10(value)), at most one too small
+    unsigned long long digits = 0;
+    for(int attempt = 0; attempt < 3; ++attempt) {
+        const int scale = 5 - exponent;                                             // 6 .. 22
+        unsigned __int128 power = 1;
+        for(int k = 0; k < scale; ++k) { power *= 10u; }
+        const unsigned __int128 numerator = static_cast<unsigned __int128>(mantissa) * power;      // < 2^24 * 2^74
+        const unsigned __int128 whole = numerator >> shift;
+        if(whole >= 1000000u) { ++exponent; continue; }
+        if(whole < 100000u) { --exponent; continue; }
+        const unsigned __int128 remainder = numerator & ((static_cast<unsigned __int128>(1) << shift) - 1);
+        const unsigned __int128 half = static_cast<unsigned __int128>(1) << (shift - 1);
+        digits = static_cast<unsigned long long>(whole);
+        if(remainder > half || (remainder == half && (digits & 1u))) { ++digits; }
+        if(digits == 1000000u) { digits = 100000u; ++exponent; }
+        break;
+    }
+    char text[6];
+    unsigned long long rest = digits;
+    for(int i = 5; i >= 0; --i) { text[i] = static_cast<char>('0' + rest % 10u); rest /= 10u; }
+    int significant = 6;
+    while(significant > 1 && text[significant - 1] == '0') { --significant; }
+    if(exponent >= 0) { out.put('1'); return; }                                     // rounded up to one
+    if(exponent < -4) {
+        out.put(text[0]);
+        if(significant > 1) { out.put('.'); for(int i = 1; i < significant; ++i) { out.put(text[i]); } }
+        out.put('e'); out.put('-');
+        const int magnitude = -exponent;
+        if(magnitude < 10) { out.put('0'); }
+        out.number(static_cast<uint32_t>(magnitude));
+        return;
+    }
+    out.put('0'); out.put('.');
+    for(int i = 0; i < -exponent - 1; ++i) { out.put('0'); }
+    for(int i = 0; i < significant; ++i) { out.put(text[i]); }
+}
+
+// one read's view of the round: its row of the planes and results, its segments in the chunks
+struct ReadView {
+    const RecordArgs* args;
+    const RecordPlan* plan;
+    uint32_t row;
+    Located at;
+
+    __device__ __forceinline__ const uint8_t* codes(const RecordDecoder& d) const { return args->base_planes + args->capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride; }
+    __device__ __forceinline__ const uint8_t* qualities(const RecordDecoder& d) const { return args->quality_planes + args->capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride; }
+    __device__ __forceinline__ const DevResult* result(const RecordDecoder& d) const { return d.result_slot >= 0 ? args->round.result + static_cast<int64_t>(d.result_slot) * args->capacity + row : nullptr; }
+    // the decoded barcode's ordinal in tag_array order, -1 = unclassified or no result
+    __device__ __forceinline__ int ordinal(const RecordDecoder& d) const {
+        const DevResult* const res = result(d);
+        if(res == nullptr || res->index <= 0 || res->index >= d.n_ordinal) { return -1; }
+        return plan->ints[d.ordinal_at + res->index];
+    }
+    // observed length of segment s of the decoder's barcode: the plane is zero filled past what the tokens brought
+    __device__ __forceinline__ int32_t observed(const RecordDecoder& d, int s) const {
+        const uint8_t* const oc = codes(d);
+        const uint8_t* const oq = qualities(d);
+        const int32_t so = d.segment_offset[s];
+        int32_t len = d.barcode_length[s];
+        while(len > 0 && oc[so + len - 1] == 0 && oq[so + len - 1] == 0) { --len; }
+        return len;
+    }
+    // raw barcode of a kind: append_to_raw_*_barcode (read.h:275-278,301-305,328-332)
+    __device__ uint32_t raw_size(int kind) const {
+        uint32_t size = 0;
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.kind != kind || d.plane_stride == 0) { continue; }
+            for(int s = 0; s < d.segment_cardinality; ++s) { size += static_cast<uint32_t>(observed(d, s)); }
+        }
+        return size;
+    }
+    template <bool WRITE>
+    __device__ void put_raw(Out<WRITE>& out, int kind, bool quality) const {
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.kind != kind || d.plane_stride == 0) { continue; }
+            const uint8_t* const from = quality ? qualities(d) : codes(d);
+            for(int s = 0; s < d.segment_cardinality; ++s) {
+                const int32_t len = observed(d, s);
+                if(!WRITE) { out.room(static_cast<uint32_t>(len)); continue; }
+                for(int32_t i = 0; i < len; ++i) {
+                    const uint8_t value = from[d.segment_offset[s] + i];
+                    out.put(quality ? static_cast<char>(value + 33) : plan->text_of_bam[value & 15u]);
+                }
+            }
+        }
+    }
+    __device__ uint32_t corrected_size(int kind) const {
+        uint32_t size = 0;
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.kind != kind || d.plane_stride == 0 || !d.closed) { continue; }
+            for(int s = 0; s < d.segment_cardinality; ++s) { size += static_cast<uint32_t>(observed(d, s)); }
+        }
+        return size;
+    }
+    // Position `wanted` of the corrected barcode of a kind (append_corrected, sequence.h:382-398): the codec's base, and the
+    // observed quality where the observation agrees, the decoder's corrected quality elsewhere.  The S9 quirk is kept: the
+    // "was this base corrected" test reads the observation at the DESTINATION length.  Visits every position when
+    // wanted < 0 (f(code, quality) for each); returns false when the position does not exist.
+    template <typename F>
+    __device__ bool corrected(int kind, int32_t wanted, F&& f) const {
+        int32_t dest = 0;
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.kind != kind || d.plane_stride == 0 || !d.closed) { continue; }
+            const uint8_t* const oc = codes(d);
+            const uint8_t* const oq = qualities(d);
+            const int which = ordinal(d);
+            for(int s = 0; s < d.segment_cardinality; ++s) {
+                const int32_t len = observed(d, s);
+                const int32_t so = d.segment_offset[s];
+                if(wanted >= 0 && wanted >= dest + len) { dest += len; continue; }
+                const int32_t first = wanted >= 0 ? wanted - dest : 0;
+                const int32_t last = wanted >= 0 ? first + 1 : len;
+                for(int32_t i = first; i < last; ++i) {
+                    const uint8_t fixed = which >= 0 ? plan->bytes[d.code_at + which * d.nucleotide_cardinality + so + i] : 0;
+                    const uint8_t probe = (dest + i) < len ? oc[so + dest + i] : 0;
+                    f(fixed, (probe == fixed || fixed == 0) ? oq[so + i] : static_cast<uint8_t>(d.corrected_quality));
+                }
+                if(wanted >= 0) { return true; }
+                dest += len;
+            }
+        }
+        return false;
+    }
+    template <bool WRITE>
+    __device__ void put_corrected(Out<WRITE>& out, int kind, bool quality) const {
+        if(!WRITE) { out.room(corrected_size(kind)); return; }
+        corrected(kind, -1, [&](uint8_t code, uint8_t q) { out.put(quality ? static_cast<char>(q + 33) : plan->text_of_bam[code & 15u]); });
+    }
+    // the per type confidence as the decoders' wrappers leave it (pamld.cpp:133-180; read.h:176-183,279-285)
+    __device__ void confidences(double (&confidence)[3]) const {
+        for(int t = 0; t < 3; ++t) { confidence[t] = 1; }
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.result_slot < 0 || !d.pamld) { continue; }
+            const DevResult& res = *result(d);
+            if(d.kind == 0 || res.index > 0) { confidence[d.kind] = confidence[d.kind] == 1 ? res.confidence : confidence[d.kind] * res.confidence; }
+            else { confidence[d.kind] = 0; }
+        }
+    }
+    // an output segment's bases or qualities from the template tokens (TemplateRule::apply, transform.h:190-226)
+    __device__ uint32_t token_size(const RecordToken& token, int32_t& start, int32_t& end) const {
+        const int32_t length = token.source >= 0 ? static_cast<int32_t>(at.length[token.source])
+                                                 : static_cast<int32_t>(corrected_size(token.source == -1 ? 0 : token.source == -2 ? 2 : 1));
+        token_range(token.start, token.end, token.end_terminated, length, start, end);
+        return end > start ? static_cast<uint32_t>(end - start) : 0u;
+    }
+    __device__ uint32_t bases_of(int o) const {
+        uint32_t size = 0;
+        for(int t = plan->out_first[o]; t < plan->out_first[o + 1]; ++t) { int32_t start, end; size += token_size(plan->token[plan->out_token[t]], start, end); }
+        return size;
+    }
+    template <bool WRITE>
+    __device__ void put_segment(Out<WRITE>& out, int o, bool quality) const {
+        for(int t = plan->out_first[o]; t < plan->out_first[o + 1]; ++t) {
+            const RecordToken& token = plan->token[plan->out_token[t]];
+            int32_t start, end;
+            const uint32_t size = token_size(token, start, end);
+            if(!WRITE) { out.room(size); continue; }
+            if(token.source >= 0) {
+                const uint8_t* const raw = args->chunk[args->plan.segment_feed[token.source]].raw;
+                const uint8_t* const from = raw + (quality ? at.quality_at[token.source] : at.sequence_at[token.source]);
+                for(uint32_t i = 0; i < size; ++i) {
+                    const uint8_t c = from[token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i)];
+                    out.put(quality ? static_cast<char>(c + plan->quality_shift) : token.reverse_complement ? plan->complement_text[c] : plan->canonical_text[c]);
+                }
+            } else {
+                const int kind = token.source == -1 ? 0 : token.source == -2 ? 2 : 1;
+                for(uint32_t i = 0; i < size; ++i) {
+                    const int32_t from = token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i);
+                    corrected(kind, from, [&](uint8_t code, uint8_t q) {
+                        out.put(quality ? static_cast<char>(q + plan->output_phred_offset)
+                                        : plan->text_of_bam[(token.reverse_complement ? plan->complement_of_bam[code & 15u] : code) & 15u]);
+                    });
+                }
+            }
+        }
+    }
+};
+
+// Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
+template <bool WRITE>
+__device__ void put_tags(Out<WRITE>& out, const ReadView& read, int group, const double (&confidence)[3], const uint32_t (&raw_size)[3], const uint32_t (&corrected_size)[3]) {
+    const RecordPlan& plan = *read.plan;
+    if(group >= 0 && group < plan.n_group) {
+        const int32_t first = plan.ints[plan.group_at + group], last = plan.ints[plan.group_at + group + 1];
+        if(last > first) { out.literal("\tRG:Z:"); out.bytes(reinterpret_cast<const char*>(plan.bytes) + first, static_cast<uint32_t>(last - first)); }
+    }
+    if(raw_size[0]) { out.literal("\tBC:Z:"); read.put_raw(out, 0, false); out.literal("\tQT:Z:"); read.put_raw(out, 0, true); }
+    if(confidence[0] > 0 && confidence[0] < 1) { out.literal("\tXB:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[0])); }
+    if(corrected_size[1]) { out.literal("\tRX:Z:"); read.put_corrected(out, 1, false); out.literal("\tQX:Z:"); read.put_corrected(out, 1, true); }
+    if(raw_size[1]) { out.literal("\tOX:Z:"); read.put_raw(out, 1, false); out.literal("\tBZ:Z:"); read.put_raw(out, 1, true); }
+    if(confidence[1] > 0 && confidence[1] < 1) { out.literal("\tXM:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[1])); }
+    if(corrected_size[2]) { out.literal("\tCB:Z:"); read.put_corrected(out, 2, false); }
+    if(raw_size[2]) { out.literal("\tCR:Z:"); read.put_raw(out, 2, false); out.literal("\tCY:Z:"); read.put_raw(out, 2, true); }
+    if(confidence[2] > 0 && confidence[2] < 1) { out.literal("\tXC:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[2])); }
+}
+
+// every record of one read, in output segment order
+template <bool WRITE>
+__device__ void put_read(Out<WRITE>& out, const ReadView& read) {
+    const RecordPlan& plan = *read.plan;
+    // Multiplexer::push -> Channel::push (multiplex.h:198-240): the channel is the multiplexing decoder's barcode
+    int channel = 0;
+    int group = -1;
+    for(int k = 0; k < plan.n_decoder; ++k) {
+        const RecordDecoder& d = plan.decoder[k];
+        if(d.plane_stride == 0) { continue; }
+        const int which = read.ordinal(d);
+        if(d.multiplexing) { channel = which + 1; }
+        if(d.result_slot >= 0 && d.kind == 0) { group = which + 1; }
+    }
+    if(channel >= plan.n_channel) { channel = 0; }
+    const uint8_t mode = plan.bytes[plan.channel_at + channel];
+    const bool qcfail = (read.args->round.word[read.row] >> 31) != 0;
+    if(!(mode & 1u) || ((mode & 2u) && qcfail)) { return; }
+
+    double confidence[3];
+    read.confidences(confidence);
+    const uint32_t raw_size[3] = {read.raw_size(0), read.raw_size(1), read.raw_size(2)};
+    const uint32_t corrected_size[3] = {read.corrected_size(0), read.corrected_size(1), read.corrected_size(2)};
+    const char* const name = reinterpret_cast<const char*>(read.args->chunk[read.args->plan.segment_feed[0]].raw) + read.at.name_at;
+    for(int o = 0; o < plan.n_out; ++o) {
+        if(plan.fastq) {
+            // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
+            out.put('@');
+            out.bytes(name, read.at.name_size);
+            out.put(' ');
+            if(plan.illumina_comment) {
+                out.number(static_cast<uint32_t>(o + 1));
+                out.literal(qcfail ? ":Y:0:" : ":N:0:");
+                read.put_raw(out, 0, false);
+            }
+            out.put('\n');
+            read.put_segment(out, o, false);
+            out.literal("\n+\n");
+            read.put_segment(out, o, true);
+            out.put('\n');
+            continue;
+        }
+        out.bytes(name, read.at.name_size);
+        out.bytes(plan.columns[o][qcfail ? 1 : 0], static_cast<uint32_t>(plan.columns_size[o][qcfail ? 1 : 0]));
+        if(read.bases_of(o) == 0) { out.literal("*\t*"); }
+        else {
+            read.put_segment(out, o, false);
+            out.put('\t');
+            read.put_segment(out, o, true);
+        }
+        if(plan.n_out > 2) {
+            out.literal("\tFI:i:"); out.number(static_cast<uint32_t>(o + 1));
+            out.literal("\tTC:i:"); out.number(static_cast<uint32_t>(plan.n_out));
+        }
+        put_tags(out, read, group, confidence, raw_size, corrected_size);
+        out.put('\n');
+    }
+}
+
+// pass 1: the bytes of every read's records, and their sum per workgroup
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void record_size_kernel(RecordArgs args) {
+    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
+    __shared__ unsigned long long block_bytes;
+    if(threadIdx.x == 0) { block_bytes = 0; }
+    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
+    if(!FILTER) { __syncthreads(); }
+    uint32_t bytes = 0;
+    if(wanted) {
+        ReadView read;
+        read.args = &args;
+        read.plan = args.round.plan;
+        read.row = row;
+        locate(args.plan, args.chunk, r, read.at);
+        Out<false> out{nullptr, 0};
+        put_read(out, read);
+        bytes = out.count;
+    }
+    if(r < args.n) { args.round.size[r] = bytes; }
+    uint32_t sum = bytes;
+    for(int step = 32; step > 0; step >>= 1) { sum += __shfl_down(sum, step); }
+    if((threadIdx.x & 63) == 0 && sum) { atomicAdd(&block_bytes, static_cast<unsigned long long>(sum)); }
+    __syncthreads();
+    if(threadIdx.x == 0) { args.round.block[blockIdx.x] = block_bytes; }
+}
+
+// exclusive prefix sums of the workgroups' bytes, in place; *total = the bytes of the round's text
+__global__ __launch_bounds__(1024) void record_scan_kernel(unsigned long long* block, uint32_t n_block, unsigned long long* total) {
+    __shared__ unsigned long long wave_sum[16];
+    __shared__ unsigned long long carried;
+    if(threadIdx.x == 0) { carried = 0; }
+    __syncthreads();
+    for(uint32_t first = 0; first < n_block; first += 1024) {
+        const uint32_t at = first + threadIdx.x;
+        const unsigned long long own = at < n_block ? block[at] : 0ull;
+        unsigned long long inclusive = own;
+        for(int step = 1; step < 64; step <<= 1) {
+            const unsigned long long below = __shfl_up(inclusive, step);
+            if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+        }
+        if((threadIdx.x & 63) == 63) { wave_sum[threadIdx.x >> 6] = inclusive; }
+        __syncthreads();
+        unsigned long long before = carried;
+        for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { before += wave_sum[w]; }
+        if(at < n_block) { block[at] = before + inclusive - own; }
+        __syncthreads();
+        if(threadIdx.x == 1023) { carried = before + inclusive; }
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) { *total = carried; }
+}
+
+// pass 2: the text, every read's records where the scan put them
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void record_write_kernel(RecordArgs args) {
+    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
+    __shared__ uint32_t wave_bytes[TILE_THREADS / 64];
+    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
+    const uint32_t own = r < args.n ? args.round.size[r] : 0u;
+    uint32_t inclusive = own;
+    for(int step = 1; step < 64; step <<= 1) {
+        const uint32_t below = __shfl_up(inclusive, step);
+        if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+    }
+    if((threadIdx.x & 63) == 63) { wave_bytes[threadIdx.x >> 6] = inclusive; }
+    __syncthreads();
+    unsigned long long place = args.round.block[blockIdx.x] + inclusive - own;
+    for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { place += wave_bytes[w]; }
+    if(!wanted || own == 0) { return; }
+    ReadView read;
+    read.args = &args;
+    read.plan = args.round.plan;
+    read.row = row;
+    locate(args.plan, args.chunk, r, read.at);
+    Out<true> out{args.round.text + place, 0};
+    put_read(out, read);
+}
+
+RecordArgs arguments_of(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                        const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round) {
+    RecordArgs call;
+    call.plan = plan;
+    for(int f = 0; f < FASTQ_MAX_FEED; ++f) { call.chunk[f] = f < plan.n_feed ? chunk[f] : FastqFeedChunk{}; }
+    call.n = n;
+    call.capacity = capacity;
+    call.base_planes = base_planes;
+    call.quality_planes = quality_planes;
+    call.keep = keep;
+    call.keep_block = keep_block;
+    call.round = round;
+    return call;
+}
+
+}  // namespace
+
+int record_sizes(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                 const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
+    if(blocks > 0) {
+        const RecordArgs call = arguments_of(plan, chunk, n, capacity, base_planes, quality_planes, keep, keep_block, round);
+        if(plan.filtering) { hipLaunchKernelGGL(record_size_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+        else { hipLaunchKernelGGL(record_size_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+    }
+    hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, s, round.block, blocks, round.total);
+    return static_cast<int>(hipGetLastError());
+}
+
+int record_write(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                 const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream) {
+    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
+    if(blocks == 0) { return 0; }
+    const RecordArgs call = arguments_of(plan, chunk, n, capacity, base_planes, quality_planes, keep, keep_block, round);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if(plan.filtering) { hipLaunchKernelGGL(record_write_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+    else { hipLaunchKernelGGL(record_write_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace phq

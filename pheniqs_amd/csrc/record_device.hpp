@@ -1,0 +1,93 @@
+// Output records — SAM or FASTQ text — assembled ON THE DEVICE from the FASTQ chunks, the observation planes and the result
+// records of a round, for a job whose every written channel goes to one uncompressed file.
+//
+//   reference read.h:187-237        Read::flush: the per type accumulators into the auxiliary tags
+//   reference auxiliary.cpp:324-354 Auxiliary::encode: the order of the tags (FI TC RG BC QT XB RX QX OX BZ XM CB CR CY XC)
+//   reference sequence.h:382-398    append_corrected: the corrected barcode and its qualities
+//   reference transform.h:190-226   TemplateRule::apply: the output segments from the template tokens
+//   reference fastq.h:144-194       FastqRecord::encode and the Illumina comment
+//   reference multiplex.h:198-240   Multiplexer::push -> Channel::push: which channel takes the read, whether it is written
+//
+// Two passes over the reads of a round, one lane per read: the first leaves every read's byte count, a scan turns the counts
+// into places, the second writes the text where it belongs.  The host only copies the finished text to the output.
+#pragma once
+
+#include <cstdint>
+
+#include "device_types.hpp"
+#include "fastq_device.hpp"
+
+namespace phq {
+
+constexpr int RECORD_MAX_TOKEN = 32;
+constexpr int RECORD_MAX_OUT = 8;
+
+struct RecordDecoder {
+    int32_t kind;                   // 0 sample, 1 molecular, 2 cellular
+    int32_t plane_prefix;
+    int32_t plane_stride;
+    int32_t result_slot;            // -1: no result record (naive, passthrough)
+    int32_t segment_cardinality;
+    int32_t nucleotide_cardinality;
+    int32_t closed;                 // PAMLD or MDD: the decoder corrects
+    int32_t pamld;
+    int32_t corrected_quality;
+    int32_t multiplexing;
+    int32_t n_ordinal;              // ints[ordinal_at + index], index < n_ordinal: the barcode's ordinal in tag_array order, -1 none
+    int32_t ordinal_at;
+    int32_t code_at;                // bytes[code_at + ordinal * nucleotide_cardinality + position]: the barcode's BAM codes
+    int32_t segment_offset[DEV_MAX_SEGMENT];
+    int32_t barcode_length[DEV_MAX_SEGMENT];
+};
+
+struct RecordToken {                // one token of the template transform
+    int32_t source;                 // >= 0: input segment; -1, -2, -3: the corrected sample, cellular, molecular barcode
+    int32_t start;
+    int32_t end;
+    int32_t end_terminated;
+    int32_t reverse_complement;
+};
+
+struct RecordPlan {
+    int32_t n_decoder;
+    int32_t n_out;                  // output segments
+    int32_t n_channel;
+    int32_t fastq;                  // 1: FASTQ records, 0: SAM
+    int32_t illumina_comment;
+    int32_t quality_shift;          // output Phred offset - input Phred offset
+    int32_t output_phred_offset;
+    int32_t n_group;                // read group ids: bytes[ints[group_at + g] .. ints[group_at + g + 1])
+    int32_t group_at;
+    int32_t channel_at;             // bytes[channel_at + channel]: bit 0 the channel is written, bit 1 it filters outgoing QC fail
+    int32_t out_first[RECORD_MAX_OUT + 1];      // out_token[out_first[o] .. out_first[o + 1]): the tokens of output segment o, in order
+    int32_t out_token[RECORD_MAX_TOKEN];
+    int32_t columns_size[RECORD_MAX_OUT][2];
+    char columns[RECORD_MAX_OUT][2][32];        // "\t<flag>\t*\t0\t0\t*\t*\t0\t0\t" per output segment and filter flag
+    RecordDecoder decoder[FASTQ_MAX_DECODER];
+    RecordToken token[RECORD_MAX_TOKEN];
+    char text_of_bam[16];
+    char canonical_text[256];       // a FASTQ letter as the output prints it: BamToAmbiguousAscii of its BAM code
+    char complement_text[256];
+    uint8_t complement_of_bam[16];
+    const int32_t* ints;            // device
+    const uint8_t* bytes;           // device
+};
+
+struct RecordRound {
+    const RecordPlan* plan;         // device
+    const DevResult* result;        // device: [slot][capacity]
+    const uint32_t* word;           // device: the summary word of every row (bit 31: the read failed QC)
+    uint32_t* size;                 // device scratch: n words
+    unsigned long long* block;      // device scratch: n / 256 + 2 words
+    unsigned long long* total;      // device: bytes of the round's text (after record_sizes)
+    char* text;                     // device: at least *total bytes (record_write)
+};
+
+// every function returns a hipError_t value; all work goes to `stream`.  `keep` / `keep_block` are what fastq_decode left
+// (a plan that filters), rows are the compacted ones the planes and results hold.
+int record_sizes(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                 const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
+int record_write(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                 const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
+
+}  // namespace phq

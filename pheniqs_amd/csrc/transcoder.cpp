@@ -17,6 +17,7 @@
 // Out of scope here: BAM/CRAM (htslib), bz2 / xz, QC histograms.
 #include "transcoder.hpp"
 #include "fastq_device.hpp"
+#include "record_device.hpp"
 
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
@@ -36,6 +37,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -249,6 +251,12 @@ public:
         return static_cast<int64_t>(records);
     }
     void release() { begin_ = consumed_; }                 // the indexed records have been decoded
+    // the records before byte `offset` of the (uncompressed) file have been taken elsewhere: the device path, which handed
+    // the rest of the run over (Transcoder::run_on_device).  Called before the first index_records.
+    void start_at(size_t offset) {
+        if(map_ != nullptr) { begin_ = consumed_ = std::min(offset, map_size_); return; }
+        if(gzseek(file_, static_cast<z_off_t>(offset), SEEK_SET) < 0) { throw IOError("error reading " + path_); }
+    }
     const char* data() const { return map_ ? map_ : buffer_.data(); }
     const std::string& path() const { return path_; }
 
@@ -832,7 +840,33 @@ struct DeviceFastqCache {
     uint32_t* kept_device = nullptr;
     uint32_t* kept_host = nullptr;                 // pinned
     hipStream_t stream = nullptr;
+    // a run that writes: the records' text is assembled on the device (record_device.hpp) and leaves on a stream of its own
+    RecordPlan* record_plan = nullptr;             // device
+    int32_t* record_ints = nullptr;                // device
+    uint8_t* record_bytes = nullptr;               // device
+    size_t record_ints_room = 0, record_bytes_room = 0;
+    int64_t record_capacity = 0;
+    uint32_t* record_size = nullptr;               // device: [capacity]
+    unsigned long long* record_block = nullptr;    // device: [capacity / 256 + 2]
+    unsigned long long* record_total = nullptr;    // device
+    struct RoundStatus { unsigned long long text_bytes; unsigned long long flagged; uint32_t irregular; uint32_t kept; };
+    RoundStatus* status_host = nullptr;            // pinned
+    char* text_device[2] = {nullptr, nullptr};
+    char* text_host[2] = {nullptr, nullptr};       // pinned
+    size_t text_device_room[2] = {0, 0}, text_host_room[2] = {0, 0};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t written[2] = {nullptr, nullptr};    // the round's text is in text_device[b]
+    hipEvent_t copied[2] = {nullptr, nullptr};     // ... and in text_host[b]
     ~DeviceFastqCache() {
+        (void)hipFree(record_plan); (void)hipFree(record_ints); (void)hipFree(record_bytes); (void)hipFree(record_size); (void)hipFree(record_block); (void)hipFree(record_total);
+        if(status_host) { (void)hipHostFree(status_host); }
+        for(int b = 0; b < 2; ++b) {
+            (void)hipFree(text_device[b]);
+            if(text_host[b]) { (void)hipHostFree(text_host[b]); }
+            if(written[b]) { (void)hipEventDestroy(written[b]); }
+            if(copied[b]) { (void)hipEventDestroy(copied[b]); }
+        }
+        if(copy_stream) { (void)hipStreamDestroy(copy_stream); }
         (void)hipFree(keep); (void)hipFree(keep_block); (void)hipFree(kept_device);
         if(kept_host) { (void)hipHostFree(kept_host); }
         for(int f = 0; f < FASTQ_MAX_FEED; ++f) {
@@ -860,18 +894,148 @@ struct PlainFile {
 
 }  // namespace
 
-// true: the whole input went through the device path; false: the run has to go through the host reader (nothing counted)
-bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
+namespace {
+std::atomic<uint64_t> device_rounds{0}, device_reads{0}, device_record_bytes{0}, device_resumed{0};
+}
+void device_path_counters(uint64_t* counters) {
+    counters[0] = device_rounds; counters[1] = device_reads; counters[2] = device_record_bytes; counters[3] = device_resumed;
+}
+
+// A run whose every written channel sends all its output segments to ONE uncompressed file: which sink, and the tables
+// the device needs to assemble the records (record_device.hpp).  `ints` and `bytes` are the two pools RecordPlan points into.
+struct DeviceText {
+    int32_t sink = -1;
+    RecordPlan plan;
+    std::vector<int32_t> ints;
+    std::vector<uint8_t> bytes;
+};
+
+namespace {
+
+// false: the job is not one the device writes (the host writer takes it)
+bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std::vector<OutputSink>& sink, const std::vector<std::string>& rg_by_index,
+                      const std::vector<std::vector<int>>& ordinal_by_index, DeviceText& out) {
+    if(std::getenv("PHQ_HOST_RECORDS") != nullptr) { return false; }
+    const int32_t n_out = job.output_segment_cardinality;
+    if(n_out < 1 || n_out > RECORD_MAX_OUT || job.template_transform.size() > static_cast<size_t>(RECORD_MAX_TOKEN) || job.decoder.size() > static_cast<size_t>(FASTQ_MAX_DECODER)) { return false; }
+    // the channels: silent ones (every URL /dev/null) and empty ones take their reads without a record; the others all write
+    // every output segment to the same file
+    out.sink = -1;
+    std::vector<uint8_t> mode(plan.channel.size(), 0);
+    for(size_t c = 0; c < plan.channel.size(); ++c) {
+        const auto& channel = plan.channel[c];
+        if(channel.feed_by_segment.empty()) { continue; }
+        bool silent = true;
+        for(const int32_t f : channel.feed_by_segment) { silent = silent && sink[static_cast<size_t>(f)].null; }
+        if(silent) { continue; }
+        for(const int32_t f : channel.feed_by_segment) {
+            if(sink[static_cast<size_t>(f)].null || (out.sink >= 0 && f != out.sink)) { return false; }
+            out.sink = f;
+        }
+        mode[c] = static_cast<uint8_t>(1u | (channel.filter_outgoing_qc_fail ? 2u : 0u));
+    }
+    if(out.sink < 0) { return false; }
+    const OutputSink& to = sink[static_cast<size_t>(out.sink)];
+    if(to.feed.gzip || (to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ)) { return false; }
+
+    RecordPlan& r = out.plan;
+    std::memset(&r, 0, sizeof(r));
+    out.ints.clear();
+    out.bytes.clear();
+    r.n_decoder = static_cast<int32_t>(job.decoder.size());
+    r.n_out = n_out;
+    r.n_channel = static_cast<int32_t>(plan.channel.size());
+    r.fastq = to.feed.format == FileFormat::FASTQ ? 1 : 0;
+    r.illumina_comment = (job.platform == "ILLUMINA" || job.platform == "ELEMENT") ? 1 : 0;      // fastq.h:176-194
+    r.quality_shift = job.output_phred_offset - job.input_phred_offset;
+    r.output_phred_offset = job.output_phred_offset;
+    // read group ids: where each one's bytes end
+    r.n_group = static_cast<int32_t>(rg_by_index.size());
+    r.group_at = static_cast<int32_t>(out.ints.size());
+    for(const auto& id : rg_by_index) {
+        out.ints.push_back(static_cast<int32_t>(out.bytes.size()));
+        out.bytes.insert(out.bytes.end(), id.begin(), id.end());
+    }
+    out.ints.push_back(static_cast<int32_t>(out.bytes.size()));
+    r.channel_at = static_cast<int32_t>(out.bytes.size());
+    out.bytes.insert(out.bytes.end(), mode.begin(), mode.end());
+    // the tokens of every output segment, in template order
+    int32_t placed = 0;
+    for(int32_t o = 0; o < n_out; ++o) {
+        r.out_first[o] = placed;
+        for(size_t t = 0; t < job.template_transform.size(); ++t) {
+            if(job.template_transform[t].output_segment_index == o) { r.out_token[placed++] = static_cast<int32_t>(t); }
+        }
+    }
+    r.out_first[n_out] = placed;
+    for(size_t t = 0; t < job.template_transform.size(); ++t) {
+        const TransformConfig& token = job.template_transform[t];
+        if(token.input_segment_index < -3 || token.output_segment_index < 0 || token.output_segment_index >= n_out) { return false; }
+        r.token[t] = RecordToken{token.input_segment_index, token.start, token.end, token.end_terminated ? 1 : 0, token.reverse_complement ? 1 : 0};
+    }
+    for(int32_t o = 0; o < n_out; ++o) {
+        for(int failed = 0; failed < 2; ++failed) {
+            int flag = 4 | 8;                                                 // BAM_FUNMAP | BAM_FMUNMAP (read.h:134-135)
+            if(n_out > 1) { flag |= 1; }
+            if(o == 0) { flag |= 64; }
+            if(n_out > 1 && o == n_out - 1) { flag |= 128; }
+            if(failed) { flag |= 512; }
+            const std::string text = "\t" + std::to_string(flag) + "\t*\t0\t0\t*\t*\t0\t0\t";
+            if(text.size() > sizeof(r.columns[o][failed])) { return false; }
+            std::memcpy(r.columns[o][failed], text.data(), text.size());
+            r.columns_size[o][failed] = static_cast<int32_t>(text.size());
+        }
+    }
+    for(size_t k = 0; k < job.decoder.size(); ++k) {
+        const DecoderConfig& d = job.decoder[k];
+        RecordDecoder& to_decoder = r.decoder[k];
+        if(d.segment_cardinality > DEV_MAX_SEGMENT) { return false; }
+        to_decoder.kind = static_cast<int32_t>(d.kind);
+        to_decoder.plane_prefix = d.plane_prefix;
+        to_decoder.plane_stride = d.plane_stride;
+        to_decoder.result_slot = d.result_slot;
+        to_decoder.segment_cardinality = d.segment_cardinality;
+        to_decoder.nucleotide_cardinality = d.nucleotide_cardinality;
+        to_decoder.closed = d.closed() ? 1 : 0;
+        to_decoder.pamld = d.algorithm == Algorithm::PAMLD ? 1 : 0;
+        to_decoder.corrected_quality = d.corrected_quality;
+        to_decoder.multiplexing = d.multiplexing_classifier ? 1 : 0;
+        to_decoder.n_ordinal = static_cast<int32_t>(ordinal_by_index[k].size());
+        to_decoder.ordinal_at = static_cast<int32_t>(out.ints.size());
+        out.ints.insert(out.ints.end(), ordinal_by_index[k].begin(), ordinal_by_index[k].end());
+        to_decoder.code_at = static_cast<int32_t>(out.bytes.size());
+        out.bytes.insert(out.bytes.end(), d.barcode_code.begin(), d.barcode_code.end());
+        for(int32_t s = 0; s < d.segment_cardinality; ++s) {
+            to_decoder.segment_offset[s] = d.segment_offset[static_cast<size_t>(s)];
+            to_decoder.barcode_length[s] = d.barcode_length[static_cast<size_t>(s)];
+        }
+    }
+    for(int c = 0; c < 16; ++c) {
+        r.text_of_bam[c] = bam_to_ascii(static_cast<uint8_t>(c));
+        r.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c));
+    }
+    for(int c = 0; c < 256; ++c) {
+        r.complement_text[c] = bam_to_ascii(reverse_complement_bam(ascii_to_bam(static_cast<uint8_t>(c))));
+        r.canonical_text[c] = bam_to_ascii(ascii_to_bam(static_cast<uint8_t>(c)));
+    }
+    out.ints.push_back(0);
+    out.bytes.push_back(0);
+    return true;
+}
+
+}  // namespace
+
+Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count, const DeviceText* text) {
     Impl& m = *impl_;
     const JobConfig& job = m.set.job();
     const TranscodePlan& plan = m.plan;
     const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
-    if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return false; }
-    if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return false; }
+    if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return OnDevice::NOT_TAKEN; }
+    if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return OnDevice::NOT_TAKEN; }
     // what the device path does not do: the quality control accumulators (they count the output read's text: host side)
-    if(job.enable_quality_control) { return false; }
+    if(job.enable_quality_control) { return OnDevice::NOT_TAKEN; }
     const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
-    if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return false; }
+    if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return OnDevice::NOT_TAKEN; }
     FastqPlan device_plan;
     std::memset(&device_plan, 0, sizeof(device_plan));
     device_plan.n_feed = n_feed;
@@ -883,7 +1047,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         device_plan.segment_feed[s] = plan.input_segment[static_cast<size_t>(s)].first;
         device_plan.segment_slot[s] = plan.input_segment[static_cast<size_t>(s)].second;
         if(device_plan.segment_feed[s] < 0 || device_plan.segment_feed[s] >= n_feed || device_plan.segment_slot[s] < 0 ||
-           device_plan.segment_slot[s] >= device_plan.feed_resolution[device_plan.segment_feed[s]]) { return false; }
+           device_plan.segment_slot[s] >= device_plan.feed_resolution[device_plan.segment_feed[s]]) { return OnDevice::NOT_TAKEN; }
     }
     // the pre-filters of the pull loop (transcode.h:193-205), on the device too: kept reads are compacted into the planes
     device_plan.filter_incoming_qc_fail = job.filter_incoming_qc_fail ? 1 : 0;
@@ -902,7 +1066,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         to.first_token = n_token;
         for(const auto& t : d.transform) {
             if(n_token >= FASTQ_MAX_TOKEN || t.input_segment_index < 0 || t.input_segment_index >= static_cast<int32_t>(plan.input_segment.size()) ||
-               t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return false; }
+               t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return OnDevice::NOT_TAKEN; }
             FastqToken& token = device_plan.token[n_token++];
             token.segment = t.input_segment_index;
             token.start = t.start;
@@ -920,16 +1084,16 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     for(int32_t f = 0; f < n_feed; ++f) {
         PlainFile& p = file[static_cast<size_t>(f)];
         p.descriptor = ::open(plan.input_feed[static_cast<size_t>(f)].path.c_str(), O_RDONLY);
-        if(p.descriptor < 0) { return false; }
+        if(p.descriptor < 0) { return OnDevice::NOT_TAKEN; }
         struct stat status;
-        if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return false; }
+        if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return OnDevice::NOT_TAKEN; }
         p.size = static_cast<size_t>(status.st_size);
         char head[1 << 16];
         const ssize_t got = ::pread(p.descriptor, head, sizeof(head), 0);
-        if(got < 4 || (static_cast<unsigned char>(head[0]) == 0x1f && static_cast<unsigned char>(head[1]) == 0x8b) || head[0] != '@') { return false; }
+        if(got < 4 || (static_cast<unsigned char>(head[0]) == 0x1f && static_cast<unsigned char>(head[1]) == 0x8b) || head[0] != '@') { return OnDevice::NOT_TAKEN; }
         size_t lines = 0;
         for(ssize_t k = 0; k < got; ++k) { lines += head[k] == '\n' ? 1 : 0; }
-        if(lines < 4) { return false; }
+        if(lines < 4) { return OnDevice::NOT_TAKEN; }
         p.bytes_per_record = 4.0 * static_cast<double>(got) / static_cast<double>(lines);
     }
 
@@ -963,6 +1127,41 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
         device_check(hipMalloc(reinterpret_cast<void**>(&c.kept_device), sizeof(uint32_t)), "hipMalloc");
         device_check(hipHostMalloc(reinterpret_cast<void**>(&c.kept_host), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
     }
+    if(text != nullptr) {
+        if(c.copy_stream == nullptr) {
+            device_check(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+            for(int b = 0; b < 2; ++b) {
+                device_check(hipEventCreateWithFlags(&c.written[b], hipEventDisableTiming), "hipEventCreate");
+                device_check(hipEventCreateWithFlags(&c.copied[b], hipEventDisableTiming), "hipEventCreate");
+            }
+            device_check(hipHostMalloc(reinterpret_cast<void**>(&c.status_host), sizeof(*c.status_host), hipHostMallocDefault), "hipHostMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_plan), sizeof(RecordPlan)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_total), sizeof(unsigned long long)), "hipMalloc");
+        }
+        if(c.record_capacity < capacity) {
+            (void)hipFree(c.record_size); (void)hipFree(c.record_block); c.record_size = nullptr; c.record_block = nullptr; c.record_capacity = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_size), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_block), (static_cast<size_t>(capacity) / 256 + 2) * sizeof(unsigned long long)), "hipMalloc");
+            c.record_capacity = capacity;
+        }
+        if(c.record_ints_room < text->ints.size()) {
+            (void)hipFree(c.record_ints); c.record_ints = nullptr; c.record_ints_room = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_ints), text->ints.size() * sizeof(int32_t)), "hipMalloc");
+            c.record_ints_room = text->ints.size();
+        }
+        if(c.record_bytes_room < text->bytes.size()) {
+            (void)hipFree(c.record_bytes); c.record_bytes = nullptr; c.record_bytes_room = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_bytes), text->bytes.size()), "hipMalloc");
+            c.record_bytes_room = text->bytes.size();
+        }
+        RecordPlan on_device = text->plan;
+        on_device.ints = c.record_ints;
+        on_device.bytes = c.record_bytes;
+        device_check(hipMemcpy(c.record_ints, text->ints.data(), text->ints.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
+        device_check(hipMemcpy(c.record_bytes, text->bytes.data(), text->bytes.size(), hipMemcpyHostToDevice), "hipMemcpy");
+        device_check(hipMemcpy(c.record_plan, &on_device, sizeof(RecordPlan), hipMemcpyHostToDevice), "hipMemcpy");
+        c.status_host->text_bytes = 0; c.status_host->flagged = 0; c.status_host->irregular = 0; c.status_host->kept = 0;
+    }
     size_t chunk_bytes[FASTQ_MAX_FEED];
     for(int32_t f = 0; f < n_feed; ++f) {
         const double wanted = static_cast<double>(capacity) * device_plan.feed_resolution[f] * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;      // a read is `resolution` records of an interleaved file
@@ -987,12 +1186,27 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     device_check(hipMemcpyAsync(c.counters_before, m.set.stats_device_pointer(), static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
     device_check(hipMemsetAsync(c.irregular, 0, sizeof(uint32_t), stream), "hipMemsetAsync");
     device_check(hipMemsetAsync(c.flagged, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
+    uint64_t reads = 0;
+    unsigned long long flagged_so_far = 0;          // a run that writes: the reads of the finished rounds whose filter flag is set
+    // a run that writes: the text of the rounds leaves in order on threads of its own, two rounds in flight
+    std::shared_future<void> drained;               // the round before this one is in the file
+    std::shared_future<void> buffer_drained[2];     // ... the round that used text_host[b]
+    int text_buffer = 0;
+    // Without text nothing has left the process: the counters go back to what they were and the host reader takes the run
+    // from its start.  With text the finished rounds are in the file: the host reader takes over at the bytes they end at.
     auto give_up = [&]() {
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(m.set.stats_device_pointer(), c.counters_before, static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice);
-        return false;
+        if(text == nullptr) {
+            (void)hipMemcpy(m.set.stats_device_pointer(), c.counters_before, static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+            return OnDevice::NOT_TAKEN;
+        }
+        if(drained.valid()) { drained.get(); }
+        incoming_count += reads;
+        incoming_pf_count += reads - flagged_so_far;
+        for(int32_t f = 0; f < n_feed; ++f) { m.stream[static_cast<size_t>(f)]->start_at(file[static_cast<size_t>(f)].position); }
+        ++device_resumed;
+        return OnDevice::RESUMED;
     };
-    uint64_t reads = 0;
     int slot = 0;
     int buffer = 0;                                  // which pinned buffer of a feed this round's bytes are in
     bool ahead_valid[FASTQ_MAX_FEED] = {false};
@@ -1080,23 +1294,109 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
             // the host reader says which
             return give_up();
         }
+        size_t round_began_at[FASTQ_MAX_FEED];
         for(int32_t f = 0; f < n_feed; ++f) {
             PlainFile& p = file[static_cast<size_t>(f)];
+            round_began_at[f] = p.position;
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
         device_check(static_cast<hipError_t>(fastq_decode(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
                                                           c.keep, c.keep_block, c.kept_device, stream)), "fastq_decode");
         uint32_t decoded = round.records;
-        if(device_plan.filtering) {
+        if(text != nullptr) {
+            // A run that writes learns now whether the round holds anything out of the ordinary: its reads are neither
+            // counted nor written then, and the host reader continues from where the round began.
+            device_check(hipMemcpyAsync(&c.status_host->irregular, c.irregular, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            device_check(hipMemcpyAsync(&c.status_host->flagged, c.flagged, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            if(device_plan.filtering) { device_check(hipMemcpyAsync(&c.status_host->kept, c.kept_device, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"); }
+            device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            if(c.status_host->irregular) {
+                for(int32_t f = 0; f < n_feed; ++f) { file[static_cast<size_t>(f)].position = round_began_at[f]; }
+                return give_up();
+            }
+            if(device_plan.filtering) { decoded = c.status_host->kept; }
+        } else if(device_plan.filtering) {
             // how many reads the pre-filters kept: the rows the planes hold
             device_check(hipMemcpyAsync(c.kept_host, c.kept_device, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
             decoded = *c.kept_host;
         }
         if(decoded > 0) { m.set.classify_device(c.capacity, 0, decoded, c.base, c.quality, c.flag, c.result, c.word, stream); }
+        if(text != nullptr && decoded > 0) {
+            // the records of the round: sizes, places, text (record_device.hpp), then off the device on the copy stream while
+            // the next round comes in on this one
+            const int b = text_buffer;
+            RecordRound record;
+            record.plan = c.record_plan;
+            record.result = c.result;
+            record.word = c.word;
+            record.size = c.record_size;
+            record.block = c.record_block;
+            record.total = c.record_total;
+            record.text = nullptr;
+            device_check(static_cast<hipError_t>(record_sizes(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
+            device_check(hipMemcpyAsync(&c.status_host->text_bytes, c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            const size_t bytes = static_cast<size_t>(c.status_host->text_bytes);
+            if(bytes > 0) {
+                if(c.text_device_room[b] < bytes) {
+                    device_check(hipStreamSynchronize(c.copy_stream), "hipStreamSynchronize");      // the copy of two rounds ago reads the old one
+                    (void)hipFree(c.text_device[b]); c.text_device[b] = nullptr; c.text_device_room[b] = 0;
+                    const size_t room = bytes + bytes / 8 + (size_t(1) << 20);
+                    device_check(hipMalloc(reinterpret_cast<void**>(&c.text_device[b]), room), "hipMalloc");
+                    c.text_device_room[b] = room;
+                }
+                device_check(hipStreamWaitEvent(stream, c.copied[b], 0), "hipStreamWaitEvent");       // text_device[b] has left (two rounds ago)
+                record.text = c.text_device[b];
+                device_check(static_cast<hipError_t>(record_write(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
+                device_check(hipEventRecord(c.written[b], stream), "hipEventRecord");
+                if(buffer_drained[b].valid()) { buffer_drained[b].get(); }                            // text_host[b] is in the file
+                if(c.text_host_room[b] < bytes) {
+                    if(c.text_host[b]) { (void)hipHostFree(c.text_host[b]); c.text_host[b] = nullptr; c.text_host_room[b] = 0; }
+                    const size_t room = bytes + bytes / 8 + (size_t(1) << 20);
+                    device_check(hipHostMalloc(reinterpret_cast<void**>(&c.text_host[b]), room, hipHostMallocDefault), "hipHostMalloc");
+                    c.text_host_room[b] = room;
+                }
+                device_check(hipStreamWaitEvent(c.copy_stream, c.written[b], 0), "hipStreamWaitEvent");
+                device_check(hipMemcpyAsync(c.text_host[b], c.text_device[b], bytes, hipMemcpyDeviceToHost, c.copy_stream), "hipMemcpyAsync");
+                device_check(hipEventRecord(c.copied[b], c.copy_stream), "hipEventRecord");
+                // into the file, after the round before: a regular file takes the bytes through a mapping, on every host thread
+                OutputSink* const to = &m.sink[static_cast<size_t>(text->sink)];
+                const char* const from = c.text_host[b];
+                hipEvent_t const arrived = c.copied[b];
+                const int device = m.set.device();
+                const std::shared_future<void> before = drained;
+                drained = std::async(std::launch::async, [to, from, bytes, arrived, device, before, threads]() {
+                    if(before.valid()) { before.get(); }
+                    device_check(hipSetDevice(device), "hipSetDevice");
+                    device_check(hipEventSynchronize(arrived), "hipEventSynchronize");
+                    char* const window = (to->seekable && bytes >= (1u << 20)) ? to->map_more(bytes) : nullptr;
+                    if(window == nullptr) { to->write(from, bytes); return; }
+                    parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, std::max(1, threads / 2), [&](int64_t first, int64_t last, int) {
+                        const size_t begin = static_cast<size_t>(first) << 20;
+                        const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
+                        std::memcpy(window + begin, from + begin, end - begin);
+                    });
+                    to->unmap();
+                }).share();
+                buffer_drained[b] = drained;
+                text_buffer ^= 1;
+                device_record_bytes += bytes;
+            }
+        }
+        if(text != nullptr) { flagged_so_far = c.status_host->flagged; }
         reads += round.records;
+        ++device_rounds;
+        device_reads += round.records;
         slot ^= 1;
+    }
+    if(text != nullptr) {
+        if(drained.valid()) { drained.get(); }
+        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        incoming_count += reads;
+        incoming_pf_count += reads - flagged_so_far;
+        return OnDevice::DONE;
     }
     uint32_t irregular = 0;
     unsigned long long flagged = 0;
@@ -1106,7 +1406,7 @@ bool Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_c
     if(irregular) { return give_up(); }
     incoming_count += reads;                                                      // transcode.cpp:304-309
     incoming_pf_count += reads - flagged;
-    return true;
+    return OnDevice::DONE;
 }
 
 void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
@@ -1171,7 +1471,19 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     }
     // nothing is written: the FASTQ text is decoded on the device when it can be (plain files, no pre-filters); a file that
     // holds anything out of the ordinary sends the whole run through the host reader below
-    if(all_silent && run_on_device(incoming_count, incoming_pf_count)) { return; }
+    if(all_silent) {
+        if(run_on_device(incoming_count, incoming_pf_count, nullptr) == OnDevice::DONE) { return; }
+    } else {
+        // every record into one uncompressed file: assembled on the device too (record_device.hpp).  An input that turns out
+        // of the ordinary part way leaves the rest of the run to the host reader and writer below.
+        DeviceText text;
+        if(plan_device_text(job, plan, m.sink, rg_by_index, ordinal_by_index, text)) {
+            if(run_on_device(incoming_count, incoming_pf_count, &text) == OnDevice::DONE) {
+                for(auto& sink : m.sink) { sink.close(); }
+                return;
+            }
+        }
+    }
     const DecoderConfig* const multiplexer = job.multiplexing_decoder >= 0 ? &job.decoder[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
     const std::vector<int>* const multiplexer_ordinal = multiplexer ? &ordinal_by_index[static_cast<size_t>(job.multiplexing_decoder)] : nullptr;
 

@@ -39,6 +39,11 @@ struct TranscodePlan {
     static TranscodePlan explicit_files(const JobConfig& job, const std::vector<std::string>& input, const std::string& sam_output);
 };
 
+// rounds and reads decoded on the device, bytes of records assembled there, runs handed to the host reader part way: since the process started
+void device_path_counters(uint64_t* counters);
+
+struct DeviceText;                     // what a run that writes its records on the device needs (transcoder.cpp, record_device.hpp)
+
 class Transcoder {
 public:
     Transcoder(DecoderSet& set, const TranscodePlan& plan, int64_t batch_capacity);
@@ -61,7 +66,12 @@ public:
 private:
     struct Impl;
     Impl* impl_;
-    bool run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count);      // report only runs: fastq_device.hpp
+    // FASTQ text decoded — and, with `text`, the output records assembled — on the device (fastq_device.hpp, record_device.hpp).
+    // NOT_TAKEN: the run goes through the host reader from its start, nothing was counted or written; DONE: the whole input
+    // went through the device; RESUMED: the host reader continues at the byte of every input file the device path stopped at
+    // (an input that turns out of the ordinary part way into a run that writes).
+    enum class OnDevice { NOT_TAKEN, DONE, RESUMED };
+    OnDevice run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count, const DeviceText* text);
 };
 
 }  // namespace phq

@@ -1,0 +1,184 @@
+"""Output records assembled on the device (csrc/record_device.hip): a job whose every written channel goes to one
+uncompressed SAM or FASTQ file has its records put together by kernels — Read::flush and Auxiliary::encode (read.h:187-237,
+auxiliary.cpp:324-354), append_corrected (sequence.h:382-398), TemplateRule::apply (transform.h:190-226), FastqRecord::encode
+(fastq.h:144-194), Channel::push (multiplex.h:198-240).  The reference's own golden SAM file is the first check (the BDGGG
+job; tests/test_gpu_parity.py holds the same file against every other route); the host writer — itself held against that
+file — is the second, byte for byte, on jobs the golden file has no case of: corrected barcodes as template tokens, `~`,
+offsets from the end, more than two output segments, FASTQ output, the outgoing filter, pre-filters, many rounds.  An input
+that turns out of the ordinary part way is handed to the host reader at the byte the device stopped at.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bdggg
+from pheniqs_amd import DecoderSet, capi, synthetic
+from test_gpu_fastq_device import _files
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(job, capacity, host, how="job", paths=None, output=None):
+    """(incoming, counter words, device path counters of the run) with the records assembled on the device or by the host"""
+    if host:
+        os.environ["PHQ_HOST_RECORDS"] = "1"
+    try:
+        before = capi.device_path_counters()
+        s = DecoderSet(job if isinstance(job, str) else json.dumps(job), device=0)
+        s.stats_reset()
+        incoming = s.transcode_job(capacity) if how == "job" else s.transcode_fastq_to_sam(paths, output, capacity)
+        words = s.stats_export()
+        s.close()
+        after = capi.device_path_counters()
+        return incoming, words, {key: after[key] - before[key] for key in after}
+    finally:
+        os.environ.pop("PHQ_HOST_RECORDS", None)
+
+
+def _records(path):
+    """the file without the @PG line (it names the program)"""
+    return b"".join(line for line in open(path, "rb").readlines() if not line.startswith(b"@PG"))
+
+
+def test_the_golden_file_from_the_device(tmp_path):
+    """valid/annotated.out byte for byte with every record assembled on the device: three input files, and the same reads
+    interleaved in one; one round each."""
+    golden = open(os.path.join(bdggg.HERE, "annotated.out.sam"), "rb").read()
+    job = bdggg.raw_job()
+    job["base input url"] = bdggg.HERE
+    job["base output url"] = str(tmp_path)
+    job["output"] = ["out.sam"]
+    incoming, _, did = _run(job, 100, host=False)
+    assert incoming == (250, 243)
+    assert did["rounds"] == 1 and did["reads"] == 250 and did["resumed"] == 0
+    mine = _records(os.path.join(str(tmp_path), "out.sam"))
+    assert mine == golden
+    assert did["record_bytes"] == sum(len(line) for line in golden.split(b"\n") if line and not line.startswith(b"@")) + 496
+    sources = [open(os.path.join(bdggg.HERE, "BDGGG_s0%d.fastq" % k)).read().split("\n") for k in (1, 2, 3)]
+    path = os.path.join(str(tmp_path), "interleaved.fastq")
+    with open(path, "w") as out:
+        for i in range(250):
+            for lines in sources:
+                out.write("\n".join(lines[4 * i:4 * i + 4]) + "\n")
+    job["input"] = [path, path, path]
+    job["output"] = ["again.sam"]
+    incoming, _, did = _run(job, 64, host=False)
+    assert incoming == (250, 243) and did["rounds"] == 1 and did["record_bytes"] > 0
+    assert _records(os.path.join(str(tmp_path), "again.sam")) == golden
+
+
+def _mixed_spec():
+    """every kind of decoder and tag: a PAMLD sample barcode, a naive and an MDD molecular barcode (RX QX OX BZ XM), a PAMLD and
+    a two segment MDD cellular barcode (CB CR CY XC); the template takes a slice from the end, the corrected sample, cellular
+    and molecular barcodes as tokens, `~` on two of them, and makes four output segments (FI, TC)"""
+    rng = np.random.default_rng(404)
+    sample = synthetic.barcode_set(rng, 24, 8)
+    umi = synthetic.barcode_set(rng, 16, 6)
+    a, b, c = synthetic.barcode_set(rng, 24, 10), synthetic.barcode_set(rng, 12, 10), synthetic.barcode_set(rng, 12, 10)
+    return {"input segment cardinality": 3,
+            "sample": synthetic.decoder_spec("pamld", [sample], ["1::8"]),
+            "molecular": [{"algorithm": "naive", "transform": {"token": ["0::8"]}}, synthetic.decoder_spec("mdd", [umi], ["0:8:14"])],
+            "cellular": [synthetic.decoder_spec("pamld", [a], ["0:14:24"]), synthetic.decoder_spec("mdd", [b, c], ["2::10", "2:10:20"], pairing="zip")],
+            "template": {"transform": {"token": ["0:24:", "s::", "c::", "m:1:", "2:-6:", "1::4", "0:24:30"], "knit": ["0", "~1:2", "3:~4", "5:~6"]}}}
+
+
+@pytest.mark.parametrize("case", ["sam_two_segments_filters", "sam_mixed_tokens", "fastq_interleaved", "outgoing_filter", "one_channel_silent"])
+def test_device_records_equal_the_host_writers(tmp_path, case):
+    directory = str(tmp_path)
+    if case in ("sam_two_segments_filters", "fastq_interleaved", "outgoing_filter", "one_channel_silent"):
+        spec = synthetic.config_spec("C2", "pamld")
+        spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+        lengths, n, capacity = (30, 8), 70001, 4096
+        if case == "sam_two_segments_filters":
+            spec["filter incoming qc fail"] = True
+            spec["min input length"] = [0, 6]
+        if case == "outgoing_filter":
+            spec["filter outgoing qc fail"] = True
+    else:
+        spec = _mixed_spec()
+        lengths, n, capacity = (40, 8, 26), 30011, 1 << 13
+    paths = _files(directory, spec, n, 5, lengths)
+    if case == "sam_two_segments_filters":
+        # a few index reads under the minimum length: the pull loop drops those reads
+        lines = open(paths[1], "rb").read().split(b"\n")
+        for i in range(0, n, 97):
+            lines[4 * i + 1] = lines[4 * i + 1][:5]
+            lines[4 * i + 3] = lines[4 * i + 3][:5]
+        open(paths[1], "wb").write(b"\n".join(lines))
+    spec["input"] = paths
+    outputs = {}
+    for host in (False, True):
+        name = ("host" if host else "device") + (".fastq" if case == "fastq_interleaved" else ".sam")
+        spec["output"] = [os.path.join(directory, name)]
+        if case == "one_channel_silent":
+            first = next(iter(spec["sample"]["codec"]))
+            spec["sample"]["codec"][first]["output"] = ["/dev/null"]
+        incoming, words, did = _run(spec, capacity, host)
+        outputs[host] = (incoming, words, _records(os.path.join(directory, name)), did)
+    device, host = outputs[False], outputs[True]
+    assert device[0] == host[0] and device[0][0] == n
+    assert np.array_equal(device[1], host[1])
+    assert device[3]["record_bytes"] > 0 and device[3]["rounds"] == -(-n // capacity) and device[3]["resumed"] == 0
+    assert host[3]["record_bytes"] == 0
+    assert len(device[2]) == len(host[2])
+    if device[2] != host[2]:
+        mine, theirs = device[2].split(b"\n"), host[2].split(b"\n")
+        for k, (a, b) in enumerate(zip(mine, theirs)):
+            assert a == b, (k, a, b)
+    assert device[2] == host[2]
+    body = b"".join(line + b"\n" for line in device[2].split(b"\n") if line and not line.startswith(b"@"))
+    if case != "fastq_interleaved":
+        assert device[3]["record_bytes"] == len(body)
+    if case == "sam_mixed_tokens":
+        text = device[2].decode()
+        for tag in ("\tFI:i:4\tTC:i:4", "\tRG:Z:", "\tBC:Z:", "\tQT:Z:", "\tXB:f:", "\tRX:Z:", "\tQX:Z:", "\tOX:Z:", "\tBZ:Z:", "\tCB:Z:", "\tCR:Z:", "\tCY:Z:", "\tXC:f:"):
+            assert tag in text, tag
+    if case == "outgoing_filter":
+        assert b"\t589\t" not in device[2] and b"\t77\t" in device[2]            # no record of a read that failed QC
+    if case == "one_channel_silent":
+        assert 0 < device[2].count(b"\n") < 2 * n                                # the silent channel's reads leave no record
+
+
+def test_an_input_out_of_the_ordinary_part_way_is_handed_to_the_host_reader(tmp_path):
+    """A carriage return in record 50 000 of 70 001, batches of 4 096 reads: twelve rounds are assembled on the device, the
+    thirteenth finds the record, and the host reader — which tolerates it, as the reference does — continues at the byte the
+    twelfth ended at.  The file and the counters are those of a run that went through the host from its start."""
+    directory = str(tmp_path)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    n, capacity = 70001, 4096
+    paths = _files(directory, spec, n, 6, (30, 8))
+    lines = open(paths[0], "rb").read().split(b"\n")
+    lines[4 * 50000 + 1] += b"\r"
+    lines[4 * 50000 + 3] += b"\r"
+    open(paths[0], "wb").write(b"\n".join(lines))
+    spec["input"] = paths
+    outputs = {}
+    for host in (False, True):
+        spec["output"] = [os.path.join(directory, "host.sam" if host else "device.sam")]
+        incoming, words, did = _run(spec, capacity, host)
+        outputs[host] = (incoming, words, _records(spec["output"][0]), did)
+    device, host = outputs[False], outputs[True]
+    assert device[3]["resumed"] == 1 and device[3]["rounds"] == 50000 // capacity and device[3]["reads"] == 50000 // capacity * capacity
+    assert device[0] == host[0] and device[0][0] == n
+    assert np.array_equal(device[1], host[1])
+    assert device[2] == host[2]
+
+
+def test_what_the_device_does_not_write(tmp_path):
+    """gzip output, channels in files of their own and quality control go through the host writer (the counters say so)"""
+    directory = str(tmp_path)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::"]}}
+    paths = _files(directory, spec, 5000, 8, (30, 8))
+    spec["input"] = paths
+    spec["output"] = [os.path.join(directory, "out.sam.gz")]
+    _, _, did = _run(spec, 2048, host=False)
+    assert did["record_bytes"] == 0 and did["rounds"] == 0
+    spec["output"] = [os.path.join(directory, "rest.sam")]
+    first = next(iter(spec["sample"]["codec"]))
+    spec["sample"]["codec"][first]["output"] = [os.path.join(directory, "first.sam")]
+    _, _, did = _run(spec, 2048, host=False)
+    assert did["record_bytes"] == 0 and did["rounds"] == 0
