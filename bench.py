@@ -108,7 +108,7 @@ def fastq_end_to_end(args, code, quality, flag, n):
     (uncompressed, to a file in the temporary directory) and the same input report only (output /dev/null: nothing is
     formatted, reference feed.h:105 NullFeed).  One file per input segment: a 50 nt template read and the index read;
     the staged rows of the pool are written back as text, so the decoder sees the same observations as the kernel
-    bench.  Host bound (parse and format on the host, classification on the GPU); never the headline value."""
+    bench.  Bound by the host's copies (files into pinned memory, text into the output) and the link; never the headline value."""
     import tempfile
     from pheniqs_amd import DecoderSet, capi, synthetic
     spec = synthetic.config_spec("C2", args.algorithm)
@@ -145,9 +145,11 @@ def fastq_end_to_end(args, code, quality, flag, n):
                 out[name]["sam_MB/s"] = os.path.getsize(target) / dt / 1e6
     s.close()
     out["note"] = ("2 uncompressed FASTQ files in memory backed storage (50 nt template + 8 nt index) -> SAM text: into a file of the same "
-                   "storage (sam_text), every record formatted and written to /dev/zero (sam_text_discarded: no page of a file to "
-                   "allocate), and report only (/dev/null: records are not formatted, reference feed.h:105 NullFeed); host threads "
-                   "parse and format, the GPU classifies")
+                   "storage (sam_text), every record assembled and written to /dev/zero (sam_text_discarded: no page of a file to "
+                   "allocate), and report only (/dev/null: records are not assembled, reference feed.h:105 NullFeed).  The FASTQ text is "
+                   "decoded and the records are assembled by kernels (fastq_device.hip, record_device.hip); host threads copy the files' "
+                   "bytes into pinned memory and the finished text into the output file")
+    out["device_path"] = capi.device_path_counters()
     return out
 
 

@@ -119,13 +119,18 @@ __device__ __forceinline__ void count_flagged(const DecodeArgs& args, bool filte
 __global__ __launch_bounds__(TILE_THREADS) void fastq_keep_kernel(DecodeArgs args) {
     __shared__ uint32_t kept_here;
     if(threadIdx.x == 0) { kept_here = 0; }
-    __syncthreads();
-    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    WaveInput bytes;
+    stage_wave_input(plan, chunk, wave_first, wave_count, (threadIdx.x >> 6) * static_cast<uint32_t>(plan.input_room), bytes);
     bool keep = false;
     bool filtered = false;
-    if(r < args.n) {
+    if(present) {
         Located at;
-        locate(args.plan, args.chunk, r, at);
+        locate(plan, chunk, bytes, r, at);
         if(at.odd) { atomicOr(args.irregular, 1u); }
         keep = !at.dropped;
         filtered = at.filtered;
@@ -141,15 +146,20 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_keep_kernel(DecodeArgs arg
 // FILTER: rows by rank among the kept reads (keep_block holds the exclusive prefix sums by now); else row r for read r
 template <bool FILTER>
 __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs args) {
-    const FastqPlan& plan = args.plan;
-    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
-    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    __shared__ uint32_t wave_kept[TILE_WAVES];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    WaveInput bytes;
+    stage_wave_input(plan, chunk, wave_first, wave_count, (threadIdx.x >> 6) * static_cast<uint32_t>(plan.input_room), bytes);
     bool wanted;
-    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
     bool filtered = false;
     if(wanted) {
         Located at;
-        locate(args.plan, args.chunk, r, at);
+        locate(plan, chunk, bytes, r, at);
         filtered = at.filtered;
         if(!FILTER && at.odd) { atomicOr(args.irregular, 1u); }
         // Rule::apply of every decoder into its plane (transform.h:142-169), zero filled past what the tokens bring
@@ -173,13 +183,13 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
                 int32_t& done = filled[token.output_segment];
                 const int32_t room = token.output_room - done;
                 const int32_t take = size < room ? size : room;
-                const uint8_t* const raw = args.chunk[plan.segment_feed[token.segment]].raw;
+                const FeedBytes text = bytes.feed(plan.segment_feed[token.segment]);
                 for(int32_t j = 0; j < take; ++j) {
                     const int32_t from = token.reverse_complement ? end - j - 1 : start + j;
-                    uint8_t code = args.bam_of_ascii[raw[at.sequence_at[token.segment] + static_cast<uint32_t>(from)]];
-                    if(token.reverse_complement) { code = args.complement_of_bam[code & 15u]; }
+                    uint8_t code = args.tables->bam_of_ascii[text(at.sequence_at[token.segment] + static_cast<uint32_t>(from))];
+                    if(token.reverse_complement) { code = args.tables->complement_of_bam[code & 15u]; }
                     row_code[token.output_offset + done + j] = code;
-                    row_quality[token.output_offset + done + j] = static_cast<uint8_t>(raw[at.quality_at[token.segment] + static_cast<uint32_t>(from)] - plan.phred_offset);
+                    row_quality[token.output_offset + done + j] = static_cast<uint8_t>(text(at.quality_at[token.segment] + static_cast<uint32_t>(from)) - plan.phred_offset);
                 }
                 done += take > 0 ? take : 0;
             }
@@ -190,6 +200,16 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
 }
 
 }  // namespace
+
+// A wave's reads by what their text takes in LDS: 64 reads of 190 bytes are 12 KiB; reads of 2 x 150 nt (700 bytes) go 16 to a wave
+void fastq_plan_waves(FastqPlan& plan, double bytes_per_read) {
+    constexpr double ROOM = 20.0 * 1024.0;
+    int32_t reads = 64;
+    while(reads > 8 && static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed > ROOM) { reads /= 2; }
+    plan.reads_per_wave = reads;
+    const double room = std::min(ROOM, static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed);
+    plan.input_room = (static_cast<int32_t>(room) + 15) & ~15;
+}
 
 int fastq_index(const FastqFeedChunk& chunk, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -211,20 +231,17 @@ int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, const int32_t*
     return static_cast<int>(hipGetLastError());
 }
 
-int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
+void fastq_fill_tables(FastqTables& tables) {
+    for(int c = 0; c < 256; ++c) { tables.bam_of_ascii[c] = ascii_to_bam(static_cast<uint8_t>(c)); }
+    for(int c = 0; c < 16; ++c) { tables.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c)); }
+}
+
+int fastq_decode(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
                  uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream) {
     if(n == 0) { return 0; }
-    // the two tables once per process: a function local static initialised by a lambda (thread safe: two host threads
-    // transcoding with two decoder sets may come here together); every call copies them into its own arguments
-    static const DecodeArgs with_tables = []() {
-        DecodeArgs filled{};
-        for(int c = 0; c < 256; ++c) { filled.bam_of_ascii[c] = ascii_to_bam(static_cast<uint8_t>(c)); }
-        for(int c = 0; c < 16; ++c) { filled.complement_of_bam[c] = reverse_complement_bam(static_cast<uint8_t>(c)); }
-        return filled;
-    }();
-    DecodeArgs call = with_tables;
-    call.plan = plan;
-    for(int f = 0; f < plan.n_feed; ++f) { call.chunk[f] = chunk[f]; }
+    DecodeArgs call;
+    call.tables = on_device;
+    call.slot = slot;
     call.n = n;
     call.capacity = capacity;
     call.base_planes = base_planes;
@@ -234,15 +251,21 @@ int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n,
     call.flagged = flagged;
     call.keep = keep;
     call.keep_block = keep_block;
-    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
+    if(plan.reads_per_wave < 1 || plan.reads_per_wave > 64 || plan.input_room < 0 || plan.input_room % 16 != 0) { return static_cast<int>(hipErrorInvalidValue); }
+    const uint32_t blocks = fastq_groups(plan, n);
+    const size_t lds = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.input_room);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    static std::atomic<uint64_t> prepared[3];
+    if(const int status = allow_lds(&fastq_keep_kernel, prepared[0], lds)) { return status; }
+    if(const int status = allow_lds(&fastq_decode_kernel<true>, prepared[1], lds)) { return status; }
+    if(const int status = allow_lds(&fastq_decode_kernel<false>, prepared[2], lds)) { return status; }
     if(plan.filtering) {
         if(keep == nullptr || keep_block == nullptr || kept == nullptr) { return static_cast<int>(hipErrorInvalidValue); }
-        hipLaunchKernelGGL(fastq_keep_kernel, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+        hipLaunchKernelGGL(fastq_keep_kernel, dim3(blocks), dim3(TILE_THREADS), lds, s, call);
         hipLaunchKernelGGL(fastq_scan_kernel, dim3(1), dim3(1024), 0, s, keep_block, blocks, kept);
-        hipLaunchKernelGGL(fastq_decode_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+        hipLaunchKernelGGL(fastq_decode_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call);
     } else {
-        hipLaunchKernelGGL(fastq_decode_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call);
+        hipLaunchKernelGGL(fastq_decode_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call);
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -55,6 +55,10 @@ struct FastqPlan {
     int32_t filter_incoming_qc_fail;
     int32_t min_length[FASTQ_MAX_FEED];
     int32_t filtering;              // either of the two
+    // how the kernels share the work out (fastq_device_inner.hpp): a wave takes `reads_per_wave` consecutive reads (64, 32, 16
+    // or 8) and copies their text into `input_room` bytes of LDS; fastq_plan_waves sets both from the files' bytes per read
+    int32_t reads_per_wave;
+    int32_t input_room;
     FastqDecoderPlan decoder[FASTQ_MAX_DECODER];
     FastqToken token[FASTQ_MAX_TOKEN];
 };
@@ -76,14 +80,28 @@ struct FastqFeedChunk {
     uint32_t* total;                // device: number of newlines found
 };
 
+// What the decode and record kernels read through a pointer, in device memory for the whole run: passed by value, the 3 KiB
+// of it were copied to every lane's scratch memory by the compiler (the kernels index them at run time) and read from there.
+struct FastqTables {
+    FastqPlan plan;
+    FastqFeedChunk chunk[2][FASTQ_MAX_FEED];     // the feeds' chunks in the two slots rounds alternate between (raw, newline)
+    uint8_t bam_of_ascii[256];
+    uint8_t complement_of_bam[16];
+};
+void fastq_fill_tables(FastqTables& tables);     // the two code tables (host)
+
+// reads_per_wave and input_room of a plan whose reads take about `bytes_per_read` bytes of the input files together
+void fastq_plan_waves(FastqPlan& plan, double bytes_per_read);
+
 // every function returns a hipError_t value; all work goes to `stream`
 int fastq_index(const FastqFeedChunk& chunk, void* stream);
 int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, const int32_t* resolution, uint32_t capacity, FastqRound* round_on_device, void* stream);
 // reads [0, n) of the round -> planes laid out for `capacity` reads; *irregular |= 1 on anything out of the ordinary;
 // *flagged += reads whose filter flag is set.  A plan that filters needs the scratch `keep` (n bytes) and `keep_block`
-// (n / 256 + 2 words) and leaves the number of rows it wrote — the reads it kept, in input order — in *kept (device);
+// (n / 32 + 2 words) and leaves the number of rows it wrote — the reads it kept, in input order — in *kept (device);
 // a plan that does not writes row r for read r and leaves *kept alone.
-int fastq_decode(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
+// `on_device` is a device copy of the tables whose plan is `plan`; the round's chunks are those of `slot`
+int fastq_decode(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
                  uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream);
 
 }  // namespace phq

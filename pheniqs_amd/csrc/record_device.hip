@@ -9,8 +9,8 @@ namespace phq {
 namespace {
 
 struct RecordArgs {
-    FastqPlan plan;
-    FastqFeedChunk chunk[FASTQ_MAX_FEED];
+    const FastqTables* tables;      // device
+    int32_t slot;
     uint32_t n;
     int64_t capacity;
     const uint8_t* base_planes;
@@ -18,33 +18,49 @@ struct RecordArgs {
     const uint8_t* keep;
     const uint32_t* keep_block;
     RecordRound round;
+    uint32_t output_room;           // bytes of LDS a wave has for the text of its reads (record_write)
 };
-static_assert(sizeof(RecordArgs) <= 4096, "kernel arguments");
 
-// the bytes of a record: counted (pass 1) or stored (pass 2)
-template <bool WRITE>
-struct Out {
-    char* at;
+// The bytes of a record: counted (pass 1), or stored (pass 2) — into the wave's LDS, from where the wave copies its reads'
+// text to the output 16 bytes a lane at a time, or straight to the output when a wave's text does not fit its room.  (Stored
+// straight from the lanes, a byte at a time to 64 lines a wave instruction, the text left at 49 GB/s.)
+struct CountOut {
+    static constexpr bool WRITES = false;
     uint32_t count;
-    __device__ __forceinline__ void put(char c) { if(WRITE) { *at++ = c; } else { ++count; } }
-    __device__ __forceinline__ void room(uint32_t bytes) { count += bytes; }      // pass 1: bytes whose values do not matter
-    __device__ __forceinline__ void literal(const char* text) { for(; *text; ++text) { put(*text); } }
-    __device__ __forceinline__ void bytes(const char* from, uint32_t size) {
-        if(WRITE) { for(uint32_t i = 0; i < size; ++i) { *at++ = from[i]; } } else { count += size; }
-    }
-    __device__ __forceinline__ void number(uint32_t value) {
-        char digits[10];
-        int n = 0;
-        do { digits[n++] = static_cast<char>('0' + value % 10u); value /= 10u; } while(value);
-        while(n > 0) { put(digits[--n]); }
-    }
+    __device__ __forceinline__ void put(char) { ++count; }
+    __device__ __forceinline__ void room(uint32_t bytes) { count += bytes; }      // bytes whose values do not matter here
 };
+struct GlobalOut {
+    static constexpr bool WRITES = true;
+    char* at;
+    __device__ __forceinline__ void put(char c) { *at++ = c; }
+    __device__ __forceinline__ void room(uint32_t) {}
+};
+struct LdsOut {
+    static constexpr bool WRITES = true;
+    uint32_t at;                    // into `staged`
+    __device__ __forceinline__ void put(char c) { staged[at++] = static_cast<uint8_t>(c); }
+    __device__ __forceinline__ void room(uint32_t) {}
+};
+template <typename W>
+__device__ __forceinline__ void put_literal(W& out, const char* text) { for(; *text; ++text) { out.put(*text); } }
+template <typename W>
+__device__ __forceinline__ void put_bytes(W& out, const char* from, uint32_t size) {
+    if(W::WRITES) { for(uint32_t i = 0; i < size; ++i) { out.put(from[i]); } } else { out.room(size); }
+}
+template <typename W>
+__device__ __forceinline__ void put_number(W& out, uint32_t value) {
+    char digits[10];
+    int n = 0;
+    do { digits[n++] = static_cast<char>('0' + value % 10u); value /= 10u; } while(value);
+    while(n > 0) { out.put(digits[--n]); }
+}
 
 // printf("%g") of a float in (0, 1]: six significant digits, round half to even on the exact binary value, trailing zeros
 // dropped, d.ddddde-XX below 1e-4 (text_format.hpp put_float_g is the host's; the values here are 1 - confidence: at least
 // 2^-53, at most 1)
-template <bool WRITE>
-__device__ void put_float_g(Out<WRITE>& out, float value) {
+template <typename W>
+__device__ void put_float_g(W& out, float value) {
     if(!(value < 1.0f)) { out.put('1'); return; }
     const uint32_t bits = __float_as_uint(value);
     const int binary_exponent = static_cast<int>((bits >> 23) & 0xffu) - 126;       // value = fraction * 2^e, fraction in [0.5, 1)
@@ -79,7 +95,7 @@ __device__ void put_float_g(Out<WRITE>& out, float value) {
         out.put('e'); out.put('-');
         const int magnitude = -exponent;
         if(magnitude < 10) { out.put('0'); }
-        out.number(static_cast<uint32_t>(magnitude));
+        put_number(out, static_cast<uint32_t>(magnitude));
         return;
     }
     out.put('0'); out.put('.');
@@ -93,6 +109,7 @@ struct ReadView {
     const RecordPlan* plan;
     uint32_t row;
     Located at;
+    const WaveInput* bytes;         // the text of the wave's reads (fastq_device_inner.hpp)
 
     __device__ __forceinline__ const uint8_t* codes(const RecordDecoder& d) const { return args->base_planes + args->capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride; }
     __device__ __forceinline__ const uint8_t* qualities(const RecordDecoder& d) const { return args->quality_planes + args->capacity * d.plane_prefix + static_cast<int64_t>(row) * d.plane_stride; }
@@ -122,15 +139,15 @@ struct ReadView {
         }
         return size;
     }
-    template <bool WRITE>
-    __device__ void put_raw(Out<WRITE>& out, int kind, bool quality) const {
+    template <typename W>
+    __device__ void put_raw(W& out, int kind, bool quality) const {
         for(int k = 0; k < plan->n_decoder; ++k) {
             const RecordDecoder& d = plan->decoder[k];
             if(d.kind != kind || d.plane_stride == 0) { continue; }
             const uint8_t* const from = quality ? qualities(d) : codes(d);
             for(int s = 0; s < d.segment_cardinality; ++s) {
                 const int32_t len = observed(d, s);
-                if(!WRITE) { out.room(static_cast<uint32_t>(len)); continue; }
+                if(!W::WRITES) { out.room(static_cast<uint32_t>(len)); continue; }
                 for(int32_t i = 0; i < len; ++i) {
                     const uint8_t value = from[d.segment_offset[s] + i];
                     out.put(quality ? static_cast<char>(value + 33) : plan->text_of_bam[value & 15u]);
@@ -177,9 +194,9 @@ struct ReadView {
         }
         return false;
     }
-    template <bool WRITE>
-    __device__ void put_corrected(Out<WRITE>& out, int kind, bool quality) const {
-        if(!WRITE) { out.room(corrected_size(kind)); return; }
+    template <typename W>
+    __device__ void put_corrected(W& out, int kind, bool quality) const {
+        if(!W::WRITES) { out.room(corrected_size(kind)); return; }
         corrected(kind, -1, [&](uint8_t code, uint8_t q) { out.put(quality ? static_cast<char>(q + 33) : plan->text_of_bam[code & 15u]); });
     }
     // the per type confidence as the decoders' wrappers leave it (pamld.cpp:133-180; read.h:176-183,279-285)
@@ -205,18 +222,18 @@ struct ReadView {
         for(int t = plan->out_first[o]; t < plan->out_first[o + 1]; ++t) { int32_t start, end; size += token_size(plan->token[plan->out_token[t]], start, end); }
         return size;
     }
-    template <bool WRITE>
-    __device__ void put_segment(Out<WRITE>& out, int o, bool quality) const {
+    template <typename W>
+    __device__ void put_segment(W& out, int o, bool quality) const {
         for(int t = plan->out_first[o]; t < plan->out_first[o + 1]; ++t) {
             const RecordToken& token = plan->token[plan->out_token[t]];
             int32_t start, end;
             const uint32_t size = token_size(token, start, end);
-            if(!WRITE) { out.room(size); continue; }
+            if(!W::WRITES) { out.room(size); continue; }
             if(token.source >= 0) {
-                const uint8_t* const raw = args->chunk[args->plan.segment_feed[token.source]].raw;
-                const uint8_t* const from = raw + (quality ? at.quality_at[token.source] : at.sequence_at[token.source]);
+                const FeedBytes text = bytes->feed(args->tables->plan.segment_feed[token.source]);
+                const uint32_t from = quality ? at.quality_at[token.source] : at.sequence_at[token.source];
                 for(uint32_t i = 0; i < size; ++i) {
-                    const uint8_t c = from[token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i)];
+                    const uint8_t c = text(from + static_cast<uint32_t>(token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i)));
                     out.put(quality ? static_cast<char>(c + plan->quality_shift) : token.reverse_complement ? plan->complement_text[c] : plan->canonical_text[c]);
                 }
             } else {
@@ -234,26 +251,26 @@ struct ReadView {
 };
 
 // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
-template <bool WRITE>
-__device__ void put_tags(Out<WRITE>& out, const ReadView& read, int group, const double (&confidence)[3], const uint32_t (&raw_size)[3], const uint32_t (&corrected_size)[3]) {
+template <typename W>
+__device__ void put_tags(W& out, const ReadView& read, int group, const double (&confidence)[3], const uint32_t (&raw_size)[3], const uint32_t (&corrected_size)[3]) {
     const RecordPlan& plan = *read.plan;
     if(group >= 0 && group < plan.n_group) {
         const int32_t first = plan.ints[plan.group_at + group], last = plan.ints[plan.group_at + group + 1];
-        if(last > first) { out.literal("\tRG:Z:"); out.bytes(reinterpret_cast<const char*>(plan.bytes) + first, static_cast<uint32_t>(last - first)); }
+        if(last > first) { put_literal(out, "\tRG:Z:"); put_bytes(out, reinterpret_cast<const char*>(plan.bytes) + first, static_cast<uint32_t>(last - first)); }
     }
-    if(raw_size[0]) { out.literal("\tBC:Z:"); read.put_raw(out, 0, false); out.literal("\tQT:Z:"); read.put_raw(out, 0, true); }
-    if(confidence[0] > 0 && confidence[0] < 1) { out.literal("\tXB:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[0])); }
-    if(corrected_size[1]) { out.literal("\tRX:Z:"); read.put_corrected(out, 1, false); out.literal("\tQX:Z:"); read.put_corrected(out, 1, true); }
-    if(raw_size[1]) { out.literal("\tOX:Z:"); read.put_raw(out, 1, false); out.literal("\tBZ:Z:"); read.put_raw(out, 1, true); }
-    if(confidence[1] > 0 && confidence[1] < 1) { out.literal("\tXM:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[1])); }
-    if(corrected_size[2]) { out.literal("\tCB:Z:"); read.put_corrected(out, 2, false); }
-    if(raw_size[2]) { out.literal("\tCR:Z:"); read.put_raw(out, 2, false); out.literal("\tCY:Z:"); read.put_raw(out, 2, true); }
-    if(confidence[2] > 0 && confidence[2] < 1) { out.literal("\tXC:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[2])); }
+    if(raw_size[0]) { put_literal(out, "\tBC:Z:"); read.put_raw(out, 0, false); put_literal(out, "\tQT:Z:"); read.put_raw(out, 0, true); }
+    if(confidence[0] > 0 && confidence[0] < 1) { put_literal(out, "\tXB:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[0])); }
+    if(corrected_size[1]) { put_literal(out, "\tRX:Z:"); read.put_corrected(out, 1, false); put_literal(out, "\tQX:Z:"); read.put_corrected(out, 1, true); }
+    if(raw_size[1]) { put_literal(out, "\tOX:Z:"); read.put_raw(out, 1, false); put_literal(out, "\tBZ:Z:"); read.put_raw(out, 1, true); }
+    if(confidence[1] > 0 && confidence[1] < 1) { put_literal(out, "\tXM:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[1])); }
+    if(corrected_size[2]) { put_literal(out, "\tCB:Z:"); read.put_corrected(out, 2, false); }
+    if(raw_size[2]) { put_literal(out, "\tCR:Z:"); read.put_raw(out, 2, false); put_literal(out, "\tCY:Z:"); read.put_raw(out, 2, true); }
+    if(confidence[2] > 0 && confidence[2] < 1) { put_literal(out, "\tXC:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[2])); }
 }
 
 // every record of one read, in output segment order
-template <bool WRITE>
-__device__ void put_read(Out<WRITE>& out, const ReadView& read) {
+template <typename W>
+__device__ void put_read(W& out, const ReadView& read) {
     const RecordPlan& plan = *read.plan;
     // Multiplexer::push -> Channel::push (multiplex.h:198-240): the channel is the multiplexing decoder's barcode
     int channel = 0;
@@ -274,36 +291,40 @@ __device__ void put_read(Out<WRITE>& out, const ReadView& read) {
     read.confidences(confidence);
     const uint32_t raw_size[3] = {read.raw_size(0), read.raw_size(1), read.raw_size(2)};
     const uint32_t corrected_size[3] = {read.corrected_size(0), read.corrected_size(1), read.corrected_size(2)};
-    const char* const name = reinterpret_cast<const char*>(read.args->chunk[read.args->plan.segment_feed[0]].raw) + read.at.name_at;
+    const FeedBytes name_text = read.bytes->feed(read.args->tables->plan.segment_feed[0]);
+    auto put_name = [&]() {
+        if(!W::WRITES) { out.room(read.at.name_size); return; }
+        for(uint32_t i = 0; i < read.at.name_size; ++i) { out.put(static_cast<char>(name_text(read.at.name_at + i))); }
+    };
     for(int o = 0; o < plan.n_out; ++o) {
         if(plan.fastq) {
             // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
             out.put('@');
-            out.bytes(name, read.at.name_size);
+            put_name();
             out.put(' ');
             if(plan.illumina_comment) {
-                out.number(static_cast<uint32_t>(o + 1));
-                out.literal(qcfail ? ":Y:0:" : ":N:0:");
+                put_number(out, static_cast<uint32_t>(o + 1));
+                put_literal(out, qcfail ? ":Y:0:" : ":N:0:");
                 read.put_raw(out, 0, false);
             }
             out.put('\n');
             read.put_segment(out, o, false);
-            out.literal("\n+\n");
+            put_literal(out, "\n+\n");
             read.put_segment(out, o, true);
             out.put('\n');
             continue;
         }
-        out.bytes(name, read.at.name_size);
-        out.bytes(plan.columns[o][qcfail ? 1 : 0], static_cast<uint32_t>(plan.columns_size[o][qcfail ? 1 : 0]));
-        if(read.bases_of(o) == 0) { out.literal("*\t*"); }
+        put_name();
+        put_bytes(out, plan.columns[o][qcfail ? 1 : 0], static_cast<uint32_t>(plan.columns_size[o][qcfail ? 1 : 0]));
+        if(read.bases_of(o) == 0) { put_literal(out, "*\t*"); }
         else {
             read.put_segment(out, o, false);
             out.put('\t');
             read.put_segment(out, o, true);
         }
         if(plan.n_out > 2) {
-            out.literal("\tFI:i:"); out.number(static_cast<uint32_t>(o + 1));
-            out.literal("\tTC:i:"); out.number(static_cast<uint32_t>(plan.n_out));
+            put_literal(out, "\tFI:i:"); put_number(out, static_cast<uint32_t>(o + 1));
+            put_literal(out, "\tTC:i:"); put_number(out, static_cast<uint32_t>(plan.n_out));
         }
         put_tags(out, read, group, confidence, raw_size, corrected_size);
         out.put('\n');
@@ -313,25 +334,31 @@ __device__ void put_read(Out<WRITE>& out, const ReadView& read) {
 // pass 1: the bytes of every read's records, and their sum per workgroup
 template <bool FILTER>
 __global__ __launch_bounds__(TILE_THREADS) void record_size_kernel(RecordArgs args) {
-    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
+    __shared__ uint32_t wave_kept[TILE_WAVES];
     __shared__ unsigned long long block_bytes;
     if(threadIdx.x == 0) { block_bytes = 0; }
-    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    WaveInput bytes_of;
+    stage_wave_input(plan, chunk, wave_first, wave_count, (threadIdx.x >> 6) * static_cast<uint32_t>(plan.input_room), bytes_of);
     bool wanted;
-    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
-    if(!FILTER) { __syncthreads(); }
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
     uint32_t bytes = 0;
     if(wanted) {
         ReadView read;
         read.args = &args;
         read.plan = args.round.plan;
         read.row = row;
-        locate(args.plan, args.chunk, r, read.at);
-        Out<false> out{nullptr, 0};
+        read.bytes = &bytes_of;
+        locate(plan, chunk, bytes_of, r, read.at);
+        CountOut out{0};
         put_read(out, read);
         bytes = out.count;
     }
-    if(r < args.n) { args.round.size[r] = bytes; }
+    if(present) { args.round.size[r] = bytes; }
     uint32_t sum = bytes;
     for(int step = 32; step > 0; step >>= 1) { sum += __shfl_down(sum, step); }
     if((threadIdx.x & 63) == 0 && sum) { atomicAdd(&block_bytes, static_cast<unsigned long long>(sum)); }
@@ -365,39 +392,73 @@ __global__ __launch_bounds__(1024) void record_scan_kernel(unsigned long long* b
     if(threadIdx.x == 0) { *total = carried; }
 }
 
-// pass 2: the text, every read's records where the scan put them
+// pass 2: the text, every read's records where the scan put them.  A wave's reads are consecutive in the output: it puts
+// their text together in LDS — at the offset that gives LDS and output addresses the same remainder by 16 — and copies it out
+// as whole units of 16 bytes a lane, the ragged ends byte by byte.
 template <bool FILTER>
 __global__ __launch_bounds__(TILE_THREADS) void record_write_kernel(RecordArgs args) {
-    __shared__ uint32_t wave_kept[TILE_THREADS / 64];
-    __shared__ uint32_t wave_bytes[TILE_THREADS / 64];
-    const uint32_t r = blockIdx.x * TILE_THREADS + threadIdx.x;
+    __shared__ uint32_t wave_kept[TILE_WAVES];
+    __shared__ uint32_t wave_bytes[TILE_WAVES];
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave_room = static_cast<uint32_t>(plan.input_room) + args.output_room + 16u;
+    WaveInput bytes_of;
+    stage_wave_input(plan, chunk, wave_first, wave_count, wave * wave_room, bytes_of);
     bool wanted;
-    const uint32_t row = row_of<FILTER>(r, r < args.n, args.keep, args.keep_block, wave_kept, wanted);
-    const uint32_t own = r < args.n ? args.round.size[r] : 0u;
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
+    const uint32_t own = present ? args.round.size[r] : 0u;
     uint32_t inclusive = own;
     for(int step = 1; step < 64; step <<= 1) {
         const uint32_t below = __shfl_up(inclusive, step);
-        if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+        if(static_cast<int>(lane) >= step) { inclusive += below; }
     }
-    if((threadIdx.x & 63) == 63) { wave_bytes[threadIdx.x >> 6] = inclusive; }
+    const uint32_t wave_total = static_cast<uint32_t>(__shfl(static_cast<int>(inclusive), 63));
+    if(lane == 63) { wave_bytes[wave] = inclusive; }
     __syncthreads();
-    unsigned long long place = args.round.block[blockIdx.x] + inclusive - own;
-    for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { place += wave_bytes[w]; }
-    if(!wanted || own == 0) { return; }
-    ReadView read;
-    read.args = &args;
-    read.plan = args.round.plan;
-    read.row = row;
-    locate(args.plan, args.chunk, r, read.at);
-    Out<true> out{args.round.text + place, 0};
-    put_read(out, read);
+    unsigned long long wave_place = args.round.block[blockIdx.x];
+    for(uint32_t w = 0; w < wave; ++w) { wave_place += wave_bytes[w]; }
+    char* const wave_text = args.round.text + wave_place;
+    const uint32_t skew = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(wave_text)) & 15u;
+    const bool through_lds = wave_total + skew <= args.output_room + 16u;
+    const uint32_t out_at = wave * wave_room + static_cast<uint32_t>(plan.input_room);       // a multiple of 16
+    if(wanted && own != 0) {
+        ReadView read;
+        read.args = &args;
+        read.plan = args.round.plan;
+        read.row = row;
+        read.bytes = &bytes_of;
+        locate(plan, chunk, bytes_of, r, read.at);
+        if(through_lds) {
+            LdsOut out{out_at + skew + inclusive - own};
+            put_read(out, read);
+        } else {
+            GlobalOut out{wave_text + (inclusive - own)};
+            put_read(out, read);
+        }
+    }
+    if(!through_lds || wave_total == 0) { return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t head = min(wave_total, (16u - skew) & 15u);
+    if(lane < head) { wave_text[lane] = static_cast<char>(staged[out_at + skew + lane]); }
+    const uint32_t units = (wave_total - head) >> 4;
+    for(uint32_t u = lane; u < units; u += 64u) {
+        reinterpret_cast<uint4*>(wave_text + head)[u] = *reinterpret_cast<const uint4*>(&staged[out_at + skew + head + 16u * u]);
+    }
+    const uint32_t tail_at = head + 16u * units;
+    if(lane < wave_total - tail_at) { wave_text[tail_at + lane] = static_cast<char>(staged[out_at + skew + tail_at + lane]); }
 }
 
-RecordArgs arguments_of(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
-                        const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round) {
+RecordArgs arguments_of(const FastqTables* on_device, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                        const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, uint32_t output_room) {
     RecordArgs call;
-    call.plan = plan;
-    for(int f = 0; f < FASTQ_MAX_FEED; ++f) { call.chunk[f] = f < plan.n_feed ? chunk[f] : FastqFeedChunk{}; }
+    call.tables = on_device;
+    call.slot = slot;
     call.n = n;
     call.capacity = capacity;
     call.base_planes = base_planes;
@@ -405,32 +466,48 @@ RecordArgs arguments_of(const FastqPlan& plan, const FastqFeedChunk* chunk, uint
     call.keep = keep;
     call.keep_block = keep_block;
     call.round = round;
+    call.output_room = output_room;
     return call;
+}
+
+// LDS a wave of record_write has for its reads' text: what the CU's 160 KiB leave four waves beside their input
+uint32_t output_room_of(const FastqPlan& plan) {
+    const int32_t room = (152 * 1024) / TILE_WAVES - plan.input_room - 16;
+    return static_cast<uint32_t>(std::max(room, 0) & ~15);
 }
 
 }  // namespace
 
-int record_sizes(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+int record_sizes(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
+    const uint32_t blocks = n > 0 ? fastq_groups(plan, n) : 0u;
     if(blocks > 0) {
-        const RecordArgs call = arguments_of(plan, chunk, n, capacity, base_planes, quality_planes, keep, keep_block, round);
-        if(plan.filtering) { hipLaunchKernelGGL(record_size_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
-        else { hipLaunchKernelGGL(record_size_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+        const RecordArgs call = arguments_of(on_device, slot, n, capacity, base_planes, quality_planes, keep, keep_block, round, 0);
+        const size_t lds = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.input_room);
+        static std::atomic<uint64_t> prepared[2];
+        if(const int status = allow_lds(&record_size_kernel<true>, prepared[0], lds)) { return status; }
+        if(const int status = allow_lds(&record_size_kernel<false>, prepared[1], lds)) { return status; }
+        if(plan.filtering) { hipLaunchKernelGGL(record_size_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+        else { hipLaunchKernelGGL(record_size_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     }
     hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, s, round.block, blocks, round.total);
     return static_cast<int>(hipGetLastError());
 }
 
-int record_write(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream) {
-    const uint32_t blocks = (n + TILE_THREADS - 1u) / TILE_THREADS;
-    if(blocks == 0) { return 0; }
-    const RecordArgs call = arguments_of(plan, chunk, n, capacity, base_planes, quality_planes, keep, keep_block, round);
+    if(n == 0) { return 0; }
+    const uint32_t blocks = fastq_groups(plan, n);
+    const uint32_t output_room = output_room_of(plan);
+    const RecordArgs call = arguments_of(on_device, slot, n, capacity, base_planes, quality_planes, keep, keep_block, round, output_room);
+    const size_t lds = static_cast<size_t>(TILE_WAVES) * (static_cast<size_t>(plan.input_room) + output_room + 16u);
+    static std::atomic<uint64_t> prepared[2];
+    if(const int status = allow_lds(&record_write_kernel<true>, prepared[0], lds)) { return status; }
+    if(const int status = allow_lds(&record_write_kernel<false>, prepared[1], lds)) { return status; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if(plan.filtering) { hipLaunchKernelGGL(record_write_kernel<true>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
-    else { hipLaunchKernelGGL(record_write_kernel<false>, dim3(blocks), dim3(TILE_THREADS), 0, s, call); }
+    if(plan.filtering) { hipLaunchKernelGGL(record_write_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    else { hipLaunchKernelGGL(record_write_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     return static_cast<int>(hipGetLastError());
 }
 

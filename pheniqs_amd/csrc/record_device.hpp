@@ -84,10 +84,10 @@ struct RecordRound {
 };
 
 // every function returns a hipError_t value; all work goes to `stream`.  `keep` / `keep_block` are what fastq_decode left
-// (a plan that filters), rows are the compacted ones the planes and results hold.
-int record_sizes(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+// (a plan that filters), rows are the compacted ones the planes and results hold; `on_device`, `plan`, `slot` as for fastq_decode.
+int record_sizes(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
-int record_write(const FastqPlan& plan, const FastqFeedChunk* chunk, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
 
 }  // namespace phq

@@ -836,10 +836,11 @@ struct DeviceFastqCache {
     DevResult* result = nullptr;
     uint32_t* word = nullptr;
     uint8_t* keep = nullptr;                       // device: a job with pre-filters: which reads of the round are decoded
-    uint32_t* keep_block = nullptr;                // device: kept reads per 256, then their prefix sums
+    uint32_t* keep_block = nullptr;                // device: kept reads per workgroup's reads (at least 32), then their prefix sums
     uint32_t* kept_device = nullptr;
     uint32_t* kept_host = nullptr;                 // pinned
     hipStream_t stream = nullptr;
+    FastqTables* tables = nullptr;                 // device: the plan, the chunks of both slots, the code tables (the kernels read them through this)
     // a run that writes: the records' text is assembled on the device (record_device.hpp) and leaves on a stream of its own
     RecordPlan* record_plan = nullptr;             // device
     int32_t* record_ints = nullptr;                // device
@@ -847,7 +848,7 @@ struct DeviceFastqCache {
     size_t record_ints_room = 0, record_bytes_room = 0;
     int64_t record_capacity = 0;
     uint32_t* record_size = nullptr;               // device: [capacity]
-    unsigned long long* record_block = nullptr;    // device: [capacity / 256 + 2]
+    unsigned long long* record_block = nullptr;    // device: [capacity / 32 + 2]
     unsigned long long* record_total = nullptr;    // device
     struct RoundStatus { unsigned long long text_bytes; unsigned long long flagged; uint32_t irregular; uint32_t kept; };
     RoundStatus* status_host = nullptr;            // pinned
@@ -858,6 +859,7 @@ struct DeviceFastqCache {
     hipEvent_t written[2] = {nullptr, nullptr};    // the round's text is in text_device[b]
     hipEvent_t copied[2] = {nullptr, nullptr};     // ... and in text_host[b]
     ~DeviceFastqCache() {
+        (void)hipFree(tables);
         (void)hipFree(record_plan); (void)hipFree(record_ints); (void)hipFree(record_bytes); (void)hipFree(record_size); (void)hipFree(record_block); (void)hipFree(record_total);
         if(status_host) { (void)hipHostFree(status_host); }
         for(int b = 0; b < 2; ++b) {
@@ -1097,6 +1099,12 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         p.bytes_per_record = 4.0 * static_cast<double>(got) / static_cast<double>(lines);
     }
 
+    {
+        // a wave's share of the reads, by what their text takes in its LDS
+        double bytes_per_read = 0;
+        for(int32_t f = 0; f < n_feed; ++f) { bytes_per_read += file[static_cast<size_t>(f)].bytes_per_record * device_plan.feed_resolution[f]; }
+        fastq_plan_waves(device_plan, bytes_per_read);
+    }
     device_check(hipSetDevice(m.set.device()), "hipSetDevice");
     if(!m.set.device_fastq_cache) { m.set.device_fastq_cache = std::make_shared<DeviceFastqCache>(); }
     DeviceFastqCache& c = *static_cast<DeviceFastqCache*>(m.set.device_fastq_cache.get());
@@ -1114,7 +1122,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         device_check(hipMalloc(reinterpret_cast<void**>(&c.word), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
         (void)hipFree(c.keep); (void)hipFree(c.keep_block); c.keep = nullptr; c.keep_block = nullptr;
         device_check(hipMalloc(reinterpret_cast<void**>(&c.keep), static_cast<size_t>(capacity)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep_block), (static_cast<size_t>(capacity) / 256 + 2) * sizeof(uint32_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep_block), (static_cast<size_t>(capacity) / 32 + 2) * sizeof(uint32_t)), "hipMalloc");
         c.capacity = capacity;
     }
     if(c.total == nullptr) {
@@ -1141,7 +1149,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         if(c.record_capacity < capacity) {
             (void)hipFree(c.record_size); (void)hipFree(c.record_block); c.record_size = nullptr; c.record_block = nullptr; c.record_capacity = 0;
             device_check(hipMalloc(reinterpret_cast<void**>(&c.record_size), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_block), (static_cast<size_t>(capacity) / 256 + 2) * sizeof(unsigned long long)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_block), (static_cast<size_t>(capacity) / 32 + 2) * sizeof(unsigned long long)), "hipMalloc");
             c.record_capacity = capacity;
         }
         if(c.record_ints_room < text->ints.size()) {
@@ -1181,11 +1189,37 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             c.raw_bytes[f] = chunk_bytes[f];
         }
     }
+    {
+        // what the kernels read through a pointer: the plan, where the chunks of either slot are, the code tables
+        FastqTables tables;
+        std::memset(&tables, 0, sizeof(tables));
+        tables.plan = device_plan;
+        fastq_fill_tables(tables);
+        for(int s = 0; s < 2; ++s) {
+            for(int32_t f = 0; f < n_feed; ++f) {
+                FastqFeedChunk& at = tables.chunk[s][f];
+                at.raw = c.raw[s][f];
+                at.newline = c.newline[s][f];
+                at.newline_capacity = static_cast<uint32_t>(chunk_bytes[f] / 8 + 1024);
+                at.block_count = c.block_count[s][f];
+                at.total = c.total + s * FASTQ_MAX_FEED + f;
+            }
+        }
+        if(c.tables == nullptr) { device_check(hipMalloc(reinterpret_cast<void**>(&c.tables), sizeof(FastqTables)), "hipMalloc"); }
+        device_check(hipMemcpy(c.tables, &tables, sizeof(FastqTables), hipMemcpyHostToDevice), "hipMemcpy");
+    }
     hipStream_t stream = c.stream;
     // the counter buffer as it is now: a run that turns out to need the host reader starts over from it
     device_check(hipMemcpyAsync(c.counters_before, m.set.stats_device_pointer(), static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
     device_check(hipMemsetAsync(c.irregular, 0, sizeof(uint32_t), stream), "hipMemsetAsync");
     device_check(hipMemsetAsync(c.flagged, 0, sizeof(unsigned long long), stream), "hipMemsetAsync");
+    int slot = 0;
+    int buffer = 0;                                  // which pinned buffer of a feed this round's bytes are in
+    bool ahead_valid[FASTQ_MAX_FEED] = {false};
+    size_t ahead_start[FASTQ_MAX_FEED] = {0}, ahead_bytes[FASTQ_MAX_FEED] = {0};
+    size_t source_bytes[FASTQ_MAX_FEED] = {0};
+    const int threads = host_threads();
+    std::future<void> ahead_task;                    // reads the next round's bytes while this one is on the device; declared after what it touches
     uint64_t reads = 0;
     unsigned long long flagged_so_far = 0;          // a run that writes: the reads of the finished rounds whose filter flag is set
     // a run that writes: the text of the rounds leaves in order on threads of its own, two rounds in flight
@@ -1196,6 +1230,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     // from its start.  With text the finished rounds are in the file: the host reader takes over at the bytes they end at.
     auto give_up = [&]() {
         (void)hipStreamSynchronize(stream);
+        if(ahead_task.valid()) { ahead_task.wait(); }
         if(text == nullptr) {
             (void)hipMemcpy(m.set.stats_device_pointer(), c.counters_before, static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice);
             return OnDevice::NOT_TAKEN;
@@ -1207,13 +1242,8 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         ++device_resumed;
         return OnDevice::RESUMED;
     };
-    int slot = 0;
-    int buffer = 0;                                  // which pinned buffer of a feed this round's bytes are in
-    bool ahead_valid[FASTQ_MAX_FEED] = {false};
-    size_t ahead_start[FASTQ_MAX_FEED] = {0}, ahead_bytes[FASTQ_MAX_FEED] = {0};
-    size_t source_bytes[FASTQ_MAX_FEED] = {0};
-    const int threads = host_threads();
     while(true) {
+        if(ahead_task.valid()) { ahead_task.get(); }
         bool any_left = false;
         FastqFeedChunk chunk[FASTQ_MAX_FEED];
         for(int32_t f = 0; f < n_feed; ++f) {
@@ -1258,33 +1288,45 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         if(!any_left) { break; }
         device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, device_plan.feed_resolution, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
         device_check(hipMemcpyAsync(c.round_host, c.round_device, sizeof(FastqRound), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
-        // While the round's bytes cross the link and are indexed, the host reads AHEAD: where the next round starts is only
+        // While the round is on the device the host reads AHEAD, on threads of its own: where the next round starts is only
         // known once this one is planned (it takes whole records), but never before 7/8 of this round's bytes — a round's
         // bytes are sized for the capacity plus 3 % — so the next round's bytes are read from there on into the other
-        // pinned buffer, and the round finds them at whatever offset its start turns out to have.
+        // pinned buffer, and the round finds them at whatever offset its start turns out to have.  (Read between this
+        // round's upload and its plan only, the files' bytes — 5.5 ms a round of 1 M reads out of the page cache — and
+        // the round's kernels took turns: 7 ms a round report only, 155 Mreads/s.)
         const int other = buffer ^ 1;
+        struct Ahead { size_t start, count; } planned[FASTQ_MAX_FEED];
         for(int32_t f = 0; f < n_feed; ++f) {
-            PlainFile& p = file[static_cast<size_t>(f)];
+            const PlainFile& p = file[static_cast<size_t>(f)];
             ahead_valid[f] = false;
-            const size_t start = p.position + (source_bytes[f] - source_bytes[f] / 8);
-            if(source_bytes[f] < (size_t(1) << 20) || start >= p.size) { continue; }                 // a small file, or its end: nothing to gain
-            const size_t count = std::min(p.size - start, chunk_bytes[f] - 1 + source_bytes[f] / 8 + 4096);
-            std::atomic<bool> failed{false};
-            parallel_ranges(static_cast<int64_t>((count + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
-                const size_t from = static_cast<size_t>(first) << 20;
-                const size_t until = std::min(count, static_cast<size_t>(last) << 20);
-                size_t done = from;
-                while(done < until) {
-                    const ssize_t got = ::pread(p.descriptor, c.pinned[other][f] + done, until - done, static_cast<off_t>(start + done));
-                    if(got <= 0) { failed = true; return; }
-                    done += static_cast<size_t>(got);
-                }
-            });
-            if(failed) { continue; }
-            ahead_valid[f] = true;
-            ahead_start[f] = start;
-            ahead_bytes[f] = count;
+            planned[f].start = p.position + (source_bytes[f] - source_bytes[f] / 8);
+            planned[f].count = 0;
+            if(source_bytes[f] < (size_t(1) << 20) || planned[f].start >= p.size) { continue; }      // a small file, or its end: nothing to gain
+            planned[f].count = std::min(p.size - planned[f].start, chunk_bytes[f] - 1 + source_bytes[f] / 8 + 4096);
         }
+        ahead_task = std::async(std::launch::async, [&file, &c, &ahead_valid, &ahead_start, &ahead_bytes, n_feed, other, threads, planned]() {
+            for(int32_t f = 0; f < n_feed; ++f) {
+                const size_t start = planned[f].start, count = planned[f].count;
+                if(count == 0) { continue; }
+                const int descriptor = file[static_cast<size_t>(f)].descriptor;
+                uint8_t* const target = c.pinned[other][f];
+                std::atomic<bool> failed{false};
+                parallel_ranges(static_cast<int64_t>((count + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
+                    const size_t from = static_cast<size_t>(first) << 20;
+                    const size_t until = std::min(count, static_cast<size_t>(last) << 20);
+                    size_t done = from;
+                    while(done < until) {
+                        const ssize_t got = ::pread(descriptor, target + done, until - done, static_cast<off_t>(start + done));
+                        if(got <= 0) { failed = true; return; }
+                        done += static_cast<size_t>(got);
+                    }
+                });
+                if(failed) { continue; }
+                ahead_valid[f] = true;
+                ahead_start[f] = start;
+                ahead_bytes[f] = count;
+            }
+        });
         device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // this round's pinned buffers are free again, the round is known
         buffer = other;
         const FastqRound round = *c.round_host;
@@ -1301,7 +1343,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
-        device_check(static_cast<hipError_t>(fastq_decode(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
+        device_check(static_cast<hipError_t>(fastq_decode(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
                                                           c.keep, c.keep_block, c.kept_device, stream)), "fastq_decode");
         uint32_t decoded = round.records;
         if(text != nullptr) {
@@ -1335,7 +1377,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             record.block = c.record_block;
             record.total = c.record_total;
             record.text = nullptr;
-            device_check(static_cast<hipError_t>(record_sizes(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
+            device_check(static_cast<hipError_t>(record_sizes(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
             device_check(hipMemcpyAsync(&c.status_host->text_bytes, c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
             const size_t bytes = static_cast<size_t>(c.status_host->text_bytes);
@@ -1349,7 +1391,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 }
                 device_check(hipStreamWaitEvent(stream, c.copied[b], 0), "hipStreamWaitEvent");       // text_device[b] has left (two rounds ago)
                 record.text = c.text_device[b];
-                device_check(static_cast<hipError_t>(record_write(device_plan, chunk, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
+                device_check(static_cast<hipError_t>(record_write(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
                 device_check(hipEventRecord(c.written[b], stream), "hipEventRecord");
                 if(buffer_drained[b].valid()) { buffer_drained[b].get(); }                            // text_host[b] is in the file
                 if(c.text_host_room[b] < bytes) {
