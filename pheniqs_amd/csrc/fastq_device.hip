@@ -1,6 +1,8 @@
 // FASTQ text -> decoder planes on the device: see fastq_device.hpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fastq_device_inner.hpp"
 
 namespace phq {
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
 void fastq_plan_waves(FastqPlan& plan, double bytes_per_read) {
     constexpr double ROOM = 20.0 * 1024.0;
     int32_t reads = 64;
+    if(const char* text = std::getenv("PHQ_FASTQ_READS_PER_WAVE")) { reads = std::max(8, std::min(64, std::atoi(text))); }      // sweeps
     while(reads > 8 && static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed > ROOM) { reads /= 2; }
     plan.reads_per_wave = reads;
     const double room = std::min(ROOM, static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed);

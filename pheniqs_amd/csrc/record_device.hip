@@ -1,6 +1,8 @@
 // Output records assembled on the device: see record_device.hpp.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "fastq_device_inner.hpp"
 #include "record_device.hpp"
 
@@ -232,9 +234,22 @@ struct ReadView {
             if(token.source >= 0) {
                 const FeedBytes text = bytes->feed(args->tables->plan.segment_feed[token.source]);
                 const uint32_t from = quality ? at.quality_at[token.source] : at.sequence_at[token.source];
-                for(uint32_t i = 0; i < size; ++i) {
-                    const uint8_t c = text(from + static_cast<uint32_t>(token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i)));
-                    out.put(quality ? static_cast<char>(c + plan->quality_shift) : token.reverse_complement ? plan->complement_text[c] : plan->canonical_text[c]);
+                // four bytes a trip: their reads, then their table lookups, are in flight together (one byte a trip is a chain
+                // of an LDS read, a table read and an LDS write, and a wave has nothing else to do while it waits)
+                const uint32_t first = from + static_cast<uint32_t>(token.reverse_complement ? end - 1 : start);
+                const uint32_t step = token.reverse_complement ? ~0u : 1u;       // - 1 or + 1
+                const char* const table = token.reverse_complement ? plan->complement_text : plan->canonical_text;
+                const char shift = static_cast<char>(plan->quality_shift);
+                uint32_t i = 0;
+                for(; i + 4u <= size; i += 4u) {
+                    const uint8_t c0 = text(first + step * i), c1 = text(first + step * (i + 1u)), c2 = text(first + step * (i + 2u)), c3 = text(first + step * (i + 3u));
+                    const char t0 = quality ? static_cast<char>(c0 + shift) : table[c0], t1 = quality ? static_cast<char>(c1 + shift) : table[c1];
+                    const char t2 = quality ? static_cast<char>(c2 + shift) : table[c2], t3 = quality ? static_cast<char>(c3 + shift) : table[c3];
+                    out.put(t0); out.put(t1); out.put(t2); out.put(t3);
+                }
+                for(; i < size; ++i) {
+                    const uint8_t c = text(first + step * i);
+                    out.put(quality ? static_cast<char>(c + shift) : table[c]);
                 }
             } else {
                 const int kind = token.source == -1 ? 0 : token.source == -2 ? 2 : 1;
@@ -294,7 +309,12 @@ __device__ void put_read(W& out, const ReadView& read) {
     const FeedBytes name_text = read.bytes->feed(read.args->tables->plan.segment_feed[0]);
     auto put_name = [&]() {
         if(!W::WRITES) { out.room(read.at.name_size); return; }
-        for(uint32_t i = 0; i < read.at.name_size; ++i) { out.put(static_cast<char>(name_text(read.at.name_at + i))); }
+        uint32_t i = 0;
+        for(; i + 4u <= read.at.name_size; i += 4u) {
+            const uint8_t c0 = name_text(read.at.name_at + i), c1 = name_text(read.at.name_at + i + 1u), c2 = name_text(read.at.name_at + i + 2u), c3 = name_text(read.at.name_at + i + 3u);
+            out.put(static_cast<char>(c0)); out.put(static_cast<char>(c1)); out.put(static_cast<char>(c2)); out.put(static_cast<char>(c3));
+        }
+        for(; i < read.at.name_size; ++i) { out.put(static_cast<char>(name_text(read.at.name_at + i))); }
     };
     for(int o = 0; o < plan.n_out; ++o) {
         if(plan.fastq) {
@@ -472,7 +492,9 @@ RecordArgs arguments_of(const FastqTables* on_device, int32_t slot, uint32_t n, 
 
 // LDS a wave of record_write has for its reads' text: what the CU's 160 KiB leave four waves beside their input
 uint32_t output_room_of(const FastqPlan& plan) {
-    const int32_t room = (152 * 1024) / TILE_WAVES - plan.input_room - 16;
+    // (twice the input's room is enough for the text of most jobs and lets a second workgroup share the CU)
+    int32_t room = std::min((152 * 1024) / TILE_WAVES - plan.input_room - 16, 2 * plan.input_room);
+    if(const char* text = std::getenv("PHQ_RECORD_OUTPUT_ROOM")) { room = std::min((152 * 1024) / TILE_WAVES - plan.input_room - 16, std::atoi(text)); }      // sweeps
     return static_cast<uint32_t>(std::max(room, 0) & ~15);
 }
 
