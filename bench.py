@@ -557,6 +557,27 @@ def host_staged(torch, w, m):
                      "step_frac_of_duplex_96GBs": m * w.bytes_per_read / dt / 1e9 / 96.0,
                      "note": "caller's planes and result buffers pinned: async copies straight from / to them, both directions of the link at once "
                              "(profiles/tools/micro/pcie_duplex.py on this pool: 57 GB/s either way alone, 96 GB/s for both together)"}
+    # one byte per nucleotide across the link (phq_pack_planes once, outside the timed call: a caller that parses FASTQ text
+    # writes the packed byte where it writes code and quality now), the same records back; checked against the call above
+    packed_planes, escapes = s.pack_planes(m, host_base, host_qual)
+    pinned_packed = torch.from_numpy(packed_planes).pin_memory()
+    escape_list = torch.from_numpy(escapes.view(np.int64).copy()) if escapes.size else torch.zeros(1, dtype=torch.int64)
+    packed_result = torch.zeros_like(out_result).pin_memory()
+    packed_word = torch.zeros(m, dtype=torch.int32).pin_memory()
+    bytes_packed = (w.bytes_per_read - sum(int(d["nucleotide_cardinality"]) for d in s.decoders)) * m + 8 * int(escapes.size)
+    for name, word_pointer, moved in (("packed", packed_word.data_ptr(), bytes_packed), ("packed_records_only", None, bytes_packed - 4 * m)):
+        call = lambda: s._check(s.lib.phq_classify_host_packed(s.handle, m, m, pinned_packed.data_ptr(), escape_list.data_ptr(), int(escapes.size),
+                                                               pinned["flag"].data_ptr(), packed_result.data_ptr(), word_pointer))
+        call()
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        out[name] = {"Mreads/s": m / dt / 1e6, "GB/s_over_pcie": moved / dt / 1e9, "bytes_per_read_over_pcie": moved / m,
+                     "identical_to_pinned": bool(torch.equal(packed_result, out_result) and (word_pointer is None or torch.equal(packed_word, out_word)))}
+    out["packed"]["escapes"] = int(escapes.size)
+    out["packed"]["note"] = ("phq_classify_host_packed: one byte per nucleotide up the link (ordinal << 6 | quality; N, qualities past 62 and the padding of "
+                             "short reads in a list beside the planes), expanded by a kernel in front of the stages; the records come back as they are; "
+                             "packed_records_only: the status word is not fetched (word = NULL)")
     return out
 
 

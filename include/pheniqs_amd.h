@@ -159,10 +159,28 @@ int phq_classify_device(phq_decoder_set* set, int64_t batch_capacity, int64_t fi
 
 /* Same call for HOST buffers laid out for batch_capacity reads (what phq_stage_reads fills): decodes
  * reads [0, n_read), chunk by chunk through the set's pinned double buffers, overlapping hipMemcpyAsync
- * in both directions with compute.  Blocks until results are in host memory. */
+ * in both directions with compute.  Blocks until results are in host memory.  word may be NULL: it is then not copied
+ * back (for a job of one decoder it repeats what the record says). */
 int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read,
                       const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                       phq_result_t* result, uint32_t* word);
+
+/* The same call with ONE byte per nucleotide across the link, for callers the link bounds (37 bytes per read of an 8 nt index
+ * move 2.2 Greads/s at this pool's 96 GB/s for both directions together).  A nucleotide is A, C, G or T with a quality of at
+ * most 62 in all but a few cases (FastqRecord::decode, fastq.h:55-78, leaves a BAM code and a Phred value, a byte each):
+ * packed byte = ordinal (A 0, C 1, G 2, T 3) << 6 | quality; (0, 0) — past the observed length, and the columns a plane's
+ * stride adds — is the byte 0x7F.  Every other nucleotide — N and the other ambiguity codes, qualities of 63 and more — is
+ * the byte 0x3F and an entry of the list beside the planes: read << 32 | column << 16 | code << 8 | quality, column = the byte's place among the plane_width bytes of its read
+ * (info[d].plane_prefix + position), the list in read order.
+ *   phq_pack_planes       host planes (phq_stage_reads' layout) -> packed planes of the same layout and the list; *n_escape is
+ *                         the number of entries the batch needs: larger than escape_capacity, only that number is valid.
+ *   phq_classify_host_packed   phq_classify_host on such planes: a chunk's packed planes are expanded on the device in front
+ *                         of the stages, results are the same bytes.  word may be NULL (it is then not copied back); a chunk
+ *                         of 2 Mi reads holds at most as many list entries as reads (PHQ_OVERFLOW_ERROR beyond). */
+int phq_pack_planes(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes,
+                    uint8_t* packed_planes, uint64_t* escapes, int64_t escape_capacity, int64_t* n_escape);
+int phq_classify_host_packed(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const uint8_t* packed_planes,
+                             const uint64_t* escapes, int64_t n_escape, const uint8_t* flag, phq_result_t* result, uint32_t* word);
 
 /* The per type accumulators of the output Read that Read::flush turns into XB / XM / XC (read.h:152-165,187-199):
  * for reads [0, n_read) of HOST result planes laid out for batch_capacity reads (what phq_classify_host fills, or a

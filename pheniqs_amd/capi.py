@@ -26,7 +26,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_device_path_counters", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_device_path_counters", "phq_pack_planes", "phq_classify_host_packed", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -107,6 +107,8 @@ def load_library():
     L.phq_profile_chain.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_copy_bandwidth.argtypes = [I32, U64, I32, ctypes.POINTER(ctypes.c_double)]
     L.phq_device_path_counters.argtypes = [ctypes.POINTER(U64)]
+    L.phq_pack_planes.argtypes = [P, I64, I64, P, P, P, P, I64, ctypes.POINTER(I64)]
+    L.phq_classify_host_packed.argtypes = [P, I64, I64, P, P, I64, P, P, P]
     L.phq_compile_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_load_job.argtypes = [ctypes.c_char_p, ctypes.POINTER(P)]
     L.phq_free_string.argtypes = [P]
@@ -256,14 +258,16 @@ class DecoderSet:
 
     # ---- layout helpers -----------------------------------------------------------------------------
 
-    def planes_from_rows(self, rows: np.ndarray, offsets: Sequence[int]) -> np.ndarray:
-        """Row major observations [n, sum L] (the oracle's staging) -> decoder major planes (flat uint8)."""
+    def planes_from_rows(self, rows: np.ndarray, offsets: Sequence[int], capacity: Optional[int] = None) -> np.ndarray:
+        """Row major observations [n, sum L] (the oracle's staging) -> decoder major planes (flat uint8) laid out for
+        `capacity` reads (default n)."""
         n = rows.shape[0]
-        out = np.zeros(n * max(self.plane_width, 1), dtype=np.uint8)
+        capacity = n if capacity is None else capacity
+        out = np.zeros(capacity * max(self.plane_width, 1), dtype=np.uint8)
         for d, offset in zip(self.decoders, offsets):
             if d["plane_stride"] == 0:
                 continue
-            plane = out[n * d["plane_prefix"]: n * (d["plane_prefix"] + d["plane_stride"])].reshape(n, d["plane_stride"])
+            plane = out[capacity * d["plane_prefix"]: capacity * d["plane_prefix"] + n * d["plane_stride"]].reshape(n, d["plane_stride"])
             plane[:, :d["nucleotide_cardinality"]] = rows[:, offset: offset + d["nucleotide_cardinality"]]
         return out
 
@@ -307,6 +311,30 @@ class DecoderSet:
         self._check(self.lib.phq_classify_host(self.handle, capacity, n, _pointer(base), _pointer(quality), _pointer(flag),
                                                result.ctypes.data, word.ctypes.data))
         return result[:self.n_result, :n], word[:n]
+
+    def pack_planes(self, n: int, base: np.ndarray, quality: np.ndarray, capacity: Optional[int] = None):
+        """phq_pack_planes: (packed planes, escape list) of host planes laid out for `capacity` reads (default n)."""
+        capacity = n if capacity is None else capacity
+        packed = np.zeros(base.size, dtype=np.uint8)
+        room = max(1024, n // 16)
+        while True:
+            escapes = np.zeros(room, dtype=np.uint64)
+            needed = ctypes.c_int64(0)
+            self._check(self.lib.phq_pack_planes(self.handle, capacity, n, _pointer(base), _pointer(quality), packed.ctypes.data,
+                                                 escapes.ctypes.data, room, ctypes.byref(needed)))
+            if needed.value <= room:
+                return packed, escapes[:needed.value]
+            room = needed.value
+
+    def classify_host_packed(self, n: int, packed: np.ndarray, escapes: np.ndarray, flag: Optional[np.ndarray], capacity: Optional[int] = None,
+                             with_word: bool = True):
+        """phq_classify_host_packed: classify_host for planes of one byte per nucleotide."""
+        capacity = n if capacity is None else capacity
+        result = np.zeros((max(1, self.n_result), max(1, capacity)), dtype=RESULT_DTYPE)
+        word = np.zeros(max(1, capacity), dtype=np.uint32) if with_word else None
+        self._check(self.lib.phq_classify_host_packed(self.handle, capacity, n, _pointer(packed), escapes.ctypes.data if escapes.size else None, int(escapes.size),
+                                                      _pointer(flag), result.ctypes.data, word.ctypes.data if with_word else None))
+        return result[:self.n_result, :n], (word[:n] if with_word else None)
 
     def transcode_fastq_to_sam(self, inputs: Sequence[str], output: str, batch_capacity: int = 1 << 20):
         """FASTQ files in (one per input segment), SAM records out; returns the incoming (count, pf count)."""

@@ -142,6 +142,27 @@ int phq_classify_host(phq_decoder_set* set, int64_t batch_capacity, int64_t n_re
     });
 }
 
+int phq_pack_planes(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes,
+                    uint8_t* packed_planes, uint64_t* escapes, int64_t escape_capacity, int64_t* n_escape) {
+    if(n_escape != nullptr) { *n_escape = 0; }
+    return guarded(set, [&]() {
+        require(set, "set");
+        require(base_planes, "base_planes");
+        require(quality_planes, "quality_planes");
+        require(packed_planes, "packed_planes");
+        require(n_escape, "n_escape");
+        *n_escape = set->impl.pack_planes(batch_capacity, n_read, base_planes, quality_planes, packed_planes, escapes, escape_capacity);
+    });
+}
+
+int phq_classify_host_packed(phq_decoder_set* set, int64_t batch_capacity, int64_t n_read, const uint8_t* packed_planes,
+                             const uint64_t* escapes, int64_t n_escape, const uint8_t* flag, phq_result_t* result, uint32_t* word) {
+    return guarded(set, [&]() {
+        require(set, "set");
+        set->impl.classify_host_packed(batch_capacity, n_read, packed_planes, escapes, n_escape, flag, reinterpret_cast<phq::DevResult*>(result), word);
+    });
+}
+
 int phq_stats_reset(phq_decoder_set* set, void* hip_stream) {
     return guarded(set, [&]() { require(set, "set"); set->impl.stats_reset(hip_stream); });
 }

@@ -3,11 +3,14 @@
 #include "../device_types.hpp"
 #include "../fastq_device.hpp"
 #include "../record_device.hpp"
+#include "../unpack.hpp"
 
 namespace phq {
 int launch_stage(const StageArgs&, const DevDecoder&, int32_t, int32_t, void*, LaunchTimer*) { return 100; }      // hipErrorNoDevice
 bool stage_uses_worklist(const DevDecoder&, int32_t) { return false; }
 // ... and the device FASTQ path (fastq_device.hip) is never taken by a set without a device
+int unpack_planes(const uint8_t*, uint8_t*, uint8_t*, size_t, void*) { return 100; }
+int patch_escapes(const uint64_t*, int64_t, int64_t, int64_t, int32_t, const int32_t*, const int32_t*, uint8_t*, uint8_t*, void*) { return 100; }
 void fastq_plan_waves(FastqPlan&, double) {}
 void fastq_fill_tables(FastqTables&) {}
 int fastq_index(const FastqFeedChunk&, void*) { return 100; }

@@ -1,4 +1,5 @@
 #include "decoder_set.hpp"
+#include "unpack.hpp"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
@@ -160,6 +161,7 @@ void DecoderSet::release() {
         if(slot.stream) { (void)hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)); }
         (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
         (void)hipFree(slot.device_result); (void)hipFree(slot.device_word); (void)hipFree(slot.device_worklist);
+        (void)hipFree(slot.device_packed); (void)hipFree(slot.device_escape); host_free(slot.pinned_escape);
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
         host_free(slot.pinned_result); host_free(slot.pinned_word);
         if(slot.done) { (void)hipEventDestroy(static_cast<hipEvent_t>(slot.done)); }
@@ -1330,7 +1332,7 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         // nothing of the old buffers is left in the slot should an allocation below throw (release() frees what it finds)
         { Slot fresh; fresh.stream = slot.stream; fresh.done = slot.done; fresh.uploaded = slot.uploaded; fresh.consumed = slot.consumed; slot = fresh; }
         chunk_capacity_ = 0;
-        const size_t planes = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4));
+        const size_t planes = (static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.plane_width, 4)) + 15) / 16 * 16;      // whole units of 16 bytes (unpack_planes)
         const size_t results = static_cast<size_t>(chunk_capacity) * static_cast<size_t>(std::max(job_.result_count, 1)) * sizeof(DevResult);
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_base), planes), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_quality), planes), "hipMalloc");
@@ -1338,6 +1340,9 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_result), results), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_word), static_cast<size_t>(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
         check(hipMalloc(reinterpret_cast<void**>(&slot.device_worklist), worklist_words(chunk_capacity) * sizeof(uint32_t)), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_packed), planes), "hipMalloc");
+        check(hipMalloc(reinterpret_cast<void**>(&slot.device_escape), static_cast<size_t>(chunk_capacity) * sizeof(uint64_t)), "hipMalloc");
+        slot.pinned_escape = static_cast<uint64_t*>(host_alloc(static_cast<size_t>(chunk_capacity) * sizeof(uint64_t)));
         slot.pinned_base = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_quality = static_cast<uint8_t*>(host_alloc(planes));
         slot.pinned_flag = static_cast<uint8_t*>(host_alloc(static_cast<size_t>(chunk_capacity)));
@@ -1374,10 +1379,62 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
 // up and then both down, and the two directions took turns: 55 GB/s for both together.)  Three slots of 2 Mi reads.
 void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                                DevResult* result, uint32_t* word) {
+    classify_host_planes(batch_capacity, n_read, base_planes, quality_planes, nullptr, nullptr, 0, flag, result, word);
+}
+
+// The same call for planes of ONE byte per nucleotide (unpack.hpp): 9 instead of 17 bytes per read of an 8 nt index go up
+// the link; a chunk's packed planes are expanded into the slot's observation planes by a kernel in front of the stages,
+// the few nucleotides that do not pack are patched in from the list beside them.
+void DecoderSet::classify_host_packed(int64_t batch_capacity, int64_t n_read, const uint8_t* packed_planes, const uint64_t* escapes, int64_t n_escape,
+                                      const uint8_t* flag, DevResult* result, uint32_t* word) {
+    if(packed_planes == nullptr) { throw InternalError("packed_planes is NULL"); }
+    if(n_escape < 0 || (n_escape > 0 && escapes == nullptr)) { throw InternalError("escapes"); }
+    for(int64_t i = 1; i < n_escape; ++i) {
+        if((escapes[i] >> 32) < (escapes[i - 1] >> 32)) { throw InternalError("the escape list is not in read order"); }
+    }
+    classify_host_planes(batch_capacity, n_read, nullptr, nullptr, packed_planes, escapes, n_escape, flag, result, word);
+}
+
+int64_t DecoderSet::pack_planes(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, uint8_t* packed_planes,
+                                uint64_t* escapes, int64_t escape_capacity) const {
+    if(n_read <= 0) { return 0; }
+    if(n_read > batch_capacity) { throw OverflowError("read count exceeds the batch capacity"); }
+    if(job_.plane_width > 0xffff) { throw OverflowError("plane width"); }
+    const int parts = host_threads();
+    std::vector<std::vector<uint64_t>> found(static_cast<size_t>(parts));
+    parallel_ranges(n_read, 1 << 14, parts, [&](int64_t first, int64_t last, int part) {
+        std::vector<uint64_t>& mine = found[static_cast<size_t>(part)];
+        for(int64_t k = first; k < last; ++k) {
+            for(const auto& c : job_.decoder) {
+                if(c.plane_stride == 0) { continue; }
+                const int64_t row = batch_capacity * c.plane_prefix + k * c.plane_stride;
+                for(int32_t j = 0; j < c.plane_stride; ++j) {
+                    const uint8_t code = base_planes[row + j], quality = quality_planes[row + j];
+                    const uint8_t packed = pack_nucleotide(code, quality);
+                    packed_planes[row + j] = packed;
+                    if(packed == PACKED_ESCAPE) { mine.push_back(escape_entry(k, c.plane_prefix + j, code, quality)); }
+                }
+            }
+        }
+    });
+    int64_t total = 0;
+    for(const auto& part : found) { total += static_cast<int64_t>(part.size()); }
+    if(total > escape_capacity || (total > 0 && escapes == nullptr)) { return total; }
+    int64_t at = 0;
+    for(const auto& part : found) {                        // the parts are ranges of reads in order: so is the list
+        if(!part.empty()) { std::memcpy(escapes + at, part.data(), part.size() * sizeof(uint64_t)); }
+        at += static_cast<int64_t>(part.size());
+    }
+    return total;
+}
+
+void DecoderSet::classify_host_planes(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* packed_planes,
+                                      const uint64_t* escapes, int64_t n_escape, const uint8_t* flag, DevResult* result, uint32_t* word) {
     require_device();
     if(n_read <= 0) { return; }
     if(n_read > batch_capacity) { throw OverflowError("read count exceeds the batch capacity"); }
-    const int64_t chunk = std::min<int64_t>(n_read, int64_t(1) << 21);
+    static const int64_t chunk_reads = []() { const char* text = std::getenv("PHQ_HOST_CHUNK"); const int64_t asked = text ? std::atoll(text) : 0; return asked >= 4096 ? asked : int64_t(1) << 21; }();      // sweeps
+    const int64_t chunk = std::min<int64_t>(n_read, chunk_reads);
     ensure_pipeline(chunk);
     hipStream_t upload = static_cast<hipStream_t>(upload_stream_);
     // batches that already live in pinned memory (phq_host_alloc) are copied straight from / to the caller's
@@ -1388,7 +1445,13 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
         if(hipPointerGetAttributes(&attributes, pointer) != hipSuccess) { (void)hipGetLastError(); return false; }
         return attributes.type == hipMemoryTypeHost;
     };
-    const bool direct_in = pinned(base_planes) && pinned(quality_planes) && pinned(flag);
+    const bool direct_in = pinned(base_planes) && pinned(quality_planes) && pinned(packed_planes) && pinned(flag);
+    int32_t plane_prefix[UNPACK_MAX_DECODER] = {0}, plane_stride[UNPACK_MAX_DECODER] = {0};
+    if(packed_planes != nullptr) {
+        if(job_.decoder.size() > static_cast<size_t>(UNPACK_MAX_DECODER)) { throw OverflowError("too many decoders for packed planes"); }
+        for(size_t d = 0; d < job_.decoder.size(); ++d) { plane_prefix[d] = job_.decoder[d].plane_prefix; plane_stride[d] = job_.decoder[d].plane_stride; }
+    }
+    int64_t escape_at = 0;                          // the list is in read order: a chunk's entries follow the previous chunk's
     const bool direct_out = pinned(result) && pinned(word);
 
     auto drain = [&](Slot& slot) {
@@ -1420,7 +1483,11 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
             const size_t bytes = static_cast<size_t>(count) * static_cast<size_t>(c.plane_stride);
             const int64_t source = batch_capacity * c.plane_prefix + first * c.plane_stride;
             const int64_t target = chunk_capacity_ * c.plane_prefix;
-            if(direct_in) {
+            if(packed_planes != nullptr) {
+                const uint8_t* from = packed_planes + source;
+                if(!direct_in) { host_copy(slot.pinned_base + target, from, bytes); from = slot.pinned_base + target; }
+                check(hipMemcpyAsync(slot.device_packed + target, from, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
+            } else if(direct_in) {
                 check(hipMemcpyAsync(slot.device_base + target, base_planes + source, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
                 check(hipMemcpyAsync(slot.device_quality + target, quality_planes + source, bytes, hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             } else {
@@ -1438,8 +1505,24 @@ void DecoderSet::classify_host(int64_t batch_capacity, int64_t n_read, const uin
                 check(hipMemcpyAsync(slot.device_flag, slot.pinned_flag, static_cast<size_t>(count), hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
             }
         }
+        int64_t chunk_escapes = 0;
+        if(packed_planes != nullptr) {
+            while(escape_at + chunk_escapes < n_escape && static_cast<int64_t>(escapes[escape_at + chunk_escapes] >> 32) < first + count) { ++chunk_escapes; }
+            if(chunk_escapes > chunk_capacity_) { throw OverflowError("more nucleotides outside the packed form than reads in a chunk: use phq_classify_host"); }
+            if(chunk_escapes > 0) {
+                std::memcpy(slot.pinned_escape, escapes + escape_at, static_cast<size_t>(chunk_escapes) * sizeof(uint64_t));
+                check(hipMemcpyAsync(slot.device_escape, slot.pinned_escape, static_cast<size_t>(chunk_escapes) * sizeof(uint64_t), hipMemcpyHostToDevice, upload), "hipMemcpyAsync");
+            }
+        }
         check(hipEventRecord(static_cast<hipEvent_t>(slot.uploaded), upload), "hipEventRecord");
         check(hipStreamWaitEvent(stream, static_cast<hipEvent_t>(slot.uploaded), 0), "hipStreamWaitEvent");
+        if(packed_planes != nullptr) {
+            const size_t planes = static_cast<size_t>(chunk_capacity_) * static_cast<size_t>(std::max(job_.plane_width, 4));
+            check(static_cast<hipError_t>(unpack_planes(slot.device_packed, slot.device_base, slot.device_quality, planes, stream)), "unpack_planes");
+            check(static_cast<hipError_t>(patch_escapes(slot.device_escape, chunk_escapes, first, chunk_capacity_, static_cast<int32_t>(job_.decoder.size()), plane_prefix, plane_stride,
+                                                        slot.device_base, slot.device_quality, stream)), "patch_escapes");
+            escape_at += chunk_escapes;
+        }
         run_stages(chunk_capacity_, 0, count, slot.device_base, slot.device_quality, flag ? slot.device_flag : nullptr,
                    slot.device_result, slot.device_word, stream, slot.device_worklist);
         check(hipEventRecord(static_cast<hipEvent_t>(slot.consumed), stream), "hipEventRecord");

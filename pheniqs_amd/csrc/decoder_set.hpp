@@ -41,6 +41,12 @@ public:
                          DevResult* result, uint32_t* word, void* stream);
     void classify_host(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* flag,
                        DevResult* result, uint32_t* word);
+    // one byte per nucleotide across the link (unpack.hpp): pack_planes returns the number of escape entries it needs — more than
+    // escape_capacity: nothing but the count is valid; classify_host_packed is classify_host for planes packed that way
+    int64_t pack_planes(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, uint8_t* packed_planes,
+                        uint64_t* escapes, int64_t escape_capacity) const;
+    void classify_host_packed(int64_t batch_capacity, int64_t n_read, const uint8_t* packed_planes, const uint64_t* escapes, int64_t n_escape,
+                              const uint8_t* flag, DevResult* result, uint32_t* word);
 
     void stats_reset(void* stream);
     uint64_t* stats_device_pointer();
@@ -113,6 +119,9 @@ private:
         DevResult* pinned_result = nullptr;
         uint32_t* pinned_word = nullptr;
         uint32_t* device_worklist = nullptr;
+        uint8_t* device_packed = nullptr;       // classify_host_packed: the chunk's planes as they cross the link
+        uint64_t* device_escape = nullptr;      // ... and the nucleotides that do not pack, chunk_capacity entries at most
+        uint64_t* pinned_escape = nullptr;
         void* stream = nullptr;
         void* done = nullptr;                   // hipEvent_t recorded after the slot's last D2H
         void* uploaded = nullptr;               // ... after its chunk's last H2D, on the upload stream
@@ -122,6 +131,8 @@ private:
         int64_t first = 0;
         int64_t count = 0;
     };
+    void classify_host_planes(int64_t batch_capacity, int64_t n_read, const uint8_t* base_planes, const uint8_t* quality_planes, const uint8_t* packed_planes,
+                              const uint64_t* escapes, int64_t n_escape, const uint8_t* flag, DevResult* result, uint32_t* word);
     static constexpr int SLOTS = 3;
     Slot slot_[SLOTS];
     void* upload_stream_ = nullptr;             // every chunk's host to device copies, one after the other

@@ -379,3 +379,43 @@ def test_a_damaged_quality_control_image_is_refused_before_anything_is_allocated
         with pytest.raises(PheniqsError):
             s.qc_merge(image)
     s.close()
+
+
+def test_pack_planes_is_lossless_on_the_host():
+    """phq_pack_planes (no device needed): ordinal << 6 | quality for A, C, G, T up to quality 62, 0x7F for (0, 0), 0x3F and a list
+    entry (read << 32 | column << 16 | code << 8 | quality, in read order) for everything else; unpacked here in numpy."""
+    from pheniqs_amd import synthetic
+    spec = synthetic.config_spec("C4", "pamld")
+    job = capi.compile_job(spec)
+    n = 5000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 17)
+    rng = np.random.default_rng(2)
+    quality[rng.random(quality.shape) < 0.01] = 70
+    code[rng.random(code.shape) < 0.01] = 5
+    s = DecoderSet(spec, device=capi.DEVICE_NONE)
+    base, qual = s.planes_from_rows(code, offsets), s.planes_from_rows(quality, offsets)
+    planes, escapes = s.pack_planes(n, base, qual)
+    codes = (1 << (planes >> 6)).astype(np.uint8)
+    values = (planes & 63).astype(np.uint8)
+    nothing = planes == 0x7F
+    codes[nothing] = 0
+    values[nothing] = 0
+    listed = planes == 0x3F
+    assert int(listed.sum()) == escapes.size > 0
+    reads = (escapes >> np.uint64(32)).astype(np.int64)
+    assert np.all(np.diff(reads) >= 0)
+    column = ((escapes >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64)
+    for d in s.decoders:
+        inside = (column >= d["plane_prefix"]) & (column < d["plane_prefix"] + d["plane_stride"])
+        at = n * d["plane_prefix"] + reads[inside] * d["plane_stride"] + column[inside] - d["plane_prefix"]
+        assert np.all(listed[at])
+        codes[at] = ((escapes[inside] >> np.uint64(8)) & np.uint64(0xFF)).astype(np.uint8)
+        values[at] = (escapes[inside] & np.uint64(0xFF)).astype(np.uint8)
+    assert np.array_equal(codes, base) and np.array_equal(values, qual)
+    # a list too small: only the count comes back
+    needed = ctypes.c_int64(0)
+    packed = np.zeros_like(base)
+    few = np.zeros(4, dtype=np.uint64)
+    assert s.lib.phq_pack_planes(s.handle, n, n, base.ctypes.data, qual.ctypes.data, packed.ctypes.data, few.ctypes.data, 4, ctypes.byref(needed)) == 0
+    assert needed.value == escapes.size and not few.any()
+    s.close()
