@@ -15,6 +15,9 @@ round_name = sys.argv[1]
 scratch = os.path.join(ROOT, "gpurun_out")
 for path in glob.glob(os.path.join(scratch, round_name + "_*_kernel_stats.csv")) + glob.glob(os.path.join(scratch, round_name + "_bench_*.json")):
     shutil.copy(path, os.path.join(ROOT, "profiles", os.path.basename(path)))
+rates = os.path.join(scratch, round_name + "_fastq_to_sam_rates.txt")
+if os.path.exists(rates):
+    shutil.copy(rates, os.path.join(ROOT, "profiles", os.path.basename(rates)))
 summary = json.load(open(os.path.join(scratch, round_name + "_traffic.json")))
 summary["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "pheniqs_amd/csrc", "include"]).decode().strip()
