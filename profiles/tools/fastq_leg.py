@@ -1,43 +1,47 @@
-"""The FASTQ -> SAM leg of bench.py alone, for tuning the host side: usage fastq_leg.py N [target ...]"""
+"""The FASTQ -> SAM legs of bench.py alone: python fastq_leg.py READS CAPACITY [target ...] (targets: file zero null); three runs each,
+with what phq_device_path_counters says the run did on the device."""
 import os
 import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+import numpy as np
 import bench
-from pheniqs_amd import DecoderSet, synthetic
+from pheniqs_amd import DecoderSet, capi, synthetic
 
-n = int(sys.argv[1])
-targets = sys.argv[2:] or ["file", "/dev/zero", "/dev/null"]
-job, recipe = synthetic.config_job("C2")
-code, quality, flag, _ = synthetic.generate_rows(job, min(n, 1 << 20), recipe["seed"])
-spec = synthetic.config_spec("C2")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+capacity = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+targets = sys.argv[3:] or ["file", "zero", "null"]
+spec = synthetic.config_spec("C2", "pamld")
 spec["template"] = {"transform": {"token": ["0::"]}}
 s = DecoderSet(spec, device=0)
+job = capi.compile_job(spec)
+pool = 1 << 20
+code, quality, flag, _ = synthetic.generate_rows(job, pool, 3)
 rng = np.random.default_rng(7)
 letters = np.frombuffer(b"=ACMGRSVTWYHKDBN", dtype=np.uint8)
-reps = -(-n // code.shape[0])
+reps = -(-n // pool)
 index_text = letters[np.tile(code, (reps, 1))[:n]]
 index_quality = (np.minimum(np.tile(quality, (reps, 1))[:n], 93) + 33).astype(np.uint8)
 template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n, 50), dtype=np.uint8)]
+template_quality = np.full((n, 50), ord("F"), dtype=np.uint8)
 filtered = np.tile(flag, reps)[:n]
 with tempfile.TemporaryDirectory(dir="/dev/shm") as directory:
     paths = []
-    for k, (text, qual) in enumerate(((template, np.full((n, 50), ord("F"), dtype=np.uint8)), (index_text, index_quality))):
+    for k, (text, qual) in enumerate(((template, template_quality), (index_text, index_quality))):
         path = os.path.join(directory, "segment_%d.fastq" % k)
         bench.write_fastq(path, k + 1, text, qual, filtered)
         paths.append(path)
-    for target in targets:
-        out = os.path.join(directory, "out.sam") if target == "file" else target
-        best = 1e9
-        for _ in range(3):
-            if os.path.isfile(out):
-                os.unlink(out)
+    for name in targets:
+        target = {"file": os.path.join(directory, "out.sam"), "zero": "/dev/zero", "null": "/dev/null"}[name]
+        for attempt in range(3):
+            if os.path.isfile(target):
+                os.unlink(target)
+            before = capi.device_path_counters()
             t0 = time.perf_counter()
-            s.transcode_fastq_to_sam(paths, out, 1 << 20)
-            best = min(best, time.perf_counter() - t0)
-        print("%s: %.1f Mreads/s (%.3f s)" % (target, n / best / 1e6, best), flush=True)
+            incoming, _ = s.transcode_fastq_to_sam(paths, target, capacity)
+            dt = time.perf_counter() - t0
+            after = capi.device_path_counters()
+            print(name, attempt, "%.1f Mreads/s  %.1f ms" % (n / dt / 1e6, dt * 1e3), {k: after[k] - before[k] for k in after}, flush=True)

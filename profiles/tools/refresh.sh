@@ -39,7 +39,7 @@ done
 python3 profiles/summarize.py $out gpurun_out/${round}_traffic.json "${shapes[@]}"
 # the kernels either side of the path (rows f1, f2): 8 M reads of FASTQ text -> SAM records, in rounds of 1 M reads
 d=$out/fastq_to_sam; rm -rf $d; mkdir -p $d
-rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 profiles/tools/scratch/fastq.py 8000000 1048576 zero null > $d/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 profiles/tools/fastq_leg.py 8000000 1048576 zero null > $d/trace.log 2>&1
 stats=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
 (head -1 $stats; grep -E "phq::|rocclr" $stats) > gpurun_out/${round}_fastq_to_sam_kernel_stats.csv
 grep -E "^(zero|null) " $d/trace.log > gpurun_out/${round}_fastq_to_sam_rates.txt

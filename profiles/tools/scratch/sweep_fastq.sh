@@ -5,7 +5,7 @@ for config in "64 0" "64 14000" "32 0" "32 7000" "16 3500"; do
   export PHQ_FASTQ_READS_PER_WAVE=$1
   if [ $2 != 0 ]; then export PHQ_RECORD_OUTPUT_ROOM=$2; else unset PHQ_RECORD_OUTPUT_ROOM; fi
   rm -rf /tmp/prof_sw
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_sw -o sw -- python3 $GRAFT_REPO_ROOT/profiles/tools/scratch/fastq.py 4000000 1048576 zero > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_sw -o sw -- python3 $GRAFT_REPO_ROOT/profiles/tools/fastq_leg.py 4000000 1048576 zero > /dev/null 2>&1
   echo "rpw $1 room $2"
   python3 - <<PY
 import sqlite3, glob
