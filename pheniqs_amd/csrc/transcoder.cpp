@@ -1109,6 +1109,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     if(!m.set.device_fastq_cache) { m.set.device_fastq_cache = std::make_shared<DeviceFastqCache>(); }
     DeviceFastqCache& c = *static_cast<DeviceFastqCache*>(m.set.device_fastq_cache.get());
     if(c.stream == nullptr) { device_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate"); }
+
     // records per round: the batch capacity, in chunks of at most 192 MiB of text per file
     const int64_t capacity = std::max<int64_t>(1 << 12, std::min<int64_t>(m.capacity, int64_t(1) << 22));
     if(c.capacity < capacity) {
@@ -1220,6 +1221,18 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     size_t source_bytes[FASTQ_MAX_FEED] = {0};
     const int threads = host_threads();
     std::future<void> ahead_task;                    // reads the next round's bytes while this one is on the device; declared after what it touches
+    // PHQ_TRANSCODE_TRACE=1: where the calling thread waited, summed over the rounds, on stderr at the end of the run
+    const bool trace = std::getenv("PHQ_TRANSCODE_TRACE") != nullptr;
+    double waited[6] = {0, 0, 0, 0, 0, 0};           // the read ahead, the plan, the decode, the sizes, the output buffer, the last round's text
+    uint64_t rounds = 0;
+    auto clock_now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double began = clock_now();
+    auto timed = [&](int which, auto&& wait) { const double t = clock_now(); wait(); waited[which] += clock_now() - t; };
+    auto report = [&]() {
+        if(!trace) { return; }
+        std::fprintf(stderr, "device path: %llu rounds, %.1f ms; waited (ms) for the read ahead %.1f, the plan %.1f, the decode %.1f, the sizes %.1f, the output buffer %.1f, the last text %.1f\n",
+                     static_cast<unsigned long long>(rounds), (clock_now() - began) * 1e3, waited[0] * 1e3, waited[1] * 1e3, waited[2] * 1e3, waited[3] * 1e3, waited[4] * 1e3, waited[5] * 1e3);
+    };
     uint64_t reads = 0;
     unsigned long long flagged_so_far = 0;          // a run that writes: the reads of the finished rounds whose filter flag is set
     // a run that writes: the text of the rounds leaves in order on threads of its own, two rounds in flight
@@ -1243,7 +1256,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         return OnDevice::RESUMED;
     };
     while(true) {
-        if(ahead_task.valid()) { ahead_task.get(); }
+        if(ahead_task.valid()) { timed(0, [&]() { ahead_task.get(); }); }
         bool any_left = false;
         FastqFeedChunk chunk[FASTQ_MAX_FEED];
         for(int32_t f = 0; f < n_feed; ++f) {
@@ -1275,15 +1288,18 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             }
             source_bytes[f] = bytes;
             if(bytes == left && bytes > 0 && to[bytes - 1] != '\n') { to[bytes++] = '\n'; }      // the last line of a file may lack its newline
-            device_check(hipMemcpyAsync(c.raw[slot][f], to, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
-            device_check(hipMemsetAsync(c.raw[slot][f] + bytes, 0, 16, stream), "hipMemsetAsync");      // zero padded to whole units of 16 bytes
+            // (the copies of the feeds on streams of their own, beside the last kernel of the round before, were measured: no
+            // gain that stands out of the box to box spread of the link's rate under the host's own memory traffic)
+            hipStream_t const up = stream;
+            device_check(hipMemcpyAsync(c.raw[slot][f], to, bytes, hipMemcpyHostToDevice, up), "hipMemcpyAsync");
+            device_check(hipMemsetAsync(c.raw[slot][f] + bytes, 0, 16, up), "hipMemsetAsync");      // zero padded to whole units of 16 bytes
             chunk[f].raw = c.raw[slot][f];
             chunk[f].bytes = static_cast<uint32_t>(bytes);
             chunk[f].newline = c.newline[slot][f];
             chunk[f].newline_capacity = static_cast<uint32_t>(chunk_bytes[f] / 8 + 1024);
             chunk[f].block_count = c.block_count[slot][f];
             chunk[f].total = c.total + slot * FASTQ_MAX_FEED + f;
-            device_check(static_cast<hipError_t>(fastq_index(chunk[f], stream)), "fastq_index");
+            device_check(static_cast<hipError_t>(fastq_index(chunk[f], up)), "fastq_index");
         }
         if(!any_left) { break; }
         device_check(static_cast<hipError_t>(fastq_plan_round(chunk, n_feed, device_plan.feed_resolution, static_cast<uint32_t>(capacity), c.round_device, stream)), "fastq_plan_round");
@@ -1327,7 +1343,8 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 ahead_bytes[f] = count;
             }
         });
-        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");       // this round's pinned buffers are free again, the round is known
+        timed(1, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });       // this round's pinned buffers are free again, the round is known
+        ++rounds;
         buffer = other;
         const FastqRound round = *c.round_host;
         if(round.irregular) { return give_up(); }
@@ -1352,7 +1369,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             device_check(hipMemcpyAsync(&c.status_host->irregular, c.irregular, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             device_check(hipMemcpyAsync(&c.status_host->flagged, c.flagged, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             if(device_plan.filtering) { device_check(hipMemcpyAsync(&c.status_host->kept, c.kept_device, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"); }
-            device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            timed(2, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });
             if(c.status_host->irregular) {
                 for(int32_t f = 0; f < n_feed; ++f) { file[static_cast<size_t>(f)].position = round_began_at[f]; }
                 return give_up();
@@ -1379,7 +1396,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             record.text = nullptr;
             device_check(static_cast<hipError_t>(record_sizes(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
             device_check(hipMemcpyAsync(&c.status_host->text_bytes, c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
-            device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            timed(3, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });
             const size_t bytes = static_cast<size_t>(c.status_host->text_bytes);
             if(bytes > 0) {
                 if(c.text_device_room[b] < bytes) {
@@ -1393,7 +1410,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 record.text = c.text_device[b];
                 device_check(static_cast<hipError_t>(record_write(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
                 device_check(hipEventRecord(c.written[b], stream), "hipEventRecord");
-                if(buffer_drained[b].valid()) { buffer_drained[b].get(); }                            // text_host[b] is in the file
+                if(buffer_drained[b].valid()) { timed(4, [&]() { buffer_drained[b].get(); }); }        // text_host[b] is in the file
                 if(c.text_host_room[b] < bytes) {
                     if(c.text_host[b]) { (void)hipHostFree(c.text_host[b]); c.text_host[b] = nullptr; c.text_host_room[b] = 0; }
                     const size_t room = bytes + bytes / 8 + (size_t(1) << 20);
@@ -1434,10 +1451,11 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         slot ^= 1;
     }
     if(text != nullptr) {
-        if(drained.valid()) { drained.get(); }
+        timed(5, [&]() { if(drained.valid()) { drained.get(); } });
         device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
         incoming_count += reads;
         incoming_pf_count += reads - flagged_so_far;
+        report();
         return OnDevice::DONE;
     }
     uint32_t irregular = 0;
@@ -1448,6 +1466,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     if(irregular) { return give_up(); }
     incoming_count += reads;                                                      // transcode.cpp:304-309
     incoming_pf_count += reads - flagged;
+    report();
     return OnDevice::DONE;
 }
 
