@@ -35,7 +35,7 @@ def counter_by_kernel(directory, counter):
     total = collections.defaultdict(float)
     calls = collections.defaultdict(int)
     for row in csv.DictReader(open(newest(directory, "*_counter_collection.csv"))):
-        if row["Counter_Name"] == counter and "phq::" in row["Kernel_Name"]:
+        if row["Counter_Name"] == counter and "phq::" in row["Kernel_Name"] and "copy_probe" not in row["Kernel_Name"]:      # the copy probe (bench.py's measured_copy_GBs) is no kernel of a step
             total[row["Kernel_Name"]] += float(row["Counter_Value"])
             calls[row["Kernel_Name"]] += 1
     return {name: (total[name], calls[name]) for name in total}
@@ -74,7 +74,7 @@ def main():
         kernels = {}
         for row in csv.DictReader(open(newest(os.path.join(where, "trace"), "*_kernel_stats.csv"))):
             name = row["Name"]
-            if "phq::" not in name:
+            if "phq::" not in name or "copy_probe" in name:
                 continue
             entry = {"calls": int(row["Calls"]), "average_ns": float(row["AverageNs"]), "launches_per_step": int(row["Calls"]) / float(trace_steps)}
             if name in fetch and name in write:
