@@ -15,7 +15,7 @@ void fastq_plan_waves(FastqPlan&, double) {}
 void fastq_fill_tables(FastqTables&) {}
 int fastq_index(const FastqFeedChunk&, void*) { return 100; }
 int fastq_plan_round(const FastqFeedChunk*, int32_t, const int32_t*, uint32_t, FastqRound*, void*) { return 100; }
-int fastq_decode(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*, unsigned long long*, uint8_t*, uint32_t*, uint32_t*, void*) { return 100; }
+int fastq_decode(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, uint8_t*, uint8_t*, uint8_t*, uint32_t*, unsigned long long*, uint8_t*, uint32_t*, uint32_t*, uint32_t*, void*) { return 100; }
 int record_sizes(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, void*) { return 100; }
 int record_write(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, void*) { return 100; }
 }

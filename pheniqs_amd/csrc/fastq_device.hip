@@ -159,9 +159,17 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
     bool wanted;
     const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
     bool filtered = false;
+    Located at;
+    if(wanted) { locate(plan, chunk, bytes, r, at); }
+    if(args.longest != nullptr) {
+        // what sizes the quality control accumulators' cycles (record_device.hpp): the longest segment so far
+        for(int s = 0; s < plan.n_segment; ++s) {
+            uint32_t longest = wanted && !at.odd ? at.length[s] : 0u;
+            for(int step = 32; step > 0; step >>= 1) { longest = max(longest, static_cast<uint32_t>(__shfl_xor(static_cast<int>(longest), step))); }
+            if((threadIdx.x & 63) == 0 && longest > 0) { atomicMax(&args.longest[s], longest); }
+        }
+    }
     if(wanted) {
-        Located at;
-        locate(plan, chunk, bytes, r, at);
         filtered = at.filtered;
         if(!FILTER && at.odd) { atomicOr(args.irregular, 1u); }
         // Rule::apply of every decoder into its plane (transform.h:142-169), zero filled past what the tokens bring
@@ -240,9 +248,10 @@ void fastq_fill_tables(FastqTables& tables) {
 }
 
 int fastq_decode(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
-                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream) {
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, uint32_t* longest, void* stream) {
     if(n == 0) { return 0; }
     DecodeArgs call;
+    call.longest = longest;
     call.tables = on_device;
     call.slot = slot;
     call.n = n;

@@ -99,9 +99,10 @@ int fastq_plan_round(const FastqFeedChunk* chunk, int32_t n_feed, const int32_t*
 // reads [0, n) of the round -> planes laid out for `capacity` reads; *irregular |= 1 on anything out of the ordinary;
 // *flagged += reads whose filter flag is set.  A plan that filters needs the scratch `keep` (n bytes) and `keep_block`
 // (n / 32 + 2 words) and leaves the number of rows it wrote — the reads it kept, in input order — in *kept (device);
-// a plan that does not writes row r for read r and leaves *kept alone.
+// a plan that does not writes row r for read r and leaves *kept alone.  `longest` (device, FASTQ_MAX_FEED words) may be NULL:
+// else longest[s] = max(longest[s], the longest segment s of the reads decoded).
 // `on_device` is a device copy of the tables whose plan is `plan`; the round's chunks are those of `slot`
 int fastq_decode(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, uint8_t* base_planes, uint8_t* quality_planes,
-                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, void* stream);
+                 uint8_t* flag, uint32_t* irregular, unsigned long long* flagged, uint8_t* keep, uint32_t* keep_block, uint32_t* kept, uint32_t* longest, void* stream);
 
 }  // namespace phq

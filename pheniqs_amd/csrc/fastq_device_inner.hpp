@@ -24,6 +24,7 @@ struct DecodeArgs {
     unsigned long long* flagged;
     uint8_t* keep;                  // a plan that filters: 1 = the read is decoded
     uint32_t* keep_block;           // ... kept reads per workgroup's reads, then their exclusive prefix sums
+    uint32_t* longest;              // NULL, or per input segment the longest one decoded so far (a running maximum)
 };
 
 // The text a wave works on, in LDS.  A wave takes `reads_per_wave` consecutive reads; their records are consecutive bytes of

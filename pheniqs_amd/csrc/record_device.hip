@@ -21,6 +21,7 @@ struct RecordArgs {
     const uint32_t* keep_block;
     RecordRound round;
     uint32_t output_room;           // bytes of LDS a wave has for the text of its reads (record_write)
+    uint32_t* overflow;             // record_quality_control: a segment longer than the cells' cycles
 };
 
 // The bytes of a record: counted (pass 1), or stored (pass 2) — into the wave's LDS, from where the wave copies its reads'
@@ -263,6 +264,44 @@ struct ReadView {
             }
         }
     }
+    // the bases of output segment o as the reference's Segment holds them: BAM code and Phred value (what the quality
+    // control accumulators count, multiplex.h:219-221)
+    template <typename F>
+    __device__ void for_each_base(int o, F&& f) const {
+        for(int t = plan->out_first[o]; t < plan->out_first[o + 1]; ++t) {
+            const RecordToken& token = plan->token[plan->out_token[t]];
+            int32_t start, end;
+            const uint32_t size = token_size(token, start, end);
+            if(token.source >= 0) {
+                const FeedBytes text = bytes->feed(args->tables->plan.segment_feed[token.source]);
+                for(uint32_t i = 0; i < size; ++i) {
+                    const uint32_t from = static_cast<uint32_t>(token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i));
+                    uint8_t code = args->tables->bam_of_ascii[text(at.sequence_at[token.source] + from)];
+                    if(token.reverse_complement) { code = plan->complement_of_bam[code & 15u]; }
+                    f(code, static_cast<uint8_t>(text(at.quality_at[token.source] + from) - plan->input_phred_offset));
+                }
+            } else {
+                const int kind = token.source == -1 ? 0 : token.source == -2 ? 2 : 1;
+                for(uint32_t i = 0; i < size; ++i) {
+                    const int32_t from = token.reverse_complement ? end - 1 - static_cast<int32_t>(i) : start + static_cast<int32_t>(i);
+                    corrected(kind, from, [&](uint8_t code, uint8_t q) { f(token.reverse_complement ? plan->complement_of_bam[code & 15u] : code, q); });
+                }
+            }
+        }
+    }
+    // Multiplexer::push (multiplex.h:198-240): the channel is the multiplexing decoder's barcode; `group` the sample barcode's read group
+    __device__ int channel_of(int& group) const {
+        int channel = 0;
+        group = -1;
+        for(int k = 0; k < plan->n_decoder; ++k) {
+            const RecordDecoder& d = plan->decoder[k];
+            if(d.plane_stride == 0) { continue; }
+            const int which = ordinal(d);
+            if(d.multiplexing) { channel = which + 1; }
+            if(d.result_slot >= 0 && d.kind == 0) { group = which + 1; }
+        }
+        return channel >= plan->n_channel ? 0 : channel;
+    }
 };
 
 // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
@@ -287,17 +326,9 @@ __device__ void put_tags(W& out, const ReadView& read, int group, const double (
 template <typename W>
 __device__ void put_read(W& out, const ReadView& read) {
     const RecordPlan& plan = *read.plan;
-    // Multiplexer::push -> Channel::push (multiplex.h:198-240): the channel is the multiplexing decoder's barcode
-    int channel = 0;
-    int group = -1;
-    for(int k = 0; k < plan.n_decoder; ++k) {
-        const RecordDecoder& d = plan.decoder[k];
-        if(d.plane_stride == 0) { continue; }
-        const int which = read.ordinal(d);
-        if(d.multiplexing) { channel = which + 1; }
-        if(d.result_slot >= 0 && d.kind == 0) { group = which + 1; }
-    }
-    if(channel >= plan.n_channel) { channel = 0; }
+    // Multiplexer::push -> Channel::push (multiplex.h:198-240)
+    int group;
+    const int channel = read.channel_of(group);
     const uint8_t mode = plan.bytes[plan.channel_at + channel];
     const bool qcfail = (read.args->round.word[read.row] >> 31) != 0;
     if(!(mode & 1u) || ((mode & 2u) && qcfail)) { return; }
@@ -384,6 +415,55 @@ __global__ __launch_bounds__(TILE_THREADS) void record_size_kernel(RecordArgs ar
     if((threadIdx.x & 63) == 0 && sum) { atomicAdd(&block_bytes, static_cast<unsigned long long>(sum)); }
     __syncthreads();
     if(threadIdx.x == 0) { args.round.block[blockIdx.x] = block_bytes; }
+}
+
+// The quality control accumulators (record_device.hpp): one lane per read, a global atomic per base.  A wave's lanes are
+// at the same cycle of 64 different reads — mostly of different channels, so of different cells — and global atomics run at
+// the memory side, a request per lane: ~46 G a second spread like this.
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void record_quality_control_kernel(RecordArgs args) {
+    __shared__ uint32_t wave_kept[TILE_WAVES];
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    WaveInput bytes_of;
+    stage_wave_input(plan, chunk, wave_first, wave_count, (threadIdx.x >> 6) * static_cast<uint32_t>(plan.input_room), bytes_of);
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
+    if(!wanted) { return; }
+    ReadView read;
+    read.args = &args;
+    read.plan = args.round.plan;
+    read.row = row;
+    read.bytes = &bytes_of;
+    locate(plan, chunk, bytes_of, r, read.at);
+    int group;
+    const int channel = read.channel_of(group);
+    const size_t cell_words = qc_cell_words(args.round.cycles);
+    for(int o = 0; o < read.plan->n_out; ++o) {
+        unsigned long long* const cell = args.round.quality_control + (static_cast<size_t>(channel) * static_cast<size_t>(read.plan->n_out) + static_cast<size_t>(o)) * cell_words;
+        if(static_cast<int32_t>(read.bases_of(o)) > args.round.cycles) { atomicOr(args.overflow, 1u); continue; }
+        uint32_t length = 0;
+        unsigned long long total = 0;
+        read.for_each_base(o, [&](uint8_t code, uint8_t quality) {
+            const uint32_t q = quality < QC_CELL_PHRED ? quality : QC_CELL_PHRED - 1;
+            atomicAdd(&cell[QC_CELL_HEAD + (static_cast<size_t>(length) * QC_CELL_CODES + (code & 15u)) * QC_CELL_PHRED + q], 1ull);
+            total += quality;
+            ++length;
+        });
+        atomicMax(&cell[0], static_cast<unsigned long long>(length));
+        atomicMax(&cell[1], 0x7fffffffull - static_cast<unsigned long long>(length));              // the shortest, so that an untouched cell reads 0x7fffffff
+        if(length > 0) {                                                     // AveragePhreadAccumulator::increment, multiplex.h:44-55
+            const double value = static_cast<double>(total) / static_cast<double>(length);
+            atomicAdd(&cell[2], 1ull);
+            atomicAdd(&cell[3], static_cast<unsigned long long>(value * 16777216.0 + 0.5));
+            atomicMax(&cell[4], static_cast<unsigned long long>(__double_as_longlong(value)));      // means are not negative: their bits order as they do
+            const unsigned long long bin = static_cast<unsigned long long>(value);
+            atomicAdd(&cell[5 + (bin < QC_CELL_PHRED ? bin : QC_CELL_PHRED - 1)], 1ull);
+        }
+    }
 }
 
 // exclusive prefix sums of the workgroups' bytes, in place; *total = the bytes of the round's text
@@ -487,6 +567,7 @@ RecordArgs arguments_of(const FastqTables* on_device, int32_t slot, uint32_t n, 
     call.keep_block = keep_block;
     call.round = round;
     call.output_room = output_room;
+    call.overflow = nullptr;
     return call;
 }
 
@@ -530,6 +611,23 @@ int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t sl
     hipStream_t s = static_cast<hipStream_t>(stream);
     if(plan.filtering) { hipLaunchKernelGGL(record_write_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     else { hipLaunchKernelGGL(record_write_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    return static_cast<int>(hipGetLastError());
+}
+
+int record_quality_control(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                           const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, uint32_t* overflow, void* stream) {
+    if(n == 0) { return 0; }
+    if(round.quality_control == nullptr || overflow == nullptr || round.cycles < 0) { return static_cast<int>(hipErrorInvalidValue); }
+    const uint32_t blocks = fastq_groups(plan, n);
+    RecordArgs call = arguments_of(on_device, slot, n, capacity, base_planes, quality_planes, keep, keep_block, round, 0);
+    call.overflow = overflow;
+    const size_t lds = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.input_room);
+    static std::atomic<uint64_t> prepared[2];
+    if(const int status = allow_lds(&record_quality_control_kernel<true>, prepared[0], lds)) { return status; }
+    if(const int status = allow_lds(&record_quality_control_kernel<false>, prepared[1], lds)) { return status; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if(plan.filtering) { hipLaunchKernelGGL(record_quality_control_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    else { hipLaunchKernelGGL(record_quality_control_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     return static_cast<int>(hipGetLastError());
 }
 

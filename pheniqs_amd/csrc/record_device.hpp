@@ -55,6 +55,7 @@ struct RecordPlan {
     int32_t fastq;                  // 1: FASTQ records, 0: SAM
     int32_t illumina_comment;
     int32_t quality_shift;          // output Phred offset - input Phred offset
+    int32_t input_phred_offset;
     int32_t output_phred_offset;
     int32_t n_group;                // read group ids: bytes[ints[group_at + g] .. ints[group_at + g + 1])
     int32_t group_at;
@@ -81,7 +82,19 @@ struct RecordRound {
     unsigned long long* block;      // device scratch: n / 256 + 2 words
     unsigned long long* total;      // device: bytes of the round's text (after record_sizes)
     char* text;                     // device: at least *total bytes (record_write)
+    unsigned long long* quality_control;        // device: the accumulators (record_quality_control), or NULL
+    int32_t cycles;                 // ... and the cycles every cell of them holds
 };
+
+// The quality control accumulators of the output reads on the device (reference multiplex.h:28-181: what Channel::push
+// counts when `enable quality control` is set; csrc/qc.hpp is the host's form).  One cell per (channel, output segment),
+// QC_CELL_HEAD words — [0] the longest segment seen, [1] 0x7fffffff - the shortest, [2] reads with a mean quality,
+// [3] the sum of those means in 2^-24 units, [4] the largest mean (the bits of a double), [5 .. 46] the distribution of the
+// means — then cycles x 16 codes x 42 Phred values of counts.  The per code totals are sums over the cycles: the host forms them.
+constexpr int QC_CELL_HEAD = 64;
+constexpr int QC_CELL_CODES = 16;
+constexpr int QC_CELL_PHRED = 42;
+constexpr size_t qc_cell_words(int32_t cycles) { return static_cast<size_t>(QC_CELL_HEAD) + static_cast<size_t>(cycles) * QC_CELL_CODES * QC_CELL_PHRED; }
 
 // every function returns a hipError_t value; all work goes to `stream`.  `keep` / `keep_block` are what fastq_decode left
 // (a plan that filters), rows are the compacted ones the planes and results hold; `on_device`, `plan`, `slot` as for fastq_decode.
@@ -89,5 +102,9 @@ int record_sizes(const FastqTables* on_device, const FastqPlan& plan, int32_t sl
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
 int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
+// every read the pull loop kept is counted in the cell of its channel, written or not (multiplex.h:219-221); an output
+// segment longer than round.cycles is not counted and sets *overflow (device)
+int record_quality_control(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                           const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, uint32_t* overflow, void* stream);
 
 }  // namespace phq

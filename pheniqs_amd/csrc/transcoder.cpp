@@ -847,10 +847,15 @@ struct DeviceFastqCache {
     uint8_t* record_bytes = nullptr;               // device
     size_t record_ints_room = 0, record_bytes_room = 0;
     int64_t record_capacity = 0;
+    unsigned long long* qc_device = nullptr;       // the quality control accumulators (record_device.hpp), cells of qc_cycles cycles
+    int32_t qc_cycles = 0;
+    size_t qc_cells = 0;
+    uint32_t* qc_overflow = nullptr;               // device
+    uint32_t* longest = nullptr;                   // device: [FASTQ_MAX_FEED] the longest input segment so far
     uint32_t* record_size = nullptr;               // device: [capacity]
     unsigned long long* record_block = nullptr;    // device: [capacity / 32 + 2]
     unsigned long long* record_total = nullptr;    // device
-    struct RoundStatus { unsigned long long text_bytes; unsigned long long flagged; uint32_t irregular; uint32_t kept; };
+    struct RoundStatus { unsigned long long text_bytes; unsigned long long flagged; uint32_t irregular; uint32_t kept; uint32_t longest[FASTQ_MAX_FEED]; uint32_t overflow; };
     RoundStatus* status_host = nullptr;            // pinned
     char* text_device[2] = {nullptr, nullptr};
     char* text_host[2] = {nullptr, nullptr};       // pinned
@@ -859,7 +864,7 @@ struct DeviceFastqCache {
     hipEvent_t written[2] = {nullptr, nullptr};    // the round's text is in text_device[b]
     hipEvent_t copied[2] = {nullptr, nullptr};     // ... and in text_host[b]
     ~DeviceFastqCache() {
-        (void)hipFree(tables);
+        (void)hipFree(tables); (void)hipFree(qc_device); (void)hipFree(qc_overflow); (void)hipFree(longest);
         (void)hipFree(record_plan); (void)hipFree(record_ints); (void)hipFree(record_bytes); (void)hipFree(record_size); (void)hipFree(record_block); (void)hipFree(record_total);
         if(status_host) { (void)hipHostFree(status_host); }
         for(int b = 0; b < 2; ++b) {
@@ -906,7 +911,8 @@ void device_path_counters(uint64_t* counters) {
 // A run whose every written channel sends all its output segments to ONE uncompressed file: which sink, and the tables
 // the device needs to assemble the records (record_device.hpp).  `ints` and `bytes` are the two pools RecordPlan points into.
 struct DeviceText {
-    int32_t sink = -1;
+    int32_t sink = -1;              // -1: no channel writes (a run that only counts: the quality control accumulators)
+    bool quality_control = false;   // the accumulators of `enable quality control` are kept on the device (record_quality_control)
     RecordPlan plan;
     std::vector<int32_t> ints;
     std::vector<uint8_t> bytes;
@@ -936,9 +942,10 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
         }
         mode[c] = static_cast<uint8_t>(1u | (channel.filter_outgoing_qc_fail ? 2u : 0u));
     }
-    if(out.sink < 0) { return false; }
-    const OutputSink& to = sink[static_cast<size_t>(out.sink)];
-    if(to.feed.gzip || (to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ)) { return false; }
+    if(out.sink >= 0) {
+        const OutputSink& to = sink[static_cast<size_t>(out.sink)];
+        if(to.feed.gzip || (to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ)) { return false; }
+    }
 
     RecordPlan& r = out.plan;
     std::memset(&r, 0, sizeof(r));
@@ -947,9 +954,10 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
     r.n_decoder = static_cast<int32_t>(job.decoder.size());
     r.n_out = n_out;
     r.n_channel = static_cast<int32_t>(plan.channel.size());
-    r.fastq = to.feed.format == FileFormat::FASTQ ? 1 : 0;
+    r.fastq = out.sink >= 0 && sink[static_cast<size_t>(out.sink)].feed.format == FileFormat::FASTQ ? 1 : 0;
     r.illumina_comment = (job.platform == "ILLUMINA" || job.platform == "ELEMENT") ? 1 : 0;      // fastq.h:176-194
     r.quality_shift = job.output_phred_offset - job.input_phred_offset;
+    r.input_phred_offset = job.input_phred_offset;
     r.output_phred_offset = job.output_phred_offset;
     // read group ids: where each one's bytes end
     r.n_group = static_cast<int32_t>(rg_by_index.size());
@@ -1034,8 +1042,9 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
     if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return OnDevice::NOT_TAKEN; }
     if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return OnDevice::NOT_TAKEN; }
-    // what the device path does not do: the quality control accumulators (they count the output read's text: host side)
-    if(job.enable_quality_control) { return OnDevice::NOT_TAKEN; }
+    if(job.enable_quality_control && (text == nullptr || !text->quality_control)) { return OnDevice::NOT_TAKEN; }
+    const bool writes = text != nullptr && text->sink >= 0;
+    const bool counts = text != nullptr && text->quality_control;
     const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
     if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return OnDevice::NOT_TAKEN; }
     FastqPlan device_plan;
@@ -1169,7 +1178,18 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         device_check(hipMemcpy(c.record_ints, text->ints.data(), text->ints.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
         device_check(hipMemcpy(c.record_bytes, text->bytes.data(), text->bytes.size(), hipMemcpyHostToDevice), "hipMemcpy");
         device_check(hipMemcpy(c.record_plan, &on_device, sizeof(RecordPlan), hipMemcpyHostToDevice), "hipMemcpy");
-        c.status_host->text_bytes = 0; c.status_host->flagged = 0; c.status_host->irregular = 0; c.status_host->kept = 0;
+        std::memset(c.status_host, 0, sizeof(*c.status_host));
+        if(counts) {
+            if(c.longest == nullptr) {
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.longest), FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.qc_overflow), sizeof(uint32_t)), "hipMalloc");
+            }
+            device_check(hipMemset(c.longest, 0, FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMemset");
+            device_check(hipMemset(c.qc_overflow, 0, sizeof(uint32_t)), "hipMemset");
+            // the accumulators start empty with every run (what a run leaves is merged into the set's when it ends)
+            (void)hipFree(c.qc_device); c.qc_device = nullptr; c.qc_cycles = 0;
+            c.qc_cells = plan.channel.size() * static_cast<size_t>(job.output_segment_cardinality);
+        }
     }
     size_t chunk_bytes[FASTQ_MAX_FEED];
     for(int32_t f = 0; f < n_feed; ++f) {
@@ -1241,6 +1261,39 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     int text_buffer = 0;
     // Without text nothing has left the process: the counters go back to what they were and the host reader takes the run
     // from its start.  With text the finished rounds are in the file: the host reader takes over at the bytes they end at.
+    // what the rounds of this run left in the device's quality control accumulators, into the set's (multiplex.cpp:405-411)
+    auto merge_quality_control = [&]() {
+        if(!counts || c.qc_device == nullptr) { return; }
+        device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        uint32_t overflow = 0;
+        device_check(hipMemcpy(&overflow, c.qc_overflow, sizeof(overflow), hipMemcpyDeviceToHost), "hipMemcpy");
+        if(overflow) { throw InternalError("quality control: an output segment longer than the bound its tokens give"); }
+        const size_t cell_words = qc_cell_words(c.qc_cycles);
+        std::vector<unsigned long long> words(c.qc_cells * cell_words);
+        device_check(hipMemcpy(words.data(), c.qc_device, words.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy");
+        QcState state;
+        state.shape(static_cast<int32_t>(plan.channel.size()), job.output_segment_cardinality);
+        for(size_t k = 0; k < c.qc_cells; ++k) {
+            const unsigned long long* const w = words.data() + k * cell_words;
+            QcSegment& cell = state.cell[k];
+            cell.capacity = static_cast<int32_t>(w[0]);
+            cell.shortest = static_cast<int32_t>(0x7fffffffull - w[1]);
+            cell.average_count = w[2];
+            cell.average_sum_fixed = w[3];
+            std::memcpy(&cell.average_max, &w[4], sizeof(double));
+            for(int q = 0; q < QC_PHRED_RANGE; ++q) { cell.average_distribution[q] = w[5 + q]; }
+            const size_t bins = static_cast<size_t>(cell.capacity) * QC_CODES * QC_PHRED_RANGE;
+            cell.cycle.assign(w + QC_CELL_HEAD, w + QC_CELL_HEAD + bins);
+            uint64_t every = 0;
+            for(size_t bin = 0; bin < bins; ++bin) {
+                cell.nucleic[(bin / QC_PHRED_RANGE) % QC_CODES] += cell.cycle[bin];
+                every += cell.cycle[bin];
+            }
+            cell.nucleic[0] += every;                                       // multiplex.h:155-156: [0] counts every base (and code 0 twice)
+        }
+        m.set.quality_control_merge(state);
+        (void)hipFree(c.qc_device); c.qc_device = nullptr; c.qc_cycles = 0;
+    };
     auto give_up = [&]() {
         (void)hipStreamSynchronize(stream);
         if(ahead_task.valid()) { ahead_task.wait(); }
@@ -1249,6 +1302,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             return OnDevice::NOT_TAKEN;
         }
         if(drained.valid()) { drained.get(); }
+        merge_quality_control();
         incoming_count += reads;
         incoming_pf_count += reads - flagged_so_far;
         for(int32_t f = 0; f < n_feed; ++f) { m.stream[static_cast<size_t>(f)]->start_at(file[static_cast<size_t>(f)].position); }
@@ -1361,7 +1415,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
         device_check(static_cast<hipError_t>(fastq_decode(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
-                                                          c.keep, c.keep_block, c.kept_device, stream)), "fastq_decode");
+                                                          c.keep, c.keep_block, c.kept_device, counts ? c.longest : nullptr, stream)), "fastq_decode");
         uint32_t decoded = round.records;
         if(text != nullptr) {
             // A run that writes learns now whether the round holds anything out of the ordinary: its reads are neither
@@ -1369,6 +1423,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             device_check(hipMemcpyAsync(&c.status_host->irregular, c.irregular, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             device_check(hipMemcpyAsync(&c.status_host->flagged, c.flagged, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             if(device_plan.filtering) { device_check(hipMemcpyAsync(&c.status_host->kept, c.kept_device, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"); }
+            if(counts) { device_check(hipMemcpyAsync(c.status_host->longest, c.longest, FASTQ_MAX_FEED * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync"); }
             timed(2, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });
             if(c.status_host->irregular) {
                 for(int32_t f = 0; f < n_feed; ++f) { file[static_cast<size_t>(f)].position = round_began_at[f]; }
@@ -1382,18 +1437,55 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             decoded = *c.kept_host;
         }
         if(decoded > 0) { m.set.classify_device(c.capacity, 0, decoded, c.base, c.quality, c.flag, c.result, c.word, stream); }
-        if(text != nullptr && decoded > 0) {
+        RecordRound record;
+        record.plan = c.record_plan;
+        record.result = c.result;
+        record.word = c.word;
+        record.size = c.record_size;
+        record.block = c.record_block;
+        record.total = c.record_total;
+        record.text = nullptr;
+        record.quality_control = nullptr;
+        record.cycles = 0;
+        if(counts && decoded > 0) {
+            // The quality control accumulators of the round's reads (record_quality_control).  A cell holds as many cycles as
+            // the longest output segment can have: every token at most the longest of its input segment so far (the decode
+            // kernel keeps that), a corrected barcode at most the job's nucleotides; the cells grow when reads grow.
+            int32_t cycles = 0;
+            for(int32_t o = 0; o < text->plan.n_out; ++o) {
+                int32_t bound = 0;
+                for(int32_t t = text->plan.out_first[o]; t < text->plan.out_first[o + 1]; ++t) {
+                    const RecordToken& token = text->plan.token[text->plan.out_token[t]];
+                    bound += token.source >= 0 ? static_cast<int32_t>(c.status_host->longest[token.source]) : job.nucleotide_width;
+                }
+                cycles = std::max(cycles, bound);
+            }
+            cycles = std::max(64, (cycles + 31) / 32 * 32);
+            if(cycles > c.qc_cycles) {
+                unsigned long long* grown = nullptr;
+                const size_t words = c.qc_cells * qc_cell_words(cycles);
+                device_check(hipMalloc(reinterpret_cast<void**>(&grown), words * sizeof(unsigned long long)), "hipMalloc");
+                device_check(hipMemsetAsync(grown, 0, words * sizeof(unsigned long long), stream), "hipMemsetAsync");
+                if(c.qc_device != nullptr) {
+                    for(size_t cell = 0; cell < c.qc_cells; ++cell) {
+                        device_check(hipMemcpyAsync(grown + cell * qc_cell_words(cycles), c.qc_device + cell * qc_cell_words(c.qc_cycles),
+                                                    qc_cell_words(c.qc_cycles) * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
+                    }
+                    device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+                    (void)hipFree(c.qc_device);
+                }
+                c.qc_device = grown;
+                c.qc_cycles = cycles;
+            }
+            record.quality_control = c.qc_device;
+            record.cycles = c.qc_cycles;
+            device_check(static_cast<hipError_t>(record_quality_control(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block,
+                                                                        record, c.qc_overflow, stream)), "record_quality_control");
+        }
+        if(writes && decoded > 0) {
             // the records of the round: sizes, places, text (record_device.hpp), then off the device on the copy stream while
             // the next round comes in on this one
             const int b = text_buffer;
-            RecordRound record;
-            record.plan = c.record_plan;
-            record.result = c.result;
-            record.word = c.word;
-            record.size = c.record_size;
-            record.block = c.record_block;
-            record.total = c.record_total;
-            record.text = nullptr;
             device_check(static_cast<hipError_t>(record_sizes(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
             device_check(hipMemcpyAsync(&c.status_host->text_bytes, c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
             timed(3, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });
@@ -1453,6 +1545,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     if(text != nullptr) {
         timed(5, [&]() { if(drained.valid()) { drained.get(); } });
         device_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        merge_quality_control();
         incoming_count += reads;
         incoming_pf_count += reads - flagged_so_far;
         report();
@@ -1532,13 +1625,15 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     }
     // nothing is written: the FASTQ text is decoded on the device when it can be (plain files, no pre-filters); a file that
     // holds anything out of the ordinary sends the whole run through the host reader below
-    if(all_silent) {
+    if(all_silent && !job.enable_quality_control) {
         if(run_on_device(incoming_count, incoming_pf_count, nullptr) == OnDevice::DONE) { return; }
     } else {
-        // every record into one uncompressed file: assembled on the device too (record_device.hpp).  An input that turns out
-        // of the ordinary part way leaves the rest of the run to the host reader and writer below.
+        // Every record into one uncompressed file, or none at all but the quality control accumulators wanted: records and
+        // accumulators come from the device too (record_device.hpp).  An input that turns out of the ordinary part way
+        // leaves the rest of the run to the host reader and writer below.
         DeviceText text;
         if(plan_device_text(job, plan, m.sink, rg_by_index, ordinal_by_index, text)) {
+            text.quality_control = job.enable_quality_control;
             if(run_on_device(incoming_count, incoming_pf_count, &text) == OnDevice::DONE) {
                 for(auto& sink : m.sink) { sink.close(); }
                 return;

@@ -30,9 +30,10 @@ def _run(job, capacity, host, how="job", paths=None, output=None):
         s.stats_reset()
         incoming = s.transcode_job(capacity) if how == "job" else s.transcode_fastq_to_sam(paths, output, capacity)
         words = s.stats_export()
+        did = {key: value - before[key] for key, value in capi.device_path_counters().items()}
+        did["quality_control"] = s.qc_export()
         s.close()
-        after = capi.device_path_counters()
-        return incoming, words, {key: after[key] - before[key] for key in after}
+        return incoming, words, did
     finally:
         os.environ.pop("PHQ_HOST_RECORDS", None)
 
@@ -196,3 +197,46 @@ def test_what_the_device_does_not_write(tmp_path):
     spec["sample"]["codec"][first]["output"] = [os.path.join(directory, "first.sam")]
     _, _, did = _run(spec, 2048, host=False)
     assert did["record_bytes"] == 0 and did["rounds"] == 0
+
+
+@pytest.mark.parametrize("case", ["written", "report_only", "mixed_tokens", "filters"])
+def test_quality_control_accumulators_on_the_device(tmp_path, case):
+    """`enable quality control` (multiplex.h:28-181): the accumulators of the output reads — per channel, output segment, cycle,
+    nucleotide and quality, and the reads' mean qualities — kept by a kernel (record_quality_control) must be word for word the
+    image the host's record threads leave (tests/test_gpu_quality_control.py holds that one against a numpy restatement of the
+    reference's accumulators): with the records written, with every output /dev/null, with corrected barcodes and `~` in the
+    template, and with reads the pull loop drops and reads the outgoing filter keeps out of the file (counted all the same,
+    multiplex.h:219-221)."""
+    directory = str(tmp_path)
+    if case == "mixed_tokens":
+        spec = _mixed_spec()
+        lengths, n, capacity = (40, 8, 26), 20011, 1 << 13
+    else:
+        spec = synthetic.config_spec("C2", "pamld")
+        spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+        lengths, n, capacity = (30, 8), 50001, 4096
+        if case == "filters":
+            spec["filter incoming qc fail"] = True
+            spec["filter outgoing qc fail"] = True
+    spec["enable quality control"] = True
+    paths = _files(directory, spec, n, 11, lengths)
+    if case == "filters":
+        # reads of two lengths: the cells grow in the run, the shortest and the longest segment differ
+        lines = open(paths[0], "rb").read().split(b"\n")
+        for i in range(0, n, 7):
+            lines[4 * i + 1] = lines[4 * i + 1][:21]
+            lines[4 * i + 3] = lines[4 * i + 3][:21]
+        open(paths[0], "wb").write(b"\n".join(lines))
+    spec["input"] = paths
+    outputs = {}
+    for host in (False, True):
+        spec["output"] = ["/dev/null"] if case == "report_only" else [os.path.join(directory, "host.sam" if host else "device.sam")]
+        incoming, words, did = _run(spec, capacity, host)
+        outputs[host] = (incoming, words, did, None if case == "report_only" else _records(spec["output"][0]))
+    device, host = outputs[False], outputs[True]
+    assert device[2]["rounds"] > 1 and host[2]["rounds"] == 0 and device[2]["resumed"] == 0
+    assert device[0] == host[0] and np.array_equal(device[1], host[1]) and device[3] == host[3]
+    mine, theirs = device[2]["quality_control"], host[2]["quality_control"]
+    assert mine.size == theirs.size > 1000 and int(mine[0]) > 1
+    assert np.array_equal(mine, theirs)
+    assert int(mine.sum()) > n
