@@ -16,6 +16,8 @@ capacity = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 targets = sys.argv[3:] or ["file", "zero", "null"]
 spec = synthetic.config_spec("C2", "pamld")
 spec["template"] = {"transform": {"token": ["0::"]}}
+if os.environ.get("QC"):
+    spec["enable quality control"] = True
 s = DecoderSet(spec, device=0)
 job = capi.compile_job(spec)
 pool = 1 << 20
