@@ -12,6 +12,7 @@
 // into places, the second writes the text where it belongs.  The host only copies the finished text to the output.
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 
 #include "device_types.hpp"
