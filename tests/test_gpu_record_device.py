@@ -240,3 +240,70 @@ def test_quality_control_accumulators_on_the_device(tmp_path, case):
     assert mine.size == theirs.size > 1000 and int(mine[0]) > 1
     assert np.array_equal(mine, theirs)
     assert int(mine.sum()) > n
+
+
+def _random_template(rng, lengths):
+    """a template of 1 to 4 output segments over random tokens: slices of the input segments (open ends, offsets from the end,
+    empty ones) and the corrected sample / cellular / molecular barcodes, some reverse complemented"""
+    tokens, knit = [], []
+    for _ in range(int(rng.integers(1, 5))):
+        pieces = []
+        for _ in range(int(rng.integers(1, 4))):
+            if rng.random() < 0.3:
+                source = str(rng.choice(["s", "c", "m"]))
+                start = "" if rng.random() < 0.5 else str(int(rng.integers(0, 4)))
+                end = "" if rng.random() < 0.5 else str(int(rng.integers(3, 12)))
+            else:
+                segment = int(rng.integers(0, len(lengths)))
+                source = str(segment)
+                kind = rng.integers(0, 5)
+                if kind == 0:
+                    start, end = "", ""
+                elif kind == 1:
+                    start, end = str(int(rng.integers(0, lengths[segment]))), ""
+                elif kind == 2:
+                    start, end = str(-int(rng.integers(1, lengths[segment]))), ""
+                elif kind == 3:
+                    first = int(rng.integers(0, lengths[segment]))
+                    start, end = str(first), str(int(rng.integers(first, lengths[segment] + 3)))
+                else:
+                    start, end = "", str(-int(rng.integers(1, lengths[segment])))
+            tokens.append("%s:%s:%s" % (source, start, end))
+            pieces.append(("~" if rng.random() < 0.3 else "") + str(len(tokens) - 1))
+        knit.append(":".join(pieces))
+    return {"transform": {"token": tokens, "knit": knit}}
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_templates_on_the_device_equal_the_host_writers(tmp_path, seed):
+    """Sixteen drawn jobs over the five decoder job of _mixed_spec: a random template (1 to 4 output segments, slices with open and
+    negative ends, corrected barcodes, `~`), SAM or FASTQ records, the pre-filters, the outgoing filter and the quality control
+    accumulators on or off.  Records byte for byte, counters and accumulators word for word the host's."""
+    rng = np.random.default_rng(1000 + seed)
+    directory = str(tmp_path)
+    spec = _mixed_spec()
+    lengths = (40, 8, 26)
+    spec["template"] = _random_template(rng, lengths)
+    if rng.random() < 0.4:
+        spec["filter incoming qc fail"] = True
+    if rng.random() < 0.4:
+        spec["filter outgoing qc fail"] = True
+    if rng.random() < 0.5:
+        spec["enable quality control"] = True
+    n, capacity = 9001, 4096
+    paths = _files(directory, spec, n, 100 + seed, lengths)
+    spec["input"] = paths
+    extension = ".fastq" if rng.random() < 0.4 else ".sam"
+    outputs = {}
+    for host in (False, True):
+        spec["output"] = [os.path.join(directory, ("host" if host else "device") + extension)]
+        incoming, words, did = _run(spec, capacity, host)
+        outputs[host] = (incoming, words, did, _records(spec["output"][0]))
+    device, host = outputs[False], outputs[True]
+    assert device[2]["rounds"] == 3 and device[2]["resumed"] == 0 and host[2]["rounds"] == 0, spec["template"]
+    assert device[0] == host[0] and np.array_equal(device[1], host[1]), spec["template"]
+    if device[3] != host[3]:
+        for k, (a, b) in enumerate(zip(device[3].split(b"\n"), host[3].split(b"\n"))):
+            assert a == b, (k, a, b, spec["template"])
+    assert device[3] == host[3], spec["template"]
+    assert np.array_equal(device[2]["quality_control"], host[2]["quality_control"]), spec["template"]
