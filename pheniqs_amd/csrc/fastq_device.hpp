@@ -1,12 +1,13 @@
-// FASTQ text -> decoder planes ON THE DEVICE, for runs that write nothing (report only: every
-// output /dev/null, reference feed.h:105 NullFeed — the workload of docs/illumina_api_vignette.md's prior estimation).
+// FASTQ text -> decoder planes ON THE DEVICE: for runs that write nothing (report only: every
+// output /dev/null, reference feed.h:105 NullFeed — the workload of docs/illumina_api_vignette.md's prior estimation) and
+// for runs whose records are assembled on the device too (record_device.hpp).
 //
 //   reference fastq.h:55-78      FastqRecord::decode: ASCII -> BAM code, quality - phred offset
 //   reference fastq.h:253-285    the Illumina comment's filter flag
 //   reference read.h:253-264     Read::validate: every segment of a read carries the same identifier
 //   reference transform.h:142-169, 65-80   Rule::apply, Token::absolute_start / absolute_end
 //
-// The host threads only move raw file bytes into a pinned buffer; kernels find the line ends, check the framing of every
+// The host threads only move raw file bytes into a pinned buffer (inflating them on the way when the file is a gzip stream); kernels find the line ends, check the framing of every
 // record, compare the names across the input files, read the filter flag and cut the decoders' tokens straight into the
 // observation planes phq_classify_device takes.  Anything out of the ordinary — a record that is not framed by '@' and
 // '+', a carriage return, a blank line, names out of sync, sequence and quality of different lengths — raises a flag and

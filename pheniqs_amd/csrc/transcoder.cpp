@@ -891,12 +891,19 @@ void device_check(hipError_t status, const char* what) {
     if(status != hipSuccess) { throw InternalError(std::string(what) + ": " + hipGetErrorString(status)); }
 }
 
-struct PlainFile {
+struct PlainFile {                     // an input file of the device path: plain, or a gzip stream inflated into the pinned buffer
     int descriptor = -1;
     size_t size = 0;
-    size_t position = 0;
+    size_t position = 0;               // of the round's first byte, in the (inflated) text
     double bytes_per_record = 0;
-    ~PlainFile() { if(descriptor >= 0) { ::close(descriptor); } }
+    gzFile zipped = nullptr;
+    bool ended = false;                // gzip: the stream has no more bytes
+    size_t held = 0;                   // gzip: bytes of text at the front of the round's pinned buffer
+    std::vector<uint8_t> head;         // gzip: the text inflated while the file was looked at, until the first round takes it
+    ~PlainFile() {
+        if(zipped) { gzclose(zipped); }
+        if(descriptor >= 0) { ::close(descriptor); }
+    }
 };
 
 }  // namespace
@@ -1090,7 +1097,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         }
         to.n_token = n_token - to.first_token;
     }
-    // plain regular files only (gzip members go through the host reader)
+    // regular files, plain or gzip
     std::vector<PlainFile> file(static_cast<size_t>(n_feed));
     for(int32_t f = 0; f < n_feed; ++f) {
         PlainFile& p = file[static_cast<size_t>(f)];
@@ -1100,8 +1107,22 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return OnDevice::NOT_TAKEN; }
         p.size = static_cast<size_t>(status.st_size);
         char head[1 << 16];
-        const ssize_t got = ::pread(p.descriptor, head, sizeof(head), 0);
-        if(got < 4 || (static_cast<unsigned char>(head[0]) == 0x1f && static_cast<unsigned char>(head[1]) == 0x8b) || head[0] != '@') { return OnDevice::NOT_TAKEN; }
+        ssize_t got = ::pread(p.descriptor, head, sizeof(head), 0);
+        if(got >= 2 && static_cast<unsigned char>(head[0]) == 0x1f && static_cast<unsigned char>(head[1]) == 0x8b) {
+            // a gzip stream: inflated on a host thread of the feed's own into the pinned buffer, the text then goes the same way
+            // (inflating bounds such a run whoever does it: 0.3 GB/s of text a stream)
+            p.zipped = gzopen(plan.input_feed[static_cast<size_t>(f)].path.c_str(), "rb");
+            if(p.zipped == nullptr) { return OnDevice::NOT_TAKEN; }
+            gzbuffer(p.zipped, 1 << 20);
+            p.head.resize(sizeof(head));
+            const int inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size()));
+            if(inflated < 4) { return OnDevice::NOT_TAKEN; }
+            p.head.resize(static_cast<size_t>(inflated));
+            std::memcpy(head, p.head.data(), p.head.size());
+            got = inflated;
+            p.size = size_t(1) << 62;                   // not known
+        }
+        if(got < 4 || head[0] != '@') { return OnDevice::NOT_TAKEN; }
         size_t lines = 0;
         for(ssize_t k = 0; k < got; ++k) { lines += head[k] == '\n' ? 1 : 0; }
         if(lines < 4) { return OnDevice::NOT_TAKEN; }
@@ -1195,7 +1216,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     for(int32_t f = 0; f < n_feed; ++f) {
         const double wanted = static_cast<double>(capacity) * device_plan.feed_resolution[f] * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;      // a read is `resolution` records of an interleaved file
         chunk_bytes[f] = static_cast<size_t>(std::min(wanted, 192.0 * 1048576.0));
-        chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1);
+        if(file[static_cast<size_t>(f)].zipped == nullptr) { chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1); }
         chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
         if(c.raw_bytes[f] < chunk_bytes[f]) {
             for(int b = 0; b < 2; ++b) { if(c.pinned[b][f]) { (void)hipHostFree(c.pinned[b][f]); c.pinned[b][f] = nullptr; } }
@@ -1313,10 +1334,30 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         if(ahead_task.valid()) { timed(0, [&]() { ahead_task.get(); }); }
         bool any_left = false;
         FastqFeedChunk chunk[FASTQ_MAX_FEED];
+        {
+            // gzip feeds: what the round before left is at the front of the pinned buffer; the feeds inflate side by side
+            std::atomic<bool> failed{false};
+            parallel_ranges(n_feed, 1, n_feed, [&](int64_t first_feed, int64_t last_feed, int) {
+                for(int64_t f = first_feed; f < last_feed; ++f) {
+                    PlainFile& p = file[static_cast<size_t>(f)];
+                    if(p.zipped == nullptr) { continue; }
+                    uint8_t* const to = c.pinned[buffer][f];
+                    if(!p.head.empty()) { std::memcpy(to, p.head.data(), p.head.size()); p.held = p.head.size(); p.head.clear(); }
+                    const size_t want = chunk_bytes[f] - 1;
+                    while(!p.ended && p.held < want) {
+                        const int got = gzread(p.zipped, to + p.held, static_cast<unsigned>(std::min<size_t>(want - p.held, size_t(1) << 30)));
+                        if(got < 0) { failed = true; return; }
+                        if(got == 0) { p.ended = true; break; }
+                        p.held += static_cast<size_t>(got);
+                    }
+                }
+            });
+            if(failed) { return give_up(); }
+        }
         for(int32_t f = 0; f < n_feed; ++f) {
             PlainFile& p = file[static_cast<size_t>(f)];
-            const size_t left = p.size - p.position;
-            size_t bytes = std::min(left, chunk_bytes[f] - 1);
+            const size_t left = p.zipped ? (p.ended ? p.held : p.held + 1) : p.size - p.position;
+            size_t bytes = p.zipped ? p.held : std::min(left, chunk_bytes[f] - 1);
             any_left = any_left || left > 0;
             // the file's bytes into a pinned buffer, on every host thread — unless the read ahead of the round before already
             // holds them: that one started a little before where this round could begin at the earliest
@@ -1334,13 +1375,15 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                     }
                 });
             };
-            if(ahead_valid[f] && p.position >= ahead_start[f] && p.position + bytes <= ahead_start[f] + ahead_bytes[f]) {
+            if(p.zipped) {
+                // inflated above
+            } else if(ahead_valid[f] && p.position >= ahead_start[f] && p.position + bytes <= ahead_start[f] + ahead_bytes[f]) {
                 to = c.pinned[buffer][f] + (p.position - ahead_start[f]);
             } else {
                 read_into(to, p.position, bytes);
                 if(failed) { return give_up(); }
             }
-            source_bytes[f] = bytes;
+            source_bytes[f] = p.zipped ? 0 : bytes;                 // (nothing is read ahead of a gzip stream)
             if(bytes == left && bytes > 0 && to[bytes - 1] != '\n') { to[bytes++] = '\n'; }      // the last line of a file may lack its newline
             // (the copies of the feeds on streams of their own, beside the last kernel of the round before, were measured: no
             // gain that stands out of the box to box spread of the link's rate under the host's own memory traffic)
@@ -1411,6 +1454,14 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         for(int32_t f = 0; f < n_feed; ++f) {
             PlainFile& p = file[static_cast<size_t>(f)];
             round_began_at[f] = p.position;
+            if(p.zipped) {
+                // what the round did not take goes to the front of the next round's buffer (`buffer` is that one by now)
+                const size_t consumed = std::min<size_t>(round.consumed[f], p.held);          // (the newline the last line lacked is not held)
+                std::memmove(c.pinned[buffer][f], c.pinned[buffer ^ 1][f] + consumed, p.held - consumed);
+                p.held -= consumed;
+                p.position += consumed;
+                continue;
+            }
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }

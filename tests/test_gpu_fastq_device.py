@@ -100,19 +100,31 @@ def _both(spec, paths, capacity):
     return out
 
 
-@pytest.mark.parametrize("config,lengths,n,capacity", [("C2", (50, 8), 150000, 1 << 20), ("C2", (50, 8), 150000, 1 << 12),
-                                                       ("C5", (20, 100), 60000, 1 << 14), ("C4", (30, 10, 10), 60000, 1 << 20)])
-def test_device_decode_equals_the_oracle_and_the_host_reader(oracle, tmp_path, config, lengths, n, capacity):
-    """C5's fourth round is a `~` token: the files hold the reverse complement of its observation"""
+@pytest.mark.parametrize("config,lengths,n,capacity,zipped", [("C2", (50, 8), 150000, 1 << 20, False), ("C2", (50, 8), 150000, 1 << 12, False),
+                                                              ("C5", (20, 100), 60000, 1 << 14, False), ("C4", (30, 10, 10), 60000, 1 << 20, False),
+                                                              ("C2", (50, 8), 150000, 1 << 12, True), ("C4", (30, 10, 10), 60000, 1 << 13, True)])
+def test_device_decode_equals_the_oracle_and_the_host_reader(oracle, tmp_path, config, lengths, n, capacity, zipped):
+    """C5's fourth round is a `~` token: the files hold the reverse complement of its observation; `zipped`: every file a gzip
+    stream, inflated by a host thread per file into the pinned buffer the text is uploaded from"""
     spec = synthetic.config_spec(config, "pamld")
     spec["template"] = {"transform": {"token": ["0::"]}}
     content = []
     paths = _files(str(tmp_path), spec, n, 77, lengths, content)
+    if zipped:
+        import gzip
+        for k, path in enumerate(paths):
+            with open(path, "rb") as plain, gzip.open(path + ".gz", "wb", compresslevel=1) as packed:
+                packed.write(plain.read())
+            paths[k] = path + ".gz"
+        before = capi.device_path_counters()
     (device_words, device_incoming), (host_words, host_incoming) = _both(spec, paths, capacity)
     assert device_incoming == host_incoming and device_incoming[0] == n
     assert int(device_words[0] + device_words[1]) == n
     assert np.array_equal(device_words, host_words)
     _assert_counters_equal_the_oracle(oracle, spec, content, device_words)
+    if zipped:
+        after = capi.device_path_counters()
+        assert after["reads"] - before["reads"] == n and after["rounds"] - before["rounds"] == -(-n // max(capacity, 4096))
 
 
 def test_reverse_complement_tokens_and_negative_offsets_on_the_device(oracle, tmp_path):

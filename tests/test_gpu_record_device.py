@@ -86,10 +86,10 @@ def _mixed_spec():
 
 
 @pytest.mark.parametrize("case", ["sam_two_segments_filters", "sam_mixed_tokens", "fastq_interleaved", "outgoing_filter", "one_channel_silent",
-                                  "long_reads", "lengths_change"])
+                                  "long_reads", "lengths_change", "gzip_input"])
 def test_device_records_equal_the_host_writers(tmp_path, case):
     directory = str(tmp_path)
-    if case in ("sam_two_segments_filters", "fastq_interleaved", "outgoing_filter", "one_channel_silent", "long_reads", "lengths_change"):
+    if case in ("sam_two_segments_filters", "fastq_interleaved", "outgoing_filter", "one_channel_silent", "long_reads", "lengths_change", "gzip_input"):
         spec = synthetic.config_spec("C2", "pamld")
         spec["template"] = {"transform": {"token": ["0::", "1::"]}}
         lengths, n, capacity = (30, 8), 70001, 4096
@@ -113,6 +113,15 @@ def test_device_records_equal_the_host_writers(tmp_path, case):
             lines = open(short, "rb").read().split(b"\n")[:4 * 3000]
             open(short, "wb").write(b"\n".join(lines) + b"\n" + open(long, "rb").read())
         n = 12000
+    if case == "gzip_input":
+        # the template file as a gzip stream of two members, the index file plain: the stream is inflated into the pinned buffer
+        import gzip
+        data = open(paths[0], "rb").read()
+        cut = data.index(b"\n@", len(data) // 2) + 1
+        with open(paths[0] + ".gz", "wb") as out:
+            out.write(gzip.compress(data[:cut], 1))
+            out.write(gzip.compress(data[cut:], 1))
+        paths[0] += ".gz"
     if case == "sam_two_segments_filters":
         # a few index reads under the minimum length: the pull loop drops those reads
         lines = open(paths[1], "rb").read().split(b"\n")
