@@ -35,6 +35,12 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as directory:
     for k, (text, qual) in enumerate(((template, template_quality), (index_text, index_quality))):
         path = os.path.join(directory, "segment_%d.fastq" % k)
         bench.write_fastq(path, k + 1, text, qual, filtered)
+        if os.environ.get("GZ"):                      # the inputs as gzip streams
+            import gzip
+            with open(path, "rb") as plain, gzip.open(path + ".gz", "wb", compresslevel=int(os.environ["GZ"])) as packed:
+                packed.write(plain.read())
+            os.unlink(path)
+            path += ".gz"
         paths.append(path)
     for name in targets:
         target = {"file": os.path.join(directory, "out.sam"), "zero": "/dev/zero", "null": "/dev/null"}[name]
