@@ -11,6 +11,8 @@ bool stage_uses_worklist(const DevDecoder&, int32_t) { return false; }
 // ... and the device FASTQ path (fastq_device.hip) is never taken by a set without a device
 int unpack_planes(const uint8_t*, uint8_t*, uint8_t*, size_t, void*) { return 100; }
 int patch_escapes(const uint64_t*, int64_t, int64_t, int64_t, int32_t, const int32_t*, const int32_t*, uint8_t*, uint8_t*, void*) { return 100; }
+int record_sizes_by_sink(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, int32_t, int32_t, void*) { return 100; }
+int record_write_by_sink(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, int32_t, int32_t, void*) { return 100; }
 int record_quality_control(const FastqTables*, const FastqPlan&, int32_t, uint32_t, int64_t, const uint8_t*, const uint8_t*, const uint8_t*, const uint32_t*, const RecordRound&, uint32_t*, void*) { return 100; }
 void fastq_plan_waves(FastqPlan&, double) {}
 void fastq_fill_tables(FastqTables&) {}

@@ -22,6 +22,7 @@ struct RecordArgs {
     RecordRound round;
     uint32_t output_room;           // bytes of LDS a wave has for the text of its reads (record_write)
     uint32_t* overflow;             // record_quality_control: a segment longer than the cells' cycles
+    int32_t n_out, n_sink;          // the kernels of several sinks: what the plan says, for the launch's LDS layout
 };
 
 // The bytes of a record: counted (pass 1), or stored (pass 2) — into the wave's LDS, from where the wave copies its reads'
@@ -322,21 +323,32 @@ __device__ void put_tags(W& out, const ReadView& read, int group, const double (
     if(confidence[2] > 0 && confidence[2] < 1) { put_literal(out, "\tXC:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[2])); }
 }
 
-// every record of one read, in output segment order
-template <typename W>
-__device__ void put_read(W& out, const ReadView& read) {
-    const RecordPlan& plan = *read.plan;
-    // Multiplexer::push -> Channel::push (multiplex.h:198-240)
-    int group;
-    const int channel = read.channel_of(group);
-    const uint8_t mode = plan.bytes[plan.channel_at + channel];
-    const bool qcfail = (read.args->round.word[read.row] >> 31) != 0;
-    if(!(mode & 1u) || ((mode & 2u) && qcfail)) { return; }
-
+// what the records of a read share: its channel, its read group, the tags' ingredients
+struct ReadTags {
+    int channel, group;
+    bool qcfail;
     double confidence[3];
-    read.confidences(confidence);
-    const uint32_t raw_size[3] = {read.raw_size(0), read.raw_size(1), read.raw_size(2)};
-    const uint32_t corrected_size[3] = {read.corrected_size(0), read.corrected_size(1), read.corrected_size(2)};
+    uint32_t raw_size[3], corrected_size[3];
+};
+
+// Multiplexer::push -> Channel::push (multiplex.h:198-240); false: no record of the read is written
+__device__ bool prepare_tags(const ReadView& read, ReadTags& tags) {
+    const RecordPlan& plan = *read.plan;
+    tags.channel = read.channel_of(tags.group);
+    const uint8_t mode = plan.bytes[plan.channel_at + tags.channel];
+    tags.qcfail = (read.args->round.word[read.row] >> 31) != 0;
+    if(!(mode & 1u) || ((mode & 2u) && tags.qcfail)) { return false; }
+    read.confidences(tags.confidence);
+    for(int kind = 0; kind < 3; ++kind) { tags.raw_size[kind] = read.raw_size(kind); tags.corrected_size[kind] = read.corrected_size(kind); }
+    return true;
+}
+// where output segment o of a channel goes: a sink of the plan, or -1
+__device__ __forceinline__ int sink_of(const RecordPlan& plan, int channel, int o) { return plan.ints[plan.sink_at + channel * plan.n_out + o]; }
+
+// one record: output segment o of the read, as a FASTQ record or a SAM line
+template <typename W>
+__device__ void put_record(W& out, const ReadView& read, const ReadTags& tags, int o, bool fastq) {
+    const RecordPlan& plan = *read.plan;
     const FeedBytes name_text = read.bytes->feed(read.args->tables->plan.segment_feed[0]);
     auto put_name = [&]() {
         if(!W::WRITES) { out.room(read.at.name_size); return; }
@@ -347,38 +359,48 @@ __device__ void put_read(W& out, const ReadView& read) {
         }
         for(; i < read.at.name_size; ++i) { out.put(static_cast<char>(name_text(read.at.name_at + i))); }
     };
-    for(int o = 0; o < plan.n_out; ++o) {
-        if(plan.fastq) {
-            // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
-            out.put('@');
-            put_name();
-            out.put(' ');
-            if(plan.illumina_comment) {
-                put_number(out, static_cast<uint32_t>(o + 1));
-                put_literal(out, qcfail ? ":Y:0:" : ":N:0:");
-                read.put_raw(out, 0, false);
-            }
-            out.put('\n');
-            read.put_segment(out, o, false);
-            put_literal(out, "\n+\n");
-            read.put_segment(out, o, true);
-            out.put('\n');
-            continue;
-        }
+    if(fastq) {
+        // FastqRecord::decode(segment) + encode (fastq.h:79-88,144-171), comment fastq.h:176-194
+        out.put('@');
         put_name();
-        put_bytes(out, plan.columns[o][qcfail ? 1 : 0], static_cast<uint32_t>(plan.columns_size[o][qcfail ? 1 : 0]));
-        if(read.bases_of(o) == 0) { put_literal(out, "*\t*"); }
-        else {
-            read.put_segment(out, o, false);
-            out.put('\t');
-            read.put_segment(out, o, true);
+        out.put(' ');
+        if(plan.illumina_comment) {
+            put_number(out, static_cast<uint32_t>(o + 1));
+            put_literal(out, tags.qcfail ? ":Y:0:" : ":N:0:");
+            read.put_raw(out, 0, false);
         }
-        if(plan.n_out > 2) {
-            put_literal(out, "\tFI:i:"); put_number(out, static_cast<uint32_t>(o + 1));
-            put_literal(out, "\tTC:i:"); put_number(out, static_cast<uint32_t>(plan.n_out));
-        }
-        put_tags(out, read, group, confidence, raw_size, corrected_size);
         out.put('\n');
+        read.put_segment(out, o, false);
+        put_literal(out, "\n+\n");
+        read.put_segment(out, o, true);
+        out.put('\n');
+        return;
+    }
+    put_name();
+    put_bytes(out, plan.columns[o][tags.qcfail ? 1 : 0], static_cast<uint32_t>(plan.columns_size[o][tags.qcfail ? 1 : 0]));
+    if(read.bases_of(o) == 0) { put_literal(out, "*\t*"); }
+    else {
+        read.put_segment(out, o, false);
+        out.put('\t');
+        read.put_segment(out, o, true);
+    }
+    if(plan.n_out > 2) {
+        put_literal(out, "\tFI:i:"); put_number(out, static_cast<uint32_t>(o + 1));
+        put_literal(out, "\tTC:i:"); put_number(out, static_cast<uint32_t>(plan.n_out));
+    }
+    put_tags(out, read, tags.group, tags.confidence, tags.raw_size, tags.corrected_size);
+    out.put('\n');
+}
+
+// every record of one read, in output segment order (a plan of one sink: they are consecutive in it)
+template <typename W>
+__device__ void put_read(W& out, const ReadView& read) {
+    const RecordPlan& plan = *read.plan;
+    ReadTags tags;
+    if(!prepare_tags(read, tags)) { return; }
+    for(int o = 0; o < plan.n_out; ++o) {
+        const int sink = sink_of(plan, tags.channel, o);
+        if(sink >= 0) { put_record(out, read, tags, o, plan.bytes[plan.format_at + sink] != 0); }
     }
 }
 
@@ -554,6 +576,191 @@ __global__ __launch_bounds__(TILE_THREADS) void record_write_kernel(RecordArgs a
     if(lane < wave_total - tail_at) { wave_text[tail_at + lane] = static_cast<char>(staged[out_at + skew + tail_at + lane]); }
 }
 
+// ---- several sinks ----------------------------------------------------------------------------------------------------
+// pass 1: the bytes of every record, and per workgroup the bytes every sink gets
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void record_size_sinks_kernel(RecordArgs args) {
+    __shared__ uint32_t wave_kept[TILE_WAVES];
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t* const sink_bytes = reinterpret_cast<uint32_t*>(&staged[static_cast<uint32_t>(TILE_WAVES) * static_cast<uint32_t>(plan.input_room)]);      // [n_sink]
+    for(int s = threadIdx.x; s < args.n_sink; s += TILE_THREADS) { sink_bytes[s] = 0; }
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    WaveInput bytes_of;
+    stage_wave_input(plan, chunk, wave_first, wave_count, (threadIdx.x >> 6) * static_cast<uint32_t>(plan.input_room), bytes_of);
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
+    if(present) {
+        ReadView read;
+        read.args = &args;
+        read.plan = args.round.plan;
+        read.row = row;
+        read.bytes = &bytes_of;
+        ReadTags tags;
+        bool written = false;
+        if(wanted) {
+            locate(plan, chunk, bytes_of, r, read.at);
+            written = prepare_tags(read, tags);
+        }
+        for(int o = 0; o < args.n_out; ++o) {
+            uint32_t bytes = 0;
+            const int sink = written ? sink_of(*read.plan, tags.channel, o) : -1;
+            if(sink >= 0) {
+                CountOut out{0};
+                put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + sink] != 0);
+                bytes = out.count;
+                atomicAdd(&sink_bytes[sink], bytes);
+            }
+            args.round.piece_size[static_cast<size_t>(r) * static_cast<size_t>(args.n_out) + static_cast<size_t>(o)] = bytes;
+        }
+    }
+    __syncthreads();
+    for(int s = threadIdx.x; s < args.n_sink; s += TILE_THREADS) {
+        args.round.sink_block[static_cast<size_t>(blockIdx.x) * static_cast<size_t>(args.n_sink) + static_cast<size_t>(s)] = sink_bytes[s];
+    }
+}
+
+// one workgroup per sink: exclusive prefix sums of its bytes over the workgroups of pass 1, in place; its total to sink_base[sink]
+__global__ __launch_bounds__(256) void record_scan_sinks_kernel(unsigned long long* sink_block, uint32_t n_block, int32_t n_sink, unsigned long long* sink_base) {
+    __shared__ unsigned long long wave_sum[4];
+    __shared__ unsigned long long carried;
+    if(threadIdx.x == 0) { carried = 0; }
+    __syncthreads();
+    const size_t sink = blockIdx.x;
+    for(uint32_t first = 0; first < n_block; first += 256) {
+        const uint32_t at = first + threadIdx.x;
+        const unsigned long long own = at < n_block ? sink_block[static_cast<size_t>(at) * static_cast<size_t>(n_sink) + sink] : 0ull;
+        unsigned long long inclusive = own;
+        for(int step = 1; step < 64; step <<= 1) {
+            const unsigned long long below = __shfl_up(inclusive, step);
+            if(static_cast<int>(threadIdx.x & 63) >= step) { inclusive += below; }
+        }
+        if((threadIdx.x & 63) == 63) { wave_sum[threadIdx.x >> 6] = inclusive; }
+        __syncthreads();
+        unsigned long long before = carried;
+        for(uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { before += wave_sum[w]; }
+        if(at < n_block) { sink_block[static_cast<size_t>(at) * static_cast<size_t>(n_sink) + sink] = before + inclusive - own; }
+        __syncthreads();
+        if(threadIdx.x == 255) { carried = before + inclusive; }
+        __syncthreads();
+    }
+    if(threadIdx.x == 0) { sink_base[sink] = carried; }
+}
+
+// the sinks' totals to where each one's records start in the text; sink_base[n_sink] = the whole text
+__global__ void record_base_kernel(unsigned long long* sink_base, int32_t n_sink) {
+    if(threadIdx.x != 0 || blockIdx.x != 0) { return; }
+    unsigned long long before = 0;
+    for(int s = 0; s < n_sink; ++s) { const unsigned long long own = sink_base[s]; sink_base[s] = before; before += own; }
+    sink_base[n_sink] = before;
+}
+
+// pass 2: a read's records are put together in the wave's LDS, one after the other, and every record then leaves for its
+// place in its sink's part of the text, the wave's lanes a byte each (a record is consecutive bytes: whole lines again)
+template <bool FILTER>
+__global__ __launch_bounds__(TILE_THREADS) void record_write_sinks_kernel(RecordArgs args) {
+    __shared__ uint32_t wave_kept[TILE_WAVES];
+    const FastqPlan& plan = args.tables->plan;
+    const FastqFeedChunk* const chunk = args.tables->chunk[args.slot];
+    uint32_t wave_first, wave_count;
+    bool present;
+    const uint32_t r = read_of_lane(plan, args.n, wave_first, wave_count, present);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave_room = static_cast<uint32_t>(plan.input_room) + args.output_room + 16u;
+    // behind the waves' text: sink and bytes of every record of the workgroup's reads, in (read, output segment) order
+    const uint32_t pieces = static_cast<uint32_t>(TILE_WAVES * plan.reads_per_wave * args.n_out);
+    uint32_t* const piece_bytes = reinterpret_cast<uint32_t*>(&staged[TILE_WAVES * wave_room]);
+    int32_t* const piece_sink = reinterpret_cast<int32_t*>(piece_bytes + pieces);
+    WaveInput bytes_of;
+    stage_wave_input(plan, chunk, wave_first, wave_count, wave * wave_room, bytes_of);
+    bool wanted;
+    const uint32_t row = row_of<FILTER>(r, present, args.keep, args.keep_block, wave_kept, wanted);
+    ReadView read;
+    read.args = &args;
+    read.plan = args.round.plan;
+    read.row = row;
+    read.bytes = &bytes_of;
+    ReadTags tags;
+    bool written = false;
+    if(wanted) {
+        locate(plan, chunk, bytes_of, r, read.at);
+        written = prepare_tags(read, tags);
+    }
+    const uint32_t local = (wave * static_cast<uint32_t>(plan.reads_per_wave) + lane) * static_cast<uint32_t>(args.n_out);      // the read's first piece
+    uint32_t own = 0;
+    if(lane < static_cast<uint32_t>(plan.reads_per_wave)) {
+        for(int o = 0; o < args.n_out; ++o) {
+            const uint32_t bytes = present ? args.round.piece_size[static_cast<size_t>(r) * static_cast<size_t>(args.n_out) + static_cast<size_t>(o)] : 0u;
+            piece_bytes[local + o] = bytes;
+            piece_sink[local + o] = bytes ? sink_of(*read.plan, tags.channel, o) : -1;
+            own += bytes;
+        }
+    }
+    uint32_t inclusive = own;
+    for(int step = 1; step < 64; step <<= 1) {
+        const uint32_t below = __shfl_up(inclusive, step);
+        if(static_cast<int>(lane) >= step) { inclusive += below; }
+    }
+    const uint32_t wave_total = static_cast<uint32_t>(__shfl(static_cast<int>(inclusive), 63));
+    __syncthreads();
+    // where each of the read's records goes: its sink's part of the text, the workgroup's place in it (pass 1's prefix sums),
+    // and the bytes of the workgroup's earlier records for the same sink
+    char* place[RECORD_MAX_OUT];
+    uint32_t bytes_of_piece[RECORD_MAX_OUT];
+#pragma unroll
+    for(int o = 0; o < RECORD_MAX_OUT; ++o) {
+        place[o] = nullptr;
+        bytes_of_piece[o] = 0;
+        if(o < args.n_out && own != 0 && piece_bytes[local + o] != 0) {
+            const int sink = piece_sink[local + o];
+            unsigned long long before = args.round.sink_base[sink] + args.round.sink_block[static_cast<size_t>(blockIdx.x) * static_cast<size_t>(args.n_sink) + static_cast<size_t>(sink)];
+            for(uint32_t e = 0; e < local + static_cast<uint32_t>(o); ++e) { before += piece_sink[e] == sink ? piece_bytes[e] : 0u; }
+            place[o] = args.round.text + before;
+            bytes_of_piece[o] = piece_bytes[local + o];
+        }
+    }
+    const bool through_lds = wave_total <= args.output_room;
+    const uint32_t out_at = wave * wave_room + static_cast<uint32_t>(plan.input_room);
+    if(written && own != 0) {
+        if(through_lds) {
+            LdsOut out{out_at + inclusive - own};
+#pragma unroll
+            for(int o = 0; o < RECORD_MAX_OUT; ++o) {
+                if(o < args.n_out && bytes_of_piece[o] != 0) { put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]] != 0); }
+            }
+        } else {
+#pragma unroll
+            for(int o = 0; o < RECORD_MAX_OUT; ++o) {
+                if(o < args.n_out && bytes_of_piece[o] != 0) {
+                    GlobalOut out{place[o]};
+                    put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]] != 0);
+                }
+            }
+        }
+    }
+    if(!through_lds || wave_total == 0) { return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t from = out_at + inclusive - own;            // the lane's first record in LDS
+#pragma unroll
+    for(int o = 0; o < RECORD_MAX_OUT; ++o) {
+        if(o >= args.n_out) { break; }
+        for(int owner = 0; owner < plan.reads_per_wave; ++owner) {
+            const uint32_t bytes = static_cast<uint32_t>(__shfl(static_cast<int>(bytes_of_piece[o]), owner));
+            if(bytes == 0) { continue; }
+            const uint32_t source = static_cast<uint32_t>(__shfl(static_cast<int>(from), owner));
+            const unsigned long long target = (static_cast<unsigned long long>(static_cast<uint32_t>(__shfl(static_cast<int>(reinterpret_cast<uintptr_t>(place[o]) >> 32), owner))) << 32) |
+                                              static_cast<uint32_t>(__shfl(static_cast<int>(reinterpret_cast<uintptr_t>(place[o]) & 0xffffffffu), owner));
+            char* const to = reinterpret_cast<char*>(target);
+            for(uint32_t k = lane; k < bytes; k += 64u) { to[k] = static_cast<char>(staged[source + k]); }
+        }
+        from += bytes_of_piece[o];
+    }
+}
+
 RecordArgs arguments_of(const FastqTables* on_device, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                         const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, uint32_t output_room) {
     RecordArgs call;
@@ -568,6 +775,8 @@ RecordArgs arguments_of(const FastqTables* on_device, int32_t slot, uint32_t n, 
     call.round = round;
     call.output_room = output_room;
     call.overflow = nullptr;
+    call.n_out = 0;
+    call.n_sink = 0;
     return call;
 }
 
@@ -611,6 +820,49 @@ int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t sl
     hipStream_t s = static_cast<hipStream_t>(stream);
     if(plan.filtering) { hipLaunchKernelGGL(record_write_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     else { hipLaunchKernelGGL(record_write_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    return static_cast<int>(hipGetLastError());
+}
+
+int record_sizes_by_sink(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                         const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, int32_t n_out, int32_t n_sink, void* stream) {
+    if(n_out < 1 || n_out > RECORD_MAX_OUT || n_sink < 1 || n_sink > RECORD_MAX_SINK) { return static_cast<int>(hipErrorInvalidValue); }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t blocks = n > 0 ? fastq_groups(plan, n) : 0u;
+    if(blocks > 0) {
+        RecordArgs call = arguments_of(on_device, slot, n, capacity, base_planes, quality_planes, keep, keep_block, round, 0);
+        call.n_out = n_out;
+        call.n_sink = n_sink;
+        const size_t lds = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.input_room) + static_cast<size_t>(n_sink) * sizeof(uint32_t);
+        static std::atomic<uint64_t> prepared[2];
+        if(const int status = allow_lds(&record_size_sinks_kernel<true>, prepared[0], lds)) { return status; }
+        if(const int status = allow_lds(&record_size_sinks_kernel<false>, prepared[1], lds)) { return status; }
+        if(plan.filtering) { hipLaunchKernelGGL(record_size_sinks_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+        else { hipLaunchKernelGGL(record_size_sinks_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    }
+    hipLaunchKernelGGL(record_scan_sinks_kernel, dim3(static_cast<unsigned>(n_sink)), dim3(256), 0, s, round.sink_block, blocks, n_sink, round.sink_base);
+    hipLaunchKernelGGL(record_base_kernel, dim3(1), dim3(1), 0, s, round.sink_base, n_sink);
+    return static_cast<int>(hipGetLastError());
+}
+
+int record_write_by_sink(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                         const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, int32_t n_out, int32_t n_sink, void* stream) {
+    if(n == 0) { return 0; }
+    if(n_out < 1 || n_out > RECORD_MAX_OUT || n_sink < 1 || n_sink > RECORD_MAX_SINK) { return static_cast<int>(hipErrorInvalidValue); }
+    const uint32_t blocks = fastq_groups(plan, n);
+    const size_t pieces = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.reads_per_wave) * static_cast<size_t>(n_out);
+    // the pieces' table takes its room from the waves' output
+    const int32_t spare = (152 * 1024 - static_cast<int32_t>(pieces * 8)) / TILE_WAVES - plan.input_room - 16;
+    const uint32_t output_room = static_cast<uint32_t>(std::max(std::min(spare, 2 * plan.input_room), 0) & ~15);
+    RecordArgs call = arguments_of(on_device, slot, n, capacity, base_planes, quality_planes, keep, keep_block, round, output_room);
+    call.n_out = n_out;
+    call.n_sink = n_sink;
+    const size_t lds = static_cast<size_t>(TILE_WAVES) * (static_cast<size_t>(plan.input_room) + output_room + 16u) + pieces * 8;
+    static std::atomic<uint64_t> prepared[2];
+    if(const int status = allow_lds(&record_write_sinks_kernel<true>, prepared[0], lds)) { return status; }
+    if(const int status = allow_lds(&record_write_sinks_kernel<false>, prepared[1], lds)) { return status; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if(plan.filtering) { hipLaunchKernelGGL(record_write_sinks_kernel<true>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
+    else { hipLaunchKernelGGL(record_write_sinks_kernel<false>, dim3(blocks), dim3(TILE_THREADS), lds, s, call); }
     return static_cast<int>(hipGetLastError());
 }
 

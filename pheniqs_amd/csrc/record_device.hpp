@@ -22,6 +22,7 @@ namespace phq {
 
 constexpr int RECORD_MAX_TOKEN = 32;
 constexpr int RECORD_MAX_OUT = 8;
+constexpr int RECORD_MAX_SINK = 1024;       // output files of a run whose records are assembled on the device
 
 struct RecordDecoder {
     int32_t kind;                   // 0 sample, 1 molecular, 2 cellular
@@ -53,7 +54,9 @@ struct RecordPlan {
     int32_t n_decoder;
     int32_t n_out;                  // output segments
     int32_t n_channel;
-    int32_t fastq;                  // 1: FASTQ records, 0: SAM
+    int32_t n_sink;                 // output files the records go to
+    int32_t sink_at;                // ints[sink_at + channel * n_out + o]: the sink of output segment o of a channel, -1 none
+    int32_t format_at;              // bytes[format_at + sink]: 1 FASTQ records, 0 SAM
     int32_t illumina_comment;
     int32_t quality_shift;          // output Phred offset - input Phred offset
     int32_t input_phred_offset;
@@ -83,6 +86,11 @@ struct RecordRound {
     unsigned long long* block;      // device scratch: n / 256 + 2 words
     unsigned long long* total;      // device: bytes of the round's text (after record_sizes)
     char* text;                     // device: at least *total bytes (record_write)
+    // a plan of several sinks (record_sizes_by_sink / record_write_by_sink): every sink's records are consecutive in `text`,
+    // sink s from byte sink_base[s] on; sink_base[n_sink] is the whole text
+    uint32_t* piece_size;           // device scratch: n x n_out words, the bytes of the record of output segment o of read r
+    unsigned long long* sink_block; // device scratch: (n / 32 + 2) x n_sink words: bytes per workgroup's reads and sink, then their prefix sums
+    unsigned long long* sink_base;  // device: n_sink + 1 words
     unsigned long long* quality_control;        // device: the accumulators (record_quality_control), or NULL
     int32_t cycles;                 // ... and the cycles every cell of them holds
 };
@@ -103,6 +111,12 @@ int record_sizes(const FastqTables* on_device, const FastqPlan& plan, int32_t sl
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
 int record_write(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
                  const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, void* stream);
+// the same two passes for a plan of several sinks: the records of a read go to the files of its channel, every file's
+// records stay in input order
+int record_sizes_by_sink(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                         const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, int32_t n_out, int32_t n_sink, void* stream);
+int record_write_by_sink(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,
+                         const uint8_t* keep, const uint32_t* keep_block, const RecordRound& round, int32_t n_out, int32_t n_sink, void* stream);
 // every read the pull loop kept is counted in the cell of its channel, written or not (multiplex.h:219-221); an output
 // segment longer than round.cycles is not counted and sets *overflow (device)
 int record_quality_control(const FastqTables* on_device, const FastqPlan& plan, int32_t slot, uint32_t n, int64_t capacity, const uint8_t* base_planes, const uint8_t* quality_planes,

@@ -847,6 +847,11 @@ struct DeviceFastqCache {
     uint8_t* record_bytes = nullptr;               // device
     size_t record_ints_room = 0, record_bytes_room = 0;
     int64_t record_capacity = 0;
+    uint32_t* piece_size = nullptr;                // several sinks: device [capacity x n_out]
+    unsigned long long* sink_block = nullptr;      // ... device [(capacity / 32 + 2) x n_sink]
+    unsigned long long* sink_base = nullptr;       // ... device [n_sink + 1]
+    unsigned long long* sink_base_host[2] = {nullptr, nullptr};      // pinned, per text buffer
+    size_t piece_room = 0, sink_block_room = 0, sink_base_room = 0;
     unsigned long long* qc_device = nullptr;       // the quality control accumulators (record_device.hpp), cells of qc_cycles cycles
     int32_t qc_cycles = 0;
     size_t qc_cells = 0;
@@ -864,6 +869,8 @@ struct DeviceFastqCache {
     hipEvent_t written[2] = {nullptr, nullptr};    // the round's text is in text_device[b]
     hipEvent_t copied[2] = {nullptr, nullptr};     // ... and in text_host[b]
     ~DeviceFastqCache() {
+        (void)hipFree(piece_size); (void)hipFree(sink_block); (void)hipFree(sink_base);
+        for(int b = 0; b < 2; ++b) { if(sink_base_host[b]) { (void)hipHostFree(sink_base_host[b]); } }
         (void)hipFree(tables); (void)hipFree(qc_device); (void)hipFree(qc_overflow); (void)hipFree(longest);
         (void)hipFree(record_plan); (void)hipFree(record_ints); (void)hipFree(record_bytes); (void)hipFree(record_size); (void)hipFree(record_block); (void)hipFree(record_total);
         if(status_host) { (void)hipHostFree(status_host); }
@@ -918,7 +925,7 @@ void device_path_counters(uint64_t* counters) {
 // A run whose every written channel sends all its output segments to ONE uncompressed file: which sink, and the tables
 // the device needs to assemble the records (record_device.hpp).  `ints` and `bytes` are the two pools RecordPlan points into.
 struct DeviceText {
-    int32_t sink = -1;              // -1: no channel writes (a run that only counts: the quality control accumulators)
+    std::vector<int32_t> sinks;     // the output files records go to (indices into the transcoder's sinks); empty: a run that only counts
     bool quality_control = false;   // the accumulators of `enable quality control` are kept on the device (record_quality_control)
     RecordPlan plan;
     std::vector<int32_t> ints;
@@ -933,26 +940,28 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
     if(std::getenv("PHQ_HOST_RECORDS") != nullptr) { return false; }
     const int32_t n_out = job.output_segment_cardinality;
     if(n_out < 1 || n_out > RECORD_MAX_OUT || job.template_transform.size() > static_cast<size_t>(RECORD_MAX_TOKEN) || job.decoder.size() > static_cast<size_t>(FASTQ_MAX_DECODER)) { return false; }
-    // the channels: silent ones (every URL /dev/null) and empty ones take their reads without a record; the others all write
-    // every output segment to the same file
-    out.sink = -1;
+    // the channels: an empty one, or one whose every URL is /dev/null, takes its reads without a record; of the others every
+    // output segment goes to the file of its URL (uncompressed or gzip, SAM or FASTQ records): the sinks of the plan
+    out.sinks.clear();
+    std::vector<int32_t> device_sink(sink.size(), -1);
+    std::vector<int32_t> sink_of_segment(plan.channel.size() * static_cast<size_t>(n_out), -1);
     std::vector<uint8_t> mode(plan.channel.size(), 0);
     for(size_t c = 0; c < plan.channel.size(); ++c) {
         const auto& channel = plan.channel[c];
         if(channel.feed_by_segment.empty()) { continue; }
-        bool silent = true;
-        for(const int32_t f : channel.feed_by_segment) { silent = silent && sink[static_cast<size_t>(f)].null; }
-        if(silent) { continue; }
-        for(const int32_t f : channel.feed_by_segment) {
-            if(sink[static_cast<size_t>(f)].null || (out.sink >= 0 && f != out.sink)) { return false; }
-            out.sink = f;
+        bool writes = false;
+        for(int32_t o = 0; o < n_out; ++o) {
+            const int32_t f = channel.feed_by_segment[static_cast<size_t>(o)];
+            const OutputSink& to = sink[static_cast<size_t>(f)];
+            if(to.null) { continue; }
+            if(to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ) { return false; }
+            if(device_sink[static_cast<size_t>(f)] < 0) { device_sink[static_cast<size_t>(f)] = static_cast<int32_t>(out.sinks.size()); out.sinks.push_back(f); }
+            sink_of_segment[c * static_cast<size_t>(n_out) + static_cast<size_t>(o)] = device_sink[static_cast<size_t>(f)];
+            writes = true;
         }
-        mode[c] = static_cast<uint8_t>(1u | (channel.filter_outgoing_qc_fail ? 2u : 0u));
+        if(writes) { mode[c] = static_cast<uint8_t>(1u | (channel.filter_outgoing_qc_fail ? 2u : 0u)); }
     }
-    if(out.sink >= 0) {
-        const OutputSink& to = sink[static_cast<size_t>(out.sink)];
-        if(to.feed.gzip || (to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ)) { return false; }
-    }
+    if(out.sinks.size() > static_cast<size_t>(RECORD_MAX_SINK)) { return false; }
 
     RecordPlan& r = out.plan;
     std::memset(&r, 0, sizeof(r));
@@ -961,7 +970,7 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
     r.n_decoder = static_cast<int32_t>(job.decoder.size());
     r.n_out = n_out;
     r.n_channel = static_cast<int32_t>(plan.channel.size());
-    r.fastq = out.sink >= 0 && sink[static_cast<size_t>(out.sink)].feed.format == FileFormat::FASTQ ? 1 : 0;
+    r.n_sink = static_cast<int32_t>(out.sinks.size());
     r.illumina_comment = (job.platform == "ILLUMINA" || job.platform == "ELEMENT") ? 1 : 0;      // fastq.h:176-194
     r.quality_shift = job.output_phred_offset - job.input_phred_offset;
     r.input_phred_offset = job.input_phred_offset;
@@ -976,6 +985,11 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
     out.ints.push_back(static_cast<int32_t>(out.bytes.size()));
     r.channel_at = static_cast<int32_t>(out.bytes.size());
     out.bytes.insert(out.bytes.end(), mode.begin(), mode.end());
+    r.format_at = static_cast<int32_t>(out.bytes.size());
+    for(const int32_t f : out.sinks) { out.bytes.push_back(sink[static_cast<size_t>(f)].feed.format == FileFormat::FASTQ ? 1 : 0); }
+    out.bytes.push_back(0);
+    r.sink_at = static_cast<int32_t>(out.ints.size());
+    out.ints.insert(out.ints.end(), sink_of_segment.begin(), sink_of_segment.end());
     // the tokens of every output segment, in template order
     int32_t placed = 0;
     for(int32_t o = 0; o < n_out; ++o) {
@@ -1050,7 +1064,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
     if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return OnDevice::NOT_TAKEN; }
     if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return OnDevice::NOT_TAKEN; }
     if(job.enable_quality_control && (text == nullptr || !text->quality_control)) { return OnDevice::NOT_TAKEN; }
-    const bool writes = text != nullptr && text->sink >= 0;
+    const bool writes = text != nullptr && !text->sinks.empty();
     const bool counts = text != nullptr && text->quality_control;
     const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
     if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return OnDevice::NOT_TAKEN; }
@@ -1182,6 +1196,30 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             device_check(hipMalloc(reinterpret_cast<void**>(&c.record_size), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
             device_check(hipMalloc(reinterpret_cast<void**>(&c.record_block), (static_cast<size_t>(capacity) / 32 + 2) * sizeof(unsigned long long)), "hipMalloc");
             c.record_capacity = capacity;
+        }
+        {
+            const size_t n_sink = std::max<size_t>(text->sinks.size(), 1);
+            const size_t pieces = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.output_segment_cardinality, 1));
+            const size_t blocks = (static_cast<size_t>(capacity) / 32 + 2) * n_sink;
+            if(c.piece_room < pieces) {
+                (void)hipFree(c.piece_size); c.piece_size = nullptr; c.piece_room = 0;
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.piece_size), pieces * sizeof(uint32_t)), "hipMalloc");
+                c.piece_room = pieces;
+            }
+            if(c.sink_block_room < blocks) {
+                (void)hipFree(c.sink_block); c.sink_block = nullptr; c.sink_block_room = 0;
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.sink_block), blocks * sizeof(unsigned long long)), "hipMalloc");
+                c.sink_block_room = blocks;
+            }
+            if(c.sink_base_room < n_sink + 1) {
+                (void)hipFree(c.sink_base); c.sink_base = nullptr;
+                device_check(hipMalloc(reinterpret_cast<void**>(&c.sink_base), (n_sink + 1) * sizeof(unsigned long long)), "hipMalloc");
+                for(int b = 0; b < 2; ++b) {
+                    if(c.sink_base_host[b]) { (void)hipHostFree(c.sink_base_host[b]); c.sink_base_host[b] = nullptr; }
+                    device_check(hipHostMalloc(reinterpret_cast<void**>(&c.sink_base_host[b]), (n_sink + 1) * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc");
+                }
+                c.sink_base_room = n_sink + 1;
+            }
         }
         if(c.record_ints_room < text->ints.size()) {
             (void)hipFree(c.record_ints); c.record_ints = nullptr; c.record_ints_room = 0;
@@ -1535,12 +1573,27 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         }
         if(writes && decoded > 0) {
             // the records of the round: sizes, places, text (record_device.hpp), then off the device on the copy stream while
-            // the next round comes in on this one
+            // the next round comes in on this one.  One sink: its records are the text; several: every sink's records are a
+            // part of the text, in the sinks' order (sink_base says where each part starts).
             const int b = text_buffer;
-            device_check(static_cast<hipError_t>(record_sizes(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
-            device_check(hipMemcpyAsync(&c.status_host->text_bytes, c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            const int32_t n_sink = static_cast<int32_t>(text->sinks.size());
+            const int32_t n_out = text->plan.n_out;
+            record.piece_size = c.piece_size;
+            record.sink_block = c.sink_block;
+            record.sink_base = c.sink_base;
+            if(buffer_drained[b].valid()) { timed(4, [&]() { buffer_drained[b].get(); }); }        // text_host[b] and sink_base_host[b] are in the files
+            unsigned long long* const base_of_sink = c.sink_base_host[b];
+            if(n_sink == 1) {
+                device_check(static_cast<hipError_t>(record_sizes(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_sizes");
+                device_check(hipMemcpyAsync(&base_of_sink[1], c.record_total, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+                base_of_sink[0] = 0;
+            } else {
+                device_check(static_cast<hipError_t>(record_sizes_by_sink(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record,
+                                                                          n_out, n_sink, stream)), "record_sizes_by_sink");
+                device_check(hipMemcpyAsync(base_of_sink, c.sink_base, static_cast<size_t>(n_sink + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+            }
             timed(3, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });
-            const size_t bytes = static_cast<size_t>(c.status_host->text_bytes);
+            const size_t bytes = static_cast<size_t>(base_of_sink[n_sink]);
             if(bytes > 0) {
                 if(c.text_device_room[b] < bytes) {
                     device_check(hipStreamSynchronize(c.copy_stream), "hipStreamSynchronize");      // the copy of two rounds ago reads the old one
@@ -1551,9 +1604,13 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 }
                 device_check(hipStreamWaitEvent(stream, c.copied[b], 0), "hipStreamWaitEvent");       // text_device[b] has left (two rounds ago)
                 record.text = c.text_device[b];
-                device_check(static_cast<hipError_t>(record_write(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
+                if(n_sink == 1) {
+                    device_check(static_cast<hipError_t>(record_write(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record, stream)), "record_write");
+                } else {
+                    device_check(static_cast<hipError_t>(record_write_by_sink(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.keep, c.keep_block, record,
+                                                                              n_out, n_sink, stream)), "record_write_by_sink");
+                }
                 device_check(hipEventRecord(c.written[b], stream), "hipEventRecord");
-                if(buffer_drained[b].valid()) { timed(4, [&]() { buffer_drained[b].get(); }); }        // text_host[b] is in the file
                 if(c.text_host_room[b] < bytes) {
                     if(c.text_host[b]) { (void)hipHostFree(c.text_host[b]); c.text_host[b] = nullptr; c.text_host_room[b] = 0; }
                     const size_t room = bytes + bytes / 8 + (size_t(1) << 20);
@@ -1563,24 +1620,58 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 device_check(hipStreamWaitEvent(c.copy_stream, c.written[b], 0), "hipStreamWaitEvent");
                 device_check(hipMemcpyAsync(c.text_host[b], c.text_device[b], bytes, hipMemcpyDeviceToHost, c.copy_stream), "hipMemcpyAsync");
                 device_check(hipEventRecord(c.copied[b], c.copy_stream), "hipEventRecord");
-                // into the file, after the round before: a regular file takes the bytes through a mapping, on every host thread
-                OutputSink* const to = &m.sink[static_cast<size_t>(text->sink)];
+                // Into the files, after the round before.  A large part for a regular file goes through a mapping on several host
+                // threads; gzip sinks are compressed a member per piece, the sinks (or the pieces of a single one) side by side.
+                std::vector<OutputSink*> to(static_cast<size_t>(n_sink));
+                for(int32_t k = 0; k < n_sink; ++k) { to[static_cast<size_t>(k)] = &m.sink[static_cast<size_t>(text->sinks[static_cast<size_t>(k)])]; }
                 const char* const from = c.text_host[b];
                 hipEvent_t const arrived = c.copied[b];
                 const int device = m.set.device();
                 const std::shared_future<void> before = drained;
-                drained = std::async(std::launch::async, [to, from, bytes, arrived, device, before, threads]() {
+                drained = std::async(std::launch::async, [to, from, base_of_sink, n_sink, arrived, device, before, threads]() {
                     if(before.valid()) { before.get(); }
                     device_check(hipSetDevice(device), "hipSetDevice");
                     device_check(hipEventSynchronize(arrived), "hipEventSynchronize");
-                    char* const window = (to->seekable && bytes >= (1u << 20)) ? to->map_more(bytes) : nullptr;
-                    if(window == nullptr) { to->write(from, bytes); return; }
-                    parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, std::max(1, threads / 2), [&](int64_t first, int64_t last, int) {
-                        const size_t begin = static_cast<size_t>(first) << 20;
-                        const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
-                        std::memcpy(window + begin, from + begin, end - begin);
+                    const int workers = std::max(1, threads / 2);
+                    if(n_sink == 1) {
+                        OutputSink& sink = *to[0];
+                        const size_t bytes = static_cast<size_t>(base_of_sink[1]);
+                        if(sink.feed.gzip) {
+                            const size_t piece = size_t(4) << 20;
+                            const int64_t pieces = static_cast<int64_t>((bytes + piece - 1) / piece);
+                            std::vector<ByteBuffer> packed(static_cast<size_t>(pieces));
+                            parallel_ranges(pieces, 1, threads, [&](int64_t first, int64_t last, int) {
+                                for(int64_t k = first; k < last; ++k) {
+                                    const size_t begin = static_cast<size_t>(k) * piece;
+                                    gzip_member(from + begin, std::min(piece, bytes - begin), sink.feed.level, packed[static_cast<size_t>(k)]);
+                                }
+                            });
+                            for(const auto& member : packed) { sink.write(member.data.get(), member.size); }
+                            return;
+                        }
+                        char* const window = (sink.seekable && bytes >= (1u << 20)) ? sink.map_more(bytes) : nullptr;
+                        if(window == nullptr) { sink.write(from, bytes); return; }
+                        parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, workers, [&](int64_t first, int64_t last, int) {
+                            const size_t begin = static_cast<size_t>(first) << 20;
+                            const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
+                            std::memcpy(window + begin, from + begin, end - begin);
+                        });
+                        sink.unmap();
+                        return;
+                    }
+                    parallel_ranges(n_sink, 1, threads, [&](int64_t first, int64_t last, int) {
+                        ByteBuffer packed;
+                        for(int64_t k = first; k < last; ++k) {
+                            OutputSink& sink = *to[static_cast<size_t>(k)];
+                            const size_t begin = static_cast<size_t>(base_of_sink[k]), bytes = static_cast<size_t>(base_of_sink[k + 1] - base_of_sink[k]);
+                            if(bytes == 0) { continue; }
+                            if(sink.feed.gzip) {
+                                packed.clear();
+                                gzip_member(from + begin, bytes, sink.feed.level, packed);
+                                sink.write(packed.data.get(), packed.size);
+                            } else { sink.write(from + begin, bytes); }
+                        }
                     });
-                    to->unmap();
                 }).share();
                 buffer_drained[b] = drained;
                 text_buffer ^= 1;

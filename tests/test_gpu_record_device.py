@@ -191,21 +191,65 @@ def test_an_input_out_of_the_ordinary_part_way_is_handed_to_the_host_reader(tmp_
     assert device[2] == host[2]
 
 
-def test_what_the_device_does_not_write(tmp_path):
-    """gzip output, channels in files of their own and quality control go through the host writer (the counters say so)"""
+@pytest.mark.parametrize("case", ["file_per_barcode", "gzip_per_segment", "one_gzip_file"])
+def test_channels_in_files_of_their_own_and_gzip_output(tmp_path, case):
+    """Multiplexer::push (multiplex.h:198-240): every barcode of the multiplexing decoder is a channel with its own URLs.  On the
+    device every output file is a sink: pass 1 sums the bytes of every (workgroup, sink), a scan places them, pass 2 sends each
+    record to its sink's part of the text; gzip sinks are compressed by the host, a member per sink and round.  The files must
+    hold what the host writer's hold — gzip files after inflating (the members are cut elsewhere)."""
+    import gzip
     directory = str(tmp_path)
     spec = synthetic.config_spec("C2", "pamld")
-    spec["template"] = {"transform": {"token": ["0::"]}}
-    paths = _files(directory, spec, 5000, 8, (30, 8))
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    n, capacity = 60001, 4096
+    paths = _files(directory, spec, n, 21, (30, 8))
     spec["input"] = paths
-    spec["output"] = [os.path.join(directory, "out.sam.gz")]
-    _, _, did = _run(spec, 2048, host=False)
-    assert did["record_bytes"] == 0 and did["rounds"] == 0
-    spec["output"] = [os.path.join(directory, "rest.sam")]
-    first = next(iter(spec["sample"]["codec"]))
-    spec["sample"]["codec"][first]["output"] = [os.path.join(directory, "first.sam")]
-    _, _, did = _run(spec, 2048, host=False)
-    assert did["record_bytes"] == 0 and did["rounds"] == 0
+    keys = list(spec["sample"]["codec"])
+    names = []
+
+    def outputs(prefix):
+        names.clear()
+        if case == "one_gzip_file":
+            spec["output"] = [os.path.join(directory, prefix + "_all.sam.gz")]
+            names.append(spec["output"][0])
+            return
+        spec["output"] = [os.path.join(directory, prefix + "_rest.sam")]
+        names.append(spec["output"][0])
+        for k, key in enumerate(keys[:40]):
+            if case == "file_per_barcode":
+                # SAM for some, one interleaved FASTQ file for others, two FASTQ files for the rest; one barcode silent, one filtered
+                if k % 3 == 0:
+                    urls = [os.path.join(directory, "%s_%d.sam" % (prefix, k))]
+                elif k % 3 == 1:
+                    urls = [os.path.join(directory, "%s_%d.fastq" % (prefix, k))]
+                else:
+                    urls = [os.path.join(directory, "%s_%d_s%d.fastq" % (prefix, k, segment)) for segment in (1, 2)]
+            else:
+                urls = [os.path.join(directory, "%s_%d_s%d.fastq.gz" % (prefix, k, segment)) for segment in (1, 2)]
+            if k == 5:
+                urls = ["/dev/null"]
+            spec["sample"]["codec"][key]["output"] = urls
+            spec["sample"]["codec"][key]["filter outgoing qc fail"] = k == 7
+            names.extend(u for u in urls if u != "/dev/null")
+
+    results = {}
+    for host in (False, True):
+        outputs("host" if host else "device")
+        incoming, words, did = _run(spec, capacity, host)
+        content = {}
+        for name in names:
+            data = open(name, "rb").read()
+            if name.endswith(".gz"):
+                data = gzip.decompress(data)
+            content[os.path.basename(name).split("_", 1)[1]] = b"".join(line for line in data.split(b"\n") if not line.startswith(b"@PG"))
+        results[host] = (incoming, words, did, content)
+    device, host = results[False], results[True]
+    assert device[2]["rounds"] == -(-n // capacity) and device[2]["record_bytes"] > 0 and host[2]["rounds"] == 0
+    assert device[0] == host[0] and np.array_equal(device[1], host[1])
+    assert set(device[3]) == set(host[3]) and len(device[3]) == len(names)
+    for name in device[3]:
+        assert device[3][name] == host[3][name], name
+    assert sum(len(v) for v in device[3].values()) > 100 * n
 
 
 @pytest.mark.parametrize("case", ["written", "report_only", "mixed_tokens", "filters"])
