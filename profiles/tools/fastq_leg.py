@@ -18,6 +18,7 @@ spec = synthetic.config_spec("C2", "pamld")
 spec["template"] = {"transform": {"token": ["0::"]}}
 if os.environ.get("QC"):
     spec["enable quality control"] = True
+SPLIT = os.environ.get("SPLIT")                  # a FASTQ file per barcode (SPLIT=plain) or a gzip one (SPLIT=gz): target "split"
 s = DecoderSet(spec, device=0)
 job = capi.compile_job(spec)
 pool = 1 << 20
@@ -43,6 +44,23 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as directory:
             path += ".gz"
         paths.append(path)
     for name in targets:
+        if name == "split":
+            split_spec = dict(spec)
+            split_spec["input"] = paths
+            split_spec["output"] = [os.path.join(directory, "rest.fastq")]
+            split_spec["sample"] = dict(spec["sample"])
+            split_spec["sample"]["codec"] = {key: dict(value, output=[os.path.join(directory, "%d.fastq%s" % (k, ".gz" if SPLIT == "gz" else ""))])
+                                             for k, (key, value) in enumerate(spec["sample"]["codec"].items())}
+            split = DecoderSet(split_spec, device=0)
+            for attempt in range(3):
+                before = capi.device_path_counters()
+                t0 = time.perf_counter()
+                incoming, _ = split.transcode_job(capacity)
+                dt = time.perf_counter() - t0
+                after = capi.device_path_counters()
+                print(name, attempt, "%.1f Mreads/s  %.1f ms" % (n / dt / 1e6, dt * 1e3), {k: after[k] - before[k] for k in after}, flush=True)
+            split.close()
+            continue
         target = {"file": os.path.join(directory, "out.sam"), "zero": "/dev/zero", "null": "/dev/null"}[name]
         for attempt in range(3):
             if os.path.isfile(target):
