@@ -1,5 +1,6 @@
 // Output records — SAM or FASTQ text — assembled ON THE DEVICE from the FASTQ chunks, the observation planes and the result
-// records of a round, for a job whose every written channel goes to one uncompressed file.
+// records of a round: one stream, or a set of files per barcode of the multiplexing decoder (the host
+// copies the finished text into them, and compresses the gzip ones).
 //
 //   reference read.h:187-237        Read::flush: the per type accumulators into the auxiliary tags
 //   reference auxiliary.cpp:324-354 Auxiliary::encode: the order of the tags (FI TC RG BC QT XB RX QX OX BZ XM CB CR CY XC)

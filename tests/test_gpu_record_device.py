@@ -331,7 +331,8 @@ def _random_template(rng, lengths):
 def test_random_templates_on_the_device_equal_the_host_writers(tmp_path, seed):
     """Sixteen drawn jobs over the five decoder job of _mixed_spec: a random template (1 to 4 output segments, slices with open and
     negative ends, corrected barcodes, `~`), SAM or FASTQ records, the pre-filters, the outgoing filter and the quality control
-    accumulators on or off.  Records byte for byte, counters and accumulators word for word the host's."""
+    accumulators on or off, and half of the time six barcodes in files of their own (SAM, FASTQ, a FASTQ file per output segment,
+    plain or gzip).  Records byte for byte, counters and accumulators word for word the host's."""
     rng = np.random.default_rng(1000 + seed)
     directory = str(tmp_path)
     spec = _mixed_spec()
@@ -347,16 +348,38 @@ def test_random_templates_on_the_device_equal_the_host_writers(tmp_path, seed):
     paths = _files(directory, spec, n, 100 + seed, lengths)
     spec["input"] = paths
     extension = ".fastq" if rng.random() < 0.4 else ".sam"
+    own_files = rng.random() < 0.5                       # some barcodes in files of their own: one per output segment, or one, plain or gzip
+    n_out = len(spec["template"]["transform"]["knit"])
+    choices = [(int(rng.integers(0, 3)), bool(rng.random() < 0.3)) for _ in range(6)]
     outputs = {}
     for host in (False, True):
-        spec["output"] = [os.path.join(directory, ("host" if host else "device") + extension)]
+        prefix = "host" if host else "device"
+        spec["output"] = [os.path.join(directory, prefix + "_rest" + extension)]
+        names = [spec["output"][0]]
+        if own_files:
+            for k, key in enumerate(list(spec["sample"]["codec"])[:6]):
+                kind, zipped = choices[k]
+                tail = (".sam" if kind == 0 else ".fastq") + (".gz" if zipped else "")
+                urls = [os.path.join(directory, "%s_%d%s" % (prefix, k, tail))] if kind < 2 else \
+                       [os.path.join(directory, "%s_%d_s%d%s" % (prefix, k, o, tail)) for o in range(n_out)]
+                spec["sample"]["codec"][key]["output"] = urls
+                names.extend(urls)
         incoming, words, did = _run(spec, capacity, host)
-        outputs[host] = (incoming, words, did, _records(spec["output"][0]))
+        content = {}
+        for name in names:
+            data = open(name, "rb").read()
+            if name.endswith(".gz"):
+                import gzip
+                data = gzip.decompress(data)
+            content[os.path.basename(name).split("_", 1)[1]] = b"\n".join(line for line in data.split(b"\n") if not line.startswith(b"@PG"))
+        outputs[host] = (incoming, words, did, content)
     device, host = outputs[False], outputs[True]
     assert device[2]["rounds"] == 3 and device[2]["resumed"] == 0 and host[2]["rounds"] == 0, spec["template"]
     assert device[0] == host[0] and np.array_equal(device[1], host[1]), spec["template"]
-    if device[3] != host[3]:
-        for k, (a, b) in enumerate(zip(device[3].split(b"\n"), host[3].split(b"\n"))):
-            assert a == b, (k, a, b, spec["template"])
-    assert device[3] == host[3], spec["template"]
+    assert set(device[3]) == set(host[3])
+    for name in device[3]:
+        if device[3][name] != host[3][name]:
+            for k, (a, b) in enumerate(zip(device[3][name].split(b"\n"), host[3][name].split(b"\n"))):
+                assert a == b, (name, k, a, b, spec["template"])
+        assert device[3][name] == host[3][name], (name, spec["template"])
     assert np.array_equal(device[2]["quality_control"], host[2]["quality_control"]), spec["template"]
