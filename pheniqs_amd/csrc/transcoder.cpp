@@ -839,6 +839,10 @@ struct DeviceFastqCache {
     uint32_t* keep_block = nullptr;                // device: kept reads per workgroup's reads (at least 32), then their prefix sums
     uint32_t* kept_device = nullptr;
     uint32_t* kept_host = nullptr;                 // pinned
+    void prepare_rounds(int64_t reads, const JobConfig& job);               // planes, results, the filters' scratch for rounds of `reads` reads
+    void prepare_records(const DeviceText& text_plan, int64_t reads, const JobConfig& job, size_t n_channel, bool counts);
+    void prepare_feed(int32_t f, size_t bytes);
+    void prepare_tables(const FastqPlan& device_plan, int32_t n_feed, const size_t* chunk_bytes);
     hipStream_t stream = nullptr;
     FastqTables* tables = nullptr;                 // device: the plan, the chunks of both slots, the code tables (the kernels read them through this)
     // a run that writes: the records' text is assembled on the device (record_device.hpp) and leaves on a stream of its own
@@ -1056,19 +1060,13 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
 
 }  // namespace
 
-Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count, const DeviceText* text) {
-    Impl& m = *impl_;
-    const JobConfig& job = m.set.job();
-    const TranscodePlan& plan = m.plan;
+namespace {
+
+// the job's input side as the decode kernels read it (fastq_device.hpp); false: a job the device path does not take
+bool device_fastq_plan(const JobConfig& job, const TranscodePlan& plan, FastqPlan& device_plan) {
     const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
-    if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return OnDevice::NOT_TAKEN; }
-    if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER) { return OnDevice::NOT_TAKEN; }
-    if(job.enable_quality_control && (text == nullptr || !text->quality_control)) { return OnDevice::NOT_TAKEN; }
-    const bool writes = text != nullptr && !text->sinks.empty();
-    const bool counts = text != nullptr && text->quality_control;
     const int32_t n_segment = static_cast<int32_t>(plan.input_segment.size());
-    if(n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return OnDevice::NOT_TAKEN; }
-    FastqPlan device_plan;
+    if(n_feed < 1 || n_feed > FASTQ_MAX_FEED || static_cast<int32_t>(job.decoder.size()) > FASTQ_MAX_DECODER || n_segment < 1 || n_segment > FASTQ_MAX_FEED) { return false; }
     std::memset(&device_plan, 0, sizeof(device_plan));
     device_plan.n_feed = n_feed;
     device_plan.n_decoder = static_cast<int32_t>(job.decoder.size());
@@ -1079,7 +1077,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         device_plan.segment_feed[s] = plan.input_segment[static_cast<size_t>(s)].first;
         device_plan.segment_slot[s] = plan.input_segment[static_cast<size_t>(s)].second;
         if(device_plan.segment_feed[s] < 0 || device_plan.segment_feed[s] >= n_feed || device_plan.segment_slot[s] < 0 ||
-           device_plan.segment_slot[s] >= device_plan.feed_resolution[device_plan.segment_feed[s]]) { return OnDevice::NOT_TAKEN; }
+           device_plan.segment_slot[s] >= device_plan.feed_resolution[device_plan.segment_feed[s]]) { return false; }
     }
     // the pre-filters of the pull loop (transcode.h:193-205), on the device too: kept reads are compacted into the planes
     device_plan.filter_incoming_qc_fail = job.filter_incoming_qc_fail ? 1 : 0;
@@ -1098,7 +1096,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         to.first_token = n_token;
         for(const auto& t : d.transform) {
             if(n_token >= FASTQ_MAX_TOKEN || t.input_segment_index < 0 || t.input_segment_index >= static_cast<int32_t>(plan.input_segment.size()) ||
-               t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return OnDevice::NOT_TAKEN; }
+               t.output_segment_index < 0 || t.output_segment_index >= DEV_MAX_SEGMENT || d.plane_stride == 0) { return false; }
             FastqToken& token = device_plan.token[n_token++];
             token.segment = t.input_segment_index;
             token.start = t.start;
@@ -1111,14 +1109,19 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         }
         to.n_token = n_token - to.first_token;
     }
-    // regular files, plain or gzip
-    std::vector<PlainFile> file(static_cast<size_t>(n_feed));
+    return true;
+}
+
+// the input files of a run on the device: regular files, plain or gzip, that start like FASTQ; false: the host reader's
+bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file) {
+    const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
+    file = std::vector<PlainFile>(static_cast<size_t>(n_feed));
     for(int32_t f = 0; f < n_feed; ++f) {
         PlainFile& p = file[static_cast<size_t>(f)];
         p.descriptor = ::open(plan.input_feed[static_cast<size_t>(f)].path.c_str(), O_RDONLY);
-        if(p.descriptor < 0) { return OnDevice::NOT_TAKEN; }
+        if(p.descriptor < 0) { return false; }
         struct stat status;
-        if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return OnDevice::NOT_TAKEN; }
+        if(::fstat(p.descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size <= 0 || static_cast<uint64_t>(status.st_size) >= (uint64_t(1) << 40)) { return false; }
         p.size = static_cast<size_t>(status.st_size);
         char head[1 << 16];
         ssize_t got = ::pread(p.descriptor, head, sizeof(head), 0);
@@ -1126,151 +1129,240 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             // a gzip stream: inflated on a host thread of the feed's own into the pinned buffer, the text then goes the same way
             // (inflating bounds such a run whoever does it: 0.3 GB/s of text a stream)
             p.zipped = gzopen(plan.input_feed[static_cast<size_t>(f)].path.c_str(), "rb");
-            if(p.zipped == nullptr) { return OnDevice::NOT_TAKEN; }
+            if(p.zipped == nullptr) { return false; }
             gzbuffer(p.zipped, 1 << 20);
             p.head.resize(sizeof(head));
             const int inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size()));
-            if(inflated < 4) { return OnDevice::NOT_TAKEN; }
+            if(inflated < 4) { return false; }
             p.head.resize(static_cast<size_t>(inflated));
             std::memcpy(head, p.head.data(), p.head.size());
             got = inflated;
             p.size = size_t(1) << 62;                   // not known
         }
-        if(got < 4 || head[0] != '@') { return OnDevice::NOT_TAKEN; }
+        if(got < 4 || head[0] != '@') { return false; }
         size_t lines = 0;
         for(ssize_t k = 0; k < got; ++k) { lines += head[k] == '\n' ? 1 : 0; }
-        if(lines < 4) { return OnDevice::NOT_TAKEN; }
+        if(lines < 4) { return false; }
         p.bytes_per_record = 4.0 * static_cast<double>(got) / static_cast<double>(lines);
     }
 
-    {
-        // a wave's share of the reads, by what their text takes in its LDS
-        double bytes_per_read = 0;
-        for(int32_t f = 0; f < n_feed; ++f) { bytes_per_read += file[static_cast<size_t>(f)].bytes_per_record * device_plan.feed_resolution[f]; }
-        fastq_plan_waves(device_plan, bytes_per_read);
-    }
-    device_check(hipSetDevice(m.set.device()), "hipSetDevice");
-    if(!m.set.device_fastq_cache) { m.set.device_fastq_cache = std::make_shared<DeviceFastqCache>(); }
-    DeviceFastqCache& c = *static_cast<DeviceFastqCache*>(m.set.device_fastq_cache.get());
-    if(c.stream == nullptr) { device_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate"); }
+    return true;
+}
 
-    // records per round: the batch capacity, in chunks of at most 192 MiB of text per file
-    const int64_t capacity = std::max<int64_t>(1 << 12, std::min<int64_t>(m.capacity, int64_t(1) << 22));
-    if(c.capacity < capacity) {
-        (void)hipFree(c.base); (void)hipFree(c.quality); (void)hipFree(c.flag); (void)hipFree(c.result); (void)hipFree(c.word);
-        c.base = c.quality = c.flag = nullptr; c.result = nullptr; c.word = nullptr; c.capacity = 0;
-        const size_t planes = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.plane_width, 4));
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.base), planes), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.quality), planes), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.flag), static_cast<size_t>(capacity)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.result), static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.word), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
-        (void)hipFree(c.keep); (void)hipFree(c.keep_block); c.keep = nullptr; c.keep_block = nullptr;
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep), static_cast<size_t>(capacity)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.keep_block), (static_cast<size_t>(capacity) / 32 + 2) * sizeof(uint32_t)), "hipMalloc");
-        c.capacity = capacity;
-    }
-    if(c.total == nullptr) {
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.total), 2 * FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.round_device), sizeof(FastqRound)), "hipMalloc");
-        device_check(hipHostMalloc(reinterpret_cast<void**>(&c.round_host), sizeof(FastqRound), hipHostMallocDefault), "hipHostMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.irregular), sizeof(uint32_t)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.flagged), sizeof(unsigned long long)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.counters_before), static_cast<size_t>(job.stats_words) * sizeof(uint64_t)), "hipMalloc");
-        device_check(hipMalloc(reinterpret_cast<void**>(&c.kept_device), sizeof(uint32_t)), "hipMalloc");
-        device_check(hipHostMalloc(reinterpret_cast<void**>(&c.kept_host), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
-    }
-    if(text != nullptr) {
-        if(c.copy_stream == nullptr) {
-            device_check(hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking), "hipStreamCreate");
-            for(int b = 0; b < 2; ++b) {
-                device_check(hipEventCreateWithFlags(&c.written[b], hipEventDisableTiming), "hipEventCreate");
-                device_check(hipEventCreateWithFlags(&c.copied[b], hipEventDisableTiming), "hipEventCreate");
-            }
-            device_check(hipHostMalloc(reinterpret_cast<void**>(&c.status_host), sizeof(*c.status_host), hipHostMallocDefault), "hipHostMalloc");
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_plan), sizeof(RecordPlan)), "hipMalloc");
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_total), sizeof(unsigned long long)), "hipMalloc");
+// the device's quality control cells (record_device.hpp) as the host's accumulators (qc.hpp)
+QcState quality_control_of_cells(const std::vector<unsigned long long>& words, size_t n_cell, int32_t cycles, int32_t n_channel, int32_t n_out) {
+    const size_t cell_words = qc_cell_words(cycles);
+    QcState state;
+    state.shape(n_channel, n_out);
+    for(size_t k = 0; k < n_cell; ++k) {
+        const unsigned long long* const w = words.data() + k * cell_words;
+        QcSegment& cell = state.cell[k];
+        cell.capacity = static_cast<int32_t>(w[0]);
+        cell.shortest = static_cast<int32_t>(0x7fffffffull - w[1]);
+        cell.average_count = w[2];
+        cell.average_sum_fixed = w[3];
+        std::memcpy(&cell.average_max, &w[4], sizeof(double));
+        for(int q = 0; q < QC_PHRED_RANGE; ++q) { cell.average_distribution[q] = w[5 + q]; }
+        const size_t bins = static_cast<size_t>(cell.capacity) * QC_CODES * QC_PHRED_RANGE;
+        cell.cycle.assign(w + QC_CELL_HEAD, w + QC_CELL_HEAD + bins);
+        uint64_t every = 0;
+        for(size_t bin = 0; bin < bins; ++bin) {
+            cell.nucleic[(bin / QC_PHRED_RANGE) % QC_CODES] += cell.cycle[bin];
+            every += cell.cycle[bin];
         }
-        if(c.record_capacity < capacity) {
-            (void)hipFree(c.record_size); (void)hipFree(c.record_block); c.record_size = nullptr; c.record_block = nullptr; c.record_capacity = 0;
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_size), static_cast<size_t>(capacity) * sizeof(uint32_t)), "hipMalloc");
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_block), (static_cast<size_t>(capacity) / 32 + 2) * sizeof(unsigned long long)), "hipMalloc");
-            c.record_capacity = capacity;
+        cell.nucleic[0] += every;                                           // multiplex.h:155-156: [0] counts every base (and code 0 twice)
+    }
+    return state;
+}
+
+// how many cycles a quality control cell needs: the longest any output segment can be — every token at most the longest of
+// its input segment so far, a corrected barcode at most the job's nucleotides
+int32_t quality_control_cycles(const RecordPlan& plan, const uint32_t* longest, int32_t nucleotide_width) {
+    int32_t cycles = 0;
+    for(int32_t o = 0; o < plan.n_out; ++o) {
+        int32_t bound = 0;
+        for(int32_t t = plan.out_first[o]; t < plan.out_first[o + 1]; ++t) {
+            const RecordToken& token = plan.token[plan.out_token[t]];
+            bound += token.source >= 0 ? static_cast<int32_t>(longest[token.source]) : nucleotide_width;
+        }
+        cycles = std::max(cycles, bound);
+    }
+    return std::max(64, (cycles + 31) / 32 * 32);
+}
+
+// A round's text into the files: sink k's records are bytes [base_of_sink[k], base_of_sink[k + 1]) of `from`.  A large part for
+// a regular file goes through a mapping on several host threads; gzip sinks are compressed a member per piece, the sinks (or
+// the pieces of a single one) side by side.
+void write_round_text(const std::vector<OutputSink*>& to, const char* from, const unsigned long long* base_of_sink, int threads) {
+    const int64_t n_sink = static_cast<int64_t>(to.size());
+    const int workers = std::max(1, threads / 2);
+    if(n_sink == 1) {
+        OutputSink& sink = *to[0];
+        const size_t bytes = static_cast<size_t>(base_of_sink[1]);
+        if(sink.feed.gzip) {
+            const size_t piece = size_t(4) << 20;
+            const int64_t pieces = static_cast<int64_t>((bytes + piece - 1) / piece);
+            std::vector<ByteBuffer> packed(static_cast<size_t>(pieces));
+            parallel_ranges(pieces, 1, threads, [&](int64_t first, int64_t last, int) {
+                for(int64_t k = first; k < last; ++k) {
+                    const size_t begin = static_cast<size_t>(k) * piece;
+                    gzip_member(from + begin, std::min(piece, bytes - begin), sink.feed.level, packed[static_cast<size_t>(k)]);
+                }
+            });
+            for(const auto& member : packed) { sink.write(member.data.get(), member.size); }
+            return;
+        }
+        char* const window = (sink.seekable && bytes >= (1u << 20)) ? sink.map_more(bytes) : nullptr;
+        if(window == nullptr) { sink.write(from, bytes); return; }
+        parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, workers, [&](int64_t first, int64_t last, int) {
+            const size_t begin = static_cast<size_t>(first) << 20;
+            const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
+            std::memcpy(window + begin, from + begin, end - begin);
+        });
+        sink.unmap();
+        return;
+    }
+    parallel_ranges(n_sink, 1, threads, [&](int64_t first, int64_t last, int) {
+        ByteBuffer packed;
+        for(int64_t k = first; k < last; ++k) {
+            OutputSink& sink = *to[static_cast<size_t>(k)];
+            const size_t begin = static_cast<size_t>(base_of_sink[k]), bytes = static_cast<size_t>(base_of_sink[k + 1] - base_of_sink[k]);
+            if(bytes == 0) { continue; }
+            if(sink.feed.gzip) {
+                packed.clear();
+                gzip_member(from + begin, bytes, sink.feed.level, packed);
+                sink.write(packed.data.get(), packed.size);
+            } else { sink.write(from + begin, bytes); }
+        }
+    });
+}
+
+}  // namespace
+
+void DeviceFastqCache::prepare_rounds(int64_t reads, const JobConfig& job) {
+    if(capacity < reads) {
+        (void)hipFree(base); (void)hipFree(quality); (void)hipFree(flag); (void)hipFree(result); (void)hipFree(word);
+        base = quality = flag = nullptr; result = nullptr; word = nullptr; capacity = 0;
+        const size_t planes = static_cast<size_t>(reads) * static_cast<size_t>(std::max(job.plane_width, 4));
+        device_check(hipMalloc(reinterpret_cast<void**>(&base), planes), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&quality), planes), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&flag), static_cast<size_t>(reads)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&result), static_cast<size_t>(reads) * static_cast<size_t>(std::max(job.result_count, 1)) * sizeof(DevResult)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&word), static_cast<size_t>(reads) * sizeof(uint32_t)), "hipMalloc");
+        (void)hipFree(keep); (void)hipFree(keep_block); keep = nullptr; keep_block = nullptr;
+        device_check(hipMalloc(reinterpret_cast<void**>(&keep), static_cast<size_t>(reads)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&keep_block), (static_cast<size_t>(reads) / 32 + 2) * sizeof(uint32_t)), "hipMalloc");
+        capacity = reads;
+    }
+    if(total == nullptr) {
+        device_check(hipMalloc(reinterpret_cast<void**>(&total), 2 * FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&round_device), sizeof(FastqRound)), "hipMalloc");
+        device_check(hipHostMalloc(reinterpret_cast<void**>(&round_host), sizeof(FastqRound), hipHostMallocDefault), "hipHostMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&irregular), sizeof(uint32_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&flagged), sizeof(unsigned long long)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&counters_before), static_cast<size_t>(job.stats_words) * sizeof(uint64_t)), "hipMalloc");
+        device_check(hipMalloc(reinterpret_cast<void**>(&kept_device), sizeof(uint32_t)), "hipMalloc");
+        device_check(hipHostMalloc(reinterpret_cast<void**>(&kept_host), sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc");
+    }
+}
+
+// what a run that writes or counts needs beside: the record plan and its pools, the passes' scratch, the sinks' tables
+void DeviceFastqCache::prepare_records(const DeviceText& text_plan, int64_t reads, const JobConfig& job, size_t n_channel, bool counts) {
+    const DeviceText* const text = &text_plan;
+    {
+        if(copy_stream == nullptr) {
+            device_check(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+            for(int b = 0; b < 2; ++b) {
+                device_check(hipEventCreateWithFlags(&written[b], hipEventDisableTiming), "hipEventCreate");
+                device_check(hipEventCreateWithFlags(&copied[b], hipEventDisableTiming), "hipEventCreate");
+            }
+            device_check(hipHostMalloc(reinterpret_cast<void**>(&status_host), sizeof(*status_host), hipHostMallocDefault), "hipHostMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_plan), sizeof(RecordPlan)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_total), sizeof(unsigned long long)), "hipMalloc");
+        }
+        if(record_capacity < reads) {
+            (void)hipFree(record_size); (void)hipFree(record_block); record_size = nullptr; record_block = nullptr; record_capacity = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_size), static_cast<size_t>(reads) * sizeof(uint32_t)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_block), (static_cast<size_t>(reads) / 32 + 2) * sizeof(unsigned long long)), "hipMalloc");
+            record_capacity = reads;
         }
         {
             const size_t n_sink = std::max<size_t>(text->sinks.size(), 1);
-            const size_t pieces = static_cast<size_t>(capacity) * static_cast<size_t>(std::max(job.output_segment_cardinality, 1));
-            const size_t blocks = (static_cast<size_t>(capacity) / 32 + 2) * n_sink;
-            if(c.piece_room < pieces) {
-                (void)hipFree(c.piece_size); c.piece_size = nullptr; c.piece_room = 0;
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.piece_size), pieces * sizeof(uint32_t)), "hipMalloc");
-                c.piece_room = pieces;
+            const size_t pieces = static_cast<size_t>(reads) * static_cast<size_t>(std::max(job.output_segment_cardinality, 1));
+            const size_t blocks = (static_cast<size_t>(reads) / 32 + 2) * n_sink;
+            if(piece_room < pieces) {
+                (void)hipFree(piece_size); piece_size = nullptr; piece_room = 0;
+                device_check(hipMalloc(reinterpret_cast<void**>(&piece_size), pieces * sizeof(uint32_t)), "hipMalloc");
+                piece_room = pieces;
             }
-            if(c.sink_block_room < blocks) {
-                (void)hipFree(c.sink_block); c.sink_block = nullptr; c.sink_block_room = 0;
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.sink_block), blocks * sizeof(unsigned long long)), "hipMalloc");
-                c.sink_block_room = blocks;
+            if(sink_block_room < blocks) {
+                (void)hipFree(sink_block); sink_block = nullptr; sink_block_room = 0;
+                device_check(hipMalloc(reinterpret_cast<void**>(&sink_block), blocks * sizeof(unsigned long long)), "hipMalloc");
+                sink_block_room = blocks;
             }
-            if(c.sink_base_room < n_sink + 1) {
-                (void)hipFree(c.sink_base); c.sink_base = nullptr;
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.sink_base), (n_sink + 1) * sizeof(unsigned long long)), "hipMalloc");
+            if(sink_base_room < n_sink + 1) {
+                (void)hipFree(sink_base); sink_base = nullptr;
+                device_check(hipMalloc(reinterpret_cast<void**>(&sink_base), (n_sink + 1) * sizeof(unsigned long long)), "hipMalloc");
                 for(int b = 0; b < 2; ++b) {
-                    if(c.sink_base_host[b]) { (void)hipHostFree(c.sink_base_host[b]); c.sink_base_host[b] = nullptr; }
-                    device_check(hipHostMalloc(reinterpret_cast<void**>(&c.sink_base_host[b]), (n_sink + 1) * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc");
+                    if(sink_base_host[b]) { (void)hipHostFree(sink_base_host[b]); sink_base_host[b] = nullptr; }
+                    device_check(hipHostMalloc(reinterpret_cast<void**>(&sink_base_host[b]), (n_sink + 1) * sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc");
                 }
-                c.sink_base_room = n_sink + 1;
+                sink_base_room = n_sink + 1;
             }
         }
-        if(c.record_ints_room < text->ints.size()) {
-            (void)hipFree(c.record_ints); c.record_ints = nullptr; c.record_ints_room = 0;
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_ints), text->ints.size() * sizeof(int32_t)), "hipMalloc");
-            c.record_ints_room = text->ints.size();
+        if(record_ints_room < text->ints.size()) {
+            (void)hipFree(record_ints); record_ints = nullptr; record_ints_room = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_ints), text->ints.size() * sizeof(int32_t)), "hipMalloc");
+            record_ints_room = text->ints.size();
         }
-        if(c.record_bytes_room < text->bytes.size()) {
-            (void)hipFree(c.record_bytes); c.record_bytes = nullptr; c.record_bytes_room = 0;
-            device_check(hipMalloc(reinterpret_cast<void**>(&c.record_bytes), text->bytes.size()), "hipMalloc");
-            c.record_bytes_room = text->bytes.size();
+        if(record_bytes_room < text->bytes.size()) {
+            (void)hipFree(record_bytes); record_bytes = nullptr; record_bytes_room = 0;
+            device_check(hipMalloc(reinterpret_cast<void**>(&record_bytes), text->bytes.size()), "hipMalloc");
+            record_bytes_room = text->bytes.size();
         }
         RecordPlan on_device = text->plan;
-        on_device.ints = c.record_ints;
-        on_device.bytes = c.record_bytes;
-        device_check(hipMemcpy(c.record_ints, text->ints.data(), text->ints.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
-        device_check(hipMemcpy(c.record_bytes, text->bytes.data(), text->bytes.size(), hipMemcpyHostToDevice), "hipMemcpy");
-        device_check(hipMemcpy(c.record_plan, &on_device, sizeof(RecordPlan), hipMemcpyHostToDevice), "hipMemcpy");
-        std::memset(c.status_host, 0, sizeof(*c.status_host));
+        on_device.ints = record_ints;
+        on_device.bytes = record_bytes;
+        device_check(hipMemcpy(record_ints, text->ints.data(), text->ints.size() * sizeof(int32_t), hipMemcpyHostToDevice), "hipMemcpy");
+        device_check(hipMemcpy(record_bytes, text->bytes.data(), text->bytes.size(), hipMemcpyHostToDevice), "hipMemcpy");
+        device_check(hipMemcpy(record_plan, &on_device, sizeof(RecordPlan), hipMemcpyHostToDevice), "hipMemcpy");
+        std::memset(status_host, 0, sizeof(*status_host));
         if(counts) {
-            if(c.longest == nullptr) {
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.longest), FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.qc_overflow), sizeof(uint32_t)), "hipMalloc");
+            if(longest == nullptr) {
+                device_check(hipMalloc(reinterpret_cast<void**>(&longest), FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMalloc");
+                device_check(hipMalloc(reinterpret_cast<void**>(&qc_overflow), sizeof(uint32_t)), "hipMalloc");
             }
-            device_check(hipMemset(c.longest, 0, FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMemset");
-            device_check(hipMemset(c.qc_overflow, 0, sizeof(uint32_t)), "hipMemset");
+            device_check(hipMemset(longest, 0, FASTQ_MAX_FEED * sizeof(uint32_t)), "hipMemset");
+            device_check(hipMemset(qc_overflow, 0, sizeof(uint32_t)), "hipMemset");
             // the accumulators start empty with every run (what a run leaves is merged into the set's when it ends)
-            (void)hipFree(c.qc_device); c.qc_device = nullptr; c.qc_cycles = 0;
-            c.qc_cells = plan.channel.size() * static_cast<size_t>(job.output_segment_cardinality);
+            (void)hipFree(qc_device); qc_device = nullptr; qc_cycles = 0;
+            qc_cells = n_channel * static_cast<size_t>(job.output_segment_cardinality);
         }
     }
-    size_t chunk_bytes[FASTQ_MAX_FEED];
-    for(int32_t f = 0; f < n_feed; ++f) {
-        const double wanted = static_cast<double>(capacity) * device_plan.feed_resolution[f] * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;      // a read is `resolution` records of an interleaved file
-        chunk_bytes[f] = static_cast<size_t>(std::min(wanted, 192.0 * 1048576.0));
-        if(file[static_cast<size_t>(f)].zipped == nullptr) { chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1); }
-        chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
-        if(c.raw_bytes[f] < chunk_bytes[f]) {
-            for(int b = 0; b < 2; ++b) { if(c.pinned[b][f]) { (void)hipHostFree(c.pinned[b][f]); c.pinned[b][f] = nullptr; } }
-            for(int s = 0; s < 2; ++s) { (void)hipFree(c.raw[s][f]); (void)hipFree(c.newline[s][f]); (void)hipFree(c.block_count[s][f]); c.raw[s][f] = nullptr; c.newline[s][f] = nullptr; c.block_count[s][f] = nullptr; }
-            c.raw_bytes[f] = 0;
-            for(int b = 0; b < 2; ++b) { device_check(hipHostMalloc(reinterpret_cast<void**>(&c.pinned[b][f]), chunk_bytes[f] + chunk_bytes[f] / 8 + 8192 + 16, hipHostMallocDefault), "hipHostMalloc"); }
-            for(int s = 0; s < 2; ++s) {
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.raw[s][f]), chunk_bytes[f] + 16), "hipMalloc");
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.newline[s][f]), (chunk_bytes[f] / 8 + 1024) * sizeof(uint32_t)), "hipMalloc");
-                device_check(hipMalloc(reinterpret_cast<void**>(&c.block_count[s][f]), (chunk_bytes[f] / 4096 + 2) * sizeof(uint32_t)), "hipMalloc");
-            }
-            c.raw_bytes[f] = chunk_bytes[f];
+}
+
+// two pinned and two device buffers of a feed's text, the newline index of either slot
+void DeviceFastqCache::prepare_feed(int32_t f, size_t bytes) {
+    size_t chunk_bytes[FASTQ_MAX_FEED] = {0};
+    chunk_bytes[f] = bytes;
+    if(raw_bytes[f] < chunk_bytes[f]) {
+        for(int b = 0; b < 2; ++b) { if(pinned[b][f]) { (void)hipHostFree(pinned[b][f]); pinned[b][f] = nullptr; } }
+        for(int s = 0; s < 2; ++s) { (void)hipFree(raw[s][f]); (void)hipFree(newline[s][f]); (void)hipFree(block_count[s][f]); raw[s][f] = nullptr; newline[s][f] = nullptr; block_count[s][f] = nullptr; }
+        raw_bytes[f] = 0;
+        for(int b = 0; b < 2; ++b) { device_check(hipHostMalloc(reinterpret_cast<void**>(&pinned[b][f]), chunk_bytes[f] + chunk_bytes[f] / 8 + 8192 + 16, hipHostMallocDefault), "hipHostMalloc"); }
+        for(int s = 0; s < 2; ++s) {
+            device_check(hipMalloc(reinterpret_cast<void**>(&raw[s][f]), chunk_bytes[f] + 16), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&newline[s][f]), (chunk_bytes[f] / 8 + 1024) * sizeof(uint32_t)), "hipMalloc");
+            device_check(hipMalloc(reinterpret_cast<void**>(&block_count[s][f]), (chunk_bytes[f] / 4096 + 2) * sizeof(uint32_t)), "hipMalloc");
         }
+        raw_bytes[f] = chunk_bytes[f];
     }
+}
+
+// what the kernels read through a pointer: the plan, where the chunks of either slot are, the code tables
+void DeviceFastqCache::prepare_tables(const FastqPlan& device_plan, int32_t n_feed, const size_t* chunk_bytes) {
+    DeviceFastqCache& c = *this;
     {
-        // what the kernels read through a pointer: the plan, where the chunks of either slot are, the code tables
         FastqTables tables;
         std::memset(&tables, 0, sizeof(tables));
         tables.plan = device_plan;
@@ -1288,6 +1380,45 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         if(c.tables == nullptr) { device_check(hipMalloc(reinterpret_cast<void**>(&c.tables), sizeof(FastqTables)), "hipMalloc"); }
         device_check(hipMemcpy(c.tables, &tables, sizeof(FastqTables), hipMemcpyHostToDevice), "hipMemcpy");
     }
+}
+
+Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_t& incoming_pf_count, const DeviceText* text) {
+    Impl& m = *impl_;
+    const JobConfig& job = m.set.job();
+    const TranscodePlan& plan = m.plan;
+    const int32_t n_feed = static_cast<int32_t>(plan.input_feed.size());
+    if(m.set.device() < 0 || m.classifier || std::getenv("PHQ_HOST_FASTQ") != nullptr) { return OnDevice::NOT_TAKEN; }
+    if(job.enable_quality_control && (text == nullptr || !text->quality_control)) { return OnDevice::NOT_TAKEN; }
+    const bool writes = text != nullptr && !text->sinks.empty();
+    const bool counts = text != nullptr && text->quality_control;
+    FastqPlan device_plan;
+    if(!device_fastq_plan(job, plan, device_plan)) { return OnDevice::NOT_TAKEN; }
+    std::vector<PlainFile> file;
+    if(!open_device_inputs(plan, file)) { return OnDevice::NOT_TAKEN; }
+    {
+        // a wave's share of the reads, by what their text takes in its LDS
+        double bytes_per_read = 0;
+        for(int32_t f = 0; f < n_feed; ++f) { bytes_per_read += file[static_cast<size_t>(f)].bytes_per_record * device_plan.feed_resolution[f]; }
+        fastq_plan_waves(device_plan, bytes_per_read);
+    }
+    device_check(hipSetDevice(m.set.device()), "hipSetDevice");
+    if(!m.set.device_fastq_cache) { m.set.device_fastq_cache = std::make_shared<DeviceFastqCache>(); }
+    DeviceFastqCache& c = *static_cast<DeviceFastqCache*>(m.set.device_fastq_cache.get());
+    if(c.stream == nullptr) { device_check(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking), "hipStreamCreate"); }
+
+    // records per round: the batch capacity, in chunks of at most 192 MiB of text per file
+    const int64_t capacity = std::max<int64_t>(1 << 12, std::min<int64_t>(m.capacity, int64_t(1) << 22));
+    c.prepare_rounds(capacity, job);
+    if(text != nullptr) { c.prepare_records(*text, capacity, job, plan.channel.size(), counts); }
+    size_t chunk_bytes[FASTQ_MAX_FEED];
+    for(int32_t f = 0; f < n_feed; ++f) {
+        const double wanted = static_cast<double>(capacity) * device_plan.feed_resolution[f] * file[static_cast<size_t>(f)].bytes_per_record * 1.03 + 65536.0;      // a read is `resolution` records of an interleaved file
+        chunk_bytes[f] = static_cast<size_t>(std::min(wanted, 192.0 * 1048576.0));
+        if(file[static_cast<size_t>(f)].zipped == nullptr) { chunk_bytes[f] = std::min(chunk_bytes[f], file[static_cast<size_t>(f)].size + 1); }
+        chunk_bytes[f] = (chunk_bytes[f] + 4095) & ~static_cast<size_t>(4095);
+        c.prepare_feed(f, chunk_bytes[f]);
+    }
+    c.prepare_tables(device_plan, n_feed, chunk_bytes);
     hipStream_t stream = c.stream;
     // the counter buffer as it is now: a run that turns out to need the host reader starts over from it
     device_check(hipMemcpyAsync(c.counters_before, m.set.stats_device_pointer(), static_cast<size_t>(job.stats_words) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream), "hipMemcpyAsync");
@@ -1327,29 +1458,9 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         uint32_t overflow = 0;
         device_check(hipMemcpy(&overflow, c.qc_overflow, sizeof(overflow), hipMemcpyDeviceToHost), "hipMemcpy");
         if(overflow) { throw InternalError("quality control: an output segment longer than the bound its tokens give"); }
-        const size_t cell_words = qc_cell_words(c.qc_cycles);
-        std::vector<unsigned long long> words(c.qc_cells * cell_words);
+        std::vector<unsigned long long> words(c.qc_cells * qc_cell_words(c.qc_cycles));
         device_check(hipMemcpy(words.data(), c.qc_device, words.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "hipMemcpy");
-        QcState state;
-        state.shape(static_cast<int32_t>(plan.channel.size()), job.output_segment_cardinality);
-        for(size_t k = 0; k < c.qc_cells; ++k) {
-            const unsigned long long* const w = words.data() + k * cell_words;
-            QcSegment& cell = state.cell[k];
-            cell.capacity = static_cast<int32_t>(w[0]);
-            cell.shortest = static_cast<int32_t>(0x7fffffffull - w[1]);
-            cell.average_count = w[2];
-            cell.average_sum_fixed = w[3];
-            std::memcpy(&cell.average_max, &w[4], sizeof(double));
-            for(int q = 0; q < QC_PHRED_RANGE; ++q) { cell.average_distribution[q] = w[5 + q]; }
-            const size_t bins = static_cast<size_t>(cell.capacity) * QC_CODES * QC_PHRED_RANGE;
-            cell.cycle.assign(w + QC_CELL_HEAD, w + QC_CELL_HEAD + bins);
-            uint64_t every = 0;
-            for(size_t bin = 0; bin < bins; ++bin) {
-                cell.nucleic[(bin / QC_PHRED_RANGE) % QC_CODES] += cell.cycle[bin];
-                every += cell.cycle[bin];
-            }
-            cell.nucleic[0] += every;                                       // multiplex.h:155-156: [0] counts every base (and code 0 twice)
-        }
+        const QcState state = quality_control_of_cells(words, c.qc_cells, c.qc_cycles, static_cast<int32_t>(plan.channel.size()), job.output_segment_cardinality);
         m.set.quality_control_merge(state);
         (void)hipFree(c.qc_device); c.qc_device = nullptr; c.qc_cycles = 0;
     };
@@ -1540,16 +1651,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             // The quality control accumulators of the round's reads (record_quality_control).  A cell holds as many cycles as
             // the longest output segment can have: every token at most the longest of its input segment so far (the decode
             // kernel keeps that), a corrected barcode at most the job's nucleotides; the cells grow when reads grow.
-            int32_t cycles = 0;
-            for(int32_t o = 0; o < text->plan.n_out; ++o) {
-                int32_t bound = 0;
-                for(int32_t t = text->plan.out_first[o]; t < text->plan.out_first[o + 1]; ++t) {
-                    const RecordToken& token = text->plan.token[text->plan.out_token[t]];
-                    bound += token.source >= 0 ? static_cast<int32_t>(c.status_host->longest[token.source]) : job.nucleotide_width;
-                }
-                cycles = std::max(cycles, bound);
-            }
-            cycles = std::max(64, (cycles + 31) / 32 * 32);
+            const int32_t cycles = quality_control_cycles(text->plan, c.status_host->longest, job.nucleotide_width);
             if(cycles > c.qc_cycles) {
                 unsigned long long* grown = nullptr;
                 const size_t words = c.qc_cells * qc_cell_words(cycles);
@@ -1628,50 +1730,11 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 hipEvent_t const arrived = c.copied[b];
                 const int device = m.set.device();
                 const std::shared_future<void> before = drained;
-                drained = std::async(std::launch::async, [to, from, base_of_sink, n_sink, arrived, device, before, threads]() {
+                drained = std::async(std::launch::async, [to, from, base_of_sink, arrived, device, before, threads]() {
                     if(before.valid()) { before.get(); }
                     device_check(hipSetDevice(device), "hipSetDevice");
                     device_check(hipEventSynchronize(arrived), "hipEventSynchronize");
-                    const int workers = std::max(1, threads / 2);
-                    if(n_sink == 1) {
-                        OutputSink& sink = *to[0];
-                        const size_t bytes = static_cast<size_t>(base_of_sink[1]);
-                        if(sink.feed.gzip) {
-                            const size_t piece = size_t(4) << 20;
-                            const int64_t pieces = static_cast<int64_t>((bytes + piece - 1) / piece);
-                            std::vector<ByteBuffer> packed(static_cast<size_t>(pieces));
-                            parallel_ranges(pieces, 1, threads, [&](int64_t first, int64_t last, int) {
-                                for(int64_t k = first; k < last; ++k) {
-                                    const size_t begin = static_cast<size_t>(k) * piece;
-                                    gzip_member(from + begin, std::min(piece, bytes - begin), sink.feed.level, packed[static_cast<size_t>(k)]);
-                                }
-                            });
-                            for(const auto& member : packed) { sink.write(member.data.get(), member.size); }
-                            return;
-                        }
-                        char* const window = (sink.seekable && bytes >= (1u << 20)) ? sink.map_more(bytes) : nullptr;
-                        if(window == nullptr) { sink.write(from, bytes); return; }
-                        parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, workers, [&](int64_t first, int64_t last, int) {
-                            const size_t begin = static_cast<size_t>(first) << 20;
-                            const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
-                            std::memcpy(window + begin, from + begin, end - begin);
-                        });
-                        sink.unmap();
-                        return;
-                    }
-                    parallel_ranges(n_sink, 1, threads, [&](int64_t first, int64_t last, int) {
-                        ByteBuffer packed;
-                        for(int64_t k = first; k < last; ++k) {
-                            OutputSink& sink = *to[static_cast<size_t>(k)];
-                            const size_t begin = static_cast<size_t>(base_of_sink[k]), bytes = static_cast<size_t>(base_of_sink[k + 1] - base_of_sink[k]);
-                            if(bytes == 0) { continue; }
-                            if(sink.feed.gzip) {
-                                packed.clear();
-                                gzip_member(from + begin, bytes, sink.feed.level, packed);
-                                sink.write(packed.data.get(), packed.size);
-                            } else { sink.write(from + begin, bytes); }
-                        }
-                    });
+                    write_round_text(to, from, base_of_sink, threads);
                 }).share();
                 buffer_drained[b] = drained;
                 text_buffer ^= 1;
