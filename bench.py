@@ -143,12 +143,29 @@ def fastq_end_to_end(args, code, quality, flag, n):
             out[name] = {"Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt}
             if os.path.isfile(target):
                 out[name]["sam_MB/s"] = os.path.getsize(target) / dt / 1e6
+        # the same reads split by barcode: a FASTQ file for each of the 96 barcodes and one for the undetermined reads
+        # (Multiplexer::push, multiplex.h:198-240), through the job's own directives (phq_transcode_job)
+        split_spec = dict(spec, input=paths, output=[os.path.join(directory, "undetermined.fastq")])
+        split_spec["sample"] = dict(spec["sample"])
+        split_spec["sample"]["codec"] = {key: dict(value, output=[os.path.join(directory, "barcode_%d.fastq" % k)])
+                                         for k, (key, value) in enumerate(spec["sample"]["codec"].items())}
+        split = DecoderSet(split_spec, device=0)
+        split.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
+        split.transcode_job(1 << 20)
+        t0 = time.perf_counter()
+        incoming, _ = split.transcode_job(1 << 20)
+        dt = time.perf_counter() - t0
+        assert incoming == n
+        out["fastq_per_barcode"] = {"Mreads/s": n / dt / 1e6, "seconds": dt, "files": 1 + len(spec["sample"]["codec"]),
+                                    "fastq_out_MB/s": sum(os.path.getsize(os.path.join(directory, name)) for name in os.listdir(directory) if name.startswith(("barcode_", "undetermined"))) / dt / 1e6}
+        split.close()
     s.close()
     out["note"] = ("2 uncompressed FASTQ files in memory backed storage (50 nt template + 8 nt index) -> SAM text: into a file of the same "
                    "storage (sam_text), every record assembled and written to /dev/zero (sam_text_discarded: no page of a file to "
                    "allocate), and report only (/dev/null: records are not assembled, reference feed.h:105 NullFeed).  The FASTQ text is "
                    "decoded and the records are assembled by kernels (fastq_device.hip, record_device.hip); host threads copy the files' "
-                   "bytes into pinned memory and the finished text into the output file")
+                   "bytes into pinned memory and the finished text into the output file(s); fastq_per_barcode: the reads split into a "
+                   "FASTQ file per barcode of the same storage")
     out["device_path"] = capi.device_path_counters()
     return out
 
