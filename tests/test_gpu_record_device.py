@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import bdggg
-from pheniqs_amd import DecoderSet, capi, synthetic
+from pheniqs_amd import DecoderSet, PheniqsError, capi, synthetic
 from test_gpu_fastq_device import _files
 
 pytestmark = pytest.mark.gpu
@@ -383,3 +383,87 @@ def test_random_templates_on_the_device_equal_the_host_writers(tmp_path, seed):
                 assert a == b, (name, k, a, b, spec["template"])
         assert device[3][name] == host[3][name], (name, spec["template"])
     assert np.array_equal(device[2]["quality_control"], host[2]["quality_control"]), spec["template"]
+
+
+@pytest.mark.parametrize("oddity", ["carriage returns from a record on", "a blank line between two records", "no last newline", "gzip input, carriage returns"])
+def test_what_the_host_reader_tolerates_part_way_gives_the_hosts_files(tmp_path, oddity):
+    """Things the reference's reader tolerates (and the device path does not look at: it hands over), met in the middle of a run
+    that writes a file per barcode with the quality control accumulators on: the rounds before are the device's, the rest the
+    host's, every file and every accumulator what a run through the host from the start leaves."""
+    import gzip
+    directory = str(tmp_path)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    spec["enable quality control"] = True
+    n, capacity = 40001, 4096
+    paths = _files(directory, spec, n, 31, (30, 8))
+    lines = open(paths[1], "rb").read().split(b"\n")
+    if oddity.endswith("carriage returns from a record on") or oddity == "gzip input, carriage returns":
+        for k in range(4 * 23000, len(lines) - 1):
+            lines[k] += b"\r"
+    elif oddity == "a blank line between two records":
+        lines.insert(4 * 23000, b"")
+    text = b"\n".join(lines)
+    if oddity == "no last newline":
+        text = text[:-1]
+    open(paths[1], "wb").write(text)
+    if oddity == "gzip input, carriage returns":
+        with gzip.open(paths[1] + ".gz", "wb", compresslevel=1) as packed:
+            packed.write(text)
+        paths[1] += ".gz"
+    spec["input"] = paths
+    keys = list(spec["sample"]["codec"])
+    results = {}
+    for host in (False, True):
+        prefix = "host" if host else "device"
+        spec["output"] = [os.path.join(directory, prefix + "_rest.sam")]
+        names = [spec["output"][0]]
+        for k, key in enumerate(keys[:10]):
+            spec["sample"]["codec"][key]["output"] = [os.path.join(directory, "%s_%d.fastq" % (prefix, k))]
+            names.append(spec["sample"]["codec"][key]["output"][0])
+        incoming, words, did = _run(spec, capacity, host)
+        results[host] = (incoming, words, did, {os.path.basename(name).split("_", 1)[1]: _records(name) for name in names})
+    device, host = results[False], results[True]
+    if oddity == "no last newline":
+        assert device[2]["resumed"] == 0 and device[2]["rounds"] == -(-n // capacity)          # the device adds the newline itself
+    else:
+        assert device[2]["resumed"] == 1 and device[2]["rounds"] == 23000 // capacity
+    assert device[0] == host[0] and device[0][0] == n
+    assert np.array_equal(device[1], host[1])
+    assert device[3] == host[3]
+    assert np.array_equal(device[2]["quality_control"], host[2]["quality_control"])
+
+
+@pytest.mark.parametrize("damage", ["names out of sync", "a file cut inside a record"])
+def test_damage_part_way_raises_the_host_readers_error(tmp_path, damage):
+    """names out of sync in record 30 000, a file that ends inside record 30 000: the device path hands over at the round that
+    holds it and the host reader raises what it raises when it reads the files from the start"""
+    directory = str(tmp_path)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    n, capacity = 50001, 4096
+    paths = _files(directory, spec, n, 32, (30, 8))
+    data = open(paths[1], "rb").read()
+    lines = data.split(b"\n")
+    if damage == "names out of sync":
+        lines[4 * 30000] = lines[4 * 30000].replace(b"@M:1:", b"@X:1:", 1)
+        open(paths[1], "wb").write(b"\n".join(lines))
+    else:
+        open(paths[1], "wb").write(b"\n".join(lines[:4 * 30000 + 2]) + b"\nFFF")
+    spec["input"] = paths
+    raised = {}
+    for host in (False, True):
+        spec["output"] = [os.path.join(directory, "host.sam" if host else "device.sam")]
+        if host:
+            os.environ["PHQ_HOST_RECORDS"] = "1"
+        try:
+            before = capi.device_path_counters()
+            s = DecoderSet(json.dumps(spec), device=0)
+            with pytest.raises(PheniqsError) as caught:
+                s.transcode_job(capacity)
+            raised[host] = (caught.value.code, str(caught.value), capi.device_path_counters()["resumed"] - before["resumed"])
+            s.close()
+        finally:
+            os.environ.pop("PHQ_HOST_RECORDS", None)
+    assert raised[False][0] == raised[True][0] and raised[False][1] == raised[True][1]
+    assert raised[False][2] == 1 and raised[True][2] == 0
