@@ -584,9 +584,25 @@ void DecoderSet::build_device_images() {
                 }
             }
             const bool paired_mdd = c.algorithm == Algorithm::MDD && c.quality_masking_threshold <= 128;
-            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors)) || paired_mdd) && c.segment_cardinality == 2 && c.nucleotide_cardinality <= 32 &&
+            // A single index of 11 to 20 nt (past the streaming kernel's 10) is taken as two PARTS of its one segment — 8 nt and the
+            // rest up to 16 nt, the last 10 beyond — by the same tier: it scores one barcode over all positions and bounds the others
+            // by their distance, wherever a segment ends.  96 barcodes of 12 nt: 16 -> 3x Greads/s (the product form over all
+            // barcodes was the first tier of such sets).
+            const bool two_parts = c.algorithm == Algorithm::PAMLD && c.segment_cardinality == 1 && c.nucleotide_cardinality >= 11 && c.nucleotide_cardinality <= 2 * NEAR_MAX_LENGTH &&
+                                   std::getenv("PHQ_NO_PAIR_PARTS") == nullptr;
+            int32_t part_start[2] = {0, 0}, part_length[2] = {0, 0};
+            if(two_parts) {
+                const int32_t L = c.nucleotide_cardinality;
+                part_length[0] = L <= 16 ? std::min(8, L - 4) : L - NEAR_MAX_LENGTH;
+                part_length[1] = L - part_length[0];
+                part_start[0] = c.segment_offset[0];
+                part_start[1] = c.segment_offset[0] + part_length[0];
+            } else if(c.segment_cardinality == 2) {
+                for(int32_t s = 0; s < 2; ++s) { part_start[s] = c.segment_offset[static_cast<size_t>(s)]; part_length[s] = c.barcode_length[static_cast<size_t>(s)]; }
+            }
+            if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors)) || paired_mdd) && (c.segment_cardinality == 2 || two_parts) && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
-               c.barcode_length[0] >= 4 && c.barcode_length[0] <= NEAR_MAX_LENGTH && c.barcode_length[1] >= 4 && c.barcode_length[1] <= NEAR_MAX_LENGTH) {
+               part_length[0] >= 4 && part_length[0] <= NEAR_MAX_LENGTH && part_length[1] >= 4 && part_length[1] <= NEAR_MAX_LENGTH) {
                 // paired barcode tier (pamld_pair.hpp): per segment the barcode of every word at most two mismatches from
                 // one of its words — which must be all different in both segments — and per barcode its code bits and
                 // the distance to the nearest other barcode
@@ -594,21 +610,31 @@ void DecoderSet::build_device_images() {
                 std::vector<uint32_t> low, high;
                 code_planes(c, low, high);
                 bool distinct = true;
+                int32_t naming = 0;                           // parts whose words name a barcode each
                 std::vector<std::vector<uint16_t>> table(2);
                 for(int32_t s = 0; s < 2 && distinct; ++s) {
-                    const int32_t start = c.segment_offset[static_cast<size_t>(s)];
-                    const int32_t length = c.barcode_length[static_cast<size_t>(s)];
+                    const int32_t start = part_start[s];
+                    const int32_t length = part_length[s];
                     const uint32_t mask = (1u << length) - 1u;
                     std::vector<uint16_t>& nearest = table[static_cast<size_t>(s)];
                     nearest.assign(static_cast<size_t>(1) << (2 * length), NEAR_NO_BARCODE);
                     std::vector<uint32_t> word_low(static_cast<size_t>(N)), word_high(static_cast<size_t>(N));
+                    std::vector<uint8_t> shared(static_cast<size_t>(N), 0);          // the barcode's word of this part is another barcode's too
                     for(int32_t b = 0; b < N; ++b) {
                         word_low[static_cast<size_t>(b)] = (low[static_cast<size_t>(b)] >> start) & mask;
                         word_high[static_cast<size_t>(b)] = (high[static_cast<size_t>(b)] >> start) & mask;
                         uint16_t& exact = nearest[word_low[static_cast<size_t>(b)] | (word_high[static_cast<size_t>(b)] << length)];
-                        if(exact != NEAR_NO_BARCODE) { distinct = false; break; }                 // two barcodes share this segment word
+                        if(exact != NEAR_NO_BARCODE) {
+                            if(!two_parts) { distinct = false; break; }                           // two barcodes share this segment word
+                            // a part of a single index: a word that several barcodes share names no one — the other part's word decides
+                            shared[static_cast<size_t>(b)] = 1;
+                            if(exact != PAIR_ANY_BARCODE) { shared[exact] = 1; }
+                            exact = PAIR_ANY_BARCODE;
+                            continue;
+                        }
                         exact = static_cast<uint16_t>(b);
                     }
+                    if(std::count(shared.begin(), shared.end(), 0) > 0) { ++naming; }
                     // every word up to two mismatches from a segment word names the barcode of the NEAREST one, the lowest
                     // ordinal among equally near ones: distance 1 over distance 2, and within a distance the lowest ordinal last
                     std::vector<uint8_t> reached(nearest.size(), 3);
@@ -623,7 +649,7 @@ void DecoderSet::build_device_images() {
                                     if(l1 == bl && h1 == bh) { continue; }
                                     if(away == 1) {
                                         const size_t at = l1 | (h1 << length);
-                                        if(reached[at] >= 1) { reached[at] = 1; nearest[at] = static_cast<uint16_t>(b); }
+                                        if(reached[at] >= 1) { reached[at] = 1; nearest[at] = shared[static_cast<size_t>(b)] ? PAIR_ANY_BARCODE : static_cast<uint16_t>(b); }
                                         continue;
                                     }
                                     for(int32_t i = j + 1; i < length; ++i) {
@@ -632,7 +658,7 @@ void DecoderSet::build_device_images() {
                                             const uint32_t h2 = (h1 & ~(1u << i)) | ((second >> 1) << i);
                                             if(((l2 ^ bl) | (h2 ^ bh)) >> i & 1u) {
                                                 const size_t at = l2 | (h2 << length);
-                                                if(reached[at] >= 2) { reached[at] = 2; nearest[at] = static_cast<uint16_t>(b); }
+                                                if(reached[at] >= 2) { reached[at] = 2; nearest[at] = shared[static_cast<size_t>(b)] ? PAIR_ANY_BARCODE : static_cast<uint16_t>(b); }
                                             }
                                         }
                                     }
@@ -641,7 +667,7 @@ void DecoderSet::build_device_images() {
                         }
                     }
                 }
-                if(distinct) {
+                if(distinct && naming > 0) {
                     std::vector<uint32_t> record(static_cast<size_t>(N) * PAIR_RECORD_WORDS, 0u);
                     int32_t usable = 0;
                     for(int32_t b = 0; b < N; ++b) {
@@ -667,12 +693,14 @@ void DecoderSet::build_device_images() {
                         std::memcpy(&entry[5], &noise_over_prior, sizeof(float));
                         std::memcpy(&entry[6], &others[1], sizeof(float));
                         std::memcpy(&entry[7], &others[2], sizeof(float));
-                        if(radius >= 6) { ++usable; }
+                        // (a single index in two parts pays from a radius of 4 on: 96 barcodes of 11 nt 16 -> 28 Greads/s; the product form
+                        // over all barcodes is what such a set takes otherwise)
+                        if(radius >= (two_parts ? 4 : 6)) { ++usable; }
                     }
                     for(int32_t s = 0; s < 2; ++s) {
                         d.pair_table[s] = static_cast<const uint16_t*>(upload(table[static_cast<size_t>(s)].data(), table[static_cast<size_t>(s)].size() * sizeof(uint16_t)));
-                        d.pair_start[s] = c.segment_offset[static_cast<size_t>(s)];
-                        d.pair_length[s] = c.barcode_length[static_cast<size_t>(s)];
+                        d.pair_start[s] = part_start[s];
+                        d.pair_length[s] = part_length[s];
                     }
                     d.pair_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
                     d.pair_ready = (c.algorithm == Algorithm::PAMLD && 2 * usable >= N) ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
@@ -680,8 +708,8 @@ void DecoderSet::build_device_images() {
                     // can be within its tolerance of an observation: tolerance <= (smallest distance between two of the
                     // segment's words - 1) / 2, the bound the compiler enforces (metric.h:228) and a hand written compiled
                     // document may exceed — such a codec takes the scan kernels
-                    bool within_bound = true;
-                    for(int32_t s = 0; s < 2; ++s) {
+                    bool within_bound = paired_mdd;           // (asked of two real segments only: the parts of a single index are PAMLD's)
+                    for(int32_t s = 0; s < 2 && paired_mdd; ++s) {
                         const uint32_t mask = (c.barcode_length[static_cast<size_t>(s)] >= 32 ? 0xffffffffu : ((1u << c.barcode_length[static_cast<size_t>(s)]) - 1u)) << c.segment_offset[static_cast<size_t>(s)];
                         int closest = 32;
                         for(int32_t b = 0; b < N; ++b) {

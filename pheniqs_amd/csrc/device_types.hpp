@@ -66,6 +66,7 @@ static_assert(CROSS_MAX_UNIQUE < CROSS_STREAM_UNKNOWN, "a word's ordinal and the
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
 constexpr int NEAR_MAX_BARCODES = 1024;
+constexpr uint16_t PAIR_ANY_BARCODE = 0xfffeu;  // pamld_pair.hpp: this part of the barcode names no one of its own (its words are shared): the other part's word decides
 constexpr uint16_t NEAR_NO_BARCODE = 0xffffu; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
 
 // Counter buffer geometry (u64 words).  Word 0/1: outgoing reads by [qc-fail | pass-filter]

@@ -1,5 +1,8 @@
 // K0p (paired barcodes): PamlDecoder<T>::classify for codecs whose barcodes are PAIRS of words that do not form every
-// combination (unique dual indexes, sci-RNA-seq ligation + RT pairs): two segments of up to 10 nt, up to 32 nt together.
+// combination (unique dual indexes, sci-RNA-seq ligation + RT pairs): two segments of up to 10 nt, up to 32 nt together —
+// and, since round 4, for single index sets of 11 to 20 nt, which the host hands over as two parts of one segment (nothing
+// below depends on where a segment ends: a barcode is scored over all its positions and the others are bounded by its
+// distance to the nearest of them).
 //
 //   reference pamld.cpp:37-123   posterior over all barcodes, noise / confidence / high quality filters
 //   reference barcode.h:131-164  P(r|b) = pow(base, sum of Phred costs), distance, high quality distance
@@ -169,8 +172,11 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         const uint32_t named0 = nearest0[key0];
         const uint32_t named1 = nearest1[key1];
         fetch(min(tile + gridDim.x, tiles - 1), next);
-        const bool known = named0 == named1 && named0 < n_barcode;
-        const uint32_t c = known ? named0 : 0u;
+        // both parts name the same barcode — or one of them names no one of its own (PAIR_ANY_BARCODE: a single index of 11 to 20 nt
+        // taken as two parts, whose shorter part's words are shared between barcodes) and the other part decides
+        const uint32_t named = named0 == PAIR_ANY_BARCODE ? named1 : named0;
+        const bool known = (named0 == named1 || named0 == PAIR_ANY_BARCODE || named1 == PAIR_ANY_BARCODE) && named < n_barcode;
+        const uint32_t c = known ? named : 0u;
         const Quad record = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u));
         // the priors of all other barcodes over c's (N - 1 when they are equal) and the noise term over c's prior (pamld.cpp:29,66)
         const Quad weights = *(LdsQuads)static_cast<uintptr_t>(Layout::RECORD_AT + c * (PAIR_RECORD_WORDS * 4u) + 16u);
