@@ -1,6 +1,6 @@
 """Greads/s of a single index PAMLD decoder of COUNT barcodes of LENGTH nt: python time_shape.py LENGTH COUNT [READS]"""
 import os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, synthetic
