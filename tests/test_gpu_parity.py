@@ -1068,6 +1068,37 @@ def test_high_quality_threshold_beyond_the_byte_parallel_compare(oracle, torch_c
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
+@pytest.mark.parametrize("length,count,shared", [(11, 96, False), (12, 96, False), (13, 200, False), (16, 384, False), (20, 96, False), (12, 96, True), (16, 300, True)])
+def test_single_index_sets_of_11_to_20_nt_take_the_paired_tier_in_two_parts(oracle, torch_cuda, length, count, shared):
+    """A single index past the streaming kernel's 10 nt is handed to the paired tier as two parts of its one segment (8 nt and
+    the rest): both modes equal the oracle, `phq_profile_chain` names pamld_pair_kernel first.  `shared`: many barcodes begin
+    with the same 8 nt or end with the same words — such words name no one (PAIR_ANY_BARCODE) and the other part decides; reads
+    are also put ON barcodes whose both parts are shared, which no table names."""
+    rng = np.random.default_rng(length * 100 + count + (7 if shared else 0))
+    words = synthetic.barcode_set(rng, count, length, min_distance=4)
+    if shared:
+        # every fourth barcode takes the first 8 nt of its neighbour, every fifth the last part of its neighbour; some both
+        mixed = []
+        for k, word in enumerate(words):
+            other = words[(k + 1) % count]
+            head = other[:8] if k % 4 == 0 else word[:8]
+            tail = other[8:] if k % 5 == 0 else word[8:]
+            mixed.append(head + tail)
+        words = sorted(set(mixed))
+    job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length])})
+    n = 40000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 9)
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    s.set_mode(capi.MODE_FAST)
+    s.profile_enable(True)
+    run_gpu(torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST, device_set=s)
+    chain = [span["kernel"] for span in s.profile_chain()]
+    if not shared:
+        assert chain[0] == "pamld_pair_kernel", chain
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+    s.close()
+
+
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (8, 1024), (8, 1030), (12, 33),
                                           (16, 256), (16, 260), (16, 512), (16, 515), (32, 5)])
