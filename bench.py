@@ -262,7 +262,8 @@ CONFIG_TEXT = {"C2": "single 8 bp index, 96 barcodes", "C3": "dual 10+10 bp, 96x
                "H94": "unique dual index, the 94 pairs of 8+8 bp of flowcell H7LT2DSXX lane 1, noise 0.05 (the reference's prior estimation run, docs/illumina_api_vignette.md:222)",
                "H94A": "the same 94 pairs with the priors and the noise that run estimated (example/H7LT2DSXX/H7LT2DSXX_l01_adjusted.json)",
                "U96": "unique dual index, 96 pairs of 8+8 bp", "U384": "unique dual index, 384 pairs of 8+8 bp",
-               "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes"}
+               "V384": "unique dual index, 384 pairs of 10+10 bp", "S384": "single 8 bp index, 384 barcodes", "S192": "single 8 bp index, 192 barcodes",
+               "L12": "single 12 bp index, 96 barcodes", "L16": "single 16 bp index, 96 barcodes"}
 
 
 class Workload:
@@ -517,7 +518,9 @@ def main():
                                                            # the one workload the reference publishes a wall clock for, and the cliffs
                                                            # outside BASELINE.json's shapes (384 indexes, 384 pairs)
                                                            ("H94_pamld", "H94", "pamld", 100_000_000, "uniform"), ("H94A_pamld", "H94A", "pamld", 100_000_000, "uniform"),
-                                                           ("S384_pamld", "S384", "pamld", 100_000_000, "uniform"), ("U384_pamld", "U384", "pamld", 100_000_000, "uniform")):
+                                                           ("S384_pamld", "S384", "pamld", 100_000_000, "uniform"), ("U384_pamld", "U384", "pamld", 100_000_000, "uniform"),
+                                                           # a single index past the streaming kernel's 10 nt: the paired tier in two parts
+                                                           ("L12_pamld", "L12", "pamld", 100_000_000, "uniform")):
                 shape = Workload(torch, device, local_rank, rank, config, algorithm, args.mode, reads, args.pool, priors)
                 sm = shape.measure(5, 2, 1, barrier)
                 shape_parity = None if args.no_parity else parity_check(torch, shape, args.mode, 1 << 16)

@@ -73,7 +73,7 @@ def decoder_spec(kind_algorithm: str, segments: Sequence[Sequence[str]], tokens:
 
 # BASELINE.json's C2..C5 (C4V: C4 with the 196 pairs of the reference's sci-RNA-seq vignette) plus shapes outside it that real runs use a lot: unique dual indexes, 96 or 384 PAIRS of
 # 8 + 8 nt in one two segment sample decoder (not every combination: pair i is word i of each list)
-CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10, "C4V": 11, "H94": 12, "H94A": 13}
+CONFIG_NUMBER = {"C2": 2, "C3": 3, "C4": 4, "C5": 5, "U96": 6, "U384": 7, "V384": 8, "S384": 9, "S192": 10, "C4V": 11, "H94": 12, "H94A": 13, "L12": 14, "L16": 15}
 # H94 / H94A: the one workload the reference publishes a wall clock for (docs/illumina_api_vignette.md:222, lane 1 of flowcell
 # H7LT2DSXX): 94 unique dual index pairs of 8 + 8 nt, PAMLD — H94 as its prior estimation run has them (uniform priors, noise
 # 0.05), H94A with the priors and the noise that run left (example/H7LT2DSXX/H7LT2DSXX_l01_adjusted.json).  The barcodes and
@@ -125,6 +125,9 @@ def config_spec(name: str, algorithm: str = "pamld") -> Dict[str, Any]:
         spec = {"input segment cardinality": 3,
                 "sample": {"algorithm": algorithm, "noise": which["noise"], "confidence threshold": which["confidence threshold"],
                            "transform": {"token": ["1::8", "2::8"]}, "codec": codec}}
+    elif name in ("L12", "L16"):       # 96 single indexes of 12 / 16 nt: past the streaming kernel's 10 nt (the paired tier in two parts)
+        spec = {"input segment cardinality": 2,
+                "sample": decoder_spec(algorithm, [barcode_set(rng, 96, 12 if name == "L12" else 16, min_distance=4)], ["1::%d" % (12 if name == "L12" else 16)])}
     elif name in ("S384", "S192"):     # 384 / 192 single 8 nt indexes
         spec = {"input segment cardinality": 2,
                 "sample": decoder_spec(algorithm, [barcode_set(rng, 384 if name == "S384" else 192, 8)], ["1::8"])}

@@ -19,8 +19,9 @@ declare -A ARGS=(
   [H94A_pamld]="--config H94A"
   [S384_pamld]="--config S384"
   [U384_pamld]="--config U384"
+  [L12_pamld]="--config L12"
 )
-shapes=("$@"); [ ${#shapes[@]} -eq 0 ] && shapes=(C2_pamld C2_pamld_literal C2_mdd C2_pamld_estimated_priors C3_pamld C3_pamld_estimated_priors C4_pamld C4V_pamld C5_pamld H94_pamld H94A_pamld S384_pamld U384_pamld)
+shapes=("$@"); [ ${#shapes[@]} -eq 0 ] && shapes=(C2_pamld C2_pamld_literal C2_mdd C2_pamld_estimated_priors C3_pamld C3_pamld_estimated_priors C4_pamld C4V_pamld C5_pamld H94_pamld H94A_pamld S384_pamld U384_pamld L12_pamld)
 out=gpurun_out/prof_$round
 for shape in "${shapes[@]}"; do
   a="${ARGS[$shape]}"

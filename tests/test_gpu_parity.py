@@ -1176,7 +1176,7 @@ def test_reads_without_information_sit_on_the_noise_threshold(oracle, torch_cuda
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
-@pytest.mark.parametrize("name", ["U96", "U384", "V384", "S384", "S192"])
+@pytest.mark.parametrize("name", ["U96", "U384", "V384", "S384", "S192", "L12", "L16"])
 def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
     """96 / 384 PAIRS of 8 + 8 nt in one two segment decoder (not every combination): the 16 nt product form / fused
     kernels, 384 pairs past the workgroup histogram (counters rebuilt from the records); 384 pairs of 10 + 10 nt (the
