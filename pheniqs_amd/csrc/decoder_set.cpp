@@ -588,7 +588,7 @@ void DecoderSet::build_device_images() {
             // rest up to 16 nt, the last 10 beyond — by the same tier: it scores one barcode over all positions and bounds the others
             // by their distance, wherever a segment ends.  96 barcodes of 12 nt: 16 -> 3x Greads/s (the product form over all
             // barcodes was the first tier of such sets).
-            const bool two_parts = c.algorithm == Algorithm::PAMLD && c.segment_cardinality == 1 && c.nucleotide_cardinality >= 11 && c.nucleotide_cardinality <= 2 * NEAR_MAX_LENGTH &&
+            const bool two_parts = (c.algorithm == Algorithm::PAMLD || paired_mdd) && c.segment_cardinality == 1 && c.nucleotide_cardinality >= 11 && c.nucleotide_cardinality <= 2 * NEAR_MAX_LENGTH &&
                                    std::getenv("PHQ_NO_PAIR_PARTS") == nullptr;
             int32_t part_start[2] = {0, 0}, part_length[2] = {0, 0};
             if(two_parts) {
@@ -611,6 +611,7 @@ void DecoderSet::build_device_images() {
                 code_planes(c, low, high);
                 bool distinct = true;
                 int32_t naming = 0;                           // parts whose words name a barcode each
+                std::vector<uint8_t> nameless(static_cast<size_t>(d.n_barcode), 0);      // in how many parts the barcode's word is another barcode's too
                 std::vector<std::vector<uint16_t>> table(2);
                 for(int32_t s = 0; s < 2 && distinct; ++s) {
                     const int32_t start = part_start[s];
@@ -635,6 +636,7 @@ void DecoderSet::build_device_images() {
                         exact = static_cast<uint16_t>(b);
                     }
                     if(std::count(shared.begin(), shared.end(), 0) > 0) { ++naming; }
+                    for(int32_t b = 0; b < N; ++b) { if(shared[static_cast<size_t>(b)]) { ++nameless[static_cast<size_t>(b)]; } }
                     // every word up to two mismatches from a segment word names the barcode of the NEAREST one, the lowest
                     // ordinal among equally near ones: distance 1 over distance 2, and within a distance the lowest ordinal last
                     std::vector<uint8_t> reached(nearest.size(), 3);
@@ -721,6 +723,23 @@ void DecoderSet::build_device_images() {
                         if(tolerance < 0 || 2 * tolerance + 1 > closest) { within_bound = false; }
                     }
                     d.mdd_pair_ready = (paired_mdd && within_bound) ? 1 : 0;
+                    if(two_parts && paired_mdd) {
+                        // one segment in two parts: the tolerance is the whole barcode's, and at most one barcode can be within it
+                        // (the same bound over all positions); a read no part names, or whose named barcode is too far, is scanned
+                        int closest = 32;
+                        for(int32_t b = 0; b < N; ++b) {
+                            for(int32_t o = b + 1; o < N; ++o) {
+                                closest = std::min(closest, __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)])));
+                            }
+                        }
+                        const int32_t tolerance = d.distance_tolerance[0];
+                        d.mdd_pair_parts = 1;
+                        // ... and every barcode must be named by a part of its own: the scan behind the lookup takes the reference's order
+                        // for granted — the exact match (mdd.cpp:43-46) before any masking — which the lookup settles only for barcodes it
+                        // can name
+                        const bool all_named = std::count(nameless.begin(), nameless.end(), 2) == 0;
+                        d.mdd_pair_ready = (all_named && tolerance >= 0 && tolerance <= 2 && 2 * tolerance + 1 <= closest) ? 1 : 0;
+                    }
                 }
             }
             if(c.all_strict && c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors) && c.segment_cardinality == 2 && d.n_barcode > 1 && d.n_barcode <= 256 &&

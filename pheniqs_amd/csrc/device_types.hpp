@@ -183,6 +183,7 @@ struct DevDecoder {
     const uint32_t* mdd_near_record;
     int32_t mdd_near_ready;
     int32_t mdd_pair_ready;               // an MDD codec of two segments with pair_table / pair_record (mdd_near.hpp, PAIRED)
+    int32_t mdd_pair_parts;               // ... or of ONE segment of 11 to 20 nt taken as two parts: one tolerance over the whole barcode, what no part names is scanned
     // a combinatorial MDD codec of two segments (mdd_near.hpp, COMBINATORIAL): cross_near_table[s] over the segment's
     // distinct words and {low plane, high plane} of segment 0's words, then of segment 1's
     const uint32_t* mdd_cross_word;

@@ -37,8 +37,9 @@ bool mdd_near_supports(const DevDecoder& host_decoder) {
 // two segments whose words belong to one barcode each (pamld_pair.hpp's tables), tolerances of at most 2
 bool mdd_pair_supports(const DevDecoder& host_decoder) {
     const int words = host_decoder.plane_stride / 4;
-    return host_decoder.algorithm == 2 && host_decoder.mdd_pair_ready != 0 && host_decoder.n_segment == 2 && words >= 2 && words <= 8 &&
-           host_decoder.nucleotide_cardinality <= 32 && host_decoder.distance_tolerance[0] <= 2 && host_decoder.distance_tolerance[1] <= 2 &&
+    const bool parts = host_decoder.mdd_pair_parts != 0;            // one segment of 11 to 20 nt as two parts (decoder_set.cpp)
+    return host_decoder.algorithm == 2 && host_decoder.mdd_pair_ready != 0 && (parts ? host_decoder.n_segment == 1 : host_decoder.n_segment == 2) && words >= 2 && words <= 8 &&
+           host_decoder.nucleotide_cardinality <= 32 && host_decoder.distance_tolerance[0] <= 2 && (parts || host_decoder.distance_tolerance[1] <= 2) &&
            fits(host_decoder, mdd_near::PAIRED);
 }
 

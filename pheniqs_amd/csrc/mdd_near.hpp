@@ -84,7 +84,8 @@ __global__ __launch_bounds__(THREADS) void mdd_lookup_kernel(StageArgs args) {
     const uint32_t length0 = KIND == SINGLE ? static_cast<uint32_t>(L) : static_cast<uint32_t>(KIND == PAIRED ? d.pair_length[0] : d.cross_length[0]);
     const uint32_t length1 = KIND == SINGLE ? 0u : static_cast<uint32_t>(KIND == PAIRED ? d.pair_length[1] : d.cross_length[1]);
     const uint32_t mask0 = (1u << length0) - 1u, mask1 = (1u << length1) - 1u;
-    const int tolerance0 = d.distance_tolerance[0], tolerance1 = TWO ? d.distance_tolerance[1] : 0;
+    const bool parts = KIND == PAIRED && d.mdd_pair_parts != 0;
+    const int tolerance0 = d.distance_tolerance[0], tolerance1 = (TWO && !parts) ? d.distance_tolerance[1] : 0;
     const uint32_t unique0 = KIND == COMBINATORIAL ? static_cast<uint32_t>(d.cross_unique[0]) : static_cast<uint32_t>(d.n_barcode);
     const uint32_t unique1 = KIND == COMBINATORIAL ? static_cast<uint32_t>(d.cross_unique[1]) : static_cast<uint32_t>(d.n_barcode);
     const uint32_t stride0 = KIND == COMBINATORIAL ? static_cast<uint32_t>(d.cross_stride[0]) : 0u;
@@ -164,8 +165,11 @@ __global__ __launch_bounds__(THREADS) void mdd_lookup_kernel(StageArgs args) {
         const uint32_t named0 = nearest0[low0 | (high0 << length0)];                   // what this word is (next to), if anything
         const uint32_t named1 = TWO ? static_cast<uint32_t>(nearest1[low1 | (high1 << length1)]) : named0;
         fetch(min(tile + gridDim.x, tiles - 1), next);
-        const bool known = KIND == COMBINATORIAL ? (named0 < unique0 && named1 < unique1) : (named0 == named1 && named0 < unique0);
-        const uint32_t u0 = known ? named0 : 0u, u1 = known ? named1 : 0u;
+        // (parts: a single index of 11 to 20 nt as two parts of its one segment — either part's word may name the barcode, a word
+        // several barcodes share names no one, PAIR_ANY_BARCODE; the tolerance is the whole barcode's)
+        const bool known = KIND == COMBINATORIAL ? (named0 < unique0 && named1 < unique1)
+                         : parts ? (named0 < unique0 || named1 < unique0) : (named0 == named1 && named0 < unique0);
+        const uint32_t u0 = known ? ((parts && !(named0 < unique0)) ? named1 : named0) : 0u, u1 = known ? named1 : 0u;
         int k0, k1 = 0;
         uint32_t c;                            // the barcode's ordinal
         uint32_t barcode_index;
@@ -184,9 +188,11 @@ __global__ __launch_bounds__(THREADS) void mdd_lookup_kernel(StageArgs args) {
             c = u0;
             barcode_index = record.w;
         }
-        const bool classified = known && k0 <= tolerance0 && k1 <= tolerance1;          // mdd.cpp:43-46 (no mismatch), 47-80
-        // the exact match comes before any masking (mdd.cpp:43-46): a masked position only matters to a read that is not a barcode
-        const bool defer = unfinished != 0 || (MASKING && masked != 0 && !(known && k0 + k1 == 0));
+        const bool classified = known && (parts ? k0 + k1 <= tolerance0 : (k0 <= tolerance0 && k1 <= tolerance1));          // mdd.cpp:43-46 (no mismatch), 47-80
+        // the exact match comes before any masking (mdd.cpp:43-46): a masked position only matters to a read that is not a barcode.
+        // Parts: the tables name the barcode of the nearest word of a part, which need not be the one barcode within the tolerance
+        // of the whole read — only a read that IS classified is finished here, the scan takes the others.
+        const bool defer = unfinished != 0 || (MASKING && masked != 0 && !(known && k0 + k1 == 0)) || (parts && !classified);
         const uint32_t index = classified ? barcode_index : 0u;
         const uint32_t distance = classified ? static_cast<uint32_t>(k0 + k1) : 0u;
         const bool qcfail = r.qcfail || !classified;                   // mdd.cpp:82-84

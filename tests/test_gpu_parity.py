@@ -1099,6 +1099,38 @@ def test_single_index_sets_of_11_to_20_nt_take_the_paired_tier_in_two_parts(orac
     s.close()
 
 
+@pytest.mark.parametrize("length,count,masking,shared", [(11, 60, 0, False), (12, 96, 25, False), (16, 200, 30, False), (20, 96, 0, False), (12, 96, 25, True)])
+def test_single_index_sets_of_11_to_20_nt_under_mdd_take_the_paired_lookup_in_two_parts(oracle, torch_cuda, length, count, masking, shared):
+    """The same two parts under MDD (mdd_near.hpp): either part's word names the candidate, the tolerance is the whole barcode's,
+    only a read that IS classified is finished by the lookup and the scan takes the rest.  With quality masking the reference
+    settles exact matches first (mdd.cpp:43-46), which the lookup can do only for barcodes a part of their own names: a set
+    where some barcode shares both its part words with others (`shared`) keeps the old chain.  Reads ON barcodes with low
+    qualities (masked positions) are in the batch."""
+    rng = np.random.default_rng(length * 131 + count + masking)
+    words = synthetic.barcode_set(rng, count, length, min_distance=5 if length >= 12 else 3)
+    if shared:
+        first = 8 if length <= 16 else length - 10
+        words = sorted(set(words + [words[0][:first] + words[1][first:], words[1][:first] + words[0][first:]]))      # four barcodes over two words a part
+    extra = {"quality masking threshold": masking} if masking else {}
+    if length >= 16:
+        extra["distance tolerance"] = [2]                  # (words this long are far apart: their Shannon bound is past the tables' reach of two)
+    job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec("mdd", [words], ["0::%d" % length], **extra)})
+    n = 40000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 10)
+    letters = {"A": 1, "C": 2, "G": 4, "T": 8}
+    for k in range(2000):                                   # reads ON a barcode, some positions under any masking threshold
+        code[k] = [letters[c] for c in words[k % len(words)]]
+        quality[k] = np.where(rng.random(length) < 0.3, 5, 37)
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    s.set_mode(capi.MODE_FAST)
+    s.profile_enable(True)
+    run_gpu(torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST, device_set=s)
+    chain = [span["kernel"] for span in s.profile_chain()]
+    assert (chain[0] == "mdd_lookup_kernel (paired)") == (not shared), chain
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+    s.close()
+
+
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (8, 1024), (8, 1030), (12, 33),
                                           (16, 256), (16, 260), (16, 512), (16, 515), (32, 5)])
