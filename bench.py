@@ -34,6 +34,81 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
+LINE_BUDGET = 4096          # characters of the contract line (the driver keeps a bounded tail of stdout; VERDICT r04: a 20 KB line did not parse)
+
+
+def sig(x, digits=5):
+    """A float at `digits` significant digits (the side file keeps every digit)."""
+    return None if x is None else float("%.*g" % (digits, x)) if isinstance(x, float) else x
+
+
+def contract_line(full):
+    """The ONE line the driver parses, from the full record of a run: the contract's fields, `roofline`, `cpu_baseline`,
+    `parity`, `literal`, and every other leg as a single figure — shapes as name -> [Greads/s, step_frac], the staged and
+    FASTQ legs as name -> Mreads/s.  Chains, per leg parity, notes, published figures live in the side file
+    (`legs`, bench_legs.json beside this script) and on stderr."""
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data") if k in full}
+    config = full["config"]
+    line["config"] = {k: config[k] for k in ("workload", "reads_per_gpu", "kernel_mode", "sharding") if k in config}
+    if config.get("ranks_share_device"):
+        line["config"]["ranks_share_device"] = True
+    for k in ("ranks", "backend", "merge", "counted_reads"):
+        if k in full:
+            line[k] = full[k]
+    r = full["roofline"]
+    line["roofline"] = {k: sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_name", "kernel_ms", "kernel_ms_profiles",
+                                                   "launches_per_step", "classify_ms_per_step", "step_frac", "algorithmic_bytes_per_read",
+                                                   "traffic_step_bytes_per_read", "traffic_file", "traffic_stale", "build", "measured_copy_GBs")}
+    if r.get("all_kernels_ms_per_step"):
+        line["roofline"]["all_kernels_ms_per_step"] = {name: sig(ms, 4) for name, ms in r["all_kernels_ms_per_step"].items()}
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        line["cpu_baseline"] = {"value": sig(c["value"]), "unit": c["unit"], "cores": c["cores"], "per_thread": sig(c.get("per_thread")),
+                                "kind": c["kind"], "sample": c["sample"]}
+    if "parity" in full:
+        line["parity"] = {k: full["parity"][k] for k in ("reads", "posterior_worst", "posterior_tolerance")}
+    if "literal" in full:
+        line["literal"] = {"dtype": "f64", "Mreads/s": sig(full["literal"]["Mreads/s"]), "step_frac": sig(full["literal"]["step_frac"], 4)}
+    if "shapes" in full:
+        line["shapes"] = {name: [sig(leg["Mreads/s"] / 1e3, 4), sig(leg["step_frac"], 3)] for name, leg in full["shapes"].items()}
+        line["shapes_are"] = "[Greads/s, step_frac]; parity of every leg checked against the oracle in the run"
+    for block in ("staged", "fastq_to_sam", "small_batches"):
+        if block in full:
+            line[block] = {name: sig(leg["Mreads/s"], 4) for name, leg in full[block].items() if isinstance(leg, dict) and "Mreads/s" in leg}
+    if "legs" in full:
+        line["legs"] = full["legs"]
+    text = json.dumps(line, separators=(", ", ": "))
+    if len(text) >= LINE_BUDGET:                       # never print a line the driver cannot keep: drop the optional legs, largest first
+        for k in ("small_batches", "staged", "fastq_to_sam", "shapes_are", "shapes", "literal"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) < LINE_BUDGET:
+                break
+    assert len(text) < LINE_BUDGET, len(text)
+    return text
+
+
+def emit(full, legs=None):
+    """Every leg in full to `legs` (default: bench_legs.json beside this script, and gpurun_out/ when that exists) and to
+    stderr; the contract line LAST on stdout."""
+    text = json.dumps(full, indent=1)
+    targets = [legs] if legs else [os.path.join(ROOT, "bench_legs.json")]
+    if not legs and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_legs.json"))
+    written = []
+    for path in targets:
+        try:
+            with open(path, "w") as out:
+                out.write(text + "\n")
+            written.append(os.path.relpath(path, ROOT))
+        except OSError:
+            pass
+    full["legs"] = written[0] if written else None
+    print(json.dumps(full), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(contract_line(full), flush=True)
+
 
 def shape_key(config, algorithm, kernel_mode, priors):
     """The name a workload has in profiles/rNN_traffic.json."""
@@ -55,8 +130,12 @@ def profiled_traffic(reads, config="C2", algorithm="pamld", kernel_mode="fast", 
             continue
         entry = summary.get("shapes", {}).get(shape_key(config, algorithm, kernel_mode, priors))
         if entry:
+            family = [k for name, k in entry.get("kernels", {}).items() if name.split("<")[0] == entry.get("dominant_kernel")]
+            # the rocprofv3 --kernel-trace --stats average of the dominant kernel's launches (all of a step together),
+            # scaled to this run's reads: the figure the in-run HIP event time has to agree with
+            kernel_ms = sum(k["average_ns"] * k["launches_per_step"] for k in family) * 1e-6 * reads / entry["reads_per_step"] if family else None
             return {"dominant": entry["dominant_bytes_per_read"] * reads, "step": entry["step_bytes_per_read"] * reads,
-                    "step_bytes_per_read": entry["step_bytes_per_read"], "file": os.path.basename(path),
+                    "step_bytes_per_read": entry["step_bytes_per_read"], "file": os.path.basename(path), "kernel_ms": kernel_ms,
                     "build": summary.get("build"), "stale": summary.get("build") != capi.build_id()}
     return None
 
@@ -218,9 +297,12 @@ def cpu_baseline(job, code, quality, flag, target_seconds=12.0):
         t.join()
     elapsed = time.perf_counter() - t0
     total = sum(done)
-    return {"value": total / elapsed / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads (64 Ki-read chunks of the same C2 pool) on %d threads with private decoder sets, %.1f s wall; "
-                      "1 thread alone: %.3f Mreads/s" % (total, cores, elapsed, single / 1e6)}
+    return {"value": total / elapsed / 1e6, "unit": "Mreads/s", "cores": cores, "kind": "port", "per_thread": total / elapsed / 1e6 / cores,
+            "one_thread_alone": single / 1e6,
+            # SURVEY.md §8d anchors the reference's own code at 0.229 Mreads/s per thread on a 2.1 GHz Xeon; the GPU box's
+            # host cores are faster ones, so the port lands above that anchor, not within +-20 % of it
+            "sample": "%d reads of the C2 batch in 64 Ki chunks, %d threads, private decoder sets, %.1f s; 1 thread alone %.3f Mreads/s "
+                      "(survey anchor 0.229 on a 2.1 GHz Xeon: other cores)" % (total, cores, elapsed, single / 1e6)}
 
 
 POSTERIOR_TOLERANCE = {"fast": 1e-8, "literal": 1e-12}       # what the kernels are designed to hold (tests/test_gpu_parity.py); the contract is 1e-6
@@ -406,6 +488,7 @@ def main():
     parser.add_argument("--no-parity", action="store_true", help="skip the oracle check of a sample of the timed batch")
     parser.add_argument("--host-staged", type=int, default=64_000_000, metavar="READS",
                         help="reads of the phq_classify_host leg (host planes -> pinned -> device -> back); 0 = skip")
+    parser.add_argument("--legs", default=None, metavar="PATH", help="where the full record of the run goes (every leg with its chain, parity, notes); default bench_legs.json beside this script")
     parser.add_argument("--no-extra-legs", action="store_true", help="only the contract line: no staged / fastq_to_sam / shapes blocks")
     args = parser.parse_args()
 
@@ -466,6 +549,9 @@ def main():
                        "ranks_share_device": bool(args.share_device)},
             "merge": "once per run",
             "counted_reads": m["counted_reads"],
+            # what the process group itself says: the ranks that took part in the barrier and the all-reduce, and its backend
+            "ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+            "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
             # the dominant kernel kind (all its launches of a step) against the HBM roofline; step_frac: the whole step
             "roofline": {"bound": "hbm", "achieved": m["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": m["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic["dominant"] if traffic else None,
@@ -478,6 +564,10 @@ def main():
                          "traffic_stale": traffic["stale"] if traffic else None,
                          "build": capi.build_id(),
                          "kernel": m["dominant"], "kernel_ms": m["kernel_ms"], "launches_per_step": m["launches_per_step"],
+                         # the kernel's name as the dispatcher gives it, and the rocprofv3 --kernel-trace --stats average of
+                         # the same kernel from profiles/ (every launch of a trace pass, warm-up included) beside the in-run one
+                         "kernel_name": max(m["chain"], key=lambda c: c["ms_per_step"])["kernel"] if m["chain"] else None,
+                         "kernel_ms_profiles": traffic["kernel_ms"] if traffic else None,
                          "algorithmic_bytes_per_read": w.bytes_per_read,
                          "step_achieved": m["step_GBs"], "step_frac": m["step_GBs"] / HBM_PEAK_GBS,
                          # the node's practical ceiling: the library's own 16 bytes a lane streaming copy (the guide: 6.3 TB/s), and torch's copy kernel
@@ -538,7 +628,7 @@ def main():
                     line["shapes"][name]["published"] = {"whole process Mreads/s": 0.459, "where": "docs/illumina_api_vignette.md:222: about 1:45 hours per lane of 2 894 717 093 reads, "
                                                          "gzip FASTQ in, /dev/null out, dual socket Xeon E5-2620 (12 cores); IO inclusive, not a kernel figure"}
                 shape.close()
-        print(json.dumps(line))
+        emit(line, args.legs)
     else:
         w.close()
     if world > 1:

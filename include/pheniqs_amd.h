@@ -229,7 +229,10 @@ int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* in
  * by the set (b mod (n_copy + 1) == 0) or by copy (b mod (n_copy + 1)) - 1, records leave in input order, and when the input
  * ends every copy's counters are added into the set's and zeroed (transcode.cpp:1816-1818 -> selector.cpp:68-77), so
  * phq_stats_export / phq_report_json on `set` then speak for the whole run.  With processes per GPU instead, the same merge
- * is phq_stats_allreduce.  A report only run that decodes its FASTQ text on the device stays on the set's own device. */
+ * is phq_stats_allreduce.  A report only run that decodes its FASTQ text on the device stays on the set's own device.
+ * NOT a speed-up as it stands: every batch's classify call blocks the one pull loop, so one device is busy at a time; the
+ * call shows the dealing of batches, the input order of the records and the counter merge.  A node's GPUs are put to work
+ * by one process per GPU over shards of the input (pheniqs_amd/distributed.py, phq_stats_allreduce). */
 int phq_transcode_job_copies(phq_decoder_set* set, int32_t n_copy, phq_decoder_set* const* copy, int64_t batch_capacity,
                              uint64_t* incoming_count, uint64_t* incoming_pf_count);
 

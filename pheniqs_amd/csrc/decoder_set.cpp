@@ -1374,8 +1374,9 @@ void DecoderSet::ensure_pipeline(int64_t chunk_capacity) {
         if(slot.stream) { check(hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)), "hipStreamSynchronize"); }
         (void)hipFree(slot.device_base); (void)hipFree(slot.device_quality); (void)hipFree(slot.device_flag);
         (void)hipFree(slot.device_result); (void)hipFree(slot.device_word); (void)hipFree(slot.device_worklist);
+        (void)hipFree(slot.device_packed); (void)hipFree(slot.device_escape);
         host_free(slot.pinned_base); host_free(slot.pinned_quality); host_free(slot.pinned_flag);
-        host_free(slot.pinned_result); host_free(slot.pinned_word);
+        host_free(slot.pinned_result); host_free(slot.pinned_word); host_free(slot.pinned_escape);
         // nothing of the old buffers is left in the slot should an allocation below throw (release() frees what it finds)
         { Slot fresh; fresh.stream = slot.stream; fresh.done = slot.done; fresh.uploaded = slot.uploaded; fresh.consumed = slot.consumed; slot = fresh; }
         chunk_capacity_ = 0;
@@ -1500,6 +1501,30 @@ void DecoderSet::classify_host_planes(int64_t batch_capacity, int64_t n_read, co
     }
     int64_t escape_at = 0;                          // the list is in read order: a chunk's entries follow the previous chunk's
     const bool direct_out = pinned(result) && pinned(word);
+    if(packed_planes != nullptr) {
+        // PHQ_OVERFLOW_ERROR is the documented, recoverable answer to a batch that does not pack (the caller falls back to
+        // phq_classify_host): it is given BEFORE anything is enqueued, so no chunk of this call is in flight when it is
+        int64_t at = 0;
+        for(int64_t first = 0; first < n_read; first += chunk) {
+            const int64_t end = first + std::min(chunk, n_read - first);
+            int64_t in_chunk = 0;
+            while(at < n_escape && static_cast<int64_t>(escapes[at] >> 32) < end) { ++at; ++in_chunk; }
+            if(in_chunk > chunk_capacity_) { throw OverflowError("more nucleotides outside the packed form than reads in a chunk: use phq_classify_host"); }
+        }
+    }
+    // whatever else is thrown part way (a HIP error): nothing of this call stays in flight behind it — the caller's buffers
+    // are not written after the call has returned, and the next call finds every slot idle
+    struct Quiesce {
+        DecoderSet* set; hipStream_t upload; bool armed;
+        ~Quiesce() {
+            if(!armed) { return; }
+            (void)hipStreamSynchronize(upload);
+            for(auto& slot : set->slot_) {
+                if(slot.stream) { (void)hipStreamSynchronize(static_cast<hipStream_t>(slot.stream)); }
+                slot.busy = false;
+            }
+        }
+    } quiesce{this, upload, true};
 
     auto drain = [&](Slot& slot) {
         if(!slot.busy) { return; }
@@ -1592,6 +1617,7 @@ void DecoderSet::classify_host_planes(int64_t batch_capacity, int64_t n_read, co
         slot.count = count;
     }
     for(auto& slot : slot_) { drain(slot); }
+    quiesce.armed = false;
 }
 
 // ---- statistics ----------------------------------------------------------------------------------------

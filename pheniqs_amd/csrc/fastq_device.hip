@@ -215,7 +215,11 @@ __global__ __launch_bounds__(TILE_THREADS) void fastq_decode_kernel(DecodeArgs a
 void fastq_plan_waves(FastqPlan& plan, double bytes_per_read) {
     constexpr double ROOM = 20.0 * 1024.0;
     int32_t reads = 64;
-    if(const char* text = std::getenv("PHQ_FASTQ_READS_PER_WAVE")) { reads = std::max(8, std::min(64, std::atoi(text))); }      // sweeps
+    if(const char* text = std::getenv("PHQ_FASTQ_READS_PER_WAVE")) {      // sweeps; a power of two from 8 to 64: the per workgroup scratch is sized for at least 32 reads a workgroup
+        const int asked = std::max(8, std::min(64, std::atoi(text)));
+        reads = 8;
+        while(reads * 2 <= asked) { reads *= 2; }
+    }
     while(reads > 8 && static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed > ROOM) { reads /= 2; }
     plan.reads_per_wave = reads;
     const double room = std::min(ROOM, static_cast<double>(reads) * bytes_per_read * 1.25 + 32.0 * plan.n_feed);
@@ -263,7 +267,8 @@ int fastq_decode(const FastqTables* on_device, const FastqPlan& plan, int32_t sl
     call.flagged = flagged;
     call.keep = keep;
     call.keep_block = keep_block;
-    if(plan.reads_per_wave < 1 || plan.reads_per_wave > 64 || plan.input_room < 0 || plan.input_room % 16 != 0) { return static_cast<int>(hipErrorInvalidValue); }
+    // 8, 16, 32 or 64 reads a wave: the callers size keep_block and the record writers' per workgroup arrays for 32 reads a workgroup at least
+    if(plan.reads_per_wave < 8 || plan.reads_per_wave > 64 || (plan.reads_per_wave & (plan.reads_per_wave - 1)) != 0 || plan.input_room < 0 || plan.input_room % 16 != 0) { return static_cast<int>(hipErrorInvalidValue); }
     const uint32_t blocks = fastq_groups(plan, n);
     const size_t lds = static_cast<size_t>(TILE_WAVES) * static_cast<size_t>(plan.input_room);
     hipStream_t s = static_cast<hipStream_t>(stream);

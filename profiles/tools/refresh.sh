@@ -26,15 +26,15 @@ out=gpurun_out/prof_$round
 for shape in "${shapes[@]}"; do
   a="${ARGS[$shape]}"
   d=$out/$shape; rm -rf $d; mkdir -p $d
-  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 bench.py $a --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra-legs > $d/trace.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -- python3 bench.py $a --steps 5 --warmup 2 --no-cpu-baseline --no-parity --no-extra-legs --legs $d/legs.json > $d/trace.log 2>&1
   grep '^{"metric"' $d/trace.log | tail -1 > $d/bench.json
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > $d/fetch.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $d/fetch -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs --legs $d/fetch_legs.json > $d/fetch.log 2>&1
   grep '^{"metric"' $d/fetch.log | tail -1 > $d/fetch.json
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs > $d/write.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $d/write -- python3 bench.py $a --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-extra-legs --legs $d/write_legs.json > $d/write.log 2>&1
   grep '^{"metric"' $d/write.log | tail -1 > $d/write.json
   stats=$(ls -t $d/trace/*/*_kernel_stats.csv | head -1)
   (head -1 $stats; grep "phq::" $stats) > gpurun_out/${round}_${shape}_kernel_stats.csv
-  cp $d/bench.json gpurun_out/${round}_bench_${shape}.json
+  cp $d/legs.json gpurun_out/${round}_bench_${shape}.json     # the full record (chain included); bench.json is the contract line
   echo "$shape: $(grep -o '"ms_per_step": [0-9.]*' $d/bench.json)"
 done
 python3 profiles/summarize.py $out gpurun_out/${round}_traffic.json "${shapes[@]}"

@@ -14,7 +14,7 @@ SHARDED_READS = 200003
 SHARDED_WORLD = 2
 _sharded = {"directory": None, "log": "", "returncode": None}
 BENCH_RANKS_COMMAND = ["--gpus", "2", "--share-device", "--reads", "2000000", "--steps", "3", "--warmup", "1", "--no-extra-legs", "--no-cpu-baseline"]
-_bench_ranks = {"log": "", "returncode": None, "command": BENCH_RANKS_COMMAND}
+_bench_ranks = {"log": "", "stdout": "", "returncode": None, "command": BENCH_RANKS_COMMAND}
 
 
 def pytest_configure(config):
@@ -48,9 +48,10 @@ def pytest_sessionstart(session):
     # bench.py's own N > 1 branch (it starts its ranks itself: python -m torch.distributed.run), two ranks on this one GPU
     try:
         done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + BENCH_RANKS_COMMAND,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, cwd=ROOT)
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
         _bench_ranks["returncode"] = done.returncode
-        _bench_ranks["log"] = done.stdout.decode(errors="replace")[-8000:]
+        _bench_ranks["stdout"] = done.stdout.decode(errors="replace")       # what the driver reads: the contract line is its LAST line
+        _bench_ranks["log"] = done.stderr.decode(errors="replace")[-8000:] + "\n" + _bench_ranks["stdout"][-8000:]
     except subprocess.TimeoutExpired as error:
         _bench_ranks["log"] = "timed out after 900 s\n" + (error.stdout or b"").decode(errors="replace")[-4000:]
     except OSError as error:

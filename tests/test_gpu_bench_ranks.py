@@ -14,9 +14,12 @@ pytestmark = pytest.mark.gpu
 def test_bench_with_two_ranks_prints_a_whole_job_line(bench_ranks_run):
     log = bench_ranks_run["log"]
     assert bench_ranks_run["returncode"] == 0, "bench.py %s failed:\n%s" % (" ".join(bench_ranks_run["command"]), log)
-    lines = [text for text in log.splitlines() if text.startswith('{"metric"')]
+    lines = [text for text in bench_ranks_run["stdout"].splitlines() if text.startswith('{"metric"')]
     assert len(lines) == 1, log                      # rank 0 alone prints
+    assert bench_ranks_run["stdout"].rstrip().splitlines()[-1] == lines[0]      # and the contract line is the LAST line of stdout
+    assert len(lines[0]) < 4096, len(lines[0])       # a line the driver can keep whole (20 KB did not parse)
     line = json.loads(lines[0])
+    assert line["ranks"] == 2 and line["backend"] == "gloo"      # what the process group itself reports
     reads, steps = 2000000, 3
     assert line["n_gpus"] == 2 and line["steps"] == steps and line["warmup"] == 1
     assert line["scaling"] == "weak" and line["merge"] == "once per run"
