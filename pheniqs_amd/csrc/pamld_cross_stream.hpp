@@ -970,8 +970,10 @@ void pamld_cross_stream_kernel(StageArgs args) {
             const float x_rest = PRIORS ? along_column[0].x * (upper0 * upper1 + x_rest_of[0] + x_rest_of[1]) * near::SLOP
                                         : (upper0 + upper1 + upper0 * upper1 - listed) * near::SLOP;
             const float x_low = __builtin_fmaf(PRIORS ? along_row[0].x : noise_over_prior, __builtin_amdgcn_rcpf(winner_probability), listed);
-            // the posterior is taken WITHOUT what was only bounded: 1 - y, y = x / (1 + x) = x - x^2 + x^3 (x at most 3e-4)
-            const float y = x_low * __builtin_fmaf(-x_low, 1.0f - x_low, 1.0f);
+            // the posterior is taken a quarter of the way into what was only bounded (pamld_near.hpp: at most 0.75 x_rest off):
+            // 1 - y, y = x / (1 + x) = x - x^2 + x^3 (x at most 3e-4)
+            const float x_mid = __builtin_fmaf(0.25f, x_rest, x_low);
+            const float y = x_mid * __builtin_fmaf(-x_mid, 1.0f - x_mid, 1.0f);
             const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
             // a low confidence read is left to pass C: its counter lives in a bin only that pass reaches
             const bool finished = all_strict && usable && winner_probability > noise_floor && listed <= near::LISTED_MAX && x_low + x_rest <= X_MAX &&

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
         const float listed = weighted_of[0] * inverse0 + weighted_of[1] * inverse1;
         const float x_rest = ratio[1][0][0] * (plain_of[0] * inverse0) * (plain_of[1] * inverse1) * near::SLOP;
         const float x_low = __builtin_fmaf(ratio[0][0][0], __builtin_amdgcn_rcpf(winner_probability), listed);
-        const float y = x_low * __builtin_amdgcn_rcpf(1.0f + x_low);           // 1 - posterior
+        const float x_mid = __builtin_fmaf(0.25f, x_rest, x_low);              // a quarter of the way into what was only bounded (pamld_near.hpp)
+        const float y = x_mid * __builtin_amdgcn_rcpf(1.0f + x_mid);           // 1 - posterior
         const double confidence = 1.0 - static_cast<double>(y);                // pamld.cpp:92
         const double confidence_margin = confidence - confidence_threshold;
         const uint32_t k0 = static_cast<uint32_t>(__popc(mismatches_of[0])), k1 = static_cast<uint32_t>(__popc(mismatches_of[1]));

@@ -752,9 +752,10 @@ void pamld_stream_kernel(StageArgs args) {
             const float x_rest = rest * inverse_winner;
             const float noise_over_prior = PRIORS ? __uint_as_float(record_word(PLANE_WORDS + 4)) : uniform_noise_over_prior;
             const float x_low = __builtin_fmaf(noise_over_prior, inverse_both, x_listed);
-            // the posterior is taken WITHOUT what was only bounded (pamld_near.hpp): 1 - y, y = x / (1 + x) = x - x^2 + x^3 up
-            // to x^4 < 7e-14 (x is at most 5e-4 where it counts)
-            const float y = x_low * __builtin_fmaf(-x_low, 1.0f - x_low, 1.0f);
+            // the posterior is taken a quarter of the way into what was only bounded (pamld_near.hpp: at most 0.75 x_rest off,
+            // 7.5e-9 with the rounding): 1 - y, y = x / (1 + x) = x - x^2 + x^3 up to x^4 < 7e-14 (x is at most 5e-4 where it counts)
+            const float x_mid = __builtin_fmaf(0.25f, x_rest, x_low);
+            const float y = x_mid * __builtin_fmaf(-x_mid, 1.0f - x_mid, 1.0f);
             const double confidence = 1.0 - static_cast<double>(y);            // pamld.cpp:92
             const int k = __popc(mismatches);
             const bool finished = all_strict && known && k <= 1 && winner * everything_matches > noise_floor &&
