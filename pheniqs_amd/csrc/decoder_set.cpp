@@ -705,6 +705,41 @@ void DecoderSet::build_device_images() {
                         d.pair_length[s] = part_length[s];
                     }
                     d.pair_record = static_cast<const uint32_t*>(upload(record.data(), record.size() * sizeof(uint32_t)));
+                    if(c.algorithm == Algorithm::PAMLD) {
+                        // the list tier behind the first look (pamld_pair.hpp, SECOND): per barcode its PAIR_LISTED nearest barcodes (the
+                        // lowest ordinal among equally near ones first), and for the bound on everyone else the distance of the nearest
+                        // barcode that is NOT listed with the others' priors over its own in three classes from there on
+                        std::vector<uint32_t> lists(static_cast<size_t>(N) * PAIR_LIST_WORDS, 0u);
+                        std::vector<std::pair<int, int32_t>> by_distance(static_cast<size_t>(N));
+                        for(int32_t b = 0; b < N; ++b) {
+                            auto away = [&](int32_t o) { return std::min(31, __builtin_popcount((low[static_cast<size_t>(b)] ^ low[static_cast<size_t>(o)]) | (high[static_cast<size_t>(b)] ^ high[static_cast<size_t>(o)]))); };
+                            by_distance.clear();
+                            for(int32_t o = 0; o < N; ++o) { if(o != b) { by_distance.emplace_back(away(o), o); } }
+                            std::sort(by_distance.begin(), by_distance.end());
+                            uint32_t* const entry = &lists[static_cast<size_t>(b) * PAIR_LIST_WORDS];
+                            const double own = concentration[static_cast<size_t>(b)];
+                            for(int32_t o = 0; o < PAIR_LISTED; ++o) {
+                                const bool there = static_cast<size_t>(o) < by_distance.size();
+                                const int32_t other = there ? by_distance[static_cast<size_t>(o)].second : b;
+                                entry[o] = low[static_cast<size_t>(other)];
+                                entry[PAIR_LISTED + o] = high[static_cast<size_t>(other)];
+                                const float ratio = !there ? 0.0f : d.uniform_prior ? 1.0f : static_cast<float>(concentration[static_cast<size_t>(other)] / own);
+                                std::memcpy(&entry[2 * PAIR_LISTED + 4 + o], &ratio, sizeof(float));
+                            }
+                            const int beyond = by_distance.size() > static_cast<size_t>(PAIR_LISTED) ? by_distance[PAIR_LISTED].first : 31;
+                            double weight[3] = {0, 0, 0};
+                            for(size_t o = PAIR_LISTED; o < by_distance.size(); ++o) {
+                                weight[std::min(by_distance[o].first - beyond, 2)] += d.uniform_prior ? 1.0 : concentration[static_cast<size_t>(by_distance[o].second)] / own;
+                            }
+                            const float up = d.uniform_prior ? 1.0f : 1.0f + 1e-6f;          // sums of ratios bound: rounded up
+                            entry[2 * PAIR_LISTED] = static_cast<uint32_t>(beyond);
+                            for(int k = 0; k < 3; ++k) {
+                                const float others = static_cast<float>(weight[k]) * up;
+                                std::memcpy(&entry[2 * PAIR_LISTED + 1 + k], &others, sizeof(float));
+                            }
+                        }
+                        d.pair_list = static_cast<const uint32_t*>(upload(lists.data(), lists.size() * sizeof(uint32_t)));
+                    }
                     d.pair_ready = (c.algorithm == Algorithm::PAMLD && 2 * usable >= N) ? 1 : 0;              // barcodes closer than that leave the bound nothing to certify
                     // one lookup per segment is the reference's first fit (mdd.cpp:50-80) only while at most ONE word of a segment
                     // can be within its tolerance of an observation: tolerance <= (smallest distance between two of the

@@ -22,6 +22,8 @@ constexpr int near_record_words(int length) { return length <= 8 ? 12 : 16; }   
 // the noise term over c's prior — again whole quads
 constexpr int near_record_words(int length, bool priors) { return near_record_words(length) + (priors ? (length <= 8 ? 16 : 16) : 0); }
 constexpr int MAX_DEFERRED_BINS = 9472;        // count_results_kernel: 16 bytes of LDS each
+constexpr int PAIR_LISTED = 4;                 // pamld_pair.hpp, the list tier behind the first look: the nearest barcodes of a barcode that are scored exactly
+constexpr int PAIR_LIST_WORDS = 16;            // ... {4 low planes, 4 high planes, distance of the nearest barcode NOT listed, the others' priors over its own from there: at that distance / one further / the rest, 4 x the listed barcode's prior over its own (0: no such barcode)}
 constexpr int PAIR_RECORD_WORDS = 8;           // pamld_pair.hpp: {low plane, high plane, radius, barcode index, others at the radius / prior, noise / prior, others one further / prior, the rest / prior}
 // pamld_stream.hpp.  A barcode's block in LDS: its 16 listed barcodes as 8 low + 8 high plane words, the four weights of
 // the bound, its counter bin (8 x 64 bits), padding to 11 quads.  STREAM_WAVES waves in its one workgroup per CU, each
@@ -232,6 +234,7 @@ struct DevDecoder {
     int32_t plate_ready;
     const uint16_t* pair_table[2];
     const uint32_t* pair_record;
+    const uint32_t* pair_list;            // PAIR_LIST_WORDS per barcode (null: no list tier)
     int32_t pair_start[2];
     int32_t pair_length[2];
     int32_t pair_ready;

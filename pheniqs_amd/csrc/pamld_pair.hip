@@ -1,4 +1,6 @@
 // Paired barcode tier of the PAMLD path (pamld_pair.hpp): two segments of up to 10 nt, one barcode scored.
+#include <cstdlib>
+
 #include "pamld_pair.hpp"
 
 namespace phq {
@@ -10,15 +12,24 @@ bool pamld_pair_supports(const DevDecoder& host_decoder) {
            (pamld_lut_supports(host_decoder) || pamld_wide_supports(host_decoder));
 }
 
+// the second look inside the launch (LISTS): the lists are there and the waves' rings fit the workgroup's LDS beside the records
+// and the histogram, several workgroups a CU
+template <int G>
+bool lists_fit(const DevDecoder& host_decoder, size_t histogram_bytes) {
+    return pair::LayoutOf<G, true>::histogram_at(host_decoder.n_barcode) + histogram_bytes <= 40u * 1024u;
+}
+
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    static const bool no_lists = std::getenv("PHQ_NO_PAIR_LISTS") != nullptr;
+    const bool lists = !no_lists && host_decoder.pair_list != nullptr;
     switch(host_decoder.plane_stride / 4) {
-        case 2: return pair::launch_one<2>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 3: return pair::launch_one<3>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 4: return pair::launch_one<4>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 5: return pair::launch_one<5>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 6: return pair::launch_one<6>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 7: return pair::launch_one<7>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
-        case 8: return pair::launch_one<8>(args, host_decoder.n_barcode, grid, histogram_bytes, stream);
+        case 2: return pair::launch_one<2>(args, host_decoder.n_barcode, lists && lists_fit<2>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 3: return pair::launch_one<3>(args, host_decoder.n_barcode, lists && lists_fit<3>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 4: return pair::launch_one<4>(args, host_decoder.n_barcode, lists && lists_fit<4>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 5: return pair::launch_one<5>(args, host_decoder.n_barcode, lists && lists_fit<5>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 6: return pair::launch_one<6>(args, host_decoder.n_barcode, lists && lists_fit<6>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 7: return pair::launch_one<7>(args, host_decoder.n_barcode, lists && lists_fit<7>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
+        case 8: return pair::launch_one<8>(args, host_decoder.n_barcode, lists && lists_fit<8>(host_decoder, histogram_bytes), grid, histogram_bytes, stream);
         default: return static_cast<int>(hipErrorInvalidValue);
     }
 }
