@@ -222,6 +222,39 @@ def fastq_end_to_end(args, code, quality, flag, n):
             out[name] = {"Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt}
             if os.path.isfile(target):
                 out[name]["sam_MB/s"] = os.path.getsize(target) / dt / 1e6
+        # the published workload's input format (docs/illumina_api_vignette.md:222: gzip FASTQ in): the same files as BGZF — bgzip's
+        # blocks, what the reference reads through htslib (fastq.h:427-440), inflated member parallel on the host's threads
+        # (csrc/gzip_members.hpp) — and, their first Mi reads, as ONE gzip member each: a stream a single thread has to inflate
+        def bgzf(data):
+            import struct
+            import zlib
+
+            def block(piece):
+                compressor = zlib.compressobj(1, zlib.DEFLATED, -15)
+                packed = compressor.compress(piece) + compressor.flush()
+                return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, len(packed) + 25) +
+                        packed + struct.pack("<II", zlib.crc32(piece), len(piece)))
+            view = memoryview(data)
+            with ThreadPoolExecutor(usable_cores()) as pool:
+                return b"".join(pool.map(block, [view[k:k + 65280] for k in range(0, len(data), 65280)] + [b""]))
+        import zlib
+        for name, reads, pack in (("report_only_bgzf", n, bgzf), ("report_only_gz", min(n, 1 << 20), lambda data: (lambda c: c.compress(data) + c.flush())(zlib.compressobj(1, zlib.DEFLATED, 31)))):
+            packed_paths = []
+            for path in paths:
+                data = np.fromfile(path, dtype=np.uint8, count=reads * (os.path.getsize(path) // n)).tobytes()
+                packed_paths.append(path + "." + name + ".gz")
+                with open(packed_paths[-1], "wb") as out_file:
+                    out_file.write(pack(data))
+                del data
+            s.transcode_fastq_to_sam(packed_paths, "/dev/null", 1 << 20)
+            t0 = time.perf_counter()
+            incoming, _ = s.transcode_fastq_to_sam(packed_paths, "/dev/null", 1 << 20)
+            dt = time.perf_counter() - t0
+            assert incoming == reads
+            out[name] = {"Mreads/s": reads / dt / 1e6, "reads": reads, "seconds": dt, "gz_MB/s": sum(os.path.getsize(p) for p in packed_paths) / dt / 1e6,
+                         "text_MB/s": reads * (size // n) / dt / 1e6}
+            for p in packed_paths:
+                os.unlink(p)
         # the same reads split by barcode: a FASTQ file for each of the 96 barcodes and one for the undetermined reads
         # (Multiplexer::push, multiplex.h:198-240), through the job's own directives (phq_transcode_job)
         split_spec = dict(spec, input=paths, output=[os.path.join(directory, "undetermined.fastq")])

@@ -591,6 +591,7 @@ void DecoderSet::build_device_images() {
             const bool two_parts = (c.algorithm == Algorithm::PAMLD || paired_mdd) && c.segment_cardinality == 1 && c.nucleotide_cardinality >= 11 && c.nucleotide_cardinality <= 2 * NEAR_MAX_LENGTH &&
                                    std::getenv("PHQ_NO_PAIR_PARTS") == nullptr;
             int32_t part_start[2] = {0, 0}, part_length[2] = {0, 0};
+            bool prefix_parts = false;             // a part is the first 10 nt of a longer segment
             if(two_parts) {
                 const int32_t L = c.nucleotide_cardinality;
                 part_length[0] = L <= 16 ? std::min(8, L - 4) : L - NEAR_MAX_LENGTH;
@@ -599,6 +600,13 @@ void DecoderSet::build_device_images() {
                 part_start[1] = c.segment_offset[0] + part_length[0];
             } else if(c.segment_cardinality == 2) {
                 for(int32_t s = 0; s < 2; ++s) { part_start[s] = c.segment_offset[static_cast<size_t>(s)]; part_length[s] = c.barcode_length[static_cast<size_t>(s)]; }
+                // segments of 11 to 16 nt (pairs of 12 + 12 or 16 + 16 nt): the lookup takes the first 10 nt of each — a table of 4^12 words
+                // is 32 MB — and the tier scores the barcode it names over ALL its positions; the prefixes must still be all different.
+                // PAMLD only: the MDD lookup decides by the whole segment's tolerance.  (Round 5: such pairs had the two word product
+                // form over all barcodes as their first tier — 96 pairs of 12 + 12 nt 4.5 Greads/s, profiles/r05_shape_grid.md.)
+                if(c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality <= 32) {
+                    for(int32_t s = 0; s < 2; ++s) { if(part_length[s] > NEAR_MAX_LENGTH) { part_length[s] = NEAR_MAX_LENGTH; prefix_parts = true; } }
+                }
             }
             if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors)) || paired_mdd) && (c.segment_cardinality == 2 || two_parts) && c.nucleotide_cardinality <= 32 &&
                d.n_barcode > 1 && d.n_barcode <= NEAR_MAX_BARCODES &&
@@ -626,7 +634,9 @@ void DecoderSet::build_device_images() {
                         word_high[static_cast<size_t>(b)] = (high[static_cast<size_t>(b)] >> start) & mask;
                         uint16_t& exact = nearest[word_low[static_cast<size_t>(b)] | (word_high[static_cast<size_t>(b)] << length)];
                         if(exact != NEAR_NO_BARCODE) {
-                            if(!two_parts) { distinct = false; break; }                           // two barcodes share this segment word
+                            // two barcodes share this segment word: an MDD lookup decides by the segment's own tolerance and needs a barcode
+                            // per word; under PAMLD (and for the parts of a single index) a shared word names no one, as below
+                            if(!two_parts && c.algorithm != Algorithm::PAMLD) { distinct = false; break; }
                             // a part of a single index: a word that several barcodes share names no one — the other part's word decides
                             shared[static_cast<size_t>(b)] = 1;
                             if(exact != PAIR_ANY_BARCODE) { shared[exact] = 1; }

@@ -1,0 +1,218 @@
+// A gzip input of SEVERAL members — BGZF blocks (bgzip, htslib: what the reference reads FASTQ through, fastq.h:427-440 with its
+// thread pool, transcode.cpp:1599-1605) or plain concatenated members (what this library writes: one member per batch part) —
+// inflated member parallel on the host's threads, a batch of members AHEAD of the reader.
+//
+// zlib inflates ~0.3 GB/s of FASTQ text a thread and a gzip stream is sequential inside a member, so a single member file
+// stays one gzread thread (the caller's old path: open() says no); members are independent deflate streams, each with its own
+// CRC and its inflated size in its last four bytes, so with the member boundaries known every member's place in the text is
+// known before anything is inflated and the threads write straight to it.
+//   * BGZF: every block's header carries its compressed size (extra subfield 'B' 'C'): the index is a walk over headers.
+//   * plain members: a scan for gzip headers — 1f 8b 08, no reserved flag bit, XFL 0 / 2 / 4, a known OS byte: by chance once
+//     in ~190 GB of deflate data — and every member is held to Z_STREAM_END at exactly the next boundary with exactly the
+//     size its trailer states and zlib's own CRC check; anything else is an IO error (the device path then hands the file to
+//     the host reader, which reads it through gzread from where the last good round ended).
+#pragma once
+
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <future>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include "error.hpp"
+#include "host_parallel.hpp"
+
+namespace phq {
+
+class MemberInflater {
+public:
+    MemberInflater() = default;
+    MemberInflater(const MemberInflater&) = delete;
+    MemberInflater& operator=(const MemberInflater&) = delete;
+    ~MemberInflater() {
+        for(auto& batch : pending_) { try { batch.get(); } catch(...) {} }
+        if(map_ != nullptr) { ::munmap(const_cast<uint8_t*>(map_), size_); }
+    }
+
+    // true: the file is a gzip stream of at least two members and is indexed; false: something else (one member, not gzip, not
+    // a regular file): the caller reads it as before
+    bool open(const std::string& path, int threads) {
+        threads_ = threads < 1 ? 1 : threads;
+        const int descriptor = ::open(path.c_str(), O_RDONLY);
+        if(descriptor < 0) { return false; }
+        struct stat status;
+        if(::fstat(descriptor, &status) != 0 || !S_ISREG(status.st_mode) || status.st_size < 36) { ::close(descriptor); return false; }
+        size_ = static_cast<size_t>(status.st_size);
+        void* const mapped = ::mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, descriptor, 0);
+        ::close(descriptor);
+        if(mapped == MAP_FAILED) { return false; }
+        map_ = static_cast<const uint8_t*>(mapped);
+        (void)::madvise(mapped, size_, MADV_SEQUENTIAL);
+        if(!(index_blocks() || index_members()) || member_.size() < 2) {
+            ::munmap(mapped, size_);
+            map_ = nullptr;
+            member_.clear();
+            return false;
+        }
+        start_batches();
+        return true;
+    }
+
+    bool blocked() const { return blocked_; }                 // BGZF
+    size_t members() const { return member_.size(); }
+
+    // up to `want` bytes of the text, in order; 0: the end.  Throws IOError for a member that does not inflate to what it states.
+    size_t read(uint8_t* to, size_t want) {
+        size_t done = 0;
+        while(done < want) {
+            if(ready_at_ == ready_.size()) {
+                if(pending_.empty()) { break; }
+                ready_ = pending_.front().get();                  // a worker's IOError crosses here
+                pending_.pop_front();
+                ready_at_ = 0;
+                start_batches();
+                if(ready_.empty()) { continue; }
+            }
+            const size_t take = std::min(want - done, ready_.size() - ready_at_);
+            if(take >= (size_t(8) << 20)) {
+                parallel_ranges(static_cast<int64_t>((take + (1 << 20) - 1) >> 20), 1, threads_, [&](int64_t first, int64_t last, int) {
+                    const size_t from = static_cast<size_t>(first) << 20, until = std::min(take, static_cast<size_t>(last) << 20);
+                    std::memcpy(to + done + from, ready_.data() + ready_at_ + from, until - from);
+                });
+            } else { std::memcpy(to + done, ready_.data() + ready_at_, take); }
+            done += take;
+            ready_at_ += take;
+        }
+        return done;
+    }
+
+private:
+    struct Member { size_t begin, end, text; };
+
+    static uint32_t le32(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); }
+
+    // BGZF (the SAM specification, section 4.1): FLG.FEXTRA, XLEN, subfield 'B' 'C' of two bytes = the block's size - 1
+    bool index_blocks() {
+        size_t at = 0;
+        std::vector<Member> found;
+        while(at + 28 <= size_) {
+            const uint8_t* const h = map_ + at;
+            if(h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 4) == 0) { return false; }
+            const size_t extra = static_cast<size_t>(h[10]) | (static_cast<size_t>(h[11]) << 8);
+            if(at + 12 + extra > size_) { return false; }
+            size_t block = 0;
+            for(size_t e = 0; e + 4 <= extra;) {
+                const uint8_t* const sub = h + 12 + e;
+                const size_t length = static_cast<size_t>(sub[2]) | (static_cast<size_t>(sub[3]) << 8);
+                if(sub[0] == 'B' && sub[1] == 'C' && length == 2 && e + 6 <= extra) { block = (static_cast<size_t>(sub[4]) | (static_cast<size_t>(sub[5]) << 8)) + 1; }
+                e += 4 + length;
+            }
+            if(block < 26 || at + block > size_) { return false; }
+            const size_t text = le32(map_ + at + block - 4);
+            if(text > 65536) { return false; }
+            if(text > 0) { found.push_back({at, at + block, text}); }             // (the empty block at the end says end of file)
+            at += block;
+        }
+        if(at != size_) { return false; }
+        member_.swap(found);
+        blocked_ = true;
+        return true;
+    }
+
+    static bool header_at(const uint8_t* h) {
+        return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 0xe0) == 0 && (h[8] == 0 || h[8] == 2 || h[8] == 4) && (h[9] <= 13 || h[9] == 255);
+    }
+
+    // plain members: where a gzip header starts, scanned on every thread
+    bool index_members() {
+        if(!header_at(map_)) { return false; }
+        const size_t last = size_ - 18;                       // a header and a trailer fit behind it
+        const int parts = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads_), (size_ >> 22) + 1));
+        std::vector<std::vector<size_t>> found(static_cast<size_t>(parts));
+        parallel_ranges(static_cast<int64_t>(last), 1 << 20, parts, [&](int64_t first, int64_t until, int part) {
+            const uint8_t* at = map_ + (first == 0 ? 1 : first);
+            const uint8_t* const end = map_ + until;
+            while(at < end) {
+                at = static_cast<const uint8_t*>(std::memchr(at, 0x1f, static_cast<size_t>(end - at)));
+                if(at == nullptr) { break; }
+                if(header_at(at)) { found[static_cast<size_t>(part)].push_back(static_cast<size_t>(at - map_)); }
+                ++at;
+            }
+        });
+        std::vector<size_t> boundary{0};
+        for(const auto& part : found) { boundary.insert(boundary.end(), part.begin(), part.end()); }
+        boundary.push_back(size_);
+        for(size_t k = 0; k + 1 < boundary.size(); ++k) {
+            if(boundary[k + 1] - boundary[k] < 18) { return false; }
+            member_.push_back({boundary[k], boundary[k + 1], le32(map_ + boundary[k + 1] - 4)});
+        }
+        return true;
+    }
+
+    static void inflate_member(const uint8_t* from, size_t bytes, uint8_t* to, size_t text) {
+        z_stream z;
+        std::memset(&z, 0, sizeof(z));
+        if(inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) { throw InternalError("inflateInit2"); }
+        size_t in_at = 0, out_at = 0;
+        int status = Z_OK;
+        while(status == Z_OK) {
+            z.next_in = const_cast<Bytef*>(from + in_at);
+            z.avail_in = static_cast<uInt>(std::min<size_t>(bytes - in_at, size_t(1) << 30));
+            z.next_out = to + out_at;
+            z.avail_out = static_cast<uInt>(std::min<size_t>(text - out_at, size_t(1) << 30));
+            const size_t in_before = z.avail_in, out_before = z.avail_out;
+            status = inflate(&z, Z_NO_FLUSH);
+            in_at += in_before - z.avail_in;
+            out_at += out_before - z.avail_out;
+            if(status == Z_OK && in_before == z.avail_in && out_before == z.avail_out) { break; }      // no room and no end: more text than stated
+        }
+        inflateEnd(&z);
+        if(status != Z_STREAM_END || in_at != bytes || out_at != text) { throw IOError("a gzip member does not inflate to the size its trailer states"); }
+    }
+
+    // AHEAD batches in flight: the reader copies one out while the next ones inflate — also while the rounds' kernels run
+    void start_batches() { while(pending_.size() < AHEAD && next_ < member_.size()) { start_batch(); } }
+
+    // the next batch — enough members for every thread and at least 64 MiB of text — inflated on threads of its own
+    void start_batch() {
+        if(next_ >= member_.size()) { return; }
+        const size_t first = next_;
+        size_t text = 0;
+        while(next_ < member_.size() && (text < (size_t(64) << 20) || next_ - first < static_cast<size_t>(2 * threads_)) && text < (size_t(768) << 20)) { text += member_[next_++].text; }
+        const size_t last = next_;
+        pending_.push_back(std::async(std::launch::async, [this, first, last, text]() {
+            std::vector<uint8_t> out(text);
+            std::vector<size_t> place(last - first);
+            size_t at = 0;
+            for(size_t k = first; k < last; ++k) { place[k - first] = at; at += member_[k].text; }
+            std::atomic<size_t> turn{first};
+            parallel_ranges(threads_, 1, threads_, [&](int64_t, int64_t, int) {
+                for(size_t k = turn.fetch_add(1); k < last; k = turn.fetch_add(1)) {
+                    inflate_member(map_ + member_[k].begin, member_[k].end - member_[k].begin, out.data() + place[k - first], member_[k].text);
+                }
+            });
+            return out;
+        }));
+    }
+
+    const uint8_t* map_ = nullptr;
+    size_t size_ = 0;
+    int threads_ = 1;
+    bool blocked_ = false;
+    std::vector<Member> member_;
+    size_t next_ = 0;
+    std::vector<uint8_t> ready_;
+    size_t ready_at_ = 0;
+    static constexpr size_t AHEAD = 2;
+    std::deque<std::future<std::vector<uint8_t>>> pending_;
+};
+
+}  // namespace phq

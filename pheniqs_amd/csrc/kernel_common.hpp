@@ -306,6 +306,7 @@ bool pamld_few_supports(const DevDecoder& host_decoder);    // pamld_few.hip: th
 int pamld_few_waves();                                      // waves (= worklist segments) per workgroup of that kernel
 int launch_pamld_few(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, hipStream_t stream);
 bool pamld_lut_supports(const DevDecoder& host_decoder);
+bool pamld_lut_preferred(const DevDecoder& host_decoder);          // ... and few enough barcodes that a combinatorial set does not take the factorised kernels instead
 int pamld_lut_block(const DevDecoder& host_decoder);       // threads per workgroup of the product form kernel
 int launch_pamld_lut(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 int pamld_near_block(const DevDecoder& host_decoder);      // threads per workgroup of the neighbour list kernel

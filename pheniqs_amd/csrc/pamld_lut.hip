@@ -11,11 +11,21 @@ static int packed_words(const DevDecoder& host_decoder) {
     return host_decoder.nucleotide_cardinality <= 8 ? padded / 2 : padded;
 }
 
-// ACGT barcodes of up to 16 nt and at most 512 packed words (LUT_MAX_WORDS: their two planes take 4 KiB of LDS); the byte parallel quality
-// compare of the kernel covers thresholds up to 128
+// ACGT barcodes of up to 16 nt and at most LUT_MOST_WORDS packed words: their two planes take 8 bytes of LDS each beside the per
+// read tables (64 KiB) — 4 096 barcodes of 9 to 16 nt are 32 KiB, one workgroup a CU instead of two.  (512 words until round 5:
+// a codec past them had NO kernel but the literal one, for every read: 768 indexes of 10 nt 0.4 Greads/s, the cliff
+// profiles/r05_shape_grid.md found.)  The byte parallel quality compare of the kernel covers thresholds up to 128
+constexpr int LUT_MOST_WORDS = 4096;
 bool pamld_lut_supports(const DevDecoder& host_decoder) {
     return host_decoder.all_strict && host_decoder.high_quality_threshold <= 128 && host_decoder.nucleotide_cardinality >= 1 && host_decoder.nucleotide_cardinality <= 16 &&
-           host_decoder.n_barcode > 0 && packed_words(host_decoder) <= 512 && host_decoder.barcode_packed2 != nullptr;
+           host_decoder.n_barcode > 0 && packed_words(host_decoder) <= LUT_MOST_WORDS && host_decoder.barcode_packed2 != nullptr &&
+           (host_decoder.use_lds_histogram == 0 || host_decoder.n_barcode <= 1024);
+}
+
+// ... and it is the FIRST choice up to 512 packed words only: a combinatorial set past them takes the factorised kernels
+// (pamld_cross*.hpp: 784 combinations of 8 nt words 25 Greads/s through the streaming kernel of sets, 2.8 through this one)
+bool pamld_lut_preferred(const DevDecoder& host_decoder) {
+    return pamld_lut_supports(host_decoder) && packed_words(host_decoder) <= 512;
 }
 
 int pamld_lut_block(const DevDecoder& host_decoder) {

@@ -90,7 +90,6 @@ template <int L> struct LutGeometry {
     }
     __host__ __device__ static constexpr uint32_t histogram_at(int n_barcode) { return WORDS_AT + words_bytes(n_barcode); }
 };
-constexpr int LUT_MAX_WORDS = 512;                // packed words of a codec: 1 024 barcodes of up to 8 nt, 512 of 9 to 16 nt
 
 typedef __attribute__((address_space(3))) const float* LdsFloats;         // an LDS address as the hardware takes it
 

@@ -6,7 +6,8 @@ namespace phq {
 bool pamld_wide_supports(const DevDecoder& host_decoder) {
     return host_decoder.algorithm == 1 && host_decoder.all_strict && host_decoder.barcode_wide != nullptr &&
            host_decoder.nucleotide_cardinality > 16 && host_decoder.nucleotide_cardinality <= 32 &&
-           host_decoder.n_barcode > 0 && host_decoder.n_barcode <= 512;      // 16 bytes of plane words + a prior per barcode in LDS
+           host_decoder.n_barcode > 0 && host_decoder.n_barcode <= 2048 &&     // 16 bytes of plane words + a prior per barcode in LDS: 40 KiB beside 64 KiB of tables (512 until round 5: past them the literal kernel took every read)
+           (host_decoder.use_lds_histogram == 0 || host_decoder.n_barcode <= 512);
 }
 
 int pamld_wide_block(const DevDecoder& host_decoder) { return wide::threads_of(host_decoder.plane_stride / 4); }

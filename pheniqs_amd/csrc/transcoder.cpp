@@ -27,6 +27,8 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "gzip_members.hpp"
+
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -908,6 +910,7 @@ struct PlainFile {                     // an input file of the device path: plai
     size_t position = 0;               // of the round's first byte, in the (inflated) text
     double bytes_per_record = 0;
     gzFile zipped = nullptr;
+    std::unique_ptr<MemberInflater> members;      // gzip of several members (BGZF blocks, concatenated members): inflated member parallel, a batch ahead (gzip_members.hpp)
     bool ended = false;                // gzip: the stream has no more bytes
     size_t held = 0;                   // gzip: bytes of text at the front of the round's pinned buffer
     std::vector<uint8_t> head;         // gzip: the text inflated while the file was looked at, until the first round takes it
@@ -1131,8 +1134,15 @@ bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file)
             p.zipped = gzopen(plan.input_feed[static_cast<size_t>(f)].path.c_str(), "rb");
             if(p.zipped == nullptr) { return false; }
             gzbuffer(p.zipped, 1 << 20);
+            // ... unless the stream has several members (bgzip's blocks, the members this library writes): those inflate side by
+            // side on every host thread, a batch ahead of the rounds (gzip_members.hpp)
+            static const bool one_thread = std::getenv("PHQ_GZIP_ONE_THREAD") != nullptr;
+            if(!one_thread) {
+                p.members.reset(new MemberInflater());
+                if(!p.members->open(plan.input_feed[static_cast<size_t>(f)].path, host_threads())) { p.members.reset(); }
+            }
             p.head.resize(sizeof(head));
-            const int inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size()));
+            const int inflated = p.members ? static_cast<int>(p.members->read(p.head.data(), p.head.size())) : gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size()));
             if(inflated < 4) { return false; }
             p.head.resize(static_cast<size_t>(inflated));
             std::memcpy(head, p.head.data(), p.head.size());
@@ -1494,7 +1504,11 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                     if(!p.head.empty()) { std::memcpy(to, p.head.data(), p.head.size()); p.held = p.head.size(); p.head.clear(); }
                     const size_t want = chunk_bytes[f] - 1;
                     while(!p.ended && p.held < want) {
-                        const int got = gzread(p.zipped, to + p.held, static_cast<unsigned>(std::min<size_t>(want - p.held, size_t(1) << 30)));
+                        int got;
+                        try {
+                            got = p.members ? static_cast<int>(p.members->read(to + p.held, std::min<size_t>(want - p.held, size_t(1) << 30)))
+                                            : gzread(p.zipped, to + p.held, static_cast<unsigned>(std::min<size_t>(want - p.held, size_t(1) << 30)));
+                        } catch(const std::exception&) { got = -1; }       // a member that does not inflate to what it states: the host reader takes the file
                         if(got < 0) { failed = true; return; }
                         if(got == 0) { p.ended = true; break; }
                         p.held += static_cast<size_t>(got);

@@ -425,3 +425,69 @@ def test_pack_planes_is_lossless_on_the_host():
     assert s.lib.phq_pack_planes(s.handle, n, n, base.ctypes.data, qual.ctypes.data, packed.ctypes.data, few.ctypes.data, 4, ctypes.byref(needed)) == 0
     assert needed.value == escapes.size and not few.any()
     s.close()
+
+
+def _bgzf(text, block=65280):
+    """bgzip's container (SAM specification 4.1): blocks of at most 64 KiB, each a gzip member whose extra subfield 'B' 'C'
+    holds its size, an empty block at the end — written here from the specification, not by htslib."""
+    import struct
+    import zlib
+    out = bytearray()
+    pieces = [text[k:k + block] for k in range(0, len(text), block)] + [b""]
+    for piece in pieces:
+        compressor = zlib.compressobj(6, zlib.DEFLATED, -15)
+        data = compressor.compress(piece) + compressor.flush()
+        size = 12 + 6 + len(data) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, size - 1)
+        out += data + struct.pack("<II", zlib.crc32(piece), len(piece))
+    return bytes(out)
+
+
+def test_gzip_members_inflate_in_parallel_to_the_same_text(tmp_path):
+    """gzip_members.hpp under ASan + UBSan: BGZF blocks and plain concatenated members come back as the text they hold, read in
+    pieces of uneven sizes across batches; a single member stream is left to gzread; a member cut short or with a damaged trailer
+    is an IO error, never wrong text (fastq.h:427-440 reads such files through htslib's bgzf)."""
+    import gzip
+    import subprocess
+
+    import numpy as np
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
+    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    if built.returncode != 0:
+        assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
+        pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
+    check = os.path.join(csrc, "build", "gzip_members_check_asan")
+    rng = np.random.default_rng(8)
+    records = []
+    for k in range(60000):
+        length = int(rng.integers(30, 90))
+        records.append(b"@M:1:FC:1:1101:%07d:%05d 1:N:0:1\n" % (k, k % 77777) + bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), length, p=[.24, .25, .25, .25, .01])) + b"\n+\n" +
+                       bytes(rng.choice(np.frombuffer(b"#-:F", dtype=np.uint8), length)) + b"\n")
+    text = b"".join(records)
+    expected = tmp_path / "text.fastq"
+    expected.write_bytes(text)
+
+    def run(data, compare=True):
+        path = tmp_path / "input.gz"
+        path.write_bytes(data)
+        return subprocess.run([check, str(path)] + ([str(expected)] if compare else []), capture_output=True, text=True)
+
+    blocked = run(_bgzf(text))
+    assert blocked.returncode == 0 and " blocked 1 " in blocked.stdout, blocked.stdout + blocked.stderr
+    assert int(blocked.stdout.split()[1]) == -(-len(text) // 65280)
+    cuts = [0, 1000, 1001, len(text) // 3, len(text) // 2, len(text) - 5, len(text)]        # members of very different sizes
+    members = b"".join(gzip.compress(text[a:b], level) for (a, b), level in zip(zip(cuts[:-1], cuts[1:]), (1, 9, 6, 1, 5, 9)))
+    plain = run(members)
+    assert plain.returncode == 0 and "members 6 blocked 0 " in plain.stdout, plain.stdout + plain.stderr
+    assert run(gzip.compress(text, 1)).returncode == 3                                      # one member: the caller's gzread path
+    assert run(text).returncode == 3                                                        # not gzip at all
+    damaged = bytearray(members)
+    damaged[-2] ^= 0x55                                                                     # the size the last member states
+    assert run(bytes(damaged)).returncode == 4
+    damaged = bytearray(members)
+    damaged[len(gzip.compress(text[:1000], 1)) + 40] ^= 0xff                                # inside the second member's deflate data
+    assert run(bytes(damaged)).returncode == 4
+    assert run(members[:-9]).returncode == 4                                                # cut short
+    cut = _bgzf(text)
+    assert run(cut[:len(cut) // 2]).returncode in (3, 4)                                    # half a BGZF file: not taken as blocks, or an error

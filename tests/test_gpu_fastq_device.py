@@ -102,19 +102,31 @@ def _both(spec, paths, capacity):
 
 @pytest.mark.parametrize("config,lengths,n,capacity,zipped", [("C2", (50, 8), 150000, 1 << 20, False), ("C2", (50, 8), 150000, 1 << 12, False),
                                                               ("C5", (20, 100), 60000, 1 << 14, False), ("C4", (30, 10, 10), 60000, 1 << 20, False),
-                                                              ("C2", (50, 8), 150000, 1 << 12, True), ("C4", (30, 10, 10), 60000, 1 << 13, True)])
+                                                              ("C2", (50, 8), 150000, 1 << 12, True), ("C4", (30, 10, 10), 60000, 1 << 13, True),
+                                                              ("C2", (50, 8), 150000, 1 << 14, "bgzf"), ("C4", (30, 10, 10), 60000, 1 << 12, "members")])
 def test_device_decode_equals_the_oracle_and_the_host_reader(oracle, tmp_path, config, lengths, n, capacity, zipped):
     """C5's fourth round is a `~` token: the files hold the reverse complement of its observation; `zipped`: every file a gzip
-    stream, inflated by a host thread per file into the pinned buffer the text is uploaded from"""
+    stream, inflated by a host thread per file into the pinned buffer the text is uploaded from; "bgzf" / "members": bgzip's
+    blocks (what the reference reads FASTQ through, fastq.h:427-440) and plain concatenated members of uneven sizes — inflated
+    member parallel, a batch ahead of the rounds (csrc/gzip_members.hpp), the first file only of the "members" case (the others
+    stay single streams: both kinds side by side in one run)"""
     spec = synthetic.config_spec(config, "pamld")
     spec["template"] = {"transform": {"token": ["0::"]}}
     content = []
     paths = _files(str(tmp_path), spec, n, 77, lengths, content)
     if zipped:
         import gzip
+        from test_capi_cpu import _bgzf
         for k, path in enumerate(paths):
-            with open(path, "rb") as plain, gzip.open(path + ".gz", "wb", compresslevel=1) as packed:
-                packed.write(plain.read())
+            data = open(path, "rb").read()
+            if zipped == "bgzf":
+                packed = _bgzf(data)
+            elif zipped == "members" and k == 0:
+                cuts = [0, 777, len(data) // 5, len(data) // 2, len(data) - 1, len(data)]                 # cut anywhere: mid record, mid line
+                packed = b"".join(gzip.compress(data[a:b], 1 + (a % 9)) for a, b in zip(cuts[:-1], cuts[1:]))
+            else:
+                packed = gzip.compress(data, 1)
+            open(path + ".gz", "wb").write(packed)
             paths[k] = path + ".gz"
         before = capi.device_path_counters()
     (device_words, device_incoming), (host_words, host_incoming) = _both(spec, paths, capacity)

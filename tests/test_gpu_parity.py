@@ -601,7 +601,9 @@ def test_paired_sets_that_are_not_combinatorial_stay_exact(oracle, torch_cuda):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
-@pytest.mark.parametrize("lengths,count,uniform", [((10, 10), 24, True), ((17,), 13, False), ((12, 12), 40, False), ((8, 8, 8, 8), 9, True), ((29,), 130, True)])
+@pytest.mark.parametrize("lengths,count,uniform", [((10, 10), 24, True), ((17,), 13, False), ((12, 12), 40, False), ((8, 8, 8, 8), 9, True), ((29,), 130, True),
+                                                   # round 5: pairs of 11 to 16 nt segments take the paired tier by the first 10 nt of each segment
+                                                   ((12, 12), 96, True), ((16, 16), 96, False), ((11, 14), 200, True), ((16, 16), 768, True)])
 def test_long_barcodes_take_the_two_word_product_form(oracle, torch_cuda, lengths, count, uniform):
     """ACGT barcodes of 17 to 32 nt that are not combinatorial (zip paired segments, long single words) go through
     pamld_wide.hpp in PHQ_MODE_FAST: every group count 5..8, barcode counts off the block of 8, priors uniform or
@@ -1133,7 +1135,10 @@ def test_single_index_sets_of_11_to_20_nt_under_mdd_take_the_paired_lookup_in_tw
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (8, 1024), (8, 1030), (12, 33),
-                                          (16, 256), (16, 260), (16, 512), (16, 515), (32, 5)])
+                                          (16, 256), (16, 260), (16, 512), (16, 515), (32, 5),
+                                          # round 5: past 512 packed words the product form stays the first tier (it was the literal
+                                          # kernel for every read): 768 / 1 536 / 4 096 barcodes, and the first size past the new limit
+                                          (8, 1536), (10, 768), (12, 1536), (16, 4096), (16, 4100), (20, 1536), (20, 2050)])
 def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     """The smallest and the largest codecs each kernel family takes, and the first sizes past them (which fall back
     to the next family): one barcode, one nucleotide, 1 024 barcodes of 8 nt in 512 packed words, 512 of 16 nt; 512 /
