@@ -9,9 +9,12 @@
 // One workgroup per CU keeps the pass filter half of every bin in LDS — 16 bytes per bin: count | distance in one
 // word, the confidence as 2^-44 fixed point in the other (at most 2^19 reads per workgroup, so neither can
 // overflow) — and flushes it once, bin after bin (contiguous words).  Reads that failed QC (a few %) are queued in
-// LDS and leave as dense global atomics whenever the queue is half full: sent directly, almost every wave would
-// issue four global atomic instructions for its one or two failed lanes, and those instructions (one memory side
-// request per lane whatever the lane count, ~50 ns each per CU) were three quarters of the kernel's time.
+// LDS, a queue per wave, and leave as dense global atomics — four lanes to an entry: its count, distance and the two limbs of
+// its confidence are 32 contiguous bytes of the counter buffer — whenever the next tile could overflow the queue: sent
+// directly, almost every wave would issue four global atomic instructions for its one or two failed lanes, and those
+// instructions (one memory side request per lane whatever the lane count, ~50 ns each per CU) were three quarters of the
+// kernel's time.  (The records a lane holds in flight do not matter: 2, 4 and 8 tiles measured the same, 0.37 ms for C3's
+// 1.6 GB of records = 4.3 TB/s.)
 // Rounding a confidence to 2^-44 moves a sum by < 3e-14 relative; sums stay independent of the order reads are
 // visited in.
 #include "kernel_common.hpp"
@@ -31,9 +34,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_results_kernel(StageArgs 
     const int n_bin = d.n_barcode + 1;
     unsigned long long* const queue_fixed = bins + 2 * n_bin;                               // [QUEUE] confidence, 2^-44 units
     uint32_t* const queue_key = reinterpret_cast<uint32_t*>(queue_fixed + QUEUE);           // [QUEUE] bin | distance << 16
-    uint32_t& queue_count = queue_key[QUEUE];
     for(int w = threadIdx.x; w < 2 * n_bin; w += COUNT_THREADS) { bins[w] = 0; }
-    if(threadIdx.x == 0) { queue_count = 0; }
     __syncthreads();
     auto send = [&](int bin, uint32_t distance, unsigned long long fixed) {                  // the QC fail half of a bin, in global memory
         unsigned long long* const words = args.stats + d.stats_offset + static_cast<int64_t>(bin) * STAT_WORDS_PER_BIN;
@@ -45,39 +46,17 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_results_kernel(StageArgs 
             atomicAdd(&words[FIELD_CONFIDENCE_HIGH], exact >> CONFIDENCE_LIMB_BITS);
         }
     };
-    // Every lane busy, and FOUR lanes to an entry — its count, distance and the two limbs of its confidence are 32 contiguous
-    // bytes of the counter buffer, inside one 64 byte line (bins are 96 bytes apart): a wave instruction then reaches 16 lines
-    // with four words each instead of 64 lines with one, and there is one instruction where there were four.  (The memory
-    // side takes an atomic a line at a time: the failed reads' atomics were 0.25 of this kernel's 0.66 ms on C3; with this
-    // 0.54 ms, and 0.95 -> 0.51 ms for a codec of 384 barcodes, whose low confidence reads are many more.)
-    auto drain = [&]() {
-        const uint32_t waiting = min(queue_count, static_cast<uint32_t>(QUEUE));
-        for(uint32_t at = threadIdx.x; at < 4u * waiting; at += COUNT_THREADS) {
-            const uint32_t e = at >> 2, field = at & 3u;
-            const uint32_t key = queue_key[e];
-            const unsigned long long exact = queue_fixed[e] << CONFIDENCE_SHIFT;
-            static_assert(FIELD_COUNT == 0 && FIELD_DISTANCE == 1 && FIELD_CONFIDENCE_LOW == 2 && FIELD_CONFIDENCE_HIGH == 3, "the four words of an entry, in the buffer's order");
-            const unsigned long long value = field == 0 ? 1ull : field == 1 ? static_cast<unsigned long long>(key >> 16)
-                                           : field == 2 ? (exact & ((1ull << CONFIDENCE_LIMB_BITS) - 1)) : (exact >> CONFIDENCE_LIMB_BITS);
-            if(value) { atomicAdd(&args.stats[d.stats_offset + static_cast<int64_t>(key & 0xffffu) * STAT_WORDS_PER_BIN + field], value); }
-        }
-    };
-
     const int64_t n = args.n_read;
     const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t first = per_block * blockIdx.x;
     const int64_t last = first + per_block < n ? first + per_block : n;
-#ifndef PHQ_COUNT_BARRIERS
     // Round 5: every WAVE a stream of its own — no workgroup barrier between the set up and the flush.  A wave takes tiles of
     // IN_FLIGHT x 64 records of the workgroup's range in turn (a load instruction = 1 KiB of consecutive records), asks for its
     // next tile before it counts the one it holds, and keeps the failed reads of its own lanes in its own queue (placed by a
     // ballot and a popcount: no atomic on a shared count), which it sends itself — four lanes to an entry — whenever the next
     // tile could overflow it.  (Until round 4 the workgroup shared one queue and settled it between barriers every fourth pass:
     // 16 waves waiting for the slowest four times per 16 Ki records; C3 0.53 ms, 3 TB/s for a pure stream of 16 byte records.)
-#ifndef PHQ_COUNT_IN_FLIGHT
-#define PHQ_COUNT_IN_FLIGHT 4
-#endif
-    constexpr int IN_FLIGHT = PHQ_COUNT_IN_FLIGHT;
+    constexpr int IN_FLIGHT = 4;
     constexpr int WAVES = COUNT_THREADS / 64;
     constexpr uint32_t WAVE_QUEUE = QUEUE / WAVES;                    // 48 entries a wave
     static_assert(WAVE_QUEUE * WAVES == QUEUE && WAVE_QUEUE >= 32, "the queue is dealt to the waves");
@@ -150,55 +129,6 @@ __global__ __launch_bounds__(COUNT_THREADS) void count_results_kernel(StageArgs 
         drain_wave();
     }
     __syncthreads();
-#else
-    auto count = [&](const DevResult& record) {
-        if(record.index <= 0) { return; }                // unclassified: bin 0 was counted by the stage kernel
-        const int bin = record.index;                    // identity numbering (count_results_supports)
-        const unsigned long long fixed = record.status == STATUS_PASS
-            ? static_cast<unsigned long long>(__double2ll_rn(record.confidence * 17592186044416.0)) : 0ull;      // 2^44
-        if(record.qcfail == 0) {
-            atomicAdd(&bins[2 * bin], 1ull | (static_cast<unsigned long long>(record.distance) << 32));
-            if(fixed) { atomicAdd(&bins[2 * bin + 1], fixed); }
-        } else {
-            const uint32_t slot = atomicAdd(&queue_count, 1u);
-            if(slot < static_cast<uint32_t>(QUEUE)) {
-                queue_key[slot] = static_cast<uint32_t>(bin) | (static_cast<uint32_t>(record.distance) << 16);
-                queue_fixed[slot] = fixed;
-            } else { send(bin, record.distance, fixed); }                                    // a full queue: straight to memory
-        }
-    };
-    // after every pass over IN_FLIGHT records per lane: a queue past half of its room is drained by the whole workgroup
-    auto settle = [&]() {
-        __syncthreads();
-        if(queue_count >= static_cast<uint32_t>(QUEUE / 2)) {
-            drain();
-            __syncthreads();
-            if(threadIdx.x == 0) { queue_count = 0; }
-        }
-        __syncthreads();
-    };
-    // The kernel is a stream of 16 byte records into LDS atomics: with one record per lane in flight its 16 waves keep
-    // 16 KiB of loads outstanding per CU and wait on HBM latency most of the time; four records per lane, loaded before
-    // any is counted, quadruple that.
-    constexpr int IN_FLIGHT = 4;
-    int pass = 0;
-    for(int64_t base = first; base < last; base += IN_FLIGHT * COUNT_THREADS, ++pass) {     // the same trips for every lane: settle() has barriers
-        DevResult record[IN_FLIGHT];
-        bool present[IN_FLIGHT];
-#pragma unroll
-        for(int k = 0; k < IN_FLIGHT; ++k) {
-            const int64_t i = base + k * COUNT_THREADS + threadIdx.x;
-            present[k] = i < last;
-            if(present[k]) { record[k] = args.result[i]; }
-        }
-#pragma unroll
-        for(int k = 0; k < IN_FLIGHT; ++k) { if(present[k]) { count(record[k]); } }
-        if((pass & 3) == 3) { settle(); }      // every fourth pass: the waves run ahead of each other in between (a full queue sends directly)
-    }
-    __syncthreads();
-    drain();
-    __syncthreads();
-#endif
     // The bins leave as DENSE atomics into the staging array: 64 consecutive words per wave instruction.  Added straight
     // into the counter buffer (96 bytes from bin to bin) every lane's request went to a row of its own — memory side
     // atomics run 17 times slower that way — and every workgroup sends every bin: that flush was most of the kernel.
