@@ -863,6 +863,25 @@ void DecoderSet::build_device_images() {
                                 }
                             }
                         }
+                        // ... and, round 5, the word TWO mismatches away where no word is nearer and no other word as near (the kernel scores
+                        // every word of the segment whichever one is named: a read two low quality calls off its word — 3 % of H94's
+                        // reads — was handed on for the name alone)
+                        for(int32_t u = 0; u < ns; ++u) {
+                            const uint32_t wl = words[s][static_cast<size_t>(u)].first, wh = words[s][static_cast<size_t>(u)].second;
+                            for(int32_t j = 0; j < length; ++j) {
+                                for(int32_t i = j + 1; i < length; ++i) {
+                                    for(uint32_t pair_of = 0; pair_of < 16; ++pair_of) {
+                                        const uint32_t first = pair_of & 3u, second = pair_of >> 2;
+                                        const uint32_t l2 = (wl & ~((1u << j) | (1u << i))) | ((first & 1u) << j) | ((second & 1u) << i);
+                                        const uint32_t h2 = (wh & ~((1u << j) | (1u << i))) | ((first >> 1) << j) | ((second >> 1) << i);
+                                        if(!((((l2 ^ wl) | (h2 ^ wh)) >> j) & 1u) || !((((l2 ^ wl) | (h2 ^ wh)) >> i) & 1u)) { continue; }       // both positions differ
+                                        const size_t at = l2 | (h2 << length);
+                                        if(reached[at] == 2) { table[at] = static_cast<uint8_t>(u); reached[at] = 4; }
+                                        else if(reached[at] == 4 && table[at] != static_cast<uint8_t>(u)) { table[at] = static_cast<uint8_t>(0xffu); reached[at] = 5; }
+                                    }
+                                }
+                            }
+                        }
                         d.plate_table[s] = static_cast<const uint8_t*>(upload(table.data(), table.size()));
                         d.plate_unique[s] = ns;
                         d.plate_start[s] = c.segment_offset[static_cast<size_t>(s)];

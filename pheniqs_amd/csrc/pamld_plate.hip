@@ -9,7 +9,7 @@
 // (pamld_pair.hpp wants them all different), too few words a segment for neighbour lists — they ran through the product form
 // over all barcodes (8.2 ms per 100 M reads).  With 16 words a segment nothing has to be bounded: EVERY word of both
 // segments is scored, per read, through the per read tables of pamld_stream.hpp:
-//   * a lookup per segment (4^length entries of one byte, the word at most one mismatch away) names c = (c0, c1); a word's
+//   * a lookup per segment (4^length entries of one byte, the word at most two mismatches away) names c = (c0, c1); a word's
 //     block in LDS lists its plane words first and then every other word of its segment, so the winner is slot 0 and the
 //     others slots 1..15, with no select;
 //   * P(r|b) factorises over the segments.  In units of the winner, the barcodes that share c1 weigh
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
         const Pair info = *(LdsPairs)static_cast<uintptr_t>(infos_at + combination * (INFO_WORDS * 4u));
         const uint32_t bin = __float_as_uint(info.x);
         const uint32_t index = __float_as_uint(info.y);
-        const bool finished = all_strict && known && bin != 0 && k0 <= 1 && k1 <= 1 && winner_probability > noise_floor && listed <= near::LISTED_MAX &&
+        const bool finished = all_strict && known && bin != 0 && k0 <= 2 && k1 <= 2 && winner_probability > noise_floor && listed <= near::LISTED_MAX &&
                               x_low + x_rest <= near::X_MAX && x_rest <= near::REST_MAX && fabs(confidence_margin) > 2e-8;
         const bool defer = !finished;
 
