@@ -162,8 +162,9 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             return (t | (t >> 14)) & 0xffu;
         };
         uint32_t q7[G];
+        uint32_t row_of[G];                              // per position the row of its factor pair: its quality, 128 for a base outside ACGT, 0 at quality 0
         uint32_t low = 0, high = 0, high_quality = 0;    // bit j = position j
-        uint32_t not_strict = 0;
+        uint32_t outside = 0;                            // bit j: the base is none of A, C, G, T
 #pragma unroll
         for(int w = 0; w < G; ++w) {
             const uint32_t x = code[w] & (0x0f0f0f0fu & valid[w]);
@@ -171,7 +172,15 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             // A, C, G or T = exactly one bit of the nibble (iupac.h:51-56)
             const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
             const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
-            not_strict |= strict ^ (0x80808080u & valid[w]);
+            // Round 5: a base outside ACGT no longer sends the read on.  Against every barcode base it costs the uniform quality
+            // (row 128: match and mismatch weigh the same; nothing at quality 0: row 0) whatever the lookup makes of its bits
+            // (phred.cpp:62-64), it counts as a mismatch (barcode.h:147-161), and as one of the read's OWN mismatches it is outside
+            // what the bound charges: another barcode differs from c there for free, which is what `n = r(c) - k` says with k
+            // counting it.  1.6 % of a 16 nt index's reads hold an N; they were the product form's for that alone.
+            const uint32_t strict_bytes = (strict - (strict >> 7)) | strict;                       // 0xff where A, C, G or T
+            const uint32_t nonzero = (q7[w] + 0x7f7f7f7fu) & 0x80808080u;
+            row_of[w] = (q7[w] & strict_bytes) | (nonzero & ~strict_bytes & valid[w]);
+            outside |= (gather((~strict & 0x80808080u & valid[w]) >> 7) & 0xfu) << (4 * w);
             // 2-bit codes: the low code bit is bit 1 | bit 3 of the nibble, the high one bit 2 | bit 3
             const uint32_t both = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
             low |= (both & 0xfu) << (4 * w);
@@ -180,7 +189,6 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             const uint32_t is_high = ((q7[w] + high_quality_addend) | quality[w]) & (0x80808080u & valid[w]);
             high_quality |= (gather(is_high >> 7) & 0xfu) << (4 * w);
         }
-        const bool all_strict = not_strict == 0;
         uint32_t either = n_barcode;                   // first look: the barcode one part names when the two do not agree
         if(!SECOND) {
             const uint32_t key0 = ((low >> start0) & mask0) | (((high >> start0) & mask0) << length0);
@@ -211,13 +219,13 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             const Quad list_low = lists[4u * c], list_high = lists[4u * c + 1u], beyond_list = lists[4u * c + 2u], ratios = lists[4u * c + 3u];
 #pragma unroll
             for(int o = 0; o < LISTED; ++o) {
-                listed_flags[o] = ((low ^ list_low[o]) | (high ^ list_high[o])) & full_mask;
+                listed_flags[o] = (((low ^ list_low[o]) | (high ^ list_high[o])) & full_mask) | outside;
                 listed_ratio[o] = __uint_as_float(ratios[o]);
             }
             radius = beyond_list.x;
             others_at_radius = __uint_as_float(beyond_list.y); others_next = __uint_as_float(beyond_list.z); others_beyond = __uint_as_float(beyond_list.w);
         }
-        const uint32_t mismatches = ((low ^ record.x) | (high ^ record.y)) & full_mask;
+        const uint32_t mismatches = (((low ^ record.x) | (high ^ record.y)) & full_mask) | outside;
         const int k = __popc(mismatches);
         // The positions by quality, for the bound — WITHOUT the read's own mismatches (round 5).  Another barcode differs from c in
         // r(c) or more positions, at most k of them the read's own: it mismatches the read in n = r(c) - k or more positions
@@ -243,9 +251,9 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         float listed_product[LISTED];
 #pragma unroll
         for(int j = 0; j < 4 * G; ++j) {
-            const uint32_t q = q7[j >> 2];
+            const uint32_t q = row_of[j >> 2];
             const int byte = j & 3;
-            const uint32_t row = and_or(byte == 0 ? (q << 3) : (q >> (8 * byte - 3)), 0x3f8u, static_cast<uint32_t>(Layout::FACTOR_AT));
+            const uint32_t row = and_or(byte == 0 ? (q << 3) : (q >> (8 * byte - 3)), 0x7f8u, static_cast<uint32_t>(Layout::FACTOR_AT));
             const uint32_t picked = and_or(j >= 2 ? (mismatches >> (j - 2)) : (mismatches << (2 - j)), 4u, row);
             const float matching = *(LdsFloats)static_cast<uintptr_t>(row);
             const float own = *(LdsFloats)static_cast<uintptr_t>(picked);
@@ -272,10 +280,10 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
             }
             return log2_bound + LOG2_RHO[MARKS - 1] * static_cast<float>(needed);
         };
-        const int outside = static_cast<int>(radius) - k;
+        const int beyond_own = static_cast<int>(radius) - k;
         const float inverse_winner = __builtin_amdgcn_rcpf(winner);
-        const float x_rest = (others_at_radius * __builtin_amdgcn_exp2f(log2_bound_of(outside)) + others_next * __builtin_amdgcn_exp2f(log2_bound_of(outside + 1)) +
-                              others_beyond * __builtin_amdgcn_exp2f(log2_bound_of(outside + 2))) * everything_matches * inverse_winner * SLOP;
+        const float x_rest = (others_at_radius * __builtin_amdgcn_exp2f(log2_bound_of(beyond_own)) + others_next * __builtin_amdgcn_exp2f(log2_bound_of(beyond_own + 1)) +
+                              others_beyond * __builtin_amdgcn_exp2f(log2_bound_of(beyond_own + 2))) * everything_matches * inverse_winner * SLOP;
         // second look: what the listed barcodes weigh, in units of the winner (a slot past the set's barcodes has ratio 0)
         float x_listed = 0.0f;
         if(SECOND) {
@@ -293,9 +301,9 @@ __global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
         Look out;
         out.confidence = 1.0 - static_cast<double>(y);                     // pamld.cpp:92
         const double confidence_margin = out.confidence - confidence_threshold;
-        out.candidate = all_strict && known && k <= MOST_MISMATCHES && winner > noise_floor;
+        out.candidate = known && k <= MOST_MISMATCHES && winner > noise_floor;
         out.finished = out.candidate && x_low + x_rest <= X_MAX && x_rest <= REST_MAX && x_listed <= X_MAX && fabs(confidence_margin) > 2e-8;
-        out.retry = !SECOND && all_strict && !known && either < n_barcode;
+        out.retry = !SECOND && !known && either < n_barcode;
         out.c = out.retry ? either : c;
         out.k = static_cast<uint32_t>(k);
         out.index = record.w;                                              // barcode_index[c]
