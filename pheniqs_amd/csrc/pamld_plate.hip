@@ -142,18 +142,25 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
         };
         uint32_t q7[G];
         uint32_t low = 0, high = 0, high_quality = 0;    // bit j = position j of the row
+        uint32_t outside = 0;                            // bit j: the base is none of A, C, G, T
         uint32_t not_strict = 0;
 #pragma unroll
         for(int w = 0; w < G; ++w) {
             const uint32_t x = in.code[w] & (0x0f0f0f0fu & valid[w]);
-            q7[w] = in.quality[w] & (0x7f7f7f7fu & valid[w]);
+            const uint32_t quality7 = in.quality[w] & (0x7f7f7f7fu & valid[w]);
             const uint32_t z = x & ((x | 0x80808080u) - 0x01010101u);
             const uint32_t strict = (x + 0x7f7f7f7fu) & ~(z + 0x7f7f7f7fu) & 0x80808080u;
-            not_strict |= (strict ^ (0x80808080u & valid[w])) | (in.quality[w] & 0x80808080u & valid[w]);      // outside ACGT, or a quality past 127
+            not_strict |= in.quality[w] & 0x80808080u & valid[w];      // a quality past 127
+            // Round 5: a base outside ACGT stays in the kernel (pamld_pair.hpp): its factor row is 128 — match and mismatch weigh the
+            // same against every word, so it moves no word against another — or 0 at quality 0; it counts as a mismatch of the winner
+            const uint32_t strict_bytes = (strict - (strict >> 7)) | strict;
+            const uint32_t nonzero = (quality7 + 0x7f7f7f7fu) & 0x80808080u;
+            q7[w] = (quality7 & strict_bytes) | (nonzero & ~strict_bytes & valid[w]);               // the factor ROW of each position
+            outside |= (gather((~strict & 0x80808080u & valid[w]) >> 7) & 0xfu) << (4 * w);
             const uint32_t both = gather((((x >> 1) | (x >> 3)) & 0x01010101u) | (((x << 2) | (x << 1)) & 0x10101010u));
             low |= (both & 0xfu) << (4 * w);
             high |= (both >> 4) << (4 * w);
-            const uint32_t is_high = ((q7[w] + high_quality_addend) | in.quality[w]) & (0x80808080u & valid[w]);
+            const uint32_t is_high = ((quality7 + high_quality_addend) | in.quality[w]) & (0x80808080u & valid[w]);
             high_quality |= (gather(is_high >> 7) & 0xfu) << (4 * w);
         }
         const bool all_strict = not_strict == 0;
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
                 const uint32_t word = quality_word[j >> 2];
                 const int byte = j & 3;
                 const uint32_t shifted = byte == 0 ? (word << 3) : (word >> (8 * byte - 3));
-                const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x3f8u, FACTOR_AT));       // row 0 (a position past the segment): {1, 1}
+                const Pair pair = *(LdsPairs)static_cast<uintptr_t>(and_or(shifted, 0x7f8u, FACTOR_AT));       // row 0 (a position past the segment): {1, 1}; row 128: a base outside ACGT
                 everything_matches = j == 0 ? pair.x : everything_matches * pair.x;
                 rho[j] = static_cast<uint32_t>(j) < length[s] ? pair.y : 1.0f;
             }
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
             plain_of[s] = plain;
             weighted_of[s] = weighted;
             matches_of[s] = everything_matches;
-            mismatches_of[s] = mismatches;
+            mismatches_of[s] = mismatches | ((outside >> start[s]) & ((1u << length[s]) - 1u));       // a base outside ACGT mismatches every word (barcode.h:147-161)
         }
         const float inverse0 = __builtin_amdgcn_rcpf(winner_of[0]), inverse1 = __builtin_amdgcn_rcpf(winner_of[1]);
         const float winner_probability = (winner_of[0] * matches_of[0]) * (winner_of[1] * matches_of[1]);      // P(r|c)
