@@ -103,6 +103,13 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
     constexpr bool PAIRED = L <= 8;           // two barcodes per 32-bit word of 2-bit codes
     constexpr int PER_WORD = PAIRED ? 2 : 1;
     static_assert(L <= 16, "2-bit codes of one barcode fit one word");
+    // Round 5: past 8 nt the tables are scaled by 2^(96 / G) a group, every barcode's probability by 2^96: nine Q37 mismatches of
+    // a 16 nt barcode are 5e-34 — under SMALLEST_CERTAIN, and a noise read (whose argmax is all that matters) sits that far from
+    // every barcode: the floats had lost its winner and the exact tier took it (H94: 2.3 % of all reads).  Scaled back in fp64.
+    constexpr int GROUP_SCALE_LOG2 = G >= 3 ? 96 / G : 0;
+    constexpr float GROUP_SCALE = static_cast<float>(1ull << GROUP_SCALE_LOG2);
+    constexpr double PRODUCT_UNSCALE = G >= 3 ? 1.0 / (static_cast<double>(1ull << 48) * static_cast<double>(1ull << 48)) : 1.0;
+    static_assert(G < 3 || GROUP_SCALE_LOG2 * G == 96, "2^96 a product");
     typedef LutGeometry<L> Layout;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
@@ -310,8 +317,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 lo[2] = lo[0];
                 lo[3] = lo[1];
                 if(base + 1 < L) { lo[0] *= fm[base + 1]; lo[1] *= fm[base + 1]; lo[2] *= fe[base + 1]; lo[3] *= fe[base + 1]; }
-                hi[0] = hi[1] = hi[2] = hi[3] = 1.0f;
-                if(base + 2 < L) { hi[0] = fm[base + 2]; hi[1] = fe[base + 2]; hi[2] = hi[0]; hi[3] = hi[1]; }
+                hi[0] = hi[1] = hi[2] = hi[3] = GROUP_SCALE;       // (1 up to 8 nt; round 5: 2^(96 / G) for 9 to 16 nt, see GROUP_SCALE)
+                if(base + 2 < L) { hi[0] = fm[base + 2] * GROUP_SCALE; hi[1] = fe[base + 2] * GROUP_SCALE; hi[2] = hi[0]; hi[3] = hi[1]; }
                 if(base + 3 < L) { hi[0] *= fm[base + 3]; hi[1] *= fm[base + 3]; hi[2] *= fe[base + 3]; hi[3] *= fe[base + 3]; }
 #pragma unroll
                 for(int m = 0; m < 16; ++m) {
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 const double prior_of_best = UNIFORM_PRIOR ? common_prior : d.concentration[best];
                 const double best_p = best_conditional * prior_of_best;
                 // everything but the winner, in units of p: only ever compared against and added to much larger terms
-                const double others = UNIFORM_PRIOR ? static_cast<double>(sigma) * prior_of_best : static_cast<double>(sigma);
+                const double others = (UNIFORM_PRIOR ? static_cast<double>(sigma) * prior_of_best : static_cast<double>(sigma)) * PRODUCT_UNSCALE;
                 const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
                 double confidence = best_p / total;                                       // pamld.cpp:92
                 const double noise_margin = best_conditional - d.random_barcode_probability;

@@ -79,6 +79,15 @@ __global__ __launch_bounds__((Geometry<G, NARROW>::THREADS)) void pamld_wide_ker
     constexpr bool PERMUTED = THREADS == 128;
     constexpr int WORDS = (G + 3) / 4;        // words of 16 positions: 2
     static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
+    // Round 5: the tables are scaled by 2^(96 / G) a group, every barcode's probability by 2^(G (96 / G)): twelve Q37 mismatches
+    // of a 20 nt barcode are 4e-45, under a float's normal range — and a noise read, whose argmax is all that matters (it is
+    // charged to it and leaves unclassified, pamld.cpp:96,113-119), sits that far from every barcode: every one of them went to
+    // the exact tier for a winner the floats had lost (C4's paired decoder: its exact tier 0.27 ms per 50 M reads for the 1 % of
+    // noise reads).  The sums are scaled back in fp64 where they meet the winner's own product.
+    constexpr int GROUP_SCALE_LOG2 = 96 / G;
+    constexpr float GROUP_SCALE = static_cast<float>(1ull << (GROUP_SCALE_LOG2 > 62 ? 62 : GROUP_SCALE_LOG2));
+    static_assert(GROUP_SCALE_LOG2 <= 62, "one shift");
+    constexpr double PRODUCT_UNSCALE = 1.0 / (static_cast<double>(1ull << (GROUP_SCALE_LOG2 * G / 2)) * static_cast<double>(1ull << (GROUP_SCALE_LOG2 * G - GROUP_SCALE_LOG2 * G / 2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
     DecoderRef d = *constant_cast(args.decoder);
@@ -181,10 +190,11 @@ __global__ __launch_bounds__((Geometry<G, NARROW>::THREADS)) void pamld_wide_ker
                 lo[1] = fe[base] * fm[base + 1];
                 lo[2] = fm[base] * fe[base + 1];
                 lo[3] = fe[base] * fe[base + 1];
-                hi[0] = fm[base + 2] * fm[base + 3];
-                hi[1] = fe[base + 2] * fm[base + 3];
-                hi[2] = fm[base + 2] * fe[base + 3];
-                hi[3] = fe[base + 2] * fe[base + 3];
+                // (round 5: every group's entries scaled by 2^(96 / G) — see GROUP_SCALE — four multiplications a group)
+                hi[0] = (fm[base + 2] * GROUP_SCALE) * fm[base + 3];
+                hi[1] = (fe[base + 2] * GROUP_SCALE) * fm[base + 3];
+                hi[2] = (fm[base + 2] * GROUP_SCALE) * fe[base + 3];
+                hi[3] = (fe[base + 2] * GROUP_SCALE) * fe[base + 3];
 #pragma unroll
                 for(int m = 0; m < 16; ++m) {
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(table) + g * GROUP_STEP + m * ENTRY_STEP + lane_offset) = lo[m & 3] * hi[m >> 2];
@@ -305,7 +315,7 @@ __global__ __launch_bounds__((Geometry<G, NARROW>::THREADS)) void pamld_wide_ker
                     best_conditional *= factor_pairs[2 * k + ((best_flags[j >> 4] >> low_bit(j)) & 1u)];
                 }
                 const double best_p = best_conditional * d.concentration[best];
-                const double others = uniform_prior ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma);
+                const double others = (uniform_prior ? static_cast<double>(sigma) * d.concentration[best] : static_cast<double>(sigma)) * PRODUCT_UNSCALE;
                 const double total = (best_p + others) + d.adjusted_noise_probability;   // pamld.cpp:61-86
                 double confidence = best_p / total;                                       // pamld.cpp:92
                 const double noise_margin = best_conditional - d.random_barcode_probability;
