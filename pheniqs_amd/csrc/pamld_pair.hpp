@@ -85,8 +85,11 @@ typedef __attribute__((address_space(3))) const Quad* LdsQuads;
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, mask, c, 0xEA); }
 
 // G = words of the plane row (4 positions each); STATE as in pamld_near.hpp; LISTS: the second look on the wave's ring
+#ifndef PHQ_PAIR_WAVES
+#define PHQ_PAIR_WAVES 5
+#endif
 template <int G, int STATE, bool LISTS>
-__global__ __launch_bounds__(THREADS) void pamld_pair_kernel(StageArgs args) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(LISTS ? PHQ_PAIR_WAVES : 7, 8))) void pamld_pair_kernel(StageArgs args) {
     typedef LayoutOf<G, LISTS> Layout;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     if(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)lds_raw) != 0) { __builtin_trap(); }
