@@ -181,8 +181,10 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
         Four ratio[2][SLOTS / 4];              // [0]: the row (segment 1's slots), [1]: the column (segment 0's slots)
 #pragma unroll
         for(int quad = 0; quad < SLOTS / 4; ++quad) {
-            ratio[0][quad] = *(LdsFours)static_cast<uintptr_t>(ratios_at + combination * (RATIO_WORDS * 4u) + 16u * quad);
-            ratio[1][quad] = *(LdsFours)static_cast<uintptr_t>(ratios_at + combination * (RATIO_WORDS * 4u) + 64u + 16u * quad);
+            // (round 5: only the quads that hold words — the row runs over segment 1's slots, the column over segment 0's; the same for
+            // every lane — 5 quads instead of 8 for a 12 x 8 plate: the kernel 2.75 -> 2.59 ms; the `holds` quads read the same way: no change)
+            if(quad == 0 || quad < quads[1]) { ratio[0][quad] = *(LdsFours)static_cast<uintptr_t>(ratios_at + combination * (RATIO_WORDS * 4u) + 16u * quad); }
+            if(quad == 0 || quad < quads[0]) { ratio[1][quad] = *(LdsFours)static_cast<uintptr_t>(ratios_at + combination * (RATIO_WORDS * 4u) + 64u + 16u * quad); }
         }
         float winner_of[2], plain_of[2], weighted_of[2], matches_of[2];
         uint32_t mismatches_of[2];
