@@ -35,6 +35,7 @@ int main(int argc, char** argv) {
         const std::vector<uint8_t> expected((std::istreambuf_iterator<char>(expected_file)), std::istreambuf_iterator<char>());
         if(expected != text) { std::printf("text differs: %zu bytes, expected %zu\n", text.size(), expected.size()); return 5; }
     }
-    std::printf("members %zu blocked %d bytes %zu crc %lu\n", inflater.members(), inflater.blocked() ? 1 : 0, text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())));
+    std::printf("members %zu blocked %d bytes %zu crc %lu fast %llu zlib %llu\n", inflater.members(), inflater.blocked() ? 1 : 0, text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())),
+                static_cast<unsigned long long>(phq::MemberInflater::fast_members().load()), static_cast<unsigned long long>(phq::MemberInflater::zlib_members().load()));
     return 0;
 }
