@@ -19,6 +19,7 @@
 #include <cstring>
 #include <deque>
 #include <future>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -75,21 +76,22 @@ public:
     size_t read(uint8_t* to, size_t want) {
         size_t done = 0;
         while(done < want) {
-            if(ready_at_ == ready_.size()) {
+            if(ready_at_ == ready_.size) {
+                if(ready_.data) { spare_.push_back(std::move(ready_)); ready_ = Batch(); }      // its pages are warm: the next batch takes them
+                ready_at_ = 0;
                 if(pending_.empty()) { break; }
                 ready_ = pending_.front().get();                  // a worker's IOError crosses here
                 pending_.pop_front();
-                ready_at_ = 0;
                 start_batches();
-                if(ready_.empty()) { continue; }
+                if(ready_.size == 0) { continue; }
             }
-            const size_t take = std::min(want - done, ready_.size() - ready_at_);
+            const size_t take = std::min(want - done, ready_.size - ready_at_);
             if(take >= (size_t(8) << 20)) {
                 parallel_ranges(static_cast<int64_t>((take + (1 << 20) - 1) >> 20), 1, threads_, [&](int64_t first, int64_t last, int) {
                     const size_t from = static_cast<size_t>(first) << 20, until = std::min(take, static_cast<size_t>(last) << 20);
-                    std::memcpy(to + done + from, ready_.data() + ready_at_ + from, until - from);
+                    std::memcpy(to + done + from, ready_.data.get() + ready_at_ + from, until - from);
                 });
-            } else { std::memcpy(to + done, ready_.data() + ready_at_, take); }
+            } else { std::memcpy(to + done, ready_.data.get() + ready_at_, take); }
             done += take;
             ready_at_ += take;
         }
@@ -200,18 +202,31 @@ private:
         size_t text = 0;
         while(next_ < member_.size() && (text < (size_t(64) << 20) || next_ - first < static_cast<size_t>(2 * threads_)) && text < (size_t(768) << 20)) { text += member_[next_++].text; }
         const size_t last = next_;
-        pending_.push_back(std::async(std::launch::async, [this, first, last, text]() {
-            std::vector<uint8_t> out(text);
+        // a buffer that has been through the reader before, where one is large enough: fresh pages cost a fault each and a
+        // batch is tens of thousands of them
+        Batch batch;
+        for(size_t k = 0; k < spare_.size(); ++k) {
+            if(spare_[k].capacity >= text) { batch = std::move(spare_[k]); spare_.erase(spare_.begin() + static_cast<std::ptrdiff_t>(k)); break; }
+        }
+        if(!batch.data) {
+            spare_.clear();
+            batch.capacity = std::max(text, size_t(96) << 20);
+            batch.data.reset(new uint8_t[batch.capacity]);
+        }
+        batch.size = text;
+        uint8_t* const out_data = batch.data.get();
+        auto shared = std::make_shared<Batch>(std::move(batch));
+        pending_.push_back(std::async(std::launch::async, [this, first, last, shared, out_data]() {
             std::vector<size_t> place(last - first);
             size_t at = 0;
             for(size_t k = first; k < last; ++k) { place[k - first] = at; at += member_[k].text; }
             std::atomic<size_t> turn{first};
             parallel_ranges(threads_, 1, threads_, [&](int64_t, int64_t, int) {
                 for(size_t k = turn.fetch_add(1); k < last; k = turn.fetch_add(1)) {
-                    inflate_member(map_ + member_[k].begin, member_[k].end - member_[k].begin, out.data() + place[k - first], member_[k].text);
+                    inflate_member(map_ + member_[k].begin, member_[k].end - member_[k].begin, out_data + place[k - first], member_[k].text);
                 }
             });
-            return out;
+            return std::move(*shared);
         }));
     }
 
@@ -221,10 +236,12 @@ private:
     bool blocked_ = false;
     std::vector<Member> member_;
     size_t next_ = 0;
-    std::vector<uint8_t> ready_;
+    struct Batch { std::unique_ptr<uint8_t[]> data; size_t capacity = 0, size = 0; };
+    Batch ready_;
     size_t ready_at_ = 0;
+    std::vector<Batch> spare_;
     static constexpr size_t AHEAD = 2;
-    std::deque<std::future<std::vector<uint8_t>>> pending_;
+    std::deque<std::future<Batch>> pending_;
 };
 
 }  // namespace phq
