@@ -1,6 +1,6 @@
 // A gzip input of SEVERAL members — BGZF blocks (bgzip, htslib: what the reference reads FASTQ through, fastq.h:427-440 with its
 // thread pool, transcode.cpp:1599-1605) or plain concatenated members (what this library writes: one member per batch part) —
-// inflated member parallel on the host's threads, a batch of members AHEAD of the reader.
+// inflated member parallel on the host's threads, straight into the reader's buffer.
 //
 // zlib inflates ~0.3 GB/s of FASTQ text a thread and a gzip stream is sequential inside a member, so a single member file
 // stays one gzread thread (the caller's old path: open() says no); members are independent deflate streams, each with its own
@@ -41,7 +41,6 @@ public:
     MemberInflater(const MemberInflater&) = delete;
     MemberInflater& operator=(const MemberInflater&) = delete;
     ~MemberInflater() {
-        for(auto& batch : pending_) { try { batch.get(); } catch(...) {} }
         if(map_ != nullptr) { ::munmap(const_cast<uint8_t*>(map_), size_); }
     }
 
@@ -65,7 +64,6 @@ public:
             member_.clear();
             return false;
         }
-        start_batches();
         return true;
     }
 
@@ -73,31 +71,60 @@ public:
     size_t members() const { return member_.size(); }
 
     // up to `want` bytes of the text, in order; 0: the end.  Throws IOError for a member that does not inflate to what it states.
+    // The members that fit `to` whole are inflated STRAIGHT INTO IT, side by side on every thread (their places in the text are
+    // known from their trailers before anything is inflated); the one member that straddles the end of `to` goes to a buffer of
+    // its own and is handed out in two pieces.  (A first version inflated batches ahead into buffers of their own and copied them
+    // out: the copy — 190 MB a round of 1 M reads, through the same memory system the inflating threads use — and the fresh
+    // pages of every batch were as much of a BGZF run as inflating itself: 19.5 -> 28 Mreads/s with the buffers reused, the rest
+    // with the copy gone.)
     size_t read(uint8_t* to, size_t want) {
         size_t done = 0;
-        while(done < want) {
-            if(ready_at_ == ready_.size) {
-                if(ready_.data) { spare_.push_back(std::move(ready_)); ready_ = Batch(); }      // its pages are warm: the next batch takes them
-                ready_at_ = 0;
-                if(pending_.empty()) { break; }
-                ready_ = pending_.front().get();                  // a worker's IOError crosses here
-                pending_.pop_front();
-                start_batches();
-                if(ready_.size == 0) { continue; }
-            }
-            const size_t take = std::min(want - done, ready_.size - ready_at_);
-            if(take >= (size_t(8) << 20)) {
-                parallel_ranges(static_cast<int64_t>((take + (1 << 20) - 1) >> 20), 1, threads_, [&](int64_t first, int64_t last, int) {
-                    const size_t from = static_cast<size_t>(first) << 20, until = std::min(take, static_cast<size_t>(last) << 20);
-                    std::memcpy(to + done + from, ready_.data.get() + ready_at_ + from, until - from);
-                });
-            } else { std::memcpy(to + done, ready_.data.get() + ready_at_, take); }
+        auto from_carry = [&]() {
+            const size_t take = std::min(want - done, carry_size_ - carry_at_);
+            std::memcpy(to + done, carry_.get() + carry_at_, take);
             done += take;
-            ready_at_ += take;
+            carry_at_ += take;
+        };
+        if(carry_at_ < carry_size_) { from_carry(); }
+        while(done < want && next_ < member_.size()) {
+            // the run of whole members that fits
+            const size_t first = next_;
+            size_t text = 0;
+            while(next_ < member_.size() && text + member_[next_].text <= want - done) { text += member_[next_++].text; }
+            if(next_ > first) {
+                const size_t last = next_;
+                uint8_t* const out = to + done;
+                if(last - first == 1) {
+                    inflate_member(map_ + member_[first].begin, member_[first].end - member_[first].begin, out, member_[first].text);
+                } else {
+                    std::vector<size_t> place(last - first);
+                    size_t at = 0;
+                    for(size_t k = first; k < last; ++k) { place[k - first] = at; at += member_[k].text; }
+                    std::atomic<size_t> turn{first};
+                    const int workers = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads_), (last - first + 3) / 4));
+                    parallel_ranges(workers, 1, workers, [&](int64_t, int64_t, int) {
+                        for(size_t k = turn.fetch_add(4); k < last; k = turn.fetch_add(4)) {               // four members a turn
+                            for(size_t m = k; m < std::min(k + 4, last); ++m) {
+                                inflate_member(map_ + member_[m].begin, member_[m].end - member_[m].begin, out + place[m - first], member_[m].text);
+                            }
+                        }
+                    });
+                }
+                done += text;
+                continue;
+            }
+            // the next member is larger than what is left of `to`: through the carry buffer
+            const Member& member = member_[next_++];
+            if(carry_capacity_ < member.text) { carry_.reset(new uint8_t[member.text]); carry_capacity_ = member.text; }
+            inflate_member(map_ + member.begin, member.end - member.begin, carry_.get(), member.text);
+            carry_size_ = member.text;
+            carry_at_ = 0;
+            from_carry();
         }
         return done;
     }
 
+private:
     struct Member { size_t begin, end, text; };
 
     static uint32_t le32(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); }
@@ -192,56 +219,14 @@ private:
         if(status != Z_STREAM_END || in_at != bytes || out_at != text) { throw IOError("a gzip member does not inflate to the size its trailer states"); }
     }
 
-    // AHEAD batches in flight: the reader copies one out while the next ones inflate — also while the rounds' kernels run
-    void start_batches() { while(pending_.size() < AHEAD && next_ < member_.size()) { start_batch(); } }
-
-    // the next batch — enough members for every thread and at least 64 MiB of text — inflated on threads of its own
-    void start_batch() {
-        if(next_ >= member_.size()) { return; }
-        const size_t first = next_;
-        size_t text = 0;
-        while(next_ < member_.size() && (text < (size_t(64) << 20) || next_ - first < static_cast<size_t>(2 * threads_)) && text < (size_t(768) << 20)) { text += member_[next_++].text; }
-        const size_t last = next_;
-        // a buffer that has been through the reader before, where one is large enough: fresh pages cost a fault each and a
-        // batch is tens of thousands of them
-        Batch batch;
-        for(size_t k = 0; k < spare_.size(); ++k) {
-            if(spare_[k].capacity >= text) { batch = std::move(spare_[k]); spare_.erase(spare_.begin() + static_cast<std::ptrdiff_t>(k)); break; }
-        }
-        if(!batch.data) {
-            spare_.clear();
-            batch.capacity = std::max(text, size_t(96) << 20);
-            batch.data.reset(new uint8_t[batch.capacity]);
-        }
-        batch.size = text;
-        uint8_t* const out_data = batch.data.get();
-        auto shared = std::make_shared<Batch>(std::move(batch));
-        pending_.push_back(std::async(std::launch::async, [this, first, last, shared, out_data]() {
-            std::vector<size_t> place(last - first);
-            size_t at = 0;
-            for(size_t k = first; k < last; ++k) { place[k - first] = at; at += member_[k].text; }
-            std::atomic<size_t> turn{first};
-            parallel_ranges(threads_, 1, threads_, [&](int64_t, int64_t, int) {
-                for(size_t k = turn.fetch_add(1); k < last; k = turn.fetch_add(1)) {
-                    inflate_member(map_ + member_[k].begin, member_[k].end - member_[k].begin, out_data + place[k - first], member_[k].text);
-                }
-            });
-            return std::move(*shared);
-        }));
-    }
-
     const uint8_t* map_ = nullptr;
     size_t size_ = 0;
     int threads_ = 1;
     bool blocked_ = false;
     std::vector<Member> member_;
     size_t next_ = 0;
-    struct Batch { std::unique_ptr<uint8_t[]> data; size_t capacity = 0, size = 0; };
-    Batch ready_;
-    size_t ready_at_ = 0;
-    std::vector<Batch> spare_;
-    static constexpr size_t AHEAD = 2;
-    std::deque<std::future<Batch>> pending_;
+    std::unique_ptr<uint8_t[]> carry_;         // the text of the one member that straddled the end of a read
+    size_t carry_capacity_ = 0, carry_size_ = 0, carry_at_ = 0;
 };
 
 }  // namespace phq
