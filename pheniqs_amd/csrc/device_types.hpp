@@ -302,6 +302,11 @@ struct StageArgs {
     // scattered global atomics run at the memory side on this part, ~3.3 of them per read cost as much as the
     // whole classification
     int32_t defer_counters;
+    // Round 5: the product form kernel (pamld_lut.hpp, NEAR_TOP) hands a noise read on for nothing but a tied argmax with bit 31 of
+    // its worklist entry set and the two blocks of eight barcodes that hold every candidate in its placeholder record; the ties
+    // kernel behind it (pamld_ties.hip) settles those from the literal sums of those barcodes alone and leaves the other entries,
+    // without the bit, to the exact tier.  Set by the dispatcher only where that kernel follows.
+    int32_t flag_ties;
     // The neighbour list tier (pamld_near.hpp) hands the reads it defers to the product form kernel WITH their inputs:
     // beside entry e < carry_stride of workgroup g's worklist segment, plane p (0..2 the code words, 3..5 the quality
     // words, 6 the carried state: flag byte or status word) holds its word at carry[(g * 7 + p) * carry_stride + e],

@@ -37,6 +37,16 @@ __host__ __device__ constexpr double dominance(int length) { return 9e-9 / (((le
 constexpr float RUNNER_UP = 0.9999f;          // runner up <= RUNNER_UP * winner: the argmax is certain in single precision
 constexpr float SMALLEST_CERTAIN = 1e-30f;    // ... for a winner well inside the normal range (a subnormal one has lost its digits)
 constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
+// Round 5, tied noise reads: a read every barcode of which is clearly under the noise filter reports nothing but its argmax
+// (pamld.cpp:113-119), and a third to a half of such reads TIE at the top — two barcodes at the same distance with the same
+// qualities under their mismatches are the same product to the last bit of a float, and which of them the reference's own Kahan
+// sums prefer is a matter of their last bits (52 % of what reached C2's exact tier, 97 % of H94's: 2.1 % of all its reads, a
+// quarter of its step).  The scan keeps, beside the block of eight that holds the maximum, WHICH block holds the runner up and the
+// third largest block maximum (four instructions a block); where the third is under NEAR_TOP of the maximum, every barcode outside
+// those two blocks is further from the argmax than the floats can blur (RUNNER_UP), and the read is handed on with bit 31 of its
+// worklist entry set and the two blocks' numbers in its placeholder record: pamld_ties.hip behind this kernel walks those sixteen
+// barcodes literally instead of the exact tier scanning the codec.  Only where that kernel follows (StageArgs::flag_ties).
+constexpr float NEAR_TOP = 0.9998f;
 
 // Bit-sliced 2-bit bases (A, C, G, T = 0..3).  Position 4f + k lives in byte f of the word: its low code bit at
 // bit 8f + 2 + k, its high code bit 4 places further up, wrapping (bits 6, 7 of the byte and bits 0, 1 of the next
@@ -237,6 +247,8 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
         }
         ReadState r{false, 0};
         bool defer = false;
+        bool tie_only = false;
+        uint32_t tie_blocks = 0;
         DevResult finished_out;                // a consumer's record of this tile: the placeholder unless the read is finished
         finished_out.index = 0; finished_out.distance = 0; finished_out.hq_distance = 0; finished_out.status = STATUS_UNCLASSIFIED; finished_out.qcfail = 0; finished_out.confidence = 0;
         {
@@ -366,10 +378,17 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             float best_value = 0;
             float runner_up = 0;           // the largest block maximum but the running one
             int best_fold = -1;
+            int runner_fold = -1;          // the block that holds the runner up (tied noise reads, NEAR_TOP above) ...
+            float third_value = 0;         // ... and the third largest block maximum
             auto fold_block = [&](int f, const float (&p)[FOLD]) {
                 const float block_max = fmaxf(fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3])), fmaxf(fmaxf(p[4], p[5]), fmaxf(p[6], p[7])));
                 const float block_sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
                 const bool takes_over = block_max > best_value;                      // strict: the first block keeps a tie
+                if(UNIFORM_PRIOR) {
+                    // third <= runner up always holds: the third of (runner up, this block's maximum, third) is their median
+                    third_value = __builtin_amdgcn_fmed3f(runner_up, block_max, third_value);
+                    runner_fold = takes_over ? best_fold : (block_max > runner_up ? f : runner_fold);
+                }
                 // the larger of the old runner up and whichever of (old maximum, this block's maximum) does not lead
                 // now: runner_up <= best_value always holds, so that is the median of the three (one v_med3_f32)
                 runner_up = __builtin_amdgcn_fmed3f(best_value, block_max, runner_up);
@@ -432,6 +451,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             // single precision tells 1 from 2 easily); such a read is handed on by raising the runner up to the winner.
             int best = -1;
             uint32_t best_flags = 0;
+            const float runner_block = runner_up;          // the largest maximum of another block (the runner up below counts the winner's block in)
             float sigma = others_sum;
             const float winner_single = best_value;
             {
@@ -503,6 +523,15 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                 defer = !noise_clear
                      || (noise_margin <= 0 ? !(winner_single >= SMALLEST_CERTAIN && runner_up <= RUNNER_UP * winner_single)
                                            : (!(others <= dominance(L) * best_p) || !(fabs(confidence_margin) > 2e-8)));
+                // handed on for a tied argmax alone (NEAR_TOP, above): every candidate a thousandth under the noise filter, in two blocks
+                if(UNIFORM_PRIOR) {
+                    tie_only = args.flag_ties != 0 && defer && noise_clear && noise_margin <= 0 && winner_single >= SMALLEST_CERTAIN &&
+                               third_value < NEAR_TOP * winner_single && best_conditional * 1.001 < d.random_barcode_probability;
+                    // bits 0..12 the winner's block, 13..25 the runner up's, 26: that one comes within NEAR_TOP (else the winner's block alone)
+                    tie_blocks = static_cast<uint32_t>(best_fold < 0 ? 0 : best_fold) | (static_cast<uint32_t>(runner_fold < 0 ? 0 : runner_fold) << 13) |
+                                 ((runner_fold >= 0 && runner_block >= NEAR_TOP * winner_single) ? 1u << 26 : 0u);
+                    if(CONSUMER && tie_only) { finished_out.confidence = __hiloint2double(0x7ff80000, static_cast<int>(tie_blocks)); }
+                }
                 // a consumer's lanes past the end of the list recompute its last read and store its record again (the counters
                 // are kept from them): every lane has a record to store
                 if(!defer && (active || CONSUMER)) {
@@ -548,7 +577,12 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
                         stream_read_state(args, i, r);
                     }
                 } else if(active && !CONSUMER) {
-                    stream_placeholder(args, i, r);                                   // the next tier overwrites it
+                    // the next tier overwrites it (a tied noise read's names its two blocks in the bits of its confidence)
+                    DevResult out;
+                    out.index = 0; out.distance = 0; out.hq_distance = 0; out.status = STATUS_UNCLASSIFIED; out.qcfail = r.qcfail ? 1 : 0;
+                    out.confidence = tie_only ? __hiloint2double(0x7ff80000, static_cast<int>(tie_blocks)) : 0.0;
+                    if(args.result) { stream_result(&args.result[i], out); }
+                    stream_read_state(args, i, r);
                 }
             }
         }
@@ -568,7 +602,7 @@ __global__ __launch_bounds__(LutGeometry<L>::THREADS) void pamld_lut_kernel(Stag
             if(lane == 0) { first = atomicAdd(&deferred_total, static_cast<uint32_t>(__popcll(deferred))); }
             first = __shfl(first, 0);
             if(active && defer) {
-                segment[gathered_at + first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i);
+                segment[gathered_at + first + __popcll(deferred & ((1ull << lane) - 1ull))] = static_cast<uint32_t>(i) | (tie_only ? 0x80000000u : 0u);
             }
         }
         count_outgoing(args, histogram, active && !defer, r);

@@ -13,6 +13,9 @@ int launch_pamld_literal_l16(const StageArgs&, const DevDecoder&, dim3, size_t, 
 int launch_pamld_literal_l24(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_literal_l32(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 
+int launch_pamld_ties(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);       // pamld_ties.hip
+bool pamld_ties_supports(const StageArgs&, const DevDecoder&);
+
 int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     const int L = host_decoder.nucleotide_cardinality;
     if(L <= 8) { return launch_pamld_literal_l8(args, host_decoder, grid, lds_bytes, stream); }
@@ -128,6 +131,9 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 producer.carry_stride = (listed && !paired && producer.carry) ? std::max<int32_t>(512, producer.worklist_stride / 4 / 512 * 512) : 0;
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
+                // the product form kernel (as a consumer or as the first kernel) flags tied noise reads where the ties kernel follows it
+                const bool lut_ties = !(streamed || few || cross_streamed) && !tiny && !factorised && !long_words && !crossed && pamld_ties_supports(args, host_decoder) &&
+                                      pamld_exact_supports(host_decoder);
                 if(streamed || few || cross_streamed) {
                     // one workgroup per CU (two of the smaller ones of the few barcode kernel), a worklist segment per WAVE: what
                     // the second pass cannot decide either goes there
@@ -182,6 +188,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     StageArgs middle = producer;
                     middle.worklist_role = 2;
                     middle.worklist_segments = static_cast<int32_t>(segment_grid.x);
+                    middle.flag_ties = lut_ties ? 1 : 0;
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, (!crossed && !long_words) ? "pamld_lut_kernel (consumer)" : crossed ? (host_decoder.uniform_prior ? "pamld_cross_kernel (consumer)" : "pamld_cross_kernel (weighted, consumer)") : "pamld_wide_kernel (consumer)");
                     if(!crossed && !long_words) {
                         // the product form kernel takes the segments in groups: as many workgroups as stay resident
@@ -195,6 +202,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                                          : launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s);
                     }
                 } else {
+                    producer.flag_ties = lut_ties ? 1 : 0;
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, tiny ? "pamld_tiny_kernel" : factorised ? (host_decoder.uniform_prior ? "pamld_cross_kernel" : "pamld_cross_kernel (weighted)") : long_words ? "pamld_wide_kernel" : "pamld_lut_kernel");
                     status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
@@ -205,6 +213,13 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 trace_worklist("the product form", producer, segment_grid.x, s);
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
+                consumer.flag_ties = 0;
+                if(lut_ties) {
+                    Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_ties_kernel");
+                    status = launch_pamld_ties(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                    if(status != 0) { return status; }
+                    trace_worklist("the ties kernel", producer, segment_grid.x, s);
+                }
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
