@@ -303,9 +303,9 @@ struct StageArgs {
     // whole classification
     int32_t defer_counters;
     // Round 5: the product form kernel (pamld_lut.hpp, NEAR_TOP) hands a noise read on for nothing but a tied argmax with bit 31 of
-    // its worklist entry set and the two blocks of eight barcodes that hold every candidate in its placeholder record; the ties
-    // kernel behind it (pamld_ties.hip) settles those from the literal sums of those barcodes alone and leaves the other entries,
-    // without the bit, to the exact tier.  Set by the dispatcher only where that kernel follows.
+    // its worklist entry set and the two blocks of eight barcodes that hold every candidate in its placeholder record; the exact
+    // tier's first pass (pamld_exact_lanes.hip, TIE_PACE) settles those from the literal sums of those barcodes alone and leaves
+    // the other entries, without the bit, to its scan.  Set by the dispatcher only where that tier follows (pamld_exact_lanes_ties).
     int32_t flag_ties;
     // The neighbour list tier (pamld_near.hpp) hands the reads it defers to the product form kernel WITH their inputs:
     // beside entry e < carry_stride of workgroup g's worklist segment, plane p (0..2 the code words, 3..5 the quality

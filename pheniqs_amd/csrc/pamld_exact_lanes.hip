@@ -48,6 +48,19 @@ constexpr int THREADS = 64 * WAVES;
 constexpr int WEIGHTED_CAP = PHQ_WEIGHTED_CAP;           // listed words of a segment in the weighted form
 constexpr int CAP = 32;                    // listed words of a segment a read may bring to the literal walk
 constexpr int GROUP_MAX = EXACT_GROUP_MAX;
+// Round 5, tied noise reads (pamld_lut.hpp, NEAR_TOP): an entry with bit 31 set is a read handed on for nothing but a tied argmax,
+// clearly under the noise filter, whose placeholder record names the two blocks of eight barcodes that hold every candidate.  A
+// third to a half of the noise reads tie — 52 % of what reached this tier on C2, 97 % on H94 — and the scan below took every word
+// of the codec through its fp64 tables for each.  A first pass settles them instead: a wave goes through its segments once, the
+// entries without the bit compacted to the segment's front (in order), the flagged ones queued in LDS; whenever a wave's worth is
+// queued every LANE takes one: the Kahan recurrence and the careful 2^x of the sixteen members, TIE_PACE of them side by side,
+// compared as the reference compares them.  (As a kernel of its own between the product form and this tier the pass cost 0.06 ms
+// with next to nothing to do; a workgroup per segment 0.11; re-scanning the codec in single precision for the candidates, with
+// nothing kept by the scan in front: as much as this tier.  Behind the STREAMING kernel — whose second pass can flag the same
+// reads — it gains nothing: C2 0.164 -> 0.170 ms, C5 0.088 -> 0.092 a decoder: not wired there.)
+constexpr int TIE_PACE = 4;                // members walked side by side: a walk is one chain of dependent fp64 operations
+constexpr int TIE_AHEAD = 2;               // entries a lane reads of a tile: their loads are in flight together
+constexpr int TIE_FOLD = 8;                // pamld_lut.hpp's blocks
 
 // pamld_cross.hpp's conventions: a position's low code bit at 8 (j / 4) + 2 + j % 4 of a word, its high bit four places up
 constexpr int FACTOR_ROWS = 129;           // 0..127 = quality of an ACGT base, 128 = a base outside ACGT with q >= 1
@@ -95,6 +108,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WEIGHTE
     // walk, and what the iteration decided until the next one stores it
     __shared__ uint32_t kept[WAVES][READS][S][G + 3];
     __shared__ uint32_t decided[WAVES][READS][11];
+    constexpr bool TIES = S == 1 && !PRIORS && !WEIGHTED;                      // the variants behind kernels that flag tied noise reads
+    __shared__ uint32_t tie_queue[TIES ? WAVES : 1][TIES ? (TIE_AHEAD + 1) * 64 : 1];
     __shared__ double weighted_value[WEIGHTED ? WAVES : 1][WEIGHTED ? READS : 1][2][WEIGHTED ? WEIGHTED_CAP : 1];      // P of the listed words
     __shared__ uint16_t weighted_word[WEIGHTED ? WAVES : 1][WEIGHTED ? READS : 1][2][WEIGHTED ? WEIGHTED_CAP : 1];     // their ordinals
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -120,22 +135,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WEIGHTE
     const int group = args.worklist_group < 1 ? 1 : (args.worklist_group > GROUP_MAX ? GROUP_MAX : args.worklist_group);
     const int first_segment = (static_cast<int>(blockIdx.x) * WAVES + wave) * group;
     const int n_segment_here = max(0, min(group, args.worklist_segments - first_segment));
-    if(lane == 0) {
-        uint32_t total = 0;
-        for(int s = 0; s < GROUP_MAX; ++s) {
-            group_start[wave][s] = total;
-            group_kept[wave][s] = 0;
-            if(s < n_segment_here) { total += args.worklist_count[first_segment + s]; }
-        }
-        group_start[wave][GROUP_MAX] = total;
-    }
     histogram_clear(d, histogram);
     __syncthreads();
 
     const StatSink sink{histogram, args.stats, args.defer_counters != 0};
     uint32_t* const segments = args.worklist + static_cast<int64_t>(first_segment) * args.worklist_stride;
-    const int64_t n = static_cast<int64_t>(group_start[wave][GROUP_MAX]);
-    const int64_t iterations = (n + READS - 1) / READS;
+    int64_t n = 0;                             // entries of the wave's segments, as one list (known behind the first pass)
 
     int first_word[S];
     int length[S];
@@ -294,6 +299,162 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WEIGHTE
         }
         count_outgoing(args, histogram, decided.writer && !decided.defer, r);
     };
+
+    // the first pass: tied noise reads (TIE_PACE, above)
+    if constexpr(TIES) {
+        if(args.flag_ties != 0) {
+            uint32_t* const queue = tie_queue[wave];
+            const double common_prior = uniform_concentration;
+            uint32_t queued = 0;                   // wave uniform, as is
+            for(int home = 0; home < n_segment_here; ++home) {
+                uint32_t* const segment = segments + static_cast<int64_t>(home) * args.worklist_stride;
+                const int64_t entries = static_cast<int64_t>(args.worklist_count[first_segment + home]);
+                uint32_t kept_total = 0;           // what the wave leaves in this segment
+                auto keep = [&](bool stays, uint32_t entry) {
+                    const unsigned long long staying = __ballot(stays);
+                    if(stays) { segment[kept_total + __popcll(staying & ((1ull << lane) - 1ull))] = entry & 0x7fffffffu; }
+                    kept_total += static_cast<uint32_t>(__popcll(staying));
+                };
+                // queue[first .. first + waiting): a read a lane
+                auto settle = [&](uint32_t first, uint32_t waiting) {
+                    const bool active = static_cast<uint32_t>(lane) < waiting;
+                    const uint32_t entry = queue[first + (active ? static_cast<uint32_t>(lane) : 0u)];
+                    const int64_t i = static_cast<int64_t>(entry);        // (a lane past the end takes the first read again, unheard)
+                    ReadState r = load_read_state(args, i);
+                    const uint32_t blocks = static_cast<uint32_t>(__double2loint(args.result[i].confidence));
+                    const uint32_t* const code_row = reinterpret_cast<const uint32_t*>(args.base + i * stride);
+                    const uint32_t* const quality_row = reinterpret_cast<const uint32_t*>(args.quality + i * stride);
+                    uint32_t c[G + 1], q[G + 1];
+#pragma unroll
+                    for(int g = 0; g <= G; ++g) {
+                        const int w = min(first_word[0] + g, row_words - 1);
+                        c[g] = code_row[w];
+                        q[g] = quality_row[w];
+                    }
+                    // per position a byte: the row of its cost pair; its 2 bit code at the words' places; the positions outside ACGT
+                    uint32_t row[G];
+                    uint32_t observed = 0, outside = 0;
+#pragma unroll
+                    for(int g = 0; g < G; ++g) {
+                        const uint32_t code_word = __builtin_amdgcn_alignbyte(c[g + 1], c[g], byte_shift[0]) & byte_mask[0][g];
+                        const uint32_t quality_word = __builtin_amdgcn_alignbyte(q[g + 1], q[g], byte_shift[0]) & byte_mask[0][g];
+                        row[g] = 0;
+#pragma unroll
+                        for(int k = 0; k < 4; ++k) {
+                            const uint32_t code = (code_word >> (8 * k)) & 0xfu;
+                            const uint32_t quality = (quality_word >> (8 * k)) & 0x7fu;          // the table has 128 rows
+                            const bool strict = strict_code(code);
+                            const bool in_word = 4 * g + k < length[0];
+                            const uint32_t two = (0x30210u >> (2 * code)) & 3u;                  // A, C, G, T (1, 2, 4, 8) -> 0 .. 3
+                            observed |= ((two & 1u) << low_bit(4 * g + k)) | ((two >> 1) << ((low_bit(4 * g + k) + 4u) & 31u));
+                            outside |= (in_word && !strict) ? 1u << low_bit(4 * g + k) : 0u;
+                            row[g] |= (strict ? quality : (quality ? 128u : 0u)) << (8 * k);
+                        }
+                    }
+                    const int block_of[2] = {static_cast<int>(blocks & 0x1fffu), static_cast<int>((blocks >> 13) & 0x1fffu)};
+                    const int members = ((blocks >> 26) & 1u) ? 2 * TIE_FOLD : TIE_FOLD;
+                    int best = 0x7fffffff;
+                    double best_p = -1.0;
+                    double best_conditional = 0;
+#pragma nounroll
+                    for(int m = 0; m < members; m += TIE_PACE) {
+                        int b[TIE_PACE];
+                        uint32_t flags[TIE_PACE];
+                        double sigma_q[TIE_PACE];
+                        double compensation[TIE_PACE];
+#pragma unroll
+                        for(int u = 0; u < TIE_PACE; ++u) {
+                            b[u] = TIE_FOLD * block_of[(m + u) / TIE_FOLD] + ((m + u) % TIE_FOLD);
+                            flags[u] = (mismatch_fields(observed ^ lds_word[b[u] < unique[0] ? b[u] : 0]) | outside) & full_mask[0];
+                            sigma_q[u] = 0;
+                            compensation[u] = 0;
+                        }
+                        // barcode.h:131-164: the Kahan sum of the costs over the barcode's positions, then pow
+#pragma unroll
+                        for(int j = 0; j < 4 * G; ++j) {
+                            if(j < length[0]) {
+                                const uint32_t at = ((row[j >> 2] >> (8 * (j & 3))) & 0xffu) * 16u;
+                                const double match = *reinterpret_cast<const double*>(cost_bytes + at);
+                                const double mismatch = *reinterpret_cast<const double*>(cost_bytes + at + 8u);
+#pragma unroll
+                                for(int u = 0; u < TIE_PACE; ++u) {
+                                    const double x = ((flags[u] >> low_bit(j)) & 1u) ? mismatch : match;
+                                    const double y = x - compensation[u];
+                                    const double t = sigma_q[u] + y;
+                                    compensation[u] = (t - sigma_q[u]) - y;
+                                    sigma_q[u] = t;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for(int u = 0; u < TIE_PACE; ++u) {
+                            const double conditional = phred_probability(sigma_q[u], d.log2_base_hi, d.log2_base_lo);
+                            const double p = conditional * common_prior;                                   // pamld.cpp:66
+                            if(b[u] < unique[0] && (p > best_p || (p == best_p && b[u] < best))) {           // strict '>' in barcode order: the lowest of equals
+                                best = b[u]; best_p = p; best_conditional = conditional;
+                            }
+                        }
+                    }
+                    // a noise read on the literal value as well (pamld.cpp:96): charged to its argmax, it leaves unclassified
+                    const bool settled = active && best != 0x7fffffff && !(best_conditional > d.random_barcode_probability);
+                    if(settled) {
+                        stat_add(d, sink, best + 1, 0, FIELD_LOW_CONDITIONAL_CONFIDENCE, 1ull);
+                        r.qcfail = true;
+                        decoder_tail(d, sink, r, 0, 0);
+                        DevResult out;
+                        out.index = 0; out.distance = 0; out.hq_distance = 0; out.status = STATUS_NOISE; out.qcfail = 1; out.confidence = 0;
+                        args.result[i] = out;
+                        store_read_state(args, i, r);
+                    }
+                    keep(active && !settled, entry);
+                    count_outgoing(args, histogram, active && settled, r);
+                };
+                for(int64_t tile = 0; tile * (TIE_AHEAD * 64) < entries; ++tile) {
+                    uint32_t entry[TIE_AHEAD];
+                    bool active[TIE_AHEAD];
+#pragma unroll
+                    for(int e = 0; e < TIE_AHEAD; ++e) {
+                        const int64_t k = (tile * TIE_AHEAD + e) * 64 + lane;
+                        active[e] = k < entries;
+                        entry[e] = active[e] ? segment[k] : 0u;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0f70);        // every entry of the tile is read before anything is written to the segment's front
+#pragma unroll
+                    for(int e = 0; e < TIE_AHEAD; ++e) {
+                        const bool flagged = active[e] && (entry[e] >> 31) != 0;
+                        keep(active[e] && !flagged, entry[e]);
+                        const unsigned long long queueing = __ballot(flagged);
+                        if(flagged) { queue[queued + __popcll(queueing & ((1ull << lane) - 1ull))] = entry[e] & 0x7fffffffu; }
+                        queued += static_cast<uint32_t>(__popcll(queueing));
+                    }
+                    __builtin_amdgcn_wave_barrier();           // (a wave's LDS operations complete in order)
+                    while(queued >= 64u) {                     // (under a wave's worth was waiting, a tile brings TIE_AHEAD of them at most)
+                        queued -= 64u;
+                        settle(queued, 64u);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                // what is still queued goes on into the wave's next segment; behind the last one it is settled
+                if(home == n_segment_here - 1 && queued > 0) { settle(0, queued); queued = 0; }
+                if(lane == 0) { args.worklist_count[first_segment + home] = kept_total; }
+            }
+            // the lists as the pass left them, before the wave reads them again: a wave's own stores, through the CU's own L1 — a
+            // fence of the workgroup's scope (the device's, __threadfence, writes the L2 back: 0.08 ms a launch, measured)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+    }
+    if(lane == 0) {
+        uint32_t total = 0;
+        for(int s = 0; s < GROUP_MAX; ++s) {
+            group_start[wave][s] = total;
+            group_kept[wave][s] = 0;
+            if(s < n_segment_here) { total += args.worklist_count[first_segment + s]; }
+        }
+        group_start[wave][GROUP_MAX] = total;
+    }
+    __builtin_amdgcn_wave_barrier();
+    n = static_cast<int64_t>(group_start[wave][GROUP_MAX]);
+    const int64_t iterations = (n + READS - 1) / READS;
 
     if(iterations > 0) {
         int home_now = 0, home_next = 0;
@@ -775,6 +936,17 @@ bool pamld_exact_lanes_supports(const DevDecoder& host_decoder, size_t histogram
     if(host_decoder.cross_segments > 2) { return false; }
     if(host_decoder.cross_segments == 2 && !host_decoder.uniform_prior && (host_decoder.cross_prior_double == nullptr || no_weighted)) { return false; }
     return host_decoder.high_quality_threshold <= 128 && histogram_bytes <= 24u * 1024u;
+}
+
+// The tier's first pass settles tied noise reads (lanes::TIE_PACE) for a single segment codec of 5 to 16 nt with uniform priors, all
+// ACGT, numbered in barcode order, whose reads' ordinals leave bit 31 of a worklist entry free and whose blocks' numbers fit their
+// thirteen bits: the kernels in front of it then flag such reads (StageArgs::flag_ties)
+bool pamld_exact_lanes_ties(const StageArgs& args, const DevDecoder& host_decoder, size_t histogram_bytes) {
+    static const bool off = std::getenv("PHQ_NO_TIES") != nullptr;
+    return !off && pamld_exact_lanes_supports(host_decoder, histogram_bytes) && host_decoder.algorithm == 1 && host_decoder.all_strict && host_decoder.uniform_prior &&
+           host_decoder.cross_segments == 1 && host_decoder.cross_identity != 0 && host_decoder.cross_unique[0] == host_decoder.n_barcode &&
+           host_decoder.nucleotide_cardinality >= 5 && host_decoder.nucleotide_cardinality <= 16 && host_decoder.n_barcode <= 8 * 8192 &&
+           args.n_read < (int64_t(1) << 31) && args.result != nullptr;
 }
 
 // `grid` is the producer's grid = the number of worklist segments; a wave takes `group` of them as one list

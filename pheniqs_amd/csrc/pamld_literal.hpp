@@ -17,11 +17,21 @@
 
 namespace phq {
 
+// Round 5: what reaches this kernel as a CONSUMER is a handful of reads (S384: ONE of 100 M, H94: 51), and a lane that walks
+// every barcode of the codec for its read alone is one chain of dependent fp64 operations 384 barcodes long: 0.16 ms for that one
+// read.  A worklist segment of at most LITERAL_SHARED_READS reads is shared out instead: the workgroup's lanes compute the Kahan
+// sums and the quickly rounded powers of the barcodes between them, into LDS, and lane 0 alone goes through them in barcode order
+// — the sum over the barcodes, the argmax and its ties exactly as below, on the same values.
+constexpr int LITERAL_SHARED_READS = 4;
+constexpr int LITERAL_SHARED_MOST = 1024;           // barcodes: 16 KiB of LDS
+
 template <int L, bool STRICT>
 __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* tpq = reinterpret_cast<double*>(lds_raw);
     unsigned long long* histogram = reinterpret_cast<unsigned long long*>(lds_raw + 128 * sizeof(double));
+    __shared__ double shared_sigma[LITERAL_SHARED_MOST];
+    __shared__ double shared_p[LITERAL_SHARED_MOST];
     DecoderRef d = *constant_cast(args.decoder);
 
     // PhredScale in LDS: 128 true positive qualities; the other two values a lookup can return are the
@@ -48,9 +58,12 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
     const int64_t tile_first = consumer ? 0 : blockIdx.x;
     const int64_t tile_step = consumer ? 1 : gridDim.x;
 
-    for(int64_t tile = tile_first; tile < tiles; tile += tile_step) {
-        const int64_t k = tile * BLOCK + threadIdx.x;
-        const bool active = k < n;
+    const bool shared = consumer && n > 0 && n <= LITERAL_SHARED_READS && n_barcode <= LITERAL_SHARED_MOST;      // (the workgroup's: LITERAL_SHARED_READS above)
+
+    for(int64_t tile = tile_first; tile < (shared ? n : tiles); tile += tile_step) {
+        if(shared) { __syncthreads(); }        // lane 0 is done with the read before
+        const int64_t k = shared ? tile : tile * BLOCK + threadIdx.x;
+        const bool active = shared || k < n;
         ReadState r{false, 0};
         if(active) {
             const int64_t i = consumer ? static_cast<int64_t>(segment[k]) : k;
@@ -110,11 +123,20 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                 }
                 return sigma_q;
             };
+            if(shared) {
+                for(int b = threadIdx.x; b < n_barcode; b += BLOCK) {
+                    const double sigma_q = kahan_of(b);
+                    shared_sigma[b] = sigma_q;
+                    shared_p[b] = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
+                }
+                __syncthreads();
+                if(threadIdx.x != 0) { continue; }
+            }
 #pragma unroll 2
             for(int b = 0; b < n_barcode; ++b) {
-                const double sigma_q = kahan_of(b);
+                const double sigma_q = shared ? shared_sigma[b] : kahan_of(b);
                 const double prior = concentration[b];
-                const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * prior;
+                const double p = shared ? shared_p[b] : phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * prior;
                 const double y = p - compensation;
                 const double t = sigma_p + y;
                 compensation = (t - sigma_p) - y;
@@ -139,8 +161,8 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_kernel(StageArgs args) {
                 }
             } else {
                 for(int b = 0; b < n_barcode; ++b) {
-                    const double sigma_q = kahan_of(b);
-                    const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
+                    const double sigma_q = shared ? shared_sigma[b] : kahan_of(b);
+                    const double p = shared ? shared_p[b] : phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * concentration[b];
                     if(p >= running * (1.0 - 1e-15)) {
                         const double conditional = phred_probability(sigma_q, log2_base_hi, log2_base_lo);
                         const double careful = conditional * concentration[b];

@@ -44,7 +44,7 @@ constexpr int FACTOR_ROWS = 129;              // 0..127 = quality of an ACGT bas
 // quarter of its step).  The scan keeps, beside the block of eight that holds the maximum, WHICH block holds the runner up and the
 // third largest block maximum (four instructions a block); where the third is under NEAR_TOP of the maximum, every barcode outside
 // those two blocks is further from the argmax than the floats can blur (RUNNER_UP), and the read is handed on with bit 31 of its
-// worklist entry set and the two blocks' numbers in its placeholder record: pamld_ties.hip behind this kernel walks those sixteen
+// worklist entry set and the two blocks' numbers in its placeholder record: the exact tier's first pass (pamld_exact_lanes.hip) walks those sixteen
 // barcodes literally instead of the exact tier scanning the codec.  Only where that kernel follows (StageArgs::flag_ties).
 constexpr float NEAR_TOP = 0.9998f;
 

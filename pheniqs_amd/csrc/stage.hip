@@ -13,8 +13,7 @@ int launch_pamld_literal_l16(const StageArgs&, const DevDecoder&, dim3, size_t, 
 int launch_pamld_literal_l24(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_literal_l32(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 
-int launch_pamld_ties(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);       // pamld_ties.hip
-bool pamld_ties_supports(const StageArgs&, const DevDecoder&);
+bool pamld_exact_lanes_ties(const StageArgs&, const DevDecoder&, size_t);       // pamld_exact_lanes.hip: its first pass settles tied noise reads
 
 int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     const int L = host_decoder.nucleotide_cardinality;
@@ -132,8 +131,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(producer.carry_stride == 0) { producer.carry = nullptr; }
                 int status;
                 // the product form kernel (as a consumer or as the first kernel) flags tied noise reads where the ties kernel follows it
-                const bool lut_ties = !(streamed || few || cross_streamed) && !tiny && !factorised && !long_words && !crossed && pamld_ties_supports(args, host_decoder) &&
-                                      pamld_exact_supports(host_decoder);
+                const bool lut_ties = !(streamed || few || cross_streamed) && !tiny && !factorised && !long_words && !crossed && pamld_exact_lanes_ties(args, host_decoder, histogram_bytes);
                 if(streamed || few || cross_streamed) {
                     // one workgroup per CU (two of the smaller ones of the few barcode kernel), a worklist segment per WAVE: what
                     // the second pass cannot decide either goes there
@@ -213,13 +211,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 trace_worklist("the product form", producer, segment_grid.x, s);
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
-                consumer.flag_ties = 0;
-                if(lut_ties) {
-                    Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_ties_kernel");
-                    status = launch_pamld_ties(consumer, host_decoder, segment_grid, histogram_bytes, s);
-                    if(status != 0) { return status; }
-                    trace_worklist("the ties kernel", producer, segment_grid.x, s);
-                }
+                consumer.flag_ties = lut_ties ? 1 : 0;             // (the lane parallel exact tier follows: pamld_exact_lanes_ties)
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
