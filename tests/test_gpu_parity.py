@@ -147,6 +147,23 @@ def test_bdggg_golden_through_the_gpu(oracle, torch_cuda):
     assert set(report.keys()) == set(golden.keys())
 
 
+@pytest.mark.parametrize("name", ["H94", "U384", "S384", "L16"])
+def test_tied_noise_reads_are_charged_to_the_references_argmax(oracle, torch_cuda, name):
+    """Half of the reads noise, a third to a half of them tied at the top in single precision: the reference charges a noise read
+    to its argmax (`low conditional confidence count`, pamld.cpp:113-119), and which of two barcodes at the same distance with the
+    same qualities under their mismatches that is, is a matter of the last bits of its own Kahan sums.  The product form kernel
+    names the two blocks of eight barcodes that hold every candidate and the exact tier's first pass walks them literally
+    (pamld_lut.hpp NEAR_TOP, pamld_exact_lanes.hip TIE_PACE); ties over more blocks take the scan.  Every integer — the per barcode
+    counts among them — must be the oracle's; with `PHQ_NO_TIES=1` the same reads take the scan, to the same counters."""
+    spec = synthetic.config_spec(name, "pamld")
+    spec["sample"]["noise"] = 0.5
+    job = capi.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, 1 << 16, 77)
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
+    options = engine.options(0)
+    assert options["low_conditional_confidence_count"].sum() > 20000 and (options["low_conditional_confidence_count"][1:] > 0).sum() > 50
+
+
 # ---- BASELINE configs at oracle-sized samples ---------------------------------------------------------------
 
 
