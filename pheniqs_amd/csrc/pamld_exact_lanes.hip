@@ -957,8 +957,12 @@ int launch_pamld_exact_lanes(const StageArgs& args, const DevDecoder& host_decod
     const bool many = host_decoder.cross_segments == 1 && host_decoder.cross_unique[0] > CROSS_MAX_UNIQUE;
     const bool weighted = host_decoder.cross_segments == 2 && !host_decoder.uniform_prior;
     const int reads = 64 / (many ? lanes::LONG_LANES : weighted ? PHQ_WEIGHTED_LANES : lanes::SHORT_LANES);
+    // (round 5, swept with PHQ_EXACT_GROUP on C2: at 1 Mi reads a call — 3.4 reads expected a segment — groups of 1 / 2 / 4 / 8 / 16 took
+    // 31.9 / 23.0 / 18.7 / 24.1 / 32.8 us, at 4 Mi 36.0 / 30.3 / 34.6 / 48.5 / 76.7, at 256 Ki 26.8 / 21.4 / 17.7 / 17.7 / 24.3: a wave wants
+    // an iteration or two, not a list — every iteration is a chain of dependent loads — and sixteen segments a wave, the rule until
+    // now, was the slowest choice but none)
     const double expected_per_segment = 0.01 * static_cast<double>(args.n_read) / static_cast<double>(std::max(1u, grid.x));
-    const int group = expected_per_segment >= 4.0 * reads ? 1 : static_cast<int>(4.0 * reads / std::max(expected_per_segment, 0.25)) + 1;
+    const int group = expected_per_segment >= 1.7 * reads ? 1 : expected_per_segment >= 0.55 * reads ? 2 : 4;
     grouped.worklist_group = std::min(lanes::GROUP_MAX, std::max(1, group));
     static const int forced = std::getenv("PHQ_EXACT_GROUP") ? std::atoi(std::getenv("PHQ_EXACT_GROUP")) : 0;       // sweeps
     if(forced > 0) { grouped.worklist_group = std::min(lanes::GROUP_MAX, forced); }
