@@ -17,6 +17,8 @@ flag and the per type confidences come from the oracle (oracle/pheniqs_oracle.c)
     auxiliary.cpp:320-354    Auxiliary::encode: FI TC (TC > 2 only) RG BC QT XB RX QX OX BZ XM CB CR CY XC, in that order
     hts.h:169-239            the record: name, flag, no reference, no position, no cigar, SEQ, QUAL; htslib prints a float tag as %g
 
+    fastq.h:144-194          a FASTQ record of an output segment and its Illumina comment (`fastq_records()`)
+
 `records()` is held against the reference's own golden SAM file (tests/test_sam_restatement.py, no GPU) before anything of the
 library's is held against it.
 """
@@ -116,16 +118,14 @@ def decoders_of(job):
     return out
 
 
-def records(job, files, result, word, confidence, filtered=None):
-    """The SAM records (text, no header) of the reads of `files` (one FASTQ file per input segment, as read_fastq returns
+def _reads(job, files, result, word, confidence, filtered=None):
+    """(name, QC fail, tags, output segments) of the reads of `files` (one FASTQ file per input segment, as read_fastq returns
     them) that pass the incoming filters; result[k][r] = (index, ...) of the r-th PAMLD / MDD decoder for the k-th read that
     PASSED them, word[k] its status word (bit 31: QC fail), confidence[k] = (sample, molecular, cellular) as the wrappers
     leave them.  `filtered`, a list, receives the ordinals of the reads the incoming filters dropped."""
     decoders = decoders_of(job)
     template = transforms_of(job["template"]["transform"])
-    cardinality = 1 + max(t[4] for t in template)
     minimum = job.get("min input length") or []
-    lines = []
     k = 0
     for ordinal, segments in enumerate(zip(*files)):
         name, qcfail_in = segments[0][0], segments[0][1]
@@ -189,6 +189,15 @@ def records(job, files, result, word, confidence, filtered=None):
             tags["OX"], tags["BZ"] = "Z:" + _letters(raw["molecular"][0]), "Z:" + _phred(raw["molecular"][1])
         if corrected["molecular"][0]:
             tags["RX"], tags["QX"] = "Z:" + _letters(corrected["molecular"][0]), "Z:" + _phred(corrected["molecular"][1])
+        yield name, qcfail, tags, output
+        k += 1
+
+
+def records(job, files, result, word, confidence, filtered=None):
+    """The SAM records (text, no header) of those reads: hts.h:169-239, read.h:349-377, auxiliary.cpp:320-354"""
+    lines = []
+    for name, qcfail, tags, output in _reads(job, files, result, word, confidence, filtered):
+        cardinality = len(output)
         for segment, (code, quality) in enumerate(output):
             flag = 4 | 8 | (1 if cardinality > 1 else 0) | (64 if segment == 0 else 0) | (128 if cardinality > 1 and segment == cardinality - 1 else 0) | (512 if qcfail else 0)
             own = dict(tags)
@@ -197,5 +206,17 @@ def records(job, files, result, word, confidence, filtered=None):
             fields = [name, str(flag), "*", "0", "0", "*", "*", "0", "0", _letters(code) if len(code) else "*", _phred(quality) if len(code) else "*"]
             fields += ["%s:%s" % (tag, own[tag]) for tag in TAG_ORDER if tag in own]
             lines.append("\t".join(fields))
-        k += 1
+    return ("\n".join(lines) + "\n").encode() if lines else b""
+
+
+def fastq_records(job, files, result, word, confidence, filtered=None):
+    """The same reads as FASTQ records, every output segment of a read one after the other (an interleaved file):
+    FastqRecord::decode(segment) + encode, fastq.h:79-88,144-171; on the platforms whose comment has that form (fastq.h:176-194)
+    the comment is `segment:Y|N:0:raw sample barcode`"""
+    illumina = job.get("platform", "ILLUMINA") in ("ILLUMINA", "ELEMENT")
+    lines = []
+    for name, qcfail, tags, output in _reads(job, files, result, word, confidence, filtered):
+        for segment, (code, quality) in enumerate(output):
+            comment = "%d:%s:0:%s" % (segment + 1, "Y" if qcfail else "N", tags["BC"][2:] if "BC" in tags else "") if illumina else ""
+            lines.append("@%s %s\n%s\n+\n%s" % (name, comment, _letters(code), _phred(quality)))
     return ("\n".join(lines) + "\n").encode() if lines else b""

@@ -165,7 +165,7 @@ def test_device_records_equal_the_host_writers(tmp_path, case):
         assert 0 < device[2].count(b"\n") < 2 * n                                # the silent channel's reads leave no record
 
 
-@pytest.mark.parametrize("case", ["two_segments_filters", "mixed_tokens", "three_output_segments"])
+@pytest.mark.parametrize("case", ["two_segments_filters", "mixed_tokens", "three_output_segments", "fastq_interleaved", "fastq_mixed_tokens"])
 @pytest.mark.parametrize("host", [False, True])
 def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case, host):
     """tests/sam_restatement.py — written from the reference's text and pinned to its golden SAM file without the library
@@ -174,7 +174,8 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
     the S9 probe, `~`, offsets from the end, the incoming filters.  Not a comparison of the library with itself."""
     import sam_restatement
     directory = str(tmp_path)
-    if case == "mixed_tokens":
+    fastq = case.startswith("fastq")
+    if case in ("mixed_tokens", "fastq_mixed_tokens"):
         spec = _mixed_spec()
         lengths, n, capacity = (40, 8, 26), 6007, 1 << 12
     else:
@@ -184,7 +185,7 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
         if case == "two_segments_filters":
             spec["filter incoming qc fail"] = True
             spec["min input length"] = [0, 6]
-        else:
+        elif case == "three_output_segments":
             spec["template"] = {"transform": {"token": ["0::12", "0:-9:", "1::", "s::"], "knit": ["0", "~2:3", "1"]}}
     paths = _files(directory, spec, n, 9, lengths)
     if case == "two_segments_filters":
@@ -194,10 +195,10 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
             lines[4 * i + 3] = lines[4 * i + 3][:5]
         open(paths[1], "wb").write(b"\n".join(lines))
     spec["input"] = paths
-    spec["output"] = [os.path.join(directory, "out.sam")]
+    spec["output"] = [os.path.join(directory, "out.fastq" if fastq else "out.sam")]
     incoming, _, did = _run(spec, capacity, host)
     assert (did["record_bytes"] == 0) == host
-    mine = b"".join(line for line in open(spec["output"][0], "rb").readlines() if not line.startswith(b"@"))
+    mine = open(spec["output"][0], "rb").read() if fastq else b"".join(line for line in open(spec["output"][0], "rb").readlines() if not line.startswith(b"@"))
 
     job = capi.compile_job(spec)
     files = [sam_restatement.read_fastq(path) for path in paths]
@@ -208,11 +209,19 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
     base, quality = engine.stage([[(files[i][k][2], files[i][k][3]) for i in range(len(files))] for k in kept])
     flags = np.array([1 if files[0][k][1] else 0 for k in kept], dtype=np.uint8)
     result, word, _, confidence = engine.classify(base, quality, flags, summary=True)
-    expected = sam_restatement.records(job, files, result, word, confidence)
+    expected = (sam_restatement.fastq_records if fastq else sam_restatement.records)(job, files, result, word, confidence)
     assert incoming[0] == n and len(kept) < n or case != "two_segments_filters"
     # byte for byte, but for the digits of XB / XM / XC: the tag prints float(1 - posterior) with six digits, and the fast mode's
     # posterior is the oracle's to 1e-8 (tests/test_gpu_parity.py), not to the bit — 1e-8 of the posterior is the fourth digit of
     # a 1e-5 tag.  Those tags must parse, sit where the oracle's sit and agree to what 1e-8 leaves; most lines are identical
+    if fastq:
+        # (a FASTQ record carries no posterior: byte for byte)
+        if mine != expected:
+            for k, (a, b) in enumerate(zip(mine.split(b"\n"), expected.split(b"\n"))):
+                assert a == b, (k, a, b)
+        assert mine == expected
+        assert (b" 4:N:0:" in mine or b" 4:Y:0:" in mine) == (case == "fastq_mixed_tokens")
+        return
     mine_lines, expected_lines = mine.split(b"\n"), expected.split(b"\n")
     assert len(mine_lines) == len(expected_lines)
     identical = 0
