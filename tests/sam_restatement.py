@@ -193,30 +193,54 @@ def _reads(job, files, result, word, confidence, filtered=None):
         k += 1
 
 
-def records(job, files, result, word, confidence, filtered=None):
-    """The SAM records (text, no header) of those reads: hts.h:169-239, read.h:349-377, auxiliary.cpp:320-354"""
+def _sam_lines(name, qcfail, tags, output):
+    """hts.h:169-239, read.h:349-377, auxiliary.cpp:320-354: a line (no line break) per output segment"""
+    cardinality = len(output)
     lines = []
-    for name, qcfail, tags, output in _reads(job, files, result, word, confidence, filtered):
-        cardinality = len(output)
-        for segment, (code, quality) in enumerate(output):
-            flag = 4 | 8 | (1 if cardinality > 1 else 0) | (64 if segment == 0 else 0) | (128 if cardinality > 1 and segment == cardinality - 1 else 0) | (512 if qcfail else 0)
-            own = dict(tags)
-            if cardinality > 2:
-                own["FI"], own["TC"] = "i:%d" % (segment + 1), "i:%d" % cardinality
-            fields = [name, str(flag), "*", "0", "0", "*", "*", "0", "0", _letters(code) if len(code) else "*", _phred(quality) if len(code) else "*"]
-            fields += ["%s:%s" % (tag, own[tag]) for tag in TAG_ORDER if tag in own]
-            lines.append("\t".join(fields))
+    for segment, (code, quality) in enumerate(output):
+        flag = 4 | 8 | (1 if cardinality > 1 else 0) | (64 if segment == 0 else 0) | (128 if cardinality > 1 and segment == cardinality - 1 else 0) | (512 if qcfail else 0)
+        own = dict(tags)
+        if cardinality > 2:
+            own["FI"], own["TC"] = "i:%d" % (segment + 1), "i:%d" % cardinality
+        fields = [name, str(flag), "*", "0", "0", "*", "*", "0", "0", _letters(code) if len(code) else "*", _phred(quality) if len(code) else "*"]
+        fields += ["%s:%s" % (tag, own[tag]) for tag in TAG_ORDER if tag in own]
+        lines.append("\t".join(fields))
+    return lines
+
+
+def _fastq_lines(illumina, name, qcfail, tags, output):
+    """FastqRecord::decode(segment) + encode, fastq.h:79-88,144-171; on the platforms whose comment has that form (fastq.h:176-194)
+    the comment is `segment:Y|N:0:raw sample barcode`: a record (four lines, no last line break) per output segment"""
+    lines = []
+    for segment, (code, quality) in enumerate(output):
+        comment = "%d:%s:0:%s" % (segment + 1, "Y" if qcfail else "N", tags["BC"][2:] if "BC" in tags else "") if illumina else ""
+        lines.append("@%s %s\n%s\n+\n%s" % (name, comment, _letters(code), _phred(quality)))
+    return lines
+
+
+def records(job, files, result, word, confidence, filtered=None):
+    """The SAM records (text, no header) of those reads"""
+    lines = []
+    for read in _reads(job, files, result, word, confidence, filtered):
+        lines.extend(_sam_lines(*read))
     return ("\n".join(lines) + "\n").encode() if lines else b""
 
 
 def fastq_records(job, files, result, word, confidence, filtered=None):
-    """The same reads as FASTQ records, every output segment of a read one after the other (an interleaved file):
-    FastqRecord::decode(segment) + encode, fastq.h:79-88,144-171; on the platforms whose comment has that form (fastq.h:176-194)
-    the comment is `segment:Y|N:0:raw sample barcode`"""
+    """The same reads as FASTQ records, every output segment of a read one after the other (an interleaved file)"""
     illumina = job.get("platform", "ILLUMINA") in ("ILLUMINA", "ELEMENT")
     lines = []
-    for name, qcfail, tags, output in _reads(job, files, result, word, confidence, filtered):
-        for segment, (code, quality) in enumerate(output):
-            comment = "%d:%s:0:%s" % (segment + 1, "Y" if qcfail else "N", tags["BC"][2:] if "BC" in tags else "") if illumina else ""
-            lines.append("@%s %s\n%s\n+\n%s" % (name, comment, _letters(code), _phred(quality)))
+    for read in _reads(job, files, result, word, confidence, filtered):
+        lines.extend(_fastq_lines(illumina, *read))
     return ("\n".join(lines) + "\n").encode() if lines else b""
+
+
+def by_channel(job, files, result, word, confidence):
+    """[(channel, QC fail, SAM line per output segment, FASTQ record per output segment)] of the reads that pass the incoming
+    filters, in input order: Multiplexer::push (multiplex.h:198-240) sends a read to the channel of the multiplexing decoder's
+    barcode — the channel index the status word carries (classifier.h:83-85) —, its URLs and its own outgoing filter"""
+    illumina = job.get("platform", "ILLUMINA") in ("ILLUMINA", "ELEMENT")
+    out = []
+    for k, read in enumerate(_reads(job, files, result, word, confidence)):
+        out.append((int(word[k]) & 0x7fffffff, read[1], _sam_lines(*read), _fastq_lines(illumina, *read)))
+    return out

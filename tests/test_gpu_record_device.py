@@ -165,6 +165,25 @@ def test_device_records_equal_the_host_writers(tmp_path, case):
         assert 0 < device[2].count(b"\n") < 2 * n                                # the silent channel's reads leave no record
 
 
+def _assert_sam_equal_but_for_posterior_digits(mine, expected):
+    """SAM records byte for byte, but for the digits of XB / XM / XC (see test_records_equal_the_independent_python_restatement)"""
+    mine_lines, expected_lines = mine.split(b"\n"), expected.split(b"\n")
+    assert len(mine_lines) == len(expected_lines)
+    identical = 0
+    for k, (a, b) in enumerate(zip(mine_lines, expected_lines)):
+        if a == b:
+            identical += 1
+            continue
+        fa, fb = a.split(b"\t"), b.split(b"\t")
+        assert len(fa) == len(fb), (k, a, b)
+        for x, y in zip(fa, fb):
+            if x != y:
+                assert x[:5] == y[:5] and x[:5] in (b"XB:f:", b"XM:f:", b"XC:f:"), (k, a, b)
+                u, v = float(x[5:]), float(y[5:])
+                assert x[5:] == b"%g" % u and abs(u - v) <= 2e-8 + 1e-6 * v, (k, a, b)
+    assert identical >= 0.5 * len(mine_lines)
+
+
 @pytest.mark.parametrize("case", ["two_segments_filters", "mixed_tokens", "three_output_segments", "fastq_interleaved", "fastq_mixed_tokens"])
 @pytest.mark.parametrize("host", [False, True])
 def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case, host):
@@ -222,21 +241,7 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
         assert mine == expected
         assert (b" 4:N:0:" in mine or b" 4:Y:0:" in mine) == (case == "fastq_mixed_tokens")
         return
-    mine_lines, expected_lines = mine.split(b"\n"), expected.split(b"\n")
-    assert len(mine_lines) == len(expected_lines)
-    identical = 0
-    for k, (a, b) in enumerate(zip(mine_lines, expected_lines)):
-        if a == b:
-            identical += 1
-            continue
-        fa, fb = a.split(b"\t"), b.split(b"\t")
-        assert len(fa) == len(fb), (k, a, b)
-        for x, y in zip(fa, fb):
-            if x != y:
-                assert x[:5] == y[:5] and x[:5] in (b"XB:f:", b"XM:f:", b"XC:f:"), (k, a, b)
-                u, v = float(x[5:]), float(y[5:])
-                assert x[5:] == b"%g" % u and abs(u - v) <= 2e-8 + 1e-6 * v, (k, a, b)
-    assert identical >= 0.5 * len(mine_lines)
+    _assert_sam_equal_but_for_posterior_digits(mine, expected)
     if case == "mixed_tokens":
         assert b"\tFI:i:4\tTC:i:4" in mine and b"\tXC:f:" in mine and b"\tRX:Z:" in mine
     if case == "three_output_segments":
@@ -328,6 +333,68 @@ def test_channels_in_files_of_their_own_and_gzip_output(tmp_path, case):
     for name in device[3]:
         assert device[3][name] == host[3][name], name
     assert sum(len(v) for v in device[3].values()) > 100 * n
+
+
+@pytest.mark.parametrize("host", [False, True])
+def test_files_per_barcode_equal_the_independent_python_restatement(oracle, tmp_path, host):
+    """The layout of test_channels_in_files_of_their_own_and_gzip_output ("file_per_barcode": a SAM file for some barcodes, one
+    interleaved FASTQ file for others, a FASTQ file per output segment for the rest, one barcode silent, one with its own outgoing
+    filter, everything else and the unclassified reads in the job's SAM file) against tests/sam_restatement.py over the ORACLE's
+    decisions: which file a read's records go to, in input order, and what they say."""
+    import sam_restatement
+    directory = str(tmp_path)
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    n, capacity = 20011, 4096
+    paths = _files(directory, spec, n, 23, (30, 8))
+    spec["input"] = paths
+    keys = list(spec["sample"]["codec"])
+    spec["output"] = [os.path.join(directory, "rest.sam")]
+    urls_of = {}
+    for k, key in enumerate(keys[:40]):
+        urls = ["%d.sam" % k] if k % 3 == 0 else ["%d.fastq" % k] if k % 3 == 1 else ["%d_s1.fastq" % k, "%d_s2.fastq" % k]
+        urls_of[k] = [] if k == 5 else urls
+        spec["sample"]["codec"][key]["output"] = ["/dev/null"] if k == 5 else [os.path.join(directory, u) for u in urls]
+        spec["sample"]["codec"][key]["filter outgoing qc fail"] = k == 7
+    incoming, _, did = _run(spec, capacity, host)
+    assert incoming[0] == n and (did["record_bytes"] == 0) == host
+
+    job = capi.compile_job(spec)
+    ordinal_of_index = {job["sample"]["codec"][key]["index"]: k for k, key in enumerate(keys)}
+    files = [sam_restatement.read_fastq(path) for path in paths]
+    engine = oracle.OracleJob(job)
+    base, quality = engine.stage([[(files[i][k][2], files[i][k][3]) for i in range(len(files))] for k in range(n)])
+    flags = np.array([1 if files[0][k][1] else 0 for k in range(n)], dtype=np.uint8)
+    result, word, _, confidence = engine.classify(base, quality, flags, summary=True)
+    expected = {}
+    for channel, qcfail, sam, fastq in sam_restatement.by_channel(job, files, result, word, confidence):
+        k = ordinal_of_index.get(channel, -1) if channel > 0 else -1
+        if k < 0 or k >= 40:
+            expected.setdefault("rest.sam", []).extend(sam)
+            continue
+        if k == 7 and qcfail:
+            continue
+        urls = urls_of[k]
+        if len(urls) == 1:
+            expected.setdefault(urls[0], []).extend(sam if urls[0].endswith(".sam") else fastq)
+        for segment, url in enumerate(urls if len(urls) == 2 else []):
+            expected.setdefault(url, []).append(fastq[segment])
+    written = 0
+    for name, lines in expected.items():
+        data = open(os.path.join(directory, name), "rb").read()
+        text = ("\n".join(lines) + "\n").encode()
+        if name.endswith(".sam"):
+            _assert_sam_equal_but_for_posterior_digits(b"".join(line for line in data.splitlines(True) if not line.startswith(b"@")), text)
+        else:
+            assert data == text, name
+        written += 1
+    assert written >= 50 and not os.path.exists(os.path.join(directory, "5.sam"))
+    # a barcode's files exist even where no read went to it; nothing but headers in them then
+    for k, urls in urls_of.items():
+        for url in urls:
+            if url not in expected:
+                data = open(os.path.join(directory, url), "rb").read()
+                assert all(line.startswith(b"@") for line in data.splitlines()) and not url.endswith(".fastq") or data == b""
 
 
 @pytest.mark.parametrize("case", ["written", "report_only", "mixed_tokens", "filters"])
