@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     { std::vector<uint8_t> t(100000, 'F'); texts.push_back({"one long run", t}); }
     { std::vector<uint8_t> t; for(int k = 0; k < 40000; ++k) { t.push_back("ACGT"[k % 3]); if(k % 1000 == 0) { t.push_back(static_cast<uint8_t>(rng())); } } texts.push_back({"short periods", t}); }
     { std::vector<uint8_t> t; for(int k = 0; k < 300000; ++k) { t.push_back(static_cast<uint8_t>((rng() % 7 == 0) ? rng() : "the quick brown fox "[k % 20])); } texts.push_back({"text with noise", t}); }
-    { std::vector<uint8_t> t; for(int k = 0; k < 66000; ++k) { t.push_back(static_cast<uint8_t>(k * k >> 3)); } texts.push_back({"far matches", t}); }
+    { std::vector<uint8_t> t; for(int k = 0; k < 66000; ++k) { t.push_back(static_cast<uint8_t>(static_cast<uint64_t>(k) * static_cast<uint64_t>(k) >> 3)); } texts.push_back({"far matches", t}); }
     size_t members = 0, refused = 0;
     for(const auto& named : texts) {
         const std::vector<uint8_t>& text = named.second;
@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
                         std::printf("refused: %s level %d strategy %d memory %d (%zu -> %zu bytes)\n", named.first.c_str(), level, strategy, memory, text.size(), packed.size());
                         continue;
                     }
-                    if(std::memcmp(out.data(), text.data(), text.size()) != 0) { std::printf("text differs: %s level %d strategy %d\n", named.first.c_str(), level, strategy); return 1; }
+                    if(!text.empty() && std::memcmp(out.data(), text.data(), text.size()) != 0) { std::printf("text differs: %s level %d strategy %d\n", named.first.c_str(), level, strategy); return 1; }
                     for(size_t k = text.size(); k < out.size(); ++k) { if(out[k] != 0xAB) { std::printf("wrote past the text: %s level %d strategy %d\n", named.first.c_str(), level, strategy); return 1; } }
                 }
             }
@@ -92,7 +92,7 @@ int main(int argc, char** argv) {
             std::vector<uint8_t> out(text.size() + 16, 0xAB);
             const size_t stated = trial % 7 == 0 ? text.size() - 1 - rng() % 5 : text.size();
             if(phq::fast_inflate::inflate_member(damaged.data(), damaged.size(), out.data(), stated)) {
-                if(stated != text.size() || std::memcmp(out.data(), text.data(), text.size()) != 0) { std::printf("a damaged member was accepted with other text\n"); return 1; }
+                if(stated != text.size() || (!text.empty() && std::memcmp(out.data(), text.data(), text.size()) != 0)) { std::printf("a damaged member was accepted with other text\n"); return 1; }
                 ++accepted;                                   // the damage was in a place that does not matter (MTIME, XFL, OS)
             }
             for(size_t k = text.size(); k < out.size(); ++k) { if(out[k] != 0xAB) { std::printf("a damaged member wrote past the text\n"); return 1; } }

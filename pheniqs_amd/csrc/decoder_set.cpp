@@ -591,7 +591,6 @@ void DecoderSet::build_device_images() {
             const bool two_parts = (c.algorithm == Algorithm::PAMLD || paired_mdd) && c.segment_cardinality == 1 && c.nucleotide_cardinality >= 11 && c.nucleotide_cardinality <= 2 * NEAR_MAX_LENGTH &&
                                    std::getenv("PHQ_NO_PAIR_PARTS") == nullptr;
             int32_t part_start[2] = {0, 0}, part_length[2] = {0, 0};
-            bool prefix_parts = false;             // a part is the first 10 nt of a longer segment
             if(two_parts) {
                 const int32_t L = c.nucleotide_cardinality;
                 part_length[0] = L <= 16 ? std::min(8, L - 4) : L - NEAR_MAX_LENGTH;
@@ -605,7 +604,10 @@ void DecoderSet::build_device_images() {
                 // PAMLD only: the MDD lookup decides by the whole segment's tolerance.  (Round 5: such pairs had the two word product
                 // form over all barcodes as their first tier — 96 pairs of 12 + 12 nt 4.5 Greads/s, profiles/r05_shape_grid.md.)
                 if(c.algorithm == Algorithm::PAMLD && c.nucleotide_cardinality <= 32) {
-                    for(int32_t s = 0; s < 2; ++s) { if(part_length[s] > NEAR_MAX_LENGTH) { part_length[s] = NEAR_MAX_LENGTH; prefix_parts = true; } }
+                    for(int32_t s = 0; s < 2; ++s) {
+                        // a part is the first 10 nt of a longer segment: the pair tier scores every position through full_mask whichever barcode the prefix names
+                        if(part_length[s] > NEAR_MAX_LENGTH) { part_length[s] = NEAR_MAX_LENGTH; }
+                    }
                 }
             }
             if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || positive_priors)) || paired_mdd) && (c.segment_cardinality == 2 || two_parts) && c.nucleotide_cardinality <= 32 &&

@@ -13,7 +13,10 @@
 #include <cstdint>
 #include <cstring>
 
+#if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
+#define PHQ_CRC_FOLDED 1
+#endif
 #include <zlib.h>
 
 namespace phq {
@@ -373,6 +376,7 @@ inline bool inflate_raw(const uint8_t* in, size_t in_size, uint8_t* const out_be
     return true;
 }
 
+#ifdef PHQ_CRC_FOLDED
 // CRC-32 (the gzip polynomial) by carry-less multiplication: four 128 bit lanes folded by 64 bytes a step (Gopal et al., "Fast CRC
 // computation for generic polynomials using PCLMULQDQ", Intel 2009: its constants for this polynomial); `crc` in and out as
 // zlib's crc32() takes and gives it.  At least 64 bytes, a multiple of 16.
@@ -424,15 +428,18 @@ __attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_folded(uint32_t c
     x1 = _mm_xor_si128(x1, x2);
     return ~static_cast<uint32_t>(_mm_extract_epi32(x1, 1));
 }
+#endif
 
 inline uint32_t crc32_of(const uint8_t* buffer, size_t bytes) {
-    static const bool folded = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
     uint32_t crc = 0;
+#ifdef PHQ_CRC_FOLDED
+    static const bool folded = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
     if(folded && bytes >= 64) {
         const size_t body = bytes & ~static_cast<size_t>(15);
         crc = crc32_folded(crc, buffer, body);
         buffer += body; bytes -= body;
     }
+#endif
     while(bytes > 0) {
         const uInt step = static_cast<uInt>(bytes > (size_t(1) << 30) ? (size_t(1) << 30) : bytes);
         crc = static_cast<uint32_t>(crc32(crc, buffer, step));

@@ -126,6 +126,7 @@ public:
 
 private:
     struct Member { size_t begin, end, text; };
+    static constexpr size_t MEMBER_LIMIT = size_t(64) << 20;      // plain members: compressed or stated text bytes
 
     static uint32_t le32(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); }
 
@@ -182,7 +183,14 @@ private:
         boundary.push_back(size_);
         for(size_t k = 0; k + 1 < boundary.size(); ++k) {
             if(boundary[k + 1] - boundary[k] < 18) { return false; }
-            member_.push_back({boundary[k], boundary[k + 1], le32(map_ + boundary[k + 1] - 4)});
+            // A trailer states a member's text size modulo 2^32, and a member that does not fit a read goes through a buffer
+            // of its own size: members past MEMBER_LIMIT bytes either way (two lanes' files joined with cat, each gigabytes) are
+            // not this reader's shape — open() says no and the caller streams the file (a member of less than 4 MiB cannot
+            // inflate to 4 GiB, deflate expands at most 1 032 times; a larger one whose trailer wrapped fails its size check in
+            // inflate_member and the caller falls back as well).
+            const size_t text = le32(map_ + boundary[k + 1] - 4);
+            if(boundary[k + 1] - boundary[k] > MEMBER_LIMIT || text > MEMBER_LIMIT) { member_.clear(); return false; }
+            member_.push_back({boundary[k], boundary[k + 1], text});
         }
         return true;
     }

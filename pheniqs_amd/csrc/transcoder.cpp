@@ -1142,7 +1142,14 @@ bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file)
                 if(!p.members->open(plan.input_feed[static_cast<size_t>(f)].path, host_threads())) { p.members.reset(); }
             }
             p.head.resize(sizeof(head));
-            const int inflated = p.members ? static_cast<int>(p.members->read(p.head.data(), p.head.size())) : gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size()));
+            int inflated = -1;
+            if(p.members) {
+                // a member that does not hold to its trailer (a text of 4 GiB and more wraps it), or no memory for it: the
+                // stream is still at its start, gzread takes the file as before
+                try { inflated = static_cast<int>(p.members->read(p.head.data(), p.head.size())); }
+                catch(const std::exception&) { p.members.reset(); inflated = -1; }
+            }
+            if(!p.members) { inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size())); }
             if(inflated < 4) { return false; }
             p.head.resize(static_cast<size_t>(inflated));
             std::memcpy(head, p.head.data(), p.head.size());

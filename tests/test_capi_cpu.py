@@ -448,7 +448,9 @@ def test_gzip_members_inflate_in_parallel_to_the_same_text(tmp_path):
     pieces of uneven sizes across batches; a single member stream is left to gzread; a member cut short or with a damaged trailer
     is an IO error, never wrong text (fastq.h:427-440 reads such files through htslib's bgzf)."""
     import gzip
+    import struct
     import subprocess
+    import zlib
 
     import numpy as np
 
@@ -492,6 +494,16 @@ def test_gzip_members_inflate_in_parallel_to_the_same_text(tmp_path):
     assert run(members[:-9]).returncode == 4                                                # cut short
     cut = _bgzf(text)
     assert run(cut[:len(cut) // 2]).returncode in (3, 4)                                    # half a BGZF file: not taken as blocks, or an error
+    # two lanes' files joined with cat: members past the reader's limit are left to the caller's streaming path ...
+    large = gzip.compress(b"A" * ((64 << 20) + 1), 1) + gzip.compress(text[:1000], 6)
+    assert run(large, compare=False).returncode == 3
+    # ... and a member of 4 GiB and more of text, whose trailer holds its size modulo 2^32, is an error at its first read, never
+    # other text (the transcoder then reads the file through gzread from its start)
+    packer = zlib.compressobj(1, zlib.DEFLATED, 31)
+    piece = bytes(64 << 20)
+    wrapped = b"".join(packer.compress(piece) for _ in range(64)) + packer.compress(b"@" * 1000) + packer.flush()
+    assert struct.unpack("<I", wrapped[-4:])[0] == 1000 and len(wrapped) < (64 << 20)
+    assert run(wrapped + gzip.compress(text[:1000], 6), compare=False).returncode == 4
 
 
 def test_the_one_shot_inflate_against_zlib_under_sanitizers():
