@@ -53,9 +53,9 @@ def contract_line(full):
     line["config"] = {k: config[k] for k in ("workload", "reads_per_gpu", "kernel_mode", "sharding") if k in config}
     if config.get("ranks_share_device"):
         line["config"]["ranks_share_device"] = True
-    for k in ("ranks", "backend", "merge", "counted_reads"):
-        if k in full:
-            line[k] = full[k]
+    for k in ("ranks", "backend", "merge", "merge_ms", "per_rank", "counted_reads"):
+        if full.get(k) is not None:
+            line[k] = sig(full[k], 4) if isinstance(full[k], float) else full[k]
     r = full["roofline"]
     line["roofline"] = {k: sig(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_name", "kernel_ms", "kernel_ms_profiles",
                                                    "launches_per_step", "classify_ms_per_step", "step_frac", "algorithmic_bytes_per_read",
@@ -447,7 +447,12 @@ class Workload:
         torch = self.torch
         for _ in range(warmup):
             self.step()
-        self.merge()
+        self.merge()                           # (the first one sets the communicator up)
+        barrier()
+        t_merge = time.perf_counter()
+        self.merge()                           # the all-reduce alone, between barriers: what the end of a run adds to its steps
+        barrier()
+        merge_ms = (time.perf_counter() - t_merge) * 1e3
         self.set.stats_reset(self.stream)
         barrier()
         self.set.profile_enable(True)          # HIP events around every kernel launch, on the launch stream
@@ -473,11 +478,19 @@ class Workload:
                 order.append(key)
             chain[key] += span["ms"]
         self.chain = [{"decoder": decoder, "kernel": kernel, "ms_per_step": chain[(decoder, kernel)] / steps} for decoder, kernel in order]
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            elapsed = float(t.item())
         classify_ms = float(np.mean([a.elapsed_time(b) for a, b in pairs]))        # all kernels of one step
+        per_rank = None
+        if world > 1:
+            # every rank's own clock and its own HIP event time, so that a scaling record can be read from the line alone: the
+            # value is computed from the slowest rank (MAX), the spread says whether a rank or the merge holds the others up
+            mine = torch.tensor([elapsed, classify_ms, merge_ms], dtype=torch.float64, device=self.device)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(every, mine)
+            table = np.array([t.cpu().numpy() for t in every])
+            elapsed = float(table[:, 0].max())
+            per_rank = {"ms_per_step": [float(table[:, 0].min() / steps * 1e3), float(table[:, 0].max() / steps * 1e3)],
+                        "classify_ms_per_step": [float(table[:, 1].min()), float(table[:, 1].max())],
+                        "merge_ms": [float(table[:, 2].min()), float(table[:, 2].max())], "are": "[fastest rank, slowest rank]"}
         # the dominant kernel KIND: all its launches of one step together (a job with several decoders launches it
         # once per decoder; the bytes below are the whole job's)
         dominant = max(kernels, key=lambda name: kernels[name]["ms"])
@@ -488,6 +501,7 @@ class Workload:
         self.counted_reads = total
         bytes_per_step = self.bytes_per_read * self.n
         return {"elapsed": elapsed, "counted_reads": total, "ms_per_step": elapsed / steps * 1e3, "Mreads/s": self.n * world * steps / elapsed / 1e6,
+                "merge_ms": merge_ms, "per_rank": per_rank,
                 "kernels": kernels, "chain": self.chain, "dominant": dominant, "kernel_ms": kernel_ms, "classify_ms": classify_ms,
                 "launches_per_step": kernels[dominant]["launches"] / steps,
                 "achieved_GBs": bytes_per_step / (kernel_ms * 1e-3) / 1e9, "step_GBs": bytes_per_step / (classify_ms * 1e-3) / 1e9}
@@ -581,7 +595,9 @@ def main():
                        "sharding": "reads x%d, the steps are batches of one run, counters merged by one all-reduce at its end" % world,
                        "ranks_share_device": bool(args.share_device)},
             "merge": "once per run",
+            "merge_ms": m["merge_ms"],                  # the all-reduce of the counters alone, between barriers (rank 0's clock)
             "counted_reads": m["counted_reads"],
+            "per_rank": m["per_rank"],
             # what the process group itself says: the ranks that took part in the barrier and the all-reduce, and its backend
             "ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
             "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

@@ -360,7 +360,7 @@ void DecoderSet::build_device_images() {
                     d.segment_mask[s][j >> 3] |= 1u << (4 * (j & 7));
                     d.full_mask[j >> 3] |= 1u << (4 * (j & 7));
                 }
-                if(end > begin) { d.segment_end_bits |= 1u << (end - 1); }
+                if(end > begin) { d.segment_end_bits[(end - 1) >> 5] |= 1u << ((end - 1) & 31); }
             }
             std::vector<uint32_t> packed(static_cast<size_t>(d.n_barcode) * static_cast<size_t>(d.n_word), 0);
             std::vector<double> concentration(static_cast<size_t>(d.n_barcode));
@@ -401,7 +401,7 @@ void DecoderSet::build_device_images() {
             d.barcode_packed = static_cast<const uint32_t*>(upload(packed.data(), packed.size() * sizeof(uint32_t)));
             d.concentration = static_cast<const double*>(upload(concentration.data(), concentration.size() * sizeof(double)));
             d.barcode_index = static_cast<const int32_t*>(upload(index.data(), index.size() * sizeof(int32_t)));
-            if(c.all_strict && c.algorithm == Algorithm::MDD && d.n_barcode > 0) {
+            if(c.all_strict && c.algorithm == Algorithm::MDD && d.n_barcode > 0 && c.nucleotide_cardinality <= DEV_TIER_NUCLEOTIDE) {
                 // exact match hash (mdd.cpp:29-31,43-46): keys are the full length barcodes, 2 bits per base
                 uint32_t slots = 16;
                 while(slots < 4u * static_cast<uint32_t>(d.n_barcode)) { slots <<= 1; }
@@ -945,7 +945,7 @@ void DecoderSet::build_device_images() {
                 d.factor_pairs = device_factor_pairs;
             }
             if(c.all_strict && ((c.algorithm == Algorithm::PAMLD && (d.uniform_prior || c.segment_cardinality == 2)) || c.algorithm == Algorithm::MDD) &&
-               d.n_barcode > 1 && c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT) {
+               d.n_barcode > 1 && c.segment_cardinality >= 1 && c.segment_cardinality <= CROSS_MAX_SEGMENT && c.nucleotide_cardinality <= DEV_TIER_NUCLEOTIDE) {
                 // A combinatorial barcode set (every combination of per segment sets, once)?  Then P(r|b) factorises
                 // over the segments and pamld_cross.hpp scans the segments' distinct words instead of the barcodes.
                 // A single segment set is the trivial case: it only uses the exact tier of that file.

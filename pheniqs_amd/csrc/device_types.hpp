@@ -7,8 +7,10 @@ namespace phq {
 
 constexpr int DEV_MAX_DECODER = 16;
 constexpr int DEV_MAX_SEGMENT = 8;
-constexpr int DEV_MAX_WORD = 4;          // 8 nucleotides per 32-bit word of 4-bit BAM codes
-constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;
+constexpr int DEV_MAX_WORD = 16;         // 8 nucleotides per 32-bit word of 4-bit BAM codes
+constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;      // 128: the reference loops over any length (barcode.h:147-161); every tier but the
+                                                          // general kernels (pamld_literal_long.hip, mdd_kernel) stops at DEV_TIER_NUCLEOTIDE
+constexpr int DEV_TIER_NUCLEOTIDE = 32;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
 constexpr int EXACT_SINGLE_UNIQUE = 512;
@@ -129,7 +131,7 @@ struct DevDecoder {
     int32_t high_quality_distance_threshold;
     int32_t quality_masking_threshold;
     int32_t use_lds_histogram;            // bins fit in LDS: workgroup histogram, else global atomics
-    uint32_t segment_end_bits;            // bit j set when position j is the last of its segment
+    uint32_t segment_end_bits[DEV_MAX_NUCLEOTIDE / 32];      // bit j (of word j / 32) set when position j is the last of its segment
     int32_t uniform_prior;                // every concentration is the same double
     int32_t identity_index;               // barcode_index[b] == b + 1 for every barcode (the compiler's numbering)
     int32_t distance_tolerance[DEV_MAX_SEGMENT];

@@ -277,6 +277,7 @@ DecoderConfig parse_decoder(const Json& node, Kind kind) {
             }
         }
         if(d.closed() && d.nucleotide_cardinality > MAX_NUCLEOTIDE) {
+            // (33 to 128 nt take the general kernels — pamld_literal_long.hip, mdd_kernel over 8 or 16 words — at their stated rate)
             throw ConfigurationError("barcodes longer than " + std::to_string(MAX_NUCLEOTIDE) + " nucleotides are not supported");
         }
     }

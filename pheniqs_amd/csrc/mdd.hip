@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_kernel(StageArgs args) {
                         if(j < L) {
                             const uint32_t c = (cw >> (8 * k)) & 0xffu;
                             const uint32_t q = (qw >> (8 * k)) & 0xffu;
-                            if((d.segment_end_bits >> j) & 1u) { seen = false; }
+                            if((d.segment_end_bits[j >> 5] >> (j & 31)) & 1u) { seen = false; }
                             seen = seen || (c != 0) || (q != 0);
                             const uint32_t flag = 1u << (4 * (j & 7));
                             observed[j >> 3] |= (c & 0xfu) << (4 * (j & 7));
@@ -388,7 +388,12 @@ int launch_mdd(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid,
         case 2: PHQ_LAUNCH_MDD(2) break;
         case 3: PHQ_LAUNCH_MDD(3) break;
         case 4: PHQ_LAUNCH_MDD(4) break;
-        default: return static_cast<int>(hipErrorInvalidValue);
+        default:
+            // barcodes of 33 to 128 nt (the reference's loops take any length, sequence.h:90-98): the same kernel over 8 or 16
+            // packed words, the segments at run time
+            if(host_decoder.n_word <= 8) { hipLaunchKernelGGL((mdd_kernel<8, 0>), grid, dim3(BLOCK), lds_bytes, stream, args); }
+            else if(host_decoder.n_word <= DEV_MAX_WORD) { hipLaunchKernelGGL((mdd_kernel<16, 0>), grid, dim3(BLOCK), lds_bytes, stream, args); }
+            else { return static_cast<int>(hipErrorInvalidValue); }
     }
 #undef PHQ_LAUNCH_MDD
     return static_cast<int>(hipGetLastError());

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
             if(j < L) {
 #pragma unroll
                 for(int k = 0; k < DEV_MAX_SEGMENT; ++k) { if(k == s) { segment_flags[k] |= 1u << low_bit(j); } }
-                if((d.segment_end_bits >> j) & 1u) { ++s; }
+                if((d.segment_end_bits[j >> 5] >> (j & 31)) & 1u) { ++s; }
             }
         }
     }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void mdd_scan_kernel(StageArgs args) {
             if(j < L) {
                 const uint32_t c = (code_words[j >> 2] >> (8 * (j & 3))) & 0xffu;
                 const uint32_t q = (quality_words[j >> 2] >> (8 * (j & 3))) & 0xffu;
-                if((d.segment_end_bits >> j) & 1u) { seen = false; }
+                if((d.segment_end_bits[j >> 5] >> (j & 31)) & 1u) { seen = false; }
                 seen = seen || (c != 0) || (q != 0);
                 const uint32_t two = (0x30210u >> (2 * (c & 0xfu))) & 3u;
                 observed |= ((two & 1u) << low_bit(j)) | ((two >> 1) << high_bit(j));

@@ -15,8 +15,11 @@ int launch_pamld_literal_l32(const StageArgs&, const DevDecoder&, dim3, size_t, 
 
 bool pamld_exact_lanes_ties(const StageArgs&, const DevDecoder&, size_t);       // pamld_exact_lanes.hip: its first pass settles tied noise reads
 
+int launch_pamld_literal_long(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
+
 int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     const int L = host_decoder.nucleotide_cardinality;
+    if(L > DEV_TIER_NUCLEOTIDE) { return launch_pamld_literal_long(args, host_decoder, grid, lds_bytes, stream); }
     if(L <= 8) { return launch_pamld_literal_l8(args, host_decoder, grid, lds_bytes, stream); }
     if(L <= 16) { return launch_pamld_literal_l16(args, host_decoder, grid, lds_bytes, stream); }
     if(L <= 24) { return launch_pamld_literal_l24(args, host_decoder, grid, lds_bytes, stream); }
@@ -24,7 +27,8 @@ int launch_pamld_literal(const StageArgs& args, const DevDecoder& host_decoder, 
 }
 
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
-    if(mode != MODE_FAST) { return false; }
+    // barcodes of 33 to 128 nt: the general kernels on every read (the reference is length agnostic, barcode.h:147-161; no tier is)
+    if(mode != MODE_FAST || host_decoder.nucleotide_cardinality > DEV_TIER_NUCLEOTIDE) { return false; }
     return (host_decoder.algorithm == 1 && (pamld_tiny_supports(host_decoder) || pamld_lut_supports(host_decoder) || pamld_cross_supports(host_decoder) || pamld_wide_supports(host_decoder))) ||
            (host_decoder.algorithm == 2 && mdd_exact_supports(host_decoder));
 }
@@ -229,12 +233,13 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
             }
             {
-                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel (every read)");
+                Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, host_decoder.nucleotide_cardinality > DEV_TIER_NUCLEOTIDE ? "pamld_literal_long_kernel (every read)" : "pamld_literal_kernel (every read)");
                 return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
             }
         case 2: {
-            const bool paired = mdd_pair_supports(host_decoder);
-            const bool crossed = !paired && mdd_cross2_supports(host_decoder);
+            const bool general = host_decoder.nucleotide_cardinality > DEV_TIER_NUCLEOTIDE;
+            const bool paired = !general && mdd_pair_supports(host_decoder);
+            const bool crossed = !general && !paired && mdd_cross2_supports(host_decoder);
             if(mode == MODE_FAST && args.result != nullptr && (paired || crossed || mdd_near_supports(host_decoder)) && stage_uses_worklist(host_decoder, mode)) {
                 // one table lookup per read — per segment for a paired codec — (mdd_near.hpp); the scan kernel on the few reads it
                 // cannot finish (same grid)
@@ -259,7 +264,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }
                 return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s);
             }
-            if(mode == MODE_FAST && mdd_fused_supports(host_decoder)) {
+            if(mode == MODE_FAST && !general && mdd_fused_supports(host_decoder)) {
                 // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
                 Timed timed(timer, KERNEL_MDD, stream, "mdd_fused_kernel");
                 const int64_t fused_blocks = share(GRID_SHARE_MDD_FUSED);

@@ -39,16 +39,16 @@ ALLOW = (
     ("single", lambda L, N, priors: L <= 10 and N > 512 and priors == "estimated", "513 to 1 024 barcodes of up to 10 nt with priors that differ: the list kernel's records with their prior ratios do not fit a CU"),
     ("single", lambda L, N, priors: L <= 8 and N > 288 and priors == "estimated", "289 to 512 barcodes of up to 8 nt with priors that differ: past the streaming kernel's blocks, and the list kernel's records with prior ratios do not fit"),
     ("single", lambda L, N, priors: crowded(L, N), "words the grid could not draw three mismatches apart (4^L too small): no list or distance bound certifies anything, the product form is the first kernel"),
-    ("paired", lambda L, N, priors: 2 * L > 32, "pairs of 20 + 20 nt: refused, 40 positions are past the 32 flag bits of a barcode's mismatch word"),
+    ("paired", lambda L, N, priors: 2 * L > 32, "pairs of 20 + 20 nt: 40 positions are past the 32 every tier stops at; the general literal kernel (pamld_literal_long.hip) walks every barcode for every read"),
     ("paired", lambda L, N, priors: N > 1024, "more than 1 024 pairs: the paired tier's records do not fit a workgroup"),
     ("paired", lambda L, N, priors: L == 6 and N >= 96, "pairs of 6 + 6 nt: 96 and more sit closer than the six mismatches the paired tier's bound needs for half of them"),
     ("paired", lambda L, N, priors: crowded(L, N), "index words the grid could not draw three mismatches apart: pairs closer than six mismatches"),
-    ("combinatorial2", lambda L, N, priors: 2 * L > 32, "two segments of 20 nt: refused, 40 positions"),
+    ("combinatorial2", lambda L, N, priors: 2 * L > 32, "two segments of 20 nt: 40 positions, the general literal kernel for every read"),
     ("combinatorial2", lambda L, N, priors: L > 10, "two segment sets of 12 and 16 nt words: the streaming kernel of sets tables words of 8 to 10 nt; the factorised product form is the first kernel"),
     ("combinatorial2", lambda L, N, priors: L == 6 and N > 256, "two segment sets of 6 nt words past a plate: under the streaming kernel of sets' 8 nt"),
     ("combinatorial2", lambda L, N, priors: L == 8 and 170 <= N <= 400, "14 to 20 words of 8 nt a segment: a plate whose histogram does not fit beside its tables, too few words for the sets' lists"),
     ("combinatorial2", lambda L, N, priors: L == 10 and N <= 256, "up to 16 words of 10 nt a segment: plates are 4 to 8 nt; the factorised product form (15-19 Greads/s) is the first kernel"),
-    ("combinatorial3", lambda L, N, priors: True, "three segment sets: no tier 0 yet (DESIGN.md §7); the factorised product form (8-17 Greads/s) with uniform priors, the two word one with priors that differ"),
+    ("combinatorial3", lambda L, N, priors: True, "three segment sets: no tier 0 yet (DESIGN.md §7); the factorised product form (8-17 Greads/s) with uniform priors, the two word one with priors that differ; past 32 nt (3 x 12 and more) the general literal kernel for every read"),
 )
 
 

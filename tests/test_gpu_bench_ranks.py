@@ -29,3 +29,10 @@ def test_bench_with_two_ranks_prints_a_whole_job_line(bench_ranks_run):
     assert line["config"]["ranks_share_device"] is True
     roofline = line["roofline"]                      # per rank: the dominant kernel of rank 0 over its own reads
     assert roofline["bound"] == "hbm" and 0 < roofline["frac"] < 1 and roofline["kernel_ms"] > 0
+    # a scaling record can be read from the line alone: both ranks' clocks (the value is computed from the slowest one) and the
+    # all-reduce of the counters on its own
+    per_rank = line["per_rank"]
+    assert 0 < per_rank["ms_per_step"][0] <= per_rank["ms_per_step"][1]
+    assert abs(per_rank["ms_per_step"][1] - line["ms_per_step"]) < 1e-3 * line["ms_per_step"]
+    assert 0 < per_rank["classify_ms_per_step"][0] <= per_rank["classify_ms_per_step"][1] and per_rank["merge_ms"][1] > 0
+    assert line["merge_ms"] > 0

@@ -1151,6 +1151,56 @@ def test_single_index_sets_of_11_to_20_nt_under_mdd_take_the_paired_lookup_in_tw
 
 
 @pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
+@pytest.mark.parametrize("lengths,count,pairing", [((33,), 24, "zip"), ((40,), 96, "zip"), ((20, 20), 96, "zip"), ((20, 20), 6, "product"),
+                                                   ((12, 12, 12), 4, "product"), ((64,), 12, "zip"), ((100, 28), 8, "zip"), ((128,), 5, "zip")])
+def test_barcodes_of_33_to_128_nt_take_the_general_kernels(oracle, torch_cuda, algorithm, lengths, count, pairing):
+    """The reference loops over any barcode length and any segment array (barcode.h:147-161, sequence.h:90-98); every tier here
+    stops at 32 nt.  Past them a job is no longer refused: pamld_literal_long.hip walks every barcode for every
+    read with the literal kernel's arithmetic and argmax rules, mdd_kernel runs over 8 or 16 packed words — in both modes, with
+    bases outside ACGT, short reads (zero filled), a barcode letter outside ACGT (S7), quality masking and reads ON
+    barcodes at low qualities in the batch."""
+    rng = np.random.default_rng(sum(lengths) * 977 + count)
+    segments = [synthetic.barcode_set(rng, count, length, min_distance=5) for length in lengths]
+    total = sum(lengths)
+    if algorithm == "pamld" and total == 40 and len(lengths) == 1:
+        segments[0][3] = segments[0][3][:7] + "N" + segments[0][3][8:]          # not every barcode letter is one of A, C, G, T
+        segments[0] = sorted(segments[0])
+    tokens, start = [], 0
+    for length in lengths:
+        tokens.append("0:%d:%d" % (start, start + length))
+        start += length
+    extra = {}
+    if algorithm == "mdd":
+        extra = {"distance tolerance": [2] * len(lengths), "quality masking threshold": 10 if total % 2 == 0 else 0}
+    job = jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec(algorithm, segments, tokens, pairing=pairing, **extra)})
+    n = 6000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 21)
+    code[rng.random((n, total)) < 0.004] = 15
+    short = rng.integers(0, n, 40)
+    for k, i in enumerate(short):                          # what Rule::apply leaves of a read that ends early
+        keep = total - 1 - (k % 9)
+        code[i, keep:] = 0
+        quality[i, keep:] = 0
+    s, engine, got, words = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    s.set_mode(capi.MODE_FAST)
+    s.profile_enable(True)
+    run_gpu(torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST, device_set=s)
+    chain = [span["kernel"] for span in s.profile_chain()]
+    assert chain == ["pamld_literal_long_kernel (every read)" if algorithm == "pamld" else "mdd_kernel (every read)"], chain
+    assert int((got[0]["status"] == 0).sum()) > n // 2
+    s.close()
+
+
+def test_barcodes_past_128_nt_are_a_configuration_error():
+    """DEV_MAX_NUCLEOTIDE: 16 packed words of a barcode; the error is the reference's ErrorCode for a bad document (error.h:32-44)"""
+    rng = np.random.default_rng(4)
+    words = synthetic.barcode_set(rng, 4, 129, min_distance=5)
+    with pytest.raises(PheniqsError) as failure:
+        DecoderSet(jobspec.compile_job({"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::129"])}), device=0)
+    assert failure.value.code == 3 and "128" in str(failure.value)          # ErrorCode::CONFIGURATION_ERROR
+
+
+@pytest.mark.parametrize("algorithm", ["pamld", "mdd"])
 @pytest.mark.parametrize("length,count", [(1, 2), (2, 3), (4, 16), (5, 7), (8, 1), (8, 512), (8, 520), (8, 1024), (8, 1030), (12, 33),
                                           (16, 256), (16, 260), (16, 512), (16, 515), (32, 5),
                                           # round 5: past 512 packed words the product form stays the first tier (it was the literal

@@ -39,6 +39,8 @@ def test_every_grid_shape_takes_a_tier_0_kernel_or_is_on_the_allow_list(family, 
     assert chain, "no kernel ran"
     first = chain[0][0]
     names = [name for name, _ in chain]
-    assert not any("every read" in name for name in names), "the literal kernel took every read: %s" % names       # never again, allow list or not
+    long_barcode = sum(len(word) for word in next(iter(spec["sample"]["codec"].values()))["barcode"]) > 32
+    # never again, allow list or not — but for barcodes past 32 nt, where the general kernel is what keeps the job from being refused
+    assert long_barcode or not any("every read" in name for name in names), "the literal kernel took every read: %s" % names
     if not any(first.startswith(name) for name in shape_grid.TIER0):
         assert reason is not None, "first kernel %s is no tier 0 and the shape is not on the allow list (chain: %s)" % (first, names)
