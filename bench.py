@@ -483,14 +483,15 @@ class Workload:
         if world > 1:
             # every rank's own clock and its own HIP event time, so that a scaling record can be read from the line alone: the
             # value is computed from the slowest rank (MAX), the spread says whether a rank or the merge holds the others up
-            mine = torch.tensor([elapsed, classify_ms, merge_ms], dtype=torch.float64, device=self.device)
-            every = [torch.zeros_like(mine) for _ in range(world)]
-            torch.distributed.all_gather(every, mine)
-            table = np.array([t.cpu().numpy() for t in every])
-            elapsed = float(table[:, 0].max())
-            per_rank = {"ms_per_step": [float(table[:, 0].min() / steps * 1e3), float(table[:, 0].max() / steps * 1e3)],
-                        "classify_ms_per_step": [float(table[:, 1].min()), float(table[:, 1].max())],
-                        "merge_ms": [float(table[:, 2].min()), float(table[:, 2].max())], "are": "[fastest rank, slowest rank]"}
+            slowest = torch.tensor([elapsed, classify_ms, merge_ms], dtype=torch.float64, device=self.device)
+            fastest = slowest.clone()
+            torch.distributed.all_reduce(slowest, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(fastest, op=torch.distributed.ReduceOp.MIN)
+            low, high = fastest.cpu().numpy(), slowest.cpu().numpy()
+            elapsed = float(high[0])
+            per_rank = {"ms_per_step": [float(low[0] / steps * 1e3), float(high[0] / steps * 1e3)],
+                        "classify_ms_per_step": [float(low[1]), float(high[1])],
+                        "merge_ms": [float(low[2]), float(high[2])], "are": "[fastest rank, slowest rank]"}
         # the dominant kernel KIND: all its launches of one step together (a job with several decoders launches it
         # once per decoder; the bytes below are the whole job's)
         dominant = max(kernels, key=lambda name: kernels[name]["ms"])

@@ -28,6 +28,7 @@
 #include <zlib.h>
 
 #include "gzip_members.hpp"
+#include "gzip_stream.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -624,7 +625,14 @@ struct OutputSink {
         const uint64_t page = static_cast<uint64_t>(::sysconf(_SC_PAGESIZE));
         window_base = at / page * page;
         window_size = static_cast<size_t>(at + size - window_base);
-        if(::ftruncate(descriptor, static_cast<off_t>(at + size)) != 0) { throw IOError("error writing " + feed.path); }
+        // The file grows by ONE fallocate: the pages of the new range are allocated in a single walk (tmpfs: 11 GB/s on a thread of
+        // this pool's hosts) and the workers' stores then take minor faults, sixteen pages each, at the memory's pace — where a
+        // mapping of a merely truncated file allocates page by page inside the faults, every thread on the same tree and lock:
+        // 3.6-4.0 GB/s on 8 or 16 threads against 5.9 / 9.1 (profiles/tools/micro/file_write.cpp, profiles/r06_file_write.txt;
+        // one thread's plain write() is 6.3, sixteen threads' pwrite() 3.4-5.5: writes to one file serialise on its lock).
+        if(::fallocate(descriptor, 0, static_cast<off_t>(at), static_cast<off_t>(size)) != 0) {
+            if(::ftruncate(descriptor, static_cast<off_t>(at + size)) != 0) { throw IOError("error writing " + feed.path); }      // a file system without fallocate
+        }
         void* mapped = ::mmap(nullptr, window_size, PROT_READ | PROT_WRITE, MAP_SHARED, descriptor, static_cast<off_t>(window_base));
         if(mapped == MAP_FAILED) { window = nullptr; return nullptr; }
         window = static_cast<char*>(mapped);
@@ -911,6 +919,7 @@ struct PlainFile {                     // an input file of the device path: plai
     double bytes_per_record = 0;
     gzFile zipped = nullptr;
     std::unique_ptr<MemberInflater> members;      // gzip of several members (BGZF blocks, concatenated members): inflated member parallel, a batch ahead (gzip_members.hpp)
+    std::unique_ptr<GzipStream> stream;           // gzip of one member (or a few large ones): the streaming form of the same decoder (gzip_stream.hpp); gzread where neither opens
     bool ended = false;                // gzip: the stream has no more bytes
     size_t held = 0;                   // gzip: bytes of text at the front of the round's pinned buffer
     std::vector<uint8_t> head;         // gzip: the text inflated while the file was looked at, until the first round takes it
@@ -1149,7 +1158,16 @@ bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file)
                 try { inflated = static_cast<int>(p.members->read(p.head.data(), p.head.size())); }
                 catch(const std::exception&) { p.members.reset(); inflated = -1; }
             }
-            if(!p.members) { inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size())); }
+            static const bool only_zlib = std::getenv("PHQ_GZIP_ZLIB") != nullptr;
+            if(!p.members && !one_thread && !only_zlib) {
+                // one member: a sequential stream, through fast_inflate.hpp's decoder in its streaming form (gzip_stream.hpp)
+                p.stream.reset(new GzipStream());
+                try {
+                    if(p.stream->open(plan.input_feed[static_cast<size_t>(f)].path)) { inflated = static_cast<int>(p.stream->read(p.head.data(), p.head.size())); }
+                    else { p.stream.reset(); }
+                } catch(const std::exception&) { p.stream.reset(); inflated = -1; }
+            }
+            if(!p.members && !p.stream) { inflated = gzread(p.zipped, p.head.data(), static_cast<unsigned>(p.head.size())); }
             if(inflated < 4) { return false; }
             p.head.resize(static_cast<size_t>(inflated));
             std::memcpy(head, p.head.data(), p.head.size());
@@ -1212,7 +1230,6 @@ int32_t quality_control_cycles(const RecordPlan& plan, const uint32_t* longest, 
 // the pieces of a single one) side by side.
 void write_round_text(const std::vector<OutputSink*>& to, const char* from, const unsigned long long* base_of_sink, int threads) {
     const int64_t n_sink = static_cast<int64_t>(to.size());
-    const int workers = std::max(1, threads / 2);
     if(n_sink == 1) {
         OutputSink& sink = *to[0];
         const size_t bytes = static_cast<size_t>(base_of_sink[1]);
@@ -1231,7 +1248,7 @@ void write_round_text(const std::vector<OutputSink*>& to, const char* from, cons
         }
         char* const window = (sink.seekable && bytes >= (1u << 20)) ? sink.map_more(bytes) : nullptr;
         if(window == nullptr) { sink.write(from, bytes); return; }
-        parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, workers, [&](int64_t first, int64_t last, int) {
+        parallel_ranges(static_cast<int64_t>((bytes + (1 << 20) - 1) >> 20), 1, threads, [&](int64_t first, int64_t last, int) {
             const size_t begin = static_cast<size_t>(first) << 20;
             const size_t end = std::min(bytes, static_cast<size_t>(last) << 20);
             std::memcpy(window + begin, from + begin, end - begin);
@@ -1513,8 +1530,9 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                     while(!p.ended && p.held < want) {
                         int got;
                         try {
-                            got = p.members ? static_cast<int>(p.members->read(to + p.held, std::min<size_t>(want - p.held, size_t(1) << 30)))
-                                            : gzread(p.zipped, to + p.held, static_cast<unsigned>(std::min<size_t>(want - p.held, size_t(1) << 30)));
+                            const size_t room = std::min<size_t>(want - p.held, size_t(1) << 30);
+                            got = p.members ? static_cast<int>(p.members->read(to + p.held, room)) : p.stream ? static_cast<int>(p.stream->read(to + p.held, room))
+                                            : gzread(p.zipped, to + p.held, static_cast<unsigned>(room));
                         } catch(const std::exception&) { got = -1; }       // a member that does not inflate to what it states: the host reader takes the file
                         if(got < 0) { failed = true; return; }
                         if(got == 0) { p.ended = true; break; }

@@ -506,6 +506,67 @@ def test_gzip_members_inflate_in_parallel_to_the_same_text(tmp_path):
     assert run(wrapped + gzip.compress(text[:1000], 6), compare=False).returncode == 4
 
 
+def test_a_single_member_gzip_stream_inflates_to_the_same_text(tmp_path):
+    """gzip_stream.hpp under ASan + UBSan: fast_inflate.hpp's decoder in streaming form — 1 MiB of work buffer behind 32 KiB of
+    history, resumed inside blocks — gives the text of single member files of every zlib level and strategy (stored, fixed and
+    dynamic blocks; FASTQ text, bytes that do not compress, long runs), of a few large members one behind another, and of a file
+    with bytes behind its last member (gzread ends the text there too); a block handed to zlib part way (the decoder's refusal,
+    forced at block 0, 1, 7) continues from the history and the bit offset of that block; damaged, cut and CRC-less files are IO
+    errors (fastq.h:427-440 reads these files through htslib)."""
+    import gzip
+    import subprocess
+    import zlib
+
+    import numpy as np
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
+    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    if built.returncode != 0:
+        assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
+        pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
+    check = os.path.join(csrc, "build", "gzip_stream_check_asan")
+    rng = np.random.default_rng(12)
+    records = []
+    for k in range(24000):                      # 3.4 MB: several work buffers of a MiB
+        length = int(rng.integers(30, 90))
+        records.append(b"@M:1:FC:1:1101:%07d:%05d 1:N:0:1\n" % (k, k % 77777) + bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), length, p=[.24, .25, .25, .25, .01])) + b"\n+\n" +
+                       bytes(rng.choice(np.frombuffer(b"#-:F", dtype=np.uint8), length, p=[.03, .07, .1, .8])) + b"\n")
+    fastq = b"".join(records)
+    texts = {"fastq": fastq, "random": rng.integers(0, 256, (1 << 20) + 77777, dtype=np.uint8).tobytes(), "run": b"F" * ((1 << 20) + 5000) + fastq[:100000] + b"G" * 70000,
+             "empty": b"", "byte": b"x"}
+
+    def run(data, text, *more):
+        path, expected = tmp_path / "input.gz", tmp_path / "text"
+        path.write_bytes(data)
+        expected.write_bytes(text)
+        return subprocess.run([check, str(path), str(expected)] + [str(m) for m in more], capture_output=True, text=True)
+
+    for name, text in texts.items():
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED),
+                                (6, zlib.Z_HUFFMAN_ONLY), (3, zlib.Z_RLE), (9, zlib.Z_FILTERED)):
+            if True:
+                packer = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+                ran = run(packer.compress(text) + packer.flush(), text)
+                assert ran.returncode == 0 and " zlib 0" in ran.stdout, (name, level, strategy, ran.stdout, ran.stderr[-500:])
+    packed = gzip.compress(fastq, 6)
+    for block in (0, 1, 7):
+        ran = run(packed, fastq, block)
+        assert ran.returncode == 0 and " zlib 1" in ran.stdout, (block, ran.stdout, ran.stderr[-500:])
+    thirds = [fastq[:len(fastq) // 3], fastq[len(fastq) // 3:len(fastq) // 2], fastq[len(fastq) // 2:]]
+    assert run(b"".join(gzip.compress(part, level) for part, level in zip(thirds, (1, 9, 5))), fastq).returncode == 0      # cat a.gz b.gz c.gz
+    assert run(packed + bytes(1000), fastq).returncode == 0                                  # padding behind the member
+    damaged = bytearray(packed)
+    damaged[len(packed) // 2] ^= 0x10
+    assert run(bytes(damaged), fastq).returncode in (4, 5)                                    # an error — or, rarely, other text that then fails its CRC: 4
+    assert run(bytes(damaged), fastq).returncode == 4
+    damaged = bytearray(packed)
+    damaged[-6] ^= 0xff                                                                       # the CRC
+    assert run(bytes(damaged), fastq).returncode == 4
+    assert run(packed[:len(packed) // 2], fastq).returncode == 4                              # cut short
+    assert run(packed[:-3], fastq).returncode == 4
+    assert run(fastq, fastq).returncode == 3                                                  # not gzip
+
+
 def test_the_one_shot_inflate_against_zlib_under_sanitizers():
     """csrc/fast_inflate.hpp (RFC 1951 / 1952) under ASan + UBSan: 800 gzip members — empty, one byte, FASTQ text, random bytes, a
     long run, short periods, noisy text, far matches; zlib levels 0 to 9, every strategy (stored, fixed and dynamic blocks) — come
