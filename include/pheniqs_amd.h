@@ -50,6 +50,12 @@ extern "C" {
                                            reference's, the posterior within 1e-8 of it; the contract is 1e-6) and handing the
                                            others on, down to the literal kernel; MDD: table lookups, the rest scanned */
 
+#define PHQ_MODE_AUTO               2   /* the default: PHQ_MODE_FAST — but a phq_transcode_* run that writes SAM records of a job of at
+                                           most 4 096 (barcode, position) cells a read over its PAMLD decoders classifies those decoders in
+                                           PHQ_MODE_LITERAL, so that XB / XM / XC, which print float(1 - posterior) to six digits
+                                           (read.h:187-199, auxiliary.cpp:327-354), carry the reference's own digits: 1e-8 of the
+                                           posterior is the fourth digit of a 1e-5 tag.  phq_set_mode(PHQ_MODE_FAST) keeps such a run fast */
+
 #define PHQ_DEVICE_NONE            (-1) /* host only set: configuration, staging, statistics, report */
 
 /* What one PAMLD / MDD decoder leaves on a read: the members Decoder<T>/PamlDecoder<T> hold after
@@ -116,7 +122,7 @@ const char* phq_last_error(const phq_decoder_set* set);                    /* Er
 
 int phq_get_layout(const phq_decoder_set* set, phq_layout_t* layout);
 int phq_get_decoder_info(const phq_decoder_set* set, int32_t decoder, phq_decoder_info_t* info);
-int phq_set_mode(phq_decoder_set* set, int32_t mode);                      /* PHQ_MODE_*, default PHQ_MODE_FAST */
+int phq_set_mode(phq_decoder_set* set, int32_t mode);                      /* PHQ_MODE_*, default PHQ_MODE_AUTO */
 
 /* ---- extraction -----------------------------------------------------------------------------------
  * Rule::apply(const Read&, Observation&) for every decoder (transform.h:142-169 with

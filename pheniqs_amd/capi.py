@@ -19,6 +19,7 @@ OPTION_DTYPE = np.dtype([("count", "<u8"), ("pf_count", "<u8"), ("accumulated_di
 
 MODE_LITERAL = 0
 MODE_FAST = 1
+MODE_AUTO = 2
 DEVICE_NONE = -1
 
 # every symbol include/pheniqs_amd.h declares

@@ -113,7 +113,7 @@ static Json compiled_document(const std::string& text) {
 DecoderSet::DecoderSet(const std::string& compiled_job_json, int32_t device) :
     job_(JobConfig::from_json(compiled_document(compiled_job_json))),
     device_(device),
-    mode_(MODE_FAST),
+    mode_(MODE_AUTO),
     max_blocks_(2048),
     device_decoder_(nullptr),
     device_stats_(nullptr),
@@ -188,8 +188,17 @@ void DecoderSet::require_device() const {
 }
 
 void DecoderSet::set_mode(int32_t mode) {
-    if(mode != MODE_LITERAL && mode != MODE_FAST) { throw ConfigurationError("unknown classification mode " + std::to_string(mode)); }
+    if(mode != MODE_LITERAL && mode != MODE_FAST && mode != MODE_AUTO) { throw ConfigurationError("unknown classification mode " + std::to_string(mode)); }
     mode_ = mode;
+}
+
+// (barcode, position) cells a read costs the literal kernel, over the job's PAMLD decoders (SURVEY.md §8d's secondary figure)
+int64_t DecoderSet::literal_cells_per_read() const {
+    int64_t cells = 0;
+    for(const auto& c : job_.decoder) {
+        if(c.algorithm == Algorithm::PAMLD) { cells += static_cast<int64_t>(c.codec.size()) * static_cast<int64_t>(c.nucleotide_cardinality); }
+    }
+    return cells;
 }
 
 // The tables of the neighbour list kernels (pamld_near.hpp) for N words of L nucleotides given as code bit planes (bit j =
@@ -1391,7 +1400,7 @@ size_t DecoderSet::carry_words(int64_t n_read) const {
 }
 
 bool DecoderSet::needs_worklist() const {
-    for(const auto& d : host_decoder_) { if(stage_uses_worklist(d, mode_)) { return true; } }
+    for(const auto& d : host_decoder_) { if(stage_uses_worklist(d, mode_ == MODE_LITERAL ? MODE_LITERAL : MODE_FAST)) { return true; } }
     return false;
 }
 
@@ -1429,7 +1438,9 @@ void DecoderSet::run_stages(int64_t batch_capacity, int64_t first_read, int64_t 
         args.echo_count = static_cast<int32_t>(folded);
         for(size_t e = 0; e < folded; ++e) { args.echo_offset[e] = host_decoder_[k + 1 + e].stats_offset; }
         if(timer_) { timer_->decoder = static_cast<int32_t>(k); }
-        check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], mode_, max_blocks_, stream, timer_)), "kernel launch");
+        // (MDD is integer work in either mode: only PAMLD stages turn literal for exact records)
+        const int32_t stage_mode = (mode_ == MODE_AUTO && host_decoder_[k].algorithm != 1) ? static_cast<int32_t>(MODE_FAST) : effective_mode();
+        check(static_cast<hipError_t>(launch_stage(args, host_decoder_[k], stage_mode, max_blocks_, stream, timer_)), "kernel launch");
         k += folded;
     }
 }

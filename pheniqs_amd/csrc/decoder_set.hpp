@@ -28,6 +28,11 @@ public:
     const JobConfig& job() const { return job_; }
     int32_t device() const { return device_; }
     void set_mode(int32_t mode);
+    int32_t mode() const { return mode_; }
+    // what MODE_AUTO means right now: literal while a transcoding run that writes SAM records of a small job holds the set (device_types.hpp)
+    int32_t effective_mode() const { return mode_ != MODE_AUTO ? mode_ : records_exact_ ? MODE_LITERAL : MODE_FAST; }
+    void set_records_exact(bool on) { records_exact_ = on; }
+    int64_t literal_cells_per_read() const;
 
     // Rule::apply + pre-filters + incoming counters (see include/pheniqs_amd.h phq_stage_reads)
     void stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* const* code, const uint8_t* const* quality,
@@ -91,6 +96,7 @@ private:
     JobConfig job_;
     int32_t device_;
     int32_t mode_;
+    bool records_exact_ = false;
     int32_t max_blocks_;
     std::vector<DevDecoder> host_decoder_;      // host copies holding DEVICE table pointers
     DevDecoder* device_decoder_;                // device array, one per decoder

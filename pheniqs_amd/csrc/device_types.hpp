@@ -265,7 +265,12 @@ struct DevDecoder {
     double cross_prior_max;               // the largest prior
 };
 
-enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1 };
+// MODE_AUTO (the default): MODE_FAST, but for a transcoding run that writes SAM records of a job small enough for it, which takes
+// MODE_LITERAL: XB / XM / XC print float(1 - posterior) to six digits (read.h:187-199, auxiliary.cpp:327-354), and 1e-8 of the
+// posterior is the fourth digit of a 1e-5 tag — with the literal kernel's posterior (the reference's to ~1e-16) the records are the
+// reference's byte for byte
+enum LaunchMode : int32_t { MODE_LITERAL = 0, MODE_FAST = 1, MODE_AUTO = 2 };
+constexpr int64_t RECORD_LITERAL_CELLS = 4096;      // ... "small enough": at most this many (barcode, position) cells a read over the job's PAMLD decoders (C2 768, C4 2 880, C5 2 328; C3's 184 320 stay fast)
 
 // One decoder stage over reads [0, n_read) of its planes.
 struct StageArgs {

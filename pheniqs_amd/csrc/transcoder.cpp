@@ -1867,6 +1867,19 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         channel_silent[c] = silent ? 1 : 0;
         all_silent = all_silent && silent;
     }
+    // MODE_AUTO (device_types.hpp): a run that writes SAM records of a small job classifies in the literal kernel's arithmetic, so
+    // that XB / XM / XC print the reference's own digits (read.h:187-199); FASTQ records carry no posterior and stay fast
+    bool writes_sam = false;
+    for(const auto& sink : m.sink) { writes_sam = writes_sam || (!sink.null && sink.feed.format == FileFormat::SAM); }
+    struct ExactRecords {
+        std::vector<DecoderSet*> sets;
+        ~ExactRecords() { for(DecoderSet* set : sets) { set->set_records_exact(false); } }
+    } exact_records;
+    if(writes_sam && m.set.literal_cells_per_read() <= RECORD_LITERAL_CELLS) {
+        exact_records.sets.push_back(&m.set);
+        exact_records.sets.insert(exact_records.sets.end(), m.copy.begin(), m.copy.end());
+        for(DecoderSet* set : exact_records.sets) { set->set_records_exact(true); }
+    }
     // nothing is written: the FASTQ text is decoded on the device when it can be (plain files, no pre-filters); a file that
     // holds anything out of the ordinary sends the whole run through the host reader below
     if(all_silent && !job.enable_quality_control) {
