@@ -1,4 +1,4 @@
-// GzipStream (gzip_stream.hpp) on the CPU, under ASan + UBSan: gzip_stream_check FILE [expected text FILE [block to refuse]]
+// GzipStream (gzip_stream.hpp) on the CPU, under ASan + UBSan: gzip_stream_check FILE [expected text FILE | - [block to refuse | -1 [threads]]]
 //   exit 0 and "stream bytes T crc C zlib Z": the file inflated to T bytes (compared with the expected text when one is given),
 //   read back in pieces of uneven sizes; Z = members handed to zlib part way; exit 3: not a gzip file; exit 4: an IOError
 //   (damaged data, a CRC or size that does not hold, a stream that ends early).  tests/test_capi_cpu.py drives it.
@@ -14,7 +14,7 @@ int main(int argc, char** argv) {
     if(argc < 2) { return 2; }
     if(argc > 3) { phq::fast_inflate::RawStream::refuse_block() = std::atol(argv[3]); }
     phq::GzipStream stream;
-    if(!stream.open(argv[1])) { std::printf("not taken\n"); return 3; }
+    if(!stream.open(argv[1], argc > 4 ? std::atoi(argv[4]) : 1)) { std::printf("not taken\n"); return 3; }
     std::vector<uint8_t> text;
     size_t piece = 1;
     try {
@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
         const std::vector<uint8_t> expected((std::istreambuf_iterator<char>(expected_file)), std::istreambuf_iterator<char>());
         if(expected != text) { std::printf("text differs: %zu bytes, expected %zu\n", text.size(), expected.size()); return 5; }
     }
-    std::printf("stream bytes %zu crc %lu zlib %llu\n", text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())), static_cast<unsigned long long>(phq::GzipStream::through_zlib()));
+    std::printf("stream bytes %zu crc %lu zlib %llu chunks %llu dropped %llu\n", text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())), static_cast<unsigned long long>(phq::GzipStream::through_zlib()),
+                static_cast<unsigned long long>(phq::GzipStream::chunks_taken()), static_cast<unsigned long long>(phq::GzipStream::chunks_dropped()));
     return 0;
 }

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -32,19 +33,27 @@
 
 #include "error.hpp"
 #include "fast_inflate.hpp"
+#include "host_parallel.hpp"
 
 namespace phq {
 namespace fast_inflate {
 
 class RawStream {
 public:
-    enum class Status { ROOM, END, DAMAGED, REFUSED };
+    enum class Status { ROOM, END, DAMAGED, REFUSED, BOUNDARY };
     static constexpr size_t MARGIN = 320;          // room the unchecked loop wants ahead: the longest match, three literals, the copies' overshoot
 
-    void start(const uint8_t* in, const uint8_t* in_end) {
-        in_next_ = in; in_end_ = in_end; bits_ = 0; held_ = 0; blocks_ = 0; last_ = false; in_block_ = false; stored_ = false; stored_left_ = 0; finished_ = false;
+    // the stream starts `bit` bits into `in` (at a block header)
+    void start(const uint8_t* in, const uint8_t* in_end, uint64_t bit = 0) {
+        origin_ = in; in_next_ = in + (bit >> 3); in_end_ = in_end; bits_ = 0; held_ = 0; blocks_ = 0; last_ = false; in_block_ = false; stored_ = false; stored_left_ = 0; finished_ = false;
         tables_ = nullptr;
+        stop_bit_ = ~uint64_t(0);
+        if((bit & 7) != 0 && in_next_ < in_end_) { bits_ = static_cast<uint64_t>(*in_next_++) >> (bit & 7); held_ = 8 - static_cast<int>(bit & 7); }
     }
+    // bits of the stream taken so far
+    uint64_t bit_position() const { return static_cast<uint64_t>(in_next_ - origin_) * 8u - static_cast<uint64_t>(held_); }
+    // run() returns BOUNDARY in front of the first block header at or past this bit (gzip_parallel: the chunk behind starts there)
+    void stop_at(uint64_t bit) { stop_bit_ = bit; }
     bool finished() const { return finished_; }
     static long& refuse_block() { static long block = -1; return block; }      // a test seam: the block header with this ordinal is refused
     // the first byte behind the stream (after END of the last block): whole bytes the bit buffer still holds were not the stream's
@@ -82,11 +91,13 @@ public:
                 if(finished_) { return leave(Status::END); }
                 refill();
                 boundary_in_ = in_next; boundary_held_ = held;
+                if(static_cast<uint64_t>(in_next - origin_) * 8u - static_cast<uint64_t>(held) >= stop_bit_) { return leave(Status::BOUNDARY); }
                 if(held < 3) { return leave(Status::DAMAGED); }
                 const uint64_t bits_before = bits;
                 auto refuse = [&]() { in_next = boundary_in_; bits = bits_before; held = boundary_held_; return leave(Status::REFUSED); };
                 // (a refused header is read again by zlib from boundary_byte(): only in_next_ and the bit count matter to it)
-                if(blocks_++ == refuse_block()) { return refuse(); }       // (the check program: the hand over to zlib at a chosen block)
+                if(blocks_ == refuse_block()) { return refuse(); }         // (the check program: the hand over to zlib at a chosen block; refused again when asked again, as a real one is)
+                ++blocks_;
                 last_ = take(1) != 0;
                 const uint32_t type = take(2);
                 if(type == 0) {
@@ -282,8 +293,10 @@ private:
         return ready ? &fixed : nullptr;
     }
 
+    const uint8_t* origin_ = nullptr;
     const uint8_t* in_next_ = nullptr;
     const uint8_t* in_end_ = nullptr;
+    uint64_t stop_bit_ = ~uint64_t(0);
     uint64_t bits_ = 0;
     int held_ = 0;
     bool last_ = false, in_block_ = false, stored_ = false, finished_ = false;
@@ -294,6 +307,274 @@ private:
     const uint8_t* boundary_in_ = nullptr;
     int boundary_held_ = 0;
 };
+
+// ---- a single deflate stream on several threads ------------------------------------------------------------------------------
+// One thread inflates ~1 GB/s of FASTQ text; a file of one member gives the others nothing to do.  The way out (Kerbiriou and
+// Chikhi, "Parallel decompression of gzip-compressed files and random access to DNA sequences", 2019: pugz) is to start in the
+// MIDDLE of the stream: a deflate block can be decoded without what came before it, except that its matches may reach up to
+// 32 KiB back into text that is not known yet.  So a chunk that starts at a block header found by search is decoded into 16 bit
+// symbols — a literal, or a MARKER: "the byte at this place of the 32 KiB in front of the chunk" — matches copy markers like
+// literals, and when the chunk before has been resolved its last 32 KiB turn every marker into its byte.
+//   * find_block: the first bit position in a range where a dynamic, non final block header parses — the code length code, the
+//     literal / length code and the distance code all complete prefix codes — and its first symbols decode.  A false find costs
+//     nothing but time: a chunk is taken only when the chunk before ENDS exactly on its first bit.
+//   * marked_decode: from such a position to the first block header at or past a stop bit (or the stream's end, or the end of
+//     its room: it then stops behind the last whole block).
+constexpr uint16_t MARKER = 0x8000u;               // symbol = MARKER | place in the 32 KiB window in front of the chunk
+constexpr size_t MARKED_WINDOW = size_t(1) << 15;
+
+struct BitReader {
+    const uint8_t* next = nullptr;
+    const uint8_t* end = nullptr;
+    uint64_t bits = 0;
+    int held = 0;
+    void refill() {
+        if(end - next >= 8) {
+            uint64_t word;
+            std::memcpy(&word, next, 8);
+            bits |= word << held;
+            next += (63 - held) >> 3;
+            held |= 56;
+        } else {
+            while(held <= 56 && next < end) { bits |= static_cast<uint64_t>(*next++) << held; held += 8; }
+        }
+    }
+    uint32_t take(int n) { const uint32_t v = static_cast<uint32_t>(bits & ((uint64_t(1) << n) - 1u)); bits >>= n; held -= n; return v; }
+    void seek(const uint8_t* origin, const uint8_t* limit, uint64_t bit) {
+        next = origin + (bit >> 3); end = limit; bits = 0; held = 0;
+        refill();
+        const int r = static_cast<int>(bit & 7);
+        bits >>= r; held -= r;
+    }
+    uint64_t position(const uint8_t* origin) const { return static_cast<uint64_t>(next - origin) * 8u - static_cast<uint64_t>(held); }
+};
+
+// the code lengths of a dynamic block (behind its three header bits) into tables; false: not a block this decoder takes
+inline bool read_dynamic_tables(BitReader& r, Tables& tables) {
+    static const uint8_t ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    r.refill();
+    if(r.held < 14) { return false; }
+    const int n_litlen = static_cast<int>(r.take(5)) + 257, n_dist = static_cast<int>(r.take(5)) + 1, n_pre = static_cast<int>(r.take(4)) + 4;
+    if(n_litlen > 286 || n_dist > 30) { return false; }
+    uint8_t pre_lengths[19] = {0};
+    r.refill();
+    for(int k = 0; k < n_pre; ++k) {
+        if(r.held < 3) { r.refill(); if(r.held < 3) { return false; } }
+        pre_lengths[ORDER[k]] = static_cast<uint8_t>(r.take(3));
+    }
+    uint32_t pre_table[128 + 8];
+    if(!build_table(pre_lengths, 19, 7, pre_table, 128 + 8, false, [](int symbol, uint32_t length) { return entry_of(static_cast<uint32_t>(symbol), LITERAL, 0, length); })) { return false; }
+    uint8_t lengths[286 + 30 + 138];
+    int at = 0;
+    while(at < n_litlen + n_dist) {
+        r.refill();
+        const uint32_t entry = pre_table[r.bits & 127u];
+        if(kind_of(entry) != LITERAL || static_cast<int>(entry & 31u) > r.held) { return false; }
+        r.take(static_cast<int>(entry & 31u));
+        const uint32_t symbol = entry >> 12;
+        if(symbol < 16) { lengths[at++] = static_cast<uint8_t>(symbol); continue; }
+        uint32_t repeat, value = 0;
+        if(symbol == 16) { if(at == 0) { return false; } value = lengths[at - 1]; repeat = 3 + r.take(2); }
+        else if(symbol == 17) { repeat = 3 + r.take(3); }
+        else { repeat = 11 + r.take(7); }
+        if(r.held < 0 || at + static_cast<int>(repeat) > n_litlen + n_dist) { return false; }
+        for(uint32_t k = 0; k < repeat; ++k) { lengths[at++] = static_cast<uint8_t>(value); }
+    }
+    if(lengths[256] == 0) { return false; }
+    return build_litlen(lengths, n_litlen, tables) && build_dist(lengths + n_litlen, n_dist, tables);
+}
+
+struct MarkedResult {
+    uint64_t end_bit = 0;          // the block header the chunk stopped in front of (or the first bit behind the stream's last block)
+    size_t made = 0;               // symbols, behind the window
+    bool ended = false;            // the stream's last block ended in this chunk
+    bool damaged = false;          // an invalid code or a block this decoder does not take: what was made up to the last whole block stands
+};
+
+// `buffer`: MARKED_WINDOW symbols of window (filled here with markers), then room for `capacity` symbols
+inline MarkedResult marked_decode(const uint8_t* origin, const uint8_t* limit, uint64_t begin_bit, uint64_t stop_bit, uint16_t* buffer, size_t capacity) {
+    static Tables fixed;
+    static const bool fixed_ready = []() {
+        uint8_t lengths[288];
+        for(int s = 0; s < 144; ++s) { lengths[s] = 8; }
+        for(int s = 144; s < 256; ++s) { lengths[s] = 9; }
+        for(int s = 256; s < 280; ++s) { lengths[s] = 7; }
+        for(int s = 280; s < 288; ++s) { lengths[s] = 8; }
+        uint8_t all[32];
+        for(int s = 0; s < 32; ++s) { all[s] = 5; }
+        return build_litlen(lengths, 288, fixed) && build_table(all, 32, DIST_BITS, fixed.dist, DIST_ENTRIES, true, [](int symbol, uint32_t length) {
+            return symbol > 29 ? entry_of(0, INVALID, 0, length) : entry_of(DIST_BASE[symbol], DISTANCE, DIST_EXTRA[symbol], length); });
+    }();
+    MarkedResult result;
+    result.end_bit = begin_bit;
+    for(size_t k = 0; k < MARKED_WINDOW; ++k) { buffer[k] = static_cast<uint16_t>(MARKER | k); }
+    uint16_t* const out_begin = buffer + MARKED_WINDOW;
+    uint16_t* out = out_begin;
+    uint16_t* const out_end = out_begin + capacity;
+    if(!fixed_ready) { result.damaged = true; return result; }
+    BitReader r;
+    r.seek(origin, limit, begin_bit);
+    std::unique_ptr<Tables> dynamic(new Tables);
+    constexpr uint32_t LITLEN_MASK = (1u << LITLEN_BITS) - 1u, DIST_MASK = (1u << DIST_BITS) - 1u;
+    for(;;) {
+        r.refill();
+        const uint64_t here = r.position(origin);
+        result.end_bit = here;
+        result.made = static_cast<size_t>(out - out_begin);
+        if(here >= stop_bit) { return result; }
+        if(r.held < 3) { result.damaged = true; return result; }
+        const bool last = r.take(1) != 0;
+        const uint32_t type = r.take(2);
+        const Tables* tables = &fixed;
+        if(type == 0) {
+            r.take(r.held & 7);
+            r.next -= r.held >> 3;
+            r.bits = 0; r.held = 0;
+            if(r.end - r.next < 4) { result.damaged = true; return result; }
+            const uint32_t length = static_cast<uint32_t>(r.next[0]) | (static_cast<uint32_t>(r.next[1]) << 8);
+            const uint32_t check = static_cast<uint32_t>(r.next[2]) | (static_cast<uint32_t>(r.next[3]) << 8);
+            r.next += 4;
+            if((length ^ check) != 0xffffu || static_cast<size_t>(r.end - r.next) < length) { result.damaged = true; return result; }
+            if(static_cast<size_t>(out_end - out) < length) { return result; }              // no room: the chunk ends in front of this block
+            for(uint32_t k = 0; k < length; ++k) { out[k] = r.next[k]; }
+            r.next += length; out += length;
+        } else {
+            if(type == 2) {
+                if(!read_dynamic_tables(r, *dynamic)) { result.damaged = true; return result; }
+                tables = dynamic.get();
+            } else if(type != 1) { result.damaged = true; return result; }
+            const uint32_t* const litlen = tables->litlen;
+            const uint32_t* const dist = tables->dist;
+            for(;;) {
+                if(static_cast<size_t>(out_end - out) < 258 + 3) { return result; }       // no room: what was made up to the block's header stands
+                r.refill();
+                uint32_t entry = litlen[r.bits & LITLEN_MASK];
+                if(kind_of(entry) <= LITERAL3) {
+                    // up to three entries of one to three literals behind one refill (3 x 11 bits)
+                    for(int round = 0; round < 3 && kind_of(entry) <= LITERAL3; ++round) {
+                        const uint32_t count = kind_of(entry) + 1u;
+                        out[0] = static_cast<uint16_t>((entry >> 8) & 0xffu);
+                        out[1] = static_cast<uint16_t>((entry >> 16) & 0xffu);
+                        out[2] = static_cast<uint16_t>((entry >> 24) & 0xffu);
+                        out += count;
+                        r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
+                        entry = litlen[r.bits & LITLEN_MASK];
+                    }
+                    if(r.held < 0) { result.damaged = true; return result; }
+                    continue;                                                               // (the entry looked at last is looked at again behind a refill)
+                }
+                if(kind_of(entry) == SUBTABLE) {
+                    entry = litlen[(entry >> 12) + ((r.bits >> LITLEN_BITS) & ((1u << extra_of(entry)) - 1u))];
+                    r.bits >>= LITLEN_BITS; r.held -= LITLEN_BITS;
+                }
+                uint32_t kind = kind_of(entry);
+                r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
+                if(r.held < 0) { result.damaged = true; return result; }
+                if(kind == LITERAL) { *out++ = static_cast<uint16_t>((entry >> 8) & 0xffu); continue; }
+                if(kind == END) { break; }
+                if(kind != LENGTH) { result.damaged = true; return result; }
+                const uint32_t length = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
+                if(r.held < 32) { r.refill(); }
+                entry = dist[r.bits & DIST_MASK];
+                if(kind_of(entry) == SUBTABLE) {
+                    entry = dist[(entry >> 12) + ((r.bits >> DIST_BITS) & ((1u << extra_of(entry)) - 1u))];
+                    r.bits >>= DIST_BITS; r.held -= DIST_BITS;
+                }
+                kind = kind_of(entry);
+                r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
+                if(kind != DISTANCE) { result.damaged = true; return result; }
+                const uint32_t distance = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
+                if(r.held < 0 || distance > static_cast<size_t>(out - buffer)) { result.damaged = true; return result; }
+                const uint16_t* from = out - distance;
+                if(distance >= 4) {
+                    uint16_t* to = out;
+                    uint16_t* const stop = out + length;
+                    do { uint64_t word; std::memcpy(&word, from, 8); std::memcpy(to, &word, 8); from += 4; to += 4; } while(to < stop);       // (up to three symbols past the match: the room check above)
+                } else {
+                    for(uint32_t k = 0; k < length; ++k) { out[k] = from[k]; }
+                }
+                out += length;
+            }
+        }
+        if(last) {
+            result.ended = true;
+            r.refill();
+            // (the first byte behind the stream: whole bytes the bit buffer holds were not the stream's)
+            result.end_bit = (static_cast<uint64_t>(r.next - origin) - static_cast<uint64_t>(r.held >> 3)) * 8u;
+            result.made = static_cast<size_t>(out - out_begin);
+            return result;
+        }
+    }
+}
+
+// the first bit in [from_bit, until_bit) where a dynamic, non final block header parses into complete codes and the block's first
+// symbols decode; false: none
+inline bool find_block(const uint8_t* origin, const uint8_t* limit, uint64_t from_bit, uint64_t until_bit, uint64_t* found) {
+    std::unique_ptr<Tables> tables(new Tables);
+    const uint64_t last_bit = static_cast<uint64_t>(limit - origin) * 8u;
+    for(uint64_t bit = from_bit; bit < until_bit && bit + 200 < last_bit; ++bit) {
+        const uint8_t* const at = origin + (bit >> 3);
+        if(limit - at < 24) { return false; }
+        uint64_t low, high;
+        std::memcpy(&low, at, 8);
+        std::memcpy(&high, at + 8, 8);
+        const int shift = static_cast<int>(bit & 7);
+        const uint64_t v = shift ? ((low >> shift) | (high << (64 - shift))) : low;
+        // BFINAL 0, BTYPE 2 (bits 1..2 = 10 binary, least significant first), HLIT <= 29, HDIST <= 29
+        if((v & 7u) != 4u) { continue; }
+        if(((v >> 3) & 31u) > 29u || ((v >> 8) & 31u) > 29u) { continue; }
+        const int n_pre = static_cast<int>((v >> 13) & 15u) + 4;
+        // the code length code: 3 bits a length from bit 17 — 57 bits at most, 47 of them in v — must be a complete prefix code
+        const uint64_t w = shift ? ((high >> shift) | 0) : high;           // bits 64.. of the candidate
+        uint32_t space = 0;
+        int used = 0;
+        for(int k = 0; k < n_pre; ++k) {
+            const int lo = 17 + 3 * k;
+            uint32_t l;
+            if(lo + 3 <= 64) { l = static_cast<uint32_t>((v >> lo) & 7u); }
+            else if(lo >= 64) { l = static_cast<uint32_t>((w >> (lo - 64)) & 7u); }
+            else { l = static_cast<uint32_t>(((v >> lo) | (w << (64 - lo))) & 7u); }
+            if(l) { space += 128u >> l; ++used; }
+        }
+        if(space != 128u || used < 2) { continue; }
+        BitReader r;
+        r.seek(origin, limit, bit + 3);
+        if(!read_dynamic_tables(r, *tables)) { continue; }
+        // the block's first symbols: no invalid code, no distance past the window
+        bool plausible = true;
+        size_t made = 0;
+        constexpr uint32_t LITLEN_MASK = (1u << LITLEN_BITS) - 1u, DIST_MASK = (1u << DIST_BITS) - 1u;
+        for(int symbol = 0; symbol < 512 && plausible; ++symbol) {
+            r.refill();
+            uint32_t entry = tables->litlen[r.bits & LITLEN_MASK];
+            if(kind_of(entry) == SUBTABLE) {
+                entry = tables->litlen[(entry >> 12) + ((r.bits >> LITLEN_BITS) & ((1u << extra_of(entry)) - 1u))];
+                r.bits >>= LITLEN_BITS; r.held -= LITLEN_BITS;
+            }
+            uint32_t kind = kind_of(entry);
+            r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
+            if(r.held < 0) { plausible = false; break; }
+            if(kind <= LITERAL3) { made += kind + 1u; continue; }
+            if(kind == END) { break; }
+            if(kind != LENGTH) { plausible = false; break; }
+            const uint32_t length = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
+            if(r.held < 32) { r.refill(); }
+            entry = tables->dist[r.bits & DIST_MASK];
+            if(kind_of(entry) == SUBTABLE) {
+                entry = tables->dist[(entry >> 12) + ((r.bits >> DIST_BITS) & ((1u << extra_of(entry)) - 1u))];
+                r.bits >>= DIST_BITS; r.held -= DIST_BITS;
+            }
+            kind = kind_of(entry);
+            r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
+            if(kind != DISTANCE) { plausible = false; break; }
+            const uint32_t distance = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
+            if(r.held < 0 || distance > MARKED_WINDOW + made) { plausible = false; break; }
+            made += length;
+        }
+        if(plausible) { *found = bit; return true; }
+    }
+    return false;
+}
 
 }  // namespace fast_inflate
 
@@ -308,8 +589,9 @@ public:
         if(map_ != nullptr) { ::munmap(const_cast<uint8_t*>(map_), size_); }
     }
 
-    // true: a regular file that starts with a gzip header
-    bool open(const std::string& path) {
+    // true: a regular file that starts with a gzip header.  threads > 1: a member of several MiB is inflated chunk parallel (above)
+    bool open(const std::string& path, int threads = 1) {
+        threads_ = threads < 1 ? 1 : threads > 64 ? 64 : threads;
         const int descriptor = ::open(path.c_str(), O_RDONLY);
         if(descriptor < 0) { return false; }
         struct stat status;
@@ -335,7 +617,15 @@ public:
                 continue;
             }
             const size_t take = std::min(want - done, static_cast<size_t>(produced_ - ready_));
-            std::memcpy(to + done, ready_, take);
+            if(threads_ > 1 && take >= (size_t(8) << 20)) {
+                // a span's text: tens of MiB, copied on several threads (one thread's copy was a sixth of a span's time)
+                uint8_t* const target = to + done;
+                const uint8_t* const source = ready_;
+                parallel_ranges(static_cast<int64_t>((take + (1 << 20) - 1) >> 20), 1, std::min(threads_, 8), [&](int64_t first, int64_t last, int) {
+                    const size_t begin = static_cast<size_t>(first) << 20, end = std::min(take, static_cast<size_t>(last) << 20);
+                    std::memcpy(target + begin, source + begin, end - begin);
+                });
+            } else { std::memcpy(to + done, ready_, take); }
             ready_ += take;
             done += take;
         }
@@ -343,10 +633,17 @@ public:
     }
 
     static uint64_t& through_zlib() { static uint64_t count = 0; return count; }      // members the decoder handed to zlib part way (diagnosis, the check program)
+    // chunks taken from the other threads / chunks decoded for nothing (a find that was no block header, a chunk behind one that stopped early)
+    static uint64_t& chunks_taken() { static uint64_t count = 0; return count; }
+    static uint64_t& chunks_dropped() { static uint64_t count = 0; return count; }
 
 private:
     static constexpr size_t WINDOW = size_t(1) << 15;
     static constexpr size_t CHUNK = size_t(1) << 20;
+    static constexpr size_t MIN_CHUNK = size_t(256) << 10;       // compressed bytes a thread: a search for a block header costs a few ms
+    static constexpr size_t MAX_CHUNK = size_t(1) << 20;
+    static constexpr size_t SEARCH = size_t(128) << 10;          // input bytes a chunk is searched for a block header
+    static constexpr size_t EXPANSION = 8;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
 
     bool begin_member() {
         const uint8_t* const in = map_ + at_;
@@ -362,7 +659,8 @@ private:
         if(flags & 16) { while(at < bytes && in[at] != 0) { ++at; } ++at; }
         if(flags & 2) { at += 2; }
         if(at + 8 > bytes) { return false; }
-        raw_.start(in + at, map_ + size_);
+        deflate_ = in + at;
+        raw_.start(deflate_, map_ + size_);
         history_ = work_.get() + WINDOW;               // nothing to reach back into yet
         ready_ = produced_ = work_.get() + WINDOW;
         crc_ = 0;
@@ -375,6 +673,12 @@ private:
         if(next_member_) {                              // cat a.gz b.gz: the member before has ended and its text is out
             next_member_ = false;
             if(!begin_member()) { throw IOError("damaged gzip header"); }
+        }
+        if(threads_ > 1 && !zlib_open_) {
+            // (a span that took no chunk — no header found, or none that chained — is followed by more and more pieces on one
+            // thread before the next attempt)
+            if(span_wait_ > 0) { --span_wait_; }
+            else if(span()) { return; }
         }
         // the last 32 KiB of the member's text move to the front
         uint8_t* const base = work_.get() + WINDOW;
@@ -427,13 +731,183 @@ private:
         if(member_ended) {
             const uint8_t* const trailer = zlib_open_ ? zlib_in_ : raw_.after();
             if(zlib_open_) { inflateEnd(&zlib_); zlib_open_ = false; }
-            if(trailer + 8 > map_ + size_) { throw IOError("a gzip stream ends early"); }
-            if(le32(trailer) != crc_ || le32(trailer + 4) != static_cast<uint32_t>(text_)) { throw IOError("a gzip member does not hold to its CRC or its size"); }
-            at_ = static_cast<size_t>(trailer + 8 - map_);
-            // another member behind it, or the end (bytes that are no gzip header end the text, as they end gzread's)
-            next_member_ = at_ + 18 <= size_ && map_[at_] == 0x1f && map_[at_ + 1] == 0x8b;
-            ended_ = !next_member_;
+            end_member(trailer);
         } else if(made == 0) { throw IOError("damaged gzip data"); }       // no progress and no end
+    }
+
+    void end_member(const uint8_t* trailer) {
+        if(trailer + 8 > map_ + size_) { throw IOError("a gzip stream ends early"); }
+        if(le32(trailer) != crc_ || le32(trailer + 4) != static_cast<uint32_t>(text_)) { throw IOError("a gzip member does not hold to its CRC or its size"); }
+        at_ = static_cast<size_t>(trailer + 8 - map_);
+        // another member behind it, or the end (bytes that are no gzip header end the text, as they end gzread's)
+        next_member_ = at_ + 18 <= size_ && map_[at_] == 0x1f && map_[at_ + 1] == 0x8b;
+        ended_ = !next_member_;
+    }
+
+    // One span of the member on threads_ threads (see marked_decode above): this thread goes on from where the stream stands, the
+    // others start at block headers found in the chunks behind, every chunk runs to the first block header in the next one;
+    // then the chunks are taken in order for as long as each ENDS where the next one STARTS, their markers resolved from the
+    // 32 KiB in front of them.  Whatever does not chain — a find that was no header, a chunk out of room — is dropped, and the
+    // stream goes on from the last bit taken, on this path or the one thread one.  false: not worth it here (little input left).
+    bool span() {
+        const uint8_t* const origin = deflate_;
+        const uint8_t* const limit = map_ + size_;
+        const uint64_t here = raw_.bit_position();
+        const size_t left = static_cast<size_t>(limit - origin) - static_cast<size_t>(here >> 3);
+        if(raw_.finished() || left < 4 * MIN_CHUNK) { return false; }
+        const int chunks = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads_), left / MIN_CHUNK));
+        const size_t chunk_bytes = std::min(MAX_CHUNK, left / static_cast<size_t>(chunks));
+        const size_t room = chunk_bytes * EXPANSION;                           // text a chunk may make before it is cut
+        // the window in front of the span: the last 32 KiB of the member's text so far (they may sit in the buffer that grows below)
+        const size_t keep = std::min(static_cast<size_t>(produced_ - history_), WINDOW);
+        std::vector<uint8_t> kept(produced_ - keep, produced_);
+        if(span_text_room_ < WINDOW + static_cast<size_t>(chunks) * room + 4096) {
+            span_text_room_ = WINDOW + static_cast<size_t>(chunks) * room + 4096;
+            span_text_.reset(new uint8_t[span_text_room_]);
+        }
+        if(marked_.size() < static_cast<size_t>(chunks)) { marked_.resize(static_cast<size_t>(chunks)); }
+        uint8_t* const base = span_text_.get() + WINDOW;
+        if(keep > 0) { std::memcpy(base - keep, kept.data(), keep); }
+        history_ = base - keep;
+        ready_ = produced_ = base;
+
+        struct Chunk { uint64_t begin = 0; bool found = false; fast_inflate::MarkedResult result; };
+        std::vector<Chunk> chunk(static_cast<size_t>(chunks));
+        const uint64_t first_byte = here >> 3;
+        const uint64_t span_end = (first_byte + static_cast<uint64_t>(chunks) * chunk_bytes) * 8u;
+        // where the chunks start: a block header in each chunk's part of the input (none found: the chunk before runs through)
+        parallel_ranges(chunks - 1, 1, chunks - 1, [&](int64_t first, int64_t last, int) {
+            for(int64_t k = first + 1; k < last + 1; ++k) {
+                Chunk& c = chunk[static_cast<size_t>(k)];
+                // (a block of zlib's or pigz's is tens of KiB of input: what is not found within SEARCH bytes is not there — text that
+                // does not compress, stored or fixed blocks — and a search through all of a chunk would cost more than its decoding)
+                const uint64_t from = (first_byte + static_cast<uint64_t>(k) * chunk_bytes) * 8u;
+                c.found = fast_inflate::find_block(origin, limit, from, std::min(from + SEARCH * 8u, (first_byte + static_cast<uint64_t>(k + 1) * chunk_bytes) * 8u), &c.begin);
+            }
+        });
+        std::vector<uint64_t> stop(static_cast<size_t>(chunks), span_end);       // the first bit of the next chunk that found one
+        {
+            uint64_t next = span_end;
+            for(int k = chunks - 1; k >= 0; --k) { stop[static_cast<size_t>(k)] = next; if(k > 0 && chunk[static_cast<size_t>(k)].found) { next = chunk[static_cast<size_t>(k)].begin; } }
+        }
+        fast_inflate::RawStream::Status own = fast_inflate::RawStream::Status::ROOM;
+        uint8_t* own_out = base;
+        parallel_ranges(chunks, 1, chunks, [&](int64_t first, int64_t last, int) {
+            for(int64_t k = first; k < last; ++k) {
+                if(k == 0) {
+                    // this thread's own chunk: bytes, with the history it has
+                    raw_.stop_at(stop[0]);
+                    own = raw_.run(history_, own_out, base + room);
+                    raw_.stop_at(~uint64_t(0));
+                    continue;
+                }
+                Chunk& c = chunk[static_cast<size_t>(k)];
+                if(!c.found) { continue; }
+                std::vector<uint16_t>& symbols = marked_[static_cast<size_t>(k)];
+                if(symbols.size() < fast_inflate::MARKED_WINDOW + room + 8) { symbols.resize(fast_inflate::MARKED_WINDOW + room + 8); }
+                c.result = fast_inflate::marked_decode(origin, limit, c.begin, stop[static_cast<size_t>(k)], symbols.data(), room);
+            }
+        });
+        if(own == fast_inflate::RawStream::Status::DAMAGED) { throw IOError("damaged gzip data"); }
+        size_t made = static_cast<size_t>(own_out - base);
+        bool member_ended = own == fast_inflate::RawStream::Status::END;
+        uint64_t end_bit = raw_.bit_position();
+        // the chain: chunk k is taken when what has been taken so far ends on its first bit
+        std::vector<int> taken;
+        std::vector<size_t> place;
+        if(own == fast_inflate::RawStream::Status::BOUNDARY) {
+            for(int k = 1; k < chunks; ++k) {
+                const Chunk& c = chunk[static_cast<size_t>(k)];
+                if(!c.found || c.begin < end_bit) { continue; }
+                if(c.begin != end_bit || c.result.made == 0 || WINDOW + made + c.result.made + 4096 > span_text_room_) { break; }
+                taken.push_back(k);
+                place.push_back(made);
+                made += c.result.made;
+                end_bit = c.result.end_bit;
+                if(c.result.ended) { member_ended = true; break; }
+                if(c.result.damaged) { break; }                  // what it made up to its last whole block stands; the stream goes on from there (and finds the damage, if it is one)
+            }
+        }
+        int found = 0;
+        for(const Chunk& c : chunk) { found += c.found ? 1 : 0; }
+        span_wait_ = taken.empty() ? (span_backoff_ = std::min(2 * span_backoff_ + 1, 255)) : (span_backoff_ = 0);
+        chunks_taken() += taken.size();
+        chunks_dropped() += static_cast<uint64_t>(found) - taken.size();
+        // the window in front of every chunk taken: the last 32 KiB of the text before it — resolved one behind another (32 KiB each)
+        std::vector<std::vector<uint8_t>> window(taken.size());
+        for(size_t t = 0; t < taken.size(); ++t) {
+            std::vector<uint8_t>& w = window[t];
+            w.assign(WINDOW, 0);
+            if(t == 0) {
+                // the bytes in front of place[0]: this thread's own text and the history in front of it
+                const size_t have = std::min(WINDOW, static_cast<size_t>(base + place[0] - history_));
+                std::memcpy(w.data() + WINDOW - have, base + place[0] - have, have);
+            } else {
+                const std::vector<uint16_t>& symbols = marked_[static_cast<size_t>(taken[t - 1])];
+                const size_t before = chunk[static_cast<size_t>(taken[t - 1])].result.made;
+                const std::vector<uint8_t>& older = window[t - 1];
+                for(size_t i = 0; i < WINDOW; ++i) {
+                    // place i of this window = symbol (before - WINDOW + i) of the chunk before, or (before < WINDOW) the older window's tail
+                    if(before + i >= WINDOW) {
+                        const uint16_t symbol = symbols[fast_inflate::MARKED_WINDOW + before + i - WINDOW];
+                        w[i] = symbol < 256 ? static_cast<uint8_t>(symbol) : older[symbol & (fast_inflate::MARKER - 1)];
+                    } else { w[i] = older[before + i]; }
+                }
+            }
+        }
+        // every chunk's symbols into bytes at its place, and its CRC
+        std::vector<uint32_t> crc(taken.size(), 0);
+        parallel_ranges(static_cast<int64_t>(taken.size()), 1, threads_, [&](int64_t first, int64_t last, int) {
+            for(int64_t t = first; t < last; ++t) {
+                const Chunk& c = chunk[static_cast<size_t>(taken[static_cast<size_t>(t)])];
+                const uint16_t* const symbols = marked_[static_cast<size_t>(taken[static_cast<size_t>(t)])].data() + fast_inflate::MARKED_WINDOW;
+                const uint8_t* const w = window[static_cast<size_t>(t)].data();
+                uint8_t* const to = base + place[static_cast<size_t>(t)];
+                const size_t n = c.result.made;
+                size_t i = 0;
+#ifdef PHQ_CRC_FOLDED
+                // sixteen symbols at a time where none of them is a marker (behind a chunk's first tens of KiB nearly all)
+                for(; i + 16 <= n; i += 16) {
+                    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(symbols + i));
+                    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(symbols + i + 8));
+                    if(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_srli_epi16(_mm_or_si128(a, b), 8), _mm_setzero_si128())) == 0xffff) {
+                        _mm_storeu_si128(reinterpret_cast<__m128i*>(to + i), _mm_packus_epi16(a, b));
+                    } else {
+                        for(size_t j = i; j < i + 16; ++j) { const uint16_t symbol = symbols[j]; to[j] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
+                    }
+                }
+#endif
+                for(; i + 4 <= n; i += 4) {
+                    uint64_t four;
+                    std::memcpy(&four, symbols + i, 8);
+                    if((four & 0xff00ff00ff00ff00ull) == 0) {
+                        to[i] = static_cast<uint8_t>(four); to[i + 1] = static_cast<uint8_t>(four >> 16); to[i + 2] = static_cast<uint8_t>(four >> 32); to[i + 3] = static_cast<uint8_t>(four >> 48);
+                    } else {
+                        for(size_t j = i; j < i + 4; ++j) { const uint16_t symbol = symbols[j]; to[j] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
+                    }
+                }
+                for(; i < n; ++i) { const uint16_t symbol = symbols[i]; to[i] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
+                crc[static_cast<size_t>(t)] = crc_more(0, to, n);
+            }
+        });
+        const size_t own_made = static_cast<size_t>(own_out - base);
+        crc_ = crc_more(crc_, base, own_made);
+        for(size_t t = 0; t < taken.size(); ++t) {
+            crc_ = static_cast<uint32_t>(crc32_combine(crc_, crc[t], static_cast<z_off_t>(chunk[static_cast<size_t>(taken[t])].result.made)));
+        }
+        text_ += made;
+        produced_ = base + made;
+        if(!taken.empty()) {
+            // the stream goes on behind the last chunk taken (a block header, or the trailer)
+            raw_.start(origin, limit, end_bit);
+            if(member_ended) { end_member(origin + (end_bit >> 3)); }
+        } else if(member_ended) {
+            end_member(raw_.after());
+        } else if(own == fast_inflate::RawStream::Status::REFUSED || made == 0) {
+            // a block the decoder does not take (the one thread path hands it to zlib), or no room: nothing was made here
+            if(made == 0) { return false; }
+        }
+        return true;
     }
 
     static uint32_t le32(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); }
@@ -456,6 +930,12 @@ private:
 
     const uint8_t* map_ = nullptr;
     size_t size_ = 0;
+    int threads_ = 1;
+    int span_wait_ = 0, span_backoff_ = 0;
+    const uint8_t* deflate_ = nullptr;             // the member's deflate stream (behind its header)
+    std::unique_ptr<uint8_t[]> span_text_;         // WINDOW of history, then a span's text
+    size_t span_text_room_ = 0;
+    std::vector<std::vector<uint16_t>> marked_;    // per chunk: the symbols of marked_decode
     size_t at_ = 0;                                // the member's first byte in the file
     std::unique_ptr<uint8_t[]> work_;              // WINDOW of history, then CHUNK of new text (and the decoder's margin)
     const uint8_t* history_ = nullptr;             // the first byte of the member's text that is still held

@@ -1163,7 +1163,7 @@ bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file)
                 // one member: a sequential stream, through fast_inflate.hpp's decoder in its streaming form (gzip_stream.hpp)
                 p.stream.reset(new GzipStream());
                 try {
-                    if(p.stream->open(plan.input_feed[static_cast<size_t>(f)].path)) { inflated = static_cast<int>(p.stream->read(p.head.data(), p.head.size())); }
+                    if(p.stream->open(plan.input_feed[static_cast<size_t>(f)].path, host_threads())) { inflated = static_cast<int>(p.stream->read(p.head.data(), p.head.size())); }
                     else { p.stream.reset(); }
                 } catch(const std::exception&) { p.stream.reset(); inflated = -1; }
             }

@@ -566,6 +566,31 @@ def test_a_single_member_gzip_stream_inflates_to_the_same_text(tmp_path):
     assert run(packed[:-3], fastq).returncode == 4
     assert run(fastq, fastq).returncode == 3                                                  # not gzip
 
+    # the same stream on four threads (gzip_stream.hpp, marked_decode): chunks that start at block headers found by search, their
+    # matches into the unknown 32 KiB in front of them kept as markers and resolved when the chunk before is — the text is the same,
+    # chunks are taken, and everything above holds: a block handed to zlib, members one behind another, damage, a cut file,
+    # streams of fixed or stored blocks (no header the search takes: the one thread decodes them through)
+    large = b"".join(records[k % len(records)][:-1] + b"%d\n" % k for k in range(120000))       # 17 MB of text, 4 MB packed
+    for level in (1, 6, 9):
+        ran = run(gzip.compress(large, level), large, -1, 4)
+        assert ran.returncode == 0 and " zlib 0 " in ran.stdout and int(ran.stdout.split()[-3]) >= 3, (level, ran.stdout, ran.stderr[-500:])
+    packed = gzip.compress(large, 6)
+    for block in (0, 3, 9):                            # (of the stream's own thread: its count starts again behind every chunk taken)
+        ran = run(packed, large, block, 4)
+        assert ran.returncode == 0 and " zlib 1 " in ran.stdout, (block, ran.stdout, ran.stderr[-500:])
+    half = len(large) // 2
+    assert run(gzip.compress(large[:half], 4) + gzip.compress(large[half:], 7) + bytes(100), large, -1, 4).returncode == 0
+    for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY):
+        packer = zlib.compressobj(6, zlib.DEFLATED, 31, 8, strategy)
+        assert run(packer.compress(large) + packer.flush(), large, -1, 4).returncode == 0
+    noise = rng.integers(0, 256, 5 << 20, dtype=np.uint8).tobytes()
+    assert run(gzip.compress(noise, 6), noise, -1, 4).returncode == 0
+    for where in (len(packed) // 5, len(packed) // 2, len(packed) - 3000):
+        damaged = bytearray(packed)
+        damaged[where] ^= 0x04
+        assert run(bytes(damaged), large, -1, 4).returncode == 4
+    assert run(packed[:len(packed) * 2 // 3], large, -1, 4).returncode == 4
+
 
 def test_the_one_shot_inflate_against_zlib_under_sanitizers():
     """csrc/fast_inflate.hpp (RFC 1951 / 1952) under ASan + UBSan: 800 gzip members — empty, one byte, FASTQ text, random bytes, a
