@@ -211,7 +211,11 @@ def fastq_end_to_end(args, code, quality, flag, n):
             write_fastq(path, k + 1, text, qual, filtered)
             paths.append(path)
         size = sum(os.path.getsize(p) for p in paths)
-        for name, target in (("sam_text", os.path.join(directory, "out.sam")), ("sam_text_discarded", "/dev/zero"), ("report_only", "/dev/null")):
+        for name, target in (("sam_text", os.path.join(directory, "out.sam")), ("sam_text_discarded", "/dev/zero"), ("sam_text_discarded_exact_tags", "/dev/zero"), ("report_only", "/dev/null")):
+            # exact_tags: PHQ_MODE_AUTO, the library's default — a run that writes SAM records of a job this small classifies in the
+            # literal kernel's arithmetic, so that XB / XM / XC print the reference's own six digits; the other legs keep the
+            # mode of the headline (fast)
+            s.set_mode(capi.MODE_AUTO if name.endswith("exact_tags") else capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
             s.transcode_fastq_to_sam(paths, target, 1 << 20)                    # warm: allocations, page cache
             if os.path.isfile(target):
                 os.unlink(target)                                               # a run creates its output: giving back the pages of the previous one is not part of it
@@ -222,9 +226,11 @@ def fastq_end_to_end(args, code, quality, flag, n):
             out[name] = {"Mreads/s": n / dt / 1e6, "fastq_MB/s": size / dt / 1e6, "seconds": dt}
             if os.path.isfile(target):
                 out[name]["sam_MB/s"] = os.path.getsize(target) / dt / 1e6
+        s.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
         # the published workload's input format (docs/illumina_api_vignette.md:222: gzip FASTQ in): the same files as BGZF — bgzip's
         # blocks, what the reference reads through htslib (fastq.h:427-440), inflated member parallel on the host's threads
-        # (csrc/gzip_members.hpp) — and, their first Mi reads, as ONE gzip member each: a stream a single thread has to inflate
+        # (csrc/gzip_members.hpp) — and as ONE gzip member each (what `gzip file.fastq` writes): a sequential stream, inflated chunk parallel from
+        # block headers found by search (csrc/gzip_stream.hpp)
         def bgzf(data):
             import struct
             import zlib
@@ -238,7 +244,7 @@ def fastq_end_to_end(args, code, quality, flag, n):
             with ThreadPoolExecutor(usable_cores()) as pool:
                 return b"".join(pool.map(block, [view[k:k + 65280] for k in range(0, len(data), 65280)] + [b""]))
         import zlib
-        for name, reads, pack in (("report_only_bgzf", n, bgzf), ("report_only_gz", min(n, 1 << 20), lambda data: (lambda c: c.compress(data) + c.flush())(zlib.compressobj(1, zlib.DEFLATED, 31)))):
+        for name, reads, pack in (("report_only_bgzf", n, bgzf), ("report_only_gz", n, lambda data: (lambda c: c.compress(data) + c.flush())(zlib.compressobj(1, zlib.DEFLATED, 31)))):
             packed_paths = []
             for path in paths:
                 data = np.fromfile(path, dtype=np.uint8, count=reads * (os.path.getsize(path) // n)).tobytes()

@@ -641,9 +641,9 @@ private:
     static constexpr size_t WINDOW = size_t(1) << 15;
     static constexpr size_t CHUNK = size_t(1) << 20;
     static constexpr size_t MIN_CHUNK = size_t(256) << 10;       // compressed bytes a thread: a search for a block header costs a few ms
-    static constexpr size_t MAX_CHUNK = size_t(1) << 20;
+    static constexpr size_t MAX_CHUNK = size_t(512) << 10;
     static constexpr size_t SEARCH = size_t(128) << 10;          // input bytes a chunk is searched for a block header
-    static constexpr size_t EXPANSION = 8;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
+    static constexpr size_t EXPANSION = 7;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
 
     bool begin_member() {
         const uint8_t* const in = map_ + at_;

@@ -20,13 +20,15 @@ from test_gpu_fastq_device import _files
 pytestmark = pytest.mark.gpu
 
 
-def _run(job, capacity, host, how="job", paths=None, output=None):
+def _run(job, capacity, host, how="job", paths=None, output=None, mode=None):
     """(incoming, counter words, device path counters of the run) with the records assembled on the device or by the host"""
     if host:
         os.environ["PHQ_HOST_RECORDS"] = "1"
     try:
         before = capi.device_path_counters()
         s = DecoderSet(job if isinstance(job, str) else json.dumps(job), device=0)
+        if mode is not None:
+            s.set_mode(mode)
         s.stats_reset()
         incoming = s.transcode_job(capacity) if how == "job" else s.transcode_fastq_to_sam(paths, output, capacity)
         words = s.stats_export()
@@ -186,7 +188,8 @@ def _assert_sam_equal_but_for_posterior_digits(mine, expected):
 
 @pytest.mark.parametrize("case", ["two_segments_filters", "mixed_tokens", "three_output_segments", "fastq_interleaved", "fastq_mixed_tokens"])
 @pytest.mark.parametrize("host", [False, True])
-def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case, host):
+@pytest.mark.parametrize("mode", ["auto", "fast"])
+def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case, host, mode):
     """tests/sam_restatement.py — written from the reference's text and pinned to its golden SAM file without the library
     (tests/test_sam_restatement.py) — formats the ORACLE's decisions for the same files; the device writer and the host writer
     must each write the same bytes: tags in Auxiliary::encode's order, `%g`, FI / TC, corrected barcodes as template tokens with
@@ -215,7 +218,7 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
         open(paths[1], "wb").write(b"\n".join(lines))
     spec["input"] = paths
     spec["output"] = [os.path.join(directory, "out.fastq" if fastq else "out.sam")]
-    incoming, _, did = _run(spec, capacity, host)
+    incoming, _, did = _run(spec, capacity, host, mode=capi.MODE_FAST if mode == "fast" else None)
     assert (did["record_bytes"] == 0) == host
     mine = open(spec["output"][0], "rb").read() if fastq else b"".join(line for line in open(spec["output"][0], "rb").readlines() if not line.startswith(b"@"))
 
@@ -241,7 +244,16 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
         assert mine == expected
         assert (b" 4:N:0:" in mine or b" 4:Y:0:" in mine) == (case == "fastq_mixed_tokens")
         return
-    _assert_sam_equal_but_for_posterior_digits(mine, expected)
+    cells = sum(len(d["codec"]) * int(d["nucleotide cardinality"]) for _, d in synthetic.iter_decoders(job) if d.get("algorithm") == "pamld")
+    if mode == "auto" and cells <= 4096:
+        # PHQ_MODE_AUTO, the default: a run that writes SAM records of a job this small classifies in the literal kernel's
+        # arithmetic — the posterior is the oracle's to ~1e-16 and the tags' six digits are the reference's: byte for byte, no exemption
+        if mine != expected:
+            for k, (a, b) in enumerate(zip(mine.split(b"\n"), expected.split(b"\n"))):
+                assert a == b, (k, a, b)
+        assert mine == expected
+    else:
+        _assert_sam_equal_but_for_posterior_digits(mine, expected)
     if case == "mixed_tokens":
         assert b"\tFI:i:4\tTC:i:4" in mine and b"\tXC:f:" in mine and b"\tRX:Z:" in mine
     if case == "three_output_segments":
