@@ -52,6 +52,8 @@ public:
     }
     // bits of the stream taken so far
     uint64_t bit_position() const { return static_cast<uint64_t>(in_next_ - origin_) * 8u - static_cast<uint64_t>(held_); }
+    uint64_t header_bit() const { return header_bit_; }
+    uint8_t* header_out() const { return header_out_; }
     // run() returns BOUNDARY in front of the first block header at or past this bit (gzip_parallel: the chunk behind starts there)
     void stop_at(uint64_t bit) { stop_bit_ = bit; }
     bool finished() const { return finished_; }
@@ -64,7 +66,14 @@ public:
 
     // Decodes into [out, out_end); `history` <= out is the first byte a distance may reach (the start of the member's text, or of the
     // 32 KiB kept of it).  ROOM: less than MARGIN bytes are left and the stream goes on; END: the last block has ended.
-    Status run(const uint8_t* history, uint8_t*& out_io, uint8_t* const out_end) {
+    Status run(const uint8_t* history, uint8_t*& out_io, uint8_t* const out_end) { return run_planes<false>(history, out_io, out_end, 0); }
+
+    // MARKED (a chunk that starts in the middle of the stream, see below): a second plane of flag bytes `delta` bytes behind the
+    // text — 0 for a byte that is known; what a match copies out of the 32 KiB in front of the chunk carries its place there, low
+    // byte in the text plane, 1 | high bits << 1 in the flag plane.  A literal stores zeros to the flag plane where it stores its
+    // bytes, a match copies both planes: the loop is the same one, at most a few stores longer per symbol.
+    template <bool MARKED>
+    Status run_planes(const uint8_t* history, uint8_t*& out_io, uint8_t* const out_end, ptrdiff_t delta) {
         static const Tables* const fixed = fixed_tables();
         if(fixed == nullptr) { return Status::REFUSED; }
         const uint8_t* in_next = in_next_;
@@ -91,7 +100,9 @@ public:
                 if(finished_) { return leave(Status::END); }
                 refill();
                 boundary_in_ = in_next; boundary_held_ = held;
-                if(static_cast<uint64_t>(in_next - origin_) * 8u - static_cast<uint64_t>(held) >= stop_bit_) { return leave(Status::BOUNDARY); }
+                header_bit_ = static_cast<uint64_t>(in_next - origin_) * 8u - static_cast<uint64_t>(held);
+                header_out_ = out;
+                if(header_bit_ >= stop_bit_) { return leave(Status::BOUNDARY); }
                 if(held < 3) { return leave(Status::DAMAGED); }
                 const uint64_t bits_before = bits;
                 auto refuse = [&]() { in_next = boundary_in_; bits = bits_before; held = boundary_held_; return leave(Status::REFUSED); };
@@ -149,6 +160,7 @@ public:
             if(stored_) {
                 const size_t n = std::min<size_t>(stored_left_, static_cast<size_t>(out_end - out));
                 std::memcpy(out, in_next, n);
+                if(MARKED) { std::memset(out + delta, 0, n); }
                 in_next += n; out += n; stored_left_ -= static_cast<uint32_t>(n);
                 if(stored_left_ > 0) { return leave(Status::ROOM); }
                 in_block_ = false;
@@ -172,18 +184,21 @@ public:
                     if(kind_of(entry) <= LITERAL3) {
                         uint32_t bytes = entry >> 8;
                         std::memcpy(out, &bytes, 4);
+                        if(MARKED) { std::memset(out + delta, 0, 4); }
                         out += kind_of(entry) + 1u;
                         bits >>= entry & 31u; held -= static_cast<int>(entry & 31u);
                         entry = litlen[bits & LITLEN_MASK];
                         if(kind_of(entry) <= LITERAL3) {
                             bytes = entry >> 8;
                             std::memcpy(out, &bytes, 4);
+                            if(MARKED) { std::memset(out + delta, 0, 4); }
                             out += kind_of(entry) + 1u;
                             bits >>= entry & 31u; held -= static_cast<int>(entry & 31u);
                             entry = litlen[bits & LITLEN_MASK];
                             if(kind_of(entry) <= LITERAL3) {
                                 bytes = entry >> 8;
                                 std::memcpy(out, &bytes, 4);
+                                if(MARKED) { std::memset(out + delta, 0, 4); }
                                 out += kind_of(entry) + 1u;
                                 bits >>= entry & 31u; held -= static_cast<int>(entry & 31u);
                                 continue;
@@ -196,7 +211,7 @@ public:
                     }
                     const uint32_t kind = kind_of(entry);
                     bits >>= entry & 31u; held -= static_cast<int>(entry & 31u);
-                    if(kind == LITERAL) { *out++ = static_cast<uint8_t>(entry >> 8); continue; }
+                    if(kind == LITERAL) { if(MARKED) { out[delta] = 0; } *out++ = static_cast<uint8_t>(entry >> 8); continue; }
                     if(kind == END) { open = false; break; }
                     if(kind != LENGTH) { return leave(Status::DAMAGED); }
                     const uint32_t extra = extra_of(entry);
@@ -223,10 +238,18 @@ public:
                     const uint8_t* from = out - distance;
                     uint8_t* const stop = out + length;
                     if(distance >= 8) {
+                        if(MARKED) {
+                            const uint8_t* flags_from = from + delta;
+                            uint8_t* flags = out + delta;
+                            uint8_t* const flags_stop = stop + delta;
+                            do { uint64_t word; std::memcpy(&word, flags_from, 8); std::memcpy(flags, &word, 8); flags_from += 8; flags += 8; } while(flags < flags_stop);
+                        }
                         do { uint64_t word; std::memcpy(&word, from, 8); std::memcpy(out, &word, 8); from += 8; out += 8; } while(out < stop);
                     } else if(distance == 1) {
+                        if(MARKED) { std::memset(out + delta, from[delta], length); }
                         std::memset(out, *from, length);
                     } else {
+                        if(MARKED) { for(uint32_t k = 0; k < length; ++k) { out[delta + static_cast<ptrdiff_t>(k)] = from[delta + static_cast<ptrdiff_t>(k)]; } }
                         for(uint32_t k = 0; k < 8; ++k) { out[k] = from[k]; }
                         if(length > 8) {
                             const uint32_t stride = distance * ((8u + distance - 1u) / distance);
@@ -250,7 +273,7 @@ public:
                 bits >>= entry & 31u; held -= static_cast<int>(entry & 31u);
                 if(held < 0) { return leave(Status::DAMAGED); }
                 if(kind <= LITERAL3) {
-                    for(uint32_t k = 0; k <= kind; ++k) { *out++ = static_cast<uint8_t>(entry >> (8 + 8 * k)); }
+                    for(uint32_t k = 0; k <= kind; ++k) { if(MARKED) { out[delta] = 0; } *out++ = static_cast<uint8_t>(entry >> (8 + 8 * k)); }
                     continue;
                 }
                 if(kind == END) { break; }
@@ -268,7 +291,7 @@ public:
                 const uint32_t distance = (entry >> 12) + take(static_cast<int>(extra_of(entry)));
                 if(held < 0 || distance > static_cast<size_t>(out - history)) { return leave(Status::DAMAGED); }
                 const uint8_t* from = out - distance;
-                for(uint32_t k = 0; k < length; ++k) { out[k] = from[k]; }
+                for(uint32_t k = 0; k < length; ++k) { out[k] = from[k]; if(MARKED) { out[delta + static_cast<ptrdiff_t>(k)] = from[delta + static_cast<ptrdiff_t>(k)]; } }
                 out += length;
             }
             in_block_ = false;
@@ -297,6 +320,8 @@ private:
     const uint8_t* in_next_ = nullptr;
     const uint8_t* in_end_ = nullptr;
     uint64_t stop_bit_ = ~uint64_t(0);
+    uint64_t header_bit_ = 0;                      // the last block header looked at, and where the text stood in front of it
+    uint8_t* header_out_ = nullptr;
     uint64_t bits_ = 0;
     int held_ = 0;
     bool last_ = false, in_block_ = false, stored_ = false, finished_ = false;
@@ -312,15 +337,14 @@ private:
 // One thread inflates ~1 GB/s of FASTQ text; a file of one member gives the others nothing to do.  The way out (Kerbiriou and
 // Chikhi, "Parallel decompression of gzip-compressed files and random access to DNA sequences", 2019: pugz) is to start in the
 // MIDDLE of the stream: a deflate block can be decoded without what came before it, except that its matches may reach up to
-// 32 KiB back into text that is not known yet.  So a chunk that starts at a block header found by search is decoded into 16 bit
-// symbols — a literal, or a MARKER: "the byte at this place of the 32 KiB in front of the chunk" — matches copy markers like
-// literals, and when the chunk before has been resolved its last 32 KiB turn every marker into its byte.
+// 32 KiB back into text that is not known yet.  So a chunk that starts at a block header found by search is decoded with a
+// second plane of flag bytes beside its text (RawStream::run_planes<true>): a byte is known, or it is a MARKER — "the byte at
+// this place of the 32 KiB in front of the chunk" — matches copy markers like literals, and when the chunk before has been
+// resolved its last 32 KiB turn every marker into its byte.  (A first version decoded into 16 bit symbols with a loop of its
+// own: 0.25 of the one thread rate a thread, profiles/r06_gzip_stream_rate_u16.txt; the planes keep the byte decoder's loop.)
 //   * find_block: the first bit position in a range where a dynamic, non final block header parses — the code length code, the
 //     literal / length code and the distance code all complete prefix codes — and its first symbols decode.  A false find costs
 //     nothing but time: a chunk is taken only when the chunk before ENDS exactly on its first bit.
-//   * marked_decode: from such a position to the first block header at or past a stop bit (or the stream's end, or the end of
-//     its room: it then stops behind the last whole block).
-constexpr uint16_t MARKER = 0x8000u;               // symbol = MARKER | place in the 32 KiB window in front of the chunk
 constexpr size_t MARKED_WINDOW = size_t(1) << 15;
 
 struct BitReader {
@@ -382,129 +406,6 @@ inline bool read_dynamic_tables(BitReader& r, Tables& tables) {
     }
     if(lengths[256] == 0) { return false; }
     return build_litlen(lengths, n_litlen, tables) && build_dist(lengths + n_litlen, n_dist, tables);
-}
-
-struct MarkedResult {
-    uint64_t end_bit = 0;          // the block header the chunk stopped in front of (or the first bit behind the stream's last block)
-    size_t made = 0;               // symbols, behind the window
-    bool ended = false;            // the stream's last block ended in this chunk
-    bool damaged = false;          // an invalid code or a block this decoder does not take: what was made up to the last whole block stands
-};
-
-// `buffer`: MARKED_WINDOW symbols of window (filled here with markers), then room for `capacity` symbols
-inline MarkedResult marked_decode(const uint8_t* origin, const uint8_t* limit, uint64_t begin_bit, uint64_t stop_bit, uint16_t* buffer, size_t capacity) {
-    static Tables fixed;
-    static const bool fixed_ready = []() {
-        uint8_t lengths[288];
-        for(int s = 0; s < 144; ++s) { lengths[s] = 8; }
-        for(int s = 144; s < 256; ++s) { lengths[s] = 9; }
-        for(int s = 256; s < 280; ++s) { lengths[s] = 7; }
-        for(int s = 280; s < 288; ++s) { lengths[s] = 8; }
-        uint8_t all[32];
-        for(int s = 0; s < 32; ++s) { all[s] = 5; }
-        return build_litlen(lengths, 288, fixed) && build_table(all, 32, DIST_BITS, fixed.dist, DIST_ENTRIES, true, [](int symbol, uint32_t length) {
-            return symbol > 29 ? entry_of(0, INVALID, 0, length) : entry_of(DIST_BASE[symbol], DISTANCE, DIST_EXTRA[symbol], length); });
-    }();
-    MarkedResult result;
-    result.end_bit = begin_bit;
-    for(size_t k = 0; k < MARKED_WINDOW; ++k) { buffer[k] = static_cast<uint16_t>(MARKER | k); }
-    uint16_t* const out_begin = buffer + MARKED_WINDOW;
-    uint16_t* out = out_begin;
-    uint16_t* const out_end = out_begin + capacity;
-    if(!fixed_ready) { result.damaged = true; return result; }
-    BitReader r;
-    r.seek(origin, limit, begin_bit);
-    std::unique_ptr<Tables> dynamic(new Tables);
-    constexpr uint32_t LITLEN_MASK = (1u << LITLEN_BITS) - 1u, DIST_MASK = (1u << DIST_BITS) - 1u;
-    for(;;) {
-        r.refill();
-        const uint64_t here = r.position(origin);
-        result.end_bit = here;
-        result.made = static_cast<size_t>(out - out_begin);
-        if(here >= stop_bit) { return result; }
-        if(r.held < 3) { result.damaged = true; return result; }
-        const bool last = r.take(1) != 0;
-        const uint32_t type = r.take(2);
-        const Tables* tables = &fixed;
-        if(type == 0) {
-            r.take(r.held & 7);
-            r.next -= r.held >> 3;
-            r.bits = 0; r.held = 0;
-            if(r.end - r.next < 4) { result.damaged = true; return result; }
-            const uint32_t length = static_cast<uint32_t>(r.next[0]) | (static_cast<uint32_t>(r.next[1]) << 8);
-            const uint32_t check = static_cast<uint32_t>(r.next[2]) | (static_cast<uint32_t>(r.next[3]) << 8);
-            r.next += 4;
-            if((length ^ check) != 0xffffu || static_cast<size_t>(r.end - r.next) < length) { result.damaged = true; return result; }
-            if(static_cast<size_t>(out_end - out) < length) { return result; }              // no room: the chunk ends in front of this block
-            for(uint32_t k = 0; k < length; ++k) { out[k] = r.next[k]; }
-            r.next += length; out += length;
-        } else {
-            if(type == 2) {
-                if(!read_dynamic_tables(r, *dynamic)) { result.damaged = true; return result; }
-                tables = dynamic.get();
-            } else if(type != 1) { result.damaged = true; return result; }
-            const uint32_t* const litlen = tables->litlen;
-            const uint32_t* const dist = tables->dist;
-            for(;;) {
-                if(static_cast<size_t>(out_end - out) < 258 + 3) { return result; }       // no room: what was made up to the block's header stands
-                r.refill();
-                uint32_t entry = litlen[r.bits & LITLEN_MASK];
-                if(kind_of(entry) <= LITERAL3) {
-                    // up to three entries of one to three literals behind one refill (3 x 11 bits)
-                    for(int round = 0; round < 3 && kind_of(entry) <= LITERAL3; ++round) {
-                        const uint32_t count = kind_of(entry) + 1u;
-                        out[0] = static_cast<uint16_t>((entry >> 8) & 0xffu);
-                        out[1] = static_cast<uint16_t>((entry >> 16) & 0xffu);
-                        out[2] = static_cast<uint16_t>((entry >> 24) & 0xffu);
-                        out += count;
-                        r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
-                        entry = litlen[r.bits & LITLEN_MASK];
-                    }
-                    if(r.held < 0) { result.damaged = true; return result; }
-                    continue;                                                               // (the entry looked at last is looked at again behind a refill)
-                }
-                if(kind_of(entry) == SUBTABLE) {
-                    entry = litlen[(entry >> 12) + ((r.bits >> LITLEN_BITS) & ((1u << extra_of(entry)) - 1u))];
-                    r.bits >>= LITLEN_BITS; r.held -= LITLEN_BITS;
-                }
-                uint32_t kind = kind_of(entry);
-                r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
-                if(r.held < 0) { result.damaged = true; return result; }
-                if(kind == LITERAL) { *out++ = static_cast<uint16_t>((entry >> 8) & 0xffu); continue; }
-                if(kind == END) { break; }
-                if(kind != LENGTH) { result.damaged = true; return result; }
-                const uint32_t length = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
-                if(r.held < 32) { r.refill(); }
-                entry = dist[r.bits & DIST_MASK];
-                if(kind_of(entry) == SUBTABLE) {
-                    entry = dist[(entry >> 12) + ((r.bits >> DIST_BITS) & ((1u << extra_of(entry)) - 1u))];
-                    r.bits >>= DIST_BITS; r.held -= DIST_BITS;
-                }
-                kind = kind_of(entry);
-                r.bits >>= entry & 31u; r.held -= static_cast<int>(entry & 31u);
-                if(kind != DISTANCE) { result.damaged = true; return result; }
-                const uint32_t distance = (entry >> 12) + r.take(static_cast<int>(extra_of(entry)));
-                if(r.held < 0 || distance > static_cast<size_t>(out - buffer)) { result.damaged = true; return result; }
-                const uint16_t* from = out - distance;
-                if(distance >= 4) {
-                    uint16_t* to = out;
-                    uint16_t* const stop = out + length;
-                    do { uint64_t word; std::memcpy(&word, from, 8); std::memcpy(to, &word, 8); from += 4; to += 4; } while(to < stop);       // (up to three symbols past the match: the room check above)
-                } else {
-                    for(uint32_t k = 0; k < length; ++k) { out[k] = from[k]; }
-                }
-                out += length;
-            }
-        }
-        if(last) {
-            result.ended = true;
-            r.refill();
-            // (the first byte behind the stream: whole bytes the bit buffer holds were not the stream's)
-            result.end_bit = (static_cast<uint64_t>(r.next - origin) - static_cast<uint64_t>(r.held >> 3)) * 8u;
-            result.made = static_cast<size_t>(out - out_begin);
-            return result;
-        }
-    }
 }
 
 // the first bit in [from_bit, until_bit) where a dynamic, non final block header parses into complete codes and the block's first
@@ -612,6 +513,7 @@ public:
         size_t done = 0;
         while(done < want) {
             if(ready_ == produced_) {
+                if(piece_ + 1 < pieces_.size()) { ++piece_; ready_ = pieces_[piece_].first; produced_ = ready_ + pieces_[piece_].second; continue; }
                 if(ended_) { break; }
                 produce();
                 continue;
@@ -661,6 +563,9 @@ private:
         if(at + 8 > bytes) { return false; }
         deflate_ = in + at;
         raw_.start(deflate_, map_ + size_);
+        tail_pending_ = false;
+        pieces_.clear();
+        piece_ = 0;
         history_ = work_.get() + WINDOW;               // nothing to reach back into yet
         ready_ = produced_ = work_.get() + WINDOW;
         crc_ = 0;
@@ -682,8 +587,9 @@ private:
         }
         // the last 32 KiB of the member's text move to the front
         uint8_t* const base = work_.get() + WINDOW;
-        const size_t keep = std::min(static_cast<size_t>(produced_ - history_), WINDOW);
-        std::memmove(base - keep, produced_ - keep, keep);
+        pieces_.clear();
+        piece_ = 0;
+        const size_t keep = history_into(base);
         history_ = base - keep;
         ready_ = produced_ = base;
         uint8_t* out = base;
@@ -735,6 +641,20 @@ private:
         } else if(made == 0) { throw IOError("damaged gzip data"); }       // no progress and no end
     }
 
+    // the last 32 KiB (or all there is) of the member's text so far to the bytes in front of `to`; how many
+    size_t history_into(uint8_t* to) {
+        size_t keep;
+        if(tail_pending_) {
+            keep = static_cast<size_t>(std::min<uint64_t>(text_, WINDOW));
+            std::memcpy(to - keep, tail_window_.data() + WINDOW - keep, keep);
+            tail_pending_ = false;
+        } else {
+            keep = std::min(static_cast<size_t>(produced_ - history_), WINDOW);
+            std::memmove(to - keep, produced_ - keep, keep);
+        }
+        return keep;
+    }
+
     void end_member(const uint8_t* trailer) {
         if(trailer + 8 > map_ + size_) { throw IOError("a gzip stream ends early"); }
         if(le32(trailer) != crc_ || le32(trailer + 4) != static_cast<uint32_t>(text_)) { throw IOError("a gzip member does not hold to its CRC or its size"); }
@@ -744,7 +664,7 @@ private:
         ended_ = !next_member_;
     }
 
-    // One span of the member on threads_ threads (see marked_decode above): this thread goes on from where the stream stands, the
+    // One span of the member on threads_ threads (see above): this thread goes on from where the stream stands, the
     // others start at block headers found in the chunks behind, every chunk runs to the first block header in the next one;
     // then the chunks are taken in order for as long as each ENDS where the next one STARTS, their markers resolved from the
     // 32 KiB in front of them.  Whatever does not chain — a find that was no header, a chunk out of room — is dropped, and the
@@ -759,19 +679,21 @@ private:
         const size_t chunk_bytes = std::min(MAX_CHUNK, left / static_cast<size_t>(chunks));
         const size_t room = chunk_bytes * EXPANSION;                           // text a chunk may make before it is cut
         // the window in front of the span: the last 32 KiB of the member's text so far (they may sit in the buffer that grows below)
-        const size_t keep = std::min(static_cast<size_t>(produced_ - history_), WINDOW);
-        std::vector<uint8_t> kept(produced_ - keep, produced_);
-        if(span_text_room_ < WINDOW + static_cast<size_t>(chunks) * room + 4096) {
-            span_text_room_ = WINDOW + static_cast<size_t>(chunks) * room + 4096;
+        std::vector<uint8_t> kept(WINDOW);
+        const size_t keep = history_into(kept.data() + WINDOW);
+        if(span_text_room_ < WINDOW + room + fast_inflate::RawStream::MARGIN + 64) {
+            span_text_room_ = WINDOW + room + fast_inflate::RawStream::MARGIN + 64;
             span_text_.reset(new uint8_t[span_text_room_]);
         }
         if(marked_.size() < static_cast<size_t>(chunks)) { marked_.resize(static_cast<size_t>(chunks)); }
         uint8_t* const base = span_text_.get() + WINDOW;
-        if(keep > 0) { std::memcpy(base - keep, kept.data(), keep); }
+        if(keep > 0) { std::memcpy(base - keep, kept.data() + WINDOW - keep, keep); }
         history_ = base - keep;
         ready_ = produced_ = base;
+        pieces_.clear();
+        piece_ = 0;
 
-        struct Chunk { uint64_t begin = 0; bool found = false; fast_inflate::MarkedResult result; };
+        struct Chunk { uint64_t begin = 0, end = 0; bool found = false, ended = false, damaged = false; size_t made = 0; };
         std::vector<Chunk> chunk(static_cast<size_t>(chunks));
         const uint64_t first_byte = here >> 3;
         const uint64_t span_end = (first_byte + static_cast<uint64_t>(chunks) * chunk_bytes) * 8u;
@@ -790,6 +712,9 @@ private:
             uint64_t next = span_end;
             for(int k = chunks - 1; k >= 0; --k) { stop[static_cast<size_t>(k)] = next; if(k > 0 && chunk[static_cast<size_t>(k)].found) { next = chunk[static_cast<size_t>(k)].begin; } }
         }
+        // a chunk's planes: WINDOW of markers, then `plane` bytes of text; the flag plane `plane_stride` behind
+        const size_t plane = room + fast_inflate::RawStream::MARGIN;
+        const size_t plane_stride = WINDOW + plane + 64;
         fast_inflate::RawStream::Status own = fast_inflate::RawStream::Status::ROOM;
         uint8_t* own_out = base;
         parallel_ranges(chunks, 1, chunks, [&](int64_t first, int64_t last, int) {
@@ -797,35 +722,49 @@ private:
                 if(k == 0) {
                     // this thread's own chunk: bytes, with the history it has
                     raw_.stop_at(stop[0]);
-                    own = raw_.run(history_, own_out, base + room);
+                    own = raw_.run(history_, own_out, base + room + fast_inflate::RawStream::MARGIN);
                     raw_.stop_at(~uint64_t(0));
                     continue;
                 }
                 Chunk& c = chunk[static_cast<size_t>(k)];
                 if(!c.found) { continue; }
-                std::vector<uint16_t>& symbols = marked_[static_cast<size_t>(k)];
-                if(symbols.size() < fast_inflate::MARKED_WINDOW + room + 8) { symbols.resize(fast_inflate::MARKED_WINDOW + room + 8); }
-                c.result = fast_inflate::marked_decode(origin, limit, c.begin, stop[static_cast<size_t>(k)], symbols.data(), room);
+                std::vector<uint8_t>& planes = marked_[static_cast<size_t>(k)];
+                if(planes.size() < 2 * plane_stride) { planes.resize(2 * plane_stride); }
+                uint8_t* const text = planes.data();
+                for(size_t i = 0; i < WINDOW; ++i) { text[i] = static_cast<uint8_t>(i); text[plane_stride + i] = static_cast<uint8_t>(1u | ((i >> 8) << 1)); }
+                std::unique_ptr<fast_inflate::RawStream> stream(new fast_inflate::RawStream);
+                stream->start(origin, limit, c.begin);
+                stream->stop_at(stop[static_cast<size_t>(k)]);
+                uint8_t* out = text + WINDOW;
+                const auto status = stream->run_planes<true>(text, out, text + WINDOW + plane, static_cast<ptrdiff_t>(plane_stride));
+                if(status == fast_inflate::RawStream::Status::BOUNDARY) { c.end = stream->bit_position(); c.made = static_cast<size_t>(out - (text + WINDOW)); }
+                else if(status == fast_inflate::RawStream::Status::END) { c.end = static_cast<uint64_t>(stream->after() - origin) * 8u; c.made = static_cast<size_t>(out - (text + WINDOW)); c.ended = true; }
+                else {
+                    // out of room, or a block the stream itself will look at again (damage, or one for zlib): what was made up to
+                    // the last block header stands
+                    c.end = stream->header_bit();
+                    c.made = stream->header_out() != nullptr ? static_cast<size_t>(stream->header_out() - (text + WINDOW)) : 0;
+                    c.damaged = status != fast_inflate::RawStream::Status::ROOM;
+                }
             }
         });
         if(own == fast_inflate::RawStream::Status::DAMAGED) { throw IOError("damaged gzip data"); }
-        size_t made = static_cast<size_t>(own_out - base);
+        const size_t own_made = static_cast<size_t>(own_out - base);
+        size_t made = own_made;
         bool member_ended = own == fast_inflate::RawStream::Status::END;
         uint64_t end_bit = raw_.bit_position();
         // the chain: chunk k is taken when what has been taken so far ends on its first bit
         std::vector<int> taken;
-        std::vector<size_t> place;
         if(own == fast_inflate::RawStream::Status::BOUNDARY) {
             for(int k = 1; k < chunks; ++k) {
                 const Chunk& c = chunk[static_cast<size_t>(k)];
                 if(!c.found || c.begin < end_bit) { continue; }
-                if(c.begin != end_bit || c.result.made == 0 || WINDOW + made + c.result.made + 4096 > span_text_room_) { break; }
+                if(c.begin != end_bit || c.made == 0) { break; }
                 taken.push_back(k);
-                place.push_back(made);
-                made += c.result.made;
-                end_bit = c.result.end_bit;
-                if(c.result.ended) { member_ended = true; break; }
-                if(c.result.damaged) { break; }                  // what it made up to its last whole block stands; the stream goes on from there (and finds the damage, if it is one)
+                made += c.made;
+                end_bit = c.end;
+                if(c.ended) { member_ended = true; break; }
+                if(c.end < stop[static_cast<size_t>(k)]) { break; }       // it stopped early: the stream goes on from there (and finds the damage, if it is one)
             }
         }
         int found = 0;
@@ -833,80 +772,85 @@ private:
         span_wait_ = taken.empty() ? (span_backoff_ = std::min(2 * span_backoff_ + 1, 255)) : (span_backoff_ = 0);
         chunks_taken() += taken.size();
         chunks_dropped() += static_cast<uint64_t>(found) - taken.size();
-        // the window in front of every chunk taken: the last 32 KiB of the text before it — resolved one behind another (32 KiB each)
-        std::vector<std::vector<uint8_t>> window(taken.size());
-        for(size_t t = 0; t < taken.size(); ++t) {
-            std::vector<uint8_t>& w = window[t];
+        // the window in front of every chunk taken — the last 32 KiB of the text before it — and the one behind the last: resolved
+        // one behind another (32 KiB each)
+        std::vector<std::vector<uint8_t>> window(taken.size() + 1);
+        {
+            std::vector<uint8_t>& w = window[0];
             w.assign(WINDOW, 0);
-            if(t == 0) {
-                // the bytes in front of place[0]: this thread's own text and the history in front of it
-                const size_t have = std::min(WINDOW, static_cast<size_t>(base + place[0] - history_));
-                std::memcpy(w.data() + WINDOW - have, base + place[0] - have, have);
-            } else {
-                const std::vector<uint16_t>& symbols = marked_[static_cast<size_t>(taken[t - 1])];
-                const size_t before = chunk[static_cast<size_t>(taken[t - 1])].result.made;
-                const std::vector<uint8_t>& older = window[t - 1];
-                for(size_t i = 0; i < WINDOW; ++i) {
-                    // place i of this window = symbol (before - WINDOW + i) of the chunk before, or (before < WINDOW) the older window's tail
-                    if(before + i >= WINDOW) {
-                        const uint16_t symbol = symbols[fast_inflate::MARKED_WINDOW + before + i - WINDOW];
-                        w[i] = symbol < 256 ? static_cast<uint8_t>(symbol) : older[symbol & (fast_inflate::MARKER - 1)];
-                    } else { w[i] = older[before + i]; }
-                }
+            const size_t have = std::min(WINDOW, static_cast<size_t>(base + own_made - history_));
+            std::memcpy(w.data() + WINDOW - have, base + own_made - have, have);
+        }
+        for(size_t t = 0; t < taken.size(); ++t) {
+            const Chunk& c = chunk[static_cast<size_t>(taken[t])];
+            const uint8_t* const text = marked_[static_cast<size_t>(taken[t])].data() + WINDOW;
+            const uint8_t* const flags = text + plane_stride;
+            const std::vector<uint8_t>& older = window[t];
+            std::vector<uint8_t>& w = window[t + 1];
+            w.assign(WINDOW, 0);
+            for(size_t i = 0; i < WINDOW; ++i) {
+                // place i of the window behind this chunk = byte (made - WINDOW + i) of the chunk, or (made < WINDOW) the older window's tail
+                if(c.made + i >= WINDOW) {
+                    const size_t at = c.made + i - WINDOW;
+                    w[i] = flags[at] == 0 ? text[at] : older[static_cast<size_t>(text[at]) | (static_cast<size_t>(flags[at] >> 1) << 8)];
+                } else { w[i] = older[c.made + i]; }
             }
         }
-        // every chunk's symbols into bytes at its place, and its CRC
+        // every chunk's markers into bytes, in place, and its CRC
         std::vector<uint32_t> crc(taken.size(), 0);
         parallel_ranges(static_cast<int64_t>(taken.size()), 1, threads_, [&](int64_t first, int64_t last, int) {
             for(int64_t t = first; t < last; ++t) {
                 const Chunk& c = chunk[static_cast<size_t>(taken[static_cast<size_t>(t)])];
-                const uint16_t* const symbols = marked_[static_cast<size_t>(taken[static_cast<size_t>(t)])].data() + fast_inflate::MARKED_WINDOW;
+                uint8_t* const text = marked_[static_cast<size_t>(taken[static_cast<size_t>(t)])].data() + WINDOW;
+                const uint8_t* const flags = text + plane_stride;
                 const uint8_t* const w = window[static_cast<size_t>(t)].data();
-                uint8_t* const to = base + place[static_cast<size_t>(t)];
-                const size_t n = c.result.made;
+                const size_t n = c.made;
+                // (markers do not die out in FASTQ text: a read's name is a match into the name before it, and what the first name of
+                // the chunk took from the window is copied from record to record to the chunk's end — a third of the bytes)
                 size_t i = 0;
 #ifdef PHQ_CRC_FOLDED
-                // sixteen symbols at a time where none of them is a marker (behind a chunk's first tens of KiB nearly all)
                 for(; i + 16 <= n; i += 16) {
-                    const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(symbols + i));
-                    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(symbols + i + 8));
-                    if(_mm_movemask_epi8(_mm_cmpeq_epi16(_mm_srli_epi16(_mm_or_si128(a, b), 8), _mm_setzero_si128())) == 0xffff) {
-                        _mm_storeu_si128(reinterpret_cast<__m128i*>(to + i), _mm_packus_epi16(a, b));
-                    } else {
-                        for(size_t j = i; j < i + 16; ++j) { const uint16_t symbol = symbols[j]; to[j] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
+                    const __m128i sixteen = _mm_loadu_si128(reinterpret_cast<const __m128i*>(flags + i));
+                    unsigned marked = ~static_cast<unsigned>(_mm_movemask_epi8(_mm_cmpeq_epi8(sixteen, _mm_setzero_si128()))) & 0xffffu;
+                    while(marked) {
+                        const size_t j = i + static_cast<size_t>(__builtin_ctz(marked));
+                        marked &= marked - 1u;
+                        text[j] = w[static_cast<size_t>(text[j]) | (static_cast<size_t>(flags[j] >> 1) << 8)];
                     }
                 }
 #endif
-                for(; i + 4 <= n; i += 4) {
-                    uint64_t four;
-                    std::memcpy(&four, symbols + i, 8);
-                    if((four & 0xff00ff00ff00ff00ull) == 0) {
-                        to[i] = static_cast<uint8_t>(four); to[i + 1] = static_cast<uint8_t>(four >> 16); to[i + 2] = static_cast<uint8_t>(four >> 32); to[i + 3] = static_cast<uint8_t>(four >> 48);
-                    } else {
-                        for(size_t j = i; j < i + 4; ++j) { const uint16_t symbol = symbols[j]; to[j] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
-                    }
+                for(; i + 8 <= n; i += 8) {
+                    uint64_t eight;
+                    std::memcpy(&eight, flags + i, 8);
+                    if(eight == 0) { continue; }
+                    for(size_t j = i; j < i + 8; ++j) { if(flags[j]) { text[j] = w[static_cast<size_t>(text[j]) | (static_cast<size_t>(flags[j] >> 1) << 8)]; } }
                 }
-                for(; i < n; ++i) { const uint16_t symbol = symbols[i]; to[i] = symbol < 256 ? static_cast<uint8_t>(symbol) : w[symbol & (fast_inflate::MARKER - 1)]; }
-                crc[static_cast<size_t>(t)] = crc_more(0, to, n);
+                for(; i < n; ++i) { if(flags[i]) { text[i] = w[static_cast<size_t>(text[i]) | (static_cast<size_t>(flags[i] >> 1) << 8)]; } }
+                crc[static_cast<size_t>(t)] = crc_more(0, text, n);
             }
         });
-        const size_t own_made = static_cast<size_t>(own_out - base);
         crc_ = crc_more(crc_, base, own_made);
         for(size_t t = 0; t < taken.size(); ++t) {
-            crc_ = static_cast<uint32_t>(crc32_combine(crc_, crc[t], static_cast<z_off_t>(chunk[static_cast<size_t>(taken[t])].result.made)));
+            crc_ = static_cast<uint32_t>(crc32_combine(crc_, crc[t], static_cast<z_off_t>(chunk[static_cast<size_t>(taken[t])].made)));
         }
         text_ += made;
-        produced_ = base + made;
+        // the span's text in pieces: this thread's own, then every chunk taken, where they were made
+        pieces_.clear();
+        piece_ = 0;
+        pieces_.push_back({base, own_made});
+        for(const int k : taken) { pieces_.push_back({marked_[static_cast<size_t>(k)].data() + WINDOW, chunk[static_cast<size_t>(k)].made}); }
+        ready_ = pieces_[0].first;
+        produced_ = ready_ + pieces_[0].second;
         if(!taken.empty()) {
+            // the history behind the span: the window behind the last chunk taken
+            tail_window_.swap(window[taken.size()]);
+            tail_pending_ = true;
             // the stream goes on behind the last chunk taken (a block header, or the trailer)
             raw_.start(origin, limit, end_bit);
             if(member_ended) { end_member(origin + (end_bit >> 3)); }
         } else if(member_ended) {
             end_member(raw_.after());
-        } else if(own == fast_inflate::RawStream::Status::REFUSED || made == 0) {
-            // a block the decoder does not take (the one thread path hands it to zlib), or no room: nothing was made here
-            if(made == 0) { return false; }
-        }
+        } else if(made == 0) { return false; }           // a block the decoder does not take (the one thread path hands it to zlib): nothing was made here
         return true;
     }
 
@@ -935,7 +879,11 @@ private:
     const uint8_t* deflate_ = nullptr;             // the member's deflate stream (behind its header)
     std::unique_ptr<uint8_t[]> span_text_;         // WINDOW of history, then a span's text
     size_t span_text_room_ = 0;
-    std::vector<std::vector<uint16_t>> marked_;    // per chunk: the symbols of marked_decode
+    std::vector<std::vector<uint8_t>> marked_;     // per chunk: its text plane and its flag plane (run_planes<true>)
+    std::vector<std::pair<const uint8_t*, size_t>> pieces_;      // a span's text where it was made: this thread's own piece, then every chunk taken
+    size_t piece_ = 0;
+    std::vector<uint8_t> tail_window_;             // the last 32 KiB of the text behind a span whose last piece is a chunk's
+    bool tail_pending_ = false;
     size_t at_ = 0;                                // the member's first byte in the file
     std::unique_ptr<uint8_t[]> work_;              // WINDOW of history, then CHUNK of new text (and the decoder's margin)
     const uint8_t* history_ = nullptr;             // the first byte of the member's text that is still held

@@ -20,6 +20,8 @@ if os.environ.get("QC"):
     spec["enable quality control"] = True
 SPLIT = os.environ.get("SPLIT")                  # a FASTQ file per barcode (SPLIT=plain) or a gzip one (SPLIT=gz): target "split"
 s = DecoderSet(spec, device=0)
+if os.environ.get("MODE"):                       # fast | literal; default: PHQ_MODE_AUTO (exact tags where SAM records are written)
+    s.set_mode({"fast": capi.MODE_FAST, "literal": capi.MODE_LITERAL}[os.environ["MODE"]])
 job = capi.compile_job(spec)
 pool = 1 << 20
 code, quality, flag, _ = synthetic.generate_rows(job, pool, 3)
