@@ -513,7 +513,26 @@ public:
         size_t done = 0;
         while(done < want) {
             if(ready_ == produced_) {
-                if(piece_ + 1 < pieces_.size()) { ++piece_; ready_ = pieces_[piece_].first; produced_ = ready_ + pieces_[piece_].second; continue; }
+                if(piece_ + 1 < pieces_.size()) {
+                    // the chunks of a span: copied out side by side where they all fit (one thread's copy of a span's text took as long as
+                    // its decoding on sixteen)
+                    size_t behind = 0;
+                    for(size_t k = piece_ + 1; k < pieces_.size(); ++k) { behind += pieces_[k].second; }
+                    if(threads_ > 1 && behind <= want - done && pieces_.size() - piece_ > 2) {
+                        std::vector<size_t> place(pieces_.size(), 0);
+                        size_t at = done;
+                        for(size_t k = piece_ + 1; k < pieces_.size(); ++k) { place[k] = at; at += pieces_[k].second; }
+                        const size_t first_piece = piece_ + 1;
+                        parallel_ranges(static_cast<int64_t>(pieces_.size() - first_piece), 1, threads_, [&](int64_t first, int64_t last, int) {
+                            for(int64_t k = first; k < last; ++k) { const size_t p = first_piece + static_cast<size_t>(k); std::memcpy(to + place[p], pieces_[p].first, pieces_[p].second); }
+                        });
+                        done = at;
+                        piece_ = pieces_.size() - 1;
+                        ready_ = produced_ = pieces_[piece_].first + pieces_[piece_].second;
+                        continue;
+                    }
+                    ++piece_; ready_ = pieces_[piece_].first; produced_ = ready_ + pieces_[piece_].second; continue;
+                }
                 if(ended_) { break; }
                 produce();
                 continue;
@@ -543,9 +562,9 @@ private:
     static constexpr size_t WINDOW = size_t(1) << 15;
     static constexpr size_t CHUNK = size_t(1) << 20;
     static constexpr size_t MIN_CHUNK = size_t(256) << 10;       // compressed bytes a thread: a search for a block header costs a few ms
-    static constexpr size_t MAX_CHUNK = size_t(512) << 10;
+    static constexpr size_t MAX_CHUNK = size_t(1) << 20;
     static constexpr size_t SEARCH = size_t(128) << 10;          // input bytes a chunk is searched for a block header
-    static constexpr size_t EXPANSION = 7;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
+    static constexpr size_t EXPANSION = 6;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
 
     bool begin_member() {
         const uint8_t* const in = map_ + at_;
@@ -696,22 +715,12 @@ private:
         struct Chunk { uint64_t begin = 0, end = 0; bool found = false, ended = false, damaged = false; size_t made = 0; };
         std::vector<Chunk> chunk(static_cast<size_t>(chunks));
         const uint64_t first_byte = here >> 3;
-        const uint64_t span_end = (first_byte + static_cast<uint64_t>(chunks) * chunk_bytes) * 8u;
-        // where the chunks start: a block header in each chunk's part of the input (none found: the chunk before runs through)
-        parallel_ranges(chunks - 1, 1, chunks - 1, [&](int64_t first, int64_t last, int) {
-            for(int64_t k = first + 1; k < last + 1; ++k) {
-                Chunk& c = chunk[static_cast<size_t>(k)];
-                // (a block of zlib's or pigz's is tens of KiB of input: what is not found within SEARCH bytes is not there — text that
-                // does not compress, stored or fixed blocks — and a search through all of a chunk would cost more than its decoding)
-                const uint64_t from = (first_byte + static_cast<uint64_t>(k) * chunk_bytes) * 8u;
-                c.found = fast_inflate::find_block(origin, limit, from, std::min(from + SEARCH * 8u, (first_byte + static_cast<uint64_t>(k + 1) * chunk_bytes) * 8u), &c.begin);
-            }
-        });
-        std::vector<uint64_t> stop(static_cast<size_t>(chunks), span_end);       // the first bit of the next chunk that found one
-        {
-            uint64_t next = span_end;
-            for(int k = chunks - 1; k >= 0; --k) { stop[static_cast<size_t>(k)] = next; if(k > 0 && chunk[static_cast<size_t>(k)].found) { next = chunk[static_cast<size_t>(k)].begin; } }
-        }
+        // Every chunk behind this thread's own starts at the first block header found in its part of the input and runs to the
+        // first block header in the next part: the same header, when the search takes every header there is (a FASTQ stream's
+        // blocks are all dynamic); where it is not — a stored or fixed block, a find that was none — the chain below breaks
+        // there and the stream goes on from the last bit taken.  (Search and decoding are ONE parallel phase: a search phase of
+        // its own in front cost a spawn and a join of every thread per span.)
+        auto nominal = [&](int64_t k) { return (first_byte + static_cast<uint64_t>(k) * chunk_bytes) * 8u; };
         // a chunk's planes: WINDOW of markers, then `plane` bytes of text; the flag plane `plane_stride` behind
         const size_t plane = room + fast_inflate::RawStream::MARGIN;
         const size_t plane_stride = WINDOW + plane + 64;
@@ -721,12 +730,15 @@ private:
             for(int64_t k = first; k < last; ++k) {
                 if(k == 0) {
                     // this thread's own chunk: bytes, with the history it has
-                    raw_.stop_at(stop[0]);
+                    raw_.stop_at(nominal(1));
                     own = raw_.run(history_, own_out, base + room + fast_inflate::RawStream::MARGIN);
                     raw_.stop_at(~uint64_t(0));
                     continue;
                 }
                 Chunk& c = chunk[static_cast<size_t>(k)];
+                // (a block of zlib's or pigz's is tens of KiB of input: what is not found within SEARCH bytes is not there — text that
+                // does not compress, stored or fixed blocks — and a search through all of a chunk would cost more than its decoding)
+                c.found = fast_inflate::find_block(origin, limit, nominal(k), std::min(nominal(k) + SEARCH * 8u, nominal(k + 1)), &c.begin);
                 if(!c.found) { continue; }
                 std::vector<uint8_t>& planes = marked_[static_cast<size_t>(k)];
                 if(planes.size() < 2 * plane_stride) { planes.resize(2 * plane_stride); }
@@ -734,7 +746,7 @@ private:
                 for(size_t i = 0; i < WINDOW; ++i) { text[i] = static_cast<uint8_t>(i); text[plane_stride + i] = static_cast<uint8_t>(1u | ((i >> 8) << 1)); }
                 std::unique_ptr<fast_inflate::RawStream> stream(new fast_inflate::RawStream);
                 stream->start(origin, limit, c.begin);
-                stream->stop_at(stop[static_cast<size_t>(k)]);
+                stream->stop_at(nominal(k + 1));
                 uint8_t* out = text + WINDOW;
                 const auto status = stream->run_planes<true>(text, out, text + WINDOW + plane, static_cast<ptrdiff_t>(plane_stride));
                 if(status == fast_inflate::RawStream::Status::BOUNDARY) { c.end = stream->bit_position(); c.made = static_cast<size_t>(out - (text + WINDOW)); }
@@ -764,7 +776,7 @@ private:
                 made += c.made;
                 end_bit = c.end;
                 if(c.ended) { member_ended = true; break; }
-                if(c.end < stop[static_cast<size_t>(k)]) { break; }       // it stopped early: the stream goes on from there (and finds the damage, if it is one)
+                if(c.end < nominal(k + 1)) { break; }       // it stopped early: the stream goes on from there (and finds the damage, if it is one)
             }
         }
         int found = 0;
@@ -788,13 +800,11 @@ private:
             const std::vector<uint8_t>& older = window[t];
             std::vector<uint8_t>& w = window[t + 1];
             w.assign(WINDOW, 0);
-            for(size_t i = 0; i < WINDOW; ++i) {
-                // place i of the window behind this chunk = byte (made - WINDOW + i) of the chunk, or (made < WINDOW) the older window's tail
-                if(c.made + i >= WINDOW) {
-                    const size_t at = c.made + i - WINDOW;
-                    w[i] = flags[at] == 0 ? text[at] : older[static_cast<size_t>(text[at]) | (static_cast<size_t>(flags[at] >> 1) << 8)];
-                } else { w[i] = older[c.made + i]; }
-            }
+            // place i of the window behind this chunk = byte (made - WINDOW + i) of the chunk, or (made < WINDOW) the older window's tail
+            const size_t from_chunk = std::min(c.made, WINDOW), from_older = WINDOW - from_chunk;
+            if(from_older > 0) { std::memcpy(w.data(), older.data() + c.made, from_older); }
+            std::memcpy(w.data() + from_older, text + c.made - from_chunk, from_chunk);
+            resolve(w.data() + from_older, flags + c.made - from_chunk, from_chunk, older.data());
         }
         // every chunk's markers into bytes, in place, and its CRC
         std::vector<uint32_t> crc(taken.size(), 0);
@@ -805,27 +815,7 @@ private:
                 const uint8_t* const flags = text + plane_stride;
                 const uint8_t* const w = window[static_cast<size_t>(t)].data();
                 const size_t n = c.made;
-                // (markers do not die out in FASTQ text: a read's name is a match into the name before it, and what the first name of
-                // the chunk took from the window is copied from record to record to the chunk's end — a third of the bytes)
-                size_t i = 0;
-#ifdef PHQ_CRC_FOLDED
-                for(; i + 16 <= n; i += 16) {
-                    const __m128i sixteen = _mm_loadu_si128(reinterpret_cast<const __m128i*>(flags + i));
-                    unsigned marked = ~static_cast<unsigned>(_mm_movemask_epi8(_mm_cmpeq_epi8(sixteen, _mm_setzero_si128()))) & 0xffffu;
-                    while(marked) {
-                        const size_t j = i + static_cast<size_t>(__builtin_ctz(marked));
-                        marked &= marked - 1u;
-                        text[j] = w[static_cast<size_t>(text[j]) | (static_cast<size_t>(flags[j] >> 1) << 8)];
-                    }
-                }
-#endif
-                for(; i + 8 <= n; i += 8) {
-                    uint64_t eight;
-                    std::memcpy(&eight, flags + i, 8);
-                    if(eight == 0) { continue; }
-                    for(size_t j = i; j < i + 8; ++j) { if(flags[j]) { text[j] = w[static_cast<size_t>(text[j]) | (static_cast<size_t>(flags[j] >> 1) << 8)]; } }
-                }
-                for(; i < n; ++i) { if(flags[i]) { text[i] = w[static_cast<size_t>(text[i]) | (static_cast<size_t>(flags[i] >> 1) << 8)]; } }
+                resolve(text, flags, n, w);
                 crc[static_cast<size_t>(t)] = crc_more(0, text, n);
             }
         });
@@ -852,6 +842,25 @@ private:
             end_member(raw_.after());
         } else if(made == 0) { return false; }           // a block the decoder does not take (the one thread path hands it to zlib): nothing was made here
         return true;
+    }
+
+    // markers into bytes: text[i] = window[place] wherever flags[i] says so.  (Markers do not die out in FASTQ text: a read's name
+    // is a match into the name before it, and what the first name of the chunk took from the window is copied from record to
+    // record to the chunk's end — a third of the bytes.)
+    static void resolve(uint8_t* text, const uint8_t* flags, size_t n, const uint8_t* w) {
+        size_t i = 0;
+#ifdef PHQ_CRC_FOLDED
+        for(; i + 16 <= n; i += 16) {
+            const __m128i sixteen = _mm_loadu_si128(reinterpret_cast<const __m128i*>(flags + i));
+            unsigned marked = ~static_cast<unsigned>(_mm_movemask_epi8(_mm_cmpeq_epi8(sixteen, _mm_setzero_si128()))) & 0xffffu;
+            while(marked) {
+                const size_t j = i + static_cast<size_t>(__builtin_ctz(marked));
+                marked &= marked - 1u;
+                text[j] = w[static_cast<size_t>(text[j]) | (static_cast<size_t>(flags[j] >> 1) << 8)];
+            }
+        }
+#endif
+        for(; i < n; ++i) { if(flags[i]) { text[i] = w[static_cast<size_t>(text[i]) | (static_cast<size_t>(flags[i] >> 1) << 8)]; } }
     }
 
     static uint32_t le32(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16) | (static_cast<uint32_t>(p[3]) << 24); }
