@@ -564,7 +564,7 @@ private:
     static constexpr size_t MIN_CHUNK = size_t(256) << 10;       // compressed bytes a thread: a search for a block header costs a few ms
     static constexpr size_t MAX_CHUNK = size_t(1) << 20;
     static constexpr size_t SEARCH = size_t(128) << 10;          // input bytes a chunk is searched for a block header
-    static constexpr size_t EXPANSION = 6;                       // text a chunk may make, in compressed bytes (FASTQ: 4 to 6; a chunk that makes more is cut at its last whole block)
+    static constexpr size_t CHUNK_TEXT = size_t(5) << 20;        // text a chunk should make
 
     bool begin_member() {
         const uint8_t* const in = map_ + at_;
@@ -694,9 +694,15 @@ private:
         const uint64_t here = raw_.bit_position();
         const size_t left = static_cast<size_t>(limit - origin) - static_cast<size_t>(here >> 3);
         if(raw_.finished() || left < 4 * MIN_CHUNK) { return false; }
-        const int chunks = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads_), left / MIN_CHUNK));
-        const size_t chunk_bytes = std::min(MAX_CHUNK, left / static_cast<size_t>(chunks));
-        const size_t room = chunk_bytes * EXPANSION;                           // text a chunk may make before it is cut
+        consumed_ = static_cast<size_t>(here >> 3);
+        // a chunk: about CHUNK_TEXT bytes of text at the ratio the stream has shown so far (FASTQ: 4 to 5; with constant qualities 8
+        // and more), and half as much again of room — a chunk that makes more is cut at its last whole block and the chain ends there
+        const double ratio = consumed_ > (size_t(64) << 10) ? std::max(1.0, static_cast<double>(text_) / static_cast<double>(consumed_)) : 5.0;
+        const size_t wanted = std::max(MIN_CHUNK, std::min(MAX_CHUNK, static_cast<size_t>(static_cast<double>(CHUNK_TEXT) / ratio)));
+        const int chunks = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads_), left / wanted));
+        if(chunks < 2) { return false; }
+        const size_t chunk_bytes = std::min(wanted, left / static_cast<size_t>(chunks));
+        const size_t room = static_cast<size_t>(static_cast<double>(chunk_bytes) * ratio * 1.5) + (size_t(256) << 10);      // text a chunk may make before it is cut
         // the window in front of the span: the last 32 KiB of the member's text so far (they may sit in the buffer that grows below)
         std::vector<uint8_t> kept(WINDOW);
         const size_t keep = history_into(kept.data() + WINDOW);
@@ -885,6 +891,7 @@ private:
     size_t size_ = 0;
     int threads_ = 1;
     int span_wait_ = 0, span_backoff_ = 0;
+    size_t consumed_ = 0;                          // bytes of the member's deflate stream behind the decoder
     const uint8_t* deflate_ = nullptr;             // the member's deflate stream (behind its header)
     std::unique_ptr<uint8_t[]> span_text_;         // WINDOW of history, then a span's text
     size_t span_text_room_ = 0;
