@@ -1163,7 +1163,8 @@ bool open_device_inputs(const TranscodePlan& plan, std::vector<PlainFile>& file)
                 // one member: a sequential stream, through fast_inflate.hpp's decoder in its streaming form (gzip_stream.hpp)
                 p.stream.reset(new GzipStream());
                 try {
-                    if(p.stream->open(plan.input_feed[static_cast<size_t>(f)].path, std::min(32, 2 * host_threads()))) {      // (twice the threads: a span's phases leave gaps — this thread's own chunk is done first, the windows are resolved by one — that a second set of chunks fills: 25 -> 34 Mreads/s for two files on 16 cores) inflated = static_cast<int>(p.stream->read(p.head.data(), p.head.size())); }
+                    // (twice the threads: a span's phases leave gaps — this thread's own chunk is done first, the windows are resolved by one — that a second set of chunks fills: 25 -> 34 Mreads/s for two files on 16 cores)
+                    if(p.stream->open(plan.input_feed[static_cast<size_t>(f)].path, std::min(32, 2 * host_threads()))) { inflated = static_cast<int>(p.stream->read(p.head.data(), p.head.size())); }
                     else { p.stream.reset(); }
                 } catch(const std::exception&) { p.stream.reset(); inflated = -1; }
             }
