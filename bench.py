@@ -270,6 +270,9 @@ def fastq_end_to_end(args, code, quality, flag, n):
         split = DecoderSet(split_spec, device=0)
         split.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
         split.transcode_job(1 << 20)
+        for name in os.listdir(directory):                                      # a run creates its outputs: giving back the pages of the previous ones is not part of it (as for sam_text)
+            if name.startswith(("barcode_", "undetermined")):
+                os.unlink(os.path.join(directory, name))
         t0 = time.perf_counter()
         incoming, _ = split.transcode_job(1 << 20)
         dt = time.perf_counter() - t0
