@@ -270,6 +270,13 @@ int phq_profile_collect(phq_decoder_set* set, double* milliseconds /* [PHQ_KERNE
  * it: *chain_json = [{"decoder": k, "kernel": "pamld_stream_kernel", "kind": PHQ_KERNEL_*, "ms": t}, ...] (release with
  * phq_free_string).  Forgets the spans like phq_profile_collect; call one or the other after a batch. */
 int phq_profile_chain(phq_decoder_set* set, char** chain_json);
+/* The chain a batch of n_read reads WOULD take in `mode` (PHQ_MODE_*), without running it: the stage dispatcher itself walks its
+ * predicates for every decoder with its launches switched off, so the names are the ones phq_profile_chain reports after a run —
+ * *chain_json = [{"decoder": k, "kernel": "...", "kind": PHQ_KERNEL_*}, ...] (release with phq_free_string).  The one table
+ * shape -> chain there is: tests/test_shape_grid_plan.py walks a grid of decoder shapes through it.  Works on a set created with
+ * PHQ_DEVICE_NONE (the tables are then built in host memory, for their presence alone; grids are sized for an MI355X's 256 CUs).
+ * No reference counterpart: the reference has one code path per algorithm (pamld.cpp:37-123, mdd.cpp:37-86). */
+int phq_plan_chain(phq_decoder_set* set, int64_t n_read, int32_t mode, char** chain_json);
 /* The node's practical HBM ceiling next to the 8 TB/s rooflines are priced against: a plain streaming copy of `bytes` (a
  * multiple of 16), 16 bytes a lane, `repeats` times; *gigabytes_per_second counts bytes read + bytes written. */
 int phq_copy_bandwidth(int32_t device, uint64_t bytes, int32_t repeats, double* gigabytes_per_second);

@@ -27,7 +27,7 @@ SYMBOLS = ("phq_create", "phq_destroy", "phq_last_error", "phq_get_layout", "phq
            "phq_stage_reads", "phq_classify_device", "phq_classify_host", "phq_host_alloc", "phq_host_free",
            "phq_stats_reset", "phq_stats_device_pointer", "phq_stats_export", "phq_stats_import", "phq_stats_merge",
            "phq_stats_allreduce", "phq_summarize", "phq_stats_options", "phq_report_json", "phq_format_double",
-           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_copy_bandwidth", "phq_device_path_counters", "phq_pack_planes", "phq_classify_host_packed", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
+           "phq_profile_enable", "phq_profile_collect", "phq_profile_chain", "phq_plan_chain", "phq_copy_bandwidth", "phq_device_path_counters", "phq_pack_planes", "phq_classify_host_packed", "phq_transcode_fastq_to_sam", "phq_transcode_job", "phq_transcode_job_copies", "phq_transcode_plan",
            "phq_compile_job", "phq_load_job", "phq_free_string", "phq_adjust_prior", "phq_build_id", "phq_qc_export", "phq_qc_merge")
 
 
@@ -106,6 +106,7 @@ def load_library():
     L.phq_profile_enable.argtypes = [P, I32]
     L.phq_profile_collect.argtypes = [P, P, P]
     L.phq_profile_chain.argtypes = [P, ctypes.POINTER(ctypes.c_void_p)]
+    L.phq_plan_chain.argtypes = [P, I64, I32, ctypes.POINTER(ctypes.c_void_p)]
     L.phq_copy_bandwidth.argtypes = [I32, U64, I32, ctypes.POINTER(ctypes.c_double)]
     L.phq_device_path_counters.argtypes = [ctypes.POINTER(U64)]
     L.phq_pack_planes.argtypes = [P, I64, I64, P, P, P, P, I64, ctypes.POINTER(I64)]
@@ -398,6 +399,15 @@ class DecoderSet:
         """phq_profile_chain: every timed launch since the last collect, in launch order, under the kernel's name."""
         out = ctypes.c_void_p()
         self._check(self.lib.phq_profile_chain(self.handle, ctypes.byref(out)))
+        try:
+            return json.loads(ctypes.string_at(out.value).decode())
+        finally:
+            self.lib.phq_free_string(out)
+
+    def plan_chain(self, n_read: int, mode: int = MODE_AUTO) -> List[Dict[str, Any]]:
+        """phq_plan_chain: the kernels a batch of n_read reads would take, named by the stage dispatcher with its launches off."""
+        out = ctypes.c_void_p()
+        self._check(self.lib.phq_plan_chain(self.handle, n_read, mode, ctypes.byref(out)))
         try:
             return json.loads(ctypes.string_at(out.value).decode())
         finally:

@@ -258,6 +258,18 @@ int phq_device_path_counters(uint64_t counters[4]) {
     });
 }
 
+int phq_plan_chain(phq_decoder_set* set, int64_t n_read, int32_t mode, char** chain_json) {
+    if(chain_json != nullptr) { *chain_json = nullptr; }
+    return guarded(set, [&]() {
+        require(set, "set"); require(chain_json, "chain_json");
+        const std::string text = set->impl.plan_chain(n_read, mode);
+        char* const out = static_cast<char*>(std::malloc(text.size() + 1));
+        if(out == nullptr) { throw std::bad_alloc(); }
+        std::memcpy(out, text.c_str(), text.size() + 1);
+        *chain_json = out;
+    });
+}
+
 int phq_profile_chain(phq_decoder_set* set, char** chain_json) {
     if(chain_json != nullptr) { *chain_json = nullptr; }
     return guarded(set, [&]() {

@@ -175,6 +175,8 @@ void DecoderSet::release() {
     if(order_event_) { (void)hipEventDestroy(static_cast<hipEvent_t>(order_event_)); order_event_ = nullptr; order_pending_ = false; }
     for(void* p : device_allocation_) { (void)hipFree(p); }
     device_allocation_.clear();
+    for(void* p : host_image_) { std::free(p); }
+    host_image_.clear();
     (void)hipFree(device_worklist_);
     device_worklist_ = nullptr;
     worklist_capacity_ = 0;
@@ -299,17 +301,30 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
 }
 
 void DecoderSet::build_device_images() {
-    int count = 0;
-    check(hipGetDeviceCount(&count), "hipGetDeviceCount");
-    if(device_ >= count) { throw ConfigurationError("no HIP device " + std::to_string(device_)); }
-    check(hipSetDevice(device_), "hipSetDevice");
-    hipDeviceProp_t properties;
-    check(hipGetDeviceProperties(&properties, device_), "hipGetDeviceProperties");
-    // the largest grid of any stage kernel, 16 workgroups per CU; stage.hip picks each kernel's own share of it
-    // (well past the 256 CUs either way, guide §6 G11)
-    max_blocks_ = properties.multiProcessorCount * GRID_BLOCKS_PER_CU;
+    // a set without a device (plan_chain): the same tables, in host memory — the dispatcher's predicates ask which of them
+    // there are; an MI355X's 256 CUs for the grids
+    const bool host_only = device_ < 0;
+    if(host_only) { max_blocks_ = 256 * GRID_BLOCKS_PER_CU; }
+    else {
+        int count = 0;
+        check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+        if(device_ >= count) { throw ConfigurationError("no HIP device " + std::to_string(device_)); }
+        check(hipSetDevice(device_), "hipSetDevice");
+        hipDeviceProp_t properties;
+        check(hipGetDeviceProperties(&properties, device_), "hipGetDeviceProperties");
+        // the largest grid of any stage kernel, 16 workgroups per CU; stage.hip picks each kernel's own share of it
+        // (well past the 256 CUs either way, guide §6 G11)
+        max_blocks_ = properties.multiProcessorCount * GRID_BLOCKS_PER_CU;
+    }
 
     auto upload = [&](const void* source, size_t bytes) -> void* {
+        if(host_only) {
+            void* const image = std::malloc(bytes > 0 ? bytes : 16);
+            if(image == nullptr) { throw std::bad_alloc(); }
+            host_image_.push_back(image);
+            if(bytes > 0) { std::memcpy(image, source, bytes); }
+            return image;
+        }
         void* pointer = nullptr;
         check(hipMalloc(&pointer, bytes > 0 ? bytes : 16), "hipMalloc");
         device_allocation_.push_back(pointer);
@@ -1241,6 +1256,7 @@ void DecoderSet::build_device_images() {
     }
     device_decoder_ = static_cast<DevDecoder*>(upload(host_decoder_.data(), host_decoder_.size() * sizeof(DevDecoder)));
 
+    if(host_only) { return; }
     void* stats = nullptr;
     check(hipMalloc(&stats, static_cast<size_t>(job_.stats_words) * sizeof(uint64_t)), "hipMalloc");
     device_allocation_.push_back(stats);
@@ -1397,6 +1413,58 @@ size_t DecoderSet::carry_words(int64_t n_read) const {
     if(!any) { return 0; }
     const size_t worst = static_cast<size_t>(n_read) + (static_cast<size_t>(max_blocks_) + 1) * 1024;
     return CARRY_PLANES * (worst / 4 + static_cast<size_t>(max_blocks_) * 512);
+}
+
+std::string DecoderSet::plan_chain(int64_t n_read, int32_t mode) {
+    if(mode != MODE_LITERAL && mode != MODE_FAST && mode != MODE_AUTO) { throw ConfigurationError("unknown classification mode " + std::to_string(mode)); }
+    if(n_read <= 0) { return "[]"; }
+    if(host_decoder_.empty() && !job_.decoder.empty()) {
+        if(device_ >= 0) { throw InternalError("the decoder set holds no tables"); }
+        build_device_images();
+    }
+    struct Recorder : LaunchTimer {
+        std::string out = "[";
+        void begin(int32_t kind, void*, const char* name) override {
+            out += std::string(out.size() > 1 ? ", " : "") + "{\"decoder\": " + std::to_string(decoder) + ", \"kernel\": \"" + name + "\", \"kind\": " + std::to_string(kind) + "}";
+        }
+        void end(void*) override {}
+    } recorder;
+    struct PlanOnly { PlanOnly() { stage_plan_only(true); } ~PlanOnly() { stage_plan_only(false); } } guard;
+    // the arguments the dispatcher looks at: which buffers there are (not what they hold), the batch's size, the stage's place
+    static unsigned char present[64];
+    const size_t n_decoder = job_.decoder.size();
+    for(size_t k = 0; k < n_decoder; ++k) {
+        const DecoderConfig& c = job_.decoder[k];
+        size_t folded = 0;
+        if(c.algorithm == Algorithm::PAMLD || c.algorithm == Algorithm::MDD) {
+            while(folded < 4 && k + folded + 1 < n_decoder &&
+                  (job_.decoder[k + folded + 1].algorithm == Algorithm::PASSTHROUGH || job_.decoder[k + folded + 1].algorithm == Algorithm::NAIVE)) { ++folded; }
+        }
+        StageArgs args;
+        std::memset(&args, 0, sizeof(args));
+        const bool worklist = needs_worklist();
+        args.worklist_count = worklist ? reinterpret_cast<uint32_t*>(present) : nullptr;
+        args.worklist = worklist ? reinterpret_cast<uint32_t*>(present) : nullptr;
+        args.carry = (worklist && carry_words(n_read) > 0) ? reinterpret_cast<uint32_t*>(present) : nullptr;
+        args.decoder = device_decoder_ + k;
+        args.n_read = n_read;
+        args.base = c.plane_stride ? present : nullptr;
+        args.quality = c.plane_stride ? present : nullptr;
+        args.input_flag = present;
+        args.result = c.result_slot >= 0 ? reinterpret_cast<DevResult*>(present) : nullptr;
+        args.word = reinterpret_cast<uint32_t*>(present);
+        args.stats = reinterpret_cast<unsigned long long*>(present);
+        args.first_stage = k == 0 ? 1 : 0;
+        args.job_outgoing = k + folded + 1 == n_decoder ? 1 : 0;
+        args.last_stage = (args.job_outgoing || folded > 0) ? 1 : 0;
+        args.echo_count = static_cast<int32_t>(folded);
+        recorder.decoder = static_cast<int32_t>(k);
+        const int32_t effective = mode != MODE_AUTO ? mode : static_cast<int32_t>(MODE_FAST);
+        const int status = launch_stage(args, host_decoder_[k], host_decoder_[k].algorithm != 1 && mode == MODE_AUTO ? static_cast<int32_t>(MODE_FAST) : effective, max_blocks_, nullptr, &recorder);
+        if(status != 0) { throw InternalError("the stage dispatcher failed on decoder " + std::to_string(k)); }
+        k += folded;
+    }
+    return recorder.out + "]";
 }
 
 bool DecoderSet::needs_worklist() const {

@@ -33,6 +33,10 @@ public:
     int32_t effective_mode() const { return mode_ != MODE_AUTO ? mode_ : records_exact_ ? MODE_LITERAL : MODE_FAST; }
     void set_records_exact(bool on) { records_exact_ = on; }
     int64_t literal_cells_per_read() const;
+    // the kernels a batch of n_read reads would take in `mode`, decoder by decoder, as the stage dispatcher names them — decided by
+    // the dispatcher itself with its launches switched off, so this is the chain phq_profile_chain reports after a run, without
+    // one; works on a set without a device (the tables' images are then built in host memory, for their presence alone)
+    std::string plan_chain(int64_t n_read, int32_t mode);
 
     // Rule::apply + pre-filters + incoming counters (see include/pheniqs_amd.h phq_stage_reads)
     void stage_reads(int64_t n_read, int32_t n_segment, const uint8_t* const* code, const uint8_t* const* quality,
@@ -101,6 +105,7 @@ private:
     std::vector<DevDecoder> host_decoder_;      // host copies holding DEVICE table pointers
     DevDecoder* device_decoder_;                // device array, one per decoder
     std::vector<void*> device_allocation_;
+    std::vector<void*> host_image_;             // a set without a device: the tables of build_device_images in host memory (plan_chain)
     unsigned long long* device_stats_;
     HostStage host_stage_;
     void* order_event_ = nullptr;               // recorded behind the kernels of the last phq_classify_device call

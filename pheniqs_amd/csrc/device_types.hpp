@@ -335,6 +335,8 @@ struct LaunchTimer {
 
 // implemented in the kernel translation units; all return a hipError_t value
 int launch_stage(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer);
+// on: launch_stage names the kernels of a stage to the timer and launches none (this thread only; DecoderSet::plan_chain)
+void stage_plan_only(bool on);
 bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode);
 
 }  // namespace phq

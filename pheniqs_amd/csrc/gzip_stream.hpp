@@ -598,7 +598,7 @@ private:
             next_member_ = false;
             if(!begin_member()) { throw IOError("damaged gzip header"); }
         }
-        if(threads_ > 1 && !zlib_open_) {
+        if(threads_ >= 4 && !zlib_open_) {              // (two or three threads do not pay: a chunk behind this thread's own costs twice its decoding — search, markers, copy)
             // (a span that took no chunk — no header found, or none that chained — is followed by more and more pieces on one
             // thread before the next attempt)
             if(span_wait_ > 0) { --span_wait_; }

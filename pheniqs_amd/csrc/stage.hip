@@ -8,6 +8,15 @@
 
 namespace phq {
 
+namespace {
+// Plan only (DecoderSet::plan_chain, phq_plan_chain): the dispatcher walks its predicates and names the kernels of a stage to
+// the timer as it always does, and launches none — the chain a decoder WOULD take is read off the one place that decides it,
+// without a device.  Per thread: a plan on one thread does not silence another thread's launches.
+thread_local bool plan_only = false;
+template <typename Launch> int launched(Launch&& launch) { return plan_only ? 0 : launch(); }
+}  // namespace
+void stage_plan_only(bool on) { plan_only = on; }
+
 int launch_pamld_literal_l8(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_literal_l16(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
 int launch_pamld_literal_l24(const StageArgs&, const DevDecoder&, dim3, size_t, hipStream_t);
@@ -36,7 +45,7 @@ bool stage_uses_worklist(const DevDecoder& host_decoder, int32_t mode) {
 // PHQ_TRACE_WORKLIST=1: after a tier, how many reads it left in the worklist (synchronises the stream: diagnosis only)
 void trace_worklist(const char* tier, const StageArgs& args, unsigned segments, hipStream_t stream) {
     static const bool wanted = std::getenv("PHQ_TRACE_WORKLIST") != nullptr;
-    if(!wanted || args.worklist_count == nullptr) { return; }
+    if(!wanted || plan_only || args.worklist_count == nullptr) { return; }
     std::vector<uint32_t> count(segments);
     if(hipStreamSynchronize(stream) != hipSuccess) { return; }
     if(hipMemcpy(count.data(), args.worklist_count, segments * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { return; }
@@ -75,7 +84,7 @@ int launch_stage(const StageArgs& caller_args, const DevDecoder& host_decoder, i
     const int status = launch_classifier(args, host_decoder, mode, max_blocks, stream, timer);
     if(status != 0 || !args.defer_counters) { return status; }
     Timed timed(timer, KERNEL_COUNT, stream, "count_results_kernel");
-    return launch_count_results(args, host_decoder, max_blocks / GRID_BLOCKS_PER_CU, static_cast<hipStream_t>(stream));      // one workgroup per CU
+    return launched([&]() { return launch_count_results(args, host_decoder, max_blocks / GRID_BLOCKS_PER_CU, static_cast<hipStream_t>(stream)); });      // one workgroup per CU
 }
 
 int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int32_t mode, int32_t max_blocks, void* stream, LaunchTimer* timer) {
@@ -149,8 +158,8 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                     producer.carry_stride = 0;
                     {
                         Timed timed(timer, few ? KERNEL_PAMLD_PRODUCT : KERNEL_PAMLD_NEAR, stream, few ? "pamld_few_kernel" : cross_streamed ? "pamld_cross_stream_kernel" : "pamld_stream_kernel");
-                        status = few ? launch_pamld_few(producer, host_decoder, stream_grid, s)
-                               : cross_streamed ? launch_pamld_cross_stream(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s);
+                        status = launched([&]() { return few ? launch_pamld_few(producer, host_decoder, stream_grid, s)
+                               : cross_streamed ? launch_pamld_cross_stream(producer, host_decoder, stream_grid, s) : launch_pamld_stream(producer, host_decoder, stream_grid, s); });
                     }
                     if(status != 0) { return status; }
                     const dim3 segment_grid(static_cast<unsigned>(segments));
@@ -162,28 +171,28 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                         StageArgs middle = consumer;
                         middle.worklist_segments = static_cast<int32_t>(segment_grid.x);
                         Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, "pamld_cross_kernel (weighted, consumer)");
-                        status = launch_pamld_cross(middle, host_decoder, segment_grid, histogram_bytes, s);
+                        status = launched([&]() { return launch_pamld_cross(middle, host_decoder, segment_grid, histogram_bytes, s); });
                         if(status != 0) { return status; }
                         trace_worklist("the product form", producer, segment_grid.x, s);
                     }
                     if(pamld_exact_supports(host_decoder)) {
                         // several lanes per read where the set is one the lane parallel tier takes (pamld_exact_lanes.hip)
                         Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
-                        status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
-                                                                                          : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                        status = launched([&]() { return pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
+                                                                                          : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s); });
                         if(status != 0) { return status; }
                         trace_worklist("the exact tier", producer, segment_grid.x, s);
                     }
                     Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
-                    return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
+                    return launched([&]() { return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s); });
                 }
                 if(listed || paired || crossed || plated) {
                     {
                         Timed timed(timer, KERNEL_PAMLD_NEAR, stream, listed ? "pamld_near_kernel" : plated ? "pamld_plate_kernel" : paired ? "pamld_pair_kernel" : "pamld_cross_near_kernel");
-                        status = listed ? launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s)
+                        status = launched([&]() { return listed ? launch_pamld_near(producer, host_decoder, wide_grid, histogram_bytes, s)
                                : plated ? launch_pamld_plate(producer, host_decoder, wide_grid, histogram_bytes, s)
                                : paired ? launch_pamld_pair(producer, host_decoder, wide_grid, histogram_bytes, s)
-                                        : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s);
+                                        : launch_pamld_cross_near(producer, host_decoder, wide_grid, histogram_bytes, s); });
                     }
                     if(status != 0) { return status; }
                     trace_worklist("the neighbour lists", producer, segment_grid.x, s);
@@ -198,18 +207,18 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                         const int64_t wanted = std::max<int64_t>(1, share(consumer_share));
                         middle.worklist_group = static_cast<int32_t>((segment_grid.x + wanted - 1) / wanted);
                         const dim3 fewer(static_cast<unsigned>((segment_grid.x + middle.worklist_group - 1) / middle.worklist_group));
-                        status = launch_pamld_lut(middle, host_decoder, fewer, histogram_bytes, s);
+                        status = launched([&]() { return launch_pamld_lut(middle, host_decoder, fewer, histogram_bytes, s); });
                     } else {
-                        status = crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
-                                         : launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s);
+                        status = launched([&]() { return crossed ? launch_pamld_cross(middle, host_decoder, wide_grid, histogram_bytes, s)
+                                         : launch_pamld_wide(middle, host_decoder, wide_grid, histogram_bytes, s); });
                     }
                 } else {
                     producer.flag_ties = lut_ties ? 1 : 0;
                     Timed timed(timer, KERNEL_PAMLD_PRODUCT, stream, tiny ? "pamld_tiny_kernel" : factorised ? (host_decoder.uniform_prior ? "pamld_cross_kernel" : "pamld_cross_kernel (weighted)") : long_words ? "pamld_wide_kernel" : "pamld_lut_kernel");
-                    status = tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
+                    status = launched([&]() { return tiny ? launch_pamld_tiny(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : factorised ? launch_pamld_cross(producer, host_decoder, wide_grid, histogram_bytes, s)
                            : long_words ? launch_pamld_wide(producer, host_decoder, wide_grid, histogram_bytes, s)
-                                        : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s);
+                                        : launch_pamld_lut(producer, host_decoder, wide_grid, histogram_bytes, s); });
                 }
                 if(status != 0) { return status; }
                 trace_worklist("the product form", producer, segment_grid.x, s);
@@ -219,22 +228,22 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
-                    status = pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
-                                                                                      : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                    status = launched([&]() { return pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
+                                                                                      : launch_pamld_cross_exact(consumer, host_decoder, segment_grid, histogram_bytes, s); });
                     if(status != 0) { return status; }
                 } else if(long_words && pamld_wide_exact_supports(host_decoder)) {
                     // the same for two word barcodes (pamld_wide_exact.hpp)
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, "pamld_wide_exact_kernel");
-                    status = launch_pamld_wide_exact(consumer, host_decoder, segment_grid, histogram_bytes, s);
+                    status = launched([&]() { return launch_pamld_wide_exact(consumer, host_decoder, segment_grid, histogram_bytes, s); });
                     if(status != 0) { return status; }
                 }
                 trace_worklist("the exact tier", producer, segment_grid.x, s);
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, "pamld_literal_kernel");
-                return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s);
+                return launched([&]() { return launch_pamld_literal(consumer, host_decoder, segment_grid, 128 * sizeof(double) + histogram_bytes, s); });
             }
             {
                 Timed timed(timer, KERNEL_PAMLD_LITERAL, stream, host_decoder.nucleotide_cardinality > DEV_TIER_NUCLEOTIDE ? "pamld_literal_long_kernel (every read)" : "pamld_literal_kernel (every read)");
-                return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s);
+                return launched([&]() { return launch_pamld_literal(args, host_decoder, grid, 128 * sizeof(double) + histogram_bytes, s); });
             }
         case 2: {
             const bool general = host_decoder.nucleotide_cardinality > DEV_TIER_NUCLEOTIDE;
@@ -252,24 +261,24 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 int status;
                 {
                     Timed timed(timer, KERNEL_MDD_EXACT, stream, paired ? "mdd_lookup_kernel (paired)" : crossed ? "mdd_lookup_kernel (combinatorial)" : "mdd_lookup_kernel");
-                    status = paired ? launch_mdd_pair(producer, host_decoder, near_grid, histogram_bytes, s)
+                    status = launched([&]() { return paired ? launch_mdd_pair(producer, host_decoder, near_grid, histogram_bytes, s)
                            : crossed ? launch_mdd_cross2(producer, host_decoder, near_grid, histogram_bytes, s)
-                                     : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s);
+                                     : launch_mdd_near(producer, host_decoder, near_grid, histogram_bytes, s); });
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 Timed timed(timer, KERNEL_MDD, stream, (crossed && mdd_cross_supports(host_decoder)) ? "mdd_cross_kernel" : mdd_scan_supports(host_decoder) ? "mdd_scan_kernel" : "mdd_kernel");
-                if(crossed && mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, near_grid, histogram_bytes, s); }
-                if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }
-                return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s);
+                if(crossed && mdd_cross_supports(host_decoder)) { return launched([&]() { return launch_mdd_cross(consumer, host_decoder, near_grid, histogram_bytes, s); }); }
+                if(mdd_scan_supports(host_decoder)) { return launched([&]() { return launch_mdd_scan(consumer, host_decoder, near_grid, histogram_bytes, s); }); }
+                return launched([&]() { return launch_mdd(consumer, host_decoder, near_grid, histogram_bytes, s); });
             }
             if(mode == MODE_FAST && !general && mdd_fused_supports(host_decoder)) {
                 // both tiers in one kernel: the deferred reads wait in an LDS ring, nothing goes through HBM twice
                 Timed timed(timer, KERNEL_MDD, stream, "mdd_fused_kernel");
                 const int64_t fused_blocks = share(GRID_SHARE_MDD_FUSED);
                 const dim3 fused_grid(static_cast<unsigned>(tiles < fused_blocks ? tiles : fused_blocks));
-                return launch_mdd_fused(args, host_decoder, fused_grid, histogram_bytes, s);
+                return launched([&]() { return launch_mdd_fused(args, host_decoder, fused_grid, histogram_bytes, s); });
             }
             if(stage_uses_worklist(host_decoder, mode)) {
                 // tier 1: exact match lookup over every read; tier 2: the scan kernel on what it deferred (same grid)
@@ -281,22 +290,22 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 int status;
                 {
                     Timed timed(timer, KERNEL_MDD_EXACT, stream, "mdd_exact_kernel");
-                    status = launch_mdd_exact(producer, host_decoder, grid, histogram_bytes, s);
+                    status = launched([&]() { return launch_mdd_exact(producer, host_decoder, grid, histogram_bytes, s); });
                 }
                 if(status != 0) { return status; }
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 Timed timed(timer, KERNEL_MDD, stream, mdd_scan_supports(host_decoder) ? "mdd_scan_kernel" : mdd_cross_supports(host_decoder) ? "mdd_cross_kernel" : "mdd_kernel");
-                if(mdd_scan_supports(host_decoder)) { return launch_mdd_scan(consumer, host_decoder, grid, histogram_bytes, s); }
-                if(mdd_cross_supports(host_decoder)) { return launch_mdd_cross(consumer, host_decoder, grid, histogram_bytes, s); }
-                return launch_mdd(consumer, host_decoder, grid, histogram_bytes, s);
+                if(mdd_scan_supports(host_decoder)) { return launched([&]() { return launch_mdd_scan(consumer, host_decoder, grid, histogram_bytes, s); }); }
+                if(mdd_cross_supports(host_decoder)) { return launched([&]() { return launch_mdd_cross(consumer, host_decoder, grid, histogram_bytes, s); }); }
+                return launched([&]() { return launch_mdd(consumer, host_decoder, grid, histogram_bytes, s); });
             }
             Timed timed(timer, KERNEL_MDD, stream, "mdd_kernel (every read)");
-            return launch_mdd(args, host_decoder, grid, histogram_bytes, s);
+            return launched([&]() { return launch_mdd(args, host_decoder, grid, histogram_bytes, s); });
         }
         default: {
             Timed timed(timer, KERNEL_COUNT, stream, "count_kernel");
-            return launch_count(args, host_decoder, grid, histogram_bytes, s);
+            return launched([&]() { return launch_count(args, host_decoder, grid, histogram_bytes, s); });
         }
     }
 }

@@ -100,6 +100,16 @@ def spec_of(family, L, N, per, priors, seed=11):
     return {"input segment cardinality": len(per) + 1, "sample": decoder}, int(np.prod(per)) if family.startswith("comb") else N
 
 
+def plan(spec, reads=100_000_000):
+    """[kernel, ...] of one shape as phq_plan_chain names them: the stage dispatcher with its launches off, no GPU needed"""
+    from pheniqs_amd import DecoderSet, capi
+    s = DecoderSet(spec, device=capi.DEVICE_NONE)
+    try:
+        return [c["kernel"] for c in s.plan_chain(reads, capi.MODE_FAST)]
+    finally:
+        s.close()
+
+
 def run(torch, spec, reads, steps=3, warmup=1):
     """(Greads/s, ms a step, [(kernel, ms a step)]) of one shape, inputs resident in HBM, every read its own draw"""
     from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, synthetic
@@ -121,7 +131,11 @@ def run(torch, spec, reads, steps=3, warmup=1):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     chain, order = {}, []
-    for span in s.profile_chain():
+    spans = s.profile_chain()
+    # what phq_plan_chain says the dispatcher WOULD do is what it did (one decision, read twice)
+    planned = [(c["decoder"], c["kernel"]) for c in s.plan_chain(reads, capi.MODE_FAST)]
+    assert planned == [(c["decoder"], c["kernel"]) for c in spans[:len(spans) // steps]], (planned, spans)
+    for span in spans:
         if span["kernel"] not in chain:
             chain[span["kernel"]] = 0.0
             order.append(span["kernel"])
