@@ -8,6 +8,7 @@
 namespace phq {
 int launch_stage(const StageArgs&, const DevDecoder&, int32_t, int32_t, void*, LaunchTimer*) { return 100; }      // hipErrorNoDevice
 bool stage_uses_worklist(const DevDecoder&, int32_t) { return false; }
+void stage_plan_only(bool) {}
 // ... and the device FASTQ path (fastq_device.hip) is never taken by a set without a device
 int unpack_planes(const uint8_t*, uint8_t*, uint8_t*, size_t, void*) { return 100; }
 int patch_escapes(const uint64_t*, int64_t, int64_t, int64_t, int32_t, const int32_t*, const int32_t*, uint8_t*, uint8_t*, void*) { return 100; }
