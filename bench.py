@@ -280,6 +280,28 @@ def fastq_end_to_end(args, code, quality, flag, n):
         out["fastq_per_barcode"] = {"Mreads/s": n / dt / 1e6, "seconds": dt, "files": 1 + len(spec["sample"]["codec"]),
                                     "fastq_out_MB/s": sum(os.path.getsize(os.path.join(directory, name)) for name in os.listdir(directory) if name.startswith(("barcode_", "undetermined"))) / dt / 1e6}
         split.close()
+        # ... and the same files gzip compressed (what a demultiplexing run usually writes; the reference's default level 5,
+        # configuration.json:6): the library's own deflate on every host thread (csrc/fast_deflate.hpp)
+        for name in os.listdir(directory):
+            if name.startswith(("barcode_", "undetermined")):
+                os.unlink(os.path.join(directory, name))
+        packed_spec = dict(split_spec, output=[os.path.join(directory, "undetermined.fastq.gz")])
+        packed_spec["sample"] = dict(spec["sample"])
+        packed_spec["sample"]["codec"] = {key: dict(value, output=[os.path.join(directory, "barcode_%d.fastq.gz" % k)])
+                                          for k, (key, value) in enumerate(spec["sample"]["codec"].items())}
+        packed = DecoderSet(packed_spec, device=0)
+        packed.set_mode(capi.MODE_FAST if args.mode == "fast" else capi.MODE_LITERAL)
+        packed.transcode_job(1 << 20)
+        for name in os.listdir(directory):
+            if name.startswith(("barcode_", "undetermined")):
+                os.unlink(os.path.join(directory, name))
+        t0 = time.perf_counter()
+        incoming, _ = packed.transcode_job(1 << 20)
+        dt = time.perf_counter() - t0
+        assert incoming == n
+        out["fastq_gz_per_barcode"] = {"Mreads/s": n / dt / 1e6, "seconds": dt, "files": 1 + len(spec["sample"]["codec"]),
+                                       "gz_out_MB/s": sum(os.path.getsize(os.path.join(directory, name)) for name in os.listdir(directory) if name.startswith(("barcode_", "undetermined"))) / dt / 1e6}
+        packed.close()
     s.close()
     out["note"] = ("2 uncompressed FASTQ files in memory backed storage (50 nt template + 8 nt index) -> SAM text: into a file of the same "
                    "storage (sam_text), every record assembled and written to /dev/zero (sam_text_discarded: no page of a file to "
