@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         const std::vector<uint8_t> expected((std::istreambuf_iterator<char>(expected_file)), std::istreambuf_iterator<char>());
         if(expected != text) { std::printf("text differs: %zu bytes, expected %zu\n", text.size(), expected.size()); return 5; }
     }
-    std::printf("stream bytes %zu crc %lu zlib %llu chunks %llu dropped %llu\n", text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())), static_cast<unsigned long long>(phq::GzipStream::through_zlib()),
-                static_cast<unsigned long long>(phq::GzipStream::chunks_taken()), static_cast<unsigned long long>(phq::GzipStream::chunks_dropped()));
+    std::printf("stream bytes %zu crc %lu zlib %llu chunks %llu dropped %llu\n", text.size(), crc32(0L, text.data(), static_cast<uInt>(text.size())), static_cast<unsigned long long>(phq::GzipStream::through_zlib().load()),
+                static_cast<unsigned long long>(phq::GzipStream::chunks_taken().load()), static_cast<unsigned long long>(phq::GzipStream::chunks_dropped().load()));
     return 0;
 }

@@ -19,6 +19,7 @@
 //     the run ends with the error instead of a result.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -553,10 +554,10 @@ public:
         return done;
     }
 
-    static uint64_t& through_zlib() { static uint64_t count = 0; return count; }      // members the decoder handed to zlib part way (diagnosis, the check program)
+    static std::atomic<uint64_t>& through_zlib() { static std::atomic<uint64_t> count{0}; return count; }      // members the decoder handed to zlib part way (diagnosis, the check program)
     // chunks taken from the other threads / chunks decoded for nothing (a find that was no block header, a chunk behind one that stopped early)
-    static uint64_t& chunks_taken() { static uint64_t count = 0; return count; }
-    static uint64_t& chunks_dropped() { static uint64_t count = 0; return count; }
+    static std::atomic<uint64_t>& chunks_taken() { static std::atomic<uint64_t> count{0}; return count; }
+    static std::atomic<uint64_t>& chunks_dropped() { static std::atomic<uint64_t> count{0}; return count; }
 
 private:
     static constexpr size_t WINDOW = size_t(1) << 15;

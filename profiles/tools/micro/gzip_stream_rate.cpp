@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
             best = std::max(best, total / dt / 1e9);
         }
         std::printf("GzipStream %2d threads: %.3f GB/s of text (first run %.3f; chunks taken %llu, dropped %llu so far)\n", threads, best, first,
-                    static_cast<unsigned long long>(phq::GzipStream::chunks_taken()), static_cast<unsigned long long>(phq::GzipStream::chunks_dropped()));
+                    static_cast<unsigned long long>(phq::GzipStream::chunks_taken().load()), static_cast<unsigned long long>(phq::GzipStream::chunks_dropped().load()));
     }
     return 0;
 }
