@@ -224,7 +224,11 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
  *           barcode (classifier.h:83-85) unless the channel sets `filter outgoing qc fail` and the read failed.
  *           Format by `?format=` or extension: fastq / fq -> FASTQ records with the Illumina comment
  *           `segment:Y|N:0:raw sample barcode` (fastq.h:144-194), anything else SAM text; `.gz` or
- *           `?compression=gz` -> gzip (one member per batch part, compressed on all host threads).
+ *           `?compression=gz` -> gzip (one member per batch part, compressed on all host threads: up to the reference's default
+ *           level 5 — configuration.json:6 — by the library's own deflate, csrc/fast_deflate.hpp, 4x zlib's rate with 5 % more
+ *           bytes; `&level=6` and more, or PHQ_GZIP_ZLIB=1, by zlib).  gzip INPUT: BGZF blocks and files of many small members
+ *           inflate member parallel (csrc/gzip_members.hpp); a file of one member — what `gzip` writes — is inflated chunk
+ *           parallel from block headers found by search, or on one thread where it is small (csrc/gzip_stream.hpp).
  * BAM / CRAM (htslib) and bz2 / xz are refused with a configuration error; QC accumulators are not collected.
  * Records keep the input order inside every file. */
 int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
