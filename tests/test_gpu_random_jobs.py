@@ -21,7 +21,9 @@ def _seeds():
 def _random_decoder(rng, algorithm, kind):
     segments = int(rng.choice([1, 1, 1, 2, 2, 3]))
     lengths = [int(rng.integers(1, 13)) for _ in range(segments)]
-    while sum(lengths) > 32:
+    if rng.random() < 0.06:
+        lengths = [int(rng.integers(12, 34)) for _ in range(segments)]      # round 6: barcodes of 33 to 128 nt (the general kernels) — and long ones that still fit 32
+    while sum(lengths) > (128 if max(lengths) >= 12 else 32):
         lengths[int(rng.integers(0, segments))] = 4
     combinatorial = segments > 1 and rng.random() < 0.6
     if combinatorial:
