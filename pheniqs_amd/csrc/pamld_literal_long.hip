@@ -9,7 +9,7 @@
 // operation, and the same argmax rules as pamld_literal.hpp, with the length at run time — a read's code and quality row
 // (up to 128 bytes each) wait in LDS, word w of lane t at [w][t] so that a wave's reads of one word never share a bank, and
 // the barcodes come as packed 4 bit codes through the constant address space (wave uniform: scalar loads).  Every read walks
-// every barcode: ~8 fp64 operations per (read, barcode, position).  96 barcodes of 40 nt: see profiles/README.md for the rate.
+// every barcode, eight of them side by side through the read's positions.  Rates: profiles/r06_shape_grid.md (96 pairs of 20 + 20 nt).
 #include <atomic>
 
 #include "kernel_common.hpp"
@@ -54,32 +54,47 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_long_kernel(StageArgs arg
             const uint32_t* const quality_at = reinterpret_cast<const uint32_t*>(args.quality + i * d.plane_stride);
             for(int w = 0; w < row_words; ++w) { my_code[w * BLOCK] = code_at[w]; my_quality[w * BLOCK] = quality_at[w]; }      // (a lane reads its own words only: no barrier)
 
-            // sigma_q of barcode b: the reference's Kahan walk over the positions (barcode.h:147-161), with
-            // PhredScale::substitution_quality spelled out (phred.cpp:44-68; a quality byte is masked to the table's 128 rows)
-            auto kahan_of = [&](int b) {
-                double sigma_q = 0;
-                double c = 0;
+            // sigma_q of the barcodes b0 .. b0 + GROUP - 1: the reference's Kahan walk over the positions (barcode.h:147-161) for
+            // each of them, side by side — a position's observed code, its table lookup (phred.cpp:44-68; the quality byte masked to the
+            // table's 128 rows) and its mismatch cost are formed once for the group, every barcode then takes its own
+            // four dependent additions: ~9 instructions a (read, barcode, position) where one barcode at a time took ~20
+            constexpr int GROUP = 8;
+            auto kahan_of_group = [&](int b0, int count, double (&sigma)[GROUP]) {
+                double c[GROUP];
+#pragma unroll
+                for(int g = 0; g < GROUP; ++g) { sigma[g] = 0; c[g] = 0; }
                 for(int w = 0; w < row_words; ++w) {
                     const uint32_t code_word = my_code[w * BLOCK];
                     const uint32_t quality_word = my_quality[w * BLOCK];
-                    const uint32_t expected_word = packed[b * n_word + (w >> 1)] >> (16 * (w & 1));
+                    uint32_t expected_word[GROUP];
+#pragma unroll
+                    for(int g = 0; g < GROUP; ++g) { expected_word[g] = g < count ? packed[(b0 + g) * n_word + (w >> 1)] >> (16 * (w & 1)) : 0u; }
 #pragma unroll
                     for(int k = 0; k < 4; ++k) {
                         if(4 * w + k < L) {
-                            const uint32_t e = (expected_word >> (4 * k)) & 0xfu;
                             const uint32_t o = (code_word >> (8 * k)) & 0xffu;
                             const uint32_t q = (quality_word >> (8 * k)) & 0x7fu;
                             const double u = q ? uniform : 0.0;
-                            double x = (o == e) ? tpq[q] : (strict_code(o) ? static_cast<double>(q) : u);
-                            if(!all_strict && !strict_code(e)) { x = u; }
-                            const double y = x - c;
-                            const double t = sigma_q + y;
-                            c = (t - sigma_q) - y;
-                            sigma_q = t;
+                            const double match = tpq[q];
+                            const double mismatch = strict_code(o) ? static_cast<double>(q) : u;
+#pragma unroll
+                            for(int g = 0; g < GROUP; ++g) {
+                                const uint32_t e = (expected_word[g] >> (4 * k)) & 0xfu;
+                                double x = (o == e) ? match : mismatch;
+                                if(!all_strict && !strict_code(e)) { x = u; }
+                                const double y = x - c[g];
+                                const double t = sigma[g] + y;
+                                c[g] = (t - sigma[g]) - y;
+                                sigma[g] = t;
+                            }
                         }
                     }
                 }
-                return sigma_q;
+            };
+            auto kahan_of = [&](int b) {
+                double sigma[GROUP];
+                kahan_of_group(b, 1, sigma);
+                return sigma[0];
             };
 
             // the sum over the barcodes and the argmax exactly as pamld_literal.hpp: quickly rounded powers for the sum, the
@@ -94,19 +109,28 @@ __global__ __launch_bounds__(BLOCK) void pamld_literal_long_kernel(StageArgs arg
             double near_sigma = 0;
             double near_prior = 0;
             bool ambiguous = false;
-            for(int b = 0; b < n_barcode; ++b) {
-                const double sigma_q = kahan_of(b);
-                const double prior = concentration[b];
-                const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * prior;
-                const double y = p - compensation;
-                const double t = sigma_p + y;
-                compensation = (t - sigma_p) - y;
-                sigma_p = t;
-                const bool clears = p * (1.0 - 1e-15) > running;
-                const bool close = !clears && p >= running * (1.0 - 1e-15) && p > 0;
-                if(clears) { near_index = b; near_sigma = sigma_q; near_prior = prior; ambiguous = false; }
-                ambiguous = ambiguous || (close && (sigma_q != near_sigma || prior != near_prior));
-                running = p > running ? p : running;
+            for(int b0 = 0; b0 < n_barcode; b0 += GROUP) {
+                const int count = min(GROUP, n_barcode - b0);
+                double sigma[GROUP];
+                kahan_of_group(b0, count, sigma);
+#pragma unroll
+                for(int g = 0; g < GROUP; ++g) {
+                    if(g < count) {                                    // (in barcode order: the sum and the first of equals are the one at a time walk's)
+                        const int b = b0 + g;
+                        const double sigma_q = sigma[g];
+                        const double prior = concentration[b];
+                        const double p = phred_probability_fast(sigma_q, log2_base_hi, log2_base_lo) * prior;
+                        const double y = p - compensation;
+                        const double t = sigma_p + y;
+                        compensation = (t - sigma_p) - y;
+                        sigma_p = t;
+                        const bool clears = p * (1.0 - 1e-15) > running;
+                        const bool close = !clears && p >= running * (1.0 - 1e-15) && p > 0;
+                        if(clears) { near_index = b; near_sigma = sigma_q; near_prior = prior; ambiguous = false; }
+                        ambiguous = ambiguous || (close && (sigma_q != near_sigma || prior != near_prior));
+                        running = p > running ? p : running;
+                    }
+                }
             }
             double best_summand = 0;
             if(!ambiguous) {
