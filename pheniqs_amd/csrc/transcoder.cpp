@@ -1526,34 +1526,44 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
         ++device_resumed;
         return OnDevice::RESUMED;
     };
+    // gzip feeds inflate into the pinned buffer of a round: behind what the round before left at its front, up to the round's bytes
+    std::atomic<bool> zipped_failed{false};
+    auto fill_zipped = [&](int into) {
+        parallel_ranges(n_feed, 1, n_feed, [&](int64_t first_feed, int64_t last_feed, int) {
+            for(int64_t f = first_feed; f < last_feed; ++f) {
+                PlainFile& p = file[static_cast<size_t>(f)];
+                if(p.zipped == nullptr) { continue; }
+                uint8_t* const to = c.pinned[into][f];
+                if(!p.head.empty()) { std::memcpy(to, p.head.data(), p.head.size()); p.held = p.head.size(); p.head.clear(); }
+                const size_t want = chunk_bytes[f] - 1;
+                while(!p.ended && p.held < want) {
+                    int got;
+                    try {
+                        const size_t room = std::min<size_t>(want - p.held, size_t(1) << 30);
+                        got = p.members ? static_cast<int>(p.members->read(to + p.held, room)) : p.stream ? static_cast<int>(p.stream->read(to + p.held, room))
+                                        : gzread(p.zipped, to + p.held, static_cast<unsigned>(room));
+                    } catch(const std::exception&) { got = -1; }       // a member that does not inflate to what it states: the host reader takes the file
+                    if(got < 0) { zipped_failed = true; return; }
+                    if(got == 0) { p.ended = true; break; }
+                    p.held += static_cast<size_t>(got);
+                }
+            }
+        });
+    };
+    std::future<void> zipped_ahead;
+    struct JoinZipped { std::future<void>& task; ~JoinZipped() { if(task.valid()) { task.wait(); } } } join_zipped{zipped_ahead};      // (whichever way the run leaves: the task holds references)
+    bool any_zipped = false;
+    for(const auto& p : file) { any_zipped = any_zipped || p.zipped != nullptr; }
     while(true) {
         if(ahead_task.valid()) { timed(0, [&]() { ahead_task.get(); }); }
         bool any_left = false;
         FastqFeedChunk chunk[FASTQ_MAX_FEED];
         {
-            // gzip feeds: what the round before left is at the front of the pinned buffer; the feeds inflate side by side
-            std::atomic<bool> failed{false};
-            parallel_ranges(n_feed, 1, n_feed, [&](int64_t first_feed, int64_t last_feed, int) {
-                for(int64_t f = first_feed; f < last_feed; ++f) {
-                    PlainFile& p = file[static_cast<size_t>(f)];
-                    if(p.zipped == nullptr) { continue; }
-                    uint8_t* const to = c.pinned[buffer][f];
-                    if(!p.head.empty()) { std::memcpy(to, p.head.data(), p.head.size()); p.held = p.head.size(); p.head.clear(); }
-                    const size_t want = chunk_bytes[f] - 1;
-                    while(!p.ended && p.held < want) {
-                        int got;
-                        try {
-                            const size_t room = std::min<size_t>(want - p.held, size_t(1) << 30);
-                            got = p.members ? static_cast<int>(p.members->read(to + p.held, room)) : p.stream ? static_cast<int>(p.stream->read(to + p.held, room))
-                                            : gzread(p.zipped, to + p.held, static_cast<unsigned>(room));
-                        } catch(const std::exception&) { got = -1; }       // a member that does not inflate to what it states: the host reader takes the file
-                        if(got < 0) { failed = true; return; }
-                        if(got == 0) { p.ended = true; break; }
-                        p.held += static_cast<size_t>(got);
-                    }
-                }
-            });
-            if(failed) { return give_up(); }
+            // gzip feeds: what the round before left is at the front of the pinned buffer; the feeds inflate side by side — from the
+            // second round on AHEAD, beside the round before on the device (zipped_ahead below): nothing is left to do here then
+            if(zipped_ahead.valid()) { timed(0, [&]() { zipped_ahead.get(); }); }
+            fill_zipped(buffer);
+            if(zipped_failed) { return give_up(); }
         }
         for(int32_t f = 0; f < n_feed; ++f) {
             PlainFile& p = file[static_cast<size_t>(f)];
@@ -1666,6 +1676,9 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
+        // ... and the next round's text is inflated behind it while this round is on the device (decode, classification, records) and its
+        // text on its way into the files: a round of gzip input was inflate THEN device; now it is the longer of the two
+        if(any_zipped && !zipped_failed) { zipped_ahead = std::async(std::launch::async, [&fill_zipped, buffer]() { fill_zipped(buffer); }); }
         device_check(static_cast<hipError_t>(fastq_decode(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
                                                           c.keep, c.keep_block, c.kept_device, counts ? c.longest : nullptr, stream)), "fastq_decode");
         uint32_t decoded = round.records;
