@@ -933,7 +933,9 @@ struct PlainFile {                     // an input file of the device path: plai
     std::unique_ptr<MemberInflater> members;      // gzip of several members (BGZF blocks, concatenated members): inflated member parallel, a batch ahead (gzip_members.hpp)
     std::unique_ptr<GzipStream> stream;           // gzip of one member (or a few large ones): the streaming form of the same decoder (gzip_stream.hpp); gzread where neither opens
     bool ended = false;                // gzip: the stream has no more bytes
-    size_t held = 0;                   // gzip: bytes of text at the front of the round's pinned buffer
+    size_t held = 0;                   // gzip: bytes of text of the round in its pinned buffer, from `offset` on
+    size_t offset = 0;                 // gzip: where the round's text starts in its pinned buffer (behind the room kept for what the round before left)
+    size_t ahead_filled = 0;           // gzip: bytes the task inflating ahead has put behind that room in the NEXT round's buffer
     std::vector<uint8_t> head;         // gzip: the text inflated while the file was looked at, until the first round takes it
     ~PlainFile() {
         if(zipped) { gzclose(zipped); }
@@ -1533,10 +1535,15 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             for(int64_t f = first_feed; f < last_feed; ++f) {
                 PlainFile& p = file[static_cast<size_t>(f)];
                 if(p.zipped == nullptr) { continue; }
-                uint8_t* const to = c.pinned[into][f];
-                if(!p.head.empty()) { std::memcpy(to, p.head.data(), p.head.size()); p.held = p.head.size(); p.head.clear(); }
+                uint8_t* const to = c.pinned[into][f] + p.offset;
                 const size_t want = chunk_bytes[f] - 1;
-                while(!p.ended && p.held < want) {
+                if(!p.head.empty() && p.held < want) {             // text inflated while the file was looked at (or set aside by a round that took little)
+                    const size_t take = std::min(p.head.size(), want - p.held);
+                    std::memcpy(to + p.held, p.head.data(), take);
+                    p.held += take;
+                    p.head.erase(p.head.begin(), p.head.begin() + static_cast<std::ptrdiff_t>(take));
+                }
+                while(!p.ended && p.head.empty() && p.held < want) {
                     int got;
                     try {
                         const size_t room = std::min<size_t>(want - p.held, size_t(1) << 30);
@@ -1562,6 +1569,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             // gzip feeds: what the round before left is at the front of the pinned buffer; the feeds inflate side by side — from the
             // second round on AHEAD, beside the round before on the device (zipped_ahead below): nothing is left to do here then
             if(zipped_ahead.valid()) { timed(0, [&]() { zipped_ahead.get(); }); }
+            for(auto& p : file) { p.held += p.ahead_filled; p.ahead_filled = 0; }
             fill_zipped(buffer);
             if(zipped_failed) { return give_up(); }
         }
@@ -1587,7 +1595,7 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 });
             };
             if(p.zipped) {
-                // inflated above
+                to += p.offset;                                     // inflated above
             } else if(ahead_valid[f] && p.position >= ahead_start[f] && p.position + bytes <= ahead_start[f] + ahead_bytes[f]) {
                 to = c.pinned[buffer][f] + (p.position - ahead_start[f]);
             } else {
@@ -1651,6 +1659,36 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
                 ahead_bytes[f] = count;
             }
         });
+        // gzip feeds likewise: the stream goes on where this round's text ended whatever the round takes of it, so the next round's text
+        // is inflated NOW — beside this round's upload, its plan, its kernels — into the other pinned buffer, behind room for what this
+        // round will turn out to have left (an eighth of a round's bytes; a round that leaves more sets the text aside, below).  A round
+        // of gzip input was inflate THEN device; now it is the longer of the two but for the last eighth, inflated when the round starts.
+        if(any_zipped && !zipped_failed) {
+            zipped_ahead = std::async(std::launch::async, [&file, &c, &chunk_bytes, &zipped_failed, n_feed, other]() {
+                parallel_ranges(n_feed, 1, n_feed, [&](int64_t first_feed, int64_t last_feed, int) {
+                    for(int64_t f = first_feed; f < last_feed; ++f) {
+                        PlainFile& p = file[static_cast<size_t>(f)];
+                        if(p.zipped == nullptr || p.ended || !p.head.empty()) { continue; }
+                        const size_t reserve = chunk_bytes[f] / 8 + 4096;
+                        uint8_t* const to = c.pinned[other][f] + reserve;
+                        const size_t want = chunk_bytes[f] - 1 - reserve;
+                        size_t filled = 0;
+                        while(filled < want) {
+                            int got;
+                            try {
+                                const size_t room = std::min<size_t>(want - filled, size_t(1) << 30);
+                                got = p.members ? static_cast<int>(p.members->read(to + filled, room)) : p.stream ? static_cast<int>(p.stream->read(to + filled, room))
+                                                : gzread(p.zipped, to + filled, static_cast<unsigned>(room));
+                            } catch(const std::exception&) { got = -1; }
+                            if(got < 0) { zipped_failed = true; break; }
+                            if(got == 0) { p.ended = true; break; }
+                            filled += static_cast<size_t>(got);
+                        }
+                        p.ahead_filled = filled;
+                    }
+                });
+            });
+        }
         timed(1, [&]() { device_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); });       // this round's pinned buffers are free again, the round is known
         ++rounds;
         buffer = other;
@@ -1666,19 +1704,31 @@ Transcoder::OnDevice Transcoder::run_on_device(uint64_t& incoming_count, uint64_
             PlainFile& p = file[static_cast<size_t>(f)];
             round_began_at[f] = p.position;
             if(p.zipped) {
-                // what the round did not take goes to the front of the next round's buffer (`buffer` is that one by now)
+                // what the round did not take goes in FRONT of what is being inflated into the next round's buffer (`buffer` is that one
+                // by now), into the room kept for it
                 const size_t consumed = std::min<size_t>(round.consumed[f], p.held);          // (the newline the last line lacked is not held)
-                std::memmove(c.pinned[buffer][f], c.pinned[buffer ^ 1][f] + consumed, p.held - consumed);
-                p.held -= consumed;
+                const size_t left_over = p.held - consumed;
+                const size_t reserve = chunk_bytes[f] / 8 + 4096;
+                const uint8_t* const from = c.pinned[buffer ^ 1][f] + p.offset + consumed;
+                if(left_over <= reserve) {
+                    std::memcpy(c.pinned[buffer][f] + reserve - left_over, from, left_over);
+                    p.offset = reserve - left_over;
+                } else {
+                    // the round took less than seven eighths of its bytes (records longer than the file's first ones said): what was
+                    // inflated ahead is set aside and follows when there is room again
+                    if(zipped_ahead.valid()) { zipped_ahead.get(); }
+                    p.head.insert(p.head.end(), c.pinned[buffer][f] + reserve, c.pinned[buffer][f] + reserve + p.ahead_filled);
+                    p.ahead_filled = 0;
+                    std::memcpy(c.pinned[buffer][f], from, left_over);
+                    p.offset = 0;
+                }
+                p.held = left_over;
                 p.position += consumed;
                 continue;
             }
             p.position += round.consumed[f];
             if(p.position > p.size) { p.position = p.size; }                      // the newline the last line lacked
         }
-        // ... and the next round's text is inflated behind it while this round is on the device (decode, classification, records) and its
-        // text on its way into the files: a round of gzip input was inflate THEN device; now it is the longer of the two
-        if(any_zipped && !zipped_failed) { zipped_ahead = std::async(std::launch::async, [&fill_zipped, buffer]() { fill_zipped(buffer); }); }
         device_check(static_cast<hipError_t>(fastq_decode(c.tables, device_plan, slot, round.records, c.capacity, c.base, c.quality, c.flag, c.irregular, c.flagged,
                                                           c.keep, c.keep_block, c.kept_device, counts ? c.longest : nullptr, stream)), "fastq_decode");
         uint32_t decoded = round.records;
