@@ -139,6 +139,50 @@ def test_device_decode_equals_the_oracle_and_the_host_reader(oracle, tmp_path, c
         assert after["reads"] - before["reads"] == n and after["rounds"] - before["rounds"] == -(-n // max(capacity, 4096))
 
 
+@pytest.mark.parametrize("packing", ["gz", "bgzf"])
+def test_gzip_rounds_that_take_little_of_their_text(oracle, tmp_path, packing):
+    """A gzip feed is inflated a round AHEAD, behind room for what the round before leaves (an eighth of a round's bytes).  A file
+    whose records get SHORTER than its first ones said — 150 nt templates at its head, 20 nt ones behind — has rounds that take
+    their capacity of reads out of a quarter of their bytes: what was inflated ahead is set aside and follows when there is room
+    again.  Counters against the oracle and the host reader, the order of the reads with them (a read out of place would be
+    another read's index)."""
+    import gzip
+    from test_capi_cpu import _bgzf
+    spec = synthetic.config_spec("C2", "pamld")
+    spec["template"] = {"transform": {"token": ["0::"]}}
+    n_long, n_short = 3000, 90000
+    job = capi.compile_job(spec)
+    code, quality, flag, offsets = synthetic.generate_rows(job, n_long + n_short, 5)
+    rng = np.random.default_rng(5)
+    pieces = [[], []]
+    for first, last, length in ((0, n_long, 150), (n_long, n_long + n_short, 20)):
+        rows = last - first
+        template = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(rows, length), dtype=np.uint8)]
+        index = LETTERS[code[first:last]]
+        for k, (text, qual) in enumerate(((template, np.full((rows, length), ord("F"), dtype=np.uint8)), (index, np.minimum(quality[first:last], 93) + 33))):
+            path = os.path.join(str(tmp_path), "piece.fastq")
+            bench.write_fastq(path, k + 1, text, qual.astype(np.uint8), flag[first:last])
+            pieces[k].append(open(path, "rb").read())
+    paths = []
+    for k in range(2):
+        data = b"".join(pieces[k])
+        paths.append(os.path.join(str(tmp_path), "segment_%d.fastq.gz" % k))
+        open(paths[-1], "wb").write(_bgzf(data) if packing == "bgzf" else gzip.compress(data, 4))
+    before = capi.device_path_counters()
+    (device_words, device_incoming), (host_words, host_incoming) = _both(spec, paths, 4096)
+    after = capi.device_path_counters()
+    assert after["reads"] - before["reads"] == n_long + n_short and after["resumed"] == before["resumed"]
+    assert device_incoming == host_incoming and device_incoming[0] == n_long + n_short
+    assert np.array_equal(device_words, host_words)
+    engine = oracle.OracleJob(job)
+    engine.classify(code, quality, flag)
+    s = DecoderSet(spec, device=0)
+    mine, theirs = s.stats_options(device_words, 0), engine.options(0)
+    for name in INTEGER_COUNTERS:
+        assert np.array_equal(mine[name], theirs[name]), name
+    s.close()
+
+
 def test_reverse_complement_tokens_and_negative_offsets_on_the_device(oracle, tmp_path):
     """tokens the forward jobs above do not hold: `~` on a two token knit, an offset from the end of the segment, an open
     start (transform.h:65-80,142-169) — the oracle's Rule::apply over the same text is the reference"""
