@@ -293,7 +293,7 @@ def test_host_side_under_sanitizers(tmp_path):
     from pheniqs_amd import synthetic
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         # no sanitizer runtime on the machine is a reason to skip; an error in the library's own sources (a stub of
         # check/no_device.cpp that no longer matches, a missing include) is not
@@ -328,7 +328,7 @@ def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
 
     here = os.path.dirname(os.path.abspath(__file__))
     csrc = os.path.join(os.path.dirname(here), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         # no sanitizer runtime on the machine is a reason to skip; an error in the library's own sources (a stub of
         # check/no_device.cpp that no longer matches, a missing include) is not
@@ -455,7 +455,7 @@ def test_gzip_members_inflate_in_parallel_to_the_same_text(tmp_path):
     import numpy as np
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
         pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
@@ -520,7 +520,7 @@ def test_a_single_member_gzip_stream_inflates_to_the_same_text(tmp_path):
     import numpy as np
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
         pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
@@ -601,7 +601,7 @@ def test_the_gzip_members_the_library_writes_come_back_through_zlib_and_its_own_
     on FASTQ text it is within 10 % of zlib level 5's size (fastq.h:144-194 writes such files through htslib's bgzf)."""
     import subprocess
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
         pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
@@ -619,7 +619,7 @@ def test_the_one_shot_inflate_against_zlib_under_sanitizers():
     import subprocess
 
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pheniqs_amd", "csrc")
-    built = subprocess.run(["make", "-s", "-C", csrc, "asan"], capture_output=True, text=True)
+    built = subprocess.run(["make", "-s", "-j", "6", "-C", csrc, "asan"], capture_output=True, text=True)
     if built.returncode != 0:
         assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
         pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
