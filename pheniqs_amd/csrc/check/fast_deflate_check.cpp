@@ -100,6 +100,35 @@ int main(int argc, char** argv) {
         if(!round_trip(prefix, "fastq prefix", &packed_size)) { return 1; }
         ++members;
     }
+    // BGZF (what a BAM file is made of): every block a gzip member that states its own size, at most 64 KiB either way
+    for(const std::vector<uint8_t>* data : std::vector<const std::vector<uint8_t>*>{&fastq, &texts[19].second /* noise */, &texts[0].second /* nothing */}) {
+        std::vector<uint8_t> blocks(phq::fast_deflate::bgzf_bound(data->size()) + 64);
+        const size_t size = phq::fast_deflate::bgzf_blocks(data->data(), data->size(), blocks.data(), blocks.size());
+        if(size == 0 && !data->empty()) { std::printf("bgzf: no room\n"); return 1; }
+        std::vector<uint8_t> back;
+        size_t at = 0;
+        while(at < size) {
+            const uint8_t* const h = blocks.data() + at;
+            if(size - at < 28 || h[0] != 0x1f || h[1] != 0x8b || h[3] != 4 || h[10] != 6 || h[12] != 'B' || h[13] != 'C') { std::printf("bgzf: no block header at %zu\n", at); return 1; }
+            const size_t block = (static_cast<size_t>(h[16]) | (static_cast<size_t>(h[17]) << 8)) + 1;
+            if(block > 65536 || at + block > size) { std::printf("bgzf: block size %zu\n", block); return 1; }
+            std::vector<uint8_t> piece(65536);
+            z_stream z;
+            std::memset(&z, 0, sizeof(z));
+            if(inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) { return 1; }
+            z.next_in = const_cast<Bytef*>(h); z.avail_in = static_cast<uInt>(block);
+            z.next_out = piece.data(); z.avail_out = static_cast<uInt>(piece.size());
+            const int status = inflate(&z, Z_FINISH);
+            const size_t made = piece.size() - z.avail_out;
+            const bool whole = z.avail_in == 0;
+            inflateEnd(&z);
+            if(status != Z_STREAM_END || !whole || made > phq::fast_deflate::BGZF_DATA) { std::printf("bgzf: block at %zu does not inflate (status %d)\n", at, status); return 1; }
+            back.insert(back.end(), piece.begin(), piece.begin() + static_cast<std::ptrdiff_t>(made));
+            at += block;
+            ++members;
+        }
+        if(back != *data) { std::printf("bgzf: other data back\n"); return 1; }
+    }
     if(!round_trip(fastq, "fastq", &packed_size)) { return 1; }
     uLongf bound = compressBound(static_cast<uLong>(fastq.size()));
     std::vector<uint8_t> other(bound);

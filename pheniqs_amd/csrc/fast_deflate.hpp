@@ -258,18 +258,21 @@ inline void write_block(BitWriter& w, const uint32_t* token, size_t n_token, con
     w.put(coder.litlen_code[256], coder.litlen_length[256]);
 }
 
-// one gzip member of `bytes` of text into `out`; the member's size, or 0 where `capacity` does not hold it (bytes + bytes / 8 + 128 always does)
-inline size_t compress_member(const uint8_t* in, size_t bytes, uint8_t* out, size_t capacity) {
-    if(capacity < 32) { return 0; }
-    static const uint8_t HEADER[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 255};       // XFL 4: the fastest algorithm; OS unknown
-    std::memcpy(out, HEADER, 10);
+// a raw deflate stream (RFC 1951) of `bytes` of text into `out`; its size, or 0 where `capacity` does not hold it
+// (bytes + bytes / 8 + 64 always does: a stored block costs five bytes per 65 535)
+inline size_t deflate_raw(const uint8_t* in, size_t bytes, uint8_t* out, size_t capacity) {
+    if(capacity < 16) { return 0; }
     BitWriter w;
-    w.next = out + 10;
-    w.end = out + capacity - 8;
-    std::unique_ptr<uint32_t[]> table(new uint32_t[size_t(1) << HASH_BITS]);
-    std::memset(table.get(), 0xff, sizeof(uint32_t) << HASH_BITS);
-    std::unique_ptr<uint32_t[]> token(new uint32_t[BLOCK_SYMBOLS]);
-    std::unique_ptr<Coder> coder(new Coder);
+    w.next = out;
+    w.end = out + capacity;
+    // (a thread's tables are kept between calls: a BGZF block is 64 KiB of input, its 128 KiB of hash table would be new every time)
+    struct Scratch { std::unique_ptr<uint32_t[]> table, token; std::unique_ptr<Coder> coder; };
+    static thread_local Scratch scratch;
+    if(!scratch.table) { scratch.table.reset(new uint32_t[size_t(1) << HASH_BITS]); scratch.token.reset(new uint32_t[BLOCK_SYMBOLS]); scratch.coder.reset(new Coder); }
+    uint32_t* const table = scratch.table.get();
+    uint32_t* const token = scratch.token.get();
+    Coder* const coder = scratch.coder.get();
+    std::memset(table, 0xff, sizeof(uint32_t) << HASH_BITS);
     // what a literal and a match cost, from the block before (the first block: 8 bits a literal, the fixed code's matches)
     uint8_t literal_bits[256];
     std::memset(literal_bits, 8, sizeof(literal_bits));
@@ -348,7 +351,7 @@ measured:
             token[n_token++] = in[at]; ++litlen_count[in[at]]; ++at;
         }
         ++litlen_count[256];
-        write_block(w, token.get(), n_token, litlen_count, dist_count, in + block_begin, at - block_begin, at == bytes, *coder);
+        write_block(w, token, n_token, litlen_count, dist_count, in + block_begin, at - block_begin, at == bytes, *coder);
         if(w.overflow) { return 0; }
         // the next block's prices
         for(int b = 0; b < 256; ++b) { literal_bits[b] = coder->litlen_length[b] ? coder->litlen_length[b] : 12; }
@@ -361,13 +364,50 @@ measured:
         }
     }
     w.align();
-    if(w.overflow || w.end - w.next < 0) { return 0; }
-    uint8_t* const trailer = w.next;
+    if(w.overflow) { return 0; }
+    return static_cast<size_t>(w.next - out);
+}
+
+// one gzip member of `bytes` of text into `out`; the member's size, or 0 where `capacity` does not hold it (bytes + bytes / 8 + 128 always does)
+inline size_t compress_member(const uint8_t* in, size_t bytes, uint8_t* out, size_t capacity) {
+    if(capacity < 32) { return 0; }
+    static const uint8_t HEADER[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 4, 255};       // XFL 4: the fastest algorithm; OS unknown
+    std::memcpy(out, HEADER, 10);
+    const size_t packed = deflate_raw(in, bytes, out + 10, capacity - 18);
+    if(packed == 0) { return 0; }
+    uint8_t* const trailer = out + 10 + packed;
     const uint32_t crc = fast_inflate::crc32_of(in, bytes);
     const uint32_t size = static_cast<uint32_t>(bytes);
     std::memcpy(trailer, &crc, 4);
     std::memcpy(trailer + 4, &size, 4);
     return static_cast<size_t>(trailer + 8 - out);
+}
+
+// BGZF (the SAM specification, section 4.1: what a BAM file is made of): `bytes` of data as blocks of at most BGZF_DATA bytes, each
+// a gzip member whose extra subfield 'B' 'C' holds its own size - 1.  Appends to `out` (a vector-like with reserve / commit as
+// the caller's); bgzf_bound(bytes) bytes of room are enough.
+constexpr size_t BGZF_DATA = 0xff00;
+constexpr uint8_t BGZF_EOF[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+inline size_t bgzf_bound(size_t bytes) { return bytes + (bytes / BGZF_DATA + 1) * 64 + bytes / 8; }
+inline size_t bgzf_blocks(const uint8_t* in, size_t bytes, uint8_t* out, size_t capacity) {
+    uint8_t* to = out;
+    for(size_t at = 0; at < bytes; at += BGZF_DATA) {
+        const size_t piece = std::min(BGZF_DATA, bytes - at);
+        if(static_cast<size_t>(out + capacity - to) < piece + 64) { return 0; }
+        static const uint8_t HEADER[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        std::memcpy(to, HEADER, 16);
+        // (a block is at most 65 536 bytes: data that does not compress is stored, 0xff00 + 5 + 26)
+        const size_t packed = deflate_raw(in + at, piece, to + 18, 65536 - 26);
+        if(packed == 0) { return 0; }
+        const uint16_t block_size = static_cast<uint16_t>(packed + 25);          // the block's size - 1
+        std::memcpy(to + 16, &block_size, 2);
+        const uint32_t crc = fast_inflate::crc32_of(in + at, piece);
+        const uint32_t size = static_cast<uint32_t>(piece);
+        std::memcpy(to + 18 + packed, &crc, 4);
+        std::memcpy(to + 22 + packed, &size, 4);
+        to += 26 + packed;
+    }
+    return static_cast<size_t>(to - out);
 }
 
 }  // namespace fast_deflate

@@ -30,6 +30,7 @@
 #include "gzip_members.hpp"
 #include "gzip_stream.hpp"
 #include "fast_deflate.hpp"
+#include "bam_record.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -656,6 +657,9 @@ struct OutputSink {
     uint64_t reserve(size_t size) { const uint64_t at = position; position += size; wrote = wrote || size > 0; return at; }
     void close() {
         if(descriptor >= 0) {
+            if(feed.format == FileFormat::BAM && !null) {    // BGZF's end of file marker: an empty block
+                try { write(reinterpret_cast<const char*>(fast_deflate::BGZF_EOF), sizeof(fast_deflate::BGZF_EOF)); } catch(...) {}
+            }
             if(feed.gzip && !wrote) {                        // an empty channel is still a valid gzip file
                 ByteBuffer member;
                 try { gzip_member("", 0, feed.level, member); write(member.data.get(), member.size); } catch(...) {}
@@ -670,7 +674,8 @@ FileFormat output_format_of(const Url& url, const std::string& path) {
     switch(url.format) {
         case FileFormat::FASTQ: case FileFormat::SAM: return url.format;
         case FileFormat::UNKNOWN: case FileFormat::NONE: return FileFormat::SAM;                  // "default output format": "sam" (configuration.json:7)
-        case FileFormat::BAM: case FileFormat::CRAM: throw ConfigurationError("BAM and CRAM output need htslib: " + path);
+        case FileFormat::BAM: return url.format;                                                  // unaligned BAM: bam_record.hpp, BGZF by fast_deflate.hpp
+        case FileFormat::CRAM: throw ConfigurationError("CRAM output needs htslib: " + path);
         default: throw ConfigurationError("unknown output format " + path);                      // transcode.cpp:1752
     }
 }
@@ -725,7 +730,8 @@ TranscodePlan TranscodePlan::from_job(const JobConfig& job) {
                 const FileCompression compression = url.compression();
                 if(compression == FileCompression::BZ2 || compression == FileCompression::XZ) { throw ConfigurationError("bz2 and xz output are not supported: " + url.path); }
                 const bool gzip = compression == FileCompression::GZIP || compression == FileCompression::BGZF;
-                plan.output_feed.push_back({url.path, output_format_of(url, url.path), gzip, url.compression_level >= 0 ? url.compression_level : 5, 0});
+                const FileFormat format = output_format_of(url, url.path);
+                plan.output_feed.push_back({url.path, format, gzip && format != FileFormat::BAM, url.compression_level >= 0 ? url.compression_level : 5, 0});       // (a BAM file is BGZF already)
                 stated_in_channel.push_back(0);
             }
             ++stated_in_channel[static_cast<size_t>(feed)];
@@ -1915,6 +1921,16 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     header += "@PG\tID:pheniqs_amd\tPN:pheniqs_amd\tVN:1\n";
     if(plan.sam_header) {
         for(auto& sink : m.sink) {
+            if(sink.feed.format == FileFormat::BAM) {
+                // "BAM\1", the same header text, no reference sequences — in BGZF blocks of its own (hts.h:96-130 hands the header to htslib)
+                const std::string binary = bam_header(header);
+                ByteBuffer blocks;
+                char* const to = blocks.reserve(fast_deflate::bgzf_bound(binary.size()));
+                const size_t packed = fast_deflate::bgzf_blocks(reinterpret_cast<const uint8_t*>(binary.data()), binary.size(), reinterpret_cast<uint8_t*>(to), fast_deflate::bgzf_bound(binary.size()));
+                if(packed == 0) { throw InternalError("BGZF"); }
+                sink.write(to, packed);
+                continue;
+            }
             if(sink.feed.format != FileFormat::SAM) { continue; }
             if(sink.feed.gzip) { ByteBuffer member; gzip_member(header.data(), header.size(), sink.feed.level, member); sink.write(member.data.get(), member.size); }
             else { sink.write(header.data(), header.size()); }
@@ -1946,7 +1962,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
     // MODE_AUTO (device_types.hpp): a run that writes SAM records of a small job classifies in the literal kernel's arithmetic, so
     // that XB / XM / XC print the reference's own digits (read.h:187-199); FASTQ records carry no posterior and stay fast
     bool writes_sam = false;
-    for(const auto& sink : m.sink) { writes_sam = writes_sam || (!sink.null && sink.feed.format == FileFormat::SAM); }
+    for(const auto& sink : m.sink) { writes_sam = writes_sam || (!sink.null && (sink.feed.format == FileFormat::SAM || sink.feed.format == FileFormat::BAM)); }
     struct ExactRecords {
         std::vector<DecoderSet*> sets;
         ~ExactRecords() { for(DecoderSet* set : sets) { set->set_records_exact(false); } }
@@ -2141,6 +2157,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
         for(auto& t : raw) { t.allocate(barcode_capacity); }
         for(auto& t : corrected) { t.allocate(barcode_capacity); }
         std::vector<char> tags(tag_capacity);
+        ByteBuffer line;                          // a BAM sink's record as the SAM line it is made from (bam_record.hpp)
         // a token's bases: BAM codes and Phred values (a corrected barcode) or printable text (an input segment)
         struct Piece { const uint8_t* code; const uint8_t* quality; const char* text; const char* quality_text; int32_t size; bool reverse_complement; bool lent; int32_t quality_shift; };
         std::vector<Piece> piece(job.template_transform.size());
@@ -2270,7 +2287,9 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
             const size_t name_size = lead.name_size(r);
             for(int32_t o = 0; o < n_out; ++o) {
                 const int32_t to_sink = channel.feed_by_segment[static_cast<size_t>(o)];
-                ByteBuffer& buffer = text_of_sink[to_sink];
+                const bool as_bam = m.sink[static_cast<size_t>(to_sink)].feed.format == FileFormat::BAM;
+                if(as_bam) { line.clear(); }
+                ByteBuffer& buffer = as_bam ? line : text_of_sink[to_sink];
                 const auto& tokens = token_of_output[static_cast<size_t>(o)];
                 size_t bases = 0;
                 for(const int32_t t : tokens) { bases += static_cast<size_t>(piece[static_cast<size_t>(t)].size); }
@@ -2333,12 +2352,25 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 to = put_bytes(to, tags.data(), tag_size);
                 *to++ = '\n';
                 buffer.commit(to);
+                if(as_bam) {
+                    // the same fields as a BAM record; XB / XM / XC from their values, not from their six printed digits (auxiliary.cpp:335-349)
+                    const float posterior[3] = {static_cast<float>(1.0 - confidence[0]), static_cast<float>(1.0 - confidence[1]), static_cast<float>(1.0 - confidence[2])};
+                    append_bam_record(text_of_sink[to_sink], line.data.get(), line.size - 1, posterior);
+                }
             }
         }
         for(int32_t f = 0; f < n_sink; ++f) {
-            if(m.sink[static_cast<size_t>(f)].feed.gzip && !text_of_sink[f].empty()) {
-                gzip_member(text_of_sink[f].data.get(), text_of_sink[f].size, m.sink[static_cast<size_t>(f)].feed.level,
-                            part_packed[static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f)]);
+            ByteBuffer& packed = part_packed[static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f)];
+            if(m.sink[static_cast<size_t>(f)].feed.format == FileFormat::BAM && !text_of_sink[f].empty()) {
+                // the part's records in BGZF blocks (a record may end in the next block: section 4.1)
+                packed.clear();
+                const size_t bound = fast_deflate::bgzf_bound(text_of_sink[f].size);
+                char* const to = packed.reserve(bound);
+                const size_t made = fast_deflate::bgzf_blocks(reinterpret_cast<const uint8_t*>(text_of_sink[f].data.get()), text_of_sink[f].size, reinterpret_cast<uint8_t*>(to), bound);
+                if(made == 0) { throw InternalError("BGZF"); }
+                packed.size = made;
+            } else if(m.sink[static_cast<size_t>(f)].feed.gzip && !text_of_sink[f].empty()) {
+                gzip_member(text_of_sink[f].data.get(), text_of_sink[f].size, m.sink[static_cast<size_t>(f)].feed.level, packed);
             }
         }
         });
@@ -2353,12 +2385,12 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                 size_t total = 0;
                 for(int part = 0; part < workers; ++part) {
                     const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
-                    total += (sink.feed.gzip ? part_packed[at] : part_text[at]).size;
+                    total += ((sink.feed.gzip || sink.feed.format == FileFormat::BAM) ? part_packed[at] : part_text[at]).size;
                 }
                 char* window = (sink.seekable && total >= (1u << 20)) ? sink.map_more(total) : nullptr;
                 for(int part = 0; part < workers; ++part) {
                     const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
-                    const ByteBuffer& bytes = sink.feed.gzip ? part_packed[at] : part_text[at];
+                    const ByteBuffer& bytes = (sink.feed.gzip || sink.feed.format == FileFormat::BAM) ? part_packed[at] : part_text[at];
                     if(bytes.size == 0) { continue; }
                     if(window != nullptr) { place[at] = window; window += bytes.size; concurrent = true; }
                     else { sink.write(bytes.data.get(), bytes.size); }
@@ -2369,7 +2401,7 @@ void Transcoder::run(uint64_t& incoming_count, uint64_t& incoming_pf_count) {
                     for(int64_t part = first_part; part < last_part; ++part) {
                         for(int32_t f = 0; f < n_sink; ++f) {
                             const size_t at = static_cast<size_t>(part) * static_cast<size_t>(n_sink) + static_cast<size_t>(f);
-                            const ByteBuffer& bytes = m.sink[static_cast<size_t>(f)].feed.gzip ? part_packed[at] : part_text[at];
+                            const ByteBuffer& bytes = (m.sink[static_cast<size_t>(f)].feed.gzip || m.sink[static_cast<size_t>(f)].feed.format == FileFormat::BAM) ? part_packed[at] : part_text[at];
                             if(place[at] != nullptr) { std::memcpy(place[at], bytes.data.get(), bytes.size); }
                         }
                     }

@@ -260,6 +260,65 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
         assert b"\tFI:i:3\tTC:i:3" in mine
 
 
+@pytest.mark.parametrize("case", ["C2", "mixed_tokens", "per_barcode"])
+def test_unaligned_bam_output_holds_the_sam_records(tmp_path, case):
+    """`output: x.bam` (what most Pheniqs runs state; the reference writes it through htslib, hts.h:169-239): the library writes
+    unaligned BAM itself — records made from the SAM lines its host writer formats (csrc/bam_record.hpp), BGZF blocks by its own
+    deflate, the empty block at the end.  tests/bam_reader.py reads the files back from the specification alone: every BGZF block
+    states its size, inflates to its ISIZE and CRC, the header is the SAM header with no references, every record is the SAM record
+    of the same run field by field — name, flag, sequence, qualities, the tags in Auxiliary::encode's order (auxiliary.cpp:320-354)
+    with FI / TC as int32 — with tid, pos, mate -1, bin, mapq, tlen 0 as the reference leaves them (hts.cpp:26-44), and XB / XM / XC
+    are the floats whose `%g` the SAM line prints."""
+    import bam_reader
+    directory = str(tmp_path)
+    if case == "mixed_tokens":
+        spec, lengths, n = _mixed_spec(), (40, 8, 26), 6007
+    else:
+        spec, lengths, n = synthetic.config_spec("C2", "pamld"), (30, 8), 20011
+        spec["template"] = {"transform": {"token": ["0::", "1::"]}}
+    paths = _files(directory, spec, n, 9, lengths)
+    spec["input"] = paths
+    outputs = {}
+    for extension in ("sam", "bam"):
+        job = json.loads(json.dumps(spec))
+        job["output"] = [os.path.join(directory, "out." + extension)]
+        if case == "per_barcode":
+            for k, record in enumerate(job["sample"]["codec"].values()):
+                if k % 3 == 0:
+                    record["output"] = [os.path.join(directory, "barcode_%d.%s" % (k, extension))]
+        incoming, _, did = _run(job, 4096, False)
+        assert incoming[0] == n
+        outputs[extension] = sorted(name for name in os.listdir(directory) if name.endswith("." + extension))
+    assert [name[:-4] for name in outputs["sam"]] == [name[:-4] for name in outputs["bam"]] and (len(outputs["bam"]) > 1) == (case == "per_barcode")
+    total = 0
+    for sam_name, bam_name in zip(outputs["sam"], outputs["bam"]):
+        lines = open(os.path.join(directory, sam_name)).read().split("\n")
+        header = "".join(line + "\n" for line in lines if line.startswith("@"))
+        body = [line for line in lines if line and not line.startswith("@")]
+        text, records, blocks = bam_reader.records(os.path.join(directory, bam_name))
+        assert text == header and len(records) == len(body)
+        total += len(records)
+        for line, record in zip(body, records):
+            field = line.split("\t")
+            assert record["name"] == field[0] and record["flag"] == int(field[1])
+            assert (record["ref"], record["pos"], record["mapq"], record["bin"], record["n_cigar"], record["next_ref"], record["next_pos"], record["tlen"]) == (-1, -1, 0, 0, 0, -1, -1, 0)
+            assert field[2:9] == ["*", "0", "0", "*", "*", "0", "0"]
+            assert record["sequence"] == ("" if field[9] == "*" else field[9])
+            assert record["quality"] == (b"" if field[9] == "*" else bytes(ord(c) - 33 for c in field[10]))
+            assert len(record["tags"]) == len(field) - 11
+            for (tag, kind, value), stated in zip(record["tags"], field[11:]):
+                assert stated[:5] == "%s:%s:" % (tag, kind), (stated, tag, kind)
+                if kind == "Z":
+                    assert value == stated[5:]
+                elif kind == "i":
+                    assert value == int(stated[5:])
+                else:
+                    assert tag in ("XB", "XM", "XC") and stated[5:] == "%g" % value, (stated, value)      # the float the line prints six digits of
+    assert total >= n
+    if case == "mixed_tokens":
+        assert total == 4 * n
+
+
 def test_an_input_out_of_the_ordinary_part_way_is_handed_to_the_host_reader(tmp_path):
     """A carriage return in record 50 000 of 70 001, batches of 4 096 reads: twelve rounds are assembled on the device, the
     thirteenth finds the record, and the host reader — which tolerates it, as the reference does — continues at the byte the
