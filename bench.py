@@ -261,6 +261,19 @@ def fastq_end_to_end(args, code, quality, flag, n):
                          "text_MB/s": reads * (size // n) / dt / 1e6}
             for p in packed_paths:
                 os.unlink(p)
+        # unaligned BAM (`output: x.bam`, what most Pheniqs runs state) without htslib: the host's record writer, records as the reference's
+        # bam1_t holds them (csrc/bam_record.hpp), BGZF by the library's own deflate
+        bam_spec = dict(spec, input=paths, output=[os.path.join(directory, "out.bam")])
+        bam = DecoderSet(bam_spec, device=0)
+        bam.transcode_job(1 << 20)
+        os.unlink(bam_spec["output"][0])
+        t0 = time.perf_counter()
+        incoming, _ = bam.transcode_job(1 << 20)
+        dt = time.perf_counter() - t0
+        assert incoming == n
+        out["bam"] = {"Mreads/s": n / dt / 1e6, "seconds": dt, "bam_MB/s": os.path.getsize(bam_spec["output"][0]) / dt / 1e6}
+        os.unlink(bam_spec["output"][0])
+        bam.close()
         # the same reads split by barcode: a FASTQ file for each of the 96 barcodes and one for the undetermined reads
         # (Multiplexer::push, multiplex.h:198-240), through the job's own directives (phq_transcode_job)
         split_spec = dict(spec, input=paths, output=[os.path.join(directory, "undetermined.fastq")])

@@ -229,7 +229,9 @@ int phq_transcode_fastq_to_sam(phq_decoder_set* set, int32_t n_input, const char
  *           bytes; `&level=6` and more, or PHQ_GZIP_ZLIB=1, by zlib).  gzip INPUT: BGZF blocks and files of many small members
  *           inflate member parallel (csrc/gzip_members.hpp); a file of one member — what `gzip` writes — is inflated chunk
  *           parallel from block headers found by search, or on one thread where it is small (csrc/gzip_stream.hpp).
- * BAM / CRAM (htslib) and bz2 / xz are refused with a configuration error; QC accumulators are not collected.
+ * `.bam` (or `?format=bam`) -> unaligned BAM, written without htslib: records as the reference's bam1_t holds them (hts.h:169-239,
+ * hts.cpp:26-44, auxiliary.cpp:320-354), BGZF blocks by the library's own deflate, the host's record writer.  CRAM (htslib) and
+ * bz2 / xz are refused with a configuration error.
  * Records keep the input order inside every file. */
 int phq_transcode_job(phq_decoder_set* set, int64_t batch_capacity, uint64_t* incoming_count, uint64_t* incoming_pf_count);
 
