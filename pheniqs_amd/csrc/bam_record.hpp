@@ -11,6 +11,10 @@
 #include <cstring>
 #include <string>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
 #include "error.hpp"
 #include "text_format.hpp"
 
@@ -42,19 +46,42 @@ inline void append_bam_record(ByteBuffer& out, const char* line, size_t size, co
         }
     } codes;
     const uint8_t* const CODE = codes.of;
+    // where the line's tabs are, in one pass (a line this writer makes has ten in front of the bases and one in front of every tag)
+    constexpr int MAX_TABS = 64;
+    uint32_t tab_at[MAX_TABS + 1];
+    int tabs = 0;
+    {
+        size_t i = 0;
+#if defined(__SSE2__)
+        const __m128i wanted = _mm_set1_epi8('\t');
+        for(; i + 16 <= size; i += 16) {
+            uint32_t mask = static_cast<uint32_t>(_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(line + i)), wanted)));
+            while(mask) {
+                if(tabs == MAX_TABS) { throw InternalError("a SAM line of more tags than this writer makes"); }
+                tab_at[tabs++] = static_cast<uint32_t>(i) + static_cast<uint32_t>(__builtin_ctz(mask));
+                mask &= mask - 1;
+            }
+        }
+#endif
+        for(; i < size; ++i) {
+            if(line[i] == '\t') {
+                if(tabs == MAX_TABS) { throw InternalError("a SAM line of more tags than this writer makes"); }
+                tab_at[tabs++] = static_cast<uint32_t>(i);
+            }
+        }
+    }
+    if(tabs < 10) { throw InternalError("a SAM line of fewer than eleven fields"); }
+    tab_at[tabs] = static_cast<uint32_t>(size);
     const char* field[11];
     size_t length[11];
-    const char* at = line;
-    const char* const end = line + size;
     for(int k = 0; k < 11; ++k) {
-        const char* const tab = static_cast<const char*>(std::memchr(at, '\t', static_cast<size_t>(end - at)));
-        field[k] = at;
-        if(tab == nullptr) {
-            if(k < 10) { throw InternalError("a SAM line of fewer than eleven fields"); }
-            length[k] = static_cast<size_t>(end - at);
-            at = end;
-        } else { length[k] = static_cast<size_t>(tab - at); at = tab + 1; }
+        const size_t first = k == 0 ? 0 : tab_at[k - 1] + 1u;
+        field[k] = line + first;
+        length[k] = tab_at[k] - first;
     }
+    const char* const end = line + size;
+    int next_tab = 10;                          // the tab in front of the first tag, if there is one
+    const char* at = tabs > 10 ? line + tab_at[10] + 1 : end;
     uint32_t flag = 0;
     for(size_t i = 0; i < length[1]; ++i) { flag = flag * 10u + static_cast<uint32_t>(field[1][i] - '0'); }
     const bool no_sequence = length[9] == 1 && field[9][0] == '*';
@@ -84,10 +111,16 @@ inline void append_bam_record(ByteBuffer& out, const char* line, size_t size, co
     }
     if(l_seq & 1) { *to++ = static_cast<char>(CODE[static_cast<uint8_t>(field[9][l_seq - 1])] << 4); }
     if(no_quality) { std::memset(to, 0xff, l_seq); to += l_seq; }
-    else { for(size_t i = 0; i < l_seq; ++i) { *to++ = static_cast<char>(field[10][i] - 33); } }
+    else {
+        const char* const quality = field[10];
+        char* const phred = to;
+        for(size_t i = 0; i < l_seq; ++i) { phred[i] = static_cast<char>(quality[i] - 33); }
+        to += l_seq;
+    }
     // TAG:TYPE:VALUE
     while(at < end) {
-        const char* const tab = static_cast<const char*>(std::memchr(at, '\t', static_cast<size_t>(end - at)));
+        ++next_tab;
+        const char* const tab = next_tab < tabs ? line + tab_at[next_tab] : nullptr;
         const char* const stop = tab ? tab : end;
         if(stop - at < 5 || at[2] != ':' || at[4] != ':') { throw InternalError("a SAM tag this writer does not make"); }
         *to++ = at[0]; *to++ = at[1];
@@ -104,10 +137,22 @@ inline void append_bam_record(ByteBuffer& out, const char* line, size_t size, co
             *to++ = 'i';
             put32(negative ? -v : v);
         } else if(type == 'f') {
-            const int which = (at[0] == 'X' && at[1] == 'B') ? 0 : (at[0] == 'X' && at[1] == 'M') ? 1 : (at[0] == 'X' && at[1] == 'C') ? 2 : -1;
-            if(which < 0 || posterior == nullptr) { throw InternalError("a float tag this writer does not make"); }
             *to++ = 'f';
-            std::memcpy(to, &posterior[which], 4);
+            if(stop - value == 9 && value[0] == '#') {
+                // a line assembled on the device for a BAM sink states the float's bits (record_device.hpp RECORD_FORMAT_SAM_FOR_BAM)
+                uint32_t bits = 0;
+                for(int k = 1; k < 9; ++k) {
+                    const char c = value[k];
+                    const uint32_t digit = (c >= '0' && c <= '9') ? static_cast<uint32_t>(c - '0') : (c >= 'a' && c <= 'f') ? static_cast<uint32_t>(c - 'a' + 10) : 16u;
+                    if(digit > 15u) { throw InternalError("a float tag that states no bits"); }
+                    bits = (bits << 4) | digit;
+                }
+                std::memcpy(to, &bits, 4);
+            } else {
+                const int which = (at[0] == 'X' && at[1] == 'B') ? 0 : (at[0] == 'X' && at[1] == 'M') ? 1 : (at[0] == 'X' && at[1] == 'C') ? 2 : -1;
+                if(which < 0 || posterior == nullptr) { throw InternalError("a float tag this writer does not make"); }
+                std::memcpy(to, &posterior[which], 4);
+            }
             to += 4;
         } else { throw InternalError("a SAM tag type this writer does not make"); }
         at = tab ? tab + 1 : end;
@@ -115,6 +160,18 @@ inline void append_bam_record(ByteBuffer& out, const char* line, size_t size, co
     const int32_t block_size = static_cast<int32_t>(to - begin - 4);
     std::memcpy(begin, &block_size, 4);
     out.commit(to);
+}
+
+// every line of `text` (whole lines, each ended by a newline) as a BAM record behind `out`'s bytes
+inline void append_bam_records(ByteBuffer& out, const char* text, size_t size) {
+    const char* at = text;
+    const char* const end = text + size;
+    while(at < end) {
+        const char* const newline = static_cast<const char*>(std::memchr(at, '\n', static_cast<size_t>(end - at)));
+        const char* const stop = newline ? newline : end;
+        if(stop > at) { append_bam_record(out, at, static_cast<size_t>(stop - at), nullptr); }
+        at = newline ? newline + 1 : end;
+    }
 }
 
 }  // namespace phq

@@ -7,7 +7,7 @@
 // usage: transcoder_check <job.json> <rounds> <work directory> <segment 0 FASTQ> [<segment 1 FASTQ> ...]
 //
 // Round 0 runs the files as they are (every record must come out); every later round runs copies with bytes flipped,
-// dropped, doubled, lines cut or the tail truncated, alternating SAM text to a file, FASTQ / SAM by the job's own output
+// dropped, doubled, lines cut or the tail truncated, alternating SAM text to a file, unaligned BAM, FASTQ / SAM by the job's own output
 // directives when it has some, and report only (/dev/null).  An Error (the reference's error codes) or a result every time.
 #include <cstdio>
 #include <cstdlib>
@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
                 input.push_back(path);
             }
             const int64_t capacity = round % 3 == 0 ? 1 << 12 : round % 3 == 1 ? 37 : 1 << 16;          // batches smaller and larger than the file
-            const std::string output = round % 2 == 0 ? work + "/out.sam" : "/dev/null";
+            const std::string output = round % 4 == 0 ? work + "/out.sam" : round % 4 == 2 ? work + "/out.bam" : "/dev/null";      // (BAM: bam_record.hpp, fast_deflate.hpp)
             try {
                 uint64_t incoming = 0, incoming_pf = 0;
                 const bool own_outputs = round % 5 == 4 && job.multiplexing_decoder >= 0;

@@ -107,6 +107,17 @@ __device__ void put_float_g(W& out, float value) {
     for(int i = 0; i < significant; ++i) { out.put(text[i]); }
 }
 
+// the float as '#' and the eight hexadecimal digits of its bits: what a line bound for a BAM record states (RECORD_FORMAT_SAM_FOR_BAM)
+template <typename W>
+__device__ __forceinline__ void put_float_bits(W& out, float value) {
+    const uint32_t bits = __float_as_uint(value);
+    out.put('#');
+    for(int shift = 28; shift >= 0; shift -= 4) {
+        const uint32_t digit = (bits >> shift) & 15u;
+        out.put(static_cast<char>(digit < 10u ? '0' + digit : 'a' + (digit - 10u)));
+    }
+}
+
 // one read's view of the round: its row of the planes and results, its segments in the chunks
 struct ReadView {
     const RecordArgs* args;
@@ -307,20 +318,22 @@ struct ReadView {
 
 // Read::flush (read.h:187-237) + Auxiliary::encode order (auxiliary.cpp:327-354): the same tags on every segment
 template <typename W>
-__device__ void put_tags(W& out, const ReadView& read, int group, const double (&confidence)[3], const uint32_t (&raw_size)[3], const uint32_t (&corrected_size)[3]) {
+__device__ void put_tags(W& out, const ReadView& read, int group, const double (&confidence)[3], const uint32_t (&raw_size)[3], const uint32_t (&corrected_size)[3], bool float_bits) {
     const RecordPlan& plan = *read.plan;
+    // a line the host turns into a BAM record carries the float itself, not six of its digits (bam_record.hpp)
+    auto put_float = [&](float value) { if(float_bits) { put_float_bits(out, value); } else { put_float_g(out, value); } };
     if(group >= 0 && group < plan.n_group) {
         const int32_t first = plan.ints[plan.group_at + group], last = plan.ints[plan.group_at + group + 1];
         if(last > first) { put_literal(out, "\tRG:Z:"); put_bytes(out, reinterpret_cast<const char*>(plan.bytes) + first, static_cast<uint32_t>(last - first)); }
     }
     if(raw_size[0]) { put_literal(out, "\tBC:Z:"); read.put_raw(out, 0, false); put_literal(out, "\tQT:Z:"); read.put_raw(out, 0, true); }
-    if(confidence[0] > 0 && confidence[0] < 1) { put_literal(out, "\tXB:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[0])); }
+    if(confidence[0] > 0 && confidence[0] < 1) { put_literal(out, "\tXB:f:"); put_float(static_cast<float>(1.0 - confidence[0])); }
     if(corrected_size[1]) { put_literal(out, "\tRX:Z:"); read.put_corrected(out, 1, false); put_literal(out, "\tQX:Z:"); read.put_corrected(out, 1, true); }
     if(raw_size[1]) { put_literal(out, "\tOX:Z:"); read.put_raw(out, 1, false); put_literal(out, "\tBZ:Z:"); read.put_raw(out, 1, true); }
-    if(confidence[1] > 0 && confidence[1] < 1) { put_literal(out, "\tXM:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[1])); }
+    if(confidence[1] > 0 && confidence[1] < 1) { put_literal(out, "\tXM:f:"); put_float(static_cast<float>(1.0 - confidence[1])); }
     if(corrected_size[2]) { put_literal(out, "\tCB:Z:"); read.put_corrected(out, 2, false); }
     if(raw_size[2]) { put_literal(out, "\tCR:Z:"); read.put_raw(out, 2, false); put_literal(out, "\tCY:Z:"); read.put_raw(out, 2, true); }
-    if(confidence[2] > 0 && confidence[2] < 1) { put_literal(out, "\tXC:f:"); put_float_g(out, static_cast<float>(1.0 - confidence[2])); }
+    if(confidence[2] > 0 && confidence[2] < 1) { put_literal(out, "\tXC:f:"); put_float(static_cast<float>(1.0 - confidence[2])); }
 }
 
 // what the records of a read share: its channel, its read group, the tags' ingredients
@@ -345,9 +358,10 @@ __device__ bool prepare_tags(const ReadView& read, ReadTags& tags) {
 // where output segment o of a channel goes: a sink of the plan, or -1
 __device__ __forceinline__ int sink_of(const RecordPlan& plan, int channel, int o) { return plan.ints[plan.sink_at + channel * plan.n_out + o]; }
 
-// one record: output segment o of the read, as a FASTQ record or a SAM line
+// one record: output segment o of the read, as a FASTQ record or a SAM line (format: RECORD_FORMAT_* of its sink)
 template <typename W>
-__device__ void put_record(W& out, const ReadView& read, const ReadTags& tags, int o, bool fastq) {
+__device__ void put_record(W& out, const ReadView& read, const ReadTags& tags, int o, uint8_t format) {
+    const bool fastq = format == RECORD_FORMAT_FASTQ;
     const RecordPlan& plan = *read.plan;
     const FeedBytes name_text = read.bytes->feed(read.args->tables->plan.segment_feed[0]);
     auto put_name = [&]() {
@@ -388,7 +402,7 @@ __device__ void put_record(W& out, const ReadView& read, const ReadTags& tags, i
         put_literal(out, "\tFI:i:"); put_number(out, static_cast<uint32_t>(o + 1));
         put_literal(out, "\tTC:i:"); put_number(out, static_cast<uint32_t>(plan.n_out));
     }
-    put_tags(out, read, tags.group, tags.confidence, tags.raw_size, tags.corrected_size);
+    put_tags(out, read, tags.group, tags.confidence, tags.raw_size, tags.corrected_size, format == RECORD_FORMAT_SAM_FOR_BAM);
     out.put('\n');
 }
 
@@ -400,7 +414,7 @@ __device__ void put_read(W& out, const ReadView& read) {
     if(!prepare_tags(read, tags)) { return; }
     for(int o = 0; o < plan.n_out; ++o) {
         const int sink = sink_of(plan, tags.channel, o);
-        if(sink >= 0) { put_record(out, read, tags, o, plan.bytes[plan.format_at + sink] != 0); }
+        if(sink >= 0) { put_record(out, read, tags, o, plan.bytes[plan.format_at + sink]); }
     }
 }
 
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(TILE_THREADS) void record_size_sinks_kernel(RecordA
             const int sink = written ? sink_of(*read.plan, tags.channel, o) : -1;
             if(sink >= 0) {
                 CountOut out{0};
-                put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + sink] != 0);
+                put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + sink]);
                 bytes = out.count;
                 atomicAdd(&sink_bytes[sink], bytes);
             }
@@ -728,14 +742,14 @@ __global__ __launch_bounds__(TILE_THREADS) void record_write_sinks_kernel(Record
             LdsOut out{out_at + inclusive - own};
 #pragma unroll
             for(int o = 0; o < RECORD_MAX_OUT; ++o) {
-                if(o < args.n_out && bytes_of_piece[o] != 0) { put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]] != 0); }
+                if(o < args.n_out && bytes_of_piece[o] != 0) { put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]]); }
             }
         } else {
 #pragma unroll
             for(int o = 0; o < RECORD_MAX_OUT; ++o) {
                 if(o < args.n_out && bytes_of_piece[o] != 0) {
                     GlobalOut out{place[o]};
-                    put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]] != 0);
+                    put_record(out, read, tags, o, read.plan->bytes[read.plan->format_at + piece_sink[local + o]]);
                 }
             }
         }

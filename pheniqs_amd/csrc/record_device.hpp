@@ -24,6 +24,11 @@ namespace phq {
 constexpr int RECORD_MAX_TOKEN = 32;
 constexpr int RECORD_MAX_OUT = 8;
 constexpr int RECORD_MAX_SINK = 1024;       // output files of a run whose records are assembled on the device
+// what a sink's records are: SAM lines, FASTQ records, or SAM lines the host turns into BAM records (bam_record.hpp) — those state
+// XB / XM / XC as '#' and the eight hexadecimal digits of the float's bits, since a BAM record holds the float and not its `%g`
+constexpr uint8_t RECORD_FORMAT_SAM = 0;
+constexpr uint8_t RECORD_FORMAT_FASTQ = 1;
+constexpr uint8_t RECORD_FORMAT_SAM_FOR_BAM = 2;
 
 struct RecordDecoder {
     int32_t kind;                   // 0 sample, 1 molecular, 2 cellular
@@ -57,7 +62,7 @@ struct RecordPlan {
     int32_t n_channel;
     int32_t n_sink;                 // output files the records go to
     int32_t sink_at;                // ints[sink_at + channel * n_out + o]: the sink of output segment o of a channel, -1 none
-    int32_t format_at;              // bytes[format_at + sink]: 1 FASTQ records, 0 SAM
+    int32_t format_at;              // bytes[format_at + sink]: RECORD_FORMAT_* of the sink
     int32_t illumina_comment;
     int32_t quality_shift;          // output Phred offset - input Phred offset
     int32_t input_phred_offset;

@@ -990,7 +990,7 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
             const int32_t f = channel.feed_by_segment[static_cast<size_t>(o)];
             const OutputSink& to = sink[static_cast<size_t>(f)];
             if(to.null) { continue; }
-            if(to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ) { return false; }
+            if(to.feed.format != FileFormat::SAM && to.feed.format != FileFormat::FASTQ && to.feed.format != FileFormat::BAM) { return false; }
             if(device_sink[static_cast<size_t>(f)] < 0) { device_sink[static_cast<size_t>(f)] = static_cast<int32_t>(out.sinks.size()); out.sinks.push_back(f); }
             sink_of_segment[c * static_cast<size_t>(n_out) + static_cast<size_t>(o)] = device_sink[static_cast<size_t>(f)];
             writes = true;
@@ -1022,7 +1022,10 @@ bool plan_device_text(const JobConfig& job, const TranscodePlan& plan, const std
     r.channel_at = static_cast<int32_t>(out.bytes.size());
     out.bytes.insert(out.bytes.end(), mode.begin(), mode.end());
     r.format_at = static_cast<int32_t>(out.bytes.size());
-    for(const int32_t f : out.sinks) { out.bytes.push_back(sink[static_cast<size_t>(f)].feed.format == FileFormat::FASTQ ? 1 : 0); }
+    for(const int32_t f : out.sinks) {
+        const FileFormat format = sink[static_cast<size_t>(f)].feed.format;
+        out.bytes.push_back(format == FileFormat::FASTQ ? RECORD_FORMAT_FASTQ : format == FileFormat::BAM ? RECORD_FORMAT_SAM_FOR_BAM : RECORD_FORMAT_SAM);
+    }
     out.bytes.push_back(0);
     r.sink_at = static_cast<int32_t>(out.ints.size());
     out.ints.insert(out.ints.end(), sink_of_segment.begin(), sink_of_segment.end());
@@ -1246,6 +1249,17 @@ int32_t quality_control_cycles(const RecordPlan& plan, const uint32_t* longest, 
     return std::max(64, (cycles + 31) / 32 * 32);
 }
 
+// SAM lines the device assembled for a BAM sink (RECORD_FORMAT_SAM_FOR_BAM) as BAM records in BGZF blocks behind `packed`'s bytes
+void bam_blocks_of_lines(const char* lines, size_t size, ByteBuffer& records, ByteBuffer& packed) {
+    if(size == 0) { return; }
+    append_bam_records(records, lines, size);
+    const size_t bound = fast_deflate::bgzf_bound(records.size);
+    char* const to = packed.reserve(bound);
+    const size_t made = fast_deflate::bgzf_blocks(reinterpret_cast<const uint8_t*>(records.data.get()), records.size, reinterpret_cast<uint8_t*>(to), bound);
+    if(made == 0) { throw InternalError("BGZF"); }
+    packed.commit(to + made);
+}
+
 // A round's text into the files: sink k's records are bytes [base_of_sink[k], base_of_sink[k + 1]) of `from`.  A large part for
 // a regular file goes through a mapping on several host threads; gzip sinks are compressed a member per piece, the sinks (or
 // the pieces of a single one) side by side.
@@ -1254,6 +1268,28 @@ void write_round_text(const std::vector<OutputSink*>& to, const char* from, cons
     if(n_sink == 1) {
         OutputSink& sink = *to[0];
         const size_t bytes = static_cast<size_t>(base_of_sink[1]);
+        if(sink.feed.format == FileFormat::BAM) {
+            // pieces of about 2 MiB of lines, each from the start of a line: records, then BGZF blocks, side by side; written in order
+            const size_t piece = size_t(2) << 20;
+            const int64_t pieces = static_cast<int64_t>((bytes + piece - 1) / piece);
+            std::vector<size_t> begin_of(static_cast<size_t>(pieces) + 1, bytes);
+            begin_of[0] = 0;
+            for(int64_t k = 1; k < pieces; ++k) {
+                const size_t from_byte = static_cast<size_t>(k) * piece - 1;
+                const char* const newline = static_cast<const char*>(std::memchr(from + from_byte, '\n', bytes - from_byte));
+                begin_of[static_cast<size_t>(k)] = newline ? static_cast<size_t>(newline - from) + 1 : bytes;
+            }
+            std::vector<ByteBuffer> packed(static_cast<size_t>(pieces));
+            parallel_ranges(pieces, 1, threads, [&](int64_t first, int64_t last, int) {
+                ByteBuffer records;
+                for(int64_t k = first; k < last; ++k) {
+                    records.clear();
+                    bam_blocks_of_lines(from + begin_of[static_cast<size_t>(k)], begin_of[static_cast<size_t>(k) + 1] - begin_of[static_cast<size_t>(k)], records, packed[static_cast<size_t>(k)]);
+                }
+            });
+            for(const auto& blocks : packed) { if(blocks.size) { sink.write(blocks.data.get(), blocks.size); } }
+            return;
+        }
         if(sink.feed.gzip) {
             const size_t piece = size_t(4) << 20;
             const int64_t pieces = static_cast<int64_t>((bytes + piece - 1) / piece);
@@ -1278,12 +1314,17 @@ void write_round_text(const std::vector<OutputSink*>& to, const char* from, cons
         return;
     }
     parallel_ranges(n_sink, 1, threads, [&](int64_t first, int64_t last, int) {
-        ByteBuffer packed;
+        ByteBuffer packed, records;
         for(int64_t k = first; k < last; ++k) {
             OutputSink& sink = *to[static_cast<size_t>(k)];
             const size_t begin = static_cast<size_t>(base_of_sink[k]), bytes = static_cast<size_t>(base_of_sink[k + 1] - base_of_sink[k]);
             if(bytes == 0) { continue; }
-            if(sink.feed.gzip) {
+            if(sink.feed.format == FileFormat::BAM) {
+                packed.clear();
+                records.clear();
+                bam_blocks_of_lines(from + begin, bytes, records, packed);
+                sink.write(packed.data.get(), packed.size);
+            } else if(sink.feed.gzip) {
                 packed.clear();
                 gzip_member(from + begin, bytes, sink.feed.level, packed);
                 sink.write(packed.data.get(), packed.size);

@@ -110,8 +110,9 @@ def plan(spec, reads=100_000_000):
         s.close()
 
 
-def run(torch, spec, reads, steps=3, warmup=1):
-    """(Greads/s, ms a step, [(kernel, ms a step)]) of one shape, inputs resident in HBM, every read its own draw"""
+def run(torch, spec, reads, steps=3, warmup=1, events=True):
+    """(Greads/s, ms a step, [(kernel, ms a step)]) of one shape, inputs resident in HBM, every read its own draw; events = False:
+    nothing recorded between the launches (phq_profile_chain's events cost a small batch a third of its time), no chain"""
     from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, synthetic
     job = capi.compile_job(spec)
     s = DecoderSet(spec, device=0)
@@ -120,21 +121,22 @@ def run(torch, spec, reads, steps=3, warmup=1):
     result = torch.zeros(max(1, s.n_result) * reads * RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     word = torch.zeros(reads, dtype=torch.int32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    s.profile_enable(True)
+    s.profile_enable(events)
     for _ in range(warmup):
         s.classify_device(reads, 0, reads, base, qual, flag, result, word, stream)
     torch.cuda.synchronize()
-    s.profile_chain()
+    if events:
+        s.profile_chain()
     t0 = time.perf_counter()
     for _ in range(steps):
         s.classify_device(reads, 0, reads, base, qual, flag, result, word, stream)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     chain, order = {}, []
-    spans = s.profile_chain()
+    spans = s.profile_chain() if events else []
     # what phq_plan_chain says the dispatcher WOULD do is what it did (one decision, read twice)
     planned = [(c["decoder"], c["kernel"]) for c in s.plan_chain(reads, capi.MODE_FAST)]
-    assert planned == [(c["decoder"], c["kernel"]) for c in spans[:len(spans) // steps]], (planned, spans)
+    assert not events or planned == [(c["decoder"], c["kernel"]) for c in spans[:len(spans) // steps]], (planned, spans)
     for span in spans:
         if span["kernel"] not in chain:
             chain[span["kernel"]] = 0.0
@@ -149,13 +151,13 @@ def run(torch, spec, reads, steps=3, warmup=1):
 
 def batches(torch, out):
     from pheniqs_amd import DecoderSet, RESULT_DTYPE, capi, synthetic
-    out.append("\n## Small batches: Greads/s by reads a call (the reference hands reads over 2 048 at a time, configuration.json:369)\n")
+    out.append("\n## Small batches: Greads/s by reads a call, calls in a row on one stream, no events between the launches (the reference hands reads over 2 048 at a time, configuration.json:369; by kernel and as a graph: `small_batch.py`)\n")
     out.append("| shape | 64 Ki | 1 Mi | 4 Mi | 16 Mi |\n|---|---|---|---|---|")
     for config in ("C2", "C3", "C4", "C5"):
         cells = []
         for reads in (1 << 16, 1 << 20, 1 << 22, 1 << 24):
             spec = synthetic.config_spec(config, "pamld")
-            rate, ms, chain, _ = run(torch, spec, reads, steps=20 if reads <= (1 << 20) else 5, warmup=3)
+            rate, ms, chain, _ = run(torch, spec, reads, steps=200 if reads <= (1 << 20) else 20, warmup=3, events=False)
             cells.append("%.2f (%.3f ms)" % (rate, ms))
         out.append("| %s | %s |" % (config, " | ".join(cells)))
 

@@ -263,8 +263,8 @@ def test_records_equal_the_independent_python_restatement(oracle, tmp_path, case
 @pytest.mark.parametrize("case", ["C2", "mixed_tokens", "per_barcode"])
 def test_unaligned_bam_output_holds_the_sam_records(tmp_path, case):
     """`output: x.bam` (what most Pheniqs runs state; the reference writes it through htslib, hts.h:169-239): the library writes
-    unaligned BAM itself — records made from the SAM lines its host writer formats (csrc/bam_record.hpp), BGZF blocks by its own
-    deflate, the empty block at the end.  tests/bam_reader.py reads the files back from the specification alone: every BGZF block
+    unaligned BAM itself — records made from the SAM lines its writers format, on the device or on the host (csrc/bam_record.hpp),
+    BGZF blocks by its own deflate, the empty block at the end.  tests/bam_reader.py reads the files back from the specification alone: every BGZF block
     states its size, inflates to its ISIZE and CRC, the header is the SAM header with no references, every record is the SAM record
     of the same run field by field — name, flag, sequence, qualities, the tags in Auxiliary::encode's order (auxiliary.cpp:320-354)
     with FI / TC as int32 — with tid, pos, mate -1, bin, mapq, tlen 0 as the reference leaves them (hts.cpp:26-44), and XB / XM / XC
@@ -279,16 +279,24 @@ def test_unaligned_bam_output_holds_the_sam_records(tmp_path, case):
     paths = _files(directory, spec, n, 9, lengths)
     spec["input"] = paths
     outputs = {}
-    for extension in ("sam", "bam"):
+    for extension, host in (("sam", False), ("bam", True), ("bam", False)):
         job = json.loads(json.dumps(spec))
         job["output"] = [os.path.join(directory, "out." + extension)]
         if case == "per_barcode":
             for k, record in enumerate(job["sample"]["codec"].values()):
                 if k % 3 == 0:
                     record["output"] = [os.path.join(directory, "barcode_%d.%s" % (k, extension))]
-        incoming, _, did = _run(job, 4096, False)
+        incoming, _, did = _run(job, 4096, host)
         assert incoming[0] == n
+        # the lines of a BAM sink are assembled on the device too (XB / XM / XC as the float's bits) and made records on the host's threads
+        assert (did["reads"] == n and did["record_bytes"] > 0) if not host else did["record_bytes"] == 0, did
         outputs[extension] = sorted(name for name in os.listdir(directory) if name.endswith("." + extension))
+        if extension == "bam" and host:
+            from_host = {name: bam_reader.blocks(open(os.path.join(directory, name), "rb").read())[0] for name in outputs["bam"]}
+            for name in outputs["bam"]:
+                os.unlink(os.path.join(directory, name))
+    # the same bytes in the blocks whichever side assembled the lines
+    assert from_host == {name: bam_reader.blocks(open(os.path.join(directory, name), "rb").read())[0] for name in outputs["bam"]}
     assert [name[:-4] for name in outputs["sam"]] == [name[:-4] for name in outputs["bam"]] and (len(outputs["bam"]) > 1) == (case == "per_barcode")
     total = 0
     for sam_name, bam_name in zip(outputs["sam"], outputs["bam"]):
