@@ -7,7 +7,7 @@
 // usage: transcoder_check <job.json> <rounds> <work directory> <segment 0 FASTQ> [<segment 1 FASTQ> ...]
 //
 // Round 0 runs the files as they are (every record must come out); every later round runs copies with bytes flipped,
-// dropped, doubled, lines cut or the tail truncated, alternating SAM text to a file, unaligned BAM, FASTQ / SAM by the job's own output
+// dropped, doubled, lines cut or the tail truncated, alternating SAM text to a file, FASTQ / SAM / BAM by the job's own output
 // directives when it has some, and report only (/dev/null).  An Error (the reference's error codes) or a result every time.
 #include <cstdio>
 #include <cstdlib>
@@ -106,12 +106,17 @@ int main(int argc, char** argv) {
                 input.push_back(path);
             }
             const int64_t capacity = round % 3 == 0 ? 1 << 12 : round % 3 == 1 ? 37 : 1 << 16;          // batches smaller and larger than the file
-            const std::string output = round % 4 == 0 ? work + "/out.sam" : round % 4 == 2 ? work + "/out.bam" : "/dev/null";      // (BAM: bam_record.hpp, fast_deflate.hpp)
+            const std::string output = round % 2 == 0 ? work + "/out.sam" : "/dev/null";
             try {
                 uint64_t incoming = 0, incoming_pf = 0;
-                const bool own_outputs = round % 5 == 4 && job.multiplexing_decoder >= 0;
+                // the job's own output directives (a file per channel: FASTQ, gzip, SAM, BAM) over this round's copies of the input
+                const bool own_outputs = round % 5 == 4 && job.multiplexing_decoder >= 0 && job.input.size() == input.size();
+                TranscodePlan plan = own_outputs ? TranscodePlan::from_job(job) : TranscodePlan::explicit_files(job, input, output);
+                if(own_outputs && plan.input_feed.size() == input.size()) {
+                    for(size_t f = 0; f < input.size(); ++f) { plan.input_feed[f].path = input[f]; }
+                }
                 {
-                    Transcoder transcoder(set, own_outputs ? TranscodePlan::from_job(job) : TranscodePlan::explicit_files(job, input, output), capacity);
+                    Transcoder transcoder(set, plan, capacity);
                     transcoder.set_classifier(classify);
                     transcoder.run(incoming, incoming_pf);
                 }
@@ -131,6 +136,22 @@ int main(int argc, char** argv) {
             } catch(const Error&) {
                 ++errors;
                 if(round == 0) { std::fprintf(stderr, "round 0 (undamaged input) raised an error\n"); ++failures; }
+            }
+        }
+        // last, the undamaged files by the job's own directives, so that what the channels' files hold can be read back by the caller
+        if(job.multiplexing_decoder >= 0 && job.input.size() == original.size()) {
+            TranscodePlan plan = TranscodePlan::from_job(job);
+            if(plan.input_feed.size() == original.size()) {
+                for(size_t f = 0; f < original.size(); ++f) {
+                    const std::string path = work + "/segment_" + std::to_string(f) + ".fastq";
+                    std::ofstream(path, std::ios::binary) << original[f];
+                    plan.input_feed[f].path = path;
+                }
+                uint64_t incoming = 0, incoming_pf = 0;
+                Transcoder transcoder(set, plan, 1 << 10);
+                transcoder.set_classifier(classify);
+                transcoder.run(incoming, incoming_pf);
+                std::printf("own outputs: %llu records in\n", static_cast<unsigned long long>(incoming));
             }
         }
     } catch(const std::exception& e) {

@@ -355,6 +355,8 @@ def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
     for number, record in enumerate(spec["sample"]["codec"].values()):
         if number < 5:
             record["output"] = ["channel_%d_s1.fastq" % number, "channel_%d_s2.fastq.gz" % number]
+        elif number < 8:
+            record["output"] = ["channel_%d.bam" % number]          # unaligned BAM: bam_record.hpp and the BGZF writer under the sanitizers
     spec["sample"]["output"] = ["rest.sam"]
     compiled = capi.compile_job(spec)
     code, quality, flag, _ = synthetic.generate_rows(compiled, 3000, 11)
@@ -366,12 +368,19 @@ def test_transcoder_reader_and_writers_under_sanitizers(tmp_path):
         path = str(work / ("segment_in_%d.fastq" % k))
         bench.write_fastq(path, k + 1, text, qual, flag)
         paths.append(path)
+    spec["input"] = paths                              # (the rounds that take the job's directives need a job that states its input: the check puts its damaged copies in their place)
     job = work / "job.json"
     job.write_text(json.dumps(spec))
     ran = subprocess.run([check, str(job), "140", str(work)] + paths, capture_output=True, text=True)
     assert ran.returncode == 0, ran.stdout + ran.stderr
     results = int(ran.stdout.split(" runs, ")[1].split(" results")[0])
     assert "141 runs" in ran.stdout and results >= 20, ran.stdout
+    # the channels' own files were written: FASTQ, gzip members, and BAM files that read back block by block
+    import bam_reader
+    assert os.path.getsize(work / "channel_0_s1.fastq") > 0 and open(work / "channel_0_s2.fastq.gz", "rb").read(2) == b"\x1f\x8b"
+    for number in (5, 6, 7):
+        _, records, blocks = bam_reader.records(str(work / ("channel_%d.bam" % number)))
+        assert blocks >= 2
 
 
 def test_a_damaged_quality_control_image_is_refused_before_anything_is_allocated():
