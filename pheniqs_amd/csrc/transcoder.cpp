@@ -14,7 +14,7 @@
 //                           Multiplexer::push: the channel of the multiplexing decoder's barcode decides the
 //                           output feeds (multiplex.h:198-240), optionally without QC failed reads.
 //
-// Out of scope here: BAM/CRAM (htslib), bz2 / xz, QC histograms.
+// Out of scope here: CRAM (htslib), bz2 / xz.  Unaligned BAM out: bam_record.hpp.
 #include "transcoder.hpp"
 #include "fastq_device.hpp"
 #include "record_device.hpp"

@@ -1039,7 +1039,7 @@ def test_job_directives_errors(torch_cuda, tmp_path):
     for changes, text in (({"output": ["a.sam", "b.sam", "c.sam"]}, "incorrect number of output URLs in channel"),
                           ({"output": ["/dev/stdin"]}, "output stream can not be set to standard input"),
                           ({"output": ["/dev/stderr"]}, "output stream can not be set to standard error"),
-                          ({"output": ["out.bam"]}, "htslib"),
+                          ({"output": ["out.cram"]}, "htslib"),
                           ({"output": ["out.fastq.bz2"]}, "not supported"),
                           ({"input": ["a.bam", "BDGGG_s02.fastq", "BDGGG_s03.fastq"]}, "only FASTQ input"),
                           ({"input": ["missing.fastq", "BDGGG_s02.fastq", "BDGGG_s03.fastq"]}, "could not open")):
