@@ -83,7 +83,8 @@ __device__ __forceinline__ double shuffle_xor(double v, int mask) {
 // lanes with their priors from L2, what the lists leave out bounded at the largest prior, the pairs within 1e-10 of the
 // largest prior P0 P1 literally.  A read with more listed words than WEIGHTED_CAP stays in the worklist for the dense kernel.
 template <int G, int S, bool PRIORS, int WORDS, int R, bool WEIGHTED = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WEIGHTED ? 2 : 3, 4))) void pamld_exact_lanes_kernel(StageArgs args) {
+// (four word groups of two segments — 13 to 16 nt each — keep 2 waves a SIMD whatever is asked for: their tables take the registers)
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu((WEIGHTED || (G == 4 && S == 2)) ? 2 : 3, 4))) void pamld_exact_lanes_kernel(StageArgs args) {
     static_assert(!WEIGHTED || (S == 2 && !PRIORS), "the weighted form is the two segment one; PRIORS is priors by word of a single segment set");
     static_assert(S == 1 || S == 2, "single segment sets and two segment combinatorial sets");
     static_assert(!PRIORS || S == 1, "priors by word are for single segment sets");
