@@ -635,3 +635,72 @@ def test_the_one_shot_inflate_against_zlib_under_sanitizers():
     ran = subprocess.run([os.path.join(csrc, "build", "fast_inflate_check_asan")], capture_output=True, text=True)
     assert ran.returncode == 0, ran.stdout[-2000:] + ran.stderr[-2000:]
     assert "members 800 refused 0" in ran.stdout
+
+
+def test_bam_records_from_sam_lines_read_back_field_by_field(tmp_path):
+    """csrc/bam_record.hpp + the BGZF writer of csrc/fast_deflate.hpp without a device and without the transcoder around them
+    (check/bam_record_check.cpp under ASan + UBSan): 6 000 unaligned SAM lines — names up to 254 characters, sequences of every
+    length from none ('*') to 300 with IUPAC letters in either case, string / int32 / float tags, the floats stated as their bits
+    the way the device states them for a BAM sink — come back through tests/bam_reader.py (written from the specification alone)
+    field by field; lines this writer does not make are errors, not records."""
+    import struct
+    import subprocess
+    import bam_reader
+    here = os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(os.path.dirname(here), "pheniqs_amd", "csrc")
+    check = str(tmp_path / "bam_record_check_asan")
+    built = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-Wall", "-Wno-unused-result",
+                            os.path.join(csrc, "check", "bam_record_check.cpp"), "-o", check, "-lz"], capture_output=True, text=True)
+    if built.returncode != 0:
+        assert "libasan" in built.stderr or "libubsan" in built.stderr or "fsanitize" in built.stderr, built.stderr[-2000:]
+        pytest.skip("sanitizer build unavailable: " + built.stderr[-200:])
+    rng = np.random.default_rng(23)
+    letters = "=ACMGRSVTWYHKDBNacgtn"
+    expected, lines = [], []
+    for k in range(6000):
+        name = "M:%d:" % k + "x" * int(rng.integers(0, 40)) if k % 500 else "n" * 254
+        length = 0 if k % 97 == 0 else int(rng.integers(1, 301))
+        sequence = "".join(letters[i] for i in rng.integers(0, len(letters), length))
+        quality = bytes(rng.integers(0, 94, length, dtype=np.uint8))
+        flag = int(rng.choice([77, 141, 589, 653, 4]))
+        tags = []
+        if k % 3:
+            tags.append(("RG", "Z", "group:%d" % (k % 7)))
+        if k % 2:
+            tags += [("BC", "Z", "ACGTNNAC-TTGA"), ("QT", "Z", "FF,:#FFF FFFF")]
+        if k % 5 == 0:
+            tags += [("FI", "i", k % 4 + 1), ("TC", "i", 4), ("XX", "i", -12345 - k)]
+        for tag in ("XB", "XM", "XC"):
+            if rng.random() < 0.5:
+                tags.append((tag, "f", struct.unpack("<f", struct.pack("<f", float(rng.random()) * 10.0 ** -int(rng.integers(0, 12))))[0]))
+        fields = [name, str(flag), "*", "0", "0", "*", "*", "0", "0", sequence or "*", "".join(chr(q + 33) for q in quality) or "*"]
+        for tag, kind, value in tags:
+            fields.append("%s:%s:%s" % (tag, kind, "#%08x" % struct.unpack("<I", struct.pack("<f", value))[0] if kind == "f" else value))
+        lines.append("\t".join(fields))
+        expected.append((name, flag, sequence.upper(), quality, tags))
+    header = "@HD\tVN:1.0\tSO:unknown\tGO:query\n@RG\tID:group:1\tPU:x\n"
+    (tmp_path / "lines.sam").write_text("\n".join(lines) + "\n")
+    (tmp_path / "header.sam").write_text(header)
+    ran = subprocess.run([check, str(tmp_path / "lines.sam"), str(tmp_path / "out.bam"), str(tmp_path / "header.sam")], capture_output=True, text=True)
+    assert ran.returncode == 0, ran.stdout + ran.stderr
+    text, records, blocks = bam_reader.records(str(tmp_path / "out.bam"))
+    assert text == header and len(records) == len(expected) and blocks > 10
+    for record, (name, flag, sequence, quality, tags) in zip(records, expected):
+        assert (record["name"], record["flag"], record["sequence"], record["quality"]) == (name, flag, sequence, quality)
+        assert (record["ref"], record["pos"], record["mapq"], record["bin"], record["n_cigar"], record["next_ref"], record["next_pos"], record["tlen"]) == (-1, -1, 0, 0, 0, -1, -1, 0)
+        assert record["tags"] == tags                   # (the floats bit for bit: both sides went through the same four bytes)
+    # no lines: a header and the end of file block
+    (tmp_path / "none.sam").write_text("")
+    assert subprocess.run([check, str(tmp_path / "none.sam"), str(tmp_path / "none.bam")], capture_output=True).returncode == 0
+    assert bam_reader.records(str(tmp_path / "none.bam"))[:2] == ("", [])
+    # lines this writer does not make
+    good = lines[1]
+    for bad, message in (("\t".join(good.split("\t")[:9]), "fewer than eleven fields"),
+                         ("q" * 255 + good[good.index("\t"):], "254"),
+                         (good + "\tXB:f:0.25", "float tag"),
+                         (good + "\tXB:f:#0000zz00", "states no bits"),
+                         (good + "\tXY:A:c", "tag type"),
+                         (good + "\tbroken", "tag this writer does not make")):
+        (tmp_path / "bad.sam").write_text(bad + "\n")
+        ran = subprocess.run([check, str(tmp_path / "bad.sam"), str(tmp_path / "bad.bam")], capture_output=True, text=True)
+        assert ran.returncode == 3 and message in ran.stderr, (bad[-40:], ran.returncode, ran.stderr[-300:])
