@@ -38,27 +38,22 @@ constexpr int MIN_MATCH = 4;
 struct BitWriter {
     uint8_t* next;
     uint8_t* end;
-    uint64_t bits = 0;
+    uint64_t bits = 0;                                   // fewer than 8 of them between two calls: whole bytes leave at once
     int held = 0;
     bool overflow = false;
-    void put(uint32_t value, int n) {                    // n <= 32, held < 32 on entry
-        bits |= static_cast<uint64_t>(value) << held;
+    void put(uint64_t value, int n) {                    // n <= 48
+        bits |= value << held;
         held += n;
-        if(held >= 32) {
-            if(end - next < 4) { overflow = true; held -= 32; bits >>= 32; return; }
-            const uint32_t word = static_cast<uint32_t>(bits);
-            std::memcpy(next, &word, 4);
-            next += 4;
-            bits >>= 32;
-            held -= 32;
-        }
+        if(end - next < 8) { overflow = true; bits = 0; held &= 7; return; }
+        std::memcpy(next, &bits, 8);                     // (the bytes past the whole ones are written again by the next call)
+        next += held >> 3;
+        bits >>= held & ~7;
+        held &= 7;
     }
     void align() {
-        while(held > 0) {
+        if(held > 0) {
             if(next >= end) { overflow = true; held = 0; bits = 0; return; }
             *next++ = static_cast<uint8_t>(bits);
-            bits >>= 8;
-            held -= 8;
         }
         held = 0; bits = 0;
     }
@@ -246,14 +241,19 @@ inline void write_block(BitWriter& w, const uint32_t* token, size_t n_token, con
     for(size_t k = 0; k < n_token; ++k) {
         const uint32_t t = token[k];
         if((t >> 31) == 0) { w.put(coder.litlen_code[t], coder.litlen_length[t]); continue; }
+        // a match's four fields — length code, its extra bits, distance code, its extra bits: at most 15 + 5 + 15 + 13 — leave as one
         const LengthSlot& slot = slots[((t >> 16) & 0xffu) + 3];
-        w.put(coder.litlen_code[slot.symbol], coder.litlen_length[slot.symbol]);
-        if(slot.extra_bits) { w.put(slot.extra, slot.extra_bits); }
         const uint32_t distance = (t & 0xffffu) + 1;
         const int symbol = dist_symbol(distance);
-        w.put(coder.dist_code[symbol], coder.dist_length[symbol]);
-        const int extra_bits = fast_inflate::DIST_EXTRA[symbol];
-        if(extra_bits) { w.put(distance - fast_inflate::DIST_BASE[symbol], extra_bits); }
+        uint64_t fields = coder.litlen_code[slot.symbol];
+        int n = coder.litlen_length[slot.symbol];
+        fields |= static_cast<uint64_t>(slot.extra) << n;
+        n += slot.extra_bits;
+        fields |= static_cast<uint64_t>(coder.dist_code[symbol]) << n;
+        n += coder.dist_length[symbol];
+        fields |= static_cast<uint64_t>(distance - fast_inflate::DIST_BASE[symbol]) << n;
+        n += fast_inflate::DIST_EXTRA[symbol];
+        w.put(fields, n);
     }
     w.put(coder.litlen_code[256], coder.litlen_length[256]);
 }
@@ -299,11 +299,16 @@ inline size_t deflate_raw(const uint8_t* in, size_t bytes, uint8_t* out, size_t 
             table[hash] = static_cast<uint32_t>(at);
             int length = 0;
             if(candidate != 0xffffffffu && at - candidate <= WINDOW) {
-                uint32_t theirs;
-                std::memcpy(&theirs, in + candidate, 4);
-                if(theirs == four) {
+                // eight bytes of both at once (bytes - at >= 8 here, and the candidate lies in front): most candidates of text whose
+                // alphabet is small — the bases of a read — are real matches of four to seven bytes, settled by this one comparison
+                uint64_t mine, theirs;
+                std::memcpy(&mine, in + at, 8);
+                std::memcpy(&theirs, in + candidate, 8);
+                const uint64_t differ = mine ^ theirs;
+                if(differ != 0) { length = static_cast<int>(static_cast<unsigned>(__builtin_ctzll(differ)) >> 3); }
+                else {
                     const size_t limit = std::min<size_t>(MAX_MATCH, bytes - at);
-                    size_t same = 4;
+                    size_t same = 8;
                     while(same + 8 <= limit) {
                         uint64_t a, b;
                         std::memcpy(&a, in + at + same, 8);
