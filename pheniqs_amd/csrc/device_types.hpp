@@ -13,7 +13,7 @@ constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;      // 128: the reference 
 constexpr int DEV_TIER_NUCLEOTIDE = 32;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
-constexpr int EXACT_SINGLE_UNIQUE = 512;
+constexpr int EXACT_SINGLE_UNIQUE = 1024;
 // neighbour list kernel (pamld_near.hpp), by barcode length: flag bits per barcode in a plane word, barcodes scored per
 // read (c and the nearest to it; a whole number of plane words), words of a barcode's record
 constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }

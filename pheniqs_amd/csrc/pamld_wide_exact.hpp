@@ -26,11 +26,10 @@ namespace phq {
 namespace wide {
 
 constexpr int EXACT_LANES = 64;
-constexpr int EXACT_MAX_BARCODES = 512;       // one list bit each: sixteen mask registers (what the wide product form takes)
-constexpr int EXACT_MASK_WORDS = EXACT_MAX_BARCODES / 32;
+constexpr int EXACT_MAX_BARCODES = 1024;      // one list bit each: sixteen mask registers up to 512 barcodes (what the wide product form takes), thirty two past them (round 6)
 __host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * 8u * sizeof(double) * EXACT_LANES; }      // two pair tables of four entries per group
 
-template <int G>
+template <int G, int EXACT_MASK_WORDS = 16>
 __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs args) {
     constexpr int WORDS = 2;
     static_assert(G >= 5 && G <= 8, "17 to 32 nucleotides");
@@ -283,16 +282,22 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
     histogram_flush(args, d, histogram);
 }
 
-template <int G>
-int launch_exact_groups(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+template <int G, int MASK_WORDS>
+int launch_exact_masked(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     const size_t bytes = ((histogram_bytes + 15u) & ~static_cast<size_t>(15u)) + exact_table_bytes(G) + static_cast<size_t>(n_barcode) * (sizeof(double) + 2 * sizeof(uint32_t));
     if(bytes > 64u * 1024u) {
         static std::atomic<uint64_t> prepared{0};
-        // at most 32 KiB of histogram + 32 KiB of tables + 8 KiB of words and priors; the kernel also has ~4 KiB of static LDS
-        if(const int status = allow_large_lds(&pamld_wide_exact_kernel<G>, prepared, 128 * 1024)) { return status; }
+        // at most 32 KiB of histogram + 32 KiB of tables + 16 KiB of words and priors; the kernel also has ~4 KiB of static LDS
+        if(const int status = allow_large_lds(&pamld_wide_exact_kernel<G, MASK_WORDS>, prepared, 128 * 1024)) { return status; }
     }
-    hipLaunchKernelGGL((pamld_wide_exact_kernel<G>), grid, dim3(EXACT_LANES), bytes, stream, args);
+    hipLaunchKernelGGL((pamld_wide_exact_kernel<G, MASK_WORDS>), grid, dim3(EXACT_LANES), bytes, stream, args);
     return static_cast<int>(hipGetLastError());
+}
+
+template <int G>
+int launch_exact_groups(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
+    return n_barcode <= 512 ? launch_exact_masked<G, 16>(args, n_barcode, grid, histogram_bytes, stream)
+                            : launch_exact_masked<G, EXACT_MAX_BARCODES / 32>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 }  // namespace wide

@@ -1219,6 +1219,30 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
 
 
+@pytest.mark.parametrize("priors", [False, True])
+@pytest.mark.parametrize("length,count", [(8, 600), (10, 768), (12, 1024), (16, 768), (16, 1024), (20, 768), (24, 1024), (32, 600), (20, 1025)])
+def test_the_exact_tiers_hold_up_to_1024_barcodes(oracle, torch_cuda, length, count, priors):
+    """Round 6: the fp64 tiers between the product forms and the literal kernel — pamld_exact_lanes (words of up to 16 nt) and
+    pamld_wide_exact (17 to 32 nt) — keep their word lists and list masks for 1 024 barcodes (512 until now: a set of 513 to 1 024
+    handed whatever its product form could not certify straight to the literal kernel, half the step of 768 x 8 nt).  Sets of 600 to
+    1 024 barcodes with uniform priors and priors that differ, noise reads and reads without a called base among them, both modes
+    against the oracle; the plan names the tier, and 1 025 barcodes are the first size without it."""
+    rng = np.random.default_rng(9000 + 10 * length + count + (1 if priors else 0))
+    words = synthetic.barcode_set(rng, count, length, min_distance=1 if length < 10 else 3)
+    spec = {"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length], noise=0.05)}
+    if priors:
+        for record in spec["sample"]["codec"].values():
+            record["concentration"] = float(10 ** rng.uniform(-1.5, 1.5))
+    job = capi.compile_job(spec)
+    n = 30000
+    code, quality, flag, offsets = synthetic.generate_rows(job, n, 5 + length)
+    code[rng.random((n, length)) < 0.01] = 15
+    s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
+    kernels = [c["kernel"] for c in s.plan_chain(100_000_000, capi.MODE_FAST)]
+    tier = "pamld_exact_lanes_kernel" if length <= 16 else "pamld_wide_exact_kernel"
+    assert (tier in kernels) == (count <= 1024), kernels
+
+
 def test_many_decoders_and_many_segments(oracle, torch_cuda):
     """The widest job the library takes: 16 decoders (DEV_MAX_DECODER) of every algorithm in one chain — the sticky QC
     fail flag and the channel index travel through all of them — among them barcodes of 5 and 8 segments
