@@ -13,7 +13,8 @@ constexpr int DEV_MAX_NUCLEOTIDE = 8 * DEV_MAX_WORD;      // 128: the reference 
 constexpr int DEV_TIER_NUCLEOTIDE = 32;
 constexpr int CROSS_MAX_SEGMENT = 3;     // factorised PAMLD kernel (pamld_cross.hpp): segments of a combinatorial barcode set
 constexpr int CROSS_MAX_UNIQUE = 128;    // distinct words per segment
-constexpr int EXACT_SINGLE_UNIQUE = 1024;
+constexpr int EXACT_SINGLE_UNIQUE = 2048;  // words of a single segment set the exact tiers hold (round 6: 512 until then)
+constexpr int EXACT_SINGLE_MEDIUM = 512;   // ... and the size up to which pamld_exact_lanes keeps its smaller image of them
 // neighbour list kernel (pamld_near.hpp), by barcode length: flag bits per barcode in a plane word, barcodes scored per
 // read (c and the nearest to it; a whole number of plane words), words of a barcode's record
 constexpr int near_field_bits(int length) { return length <= 8 ? 8 : 10; }
@@ -69,7 +70,7 @@ constexpr uint8_t CROSS_STREAM_UNKNOWN = 0xffu; // pamld_cross_stream.hpp's byte
 static_assert(CROSS_MAX_UNIQUE < CROSS_STREAM_UNKNOWN, "a word's ordinal and the unknown mark share a byte");
 constexpr int NEAR_MIN_LENGTH = 5;
 constexpr int NEAR_MAX_LENGTH = 10;
-constexpr int NEAR_MAX_BARCODES = 1024;
+constexpr int NEAR_MAX_BARCODES = 2048;
 constexpr uint16_t PAIR_ANY_BARCODE = 0xfffeu;  // pamld_pair.hpp: this part of the barcode names no one of its own (its words are shared): the other part's word decides
 constexpr uint16_t NEAR_NO_BARCODE = 0xffffu; // ... of a set taken as ONE segment by the exact PAMLD tier (a codec that is not combinatorial)
 

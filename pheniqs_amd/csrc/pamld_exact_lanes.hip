@@ -20,7 +20,7 @@
 //     iterations ahead and their rows one ahead, and compacts what it cannot decide either — a confidence within 1e-12
 //     of its threshold, more listed words than the list holds — to the front of the read's own segment for the literal
 //     kernel: no barrier after the set up, nothing shared between waves but the counter histogram.
-// Serves single segment sets (up to EXACT_SINGLE_UNIQUE words of up to 16 nt, priors that differ or not) and two segment
+// Serves single segment sets (up to EXACT_SINGLE_UNIQUE words of up to 16 nt — an image of EXACT_SINGLE_MEDIUM where that holds them —, priors that differ or not) and two segment
 // combinatorial sets, with uniform priors or (WEIGHTED, below) priors that differ; three segment sets keep pamld_cross.hpp's kernel.
 #include <algorithm>
 #include <cstdlib>
@@ -976,9 +976,13 @@ int launch_pamld_exact_lanes(const StageArgs& args, const DevDecoder& host_decod
         return launch_pamld_cross_exact_dense(args, host_decoder, grid, histogram_bytes, stream);
     }
     if(host_decoder.cross_segments == 1) {
-        if(many) {
+        if(many && host_decoder.cross_unique[0] > EXACT_SINGLE_MEDIUM) {
             return host_decoder.uniform_prior ? lanes::launch_groups<1, false, EXACT_SINGLE_UNIQUE, lanes::LONG_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream)
                                               : lanes::launch_groups<1, true, EXACT_SINGLE_UNIQUE, lanes::LONG_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream);
+        }
+        if(many) {
+            return host_decoder.uniform_prior ? lanes::launch_groups<1, false, EXACT_SINGLE_MEDIUM, lanes::LONG_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream)
+                                              : lanes::launch_groups<1, true, EXACT_SINGLE_MEDIUM, lanes::LONG_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream);
         }
         return host_decoder.uniform_prior ? lanes::launch_groups<1, false, CROSS_MAX_UNIQUE, lanes::SHORT_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream)
                                           : lanes::launch_groups<1, true, CROSS_MAX_UNIQUE, lanes::SHORT_LANES>(grouped, host_decoder, fewer, histogram_bytes, stream);

@@ -26,7 +26,7 @@ namespace phq {
 namespace wide {
 
 constexpr int EXACT_LANES = 64;
-constexpr int EXACT_MAX_BARCODES = 1024;      // one list bit each: sixteen mask registers up to 512 barcodes (what the wide product form takes), thirty two past them (round 6)
+constexpr int EXACT_MAX_BARCODES = 2048;      // one list bit each: sixteen mask registers up to 512 barcodes (what the wide product form takes), thirty two and sixty four past them (round 6)
 __host__ __device__ constexpr size_t exact_table_bytes(int groups) { return static_cast<size_t>(groups) * 8u * sizeof(double) * EXACT_LANES; }      // two pair tables of four entries per group
 
 template <int G, int EXACT_MASK_WORDS = 16>
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
         double top = 0;
         double sum = 0;
         uint32_t list_mask[EXACT_MASK_WORDS];
+        int first_listed = 0;
 #pragma unroll
         for(int e = 0; e < EXACT_MASK_WORDS; ++e) { list_mask[e] = 0u; }
         auto scan_chunk = [&](auto which) {
@@ -165,8 +166,14 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
                 const double p = probability_of(word_list[2 * b], word_list[2 * b + 1]) * prior_list[b];      // scalar loads; pamld.cpp:66
                 sum += p;
                 const bool clears = p * near > top;
+                if constexpr (EXACT_MASK_WORDS > 32) {
+                    // sixty four words: what was listed in front of b is left where it is and the walk below starts at b (taking it
+                    // out of the words in front as the shorter masks do — measured the faster way for those — is 63 selects a barcode)
+                    first_listed = clears ? b : first_listed;
+                } else {
 #pragma unroll
-                for(int e = 0; e < c; ++e) { list_mask[e] = clears ? 0u : list_mask[e]; }
+                    for(int e = 0; e < c; ++e) { list_mask[e] = clears ? 0u : list_mask[e]; }
+                }
                 current = clears ? 0u : current;
                 current |= p >= top * near ? bit : 0u;
                 top = fmax(top, p);
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(EXACT_LANES) void pamld_wide_exact_kernel(StageArgs
         double best_conditional = 0;
         double best_p = -1.0;
         uint32_t best_flags[WORDS] = {0u, 0u};
-        for(int b = defer ? -1 : next_listed(0); b >= 0; b = next_listed(b + 1)) {
+        for(int b = defer ? -1 : next_listed(first_listed); b >= 0; b = next_listed(b + 1)) {
             uint32_t flags[WORDS];
             flags_of(lds_word[2 * b], lds_word[2 * b + 1], flags);
             double sigma = 0;
@@ -297,7 +304,8 @@ int launch_exact_masked(const StageArgs& args, int n_barcode, dim3 grid, size_t 
 template <int G>
 int launch_exact_groups(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     return n_barcode <= 512 ? launch_exact_masked<G, 16>(args, n_barcode, grid, histogram_bytes, stream)
-                            : launch_exact_masked<G, EXACT_MAX_BARCODES / 32>(args, n_barcode, grid, histogram_bytes, stream);
+         : n_barcode <= 1024 ? launch_exact_masked<G, 32>(args, n_barcode, grid, histogram_bytes, stream)
+                             : launch_exact_masked<G, EXACT_MAX_BARCODES / 32>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 }  // namespace wide

@@ -1220,13 +1220,15 @@ def test_codec_size_extremes(oracle, torch_cuda, algorithm, length, count):
 
 
 @pytest.mark.parametrize("priors", [False, True])
-@pytest.mark.parametrize("length,count", [(8, 600), (10, 768), (12, 1024), (16, 768), (16, 1024), (20, 768), (24, 1024), (32, 600), (20, 1025)])
-def test_the_exact_tiers_hold_up_to_1024_barcodes(oracle, torch_cuda, length, count, priors):
+@pytest.mark.parametrize("length,count", [(8, 600), (10, 768), (12, 1024), (16, 768), (16, 1024), (20, 768), (24, 1024), (32, 600), (20, 1025),
+                                          (8, 1536), (12, 1536), (16, 2048), (16, 2049), (20, 1536), (32, 2048), (24, 2049)])
+def test_the_exact_tiers_hold_up_to_2048_barcodes(oracle, torch_cuda, length, count, priors):
     """Round 6: the fp64 tiers between the product forms and the literal kernel — pamld_exact_lanes (words of up to 16 nt) and
-    pamld_wide_exact (17 to 32 nt) — keep their word lists and list masks for 1 024 barcodes (512 until now: a set of 513 to 1 024
-    handed whatever its product form could not certify straight to the literal kernel, half the step of 768 x 8 nt).  Sets of 600 to
-    1 024 barcodes with uniform priors and priors that differ, noise reads and reads without a called base among them, both modes
-    against the oracle; the plan names the tier, and 1 025 barcodes are the first size without it."""
+    pamld_wide_exact (17 to 32 nt) — keep their word lists and list masks for 2 048 barcodes (512 until now: a
+    larger set handed whatever its product form could not certify straight to the literal kernel, half the step of 768 x 8 nt), and the
+    lookup tiers in front of them (pamld_near, pamld_pair) take sets of up to 2 048 (1 024).  Sets of 600 to 2 049 barcodes with uniform
+    priors and priors that differ, noise reads and reads without a called base among them, both modes against the oracle; the plan
+    names the tier up to its size and not past it."""
     rng = np.random.default_rng(9000 + 10 * length + count + (1 if priors else 0))
     words = synthetic.barcode_set(rng, count, length, min_distance=1 if length < 10 else 3)
     spec = {"input segment cardinality": 1, "sample": synthetic.decoder_spec("pamld", [words], ["0::%d" % length], noise=0.05)}
@@ -1240,7 +1242,7 @@ def test_the_exact_tiers_hold_up_to_1024_barcodes(oracle, torch_cuda, length, co
     s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets)
     kernels = [c["kernel"] for c in s.plan_chain(100_000_000, capi.MODE_FAST)]
     tier = "pamld_exact_lanes_kernel" if length <= 16 else "pamld_wide_exact_kernel"
-    assert (tier in kernels) == (count <= 1024), kernels
+    assert (tier in kernels) == (count <= 2048), kernels
 
 
 def test_many_decoders_and_many_segments(oracle, torch_cuda):
