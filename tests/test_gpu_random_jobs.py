@@ -31,8 +31,10 @@ def _random_decoder(rng, algorithm, kind):
         words = [synthetic.barcode_set(rng, c, l, min_distance=1) for c, l in zip(counts, lengths)]
         pairing = "product"
     else:
-        # mostly small codecs; one in seven past the workgroup histogram sizes (117.., 341..) up to 600 barcodes
-        limit = 600 if (rng.random() < 0.15 and min(lengths) >= 5) else 120
+        # mostly small codecs; one in seven past the workgroup histogram sizes (117.., 341..) up to 600 barcodes; three in a hundred
+        # up to 2 100 (round 6: the lookup and the exact tiers hold 2 048 barcodes, the product forms take over past them)
+        size = rng.random()
+        limit = 2100 if (size < 0.03 and min(lengths) >= 6) else 600 if (size < 0.15 and min(lengths) >= 5) else 120
         count = int(min(rng.integers(1, limit), 4 ** min(lengths)))
         words = [synthetic.barcode_set(rng, count, l, min_distance=1) for l in lengths]
         for w in words[1:]:
