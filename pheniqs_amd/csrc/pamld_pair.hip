@@ -13,10 +13,16 @@ bool pamld_pair_supports(const DevDecoder& host_decoder) {
 }
 
 // the second look inside the launch (LISTS): the lists are there and the waves' rings fit the workgroup's LDS beside the records
-// and the histogram, several workgroups a CU
+// and the histogram, several workgroups a CU.  Round 6: sets of more than 512 barcodes take up to 80 KiB for it — two workgroups
+// a CU; their product form behind the kernel is dear enough for the second look to pay whatever the occupancy (1 536 pairs of
+// 10 + 10 nt 4.08 -> 2.88 ms per 16 M reads, 768 pairs of 12 + 12 nt 2.07 -> 1.75) — while sets of 192 and 288 pairs with their
+// histogram in LDS lose 5 to 19 % the same way and keep the 40 KiB rule (profiles/tools/scratch/pair_lists_room.sh)
 template <int G>
 bool lists_fit(const DevDecoder& host_decoder, size_t histogram_bytes) {
-    return pair::LayoutOf<G, true>::histogram_at(host_decoder.n_barcode) + histogram_bytes <= 40u * 1024u;
+    static const size_t forced = []() { const char* text = std::getenv("PHQ_PAIR_LISTS_LDS"); return text ? static_cast<size_t>(std::atol(text)) : size_t(0); }();      // (the variable: sweeps)
+    const size_t bytes = pair::LayoutOf<G, true>::histogram_at(host_decoder.n_barcode) + histogram_bytes;
+    if(forced) { return bytes <= forced; }
+    return bytes <= 40u * 1024u || (host_decoder.n_barcode > 512 && bytes <= 80u * 1024u);
 }
 
 int launch_pamld_pair(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
