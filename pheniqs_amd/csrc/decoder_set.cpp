@@ -256,7 +256,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
             }
         }
     }
-    if(N <= list) { return out; }                            // the table alone (mdd_near.hpp): no lists of a set this small
+    if(N < list) { return out; }                             // the table alone (mdd_near.hpp): no lists of a set this small (N == list: every word is listed, nothing left to bound)
     out.record.assign(static_cast<size_t>(N) * static_cast<size_t>(record_words), 0u);
     out.listed.assign(static_cast<size_t>(N) * static_cast<size_t>(list), 0);
     std::vector<std::pair<int, int32_t>> order(static_cast<size_t>(N));
@@ -271,7 +271,7 @@ NearTables build_near_tables(const std::vector<uint32_t>& low, const std::vector
             out.listed[static_cast<size_t>(b) * static_cast<size_t>(list) + static_cast<size_t>(k)] = o;
         }
         // the first word not listed sets the radius, at most 5 (the kernels form their bounds for 4 and 5)
-        const int radius = std::min(order[static_cast<size_t>(list)].first, 5);
+        const int radius = N > list ? std::min(order[static_cast<size_t>(list)].first, 5) : 5;
         // what is not listed, at the radius and beyond it: how many — or, with priors that differ, their priors over b's
         double at_radius = 0;
         double beyond = 0;
@@ -1040,7 +1040,7 @@ void DecoderSet::build_device_images() {
                         d.cross_ordinal = static_cast<const int32_t*>(upload(ordinal.data(), ordinal.size() * sizeof(int32_t)));
                         if(S == 2 && c.algorithm == Algorithm::PAMLD && d.cross_identity && d.identity_index &&
                            c.barcode_length[0] == c.barcode_length[1] && c.barcode_length[0] >= NEAR_MIN_LENGTH && c.barcode_length[0] <= NEAR_MAX_LENGTH &&
-                           static_cast<int32_t>(distinct[0].size()) > near_list(c.barcode_length[0]) && static_cast<int32_t>(distinct[1].size()) > near_list(c.barcode_length[0])) {
+                           static_cast<int32_t>(distinct[0].size()) >= near_list(c.barcode_length[0]) && static_cast<int32_t>(distinct[1].size()) >= near_list(c.barcode_length[0])) {
                             // neighbour list tier of the set (pamld_cross_near.hpp): pamld_near.hpp's tables per segment
                             const int32_t length = c.barcode_length[0];
                             int32_t usable = 0;

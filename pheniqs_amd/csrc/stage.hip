@@ -120,7 +120,12 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 // precision, the fp64 products of the tiny kernel on the wave's ring (pamld_few.hip)
                 static const bool no_few = std::getenv("PHQ_NO_FEW") != nullptr;
                 const bool few = tiny && !no_few && args.result != nullptr && !args.defer_counters && pamld_few_supports(host_decoder);
-                const bool factorised = !tiny && !pamld_lut_preferred(host_decoder) && pamld_cross_supports(host_decoder);
+                // (round 6: a two segment set the streaming kernel of sets takes goes to it whatever its size — 400 combinations of 8 nt
+                // words 3.3 ms through the product form over all of them, 0.44 through that kernel)
+                static const bool no_set_stream = std::getenv("PHQ_NO_STREAM") != nullptr || std::getenv("PHQ_NO_CROSS_STREAM") != nullptr;
+                const bool set_streamed = !tiny && !no_set_stream && !plated && args.result != nullptr && args.defer_counters && pamld_cross_supports(host_decoder) &&
+                                          pamld_cross_near_supports(host_decoder) && pamld_cross_stream_supports(host_decoder);
+                const bool factorised = !tiny && (set_streamed || !pamld_lut_preferred(host_decoder)) && pamld_cross_supports(host_decoder);
                 const bool long_words = !tiny && !pamld_lut_supports(host_decoder) && !factorised;
                 // tier 0 of a two segment combinatorial set: neighbour lists per segment, the factorised scan on what they leave
                 const bool crossed = !plated && factorised && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_cross_near_supports(host_decoder);

@@ -1317,7 +1317,10 @@ def test_unique_dual_index_pairs(oracle, torch_cuda, algorithm, name):
     assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, pieces=2)
 
 
-@pytest.mark.parametrize("length,counts", [(8, (24, 20)), (9, (20, 24)), (10, (24, 20)), (8, (96, 96)), (10, (128, 17))])
+@pytest.mark.parametrize("length,counts", [(8, (24, 20)), (9, (20, 24)), (10, (24, 20)), (8, (96, 96)), (10, (128, 17)),
+                                           # round 6: a segment of exactly as many words as the lists hold (every word listed, nothing left to
+                                           # bound), and sets of fewer than 512 combinations, which the product form over all of them took
+                                           (8, (24, 16)), (8, (16, 16)), (8, (17, 17)), (9, (8, 40)), (10, (40, 8)), (10, (8, 8))])
 def test_combinatorial_sets_in_the_streaming_kernel(oracle, torch_cuda, length, counts):
     """Dual index sets of 8 to 10 nt words holding every combination, past the workgroup histogram (340 bins): lists and
     factorised scan in one persistent kernel (pamld_cross_stream.hpp) — per segment the lookup, the listed words, the
