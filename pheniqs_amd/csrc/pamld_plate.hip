@@ -293,7 +293,10 @@ __global__ __launch_bounds__(THREADS) void pamld_plate_kernel(StageArgs args) {
             __builtin_nontemporal_store((channel & 0x7fffffffu) | (qcfail_out ? 0x80000000u : 0u), reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(args.word) + first * 4 + at * 4u));
         }
         r.qcfail = qcfail_out;
-        if(finished && active) {
+        if(finished && active && args.defer_counters) {
+            // count, distance and confidence come from the records (counters.hip); the rare count goes straight to the buffer
+            if(!confident) { atomicAdd(&args.stats[d.stats_offset + bin * STAT_WORDS_PER_BIN + FIELD_LOW_CONFIDENCE], 1ull); }      // pamld.cpp:104-106
+        } else if(finished && active) {
             const uint32_t word = STAT_JOB_WORDS + bin * STAT_WORDS_PER_BIN + (qcfail ? 0u : static_cast<uint32_t>(STAT_FIELDS));
             uint32_t* const low_words = reinterpret_cast<uint32_t*>(histogram);      // a workgroup's counts and distances stay below 2^32
             atomicAdd(&low_words[2 * (word + FIELD_COUNT)], 1u);
@@ -349,9 +352,12 @@ int launch_one(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid,
 bool pamld_plate_supports(const DevDecoder& host_decoder) {
     static const bool off = std::getenv("PHQ_NO_PLATE") != nullptr;
     const int words = host_decoder.plane_stride / 4;
-    if(off || host_decoder.algorithm != 1 || host_decoder.plate_ready == 0 || host_decoder.use_lds_histogram == 0 || words < 2 || words > 4) { return false; }
+    if(off || host_decoder.algorithm != 1 || host_decoder.plate_ready == 0 || words < 2 || words > 4) { return false; }
+    // (round 6: a plate whose bins do not fit the workgroup — 171 to 256 wells — leaves the classified reads' counters to
+    // count_results_kernel, as the other tier 0 kernels do for such codecs)
+    if(host_decoder.use_lds_histogram == 0 && !count_results_supports(host_decoder)) { return false; }
     const size_t lds_bytes = plate::histogram_at(host_decoder.plate_unique[0], host_decoder.plate_unique[1]) +
-                             sizeof(unsigned long long) * static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.n_barcode + 1) * STAT_WORDS_PER_BIN);
+                             sizeof(unsigned long long) * static_cast<size_t>(STAT_JOB_WORDS + (host_decoder.use_lds_histogram ? host_decoder.n_barcode + 1 : 1) * STAT_WORDS_PER_BIN);
     return lds_bytes <= 160u * 1024u && host_decoder.high_quality_threshold <= 128 && pamld_lut_supports(host_decoder);
 }
 

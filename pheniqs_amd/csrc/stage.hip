@@ -108,7 +108,10 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 const bool tiny = pamld_tiny_supports(host_decoder);
                 const bool listed = !tiny && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_near_supports(host_decoder);      // tier 0: neighbour lists, then the product form on what it leaves
                 // tier 0 of plates: dual index sets of few words a segment, every word of both segments scored (pamld_plate.hip)
-                const bool plated = !tiny && !listed && args.result != nullptr && host_decoder.use_lds_histogram && !args.defer_counters && pamld_plate_supports(host_decoder);
+                // (... with its bins in the workgroup, or — 171 to 256 wells — with the counters left to count_results_kernel; a set the
+                // streaming kernel of sets takes goes there instead)
+                const bool plated = !tiny && !listed && args.result != nullptr && (host_decoder.use_lds_histogram ? !args.defer_counters : args.defer_counters != 0) && pamld_plate_supports(host_decoder) &&
+                                    !(args.defer_counters && pamld_cross_near_supports(host_decoder) && pamld_cross_stream_supports(host_decoder));
                 const bool paired = !tiny && !listed && !plated && args.result != nullptr && (host_decoder.use_lds_histogram || args.defer_counters) && pamld_pair_supports(host_decoder);      // tier 0 of paired barcodes: one barcode scored
                 // ... and where the streaming kernel takes the codec (5 to 10 nt), lists and scan are ONE launch, every
                 // wave a pipeline of its own with the deferred reads in an LDS ring (pamld_stream.hpp)

@@ -44,7 +44,6 @@ ALLOW = (
     ("combinatorial2", lambda L, N, priors: 2 * L > 32, "two segments of 20 nt: 40 positions, the general literal kernel for every read"),
     ("combinatorial2", lambda L, N, priors: L > 10, "two segment sets of 12 and 16 nt words: the streaming kernel of sets tables words of 8 to 10 nt; the factorised product form is the first kernel"),
     ("combinatorial2", lambda L, N, priors: L == 6 and N > 256, "two segment sets of 6 nt words past a plate: under the streaming kernel of sets' 8 nt"),
-    ("combinatorial2", lambda L, N, priors: L == 8 and 170 <= N <= 400, "14 to 20 words of 8 nt a segment: a plate whose histogram does not fit beside its tables, too few words for the sets' lists"),
     ("combinatorial2", lambda L, N, priors: L == 10 and N <= 256, "up to 16 words of 10 nt a segment: plates are 4 to 8 nt; the factorised product form (15-19 Greads/s) is the first kernel"),
     ("combinatorial3", lambda L, N, priors: True, "three segment sets: no tier 0 yet (DESIGN.md §7); the factorised product form (8-17 Greads/s) with uniform priors, the two word one with priors that differ; past 32 nt (3 x 12 and more) the general literal kernel for every read"),
 )
