@@ -336,6 +336,7 @@ int launch_pamld_wide_exact(const StageArgs& args, const DevDecoder& host_decode
 bool pamld_cross_supports(const DevDecoder& host_decoder);
 int launch_pamld_cross(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 bool pamld_exact_supports(const DevDecoder& host_decoder);
+bool pamld_exact_legacy_fits(const DevDecoder& host_decoder);   // ... by the kernels of pamld_cross.hpp themselves (pamld_exact_lanes.hip holds larger single segment sets)
 int launch_pamld_cross_exact(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);
 int launch_pamld_cross_exact_dense(const StageArgs& args, const DevDecoder& host_decoder, dim3 grid, size_t histogram_bytes, hipStream_t stream);   // pamld_cross_w2.hip
 bool pamld_exact_lanes_supports(const DevDecoder& host_decoder, size_t histogram_bytes);   // pamld_exact_lanes.hip: the same tier with eight lanes a read

@@ -38,6 +38,12 @@ bool pamld_exact_supports(const DevDecoder& host_decoder) {
            host_decoder.cross_words != nullptr && host_decoder.cross_ordinal != nullptr;
 }
 
+// ... and the kernels of this file hold a single segment set of up to EXACT_SINGLE_MEDIUM words (their list is a bit a word in
+// registers); a larger one — up to EXACT_SINGLE_UNIQUE — has pamld_exact_lanes.hip for its exact tier, or none
+bool pamld_exact_legacy_fits(const DevDecoder& host_decoder) {
+    return host_decoder.cross_segments != 1 || host_decoder.cross_unique[0] <= EXACT_SINGLE_MEDIUM;
+}
+
 // tier 1.5: consumes and compacts the producer's worklist in place.  `grid` is the producer's grid = the number of
 // segments.  A segment holds ~1.4 % of a workgroup's reads, a fraction of a tile when the batch is small, and every
 // workgroup pays its set up (factor and cost rows, histogram): for small batches the kernel takes groups of segments

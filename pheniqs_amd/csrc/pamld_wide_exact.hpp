@@ -301,11 +301,12 @@ int launch_exact_masked(const StageArgs& args, int n_barcode, dim3 grid, size_t 
     return static_cast<int>(hipGetLastError());
 }
 
+// (the 64 word masks — 1 025 to 2 048 barcodes — are instantiated in a unit of their own, pamld_wide_exact_big.hip: they take as
+// long to compile as the others together)
 template <int G>
 int launch_exact_groups(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
     return n_barcode <= 512 ? launch_exact_masked<G, 16>(args, n_barcode, grid, histogram_bytes, stream)
-         : n_barcode <= 1024 ? launch_exact_masked<G, 32>(args, n_barcode, grid, histogram_bytes, stream)
-                             : launch_exact_masked<G, EXACT_MAX_BARCODES / 32>(args, n_barcode, grid, histogram_bytes, stream);
+                            : launch_exact_masked<G, 32>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 }  // namespace wide

@@ -183,7 +183,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                         if(status != 0) { return status; }
                         trace_worklist("the product form", producer, segment_grid.x, s);
                     }
-                    if(pamld_exact_supports(host_decoder)) {
+                    if(pamld_exact_lanes_supports(host_decoder, histogram_bytes) || (pamld_exact_supports(host_decoder) && pamld_exact_legacy_fits(host_decoder))) {
                         // several lanes per read where the set is one the lane parallel tier takes (pamld_exact_lanes.hip)
                         Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
                         status = launched([&]() { return pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
@@ -233,7 +233,7 @@ int launch_classifier(const StageArgs& args, const DevDecoder& host_decoder, int
                 StageArgs consumer = producer;
                 consumer.worklist_role = 2;
                 consumer.flag_ties = lut_ties ? 1 : 0;             // (the lane parallel exact tier follows: pamld_exact_lanes_ties)
-                if(factorised || (!long_words && pamld_exact_supports(host_decoder))) {
+                if(factorised || (!long_words && (pamld_exact_lanes_supports(host_decoder, histogram_bytes) || (pamld_exact_supports(host_decoder) && pamld_exact_legacy_fits(host_decoder))))) {
                     // tier 1.5: exact but still factorised; leaves in the worklist only what needs the reference's own sums
                     Timed timed(timer, KERNEL_PAMLD_EXACT, stream, exact_name(host_decoder, histogram_bytes));
                     status = launched([&]() { return pamld_exact_lanes_supports(host_decoder, histogram_bytes) ? launch_pamld_exact_lanes(consumer, host_decoder, segment_grid, histogram_bytes, s)
