@@ -67,10 +67,14 @@ constexpr float SLOP = 1.0f + 1e-5f;           // single precision rounding of t
 // than two of 512), its tables laid out [wave][group] so that a group is still reached through the offset field.
 // BIG: a codec whose records alone push two 512 lane workgroups out of a CU (more than ~120 barcodes of 5 to 8 nt) takes the
 // same 1024 lane shape.
-template <int L, bool PRIORS = false, bool BIG = false> struct Shape {
+// SLIM (round 6): prior ratios in the 512 lane layout, ONE such workgroup a CU — 64 KiB of tables instead of 128 leave the records
+// of up to ~850 barcodes their room (the 1 024 lane shape holds 190 with ratios: a 384-plex after its prior estimation pass had
+// the product form over all barcodes as first kernel).
+template <int L, bool PRIORS = false, bool BIG = false, bool SLIM = false> struct Shape {
     static_assert(L >= 5 && L <= 10, "two or three groups of 4 positions");
     static constexpr int G = (L + 3) / 4;
-    static constexpr bool WIDE = (PRIORS || BIG) && G == 2;
+    static constexpr bool WIDE = (PRIORS || BIG) && G == 2 && !SLIM;
+    static_assert(!SLIM || (PRIORS && !BIG && G == 2), "the slim shape is the two group one with prior ratios");
     static constexpr int FIELD = near_field_bits(L);
     static constexpr int PER_WORD = 32 / FIELD;
     static constexpr int LIST = near_list(L);
@@ -110,9 +114,9 @@ __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c
 // STATE: where a read's carried state comes from — 0 the first stage of a job without input flags (nothing to load),
 // 1 the first stage with flag bytes, 2 a later stage (the status word).  A template parameter so that the loads of
 // the prefetch sit in straight line code: behind a branch the compiler can no longer count them and waits for all.
-template <int L, int STATE, bool PRIORS, bool BIG>
-__global__ __launch_bounds__((Shape<L, PRIORS, BIG>::THREADS)) void pamld_near_kernel(StageArgs args) {
-    typedef Shape<L, PRIORS, BIG> Layout;
+template <int L, int STATE, bool PRIORS, bool BIG, bool SLIM = false>
+__global__ __launch_bounds__((Shape<L, PRIORS, BIG, SLIM>::THREADS)) void pamld_near_kernel(StageArgs args) {
+    typedef Shape<L, PRIORS, BIG, SLIM> Layout;
     constexpr int G = Layout::G;
     constexpr int THREADS = Layout::THREADS;
     constexpr int FIELD = Layout::FIELD;
@@ -477,20 +481,20 @@ __global__ __launch_bounds__((Shape<L, PRIORS, BIG>::THREADS)) void pamld_near_k
     histogram_flush(args, d, histogram);
 }
 
-template <int L, int STATE, bool PRIORS, bool BIG>
+template <int L, int STATE, bool PRIORS, bool BIG, bool SLIM = false>
 int launch_state(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    const size_t lds_bytes = Shape<L, PRIORS, BIG>::histogram_at(n_barcode) + histogram_bytes;
+    const size_t lds_bytes = Shape<L, PRIORS, BIG, SLIM>::histogram_at(n_barcode) + histogram_bytes;
     static std::atomic<uint64_t> prepared{0};
-    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE, PRIORS, BIG>, prepared)) { return status; }
-    hipLaunchKernelGGL((pamld_near_kernel<L, STATE, PRIORS, BIG>), grid, dim3(Shape<L, PRIORS, BIG>::THREADS), lds_bytes, stream, args);
+    if(const int status = allow_large_lds(&pamld_near_kernel<L, STATE, PRIORS, BIG, SLIM>, prepared)) { return status; }
+    hipLaunchKernelGGL((pamld_near_kernel<L, STATE, PRIORS, BIG, SLIM>), grid, dim3(Shape<L, PRIORS, BIG, SLIM>::THREADS), lds_bytes, stream, args);
     return static_cast<int>(hipGetLastError());
 }
 
-template <int L, bool PRIORS, bool BIG>
+template <int L, bool PRIORS, bool BIG, bool SLIM = false>
 int launch_one(const StageArgs& args, int n_barcode, dim3 grid, size_t histogram_bytes, hipStream_t stream) {
-    if(!args.first_stage) { return launch_state<L, 2, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream); }
-    return args.input_flag ? launch_state<L, 1, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream)
-                           : launch_state<L, 0, PRIORS, BIG>(args, n_barcode, grid, histogram_bytes, stream);
+    if(!args.first_stage) { return launch_state<L, 2, PRIORS, BIG, SLIM>(args, n_barcode, grid, histogram_bytes, stream); }
+    return args.input_flag ? launch_state<L, 1, PRIORS, BIG, SLIM>(args, n_barcode, grid, histogram_bytes, stream)
+                           : launch_state<L, 0, PRIORS, BIG, SLIM>(args, n_barcode, grid, histogram_bytes, stream);
 }
 
 // the 1024 lane shape for the two group lengths when two 512 lane workgroups with this codec's records (and histogram)

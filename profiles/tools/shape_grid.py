@@ -35,8 +35,7 @@ def crowded(L, words):
 
 
 ALLOW = (
-    ("single", lambda L, N, priors: L <= 10 and N > 512 and priors == "estimated", "more than 512 barcodes of up to 10 nt with priors that differ: the list kernel's records with their prior ratios do not fit a CU"),
-    ("single", lambda L, N, priors: L <= 8 and N > 288 and priors == "estimated", "289 to 512 barcodes of up to 8 nt with priors that differ: past the streaming kernel's blocks, and the list kernel's records with prior ratios do not fit"),
+    ("single", lambda L, N, priors: L <= 10 and N > 1024 and priors == "estimated", "more than some 800 barcodes of up to 10 nt with priors that differ: the list kernel's records with their prior ratios do not fit a CU, not even in its 512 lane layout"),
     ("single", lambda L, N, priors: crowded(L, N), "words the grid could not draw three mismatches apart (4^L too small): no list or distance bound certifies anything, the product form is the first kernel"),
     ("paired", lambda L, N, priors: 2 * L > 32, "pairs of 20 + 20 nt: 40 positions are past the 32 every tier stops at; the general literal kernel (pamld_literal_long.hip) walks every barcode for every read"),
     ("paired", lambda L, N, priors: L == 6 and N >= 96, "pairs of 6 + 6 nt: 96 and more sit closer than the six mismatches the paired tier's bound needs for half of them"),

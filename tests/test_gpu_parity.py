@@ -226,7 +226,9 @@ def test_plates_every_word_of_both_segments_scored(oracle, torch_cuda, rows, col
 
 
 @pytest.mark.parametrize("length,count,spread,absent", [(8, 96, 1.0, 0), (8, 96, 3.0, 0), (10, 96, 1.0, 0), (6, 40, 1.5, 0), (9, 64, 2.0, 0), (8, 192, 1.0, 0),
-                                                        (5, 20, 0.5, 0), (8, 96, 1.0, 5), (10, 64, 2.0, 2)])
+                                                        (5, 20, 0.5, 0), (8, 96, 1.0, 5), (10, 64, 2.0, 2),
+                                                        # round 6: the 512 lane layout with prior ratios (193 to ~850 barcodes of up to 8 nt)
+                                                        (8, 384, 1.0, 0), (8, 512, 2.0, 7), (7, 300, 1.0, 0), (8, 800, 0.5, 0)])
 def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread, absent):
     """Single index sets whose priors differ (what phq_adjust_prior leaves behind): the neighbour list kernel weighs the
     listed barcodes and its bound by their priors over the nearest barcode's (pamld.cpp:66-79); 192 barcodes with their
@@ -244,6 +246,8 @@ def test_neighbour_lists_with_priors(oracle, torch_cuda, length, count, spread, 
         code[: 1 << 10] = np.array([[{"A": 1, "C": 2, "G": 4, "T": 8}[c] for c in words[k]] for k in picks], dtype=np.uint8)
     s, engine, got, words_out = assert_parity(oracle, torch_cuda, job, code, quality, flag, offsets, mode=capi.MODE_FAST)
     assert int((got[0]["status"] == 0).sum()) > (1 << 15)
+    if count > 288:
+        assert [c["kernel"] for c in s.plan_chain(1 << 16, capi.MODE_FAST)][0] == "pamld_near_kernel"
 
 
 @pytest.mark.parametrize("priors", [False, True])
