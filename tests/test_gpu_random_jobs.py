@@ -1,7 +1,7 @@
 """Randomised jobs against the oracle: codec shapes, priors, thresholds and read quality drawn at random, both
 kernel modes.  200 seeds by default (about a minute on one MI355X); PHQ_STRESS_SEEDS=first:last widens it.
-Known: seed 66971 (round 6, the one failure in ~102 000 seeds) is the literal kernels' careful power against glibc's pow on two
-barcodes with IUPAC letters whose costs are one multiset in two orders — DESIGN.md §4 K1a."""
+Seed 66971 (round 6) was the one failure in ~102 000 seeds: two barcodes with IUPAC letters whose costs are one multiset in two
+orders, settled by an ulp of glibc's pow — what made the literal kernels' careful power table driven."""
 import os
 
 import numpy as np
